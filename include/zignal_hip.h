@@ -1,0 +1,244 @@
+/*
+ * zignal_hip.h — C ABI of libzignal_hip.so, the MI355X (gfx950) implementation of
+ * zignal's per-pixel image hot path (src/image: convolution, resize / rotate / warp
+ * sampling, colour conversion).
+ *
+ * The reference has no FFI seam for this path: `Image(T)` methods forward at comptime
+ * into module functions (reference src/image.zig:523-525, :621-623, :917-994, :396-407).
+ * The replacement seam is therefore those method bodies; each entry point below names
+ * the reference function whose body it replaces. `Image(T)` is not an extern struct
+ * (reference src/image.zig:97-103: {rows:u32, cols:u32, data:[]T, stride:usize}), so
+ * its fields travel in `zg_image`.
+ *
+ * Two layers, same semantics:
+ *   zg_<op>(..., zg_stream)   device pointers, asynchronous on `stream`
+ *   zg_<op>_host(...)         host pointers, synchronous (H2D -> kernel -> D2H)
+ *
+ * Return value: zg_status. The Zig shim maps 1 -> error.DimensionMismatch,
+ * 2 -> error.InvalidArgument (InvalidSigma / InvalidScaleFactor / InvalidDimensions
+ * as documented per op), 3 -> error.OutOfMemory; 4 is a HIP runtime failure.
+ *
+ * Enum ordinals follow the declaration order of the reference enums:
+ *   BorderMode     reference src/image/border.zig:10-18
+ *   Interpolation  reference src/image/interpolation.zig:53-68
+ */
+#ifndef ZIGNAL_HIP_H
+#define ZIGNAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZG_API __attribute__((visibility("default")))
+
+typedef enum zg_status {
+    ZG_OK = 0,
+    ZG_ERR_DIMENSION_MISMATCH = 1, /* error.DimensionMismatch (src/image.zig:636,927,947,962) */
+    ZG_ERR_INVALID_ARGUMENT = 2,   /* error.InvalidSigma (:970), InvalidScaleFactor / InvalidDimensions (:531-536) */
+    ZG_ERR_OUT_OF_MEMORY = 3,      /* error.OutOfMemory (device scratch) */
+    ZG_ERR_HIP = 4,                /* HIP runtime error; see zg_last_error() */
+    ZG_ERR_UNSUPPORTED = 5         /* pixel type / op combination the reference rejects at comptime */
+} zg_status;
+
+/* Pixel layouts. Element index is row*stride + col, stride in PIXELS (src/image.zig:426-430). */
+typedef enum zg_pixel {
+    ZG_PIXEL_U8 = 0,       /* u8 / Gray(u8): 1 B                                  */
+    ZG_PIXEL_F32 = 1,      /* f32: 4 B                                            */
+    ZG_PIXEL_RGB_U8 = 2,   /* Rgb(u8): r,g,b bytes, 3 B (src/color.zig:286-290)   */
+    ZG_PIXEL_RGBA_U8 = 3,  /* Rgba(u8): packed r,g,b,a, 4 B (src/color.zig:400)   */
+    ZG_PIXEL_RGB_F32 = 4,  /* any 3 x f32 struct: Rgb(f32), Oklab(f32), Xyz(f32)  */
+    ZG_PIXEL_RGBA_F32 = 5  /* Rgba(f32): 16 B                                     */
+} zg_pixel;
+
+typedef enum zg_border {   /* src/image/border.zig:10-18 */
+    ZG_BORDER_ZERO = 0,
+    ZG_BORDER_REPLICATE = 1,
+    ZG_BORDER_MIRROR = 2,  /* reflect-101, period 2(L-1) (border.zig:56-59) */
+    ZG_BORDER_WRAP = 3
+} zg_border;
+
+typedef enum zg_interp {   /* src/image/interpolation.zig:53-68 */
+    ZG_INTERP_NEAREST = 0,
+    ZG_INTERP_BILINEAR = 1,
+    ZG_INTERP_BICUBIC = 2,
+    ZG_INTERP_CATMULL_ROM = 3,
+    ZG_INTERP_MITCHELL = 4, /* takes (b, c) */
+    ZG_INTERP_LANCZOS = 5
+} zg_interp;
+
+typedef enum zg_transform_kind { /* src/geometry/transforms.zig:10,118,197 */
+    ZG_TRANSFORM_SIMILARITY = 0, /* m = {a00,a01,a10,a11, b0,b1}            */
+    ZG_TRANSFORM_AFFINE = 1,     /* m = {a00,a01,a10,a11, b0,b1}            */
+    ZG_TRANSFORM_PROJECTIVE = 2  /* m = row-major 3x3                       */
+} zg_transform_kind;
+
+typedef enum zg_colorspace { /* subset of src/color.zig ColorSpace used on the image path */
+    ZG_CS_GRAY = 0,
+    ZG_CS_RGB = 1,
+    ZG_CS_RGBA = 2,
+    ZG_CS_OKLAB = 3,
+    ZG_CS_XYZ = 4,
+    ZG_CS_YCBCR = 5
+} zg_colorspace;
+
+/* Mirrors Image(T) (src/image.zig:97-103) plus the pixel tag that T carries at comptime. */
+typedef struct zg_image {
+    void *data;     /* first pixel (device pointer for zg_<op>, host pointer for zg_<op>_host) */
+    size_t stride;  /* in pixels; stride >= cols; views keep the parent's stride (image.zig:332) */
+    uint32_t rows;
+    uint32_t cols;
+    int32_t pixel;  /* zg_pixel */
+} zg_image;
+
+/* Interpolation method with Mitchell parameters (interpolation.zig:57-66). */
+typedef struct zg_method {
+    int32_t kind;   /* zg_interp */
+    float b, c;     /* used when kind == ZG_INTERP_MITCHELL */
+    /* Optional 1025-entry Lanczos3 table (interpolation.zig:256-267 builds it at comptime with
+     * Zig's @sin). NULL -> the library's own table. Host pointer in both layers. */
+    const float *lanczos_lut;
+} zg_method;
+
+typedef void *zg_stream; /* hipStream_t; NULL = default stream */
+
+/* ---- runtime ------------------------------------------------------------------------- */
+ZG_API int zg_init(int device);               /* hipSetDevice + warm the per-device tables */
+ZG_API void zg_shutdown(void);
+ZG_API const char *zg_last_error(void);       /* thread-local message of the last non-OK status */
+ZG_API int zg_version(void);
+ZG_API int zg_device_count(void);
+
+ZG_API int zg_malloc(void **dev_ptr, size_t bytes);
+ZG_API int zg_free(void *dev_ptr);
+ZG_API int zg_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, zg_stream stream);
+ZG_API int zg_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, zg_stream stream);
+ZG_API int zg_stream_create(zg_stream *out);
+ZG_API int zg_stream_destroy(zg_stream s);
+ZG_API int zg_stream_synchronize(zg_stream s);
+ZG_API size_t zg_pixel_size(int pixel);
+
+/* ---- filters ------------------------------------------------------------------------- */
+
+/* Image(T).convolveSeparable (src/image.zig:935-951 -> src/image/convolution.zig:313-438,
+ * worker :441-647). Types: U8, F32, RGB_U8, RGBA_U8 as in the reference; RGB_F32 / RGBA_F32
+ * are an extension (the reference rejects them at comptime, convolution.zig:431-435) whose
+ * per-channel result equals the F32 plane path. kx/ky are host pointers. */
+ZG_API int zg_conv_separable(const zg_image *src, const zg_image *dst,
+                             const float *kx, uint32_t nkx, const float *ky, uint32_t nky,
+                             int border, zg_stream stream);
+ZG_API int zg_conv_separable_host(const zg_image *src, const zg_image *dst,
+                                  const float *kx, uint32_t nkx, const float *ky, uint32_t nky,
+                                  int border);
+
+/* Image(T).gaussianBlur (src/image.zig:954-994): radius = ceil(3 sigma), taps exp(-x^2/(2 s^2))
+ * normalised in f32, then convolveSeparable(.mirror). sigma == 0 copies; sigma < 0 ->
+ * ZG_ERR_INVALID_ARGUMENT (error.InvalidSigma). */
+ZG_API int zg_gaussian_blur(const zg_image *src, const zg_image *dst, float sigma, zg_stream stream);
+ZG_API int zg_gaussian_blur_host(const zg_image *src, const zg_image *dst, float sigma);
+/* The 1-D taps gaussianBlur builds (src/image.zig:973-990). Returns the tap count (2*radius+1),
+ * or a negative zg_status. `taps` may be NULL to query the count. */
+ZG_API int zg_gaussian_kernel(float sigma, float *taps, uint32_t capacity);
+
+/* Image(T).convolve (src/image.zig:917-932 -> src/image/convolution.zig:76-301); kernel is
+ * row-major kh x kw f32 on the host. */
+ZG_API int zg_convolve(const zg_image *src, const zg_image *dst,
+                       const float *kernel, uint32_t kh, uint32_t kw, int border, zg_stream stream);
+ZG_API int zg_convolve_host(const zg_image *src, const zg_image *dst,
+                            const float *kernel, uint32_t kh, uint32_t kw, int border);
+
+/* Image(T).boxBlur (src/image.zig:635-648 -> src/image/integral.zig:41-90,194-269):
+ * f32 summed-area table, window and area clipped at the borders. src may equal dst. */
+ZG_API int zg_box_blur(const zg_image *src, const zg_image *dst, uint32_t radius, zg_stream stream);
+ZG_API int zg_box_blur_host(const zg_image *src, const zg_image *dst, uint32_t radius);
+
+/* ---- resampling ---------------------------------------------------------------------- */
+
+/* Image(T).resize (src/image.zig:523 -> src/image/interpolation.zig:89-214 and the u8 plane
+ * kernels src/image/channel_ops.zig:144-493). Never fails in the reference (void). */
+ZG_API int zg_resize(const zg_image *src, const zg_image *dst, const zg_method *method, zg_stream stream);
+ZG_API int zg_resize_host(const zg_image *src, const zg_image *dst, const zg_method *method);
+
+/* Image(T).letterbox (src/image.zig:546 -> src/image/transforms.zig:49-108). Writes the content
+ * rectangle {l,t,r,b} to rect_out (may be NULL). */
+ZG_API int zg_letterbox(const zg_image *src, const zg_image *dst, const zg_method *method,
+                        uint32_t rect_out[4], zg_stream stream);
+ZG_API int zg_letterbox_host(const zg_image *src, const zg_image *dst, const zg_method *method,
+                             uint32_t rect_out[4]);
+
+/* Image(T).warp (src/image.zig:621 -> src/image/transforms.zig:522-531) with the project()
+ * of src/geometry/transforms.zig:39-42 / :147-150 / :224-231. m is a host pointer. */
+ZG_API int zg_warp(const zg_image *src, const zg_image *dst, int kind, const float *m,
+                   const zg_method *method, zg_stream stream);
+ZG_API int zg_warp_host(const zg_image *src, const zg_image *dst, int kind, const float *m,
+                        const zg_method *method);
+
+/* Image(T).rotateInto (src/image.zig:566 -> src/image/transforms.zig:163-212, exact
+ * 0/90/180/270 paths :385-462). cos_a / sin_a are @cos(angle) / @sin(angle) as the caller's
+ * maths library computes them (the Zig shim passes Zig's); zg_rotate_into_angle uses the
+ * library's own. */
+ZG_API int zg_rotate_into(const zg_image *src, const zg_image *dst, float angle,
+                          float cos_a, float sin_a, const zg_method *method, int border, zg_stream stream);
+ZG_API int zg_rotate_into_host(const zg_image *src, const zg_image *dst, float angle,
+                               float cos_a, float sin_a, const zg_method *method, int border);
+/* Image(T).rotateBounds (src/image/transforms.zig:112-148). */
+ZG_API int zg_rotate_bounds(uint32_t rows, uint32_t cols, float angle, float cos_a, float sin_a,
+                            uint32_t *out_rows, uint32_t *out_cols);
+
+/* Image(T).extract (src/image.zig:593 -> src/image/transforms.zig:231-282); rect = {l,t,r,b}. */
+ZG_API int zg_extract(const zg_image *src, const zg_image *dst, const float rect[4], float angle,
+                      float cos_a, float sin_a, const zg_method *method, int border, zg_stream stream);
+ZG_API int zg_extract_host(const zg_image *src, const zg_image *dst, const float rect[4], float angle,
+                           float cos_a, float sin_a, const zg_method *method, int border);
+
+/* Image(T).crop (src/image.zig:582 -> src/image/transforms.zig:216-222): dst must be
+ * round(rect.height) x round(rect.width) (zg_crop_dims). Bit-exact copy. */
+ZG_API int zg_crop(const zg_image *src, const zg_image *dst, const float rect[4], zg_stream stream);
+ZG_API int zg_crop_host(const zg_image *src, const zg_image *dst, const float rect[4]);
+ZG_API int zg_crop_dims(const float rect[4], uint32_t *out_rows, uint32_t *out_cols);
+
+/* Image(T).flipLeftRight / flipTopBottom (src/image/transforms.zig:28-44), in place. */
+ZG_API int zg_flip_left_right(const zg_image *img, zg_stream stream);
+ZG_API int zg_flip_top_bottom(const zg_image *img, zg_stream stream);
+ZG_API int zg_flip_left_right_host(const zg_image *img);
+ZG_API int zg_flip_top_bottom_host(const zg_image *img);
+
+/* Image(T).insert (src/image.zig:606 -> src/image/transforms.zig:293-378) with blend mode
+ * `.none` (store) or `.normal` alpha compositing for RGBA sources. self is modified in place. */
+ZG_API int zg_insert(const zg_image *self, const zg_image *source, const float rect[4], float angle,
+                     float cos_a, float sin_a, const zg_method *method, int blend_mode, zg_stream stream);
+ZG_API int zg_insert_host(const zg_image *self, const zg_image *source, const float rect[4], float angle,
+                          float cos_a, float sin_a, const zg_method *method, int blend_mode);
+
+/* Image(T).copy (src/image.zig:375-392), Image(T).fill, Image(T).setBorder (:200). */
+ZG_API int zg_copy(const zg_image *src, const zg_image *dst, zg_stream stream);
+ZG_API int zg_fill(const zg_image *img, const void *pixel_value, zg_stream stream);
+ZG_API int zg_set_border(const zg_image *img, const uint32_t rect[4], const void *pixel_value, zg_stream stream);
+
+/* ---- colour -------------------------------------------------------------------------- */
+
+/* Image(T).convertInto (src/image.zig:396-407 -> convertColor src/color.zig:108-151).
+ * The pixel layout comes from the images, the colour space from the arguments, e.g.
+ * (RGBA_U8, ZG_CS_RGBA) -> (RGB_F32, ZG_CS_OKLAB) is Image(Rgba(u8)).convert(Oklab(f32)).
+ * srgb_lut: optional 256-entry host table of gammaToLinear(i/255) (color.zig:1252-1258), so a
+ * Zig caller can supply values made with Zig's std.math.pow; NULL -> the library's own. */
+ZG_API int zg_convert(const zg_image *src, int src_space, const zg_image *dst, int dst_space,
+                      const float *srgb_lut, zg_stream stream);
+ZG_API int zg_convert_host(const zg_image *src, int src_space, const zg_image *dst, int dst_space,
+                           const float *srgb_lut);
+
+/* ---- batch (config: N frames, gaussianBlur(sigma) then bilinear resize) ----------------- */
+
+/* Semantics of the `pipeline` recipe [blur gaussian, resize] (src/cli/pipeline.zig:153-179)
+ * applied to n_frames images laid out back to back. scratch may be NULL (allocated inside). */
+ZG_API int zg_batch_blur_resize(const void *src_frames, uint32_t n_frames,
+                                uint32_t rows, uint32_t cols, int pixel, float sigma,
+                                void *dst_frames, uint32_t out_rows, uint32_t out_cols,
+                                const zg_method *method, zg_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZIGNAL_HIP_H */

@@ -1,0 +1,329 @@
+"""ctypes binding of oracle/liboracle.so (C restatement of the reference's CPU path).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg. Images are numpy arrays: (R,C) uint8/float32 or (R,C,3|4) uint8/float32; the row stride may
+exceed cols (views), the channel axis must be contiguous.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+U8, F32, RGB_U8, RGBA_U8, RGB_F32, RGBA_F32 = range(6)
+ZERO, REPLICATE, MIRROR, WRAP = range(4)
+NEAREST, BILINEAR, BICUBIC, CATMULL_ROM, MITCHELL, LANCZOS = range(6)
+SIMILARITY, AFFINE, PROJECTIVE = range(3)
+CS_GRAY, CS_RGB, CS_RGBA, CS_OKLAB, CS_XYZ, CS_YCBCR = range(6)
+
+
+class ZoImage(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("stride", C.c_size_t), ("rows", C.c_uint32),
+                ("cols", C.c_uint32), ("pixel", C.c_int32)]
+
+
+class ZoMethod(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("b", C.c_float), ("c", C.c_float), ("lanczos_lut", C.c_void_p)]
+
+
+def build(native: bool = False) -> str:
+    target = "liboracle_native.so" if native else "liboracle.so"
+    subprocess.run(["make", "-C", _HERE] + (["native"] if native else []), check=True,
+                   stdout=subprocess.DEVNULL)
+    return os.path.join(_HERE, target)
+
+
+_libs: dict[str, C.CDLL] = {}
+
+
+def lib(native: bool = False) -> C.CDLL:
+    key = "native" if native else "default"
+    if key in _libs:
+        return _libs[key]
+    path = os.path.join(_HERE, "liboracle_native.so" if native else "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
+        path = build(native)
+    l = C.CDLL(path)
+    l.zo_resolve_index.restype = C.c_int64
+    l.zo_resolve_index.argtypes = [C.c_int64, C.c_int64, C.c_int]
+    for name in ("zo_expf", "zo_logf", "zo_cbrtf", "zo_sinf", "zo_cosf"):
+        getattr(l, name).restype = C.c_float
+        getattr(l, name).argtypes = [C.c_float]
+    l.zo_powf.restype = C.c_float
+    l.zo_powf.argtypes = [C.c_float, C.c_float]
+    l.zo_clamp_u8_f32.restype = C.c_uint8
+    l.zo_clamp_u8_f32.argtypes = [C.c_float]
+    _libs[key] = l
+    return l
+
+
+def pixel_of(a: np.ndarray) -> int:
+    if a.ndim == 2:
+        if a.dtype == np.uint8:
+            return U8
+        if a.dtype == np.float32:
+            return F32
+    elif a.ndim == 3:
+        key = (a.dtype.type, a.shape[2])
+        table = {(np.uint8, 3): RGB_U8, (np.uint8, 4): RGBA_U8, (np.float32, 3): RGB_F32,
+                 (np.float32, 4): RGBA_F32}
+        if key in table:
+            return table[key]
+    raise TypeError(f"unsupported image array {a.dtype} {a.shape}")
+
+
+def as_image(a: np.ndarray) -> ZoImage:
+    """Describe a numpy array (possibly a row-strided view) as Image(T)."""
+    pixel = pixel_of(a)
+    psize = a.itemsize * (a.shape[2] if a.ndim == 3 else 1)
+    rows, cols = a.shape[0], a.shape[1]
+    if a.ndim == 3 and a.shape[2] > 1:
+        assert a.strides[2] == a.itemsize, "channel axis must be contiguous"
+    if cols > 0 and rows > 0:
+        assert a.strides[1] == psize, "pixels of a row must be contiguous"
+        assert a.strides[0] % psize == 0
+        stride = a.strides[0] // psize if rows > 1 else max(cols, a.strides[0] // psize)
+    else:
+        stride = cols
+    return ZoImage(a.ctypes.data, stride, rows, cols, pixel)
+
+
+def method(kind: int, b: float = 0.0, c: float = 0.0) -> ZoMethod:
+    return ZoMethod(kind, b, c, None)
+
+
+def _f32p(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"oracle {what} failed with status {rc}")
+
+
+# ---- thin functional API (allocates the output like the reference's allocating variants) --------
+
+def resolve_index(idx, length, border):
+    r = lib().zo_resolve_index(idx, length, border)
+    return None if r < 0 else r
+
+
+def gaussian_kernel(sigma: float) -> np.ndarray:
+    n = lib().zo_gaussian_kernel(C.c_float(sigma), None, 0)
+    if n < 0:
+        raise ValueError("invalid sigma")
+    out = np.empty(n, np.float32)
+    lib().zo_gaussian_kernel(C.c_float(sigma), out.ctypes.data_as(C.POINTER(C.c_float)), n)
+    return out
+
+
+def conv_separable(src, kx, ky, border, out=None, native=False):
+    out = np.empty_like(src) if out is None else out
+    kxa, kxp = _f32p(kx)
+    kya, kyp = _f32p(ky)
+    s, d = as_image(src), as_image(out)
+    rc = lib(native).zo_conv_separable(C.byref(s), C.byref(d), kxp, len(kxa), kyp, len(kya), border)
+    _check(rc, "conv_separable")
+    return out
+
+
+def gaussian_blur(src, sigma, out=None, native=False):
+    out = np.empty_like(src) if out is None else out
+    s, d = as_image(src), as_image(out)
+    rc = lib(native).zo_gaussian_blur(C.byref(s), C.byref(d), C.c_float(sigma))
+    if rc == 2:
+        raise ValueError("InvalidSigma")
+    _check(rc, "gaussian_blur")
+    return out
+
+
+def convolve(src, kernel, border, out=None):
+    out = np.empty_like(src) if out is None else out
+    k, kp = _f32p(kernel)
+    s, d = as_image(src), as_image(out)
+    rc = lib().zo_convolve(C.byref(s), C.byref(d), kp, k.shape[0], k.shape[1], border)
+    _check(rc, "convolve")
+    return out
+
+
+def box_blur(src, radius, out=None):
+    out = np.empty_like(src) if out is None else out
+    s, d = as_image(src), as_image(out)
+    _check(lib().zo_box_blur(C.byref(s), C.byref(d), radius), "box_blur")
+    return out
+
+
+def interpolate(img, x, y, m: ZoMethod, border):
+    px = np.zeros(img.shape[2:] if img.ndim == 3 else (), img.dtype)
+    buf = np.zeros(4, img.dtype)
+    s = as_image(img)
+    ok = lib().zo_interpolate(C.byref(s), C.c_float(x), C.c_float(y), C.byref(m), border,
+                              C.c_void_p(buf.ctypes.data))
+    if not ok:
+        return None
+    if img.ndim == 2:
+        return buf[0].copy()
+    px[...] = buf[: img.shape[2]]
+    return px
+
+
+def resize(src, out_shape_or_out, m: ZoMethod):
+    if isinstance(out_shape_or_out, np.ndarray):
+        out = out_shape_or_out
+    else:
+        out = np.empty(tuple(out_shape_or_out) + src.shape[2:], src.dtype)
+    s, d = as_image(src), as_image(out)
+    _check(lib().zo_resize(C.byref(s), C.byref(d), C.byref(m)), "resize")
+    return out
+
+
+def letterbox(src, out, m: ZoMethod):
+    rect = (C.c_uint32 * 4)()
+    s, d = as_image(src), as_image(out)
+    _check(lib().zo_letterbox(C.byref(s), C.byref(d), C.byref(m), rect), "letterbox")
+    return tuple(rect)
+
+
+def project(kind, mat, x, y):
+    m, mp = _f32p(mat)
+    ox, oy = C.c_float(), C.c_float()
+    lib().zo_project(kind, mp, C.c_float(x), C.c_float(y), C.byref(ox), C.byref(oy))
+    return ox.value, oy.value
+
+
+def warp(src, out_shape_or_out, kind, mat, m: ZoMethod):
+    if isinstance(out_shape_or_out, np.ndarray):
+        out = out_shape_or_out
+    else:
+        out = np.empty(tuple(out_shape_or_out) + src.shape[2:], src.dtype)
+    ma, mp = _f32p(mat)
+    s, d = as_image(src), as_image(out)
+    _check(lib().zo_warp(C.byref(s), C.byref(d), kind, mp, C.byref(m)), "warp")
+    return out
+
+
+def cos_sin(angle: float):
+    l = lib()
+    return l.zo_cosf(C.c_float(angle)), l.zo_sinf(C.c_float(angle))
+
+
+def rotate_bounds(rows, cols, angle):
+    ca, sa = cos_sin(angle)
+    r, c = C.c_uint32(), C.c_uint32()
+    lib().zo_rotate_bounds(rows, cols, C.c_float(angle), C.c_float(ca), C.c_float(sa), C.byref(r), C.byref(c))
+    return r.value, c.value
+
+
+def rotate_into(src, out, angle, m: ZoMethod, border):
+    ca, sa = cos_sin(angle)
+    s, d = as_image(src), as_image(out)
+    _check(lib().zo_rotate_into(C.byref(s), C.byref(d), C.c_float(angle), C.c_float(ca), C.c_float(sa),
+                                C.byref(m), border), "rotate_into")
+    return out
+
+
+def rotate(src, angle, m: ZoMethod, border):
+    r, c = rotate_bounds(src.shape[0], src.shape[1], angle)
+    out = np.empty((r, c) + src.shape[2:], src.dtype)
+    return rotate_into(src, out, angle, m, border)
+
+
+def extract(src, out, rect, angle, m: ZoMethod, border):
+    ca, sa = cos_sin(angle)
+    ra, rp = _f32p(rect)
+    s, d = as_image(src), as_image(out)
+    _check(lib().zo_extract(C.byref(s), C.byref(d), rp, C.c_float(angle), C.c_float(ca), C.c_float(sa),
+                            C.byref(m), border), "extract")
+    return out
+
+
+def crop(src, rect):
+    ra, rp = _f32p(rect)
+    r, c = C.c_uint32(), C.c_uint32()
+    lib().zo_crop_dims(rp, C.byref(r), C.byref(c))
+    out = np.empty((r.value, c.value) + src.shape[2:], src.dtype)
+    s, d = as_image(src), as_image(out)
+    _check(lib().zo_crop(C.byref(s), C.byref(d), rp), "crop")
+    return out
+
+
+def flip_left_right(img):
+    s = as_image(img)
+    _check(lib().zo_flip_left_right(C.byref(s)), "flip_left_right")
+    return img
+
+
+def flip_top_bottom(img):
+    s = as_image(img)
+    _check(lib().zo_flip_top_bottom(C.byref(s)), "flip_top_bottom")
+    return img
+
+
+def insert(self_img, source, rect, angle, m: ZoMethod, blend_mode=0):
+    ca, sa = cos_sin(angle)
+    ra, rp = _f32p(rect)
+    s, d = as_image(self_img), as_image(source)
+    _check(lib().zo_insert(C.byref(s), C.byref(d), rp, C.c_float(angle), C.c_float(ca), C.c_float(sa),
+                           C.byref(m), blend_mode), "insert")
+    return self_img
+
+
+def srgb_to_linear_lut() -> np.ndarray:
+    out = np.empty(256, np.float32)
+    lib().zo_srgb_to_linear_lut(out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+_CS_LAYOUT = {(CS_GRAY, np.uint8): ((), np.uint8), (CS_GRAY, np.float32): ((), np.float32)}
+
+
+def convert(src, src_space, dst_space, dst_dtype, dst_channels, out=None, srgb_lut=None):
+    if out is None:
+        shape = src.shape[:2] + ((dst_channels,) if dst_channels > 1 else ())
+        out = np.empty(shape, dst_dtype)
+    s, d = as_image(src), as_image(out)
+    lut = None
+    if srgb_lut is not None:
+        srgb_lut = np.ascontiguousarray(srgb_lut, np.float32)
+        lut = srgb_lut.ctypes.data_as(C.POINTER(C.c_float))
+    _check(lib().zo_convert(C.byref(s), src_space, C.byref(d), dst_space, lut), "convert")
+    return out
+
+
+def homography_from_4pts(from_pts, to_pts) -> np.ndarray:
+    f = np.ascontiguousarray(from_pts, np.float64).reshape(8)
+    t = np.ascontiguousarray(to_pts, np.float64).reshape(8)
+    m = np.empty(9, np.float32)
+    rc = lib().zo_homography_from_4pts(f.ctypes.data_as(C.POINTER(C.c_double)),
+                                       t.ctypes.data_as(C.POINTER(C.c_double)),
+                                       m.ctypes.data_as(C.POINTER(C.c_float)))
+    _check(rc, "homography")
+    return m.reshape(3, 3)
+
+
+def splitmix64_bytes(seed: int, n: int) -> np.ndarray:
+    """Seeded byte stream shared by oracle and GPU inputs."""
+    m = (n + 7) // 8
+    idx = (np.arange(1, m + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(seed))
+    z = idx
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    z = z ^ (z >> np.uint64(31))
+    return z.view(np.uint8)[:n].copy()
+
+
+def synth_u8(seed: int, shape) -> np.ndarray:
+    n = int(np.prod(shape))
+    return splitmix64_bytes(seed, n).reshape(shape)
+
+
+def synth_f32(seed: int, shape) -> np.ndarray:
+    n = int(np.prod(shape))
+    u = splitmix64_bytes(seed, 4 * n).view(np.uint32)
+    return ((u >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)).reshape(shape)

@@ -1,0 +1,107 @@
+/*
+ * oracle/zo.h — CPU restatement of zignal's per-pixel image hot path. TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product (libzignal_hip.so) never links, loads or calls it.
+ *
+ * Parity pinning: the reference (Zig) cannot be compiled in this image (no zig toolchain, see
+ * DESIGN.md), so this oracle is pinned against the known-answer values of the reference's own
+ * unit tests (tests/test_oracle_*.py cite them file:line). Anything that flows through Zig's
+ * std maths (@exp, @sin, @cos, std.math.pow, std.math.cbrt) is restated from memory of the
+ * musl/Go algorithms Zig ports and is PARITY UNPINNED at the last ulp (zigmath.c header).
+ *
+ * Build: gcc -O2 -ffp-contract=off (no FMA contraction, no fast-math: the reference uses
+ * strict IEEE f32 with separate mul and add everywhere on this path).
+ */
+#ifndef ZO_H
+#define ZO_H
+#include <stddef.h>
+#include <stdint.h>
+
+#define ZO_API __attribute__((visibility("default")))
+
+/* same ordinals as include/zignal_hip.h */
+enum { ZO_U8 = 0, ZO_F32 = 1, ZO_RGB_U8 = 2, ZO_RGBA_U8 = 3, ZO_RGB_F32 = 4, ZO_RGBA_F32 = 5 };
+enum { ZO_ZERO = 0, ZO_REPLICATE = 1, ZO_MIRROR = 2, ZO_WRAP = 3 };
+enum { ZO_NEAREST = 0, ZO_BILINEAR = 1, ZO_BICUBIC = 2, ZO_CATMULL_ROM = 3, ZO_MITCHELL = 4, ZO_LANCZOS = 5 };
+enum { ZO_SIMILARITY = 0, ZO_AFFINE = 1, ZO_PROJECTIVE = 2 };
+enum { ZO_CS_GRAY = 0, ZO_CS_RGB = 1, ZO_CS_RGBA = 2, ZO_CS_OKLAB = 3, ZO_CS_XYZ = 4, ZO_CS_YCBCR = 5 };
+
+typedef struct zo_image {
+    void *data;
+    size_t stride; /* pixels */
+    uint32_t rows, cols;
+    int32_t pixel;
+} zo_image;
+
+static inline int zo_channels(int pixel) {
+    switch (pixel) {
+    case ZO_U8: case ZO_F32: return 1;
+    case ZO_RGB_U8: case ZO_RGB_F32: return 3;
+    default: return 4;
+    }
+}
+static inline int zo_is_float(int pixel) { return pixel == ZO_F32 || pixel == ZO_RGB_F32 || pixel == ZO_RGBA_F32; }
+static inline size_t zo_pixel_size(int pixel) { return (size_t)zo_channels(pixel) * (zo_is_float(pixel) ? 4 : 1); }
+
+/* border.c — reference src/image/border.zig:46-63. Returns -1 for `null`. */
+ZO_API int64_t zo_resolve_index(int64_t idx, int64_t length, int border);
+
+/* meta.c-ish helpers (reference src/meta.zig:110-135) */
+static inline uint8_t zo_clamp_u8_i64(int64_t v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+ZO_API uint8_t zo_clamp_u8_f32(float v);
+
+/* zigmath.c — restated Zig std / compiler-rt maths (parity unpinned, see file header) */
+ZO_API float zo_expf(float x);
+ZO_API float zo_logf(float x);
+ZO_API float zo_powf(float x, float y);
+ZO_API float zo_cbrtf(float x);
+ZO_API float zo_sinf(float x);
+ZO_API float zo_cosf(float x);
+
+/* conv.c */
+ZO_API int zo_gaussian_kernel(float sigma, float *taps, uint32_t capacity);
+ZO_API int zo_conv_separable(const zo_image *src, const zo_image *dst, const float *kx, uint32_t nkx,
+                             const float *ky, uint32_t nky, int border);
+ZO_API int zo_gaussian_blur(const zo_image *src, const zo_image *dst, float sigma);
+ZO_API int zo_convolve(const zo_image *src, const zo_image *dst, const float *kernel, uint32_t kh,
+                       uint32_t kw, int border);
+/* integral.c */
+ZO_API int zo_integral_plane_f32(const float *src, size_t src_stride, float *sat, uint32_t rows, uint32_t cols);
+ZO_API int zo_box_blur(const zo_image *src, const zo_image *dst, uint32_t radius);
+
+/* interp.c */
+typedef struct zo_method { int32_t kind; float b, c; const float *lanczos_lut; } zo_method;
+/* returns 1 and writes one pixel to out, or 0 for `null` */
+ZO_API int zo_interpolate(const zo_image *img, float x, float y, const zo_method *m, int border, void *out);
+ZO_API const float *zo_lanczos3_lut(void);
+ZO_API int zo_resize(const zo_image *src, const zo_image *dst, const zo_method *m);
+ZO_API int zo_letterbox(const zo_image *src, const zo_image *dst, const zo_method *m, uint32_t rect_out[4]);
+
+/* transforms.c */
+ZO_API void zo_project(int kind, const float *m, float x, float y, float *ox, float *oy);
+ZO_API int zo_warp(const zo_image *src, const zo_image *dst, int kind, const float *m, const zo_method *method);
+ZO_API int zo_rotate_bounds(uint32_t rows, uint32_t cols, float angle, float cos_a, float sin_a,
+                            uint32_t *out_rows, uint32_t *out_cols);
+ZO_API int zo_rotate_into(const zo_image *src, const zo_image *dst, float angle, float cos_a, float sin_a,
+                          const zo_method *m, int border);
+ZO_API int zo_extract(const zo_image *src, const zo_image *dst, const float rect[4], float angle,
+                      float cos_a, float sin_a, const zo_method *m, int border);
+ZO_API int zo_crop_dims(const float rect[4], uint32_t *rows, uint32_t *cols);
+ZO_API int zo_crop(const zo_image *src, const zo_image *dst, const float rect[4]);
+ZO_API int zo_flip_left_right(const zo_image *img);
+ZO_API int zo_flip_top_bottom(const zo_image *img);
+ZO_API int zo_insert(const zo_image *self, const zo_image *source, const float rect[4], float angle,
+                     float cos_a, float sin_a, const zo_method *m, int blend_mode);
+ZO_API int zo_copy(const zo_image *src, const zo_image *dst);
+ZO_API int zo_fill(const zo_image *img, const void *pixel);
+ZO_API int zo_set_border(const zo_image *img, const uint32_t rect[4], const void *pixel);
+
+/* color.c */
+ZO_API int zo_convert(const zo_image *src, int src_space, const zo_image *dst, int dst_space, const float *srgb_lut);
+ZO_API void zo_srgb_to_linear_lut(float lut[256]);
+
+/* homography (geometry/transforms.zig:242-263, exact 4-point solve in f64 then cast) */
+ZO_API int zo_homography_from_4pts(const double from_xy[8], const double to_xy[8], float m_out[9]);
+
+#endif
