@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py — throughput of the zignal image hot path on MI355X.
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+    Image.gaussianBlur(sigma=0.6)  ==  5x5 separable Gaussian, .mirror border,
+    4096 x 4096 RGBA f32 (interleaved float4; per-channel results equal the reference's f32 plane path),
+    frames resident in HBM before the timed region, rotating through a ring of distinct buffers whose
+    footprint (>= 2 GiB) is far above the 256 MiB Infinity Cache so the rate is an HBM rate.
+
+A step = one frame through the hot path (one kernel launch). N GPUs: one process per GPU, frames sharded
+across ranks with no data-path collective (independent frames) -> weak scaling; value is the
+whole-job Mpixels/s = N * frame pixels * steps / max-over-ranks time.
+
+Extra legs (rank 0, N = 1 only):
+    roofline      algorithmic bytes (32 B/px: 16 read + 16 written) / mean kernel time from HIP events
+                  recorded around each launch on the launch stream, against the 8.0 TB/s HBM3E peak.
+    cpu_baseline  the CPU oracle ("port" of the reference's convolveSeparablePlane, 1 thread) on a bounded
+                  sample of the same workload.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+ROWS = COLS = 4096
+SIGMA = 0.6
+METRIC = "Mpixels/s (and % HBM roofline), 5x5 blur + bilinear resize, 4K RGBA"
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--ring", type=int, default=4, help="distinct (src, dst) frame pairs to rotate through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(budget_s: float = 12.0):
+    """Oracle ('port') timed on this box's host cores, one thread, on a bounded sample: whole 4096x4096 f32
+    planes (the reference has no Rgba(f32) convolution, so an RGBA f32 frame is four Image(f32) planes)."""
+    import numpy as np
+    from oracle import pyoracle as oracle  # checker / baseline only — never on the product path
+
+    try:
+        oracle.lib(native=True)
+        native = True
+    except Exception:
+        native = False
+    k = oracle.gaussian_kernel(SIGMA)
+    plane = oracle.synth_f32(2, (ROWS, COLS))
+    out = np.empty_like(plane)
+    oracle.conv_separable(plane, k, k, oracle.MIRROR, out=out, native=native)  # warm-up (page faults)
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 8 and (time.perf_counter() - t_start) < budget_s:
+        t0 = time.perf_counter()
+        oracle.conv_separable(plane, k, k, oracle.MIRROR, out=out, native=native)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    mpix = ROWS * COLS / (4 * best) / 1e6  # an RGBA frame = 4 planes
+    return {"value": round(mpix, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "sample": f"{len(times)} x gaussianBlur(0.6) on one 4096x4096 f32 plane (best of), x4 planes per RGBA frame; "
+                      f"oracle/conv.c {'-march=native' if native else '-march=x86-64-v3'} -O3 -ffp-contract=off; "
+                      f"host has {os.cpu_count()} logical cores"}
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+
+    import zignal_amd as zg
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    lib = zg.lib()
+    rc = lib.zg_init(local_rank)
+    assert rc == 0, lib.zg_last_error()
+
+    # synthetic frames, seeded per rank; uniform [0,1) f32 like SURVEY §8d
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(2 + rank)
+    ring = max(2, args.ring)
+    srcs = [torch.rand((ROWS, COLS, 4), dtype=torch.float32, device="cuda", generator=gen) for _ in range(ring)]
+    dsts = [torch.empty_like(s) for s in srcs]
+    imgs = [(zg.Image(s), zg.Image(d)) for s, d in zip(srcs, dsts)]
+    ring_bytes = sum(s.numel() * 4 for s in srcs) * 2
+
+    def step(i):
+        s, d = imgs[i % ring]
+        s.gaussian_blur(SIGMA, out=d)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    pixels = ROWS * COLS
+    value = world * pixels * args.steps / elapsed / 1e6
+    result = {
+        "metric": METRIC, "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "gaussianBlur(sigma=0.6): 5x5 separable Gaussian, mirror border, 4096x4096 RGBA f32 "
+                               "(BASELINE.json configs[1]); one frame per step per GPU, frames resident in HBM",
+                   "frame": [ROWS, COLS, 4], "ring_bytes": ring_bytes, "frames_per_step_per_gpu": 1,
+                   "parallelism": f"frame-sharded x{world}, no data-path collective"},
+    }
+
+    if rank == 0 and world == 1:
+        # per-launch kernel time: HIP events on the launch stream (torch's current stream is the stream handed
+        # to zg_gaussian_blur), one pair per launch
+        n = min(args.steps, 100)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for i, (a, b) in enumerate(evs):
+            a.record()
+            step(i)
+            b.record()
+        torch.cuda.synchronize()
+        kernel_ms = sorted(a.elapsed_time(b) for a, b in evs)
+        mean_ms = sum(kernel_ms) / len(kernel_ms)
+        alg_bytes = 32 * pixels  # 16 B read + 16 B written per pixel
+        achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_sep_fused_rgba_f32_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                              "kernel": "k_sep_fused<RGBA_F32,5>", "kernel_ms_mean": round(mean_ms, 5),
+                              "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 5),
+                              "algorithmic_bytes_per_launch": alg_bytes}
+        if not args.no_extras:
+            result["extras"] = extras(zg, torch, np)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _time_kernel(torch, fn, n=50, warm=5):
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(n):
+        fn(i)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def extras(zg, torch, np):
+    """Secondary numbers (not the headline): the other halves of the metric on their own configs."""
+    out = {}
+    try:
+        ring = 8
+        srcs = [torch.randint(0, 256, (ROWS, COLS, 4), dtype=torch.uint8, device="cuda") for _ in range(ring)]
+        dsts = [torch.empty_like(s) for s in srcs]
+        im = [(zg.Image(s), zg.Image(d)) for s, d in zip(srcs, dsts)]
+        ms = _time_kernel(torch, lambda i: im[i % ring][0].gaussian_blur(SIGMA, out=im[i % ring][1]))
+        out["gaussian_blur_rgba_u8_4096"] = {"ms": round(ms, 5), "Mpixels/s": round(ROWS * COLS / ms / 1e3, 1),
+                                             "GB/s_algorithmic(8B/px)": round(8 * ROWS * COLS / ms / 1e6, 1)}
+    except Exception as e:  # an extra must never take the headline down
+        out["gaussian_blur_rgba_u8_4096"] = {"error": str(e)}
+    try:
+        ring = 8
+        srcs = [torch.randint(0, 256, (ROWS, COLS, 4), dtype=torch.uint8, device="cuda") for _ in range(ring)]
+        dsts = [torch.empty((1024, 1024, 4), dtype=torch.uint8, device="cuda") for _ in range(ring)]
+        im = [(zg.Image(s), zg.Image(d)) for s, d in zip(srcs, dsts)]
+        ms = _time_kernel(torch, lambda i: im[i % ring][0].resize(im[i % ring][1], zg.Interpolation.bilinear))
+        out["resize_bilinear_rgba_u8_4096_to_1024"] = {
+            "ms": round(ms, 5), "Mpixels/s(source)": round(ROWS * COLS / ms / 1e3, 1),
+            "GB/s_algorithmic(20B/out-px)": round(20 * 1024 * 1024 / ms / 1e6, 1)}
+    except Exception as e:
+        out["resize_bilinear_rgba_u8_4096_to_1024"] = {"error": str(e)}
+    return out
+
+
+if __name__ == "__main__":
+    main()

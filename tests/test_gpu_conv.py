@@ -1,0 +1,168 @@
+"""GPU parity: Image.convolveSeparable / gaussianBlur through the C ABI vs the CPU oracle.
+
+Bit-exact for every pixel type (integer paths by construction; f32 because the kernels keep the
+reference's operation order and never contract mul+add)."""
+import numpy as np
+import pytest
+
+import zignal_amd as zg
+from tests.util import ALL_TYPES, assert_bits_equal, synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+BORDERS = (zg.BorderMode.zero, zg.BorderMode.replicate, zg.BorderMode.mirror, zg.BorderMode.wrap)
+
+
+def dev(a):
+    return zg.Image(torch.from_numpy(np.ascontiguousarray(a)).cuda())
+
+
+def run_dev(a, kx, ky, border):
+    out = dev(a).convolve_separable(kx, ky, border)
+    torch.cuda.synchronize()
+    return out.to_numpy()
+
+
+# ---- reference known answers, through both layers (tests/filters.zig) -----------------------------
+def test_impulse_f32():  # filters.zig:469-491
+    img = np.zeros((7, 7), np.float32)
+    img[3, 3] = 1.0
+    g = [0.25, 0.5, 0.25]
+    for out in (zg.Image(img).convolve_separable(g, g, zg.BorderMode.zero).data, run_dev(img, g, g, zg.BorderMode.zero)):
+        assert out[3, 3] == np.float32(0.25) and out[3, 2] == np.float32(0.125)
+
+
+def test_separable_identity_on_strided_f32_view():  # filters.zig:602-632
+    base = (np.arange(5)[:, None] * 10 + np.arange(5)[None, :]).astype(np.float32)
+    view = zg.Image(base).view((1, 1, 4, 4))
+    out = view.convolve_separable([1.0], [1.0], zg.BorderMode.zero, out=zg.Image(np.empty((3, 3), np.float32)))
+    assert np.array_equal(out.data, base[1:4, 1:4])
+
+
+def test_separable_into_view_leaves_outside_untouched():  # filters.zig:746-783
+    r, c = np.mgrid[0:7, 0:9]
+    base_src = ((r * 7 + c * 3) % 256).astype(np.uint8)
+    for device in (False, True):
+        base_dst = np.full((7, 9), 0x55, np.uint8)
+        if device:
+            ts, td = torch.from_numpy(base_src).cuda(), torch.from_numpy(base_dst).cuda()
+            zg.Image(ts).view((1, 2, 6, 6)).convolve_separable([1.0], [1.0], zg.BorderMode.zero, out=zg.Image(td).view((1, 2, 6, 6)))
+            torch.cuda.synchronize()
+            base_dst = td.cpu().numpy()
+        else:
+            zg.Image(base_src).view((1, 2, 6, 6)).convolve_separable([1.0], [1.0], zg.BorderMode.zero, out=zg.Image(base_dst).view((1, 2, 6, 6)))
+        assert np.array_equal(base_dst[2:6, 1:6], base_src[2:6, 1:6])
+        mask = np.ones((7, 9), bool)
+        mask[2:6, 1:6] = False
+        assert np.all(base_dst[mask] == 0x55)
+
+
+def test_gaussian_sigma_zero_copies_and_negative_raises():  # filters.zig:1159-1180, image.zig:970
+    img = np.arange(25, dtype=np.float32).reshape(5, 5)
+    assert np.array_equal(zg.Image(img).gaussian_blur(0.0).data, img)
+    out = dev(img).gaussian_blur(0.0)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.to_numpy(), img)
+    with pytest.raises(zg.InvalidArgument):
+        zg.Image(img).gaussian_blur(-1.0)
+
+
+def test_dimension_mismatch():  # image.zig:947
+    with pytest.raises(zg.DimensionMismatch):
+        zg.Image(np.zeros((4, 4), np.uint8)).convolve_separable([1.0], [1.0], 0, out=zg.Image(np.zeros((4, 5), np.uint8)))
+
+
+# ---- seeded parity sweep ------------------------------------------------------------------------
+SIZES = ((1, 1), (3, 5), (2, 9), (17, 31), (257, 63), (100, 300))
+
+
+@pytest.mark.parametrize("kind", ALL_TYPES)
+@pytest.mark.parametrize("border", BORDERS)
+def test_parity_small_kernels(oracle, kind, border):
+    rng = np.random.default_rng(5)
+    for n in (1, 3, 5, 7, 9):
+        k = rng.random(n).astype(np.float32)
+        k /= k.sum()
+        for (rows, cols) in SIZES:
+            img = synth(oracle, kind, 100 + n, rows, cols)
+            assert_bits_equal(run_dev(img, k, k, border), oracle.conv_separable(img, k, k, border),
+                              f"{kind} {rows}x{cols} taps={n} border={border}")
+
+
+@pytest.mark.parametrize("kind", ALL_TYPES)
+def test_parity_two_pass_and_asymmetric(oracle, kind):
+    rng = np.random.default_rng(6)
+    for nx, ny in ((15, 15), (3, 7), (21, 1), (2, 4), (31, 31)):  # even lengths too: half = n / 2
+        kx = (rng.random(nx).astype(np.float32) - np.float32(0.3))
+        ky = (rng.random(ny).astype(np.float32) - np.float32(0.3))
+        for border in BORDERS:
+            img = synth(oracle, kind, 7, 37, 53)
+            assert_bits_equal(run_dev(img, kx, ky, border), oracle.conv_separable(img, kx, ky, border),
+                              f"{kind} taps=({nx},{ny}) border={border}")
+
+
+@pytest.mark.parametrize("kind", ("f32", "rgba_f32"))
+def test_negligible_taps_are_skipped_only_in_the_interior(oracle, kind):
+    # convolution.zig:459-467,541,594: |k| < 1e-10 skipped for interior pixels, not for border pixels
+    k = np.array([1e-12, 0.25, 0.5, 0.25, -3e-11], np.float32)
+    img = synth(oracle, kind, 8, 40, 70) * np.float32(1e12)  # make k*x visible at f32 precision
+    for border in BORDERS:
+        assert_bits_equal(run_dev(img, k, k, border), oracle.conv_separable(img, k, k, border), f"skip {kind} {border}")
+    k15 = np.zeros(15, np.float32)
+    k15[7] = 1.0
+    k15[0] = 5e-11
+    assert_bits_equal(run_dev(img, k15, k15, 2), oracle.conv_separable(img, k15, k15, 2), "skip two-pass")
+
+
+@pytest.mark.parametrize("kind", ("u8", "rgba_u8"))
+def test_wide_integer_taps_use_the_i64_path(oracle, kind):
+    # taps * 256 beyond 2^23: products leave i32, the reference accumulates in i64 and clamps temp to i32
+    k = np.array([-40000.0, 70000.0, -29000.0], np.float32)
+    k2 = np.array([0.001, 0.002, 0.001], np.float32)
+    img = synth(oracle, kind, 9, 33, 65)
+    for border in BORDERS:
+        assert_bits_equal(run_dev(img, k, k2, border), oracle.conv_separable(img, k, k2, border), f"i64 {kind}")
+        assert_bits_equal(run_dev(img, k, k, border), oracle.conv_separable(img, k, k, border), f"i64 clamp {kind}")
+
+
+@pytest.mark.parametrize("kind", ALL_TYPES)
+def test_views_on_both_sides(oracle, kind):
+    base = synth(oracle, kind, 10, 64, 96)
+    k = oracle.gaussian_kernel(1.0)
+    src_t = torch.from_numpy(base).cuda()
+    dst_t = torch.zeros_like(src_t)
+    zg.Image(src_t).view((5, 3, 85, 60)).convolve_separable(k, k, 2, out=zg.Image(dst_t).view((7, 4, 87, 61)))
+    torch.cuda.synchronize()
+    want = oracle.conv_separable(base[3:60, 5:85], k, k, 2)
+    got = dst_t.cpu().numpy()
+    assert_bits_equal(got[4:61, 7:87], want, f"view {kind}")
+    got[4:61, 7:87] = 0
+    assert not got.any(), "pixels outside the destination view were written"
+
+
+@pytest.mark.parametrize("kind,sigma", [("rgba_u8", 0.6), ("rgba_f32", 0.6), ("f32", 0.6), ("u8", 1.0), ("rgb_u8", 0.6)])
+def test_gaussian_blur_host_and_device_layers(oracle, kind, sigma):
+    img = synth(oracle, kind, 12, 123, 211)
+    want = oracle.gaussian_blur(img, sigma)
+    assert_bits_equal(zg.Image(img).gaussian_blur(sigma).data, want, f"host {kind}")
+    out = dev(img).gaussian_blur(sigma)
+    torch.cuda.synchronize()
+    assert_bits_equal(out.to_numpy(), want, f"device {kind}")
+
+
+# ---- BASELINE.json configs[1]: 5x5 Gaussian on 4096x4096 RGBA -------------------------------------
+@pytest.mark.parametrize("kind", ("rgba_f32", "rgba_u8"))
+def test_config2_full_size(oracle, kind):
+    img = synth(oracle, kind, 2, 4096, 4096)
+    out = dev(img).gaussian_blur(0.6)
+    torch.cuda.synchronize()
+    got = out.to_numpy()
+    # size-independent property: a normalised kernel leaves a constant frame constant (u8 taps sum to 256)
+    const = np.full_like(img[:64, :64], 77 if kind == "rgba_u8" else np.float32(0.5))
+    cout = dev(const).gaussian_blur(0.6)
+    torch.cuda.synchronize()
+    if kind == "rgba_u8":
+        assert np.all(cout.to_numpy() == 77)
+    # full comparison against the oracle (a few seconds of CPU)
+    assert_bits_equal(got, oracle.gaussian_blur(img, 0.6), f"4096^2 {kind}")

@@ -1,0 +1,13 @@
+"""zignal_amd — MI355X (gfx950) implementation of zignal's per-pixel image hot path.
+
+The product is `libzignal_hip.so` (hand-written HIP kernels behind the C ABI in
+include/zignal_hip.h); this package is the thin host-side mirror of the reference's `Image(T)`
+surface on top of it. There is no CPU fallback: importing works without a GPU, calling does not.
+"""
+from ._lib import (BORDER_MIRROR, BORDER_REPLICATE, BORDER_WRAP, BORDER_ZERO, CS_GRAY, CS_OKLAB, CS_RGB,
+                   CS_RGBA, CS_XYZ, CS_YCBCR, DimensionMismatch, InvalidArgument, ZignalError, lib)
+from .image import (AffineTransform, Blending, BorderMode, Image, Interpolation, ProjectiveTransform,
+                    SimilarityTransform, gaussian_kernel)
+
+__all__ = ["Image", "Interpolation", "BorderMode", "Blending", "ProjectiveTransform", "AffineTransform",
+           "SimilarityTransform", "gaussian_kernel", "DimensionMismatch", "InvalidArgument", "ZignalError", "lib"]

@@ -1,0 +1,138 @@
+"""ctypes binding of libzignal_hip.so — the C ABI declared in include/zignal_hip.h.
+
+There is no CPU fallback anywhere in this package: if the HIP library is missing or an entry point
+fails, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzignal_hip.so")
+
+# enums (ordinals as in include/zignal_hip.h == the reference's declaration order)
+PIXEL_U8, PIXEL_F32, PIXEL_RGB_U8, PIXEL_RGBA_U8, PIXEL_RGB_F32, PIXEL_RGBA_F32 = range(6)
+BORDER_ZERO, BORDER_REPLICATE, BORDER_MIRROR, BORDER_WRAP = range(4)
+INTERP_NEAREST, INTERP_BILINEAR, INTERP_BICUBIC, INTERP_CATMULL_ROM, INTERP_MITCHELL, INTERP_LANCZOS = range(6)
+TRANSFORM_SIMILARITY, TRANSFORM_AFFINE, TRANSFORM_PROJECTIVE = range(3)
+CS_GRAY, CS_RGB, CS_RGBA, CS_OKLAB, CS_XYZ, CS_YCBCR = range(6)
+
+OK, ERR_DIMENSION_MISMATCH, ERR_INVALID_ARGUMENT, ERR_OUT_OF_MEMORY, ERR_HIP, ERR_UNSUPPORTED = range(6)
+
+
+class ZgImage(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("stride", C.c_size_t), ("rows", C.c_uint32),
+                ("cols", C.c_uint32), ("pixel", C.c_int32)]
+
+
+class ZgMethod(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("b", C.c_float), ("c", C.c_float), ("lanczos_lut", C.c_void_p)]
+
+
+class ZignalError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"zignal_hip status {status}: {message}")
+        self.status = status
+
+
+class DimensionMismatch(ZignalError):
+    """error.DimensionMismatch (reference src/image.zig:636,927,947,962)."""
+
+
+class InvalidArgument(ZignalError, ValueError):
+    """error.InvalidSigma / InvalidScaleFactor / InvalidDimensions."""
+
+
+_lib = None
+
+_IMG = C.POINTER(ZgImage)
+_METHOD = C.POINTER(ZgMethod)
+_F32P = C.POINTER(C.c_float)
+_U32P = C.POINTER(C.c_uint32)
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+_SIGNATURES = {
+    "zg_init": [C.c_int],
+    "zg_shutdown": [],
+    "zg_last_error": [],
+    "zg_version": [],
+    "zg_device_count": [],
+    "zg_malloc": [C.POINTER(C.c_void_p), C.c_size_t],
+    "zg_free": [C.c_void_p],
+    "zg_memcpy_h2d": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+    "zg_memcpy_d2h": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+    "zg_stream_create": [C.POINTER(C.c_void_p)],
+    "zg_stream_destroy": [C.c_void_p],
+    "zg_stream_synchronize": [C.c_void_p],
+    "zg_pixel_size": [C.c_int],
+    "zg_conv_separable": [_IMG, _IMG, _F32P, C.c_uint32, _F32P, C.c_uint32, C.c_int, C.c_void_p],
+    "zg_conv_separable_host": [_IMG, _IMG, _F32P, C.c_uint32, _F32P, C.c_uint32, C.c_int],
+    "zg_gaussian_blur": [_IMG, _IMG, C.c_float, C.c_void_p],
+    "zg_gaussian_blur_host": [_IMG, _IMG, C.c_float],
+    "zg_gaussian_kernel": [C.c_float, _F32P, C.c_uint32],
+    "zg_convolve": [_IMG, _IMG, _F32P, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p],
+    "zg_convolve_host": [_IMG, _IMG, _F32P, C.c_uint32, C.c_uint32, C.c_int],
+    "zg_box_blur": [_IMG, _IMG, C.c_uint32, C.c_void_p],
+    "zg_box_blur_host": [_IMG, _IMG, C.c_uint32],
+    "zg_resize": [_IMG, _IMG, _METHOD, C.c_void_p],
+    "zg_resize_host": [_IMG, _IMG, _METHOD],
+    "zg_letterbox": [_IMG, _IMG, _METHOD, _U32P, C.c_void_p],
+    "zg_letterbox_host": [_IMG, _IMG, _METHOD, _U32P],
+    "zg_warp": [_IMG, _IMG, C.c_int, _F32P, _METHOD, C.c_void_p],
+    "zg_warp_host": [_IMG, _IMG, C.c_int, _F32P, _METHOD],
+    "zg_rotate_into": [_IMG, _IMG, C.c_float, C.c_float, C.c_float, _METHOD, C.c_int, C.c_void_p],
+    "zg_rotate_into_host": [_IMG, _IMG, C.c_float, C.c_float, C.c_float, _METHOD, C.c_int],
+    "zg_rotate_bounds": [C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, _U32P, _U32P],
+    "zg_extract": [_IMG, _IMG, _F32P, C.c_float, C.c_float, C.c_float, _METHOD, C.c_int, C.c_void_p],
+    "zg_extract_host": [_IMG, _IMG, _F32P, C.c_float, C.c_float, C.c_float, _METHOD, C.c_int],
+    "zg_crop": [_IMG, _IMG, _F32P, C.c_void_p],
+    "zg_crop_host": [_IMG, _IMG, _F32P],
+    "zg_crop_dims": [_F32P, _U32P, _U32P],
+    "zg_flip_left_right": [_IMG, C.c_void_p],
+    "zg_flip_top_bottom": [_IMG, C.c_void_p],
+    "zg_flip_left_right_host": [_IMG],
+    "zg_flip_top_bottom_host": [_IMG],
+    "zg_insert": [_IMG, _IMG, _F32P, C.c_float, C.c_float, C.c_float, _METHOD, C.c_int, C.c_void_p],
+    "zg_insert_host": [_IMG, _IMG, _F32P, C.c_float, C.c_float, C.c_float, _METHOD, C.c_int],
+    "zg_copy": [_IMG, _IMG, C.c_void_p],
+    "zg_fill": [_IMG, C.c_void_p, C.c_void_p],
+    "zg_set_border": [_IMG, _U32P, C.c_void_p, C.c_void_p],
+    "zg_convert": [_IMG, C.c_int, _IMG, C.c_int, _F32P, C.c_void_p],
+    "zg_convert_host": [_IMG, C.c_int, _IMG, C.c_int, _F32P],
+    "zg_batch_blur_resize": [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_float,
+                             C.c_void_p, C.c_uint32, C.c_uint32, _METHOD, C.c_void_p],
+}
+_RESTYPES = {"zg_last_error": C.c_char_p, "zg_shutdown": None, "zg_pixel_size": C.c_size_t}
+
+# every symbol include/zignal_hip.h declares; tests check the library exports all of them
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). zignal_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, argtypes in _SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the library does not export it
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, C.c_int)
+        _lib = l
+    return _lib
+
+
+def check(status: int) -> None:
+    if status == OK:
+        return
+    msg = (lib().zg_last_error() or b"").decode("utf-8", "replace")
+    if status == ERR_DIMENSION_MISMATCH:
+        raise DimensionMismatch(status, msg)
+    if status == ERR_INVALID_ARGUMENT:
+        raise InvalidArgument(status, msg)
+    if status == ERR_OUT_OF_MEMORY:
+        raise MemoryError(f"zignal_hip: {msg}")
+    raise ZignalError(status, msg)

@@ -1,0 +1,440 @@
+// conv_separable.hip — Image(T).convolveSeparable / gaussianBlur on gfx950.
+//
+// Replaces reference src/image/convolution.zig:313-438 (type switch) and :441-647
+// (convolveSeparablePlane) plus src/image.zig:954-994 (gaussianBlur).
+//
+// Arithmetic contract (what makes the output bit-identical to the reference CPU path):
+//   horizontal  temp[r,c] = sum_i  src[r, c+i-hx] * kx[i]   ascending i, acc starts at 0
+//   vertical    dst[r,c]  = sum_i temp[r+i-hy, c] * ky[i]   ascending i, acc starts at 0
+//   f32: separate multiply and add (no FMA);  u8: taps round(k*256) as i32, i64-exact accumulate,
+//   temp clamped to i32, output divClampU8(65536) = round-half-away then clamp.
+//   Out-of-range taps go through border.resolveIndex on BOTH passes; `temp` at a resolved row is the
+//   horizontal result of that row, so the two passes fuse without changing a single bit.
+//   Interior pixels skip taps with |k| < 1e-10 (f32) (convolution.zig:459-467,541,594); border pixels
+//   do not. For integers skipping a zero tap is a no-op, so only the f32 path carries the skip mask.
+//
+// The reference de-interleaves struct pixels into planes and runs the plane kernel per channel
+// (convolution.zig:358-430). Channels are independent, so the kernels here stay interleaved (one
+// coalesced read and one coalesced write of the image) and produce the same bytes. The uniform-
+// channel shortcut (:367-412) yields the same values as the full computation for every border mode
+// it is enabled for, so it is not reproduced.
+//
+// Kernels:
+//   k_sep_fused<PIX,NK,MODE,SKIP>  one launch: (TW+2h)x(TH+2h) source tile -> LDS (border resolved at
+//       load time), row pass from LDS into a register sliding window of NK temps, column pass from
+//       the window, one coalesced store. HBM traffic = read once + write once.
+//   k_sep_h / k_sep_v              general two-pass fallback for long or asymmetric kernels
+//       (temp plane in HBM, as the reference does).
+#include "zg_common.h"
+#include "zg_hostmath.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace zg {
+
+constexpr int MAX_TAPS = 255;
+
+enum : int { MODE_F32 = 0, MODE_I24 = 1, MODE_I64 = 2 };
+
+template <int N> struct TapsArg {
+    union { float f[N]; int32_t i[N]; };
+};
+
+template <int MODE> struct Arith;
+template <> struct Arith<MODE_F32> {
+    using Temp = float; using Acc = float;
+    __device__ static Acc mac(Acc a, Temp v, float k) { const float p = v * k; return a + p; }
+    __device__ static Temp to_temp(Acc a) { return a; }
+};
+template <> struct Arith<MODE_I24> { // host proved every product and sum fits: exact in i32
+    using Temp = int32_t; using Acc = int32_t;
+    __device__ static Acc mac(Acc a, Temp v, int32_t k) { return a + __mul24(v, k); }
+    __device__ static Temp to_temp(Acc a) { return a; }
+};
+template <> struct Arith<MODE_I64> { // reference widths: i64 accumulate, temp clamped to i32
+    using Temp = int32_t; using Acc = int64_t;
+    __device__ static Acc mac(Acc a, Temp v, int32_t k) { return a + (int64_t)v * (int64_t)k; }
+    __device__ static Temp to_temp(Acc a) {
+        return (int32_t)(a < INT32_MIN ? (int64_t)INT32_MIN : (a > INT32_MAX ? (int64_t)INT32_MAX : a));
+    }
+};
+
+// divClampU8(65536, acc) (convolution.zig:18-22): symmetric rounding divide, clamp to u8.
+template <typename Acc> __device__ inline uint8_t div_clamp_u8_sq(Acc acc) {
+    if (acc < 0) return 0; // (acc - 32768) / 65536 truncates to <= 0
+    const Acc q = (acc + 32768) >> 16;
+    return (uint8_t)(q > 255 ? 255 : q);
+}
+
+template <int MODE, typename TapsT> __device__ inline auto tap(const TapsT &t, int i) {
+    if constexpr (MODE == MODE_F32) return t.f[i]; else return t.i[i];
+}
+
+constexpr int TW = 64;  // tile width  = one wavefront of columns
+constexpr int TH = 32;  // tile height = 4 waves x 8 rows
+constexpr int RPT = 8;  // rows per thread
+
+template <int PIX, int NK, int MODE, bool SKIP>
+__global__ __launch_bounds__(256) void k_sep_fused(DImg src, DImg dst, TapsArg<NK> kx, TapsArg<NK> ky,
+                                                   int border, uint32_t skipx, uint32_t skipy, int tiles_x) {
+    using P = Px<PIX>;
+    using Vec = typename P::Vec;
+    using A = Arith<MODE>;
+    using Temp = typename A::Temp;
+    using Acc = typename A::Acc;
+    constexpr int C = P::C;
+    constexpr int H = NK / 2;
+    constexpr int LW = TW + 2 * H;
+    constexpr int LH = TH + 2 * H;
+
+    __shared__ Vec tile[LH * LW];
+
+    const int tile_id = blockIdx.x;
+    const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
+    const int x0 = tx * TW, y0 = ty * TH;
+
+    for (int i = threadIdx.x; i < LH * LW; i += 256) {
+        const int r = i / LW, c = i - r * LW;
+        const int gr = resolve_index(y0 - H + r, src.rows, border);
+        const int gc = resolve_index(x0 - H + c, src.cols, border);
+        Vec v = P::zero();
+        if (gr >= 0 && gc >= 0) v = P::load(src.data, (size_t)gr * src.stride + (size_t)gc);
+        tile[i] = v;
+    }
+    __syncthreads();
+
+    const int lx = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int gx = x0 + lx;
+    const bool col_interior = (src.cols > 2 * H) && gx >= H && gx < src.cols - H;
+    const bool rows_have_interior = src.rows > 2 * H;
+
+    Temp win[NK][C];
+#pragma unroll
+    for (int j = 0; j < RPT + 2 * H; ++j) {
+        const int lr = wave * RPT + j; // tile row whose horizontal result enters the window
+        Acc acc[C];
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) acc[ch] = 0;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            if (SKIP && col_interior && ((skipx >> i) & 1u)) continue;
+            const Vec v = tile[lr * LW + lx + i];
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) acc[ch] = A::mac(acc[ch], (Temp)v[ch], tap<MODE>(kx, i));
+        }
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) win[j % NK][ch] = A::to_temp(acc[ch]);
+
+        if (j >= 2 * H) {
+            const int gy = y0 + wave * RPT + (j - 2 * H);
+            const bool row_interior = rows_have_interior && gy >= H && gy < src.rows - H;
+            Acc out[C];
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) out[ch] = 0;
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                if (SKIP && row_interior && ((skipy >> i) & 1u)) continue;
+                // tap i reads temp row (j - 2H + i) of this thread's strip = window slot (j + 1 + i) % NK
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch)
+                    out[ch] = A::mac(out[ch], win[(j + 1 + i) % NK][ch], tap<MODE>(ky, i));
+            }
+            if (gx < dst.cols && gy < dst.rows) {
+                Vec o;
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    if constexpr (MODE == MODE_F32) o[ch] = out[ch];
+                    else o[ch] = div_clamp_u8_sq<Acc>(out[ch]);
+                }
+                P::store(dst.data, (size_t)gy * dst.stride + (size_t)gx, o);
+            }
+        }
+    }
+}
+
+// ---- general two-pass fallback ----------------------------------------------------------------
+template <int PIX, int MODE>
+__global__ __launch_bounds__(256) void k_sep_h(DImg src, typename Arith<MODE>::Temp *temp, const void *taps,
+                                               int nk, int border) {
+    using P = Px<PIX>;
+    using Vec = typename P::Vec;
+    using A = Arith<MODE>;
+    constexpr int C = P::C;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= src.cols) return;
+    const int h = nk / 2;
+    const bool interior = (src.cols > 2 * h) && c >= h && c < src.cols - h;
+    typename A::Acc acc[C];
+    for (int ch = 0; ch < C; ++ch) acc[ch] = 0;
+    const size_t row = (size_t)r * src.stride;
+    for (int i = 0; i < nk; ++i) {
+        if constexpr (MODE == MODE_F32) {
+            const float k = ((const float *)taps)[i];
+            if (interior && fabsf(k) < 1e-10f) continue;
+            const int gc = resolve_index(c + i - h, src.cols, border);
+            Vec v = P::zero();
+            if (gc >= 0) v = P::load(src.data, row + gc);
+            for (int ch = 0; ch < C; ++ch) acc[ch] = A::mac(acc[ch], v[ch], k);
+        } else {
+            const int32_t k = ((const int32_t *)taps)[i];
+            const int gc = resolve_index(c + i - h, src.cols, border);
+            Vec v = P::zero();
+            if (gc >= 0) v = P::load(src.data, row + gc);
+            for (int ch = 0; ch < C; ++ch) acc[ch] = A::mac(acc[ch], (int32_t)v[ch], k);
+        }
+    }
+    typename A::Temp *t = temp + ((size_t)r * src.cols + c) * C;
+    for (int ch = 0; ch < C; ++ch) t[ch] = A::to_temp(acc[ch]);
+}
+
+template <int PIX, int MODE>
+__global__ __launch_bounds__(256) void k_sep_v(const typename Arith<MODE>::Temp *temp, DImg dst, const void *taps,
+                                               int nk, int border) {
+    using P = Px<PIX>;
+    using Vec = typename P::Vec;
+    using A = Arith<MODE>;
+    constexpr int C = P::C;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= dst.cols) return;
+    const int h = nk / 2;
+    const bool interior = (dst.rows > 2 * h) && r >= h && r < dst.rows - h;
+    typename A::Acc acc[C];
+    for (int ch = 0; ch < C; ++ch) acc[ch] = 0;
+    for (int i = 0; i < nk; ++i) {
+        const int gr = resolve_index(r + i - h, dst.rows, border);
+        if constexpr (MODE == MODE_F32) {
+            const float k = ((const float *)taps)[i];
+            if (interior && fabsf(k) < 1e-10f) continue;
+            for (int ch = 0; ch < C; ++ch) {
+                const float v = gr >= 0 ? temp[((size_t)gr * dst.cols + c) * C + ch] : 0.0f;
+                acc[ch] = A::mac(acc[ch], v, k);
+            }
+        } else {
+            const int32_t k = ((const int32_t *)taps)[i];
+            for (int ch = 0; ch < C; ++ch) {
+                const int32_t v = gr >= 0 ? temp[((size_t)gr * dst.cols + c) * C + ch] : 0;
+                acc[ch] = A::mac(acc[ch], v, k);
+            }
+        }
+    }
+    Vec o;
+    for (int ch = 0; ch < C; ++ch) {
+        if constexpr (MODE == MODE_F32) o[ch] = acc[ch];
+        else o[ch] = div_clamp_u8_sq<typename A::Acc>(acc[ch]);
+    }
+    P::store(dst.data, (size_t)r * dst.stride + c, o);
+}
+
+// ---- host dispatch ----------------------------------------------------------------------------
+struct SepPlan {
+    int nkx, nky;
+    std::vector<float> fx, fy;
+    std::vector<int32_t> ix, iy;
+    uint32_t skipx = 0, skipy = 0;
+    int mode = MODE_F32;
+};
+
+template <int PIX, int NK, int MODE, bool SKIP>
+static int launch_fused(const zg_image *src, const zg_image *dst, const SepPlan &p, int border, hipStream_t s) {
+    TapsArg<NK> kx, ky;
+    for (int i = 0; i < NK; ++i) {
+        if constexpr (MODE == MODE_F32) { kx.f[i] = p.fx[i]; ky.f[i] = p.fy[i]; }
+        else { kx.i[i] = p.ix[i]; ky.i[i] = p.iy[i]; }
+    }
+    const int tiles_x = (int)ceil_div(src->cols, TW), tiles_y = (int)ceil_div(src->rows, TH);
+    hipLaunchKernelGGL((k_sep_fused<PIX, NK, MODE, SKIP>), dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s,
+                       dimg(src), dimg(dst), kx, ky, border, p.skipx, p.skipy, tiles_x);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+template <int PIX, int NK, int MODE>
+static int launch_fused_skip(const zg_image *src, const zg_image *dst, const SepPlan &p, int border, hipStream_t s) {
+    if (MODE == MODE_F32 && (p.skipx | p.skipy)) return launch_fused<PIX, NK, MODE, true>(src, dst, p, border, s);
+    return launch_fused<PIX, NK, MODE, false>(src, dst, p, border, s);
+}
+
+template <int PIX, int MODE>
+static int launch_fused_nk(const zg_image *src, const zg_image *dst, const SepPlan &p, int border, hipStream_t s) {
+    switch (p.nkx) {
+    case 1: return launch_fused_skip<PIX, 1, MODE>(src, dst, p, border, s);
+    case 3: return launch_fused_skip<PIX, 3, MODE>(src, dst, p, border, s);
+    case 5: return launch_fused_skip<PIX, 5, MODE>(src, dst, p, border, s);
+    case 7: return launch_fused_skip<PIX, 7, MODE>(src, dst, p, border, s);
+    case 9: return launch_fused_skip<PIX, 9, MODE>(src, dst, p, border, s);
+    case 11: return launch_fused_skip<PIX, 11, MODE>(src, dst, p, border, s);
+    case 13: return launch_fused_skip<PIX, 13, MODE>(src, dst, p, border, s);
+    }
+    return -1;
+}
+
+template <int PIX, int MODE>
+static int launch_two_pass(const zg_image *src, const zg_image *dst, const SepPlan &p, int border, hipStream_t s) {
+    using Temp = typename Arith<MODE>::Temp;
+    constexpr int C = Px<PIX>::C;
+    const size_t temp_bytes = (size_t)src->rows * src->cols * C * sizeof(Temp);
+    const size_t tap_bytes = (size_t)(p.nkx + p.nky) * 4;
+    char *scratch = nullptr;
+    ZG_HIP(hipMallocAsync((void **)&scratch, temp_bytes + tap_bytes, s));
+    Temp *temp = (Temp *)scratch;
+    void *dkx = scratch + temp_bytes;
+    void *dky = scratch + temp_bytes + (size_t)p.nkx * 4;
+    const void *hx = MODE == MODE_F32 ? (const void *)p.fx.data() : (const void *)p.ix.data();
+    const void *hy = MODE == MODE_F32 ? (const void *)p.fy.data() : (const void *)p.iy.data();
+    // pageable host memory: hipMemcpyAsync copies out of the source before returning
+    ZG_HIP(hipMemcpyAsync(dkx, hx, (size_t)p.nkx * 4, hipMemcpyHostToDevice, s));
+    ZG_HIP(hipMemcpyAsync(dky, hy, (size_t)p.nky * 4, hipMemcpyHostToDevice, s));
+    ZG_HIP(hipStreamSynchronize(s)); // taps live in caller-owned vectors
+    const dim3 grid(ceil_div(src->cols, 256), src->rows);
+    hipLaunchKernelGGL((k_sep_h<PIX, MODE>), grid, dim3(256), 0, s, dimg(src), temp, dkx, p.nkx, border);
+    hipLaunchKernelGGL((k_sep_v<PIX, MODE>), grid, dim3(256), 0, s, temp, dimg(dst), dky, p.nky, border);
+    ZG_HIP(hipGetLastError());
+    ZG_HIP(hipFreeAsync(scratch, s));
+    return ZG_OK;
+}
+
+template <int PIX, int MODE>
+static int run_sep(const zg_image *src, const zg_image *dst, const SepPlan &p, int border, hipStream_t s) {
+    if (p.nkx == p.nky && p.nkx <= 13 && (p.nkx & 1)) {
+        const int rc = launch_fused_nk<PIX, MODE>(src, dst, p, border, s);
+        if (rc >= 0) return rc;
+    }
+    return launch_two_pass<PIX, MODE>(src, dst, p, border, s);
+}
+
+static int conv_separable_impl(const zg_image *src, const zg_image *dst, const float *kx, uint32_t nkx,
+                               const float *ky, uint32_t nky, int border, hipStream_t s) {
+    int rc;
+    if ((rc = check_image(src, "src")) || (rc = check_image(dst, "dst"))) return rc;
+    ZG_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, ZG_ERR_DIMENSION_MISMATCH,
+               "convolveSeparable: %ux%u vs %ux%u", src->rows, src->cols, dst->rows, dst->cols);
+    ZG_REQUIRE(src->pixel == dst->pixel, ZG_ERR_INVALID_ARGUMENT, "convolveSeparable: pixel types differ");
+    ZG_REQUIRE(kx && ky && nkx >= 1 && nky >= 1 && nkx <= MAX_TAPS && nky <= MAX_TAPS, ZG_ERR_INVALID_ARGUMENT,
+               "convolveSeparable: kernel lengths %u, %u (1..%d supported)", nkx, nky, MAX_TAPS);
+    ZG_REQUIRE(border >= ZG_BORDER_ZERO && border <= ZG_BORDER_WRAP, ZG_ERR_INVALID_ARGUMENT, "invalid border %d", border);
+    if (src->rows == 0 || src->cols == 0) return ZG_OK;
+
+    SepPlan p;
+    p.nkx = (int)nkx;
+    p.nky = (int)nky;
+    const bool is_float = pixel_is_float(src->pixel);
+    if (is_float) {
+        p.mode = MODE_F32;
+        p.fx.assign(kx, kx + nkx);
+        p.fy.assign(ky, ky + nky);
+        for (uint32_t i = 0; i < nkx && i < 32; ++i) if (std::fabs(kx[i]) < 1e-10f) p.skipx |= 1u << i;
+        for (uint32_t i = 0; i < nky && i < 32; ++i) if (std::fabs(ky[i]) < 1e-10f) p.skipy |= 1u << i;
+    } else {
+        // scaleKernelToInt (convolution.zig:303-309): @round(k * 256) -> i32
+        p.ix.resize(nkx);
+        p.iy.resize(nky);
+        int64_t sax = 0, say = 0, mx = 0, my = 0;
+        for (uint32_t i = 0; i < nkx; ++i) {
+            const float r = std::round(kx[i] * 256.0f);
+            ZG_REQUIRE(std::fabs(r) < 2147483648.0f, ZG_ERR_INVALID_ARGUMENT, "kernel_x[%u] does not fit i32 after scaling", i);
+            p.ix[i] = (int32_t)r;
+            sax += std::llabs((long long)p.ix[i]);
+            mx = std::max<int64_t>(mx, std::llabs((long long)p.ix[i]));
+        }
+        for (uint32_t i = 0; i < nky; ++i) {
+            const float r = std::round(ky[i] * 256.0f);
+            ZG_REQUIRE(std::fabs(r) < 2147483648.0f, ZG_ERR_INVALID_ARGUMENT, "kernel_y[%u] does not fit i32 after scaling", i);
+            p.iy[i] = (int32_t)r;
+            say += std::llabs((long long)p.iy[i]);
+            my = std::max<int64_t>(my, std::llabs((long long)p.iy[i]));
+        }
+        // i24 multiplies are exact when both operands fit 24 signed bits and no sum leaves i32.
+        const int64_t max_temp = 255 * sax;
+        const bool fits = mx < (1 << 23) && my < (1 << 23) && max_temp < (1 << 23) &&
+                          max_temp * say < (int64_t)INT32_MAX - 65536;
+        p.mode = fits ? MODE_I24 : MODE_I64;
+    }
+
+    return dispatch_pixel(src->pixel, [&](auto tag) -> int {
+        constexpr int PIX = decltype(tag)::value;
+        if constexpr (std::is_same<typename Px<PIX>::Elem, float>::value) {
+            return run_sep<PIX, MODE_F32>(src, dst, p, border, s);
+        } else {
+            if (p.mode == MODE_I24) return run_sep<PIX, MODE_I24>(src, dst, p, border, s);
+            return run_sep<PIX, MODE_I64>(src, dst, p, border, s);
+        }
+    });
+}
+
+int copy_impl(const zg_image *src, const zg_image *dst, hipStream_t s);
+
+} // namespace zg
+
+using namespace zg;
+
+extern "C" {
+
+int zg_conv_separable(const zg_image *src, const zg_image *dst, const float *kx, uint32_t nkx,
+                      const float *ky, uint32_t nky, int border, zg_stream stream) {
+    return conv_separable_impl(src, dst, kx, nkx, ky, nky, border, as_stream(stream));
+}
+
+int zg_conv_separable_host(const zg_image *src, const zg_image *dst, const float *kx, uint32_t nkx,
+                           const float *ky, uint32_t nky, int border) {
+    HostStage a, b;
+    int rc;
+    if ((rc = a.upload(src, true, false))) return rc;
+    if ((rc = b.upload(dst, false, true))) return rc;
+    if ((rc = conv_separable_impl(&a.dev, &b.dev, kx, nkx, ky, nky, border, nullptr))) return rc;
+    ZG_HIP(hipStreamSynchronize(nullptr));
+    return b.finish();
+}
+
+// image.zig:973-990
+int zg_gaussian_kernel(float sigma, float *taps, uint32_t capacity) {
+    if (!(sigma > 0)) { set_error("gaussian kernel: sigma must be > 0"); return -ZG_ERR_INVALID_ARGUMENT; }
+    const float rf = std::ceil(3.0f * sigma);
+    if (!(rf < (float)(MAX_TAPS / 2 + 1))) { set_error("gaussian kernel: sigma %g too large", sigma); return -ZG_ERR_INVALID_ARGUMENT; }
+    const uint32_t radius = (uint32_t)rf, size = 2 * radius + 1;
+    if (!taps) return (int)size;
+    if (capacity < size) { set_error("gaussian kernel: capacity %u < %u", capacity, size); return -ZG_ERR_INVALID_ARGUMENT; }
+    float sum = 0;
+    for (uint32_t i = 0; i < size; ++i) {
+        const float x = (float)i - (float)radius;
+        taps[i] = hostmath::exp_f32(-(x * x) / (2.0f * sigma * sigma));
+        sum += taps[i];
+    }
+    for (uint32_t i = 0; i < size; ++i) taps[i] /= sum;
+    return (int)size;
+}
+
+static int gaussian_impl(const zg_image *src, const zg_image *dst, float sigma, hipStream_t s) {
+    int rc;
+    if ((rc = check_image(src, "src")) || (rc = check_image(dst, "dst"))) return rc;
+    ZG_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, ZG_ERR_DIMENSION_MISMATCH,
+               "gaussianBlur: %ux%u vs %ux%u", src->rows, src->cols, dst->rows, dst->cols);
+    if (sigma == 0) return copy_impl(src, dst, s);                       // image.zig:966
+    ZG_REQUIRE(sigma > 0, ZG_ERR_INVALID_ARGUMENT, "gaussianBlur: InvalidSigma (%g)", sigma); // image.zig:970
+    float taps[MAX_TAPS];
+    const int n = zg_gaussian_kernel(sigma, taps, MAX_TAPS);
+    if (n < 0) return -n;
+    return conv_separable_impl(src, dst, taps, (uint32_t)n, taps, (uint32_t)n, ZG_BORDER_MIRROR, s);
+}
+
+int zg_gaussian_blur(const zg_image *src, const zg_image *dst, float sigma, zg_stream stream) {
+    return gaussian_impl(src, dst, sigma, as_stream(stream));
+}
+
+int zg_gaussian_blur_host(const zg_image *src, const zg_image *dst, float sigma) {
+    HostStage a, b;
+    int rc;
+    if ((rc = a.upload(src, true, false))) return rc;
+    if ((rc = b.upload(dst, false, true))) return rc;
+    if ((rc = gaussian_impl(&a.dev, &b.dev, sigma, nullptr))) return rc;
+    ZG_HIP(hipStreamSynchronize(nullptr));
+    return b.finish();
+}
+
+} // extern "C"

@@ -1,0 +1,173 @@
+// zg_common.h — shared host/device helpers of libzignal_hip (gfx950 only).
+//
+// Everything numeric in this library is compiled with -ffp-contract=off: the reference computes
+// f32 with separate multiply and add (no @mulAdd anywhere under src/image*), and bit parity with
+// it depends on never forming an FMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <type_traits>
+
+#include "../../include/zignal_hip.h"
+
+#pragma clang fp contract(off)
+
+namespace zg {
+
+// ---- error plumbing ------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define ZG_HIP(expr)                                                        \
+    do {                                                                    \
+        hipError_t _e = (expr);                                             \
+        if (_e != hipSuccess) return ::zg::hip_fail(_e, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define ZG_REQUIRE(cond, status, ...)      \
+    do {                                   \
+        if (!(cond)) {                     \
+            ::zg::set_error(__VA_ARGS__);  \
+            return (status);               \
+        }                                  \
+    } while (0)
+
+inline hipStream_t as_stream(zg_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- pixel layouts -------------------------------------------------------------------------
+__host__ __device__ inline int pixel_channels(int pixel) {
+    switch (pixel) {
+    case ZG_PIXEL_U8: case ZG_PIXEL_F32: return 1;
+    case ZG_PIXEL_RGB_U8: case ZG_PIXEL_RGB_F32: return 3;
+    default: return 4;
+    }
+}
+__host__ __device__ inline bool pixel_is_float(int pixel) {
+    return pixel == ZG_PIXEL_F32 || pixel == ZG_PIXEL_RGB_F32 || pixel == ZG_PIXEL_RGBA_F32;
+}
+__host__ __device__ inline size_t pixel_size(int pixel) {
+    return (size_t)pixel_channels(pixel) * (pixel_is_float(pixel) ? 4 : 1);
+}
+inline bool pixel_valid(int pixel) { return pixel >= ZG_PIXEL_U8 && pixel <= ZG_PIXEL_RGBA_F32; }
+
+// Device-side image descriptor (Image(T) fields, reference src/image.zig:97-103).
+struct DImg {
+    void *data;
+    uint64_t stride; // pixels
+    int32_t rows, cols;
+};
+inline DImg dimg(const zg_image *im) {
+    return DImg{im->data, (uint64_t)im->stride, (int32_t)im->rows, (int32_t)im->cols};
+}
+
+// Compile-time pixel traits. `Vec` is the register / LDS form of one pixel (a clang ext vector, so
+// it lives in VGPRs and moves with one instruction); 3-channel pixels pad to 4 lanes in registers
+// and LDS but are 3 tightly packed elements in memory (reference src/color.zig:286-290).
+template <typename E, int N> struct VecOf { typedef E type __attribute__((ext_vector_type(N))); };
+
+template <typename E, int CH> struct PxBase {
+    using Elem = E;
+    static constexpr int C = CH;
+    static constexpr int BYTES = CH * (int)sizeof(E);
+    using Vec = typename VecOf<E, CH>::type;
+    __device__ static Vec zero() {
+        Vec v;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) v[i] = (E)0;
+        return v;
+    }
+    __device__ static Vec load(const void *base, size_t idx) {
+        if constexpr (CH == 3) {
+            const E *p = (const E *)base + idx * 3;
+            Vec v;
+            v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+            return v;
+        } else {
+            return ((const Vec *)base)[idx];
+        }
+    }
+    __device__ static void store(void *base, size_t idx, Vec v) {
+        if constexpr (CH == 3) {
+            E *p = (E *)base + idx * 3;
+            p[0] = v[0]; p[1] = v[1]; p[2] = v[2];
+        } else {
+            ((Vec *)base)[idx] = v;
+        }
+    }
+};
+template <int PIX> struct Px;
+template <> struct Px<ZG_PIXEL_U8> : PxBase<uint8_t, 1> {};
+template <> struct Px<ZG_PIXEL_F32> : PxBase<float, 1> {};
+template <> struct Px<ZG_PIXEL_RGB_U8> : PxBase<uint8_t, 3> {};
+template <> struct Px<ZG_PIXEL_RGBA_U8> : PxBase<uint8_t, 4> {};
+template <> struct Px<ZG_PIXEL_RGB_F32> : PxBase<float, 3> {};
+template <> struct Px<ZG_PIXEL_RGBA_F32> : PxBase<float, 4> {};
+
+// Dispatch a runtime zg_pixel to a compile-time tag: f(std::integral_constant<int, PIX>{}).
+template <typename F> inline int dispatch_pixel(int pixel, F &&f) {
+    switch (pixel) {
+    case ZG_PIXEL_U8: return f(std::integral_constant<int, ZG_PIXEL_U8>{});
+    case ZG_PIXEL_F32: return f(std::integral_constant<int, ZG_PIXEL_F32>{});
+    case ZG_PIXEL_RGB_U8: return f(std::integral_constant<int, ZG_PIXEL_RGB_U8>{});
+    case ZG_PIXEL_RGBA_U8: return f(std::integral_constant<int, ZG_PIXEL_RGBA_U8>{});
+    case ZG_PIXEL_RGB_F32: return f(std::integral_constant<int, ZG_PIXEL_RGB_F32>{});
+    case ZG_PIXEL_RGBA_F32: return f(std::integral_constant<int, ZG_PIXEL_RGBA_F32>{});
+    }
+    set_error("invalid pixel type %d", pixel);
+    return ZG_ERR_INVALID_ARGUMENT;
+}
+
+// ---- border (reference src/image/border.zig:46-63) ------------------------------------------
+// Returns the in-range index, or -1 for the reference's `null` (sample is zero).
+__host__ __device__ inline int resolve_index(int idx, int length, int border) {
+    if (idx >= 0 && idx < length) return idx;
+    switch (border) {
+    case ZG_BORDER_ZERO: return -1;
+    case ZG_BORDER_REPLICATE:
+        if (length == 0) return -1;
+        return idx < 0 ? 0 : length - 1;
+    case ZG_BORDER_MIRROR: {
+        if (length <= 0) return -1;
+        if (length == 1) return 0;
+        const int period = 2 * (length - 1);
+        int m = idx % period;
+        if (m < 0) m += period; // @mod is floored
+        return m >= length ? period - m : m;
+    }
+    default: { // wrap
+        if (length == 0) return -1;
+        int m = idx % length;
+        if (m < 0) m += length;
+        return m;
+    }
+    }
+}
+
+// ---- meta.clamp (reference src/meta.zig:110-135) ---------------------------------------------
+// float -> u8: trunc(clamp(round(f64(v)), 0, 255)); rounding an f32 in f64 equals roundf in f32.
+__device__ inline uint8_t clamp_u8_f32(float v) {
+    float r = roundf(v);                 // half away from zero (@round)
+    r = fminf(r, 255.0f);                // @min returns the non-NaN operand, as fminf
+    r = fmaxf(0.0f, r);
+    return (uint8_t)(int)r;
+}
+__device__ inline uint8_t clamp_u8_i32(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+// ---- launch helpers ------------------------------------------------------------------------
+inline unsigned ceil_div(unsigned a, unsigned b) { return (a + b - 1) / b; }
+
+// Host-layer scaffolding (zg_runtime.cpp): stage host images to the device, run, copy back.
+struct HostStage {
+    zg_image dev{};       // device twin (contiguous: stride == cols)
+    const zg_image *host{};
+    bool writeback = false;
+    ~HostStage();
+    int upload(const zg_image *h, bool copy_in, bool write_back);
+    int finish();         // D2H if writeback
+};
+
+int check_image(const zg_image *im, const char *name);
+
+} // namespace zg

@@ -1,0 +1,429 @@
+"""Host-side mirror of zignal's `Image(T)` call surface over the libzignal_hip C ABI.
+
+Method names, argument meaning and error behaviour follow the reference's Python binding
+(`zignal.Image`, reference bindings/python/src/image.zig:922-1180) and, underneath, the Zig methods
+(reference src/image.zig:375-994): outputs are pre-allocated by the allocating variants exactly
+where the reference allocates, `DimensionMismatch` / `InvalidArgument` are raised where the
+reference returns `error.DimensionMismatch` / `error.InvalidSigma` / `error.InvalidScaleFactor`.
+
+Two flavours share all code:
+  * `Image(ndarray)`        host pixels (numpy); every call is synchronous: H2D -> kernel -> D2H
+                            through the zg_<op>_host entry points.
+  * `Image(torch_tensor)`   device pixels (a CUDA/HIP tensor used purely as device memory); calls are
+                            asynchronous on torch's current stream through the zg_<op> entry points.
+
+Pixels: (R, C) uint8 / float32, (R, C, 3|4) uint8 / float32. Views (row stride > cols) are allowed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib as L
+
+try:  # torch is plumbing (device memory + streams); the host flavour works without it
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+class Interpolation:
+    """reference src/image/interpolation.zig:53-68 (a tagged union; Mitchell carries b, c)."""
+
+    def __init__(self, kind: int, b: float = 0.0, c: float = 0.0):
+        self.kind, self.b, self.c = kind, float(b), float(c)
+
+    def _c(self) -> L.ZgMethod:
+        return L.ZgMethod(self.kind, self.b, self.c, None)
+
+    def __repr__(self):
+        names = ["nearest", "bilinear", "bicubic", "catmull_rom", "mitchell", "lanczos"]
+        return f"Interpolation.{names[self.kind]}"
+
+
+Interpolation.nearest = Interpolation(L.INTERP_NEAREST)
+Interpolation.bilinear = Interpolation(L.INTERP_BILINEAR)
+Interpolation.bicubic = Interpolation(L.INTERP_BICUBIC)
+Interpolation.catmull_rom = Interpolation(L.INTERP_CATMULL_ROM)
+Interpolation.lanczos = Interpolation(L.INTERP_LANCZOS)
+# `.{ .b = 1 / 3, .c = 1 / 3 }` is comptime-integer division in the reference (interpolation.zig:65),
+# i.e. b = c = 0; kept as written there. Interpolation.mitchell(1/3, 1/3) gives the textbook filter.
+Interpolation.mitchell_default = Interpolation(L.INTERP_MITCHELL, 0.0, 0.0)
+Interpolation.mitchell = staticmethod(lambda b, c: Interpolation(L.INTERP_MITCHELL, b, c))
+
+
+class BorderMode:
+    """reference src/image/border.zig:10-18"""
+    zero, replicate, mirror, wrap = range(4)
+
+
+class Blending:
+    none, normal = 0, 1
+
+
+_PIXEL_BY_LAYOUT = {
+    ("uint8", 1): L.PIXEL_U8, ("float32", 1): L.PIXEL_F32,
+    ("uint8", 3): L.PIXEL_RGB_U8, ("uint8", 4): L.PIXEL_RGBA_U8,
+    ("float32", 3): L.PIXEL_RGB_F32, ("float32", 4): L.PIXEL_RGBA_F32,
+}
+
+
+def _is_torch(a) -> bool:
+    return torch is not None and isinstance(a, torch.Tensor)
+
+
+def _f32_array(values) -> Tuple[np.ndarray, "C._Pointer"]:
+    a = np.ascontiguousarray(values, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Image:
+    """Image(T): rows, cols, stride (pixels) and a pixel buffer, on the host or on the device."""
+
+    def __init__(self, data):
+        if _is_torch(data):
+            if not data.is_cuda:
+                raise ValueError("torch tensors are accepted as device memory only; pass numpy for host pixels")
+            dtype = str(data.dtype).replace("torch.", "")
+            itemsize = data.element_size()
+            strides = tuple(s * itemsize for s in data.stride())
+        else:
+            data = np.asarray(data)
+            dtype = data.dtype.name
+            itemsize = data.itemsize
+            strides = data.strides
+        if data.ndim not in (2, 3):
+            raise ValueError("expected (rows, cols) or (rows, cols, channels)")
+        ch = 1 if data.ndim == 2 else int(data.shape[2])
+        key = (dtype, ch)
+        if key not in _PIXEL_BY_LAYOUT:
+            raise TypeError(f"unsupported pixel layout {dtype} x {ch}")
+        self.data = data
+        self.pixel = _PIXEL_BY_LAYOUT[key]
+        self.rows, self.cols = int(data.shape[0]), int(data.shape[1])
+        psize = itemsize * ch
+        if data.ndim == 3 and ch > 1 and strides[2] != itemsize:
+            raise ValueError("the channel axis must be contiguous")
+        if self.rows and self.cols:
+            if strides[1] != psize or strides[0] % psize:
+                raise ValueError("pixels of a row must be contiguous and rows pixel-aligned")
+            self.stride = strides[0] // psize if self.rows > 1 else max(self.cols, strides[0] // psize)
+        else:
+            self.stride = self.cols
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    @property
+    def on_device(self) -> bool:
+        return _is_torch(self.data)
+
+    @property
+    def shape(self):
+        return tuple(self.data.shape)
+
+    def _desc(self) -> L.ZgImage:
+        ptr = self.data.data_ptr() if self.on_device else self.data.ctypes.data
+        return L.ZgImage(ptr, self.stride, self.rows, self.cols, self.pixel)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _like(self, rows: Optional[int] = None, cols: Optional[int] = None, dtype=None, channels=None) -> "Image":
+        rows = self.rows if rows is None else rows
+        cols = self.cols if cols is None else cols
+        if channels is None:
+            shape = (rows, cols) + tuple(self.data.shape[2:])
+        else:
+            shape = (rows, cols) if channels == 1 else (rows, cols, channels)
+        if self.on_device:
+            return Image(torch.empty(shape, dtype=dtype or self.data.dtype, device=self.data.device))
+        return Image(np.empty(shape, dtype or self.data.dtype))
+
+    def _call(self, name: str, *args):
+        """Run zg_<name> (device) or zg_<name>_host (host) with the stream appended as needed."""
+        lib = L.lib()
+        if self.on_device:
+            L.check(getattr(lib, f"zg_{name}")(*args, self._stream()))
+        else:
+            L.check(getattr(lib, f"zg_{name}_host")(*args))
+
+    def _same_side(self, other: "Image"):
+        if self.on_device != other.on_device:
+            raise ValueError("source and destination must both be host or both be device images")
+
+    @staticmethod
+    def _wrap(x) -> "Image":
+        return x if isinstance(x, Image) else Image(x)
+
+    def to_numpy(self) -> np.ndarray:
+        return self.data.cpu().numpy() if self.on_device else self.data
+
+    @staticmethod
+    def from_numpy(a) -> "Image":
+        return Image(np.asarray(a))
+
+    def to_device(self, device="cuda") -> "Image":
+        if self.on_device:
+            return self
+        return Image(torch.from_numpy(np.ascontiguousarray(self.data)).to(device))
+
+    # ---- container ops (reference src/image.zig:304-392) -------------------------------------
+    def has_same_shape(self, other: "Image") -> bool:
+        return self.rows == other.rows and self.cols == other.cols
+
+    def is_contiguous(self) -> bool:
+        return self.cols == self.stride
+
+    def view(self, rect: Sequence[int]) -> "Image":
+        """Image.view (image.zig:332-352): rect = (l, t, r, b), clipped; shares memory."""
+        l, t, r, b = (int(v) for v in rect)
+        l, t, r, b = max(l, 0), max(t, 0), min(r, self.cols), min(b, self.rows)
+        if l >= r or t >= b:
+            return Image(self.data[0:0, 0:0])
+        return Image(self.data[t:b, l:r])
+
+    def copy(self, dst: Optional["Image"] = None) -> "Image":
+        dst = self._like() if dst is None else self._wrap(dst)
+        self._same_side(dst)
+        if not self.has_same_shape(dst):
+            raise L.DimensionMismatch(L.ERR_DIMENSION_MISMATCH, "copy: shapes differ")
+        if self.on_device:
+            s, d = self._desc(), dst._desc()
+            L.check(L.lib().zg_copy(C.byref(s), C.byref(d), self._stream()))
+        else:
+            dst.data[...] = self.data
+        return dst
+
+    # ---- filters ----------------------------------------------------------------------------
+    def convolve_separable(self, kernel_x, kernel_y, border: int = BorderMode.mirror,
+                           out: Optional["Image"] = None) -> "Image":
+        """Image.convolveSeparable (image.zig:935-951)."""
+        out = self._like() if out is None else self._wrap(out)
+        self._same_side(out)
+        kx, kxp = _f32_array(kernel_x)
+        ky, kyp = _f32_array(kernel_y)
+        s, d = self._desc(), out._desc()
+        self._call("conv_separable", C.byref(s), C.byref(d), kxp, len(kx), kyp, len(ky), int(border))
+        return out
+
+    def gaussian_blur(self, sigma: float, out: Optional["Image"] = None) -> "Image":
+        """Image.gaussianBlur (image.zig:954-994): sigma 0 copies, sigma < 0 raises InvalidArgument."""
+        out = self._like() if out is None else self._wrap(out)
+        self._same_side(out)
+        s, d = self._desc(), out._desc()
+        self._call("gaussian_blur", C.byref(s), C.byref(d), C.c_float(sigma))
+        return out
+
+    def convolve(self, kernel, border: int = BorderMode.mirror, out: Optional["Image"] = None) -> "Image":
+        """Image.convolve (image.zig:917-932); kernel is a 2-D array."""
+        out = self._like() if out is None else self._wrap(out)
+        self._same_side(out)
+        k, kp = _f32_array(kernel)
+        if k.ndim != 2:
+            raise ValueError("Kernel must be a 2D array")
+        s, d = self._desc(), out._desc()
+        self._call("convolve", C.byref(s), C.byref(d), kp, k.shape[0], k.shape[1], int(border))
+        return out
+
+    def box_blur(self, radius: int, out: Optional["Image"] = None) -> "Image":
+        """Image.boxBlur (image.zig:635-648)."""
+        out = self._like() if out is None else self._wrap(out)
+        self._same_side(out)
+        s, d = self._desc(), out._desc()
+        self._call("box_blur", C.byref(s), C.byref(d), int(radius))
+        return out
+
+    # ---- resampling -------------------------------------------------------------------------
+    def resize(self, size_or_out, method: Interpolation = Interpolation.bilinear) -> "Image":
+        """Image.resize (image.zig:523): `size_or_out` is (rows, cols) or a pre-allocated Image."""
+        out = size_or_out if isinstance(size_or_out, Image) else self._like(int(size_or_out[0]), int(size_or_out[1]))
+        self._same_side(out)
+        s, d, m = self._desc(), out._desc(), method._c()
+        self._call("resize", C.byref(s), C.byref(d), C.byref(m))
+        return out
+
+    def scale(self, factor: float, method: Interpolation = Interpolation.bilinear) -> "Image":
+        """Image.scale (image.zig:530-541): InvalidScaleFactor / InvalidDimensions as InvalidArgument."""
+        if factor <= 0:
+            raise L.InvalidArgument(L.ERR_INVALID_ARGUMENT, "InvalidScaleFactor")
+        f = np.float32(factor)
+        new_rows = int(_round_half_away(np.float32(self.rows) * f))
+        new_cols = int(_round_half_away(np.float32(self.cols) * f))
+        if new_rows == 0 or new_cols == 0:
+            raise L.InvalidArgument(L.ERR_INVALID_ARGUMENT, "InvalidDimensions")
+        return self.resize((new_rows, new_cols), method)
+
+    def letterbox(self, size_or_out, method: Interpolation = Interpolation.bilinear):
+        """Image.letterbox (image.zig:546): returns (image, content_rect(l, t, r, b))."""
+        out = size_or_out if isinstance(size_or_out, Image) else self._like(int(size_or_out[0]), int(size_or_out[1]))
+        self._same_side(out)
+        rect = (C.c_uint32 * 4)()
+        s, d, m = self._desc(), out._desc(), method._c()
+        self._call("letterbox", C.byref(s), C.byref(d), C.byref(m), rect)
+        return out, tuple(rect)
+
+    def warp(self, transform, shape_or_out=None, method: Interpolation = Interpolation.bilinear) -> "Image":
+        """Image.warp (image.zig:621): `transform` exposes .kind and .coefficients()."""
+        if shape_or_out is None:
+            out = self._like()
+        elif isinstance(shape_or_out, Image):
+            out = shape_or_out
+        else:
+            out = self._like(int(shape_or_out[0]), int(shape_or_out[1]))
+        self._same_side(out)
+        coef, cp = _f32_array(transform.coefficients())
+        s, d, m = self._desc(), out._desc(), method._c()
+        self._call("warp", C.byref(s), C.byref(d), int(transform.kind), cp, C.byref(m))
+        return out
+
+    def rotate_bounds(self, angle: float, cos_sin: Optional[Tuple[float, float]] = None) -> Tuple[int, int]:
+        """Image.rotateBounds (transforms.zig:112-148) -> (rows, cols)."""
+        ca, sa = cos_sin if cos_sin is not None else _cos_sin(angle)
+        r, c = C.c_uint32(), C.c_uint32()
+        L.check(L.lib().zg_rotate_bounds(self.rows, self.cols, C.c_float(angle), C.c_float(ca), C.c_float(sa),
+                                         C.byref(r), C.byref(c)))
+        return r.value, c.value
+
+    def rotate_into(self, out: "Image", angle: float, method: Interpolation = Interpolation.bilinear,
+                    border: int = BorderMode.zero, cos_sin: Optional[Tuple[float, float]] = None) -> "Image":
+        """Image.rotateInto (image.zig:566)."""
+        self._same_side(out)
+        ca, sa = cos_sin if cos_sin is not None else _cos_sin(angle)
+        s, d, m = self._desc(), out._desc(), method._c()
+        self._call("rotate_into", C.byref(s), C.byref(d), C.c_float(angle), C.c_float(ca), C.c_float(sa),
+                   C.byref(m), int(border))
+        return out
+
+    def rotate(self, angle: float, method: Interpolation = Interpolation.bilinear,
+               border: int = BorderMode.zero, cos_sin: Optional[Tuple[float, float]] = None) -> "Image":
+        """Image.rotate (image.zig:558): new image sized by rotateBounds."""
+        rows, cols = self.rotate_bounds(angle, cos_sin)
+        return self.rotate_into(self._like(rows, cols), angle, method, border, cos_sin)
+
+    def extract(self, rect: Sequence[float], angle: float = 0.0, size_or_out=None,
+                method: Interpolation = Interpolation.bilinear, border: int = BorderMode.zero,
+                cos_sin: Optional[Tuple[float, float]] = None) -> "Image":
+        """Image.extract (image.zig:593); rect = (l, t, r, b) in source coordinates."""
+        if size_or_out is None:
+            l, t, r, b = rect
+            out = self._like(int(_round_half_away(b - t)), int(_round_half_away(r - l)))
+        elif isinstance(size_or_out, Image):
+            out = size_or_out
+        else:
+            out = self._like(int(size_or_out[0]), int(size_or_out[1]))
+        self._same_side(out)
+        ca, sa = cos_sin if cos_sin is not None else _cos_sin(angle)
+        ra, rp = _f32_array(rect)
+        s, d, m = self._desc(), out._desc(), method._c()
+        self._call("extract", C.byref(s), C.byref(d), rp, C.c_float(angle), C.c_float(ca), C.c_float(sa),
+                   C.byref(m), int(border))
+        return out
+
+    def crop(self, rect: Sequence[float]) -> "Image":
+        """Image.crop (image.zig:582): rounded size, out-of-bounds zero filled, bit-exact copy."""
+        ra, rp = _f32_array(rect)
+        r, c = C.c_uint32(), C.c_uint32()
+        L.check(L.lib().zg_crop_dims(rp, C.byref(r), C.byref(c)))
+        out = self._like(r.value, c.value)
+        s, d = self._desc(), out._desc()
+        self._call("crop", C.byref(s), C.byref(d), rp)
+        return out
+
+    def insert(self, source: "Image", rect: Sequence[float], angle: float = 0.0,
+               method: Interpolation = Interpolation.bilinear, blend_mode: int = Blending.none,
+               cos_sin: Optional[Tuple[float, float]] = None) -> "Image":
+        """Image.insert (image.zig:606): mutates self in place."""
+        source = self._wrap(source)
+        self._same_side(source)
+        ca, sa = cos_sin if cos_sin is not None else _cos_sin(angle)
+        ra, rp = _f32_array(rect)
+        s, d, m = self._desc(), source._desc(), method._c()
+        self._call("insert", C.byref(s), C.byref(d), rp, C.c_float(angle), C.c_float(ca), C.c_float(sa),
+                   C.byref(m), int(blend_mode))
+        return self
+
+    def flip_left_right(self) -> "Image":
+        """Image.flipLeftRight (transforms.zig:28-33), in place."""
+        s = self._desc()
+        self._call("flip_left_right", C.byref(s))
+        return self
+
+    def flip_top_bottom(self) -> "Image":
+        """Image.flipTopBottom (transforms.zig:36-44), in place."""
+        s = self._desc()
+        self._call("flip_top_bottom", C.byref(s))
+        return self
+
+    # ---- colour -----------------------------------------------------------------------------
+    def convert(self, dst_space: int, dtype=np.float32, src_space: Optional[int] = None,
+                out: Optional["Image"] = None, srgb_lut=None) -> "Image":
+        """Image.convert (image.zig:418): e.g. rgba_u8.convert(CS_OKLAB, np.float32)."""
+        if src_space is None:
+            src_space = {1: L.CS_GRAY, 3: L.CS_RGB, 4: L.CS_RGBA}[1 if self.data.ndim == 2 else self.data.shape[2]]
+        ch = {L.CS_GRAY: 1, L.CS_RGB: 3, L.CS_RGBA: 4, L.CS_OKLAB: 3, L.CS_XYZ: 3, L.CS_YCBCR: 3}[dst_space]
+        if out is None:
+            if self.on_device:
+                tdtype = {np.uint8: torch.uint8, np.float32: torch.float32}[np.dtype(dtype).type]
+                out = self._like(dtype=tdtype, channels=ch)
+            else:
+                out = self._like(dtype=np.dtype(dtype), channels=ch)
+        self._same_side(out)
+        lut = None
+        if srgb_lut is not None:
+            _keep, lut = _f32_array(srgb_lut)
+        s, d = self._desc(), out._desc()
+        self._call("convert", C.byref(s), int(src_space), C.byref(d), int(dst_space), lut)
+        return out
+
+
+def _round_half_away(v) -> float:
+    v = float(v)
+    return math.floor(abs(v) + 0.5) * (1.0 if v >= 0 else -1.0)
+
+
+def _cos_sin(angle: float) -> Tuple[float, float]:
+    """cos/sin in f32 as the caller's maths library gives them (numpy here; Zig's @cos/@sin in the
+    Zig shim). Passed explicitly so the kernels never depend on a device libm."""
+    a = np.float32(angle)
+    return float(np.cos(a, dtype=np.float32)), float(np.sin(a, dtype=np.float32))
+
+
+def gaussian_kernel(sigma: float) -> np.ndarray:
+    """The taps Image.gaussianBlur builds (image.zig:973-990)."""
+    lib = L.lib()
+    n = lib.zg_gaussian_kernel(C.c_float(sigma), None, 0)
+    if n < 0:
+        L.check(-n)
+    out = np.empty(n, np.float32)
+    lib.zg_gaussian_kernel(C.c_float(sigma), out.ctypes.data_as(C.POINTER(C.c_float)), n)
+    return out
+
+
+class ProjectiveTransform:
+    """reference src/geometry/transforms.zig:197-231 (f32 matrix, project = M [x y 1]^T scaled by 1/w)."""
+    kind = L.TRANSFORM_PROJECTIVE
+
+    def __init__(self, matrix):
+        self.matrix = np.asarray(matrix, np.float32).reshape(3, 3)
+
+    def coefficients(self):
+        return self.matrix.reshape(9)
+
+
+class AffineTransform:
+    """reference src/geometry/transforms.zig:118-150 (2x2 matrix + bias)."""
+    kind = L.TRANSFORM_AFFINE
+
+    def __init__(self, matrix, bias):
+        self.matrix = np.asarray(matrix, np.float32).reshape(2, 2)
+        self.bias = np.asarray(bias, np.float32).reshape(2)
+
+    def coefficients(self):
+        return np.concatenate([self.matrix.reshape(4), self.bias])
+
+
+class SimilarityTransform(AffineTransform):
+    """reference src/geometry/transforms.zig:10-42"""
+    kind = L.TRANSFORM_SIMILARITY
