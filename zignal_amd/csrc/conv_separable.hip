@@ -93,22 +93,89 @@ __global__ __launch_bounds__(256) void k_sep_fused(DImg src, DImg dst, TapsArg<N
 
     __shared__ Vec tile[LH * LW];
 
-    const int tile_id = blockIdx.x;
+    // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (each XCD has a private L2), so give
+    // every XCD a contiguous run of tiles; neighbouring tiles then share their halo lines in one L2.
+    const int nblk = gridDim.x;
+    const int per_xcd = nblk >> 3;
+    int tile_id = blockIdx.x;
+    if (tile_id < (per_xcd << 3)) tile_id = (tile_id & 7) * per_xcd + (tile_id >> 3);
     const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
     const int x0 = tx * TW, y0 = ty * TH;
 
-    for (int i = threadIdx.x; i < LH * LW; i += 256) {
-        const int r = i / LW, c = i - r * LW;
-        const int gr = resolve_index(y0 - H + r, src.rows, border);
-        const int gc = resolve_index(x0 - H + c, src.cols, border);
-        Vec v = P::zero();
-        if (gr >= 0 && gc >= 0) v = P::load(src.data, (size_t)gr * src.stride + (size_t)gc);
-        tile[i] = v;
+    const int lx = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+
+    // Stage the (TH+2H) x (TW+2H) source tile in LDS, border already resolved. Every global load is issued
+    // before the first LDS write so each lane keeps RW+EX 16-byte loads in flight (memory-level parallelism
+    // is what bounds this kernel, not arithmetic). Tiles whose halo lies inside the image (all but the
+    // frame's rim) take a branch-free path with no index resolution at all.
+    {
+        constexpr int RW = (LH + 3) / 4;                  // tile rows per wave, rows interleaved by wave
+        constexpr int NEXTRA = LH * 2 * H;                // halo columns TW .. TW+2H-1 of every row
+        constexpr int EX = (NEXTRA + 255) / 256;
+        Vec main_v[RW];
+        Vec extra_v[EX > 0 ? EX : 1];
+        const bool inside = x0 - H >= 0 && x0 + TW + H <= src.cols && y0 - H >= 0 && y0 + TH + H <= src.rows;
+        if (inside) {
+            const size_t base = (size_t)(y0 - H) * src.stride + (size_t)(x0 - H);
+#pragma unroll
+            for (int k = 0; k < RW; ++k) {
+                const int r = wave + 4 * k;
+                if (r < LH) main_v[k] = P::load(src.data, base + (size_t)r * src.stride + (size_t)lx);
+            }
+            if constexpr (H > 0) {
+#pragma unroll
+                for (int k = 0; k < EX; ++k) {
+                    const int e = (int)threadIdx.x + 256 * k;
+                    if (e < NEXTRA) {
+                        const int r = e / (2 * H), c = TW + e - r * (2 * H);
+                        extra_v[k] = P::load(src.data, base + (size_t)r * src.stride + (size_t)c);
+                    }
+                }
+            }
+        } else {
+            const int gc_main = resolve_index(x0 - H + lx, src.cols, border);
+#pragma unroll
+            for (int k = 0; k < RW; ++k) {
+                const int r = wave + 4 * k;
+                main_v[k] = P::zero();
+                if (r < LH) {
+                    const int gr = resolve_index(y0 - H + r, src.rows, border); // wave-uniform
+                    if (gr >= 0 && gc_main >= 0) main_v[k] = P::load(src.data, (size_t)gr * src.stride + (size_t)gc_main);
+                }
+            }
+            if constexpr (H > 0) {
+#pragma unroll
+                for (int k = 0; k < EX; ++k) {
+                    const int e = (int)threadIdx.x + 256 * k;
+                    extra_v[k] = P::zero();
+                    if (e < NEXTRA) {
+                        const int r = e / (2 * H), c = TW + e - r * (2 * H);
+                        const int gr = resolve_index(y0 - H + r, src.rows, border);
+                        const int gc = resolve_index(x0 - H + c, src.cols, border);
+                        if (gr >= 0 && gc >= 0) extra_v[k] = P::load(src.data, (size_t)gr * src.stride + (size_t)gc);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RW; ++k) {
+            const int r = wave + 4 * k;
+            if (r < LH) tile[r * LW + lx] = main_v[k];
+        }
+        if constexpr (H > 0) {
+#pragma unroll
+            for (int k = 0; k < EX; ++k) {
+                const int e = (int)threadIdx.x + 256 * k;
+                if (e < NEXTRA) {
+                    const int r = e / (2 * H), c = TW + e - r * (2 * H);
+                    tile[r * LW + c] = extra_v[k];
+                }
+            }
+        }
     }
     __syncthreads();
 
-    const int lx = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
     const int gx = x0 + lx;
     const bool col_interior = (src.cols > 2 * H) && gx >= H && gx < src.cols - H;
     const bool rows_have_interior = src.rows > 2 * H;
