@@ -39,9 +39,12 @@ METRIC = "Mpixels/s (and % HBM roofline), 5x5 blur + bilinear resize, 4K RGBA"
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # the GPU's power management needs a few ms of sustained load to settle (kernel time drifts 90 -> 117 -> 87 us
+    # over the first ~25 ms, profiles/r01_blur_rgba_f32_kernel_series.txt), hence the long default warm-up
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--ring", type=int, default=4, help="distinct (src, dst) frame pairs to rotate through")
+    ap.add_argument("--eager", action="store_true", help="launch every step from Python instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     return ap.parse_args()
@@ -116,12 +119,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
+    # The launch-bound inner loop is captured once into a HIP graph (`ring` launches, one per ring slot) and
+    # replayed; each replayed launch is still one frame through the hot path, and exactly `steps` of them are timed.
+    graph = None
+    side = torch.cuda.Stream()
+    chunk = 0
+    for cand in (25 * ring, 10 * ring, 5 * ring, ring):  # launches per graph: long enough to hide the ~11 us replay gap
+        if args.steps % cand == 0:
+            chunk = cand
+            break
+    if not args.eager and chunk:
+        try:
+            with torch.cuda.stream(side):
+                for i in range(ring):
+                    step(i)
+                side.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    for i in range(chunk):
+                        step(i)
+        except Exception as e:  # capture is an optimisation; eager launches are always valid
+            print(f"[bench] graph capture failed ({e}); falling back to eager launches", file=sys.stderr)
+            graph = None
+
+    def run(n_steps):
+        if graph is not None:
+            for _ in range(n_steps // chunk):
+                graph.replay()
+        else:
+            for i in range(n_steps):
+                step(i)
+
+    run(max(chunk, args.warmup - args.warmup % chunk) if graph is not None else args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -138,13 +170,14 @@ def main():
         "config": {"workload": "gaussianBlur(sigma=0.6): 5x5 separable Gaussian, mirror border, 4096x4096 RGBA f32 "
                                "(BASELINE.json configs[1]); one frame per step per GPU, frames resident in HBM",
                    "frame": [ROWS, COLS, 4], "ring_bytes": ring_bytes, "frames_per_step_per_gpu": 1,
+                   "launch": f"hipGraph replay, {chunk} launches per graph" if graph is not None else "eager",
                    "parallelism": f"frame-sharded x{world}, no data-path collective"},
     }
 
     if rank == 0 and world == 1:
         # per-launch kernel time: HIP events on the launch stream (torch's current stream is the stream handed
         # to zg_gaussian_blur), one pair per launch
-        n = min(args.steps, 100)
+        n = min(args.steps, 200)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
         for i, (a, b) in enumerate(evs):
             a.record()

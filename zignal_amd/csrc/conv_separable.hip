@@ -30,6 +30,10 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #pragma clang fp contract(off)
@@ -74,49 +78,32 @@ template <int MODE, typename TapsT> __device__ inline auto tap(const TapsT &t, i
     if constexpr (MODE == MODE_F32) return t.f[i]; else return t.i[i];
 }
 
-constexpr int TW = 64;  // tile width  = one wavefront of columns
-constexpr int TH = 32;  // tile height = 4 waves x 8 rows
-constexpr int RPT = 8;  // rows per thread
+constexpr int TW = 64;  // tile width = one wavefront of columns; tile height = 4 waves x RPT rows
 
-template <int PIX, int NK, int MODE, bool SKIP>
-__global__ __launch_bounds__(256) void k_sep_fused(DImg src, DImg dst, TapsArg<NK> kx, TapsArg<NK> ky,
-                                                   int border, uint32_t skipx, uint32_t skipy, int tiles_x) {
+// Tuning variant (A/B on hardware through ZG_SEP_VARIANT; the default is what measured best):
+//   RPT      output rows per thread (tile height = 4 * RPT)
+//   PERSIST  persistent workgroups that prefetch tile t+1 into registers while convolving tile t
+//   NT       non-temporal stores for the output
+struct SepVariant { int rpt; bool persist; bool nt; };
+
+// Tile staging shared by the persistent kernel: load one (TH+2H) x (TW+2H) source tile into registers
+// (every load issued back to back), and later spill those registers to LDS.
+template <int PIX, int NK, int RPT> struct TileStage {
     using P = Px<PIX>;
     using Vec = typename P::Vec;
-    using A = Arith<MODE>;
-    using Temp = typename A::Temp;
-    using Acc = typename A::Acc;
-    constexpr int C = P::C;
-    constexpr int H = NK / 2;
-    constexpr int LW = TW + 2 * H;
-    constexpr int LH = TH + 2 * H;
+    static constexpr int H = NK / 2;
+    static constexpr int TH = 4 * RPT;
+    static constexpr int LW = TW + 2 * H;
+    static constexpr int LH = TH + 2 * H;
+    static constexpr int RW = (LH + 3) / 4;          // tile rows per wave, interleaved by wave
+    static constexpr int NEXTRA = LH * 2 * H;        // halo columns TW .. TW+2H-1 of every row
+    static constexpr int EX = (NEXTRA + 255) / 256;
+    Vec main_v[RW];
+    Vec extra_v[EX > 0 ? EX : 1];
 
-    __shared__ Vec tile[LH * LW];
-
-    // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (each XCD has a private L2), so give
-    // every XCD a contiguous run of tiles; neighbouring tiles then share their halo lines in one L2.
-    const int nblk = gridDim.x;
-    const int per_xcd = nblk >> 3;
-    int tile_id = blockIdx.x;
-    if (tile_id < (per_xcd << 3)) tile_id = (tile_id & 7) * per_xcd + (tile_id >> 3);
-    const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
-    const int x0 = tx * TW, y0 = ty * TH;
-
-    const int lx = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-
-    // Stage the (TH+2H) x (TW+2H) source tile in LDS, border already resolved. Every global load is issued
-    // before the first LDS write so each lane keeps RW+EX 16-byte loads in flight (memory-level parallelism
-    // is what bounds this kernel, not arithmetic). Tiles whose halo lies inside the image (all but the
-    // frame's rim) take a branch-free path with no index resolution at all.
-    {
-        constexpr int RW = (LH + 3) / 4;                  // tile rows per wave, rows interleaved by wave
-        constexpr int NEXTRA = LH * 2 * H;                // halo columns TW .. TW+2H-1 of every row
-        constexpr int EX = (NEXTRA + 255) / 256;
-        Vec main_v[RW];
-        Vec extra_v[EX > 0 ? EX : 1];
+    __device__ void load(const DImg &src, int x0, int y0, int border, int lx, int wave) {
         const bool inside = x0 - H >= 0 && x0 + TW + H <= src.cols && y0 - H >= 0 && y0 + TH + H <= src.rows;
-        if (inside) {
+        if (inside) { // all but the frame's rim: no index resolution at all
             const size_t base = (size_t)(y0 - H) * src.stride + (size_t)(x0 - H);
 #pragma unroll
             for (int k = 0; k < RW; ++k) {
@@ -158,6 +145,9 @@ __global__ __launch_bounds__(256) void k_sep_fused(DImg src, DImg dst, TapsArg<N
                 }
             }
         }
+    }
+
+    __device__ void spill(Vec *tile, int lx, int wave) const {
 #pragma unroll
         for (int k = 0; k < RW; ++k) {
             const int r = wave + 4 * k;
@@ -174,7 +164,61 @@ __global__ __launch_bounds__(256) void k_sep_fused(DImg src, DImg dst, TapsArg<N
             }
         }
     }
-    __syncthreads();
+};
+
+// Row-clipped pixel store. The row's buffer descriptor (wave-uniform, SGPRs) carries the row length, so the
+// hardware drops lanes that fall outside the image and the store needs no branch. Unconditional stores let
+// the compiler count them exactly in s_waitcnt, which is what keeps the next tile's loads from being
+// serialised behind this tile's stores (gfx9 has one vmcnt for loads and stores).
+template <int PIX, bool NT> struct RowStore {
+    using P = Px<PIX>;
+    using Vec = typename P::Vec;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    __device__ static void store(const DImg &dst, int gy, int gx, Vec v) {
+        const bool row_ok = gy >= 0 && gy < dst.rows;
+        char *row = (char *)dst.data + (row_ok ? (size_t)gy * dst.stride * P::BYTES : (size_t)0);
+        const int bytes = row_ok ? dst.cols * P::BYTES : 0;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)row, (short)0, bytes, 0x00020000);
+        const int off = gx * P::BYTES;
+        constexpr int AUX = NT ? 2 : 0; // bit 1 = nt (streaming): the output is never re-read by this kernel
+        if constexpr (P::BYTES == 16) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, AUX);
+        } else if constexpr (P::BYTES == 12) {
+            const float e0 = v[0], e1 = v[1], e2 = v[2];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e0), rsrc, off, 0, AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e1), rsrc, off + 4, 0, AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e2), rsrc, off + 8, 0, AUX);
+        } else if constexpr (P::BYTES == 4) {
+            if constexpr (std::is_same<typename P::Elem, float>::value) {
+                const float e0 = v[0];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e0), rsrc, off, 0, AUX);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rsrc, off, 0, AUX);
+            }
+        } else if constexpr (P::BYTES == 3) {
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v[0], rsrc, off, 0, AUX);
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v[1], rsrc, off + 1, 0, AUX);
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v[2], rsrc, off + 2, 0, AUX);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v[0], rsrc, off, 0, AUX);
+        }
+    }
+};
+
+// Convolve one staged tile out of LDS: row pass into a register sliding window of NK temps, column pass
+// from the window, one row-clipped store per output row.
+template <int PIX, int NK, int MODE, bool SKIP, int RPT, bool NT>
+__device__ __forceinline__ void convolve_tile(const typename Px<PIX>::Vec *tile, const DImg &src, const DImg &dst,
+                                              const TapsArg<NK> &kx, const TapsArg<NK> &ky, uint32_t skipx,
+                                              uint32_t skipy, int x0, int y0, int lx, int wave) {
+    using P = Px<PIX>;
+    using Vec = typename P::Vec;
+    using A = Arith<MODE>;
+    using Temp = typename A::Temp;
+    using Acc = typename A::Acc;
+    constexpr int C = P::C;
+    constexpr int H = NK / 2;
+    constexpr int LW = TW + 2 * H;
 
     const int gx = x0 + lx;
     const bool col_interior = (src.cols > 2 * H) && gx >= H && gx < src.cols - H;
@@ -211,16 +255,73 @@ __global__ __launch_bounds__(256) void k_sep_fused(DImg src, DImg dst, TapsArg<N
                 for (int ch = 0; ch < C; ++ch)
                     out[ch] = A::mac(out[ch], win[(j + 1 + i) % NK][ch], tap<MODE>(ky, i));
             }
-            if (gx < dst.cols && gy < dst.rows) {
-                Vec o;
+            Vec o;
 #pragma unroll
-                for (int ch = 0; ch < C; ++ch) {
-                    if constexpr (MODE == MODE_F32) o[ch] = out[ch];
-                    else o[ch] = div_clamp_u8_sq<Acc>(out[ch]);
-                }
-                P::store(dst.data, (size_t)gy * dst.stride + (size_t)gx, o);
+            for (int ch = 0; ch < C; ++ch) {
+                if constexpr (MODE == MODE_F32) o[ch] = out[ch];
+                else o[ch] = div_clamp_u8_sq<Acc>(out[ch]);
             }
+            RowStore<PIX, NT>::store(dst, gy, gx, o);
         }
+    }
+}
+
+// Persistent, software-pipelined fused kernel. Each workgroup owns a contiguous run of tiles; while it
+// convolves tile t out of LDS, the global loads of tile t+1 are already in flight into registers, so a CU
+// never drains its memory queue between tiles. grid = min(#tiles, resident workgroups).
+template <int PIX, int NK, int MODE, bool SKIP, int RPT, bool PERSIST, bool NT>
+__global__ __launch_bounds__(256) void k_sep_fused(DImg src, DImg dst, TapsArg<NK> kx, TapsArg<NK> ky,
+                                                   int border, uint32_t skipx, uint32_t skipy, int tiles_x,
+                                                   int n_tiles) {
+    using P = Px<PIX>;
+    using Vec = typename P::Vec;
+    using Stage = TileStage<PIX, NK, RPT>;
+    constexpr int TH = Stage::TH;
+
+    __shared__ Vec tile[Stage::LH * Stage::LW];
+
+    const int lx = threadIdx.x & 63;
+    // wave-uniform by construction; readfirstlane tells the compiler, so row indices, bounds tests and the
+    // store descriptors live in SGPRs (otherwise hipcc wraps every buffer store in a waterfall loop)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+
+    // Workgroup b sits on XCD b % 8 (private L2 per XCD): number the workgroups XCD-major so that each XCD
+    // sweeps one contiguous band of the image and neighbouring tiles (which share halo lines) hit the same L2.
+    const int nwg = gridDim.x;
+    const int per_xcd = nwg >> 3;
+    int wg = blockIdx.x;
+    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+
+    Stage st;
+    if constexpr (!PERSIST) { // one tile per workgroup; the hardware dispatcher overlaps load and compute phases
+        const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
+        st.load(src, tx * TW, ty * TH, border, lx, wave);
+        st.spill(tile, lx, wave);
+        __syncthreads();
+        convolve_tile<PIX, NK, MODE, SKIP, RPT, NT>(tile, src, dst, kx, ky, skipx, skipy, tx * TW, ty * TH, lx, wave);
+    } else {
+        // Tiles [t_begin, t_end) of this workgroup; tile t+1 is prefetched into registers while tile t is convolved.
+        const int t_begin = (int)(((long long)n_tiles * wg) / nwg);
+        const int t_end = (int)(((long long)n_tiles * (wg + 1)) / nwg);
+        if (t_begin >= t_end) return;
+        int ty = t_begin / tiles_x, tx = t_begin - ty * tiles_x;
+        st.load(src, tx * TW, ty * TH, border, lx, wave);
+        st.spill(tile, lx, wave);
+        __syncthreads();
+        // Steady state, straight-line per iteration: [loads of t+1] [convolve t: LDS reads, NK-row window, stores]
+        // [barrier] [spill t+1 -> LDS] [barrier]. The spill waits on the loads only (vmcnt = #stores behind them).
+        for (int t = t_begin; t + 1 < t_end; ++t) {
+            int ny = ty, nx = tx + 1;
+            if (nx == tiles_x) { nx = 0; ++ny; }
+            st.load(src, nx * TW, ny * TH, border, lx, wave);
+            convolve_tile<PIX, NK, MODE, SKIP, RPT, NT>(tile, src, dst, kx, ky, skipx, skipy, tx * TW, ty * TH, lx, wave);
+            __syncthreads(); // every wave is done reading tile t
+            st.spill(tile, lx, wave);
+            __syncthreads();
+            tx = nx;
+            ty = ny;
+        }
+        convolve_tile<PIX, NK, MODE, SKIP, RPT, NT>(tile, src, dst, kx, ky, skipx, skipy, tx * TW, ty * TH, lx, wave);
     }
 }
 
@@ -308,23 +409,79 @@ struct SepPlan {
     int mode = MODE_F32;
 };
 
-template <int PIX, int NK, int MODE, bool SKIP>
-static int launch_fused(const zg_image *src, const zg_image *dst, const SepPlan &p, int border, hipStream_t s) {
+// Workgroups that are resident at once for `kernel` (256 threads, static LDS): CUs x blocks per CU, cached.
+static int persistent_grid(const void *kernel) {
+    static std::mutex mu;
+    static std::unordered_map<const void *, int> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(kernel);
+    if (it != cache.end()) return it->second;
+    int dev = 0, cus = 256, per_cu = 1;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    const int grid = cus * std::min(per_cu, 8);
+    cache[kernel] = grid;
+    return grid;
+}
+
+static SepVariant sep_variant() {
+    static const SepVariant v = [] {
+        SepVariant d{8, false, false};
+        if (const char *e = getenv("ZG_SEP_VARIANT")) { // e.g. "8p" "4n" "8": rows per thread, p = persistent, n = nt stores
+            d.rpt = atoi(e);
+            d.persist = strchr(e, 'p') != nullptr;
+            d.nt = strchr(e, 'n') != nullptr;
+        }
+        return d;
+    }();
+    return v;
+}
+
+template <int PIX, int NK, int MODE, bool SKIP, int RPT, bool PERSIST, bool NT>
+static int launch_fused_v(const zg_image *src, const zg_image *dst, const SepPlan &p, int border, hipStream_t s) {
     TapsArg<NK> kx, ky;
     for (int i = 0; i < NK; ++i) {
         if constexpr (MODE == MODE_F32) { kx.f[i] = p.fx[i]; ky.f[i] = p.fy[i]; }
         else { kx.i[i] = p.ix[i]; ky.i[i] = p.iy[i]; }
     }
-    const int tiles_x = (int)ceil_div(src->cols, TW), tiles_y = (int)ceil_div(src->rows, TH);
-    hipLaunchKernelGGL((k_sep_fused<PIX, NK, MODE, SKIP>), dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s,
-                       dimg(src), dimg(dst), kx, ky, border, p.skipx, p.skipy, tiles_x);
+    const int tiles_x = (int)ceil_div(src->cols, TW), tiles_y = (int)ceil_div(src->rows, 4 * RPT);
+    const int n_tiles = tiles_x * tiles_y;
+    auto kernel = k_sep_fused<PIX, NK, MODE, SKIP, RPT, PERSIST, NT>;
+    const int grid = PERSIST ? std::min(n_tiles, persistent_grid((const void *)kernel)) : n_tiles;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), 0, s,
+                       dimg(src), dimg(dst), kx, ky, border, p.skipx, p.skipy, tiles_x, n_tiles);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
 
+template <int PIX, int NK, int MODE, bool SKIP>
+static int launch_fused(const zg_image *src, const zg_image *dst, const SepPlan &p, int border, hipStream_t s) {
+#ifdef ZG_SEP_TUNE
+    const SepVariant v = sep_variant();
+    if (NK == 5 && (PIX == ZG_PIXEL_RGBA_F32 || PIX == ZG_PIXEL_RGBA_U8) && !SKIP) {
+        if (v.rpt == 4 && !v.persist && !v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 4, false, false>(src, dst, p, border, s);
+        if (v.rpt == 4 && !v.persist && v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 4, false, true>(src, dst, p, border, s);
+        if (v.rpt == 4 && v.persist && !v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 4, true, false>(src, dst, p, border, s);
+        if (v.rpt == 8 && !v.persist && v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 8, false, true>(src, dst, p, border, s);
+        if (v.rpt == 8 && v.persist && !v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 8, true, false>(src, dst, p, border, s);
+        if (v.rpt == 8 && v.persist && v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 8, true, true>(src, dst, p, border, s);
+        if (v.rpt == 16 && !v.persist && !v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 16, false, false>(src, dst, p, border, s);
+        if (v.rpt == 16 && !v.persist && v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 16, false, true>(src, dst, p, border, s);
+        if (v.rpt == 2 && !v.persist && !v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 2, false, false>(src, dst, p, border, s);
+    }
+#endif
+    // measured on MI355X (profiles/r01_sep_variant_sweep.txt): 16-byte pixels like many small tiles (more
+    // workgroups per CU overlap each other's load and compute phases); every type likes streaming stores.
+    if constexpr (Px<PIX>::BYTES >= 12) return launch_fused_v<PIX, NK, MODE, SKIP, 4, false, true>(src, dst, p, border, s);
+    else return launch_fused_v<PIX, NK, MODE, SKIP, 8, false, true>(src, dst, p, border, s);
+}
+
 template <int PIX, int NK, int MODE>
 static int launch_fused_skip(const zg_image *src, const zg_image *dst, const SepPlan &p, int border, hipStream_t s) {
-    if (MODE == MODE_F32 && (p.skipx | p.skipy)) return launch_fused<PIX, NK, MODE, true>(src, dst, p, border, s);
+    if constexpr (MODE == MODE_F32) {
+        if (p.skipx | p.skipy) return launch_fused<PIX, NK, MODE, true>(src, dst, p, border, s);
+    }
     return launch_fused<PIX, NK, MODE, false>(src, dst, p, border, s);
 }
 
