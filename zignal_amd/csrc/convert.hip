@@ -1,0 +1,340 @@
+// convert.hip — Image(T).convertInto: per-pixel colour conversion.
+//
+// Replaces reference src/image.zig:396-407 (loop) and the parts of convertColor (src/color.zig:108-151) that
+// lie on the image hot path:
+//   Rgb/Rgba(u8|f32) -> Oklab(f32) / Xyz(f32)   color.zig:1252-1272 (gammaToLinear, rgbToXyz), :1381-1400 (xyzToOklab)
+//   Rgb/Rgba(u8|f32) -> u8 / f32 luminance        color.zig:1031-1047 (u8: BT.709 16.16 fixed point)
+//   Rgb <-> Rgba, u8 <-> f32 backing              color.zig:365-390, :484-512 (.as: /255 ; @round(255 * clamp))
+//   u8 / f32 scalar -> Rgb / Rgba (grey replicate) color.zig:121-131, :1050-1052
+//   Rgb/Rgba(u8) -> Ycbcr(u8)                     color.zig:987-1009 (BT.601 16.16 fixed point)
+//
+// Zig-std transcendentals are isolated: for u8 sources gammaToLinear has 256 possible arguments, so the kernel
+// reads a 256-entry host-supplied table (std.math.pow stays on the caller's side); cbrt (continuous argument)
+// is the musl cbrtf algorithm Zig ports — two Newton steps in f64, one final rounding — written out here.
+// For float-typed RGB sources gammaToLinear needs pow on the device: restated below (exp/log based, as Zig's
+// port of Go's Pow); like the oracle's it is parity-unpinned against real Zig at the last ulp.
+#include "zg_common.h"
+#include "zg_hostmath.h"
+
+#include <cmath>
+#include <mutex>
+
+#pragma clang fp contract(off)
+
+namespace zg {
+
+// ---- device maths -------------------------------------------------------------------------------------
+__device__ inline float dev_cbrtf(float x) { // Zig std.math.cbrt cbrt32 == musl cbrtf
+    const uint32_t B1 = 709958130u, B2 = 642849266u;
+    uint32_t u = __float_as_uint(x);
+    uint32_t hx = u & 0x7fffffffu;
+    if (hx >= 0x7f800000u) return x + x;
+    if (hx < 0x00800000u) {
+        if (hx == 0) return x;
+        u = __float_as_uint(x * 0x1p24f);
+        hx = u & 0x7fffffffu;
+        hx = hx / 3 + B2;
+    } else {
+        hx = hx / 3 + B1;
+    }
+    u &= 0x80000000u;
+    u |= hx;
+    double t = (double)__uint_as_float(u);
+    double r = t * t * t;
+    t = t * ((double)x + x + r) / (x + r + r);
+    r = t * t * t;
+    t = t * ((double)x + x + r) / (x + r + r);
+    return (float)t;
+}
+
+__device__ inline float dev_scalbnf(float x, int n) {
+    float y = x;
+    if (n > 127) {
+        y *= 0x1p127f; n -= 127;
+        if (n > 127) { y *= 0x1p127f; n -= 127; if (n > 127) n = 127; }
+    } else if (n < -126) {
+        y *= 0x1p-126f * 0x1p24f; n += 126 - 24;
+        if (n < -126) { y *= 0x1p-126f * 0x1p24f; n += 126 - 24; if (n < -126) n = -126; }
+    }
+    return y * __uint_as_float((uint32_t)(0x7f + n) << 23);
+}
+__device__ inline float dev_expf(float x) { // musl expf
+    const float ln2hi = 6.9314575195e-1f, ln2lo = 1.4286067653e-6f, invln2 = 1.4426950216e+0f;
+    const float P1 = 1.6666625440e-1f, P2 = -2.7667332906e-3f;
+    uint32_t hx = __float_as_uint(x);
+    const int sign = (int)(hx >> 31);
+    hx &= 0x7fffffffu;
+    if (hx >= 0x42aeac50u) {
+        if (hx > 0x7f800000u) return x;
+        if (hx >= 0x42b17218u && !sign) return x * 0x1p127f;
+        if (sign && hx >= 0x42cff1b5u) return 0.0f;
+    }
+    float hi, lo;
+    int k;
+    if (hx > 0x3eb17218u) {
+        if (hx > 0x3f851592u) k = (int)(invln2 * x + (sign ? -0.5f : 0.5f));
+        else k = 1 - sign - sign;
+        hi = x - (float)k * ln2hi;
+        lo = (float)k * ln2lo;
+        x = hi - lo;
+    } else if (hx > 0x39000000u) {
+        k = 0; hi = x; lo = 0;
+    } else {
+        return 1 + x;
+    }
+    const float xx = x * x;
+    const float c = x - xx * (P1 + xx * P2);
+    const float y = 1 + (x * c / (2 - c) - lo + hi);
+    return k == 0 ? y : dev_scalbnf(y, k);
+}
+__device__ inline float dev_logf(float x) { // musl logf
+    const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+    const float Lg1 = 0xaaaaaa.0p-24f, Lg2 = 0xccce13.0p-25f, Lg3 = 0x91e9ee.0p-25f, Lg4 = 0xf89e26.0p-26f;
+    uint32_t ix = __float_as_uint(x);
+    int k = 0;
+    if (ix < 0x00800000u || (ix >> 31)) {
+        if ((ix << 1) == 0) return -1 / (x * x);
+        if (ix >> 31) return (x - x) / 0.0f;
+        k -= 25; x *= 0x1p25f; ix = __float_as_uint(x);
+    } else if (ix >= 0x7f800000u) {
+        return x;
+    } else if (ix == 0x3f800000u) {
+        return 0;
+    }
+    ix += 0x3f800000u - 0x3f3504f3u;
+    k += (int)(ix >> 23) - 0x7f;
+    ix = (ix & 0x007fffffu) + 0x3f3504f3u;
+    x = __uint_as_float(ix);
+    const float f = x - 1.0f, s = f / (2.0f + f), z = s * s, w = z * z;
+    const float t1 = w * (Lg2 + w * Lg4), t2 = z * (Lg1 + w * Lg3), R = t2 + t1;
+    const float hfsq = 0.5f * f * f, dk = (float)k;
+    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+}
+// pow(x, 2.4) for finite x > 0 the way Zig's std.math.pow computes it: yi = 2, yf = 0.4.
+__device__ inline float dev_pow_2p4(float x) {
+    if (x == 1) return 1;
+    if (!(x > 0) || !isfinite(x)) return powf(x, 2.4f); // outside the sRGB domain: defer
+    const float yf = 2.4f - 2.0f; // modf(|y|).fpart in f32 = 0.4000001, not 0.4f
+    float a1 = dev_expf(yf * dev_logf(x));
+    int xe;
+    float x1 = frexpf(x, &xe);
+    int ae = 0;
+    // i = 2: bit 0 clear -> square; then i = 1: multiply
+    x1 *= x1; xe <<= 1;
+    if (x1 < 0.5f) { x1 += x1; xe -= 1; }
+    a1 *= x1; ae += xe;
+    return dev_scalbnf(a1, ae);
+}
+__device__ inline float dev_gamma_to_linear(float c) { // color.zig:1252-1258
+    return c > 0.04045f ? dev_pow_2p4((c + 0.055f) / 1.055f) : c / 12.92f;
+}
+
+__device__ inline float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+__device__ inline uint8_t unit_to_u8(float v) { return (uint8_t)(int)roundf(255.0f * clamp01(v)); }
+__device__ inline uint8_t gray_u8(int r, int g, int b) { // color.zig:1031-1042
+    const int v = (13933 * r + 46871 * g + 4732 * b + 32768) >> 16;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+struct ConvertArgs {
+    int src_space, dst_space;
+    const float *srgb_lut; // device, 256 entries
+};
+
+template <int SPIX, int DPIX>
+__global__ __launch_bounds__(256) void k_convert(DImg src, DImg dst, ConvertArgs a) {
+    using SP = Px<SPIX>;
+    using DP = Px<DPIX>;
+    constexpr bool SF = std::is_same<typename SP::Elem, float>::value;
+    constexpr bool DF = std::is_same<typename DP::Elem, float>::value;
+    constexpr int SC = SP::C, DC = DP::C;
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= src.cols) return;
+    const typename SP::Vec sv = SP::load(src.data, (size_t)r * src.stride + (size_t)c);
+    typename DP::Vec dv = DP::zero();
+
+    // source as (r, g, b, a) in its own element type; grey replicated, missing alpha opaque
+    float sf[4] = {0, 0, 0, 1.0f};
+    int su[4] = {0, 0, 0, 255};
+    if constexpr (SF) {
+#pragma unroll
+        for (int i = 0; i < SC; ++i) sf[i] = sv[i];
+        if constexpr (SC == 1) { sf[1] = sf[0]; sf[2] = sf[0]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < SC; ++i) su[i] = sv[i];
+        if constexpr (SC == 1) { su[1] = su[0]; su[2] = su[0]; }
+    }
+
+    switch (a.dst_space) {
+    case ZG_CS_GRAY:
+        if constexpr (DC == 1) {
+            if constexpr (SC == 1) { // scalar <-> scalar (color.zig:113-119)
+                if constexpr (!SF && !DF) dv[0] = (uint8_t)su[0];
+                else if constexpr (!SF && DF) dv[0] = (float)su[0] / 255.0f;
+                else if constexpr (SF && !DF) {
+                    double v = (double)sf[0];
+                    v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+                    dv[0] = (uint8_t)(int)round(v * 255.0);
+                } else dv[0] = sf[0];
+            } else if constexpr (!SF) {
+                const uint8_t y = gray_u8(su[0], su[1], su[2]);
+                if constexpr (DF) dv[0] = (float)y / 255.0f; else dv[0] = y;
+            } else {
+                const float y = clamp01(0.2126f * sf[0] + 0.7152f * sf[1] + 0.0722f * sf[2]);
+                if constexpr (DF) dv[0] = y; else dv[0] = unit_to_u8(y);
+            }
+        }
+        break;
+    case ZG_CS_RGB:
+    case ZG_CS_RGBA:
+        if constexpr (DC >= 3) {
+            if constexpr (DF) {
+                float o[4];
+                if constexpr (SF) { o[0] = sf[0]; o[1] = sf[1]; o[2] = sf[2]; o[3] = sf[3]; }
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (float)su[i] / 255.0f;
+                    if constexpr (SC != 4) o[3] = 1.0f;
+                }
+#pragma unroll
+                for (int i = 0; i < DC; ++i) dv[i] = o[i];
+            } else {
+                uint8_t o[4];
+                if constexpr (!SF) { o[0] = (uint8_t)su[0]; o[1] = (uint8_t)su[1]; o[2] = (uint8_t)su[2]; o[3] = (uint8_t)su[3]; }
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = unit_to_u8(sf[i]);
+                    if constexpr (SC != 4) o[3] = 255;
+                }
+#pragma unroll
+                for (int i = 0; i < DC; ++i) dv[i] = o[i];
+            }
+        }
+        break;
+    case ZG_CS_XYZ:
+    case ZG_CS_OKLAB:
+        if constexpr (DF && DC == 3) {
+            float lin[3];
+            if constexpr (!SF) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) lin[i] = a.srgb_lut[su[i]];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) lin[i] = dev_gamma_to_linear(sf[i]);
+            }
+            const float X = (lin[0] * 0.4124f + lin[1] * 0.3576f + lin[2] * 0.1805f) * 100;
+            const float Y = (lin[0] * 0.2126f + lin[1] * 0.7152f + lin[2] * 0.0722f) * 100;
+            const float Z = (lin[0] * 0.0193f + lin[1] * 0.1192f + lin[2] * 0.9505f) * 100;
+            if (a.dst_space == ZG_CS_XYZ) {
+                dv[0] = X; dv[1] = Y; dv[2] = Z;
+            } else {
+                const float x = X / 100.0f, y = Y / 100.0f, z = Z / 100.0f;
+                const float l_linear = 0.8189330101f * x + 0.3618667424f * y - 0.1288597137f * z;
+                const float m_linear = 0.0329845436f * x + 0.9293118715f * y + 0.0361456387f * z;
+                const float s_linear = 0.0482003018f * x + 0.2643662691f * y + 0.6338517070f * z;
+                const float l_dash = dev_cbrtf(l_linear), m_dash = dev_cbrtf(m_linear), s_dash = dev_cbrtf(s_linear);
+                dv[0] = 0.2104542553f * l_dash + 0.7936177850f * m_dash - 0.0040720468f * s_dash;
+                dv[1] = 1.9779984951f * l_dash - 2.4285922050f * m_dash + 0.4505937099f * s_dash;
+                dv[2] = 0.0259040371f * l_dash + 0.7827717662f * m_dash - 0.8086757660f * s_dash;
+            }
+        }
+        break;
+    case ZG_CS_YCBCR:
+        if constexpr (!SF && !DF && DC == 3) { // color.zig:987-1009
+            const long long rr = su[0], gg = su[1], bb = su[2];
+            const long long y = (19595ll * rr + 38470ll * gg + 7471ll * bb + 32768) >> 16;
+            const long long cb = ((-11059ll * rr + -21710ll * gg + 32768ll * bb + 32768) >> 16) + 128;
+            const long long cr = ((32768ll * rr + -27439ll * gg + -5329ll * bb + 32768) >> 16) + 128;
+            dv[0] = (uint8_t)(y < 0 ? 0 : (y > 255 ? 255 : y));
+            dv[1] = (uint8_t)(cb < 0 ? 0 : (cb > 255 ? 255 : cb));
+            dv[2] = (uint8_t)(cr < 0 ? 0 : (cr > 255 ? 255 : cr));
+        }
+        break;
+    }
+    DP::store(dst.data, (size_t)r * dst.stride + (size_t)c, dv);
+}
+
+static int device_srgb_lut(const float *host_lut, hipStream_t s, const float **out, float **owned) {
+    *owned = nullptr;
+    if (host_lut) {
+        ZG_HIP(hipMallocAsync((void **)owned, 256 * sizeof(float), s));
+        ZG_HIP(hipMemcpyAsync(*owned, host_lut, 256 * sizeof(float), hipMemcpyHostToDevice, s));
+        ZG_HIP(hipStreamSynchronize(s));
+        *out = *owned;
+        return ZG_OK;
+    }
+    static std::mutex mu;
+    static float *per_device[64] = {nullptr};
+    int dev = 0;
+    ZG_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < 64 && !per_device[dev]) {
+        float *p = nullptr;
+        ZG_HIP(hipMalloc((void **)&p, 256 * sizeof(float)));
+        ZG_HIP(hipMemcpy(p, hostmath::srgb_u8_lut(), 256 * sizeof(float), hipMemcpyHostToDevice));
+        per_device[dev] = p;
+    }
+    *out = per_device[dev];
+    return ZG_OK;
+}
+
+static int space_channels(int space) { return space == ZG_CS_GRAY ? 1 : (space == ZG_CS_RGBA ? 4 : 3); }
+
+int copy_impl(const zg_image *src, const zg_image *dst, hipStream_t s);
+
+static int convert_impl(const zg_image *src, int src_space, const zg_image *dst, int dst_space, const float *srgb_lut, hipStream_t s) {
+    int rc;
+    if ((rc = check_image(src, "src")) || (rc = check_image(dst, "dst"))) return rc;
+    ZG_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, ZG_ERR_DIMENSION_MISMATCH, "convert: shapes differ");
+    ZG_REQUIRE(src_space == ZG_CS_GRAY || src_space == ZG_CS_RGB || src_space == ZG_CS_RGBA, ZG_ERR_UNSUPPORTED,
+               "convert: source colour space %d is not on the image hot path", src_space);
+    ZG_REQUIRE(dst_space >= ZG_CS_GRAY && dst_space <= ZG_CS_YCBCR, ZG_ERR_INVALID_ARGUMENT, "convert: invalid destination space %d", dst_space);
+    ZG_REQUIRE(pixel_channels(src->pixel) == space_channels(src_space), ZG_ERR_INVALID_ARGUMENT, "convert: source layout does not match its colour space");
+    ZG_REQUIRE(pixel_channels(dst->pixel) == space_channels(dst_space), ZG_ERR_INVALID_ARGUMENT, "convert: destination layout does not match its colour space");
+    const bool df = pixel_is_float(dst->pixel), sf = pixel_is_float(src->pixel);
+    if (dst_space == ZG_CS_XYZ || dst_space == ZG_CS_OKLAB) ZG_REQUIRE(df, ZG_ERR_UNSUPPORTED, "convert: Xyz / Oklab need a float destination");
+    if (dst_space == ZG_CS_YCBCR) ZG_REQUIRE(!df && !sf, ZG_ERR_UNSUPPORTED, "convert: Ycbcr path is u8 -> u8");
+    if (src->rows == 0 || src->cols == 0) return ZG_OK;
+    if (src_space == dst_space && src->pixel == dst->pixel) return copy_impl(src, dst, s); // T == TargetType
+
+    ConvertArgs a{src_space, dst_space, nullptr};
+    float *owned = nullptr;
+    if (!sf && (dst_space == ZG_CS_XYZ || dst_space == ZG_CS_OKLAB)) {
+        if ((rc = device_srgb_lut(srgb_lut, s, &a.srgb_lut, &owned))) return rc;
+    }
+    const dim3 grid(ceil_div(src->cols, 256), src->rows);
+    rc = dispatch_pixel(src->pixel, [&](auto stag) -> int {
+        constexpr int SPIX = decltype(stag)::value;
+        return dispatch_pixel(dst->pixel, [&](auto dtag) -> int {
+            constexpr int DPIX = decltype(dtag)::value;
+            hipLaunchKernelGGL((k_convert<SPIX, DPIX>), grid, dim3(256), 0, s, dimg(src), dimg(dst), a);
+            ZG_HIP(hipGetLastError());
+            return ZG_OK;
+        });
+    });
+    if (owned) (void)hipFreeAsync(owned, s);
+    return rc;
+}
+
+} // namespace zg
+
+using namespace zg;
+
+extern "C" {
+
+int zg_convert(const zg_image *src, int src_space, const zg_image *dst, int dst_space, const float *srgb_lut, zg_stream stream) {
+    return convert_impl(src, src_space, dst, dst_space, srgb_lut, as_stream(stream));
+}
+
+int zg_convert_host(const zg_image *src, int src_space, const zg_image *dst, int dst_space, const float *srgb_lut) {
+    HostStage a, b;
+    int rc;
+    if ((rc = a.upload(src, true, false))) return rc;
+    if ((rc = b.upload(dst, false, true))) return rc;
+    if ((rc = convert_impl(&a.dev, src_space, &b.dev, dst_space, srgb_lut, nullptr))) return rc;
+    ZG_HIP(hipStreamSynchronize(nullptr));
+    return b.finish();
+}
+
+} // extern "C"

@@ -1,0 +1,593 @@
+// geom.hip — backward-mapped resampling: one thread per destination pixel computes a source coordinate and
+// samples it with zg_sample.h. Covers
+//   resizeGeneric       reference src/image/interpolation.zig:194-214 (u8, f32, Rgb(f32), Rgba(f32) ...)
+//   Image.warp          reference src/image/transforms.zig:522-531 + project() of
+//                       src/geometry/transforms.zig:39-42,147-150,224-231 (SMatrix.gemm 3-term scalar dot,
+//                       left to right, then scale by the reciprocal of w)
+//   Image.rotateInto    reference src/image/transforms.zig:163-212 (general angle; 0/90/180/270 are exact
+//                       permutations, :385-462)
+//   Image.extract       reference src/image/transforms.zig:231-282 (general path; the aligned case is copyRect)
+//   Image.crop          reference src/image/transforms.zig:216-222 -> copyRect :465-518 (bit-exact copy)
+//   Image.insert        reference src/image/transforms.zig:293-378 + assignPixel src/image.zig:67-94
+//   Image.letterbox     reference src/image/transforms.zig:49-108 (host logic around resize)
+//
+// Every coordinate is computed in f32 with the reference's operation order and no FMA; cos/sin of the angle
+// are host-supplied scalars. A wave covers 64 consecutive destination pixels of one row (coalesced stores);
+// the source side is a gather served by L1/L2 (neighbouring lanes read neighbouring source pixels).
+#include "zg_common.h"
+#include "zg_hostmath.h"
+#include "zg_sample.h"
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#pragma clang fp contract(off)
+
+namespace zg {
+
+int copy_impl(const zg_image *src, const zg_image *dst, hipStream_t s);
+int fill_outside_impl(const zg_image *img, const void *pixel_value, int l, int t, int r, int b, hipStream_t s);
+int set_border_impl(const zg_image *img, const uint32_t rect[4], const void *pixel_value, hipStream_t s);
+int resize_planes_impl(const zg_image *src, const zg_image *dst, const zg_method *method, hipStream_t s);
+
+enum : int { GEOM_RESIZE = 0, GEOM_PROJECTIVE = 1, GEOM_AFFINE = 2, GEOM_ROTATE = 3, GEOM_EXTRACT = 4 };
+
+struct GeomParams {
+    int mode;
+    float p[12];
+};
+
+// Source coordinate of destination pixel (c, r).
+__device__ inline void source_coord(const GeomParams &g, int c, int r, float &sx, float &sy) {
+    const float x = (float)c, y = (float)r;
+    switch (g.mode) {
+    case GEOM_RESIZE: // src = (dst + 0.5) * scale - 0.5
+        sx = (x + 0.5f) * g.p[0] - 0.5f;
+        sy = (y + 0.5f) * g.p[1] - 0.5f;
+        break;
+    case GEOM_PROJECTIVE: { // gemm: acc = 0; acc += a*b (k ascending); result = 0 + 1.0 * acc
+        float acc, X, Y, W;
+        acc = 0.0f; acc = acc + g.p[0] * x; acc = acc + g.p[1] * y; acc = acc + g.p[2] * 1.0f; X = 0.0f + 1.0f * acc;
+        acc = 0.0f; acc = acc + g.p[3] * x; acc = acc + g.p[4] * y; acc = acc + g.p[5] * 1.0f; Y = 0.0f + 1.0f * acc;
+        acc = 0.0f; acc = acc + g.p[6] * x; acc = acc + g.p[7] * y; acc = acc + g.p[8] * 1.0f; W = 0.0f + 1.0f * acc;
+        if (W != 0.0f) {
+            const float inv = 1.0f / W;
+            X = inv * X;
+            Y = inv * Y;
+        }
+        sx = X;
+        sy = Y;
+        break;
+    }
+    case GEOM_AFFINE: { // matrix.dot(src).add(bias)
+        float acc, X, Y;
+        acc = 0.0f; acc = acc + g.p[0] * x; acc = acc + g.p[1] * y; X = 0.0f + 1.0f * acc;
+        acc = 0.0f; acc = acc + g.p[2] * x; acc = acc + g.p[3] * y; Y = 0.0f + 1.0f * acc;
+        sx = X + g.p[4];
+        sy = Y + g.p[5];
+        break;
+    }
+    case GEOM_ROTATE: { // p = {cos, sin, rotated_center_x, rotated_center_y, center_x, center_y}
+        const float dx = x - g.p[2], dy = y - g.p[3];
+        const float rdx = g.p[0] * dx - g.p[1] * dy;
+        const float rdy = g.p[1] * dx + g.p[0] * dy;
+        sx = rdx + g.p[4];
+        sy = rdy + g.p[5];
+        break;
+    }
+    default: { // extract: p = {cos, sin, rect.l, rect.t, width, height, cx, cy, fcols - 1, frows - 1, cols == 1, rows == 1}
+        const float ty = g.p[11] != 0.0f ? 0.5f : y / g.p[9];
+        const float y_rect = g.p[3] + ty * g.p[5];
+        const float tx = g.p[10] != 0.0f ? 0.5f : x / g.p[8];
+        const float x_rect = g.p[2] + tx * g.p[4];
+        const float dx = x_rect - g.p[6], dy = y_rect - g.p[7];
+        sx = g.p[6] + g.p[0] * dx - g.p[1] * dy;
+        sy = g.p[7] + g.p[1] * dx + g.p[0] * dy;
+        break;
+    }
+    }
+}
+
+template <int PIX, int KIND>
+__global__ __launch_bounds__(256) void k_geom(DImg src, DImg dst, GeomParams g, MethodArg m, int border, int tiles_x) {
+    using P = Px<PIX>;
+    using Vec = typename P::Vec;
+    // 64 x 4 destination tile per workgroup; workgroups numbered XCD-major so one XCD's L2 serves a
+    // contiguous band of destination (hence, for smooth maps, of source) rows.
+    const int nwg = gridDim.x, per_xcd = nwg >> 3;
+    int wg = blockIdx.x;
+    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
+    const int c = tx * 64 + (int)(threadIdx.x & 63);
+    const int r = ty * 4 + (int)(threadIdx.x >> 6);
+    if (c >= dst.cols || r >= dst.rows) return;
+    float sx, sy;
+    source_coord(g, c, r, sx, sy);
+    Vec v;
+    if (!interpolate<PIX, KIND>(src, sx, sy, m, border, v)) v = P::zero();
+    P::store(dst.data, (size_t)r * dst.stride + (size_t)c, v);
+}
+
+// ---- Lanczos table on the device ---------------------------------------------------------------
+struct LutHolder {
+    const float *dev = nullptr;   // what the kernel reads
+    float *owned = nullptr;       // per-call upload of a caller-supplied table (freed on the stream)
+};
+static int device_lanczos_lut(const zg_method *method, hipStream_t s, LutHolder &h) {
+    if (method->kind != ZG_INTERP_LANCZOS) return ZG_OK;
+    if (method->lanczos_lut) {
+        ZG_HIP(hipMallocAsync((void **)&h.owned, 1025 * sizeof(float), s));
+        ZG_HIP(hipMemcpyAsync(h.owned, method->lanczos_lut, 1025 * sizeof(float), hipMemcpyHostToDevice, s));
+        ZG_HIP(hipStreamSynchronize(s)); // the caller's table may be pageable / short-lived
+        h.dev = h.owned;
+        return ZG_OK;
+    }
+    static std::mutex mu;
+    static float *per_device[64] = {nullptr};
+    int dev = 0;
+    ZG_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < 64 && !per_device[dev]) {
+        float *p = nullptr;
+        ZG_HIP(hipMalloc((void **)&p, 1025 * sizeof(float)));
+        ZG_HIP(hipMemcpy(p, hostmath::lanczos3_lut(), 1025 * sizeof(float), hipMemcpyHostToDevice));
+        per_device[dev] = p;
+    }
+    h.dev = per_device[dev];
+    return ZG_OK;
+}
+static void release_lut(LutHolder &h, hipStream_t s) {
+    if (h.owned) (void)hipFreeAsync(h.owned, s);
+    h.owned = nullptr;
+}
+
+static int check_method(const zg_method *method) {
+    ZG_REQUIRE(method != nullptr, ZG_ERR_INVALID_ARGUMENT, "null interpolation method");
+    ZG_REQUIRE(method->kind >= ZG_INTERP_NEAREST && method->kind <= ZG_INTERP_LANCZOS, ZG_ERR_INVALID_ARGUMENT,
+               "invalid interpolation kind %d", method->kind);
+    return ZG_OK;
+}
+
+template <int PIX, int KIND>
+static int launch_geom_k(const zg_image *src, const zg_image *dst, const GeomParams &g, const MethodArg &m, int border, hipStream_t s) {
+    const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, 4);
+    hipLaunchKernelGGL((k_geom<PIX, KIND>), dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, dimg(src), dimg(dst), g, m, border, tiles_x);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+static int launch_geom(const zg_image *src, const zg_image *dst, const GeomParams &g, const zg_method *method, int border, hipStream_t s) {
+    int rc;
+    if ((rc = check_method(method))) return rc;
+    ZG_REQUIRE(border >= ZG_BORDER_ZERO && border <= ZG_BORDER_WRAP, ZG_ERR_INVALID_ARGUMENT, "invalid border %d", border);
+    if (dst->rows == 0 || dst->cols == 0) return ZG_OK;
+    LutHolder lut;
+    if ((rc = device_lanczos_lut(method, s, lut))) return rc;
+    const MethodArg m{method->kind, method->b, method->c, lut.dev};
+    rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
+        constexpr int PIX = decltype(tag)::value;
+        switch (method->kind) {
+        case ZG_INTERP_NEAREST: return launch_geom_k<PIX, ZG_INTERP_NEAREST>(src, dst, g, m, border, s);
+        case ZG_INTERP_BILINEAR: return launch_geom_k<PIX, ZG_INTERP_BILINEAR>(src, dst, g, m, border, s);
+        case ZG_INTERP_BICUBIC: return launch_geom_k<PIX, ZG_INTERP_BICUBIC>(src, dst, g, m, border, s);
+        case ZG_INTERP_CATMULL_ROM: return launch_geom_k<PIX, ZG_INTERP_CATMULL_ROM>(src, dst, g, m, border, s);
+        case ZG_INTERP_MITCHELL: return launch_geom_k<PIX, ZG_INTERP_MITCHELL>(src, dst, g, m, border, s);
+        default: return launch_geom_k<PIX, ZG_INTERP_LANCZOS>(src, dst, g, m, border, s);
+        }
+    });
+    release_lut(lut, s);
+    return rc;
+}
+
+static int check_pair(const zg_image *src, const zg_image *dst, const char *op) {
+    int rc;
+    if ((rc = check_image(src, "src")) || (rc = check_image(dst, "dst"))) return rc;
+    ZG_REQUIRE(src->pixel == dst->pixel, ZG_ERR_INVALID_ARGUMENT, "%s: pixel types differ", op);
+    return ZG_OK;
+}
+
+// ---- resize (interpolation.zig:89-191) -----------------------------------------------------------
+int resize_impl(const zg_image *src, const zg_image *dst, const zg_method *method, hipStream_t s) {
+    int rc;
+    if ((rc = check_pair(src, dst, "resize")) || (rc = check_method(method))) return rc;
+    if (dst->rows == 0 || dst->cols == 0) return ZG_OK;
+    if (src->rows == dst->rows && src->cols == dst->cols) return copy_impl(src, dst, s); // :91-108
+    const bool is_rgb_u8 = src->pixel == ZG_PIXEL_RGB_U8 || src->pixel == ZG_PIXEL_RGBA_U8; // meta.isRgb(T)
+    if (is_rgb_u8 && src->rows > 0 && src->cols > 0) return resize_planes_impl(src, dst, method, s);
+    GeomParams g{};
+    g.mode = GEOM_RESIZE;
+    g.p[0] = (float)src->cols / (float)dst->cols;
+    g.p[1] = (float)src->rows / (float)dst->rows;
+    return launch_geom(src, dst, g, method, ZG_BORDER_MIRROR, s);
+}
+
+// ---- letterbox (transforms.zig:49-108) -------------------------------------------------------------
+static int letterbox_impl(const zg_image *src, const zg_image *dst, const zg_method *method, uint32_t rect_out[4], hipStream_t s) {
+    int rc;
+    if ((rc = check_pair(src, dst, "letterbox")) || (rc = check_method(method))) return rc;
+    uint32_t rect[4] = {0, 0, 0, 0};
+    const uint8_t zero[16] = {0};
+    auto done = [&](int status) {
+        if (rect_out) std::memcpy(rect_out, rect, sizeof rect);
+        return status;
+    };
+    if (dst->rows == 0 || dst->cols == 0) return done(ZG_OK);
+    if (src->rows == 0 || src->cols == 0) return done(fill_outside_impl(dst, zero, 0, 0, 0, 0, s));
+    if (src->rows == dst->rows && src->cols == dst->cols) {
+        rect[2] = dst->cols; rect[3] = dst->rows;
+        return done(copy_impl(src, dst, s));
+    }
+    const float rows_scale = (float)dst->rows / (float)src->rows, cols_scale = (float)dst->cols / (float)src->cols;
+    if (rows_scale == cols_scale) {
+        rect[2] = dst->cols; rect[3] = dst->rows;
+        return done(resize_impl(src, dst, method, s));
+    }
+    const float aspect = std::fmin(rows_scale, cols_scale);
+    const uint32_t scaled_rows = (uint32_t)std::round(aspect * (float)src->rows);
+    const uint32_t scaled_cols = (uint32_t)std::round(aspect * (float)src->cols);
+    const uint32_t off_r = (dst->rows > scaled_rows ? dst->rows - scaled_rows : 0) / 2;
+    const uint32_t off_c = (dst->cols > scaled_cols ? dst->cols - scaled_cols : 0) / 2;
+    rect[0] = off_c; rect[1] = off_r; rect[2] = off_c + scaled_cols; rect[3] = off_r + scaled_rows;
+    const uint32_t l = rect[0], t = rect[1], r = std::min(rect[2], dst->cols), b = std::min(rect[3], dst->rows);
+    if (l < r && t < b) { // out.view(content_rect)
+        zg_image view = *dst;
+        view.rows = b - t;
+        view.cols = r - l;
+        view.data = (char *)dst->data + ((size_t)t * dst->stride + l) * pixel_size(dst->pixel);
+        if ((rc = resize_impl(src, &view, method, s))) return done(rc);
+    }
+    return done(set_border_impl(dst, rect, zero, s));
+}
+
+// ---- warp (transforms.zig:522-531) ------------------------------------------------------------------
+static int warp_impl(const zg_image *src, const zg_image *dst, int kind, const float *mat, const zg_method *method, hipStream_t s) {
+    int rc;
+    if ((rc = check_pair(src, dst, "warp"))) return rc;
+    ZG_REQUIRE(mat != nullptr, ZG_ERR_INVALID_ARGUMENT, "warp: null transform coefficients");
+    ZG_REQUIRE(kind >= ZG_TRANSFORM_SIMILARITY && kind <= ZG_TRANSFORM_PROJECTIVE, ZG_ERR_INVALID_ARGUMENT, "warp: invalid transform kind %d", kind);
+    GeomParams g{};
+    if (kind == ZG_TRANSFORM_PROJECTIVE) {
+        g.mode = GEOM_PROJECTIVE;
+        for (int i = 0; i < 9; ++i) g.p[i] = mat[i];
+    } else {
+        g.mode = GEOM_AFFINE;
+        for (int i = 0; i < 6; ++i) g.p[i] = mat[i];
+    }
+    return launch_geom(src, dst, g, method, ZG_BORDER_MIRROR, s);
+}
+
+// ---- rotate (transforms.zig:112-212, :385-462) -----------------------------------------------------
+static float mod_tau(float a) { // @mod(angle, tau): floored
+    const float tau = 6.28318530717958647692f;
+    float r = std::fmod(a, tau);
+    if (r < 0) r += tau;
+    return r;
+}
+static int orthogonal_case(float angle) {
+    const float n = mod_tau(angle), eps = 1e-6f, pi = 3.14159265358979323846f, tau = 6.28318530717958647692f;
+    if (std::fabs(n) < eps || std::fabs(n - tau) < eps) return 0;
+    if (std::fabs(n - pi / 2.0f) < eps) return 1;
+    if (std::fabs(n - pi) < eps) return 2;
+    if (std::fabs(n - 3.0f * pi / 2.0f) < eps) return 3;
+    return -1;
+}
+
+// Exact index permutation: out[new_r + off_r, new_c + off_c] = src[r, c]; one thread per source pixel.
+template <int PS>
+__global__ __launch_bounds__(256) void k_rotate_orthogonal(DImg src, DImg out, int which, int off_r, int off_c) {
+    struct B { uint8_t b[PS]; };
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= src.cols) return;
+    int nr, nc;
+    switch (which) {
+    case 0: nr = r; nc = c; break;
+    case 1: nr = src.cols - 1 - c; nc = r; break;
+    case 2: nr = src.rows - 1 - r; nc = src.cols - 1 - c; break;
+    default: nr = c; nc = src.rows - 1 - r; break;
+    }
+    nr += off_r;
+    nc += off_c;
+    if (nr < out.rows && nc < out.cols)
+        ((B *)out.data)[(size_t)nr * out.stride + nc] = ((const B *)src.data)[(size_t)r * src.stride + c];
+}
+
+static int rotate_into_impl(const zg_image *src, const zg_image *dst, float angle, float cos_a, float sin_a,
+                            const zg_method *method, int border, hipStream_t s) {
+    int rc;
+    if ((rc = check_pair(src, dst, "rotateInto")) || (rc = check_method(method))) return rc;
+    const int oc = orthogonal_case(angle);
+    if (oc >= 0) {
+        const uint32_t rr = (oc & 1) ? src->cols : src->rows, rcols = (oc & 1) ? src->rows : src->cols;
+        const uint32_t off_r = (dst->rows > rr ? dst->rows - rr : 0) / 2, off_c = (dst->cols > rcols ? dst->cols - rcols : 0) / 2;
+        if (src->rows && src->cols) {
+            const dim3 grid(ceil_div(src->cols, 256), src->rows);
+#define ZG_ROT(PS) case PS: hipLaunchKernelGGL(k_rotate_orthogonal<PS>, grid, dim3(256), 0, s, dimg(src), dimg(dst), oc, (int)off_r, (int)off_c); break;
+            switch ((int)pixel_size(src->pixel)) { ZG_ROT(1) ZG_ROT(3) ZG_ROT(4) ZG_ROT(12) ZG_ROT(16) }
+#undef ZG_ROT
+            ZG_HIP(hipGetLastError());
+        }
+        if (off_r != 0 || off_c != 0) {
+            const uint32_t inner[4] = {off_c, off_r, off_c + rcols, off_r + rr};
+            const uint8_t zero[16] = {0};
+            return set_border_impl(dst, inner, zero, s);
+        }
+        return ZG_OK;
+    }
+    const float cx = (float)src->cols / 2.0f, cy = (float)src->rows / 2.0f; // getCenter
+    const float offset_x = ((float)dst->cols - (float)src->cols) / 2.0f;
+    const float offset_y = ((float)dst->rows - (float)src->rows) / 2.0f;
+    GeomParams g{};
+    g.mode = GEOM_ROTATE;
+    g.p[0] = cos_a; g.p[1] = sin_a; g.p[2] = cx + offset_x; g.p[3] = cy + offset_y; g.p[4] = cx; g.p[5] = cy;
+    return launch_geom(src, dst, g, method, border, s);
+}
+
+// ---- extract / crop (transforms.zig:216-282, copyRect :465-518) ---------------------------------------
+static float rect_w(const float r[4]) { return r[0] >= r[2] ? 0.0f : r[2] - r[0]; }
+static float rect_h(const float r[4]) { return r[1] >= r[3] ? 0.0f : r[3] - r[1]; }
+
+template <int PS>
+__global__ __launch_bounds__(256) void k_copy_rect(DImg src, DImg out, int rect_top, int rect_left, int border) {
+    struct B { uint8_t b[PS]; };
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= out.cols) return;
+    const int rr = resolve_index(r + rect_top, src.rows, border);
+    const int cc = rr < 0 ? -1 : resolve_index(c + rect_left, src.cols, border);
+    B v = {};
+    if (rr >= 0 && cc >= 0) v = ((const B *)src.data)[(size_t)rr * src.stride + cc];
+    ((B *)out.data)[(size_t)r * out.stride + c] = v;
+}
+
+static int copy_rect_impl(const zg_image *src, int rect_top, int rect_left, const zg_image *out, int border, hipStream_t s) {
+    if (out->rows == 0 || out->cols == 0) return ZG_OK;
+    const dim3 grid(ceil_div(out->cols, 256), out->rows);
+#define ZG_CR(PS) case PS: hipLaunchKernelGGL(k_copy_rect<PS>, grid, dim3(256), 0, s, dimg(src), dimg(out), rect_top, rect_left, border); break;
+    switch ((int)pixel_size(src->pixel)) { ZG_CR(1) ZG_CR(3) ZG_CR(4) ZG_CR(12) ZG_CR(16) }
+#undef ZG_CR
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+static int extract_impl(const zg_image *src, const zg_image *dst, const float rect[4], float angle, float cos_a, float sin_a,
+                        const zg_method *method, int border, hipStream_t s) {
+    int rc;
+    if ((rc = check_pair(src, dst, "extract")) || (rc = check_method(method))) return rc;
+    ZG_REQUIRE(rect != nullptr, ZG_ERR_INVALID_ARGUMENT, "extract: null rect");
+    if (dst->rows == 0 || dst->cols == 0) return ZG_OK;
+    const float frows = (float)dst->rows, fcols = (float)dst->cols;
+    const float width = rect_w(rect), height = rect_h(rect), eps = 1e-6f;
+    if (std::fabs(angle) < eps && std::fabs(width - fcols) < eps && std::fabs(height - frows) < eps)
+        return copy_rect_impl(src, (int)std::round(rect[1]), (int)std::round(rect[0]), dst, border, s);
+    GeomParams g{};
+    g.mode = GEOM_EXTRACT;
+    g.p[0] = cos_a; g.p[1] = sin_a; g.p[2] = rect[0]; g.p[3] = rect[1]; g.p[4] = width; g.p[5] = height;
+    g.p[6] = (rect[0] + rect[2]) * 0.5f; g.p[7] = (rect[1] + rect[3]) * 0.5f;
+    g.p[8] = fcols - 1; g.p[9] = frows - 1;
+    g.p[10] = dst->cols == 1 ? 1.0f : 0.0f; g.p[11] = dst->rows == 1 ? 1.0f : 0.0f;
+    return launch_geom(src, dst, g, method, border, s);
+}
+
+// ---- insert (transforms.zig:293-378) -------------------------------------------------------------------
+struct InsertParams {
+    int aligned;             // fast path: axis aligned, no resampling
+    int dst_top, dst_left;
+    int min_r, max_r, min_c, max_c;
+    float cx, cy, cos_a, sin_a, inv_width, inv_height, half_width, half_height, fcols_m1, frows_m1;
+    int blend;
+};
+
+// Rgba(u8).blend(overlay, .normal) — reference src/blending.zig:27-157
+__device__ inline void blend_normal_u8(typename Px<ZG_PIXEL_RGBA_U8>::Vec &base, typename Px<ZG_PIXEL_RGBA_U8>::Vec overlay) {
+    if (overlay[3] == 0) return;
+    if (base[3] == 0 || overlay[3] == 255) { base = overlay; return; }
+    float b[4], o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { b[i] = (float)base[i] / 255.0f; o[i] = (float)overlay[i] / 255.0f; }
+    const float result_a = o[3] + b[3] * (1.0f - o[3]);
+    if (result_a <= 0) { base = Px<ZG_PIXEL_RGBA_U8>::zero(); return; }
+    const float base_weight = b[3] * (1.0f - o[3]);
+    const float inv = 1.0f / result_a;
+    float out[4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = (o[i] * o[3] + b[i] * base_weight) * inv;
+    out[3] = result_a;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float v = out[i] < 0.0f ? 0.0f : (out[i] > 1.0f ? 1.0f : out[i]);
+        base[i] = (uint8_t)(int)roundf(255.0f * v);
+    }
+}
+
+template <int PIX, int KIND>
+__global__ __launch_bounds__(256) void k_insert(DImg self, DImg source, InsertParams q, MethodArg m) {
+    using P = Px<PIX>;
+    using Vec = typename P::Vec;
+    const int c = q.min_c + (int)(blockIdx.x * 64 + (threadIdx.x & 63));
+    const int r = q.min_r + (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+    if (c >= q.max_c || r >= q.max_r) return;
+    Vec sample;
+    if (q.aligned) { // iterate destination pixels covered by the source rectangle
+        const int sr = r - q.dst_top, sc = c - q.dst_left;
+        sample = P::load(source.data, (size_t)sr * source.stride + (size_t)sc);
+    } else {
+        const float dy = (float)r - q.cy, dx = (float)c - q.cx;
+        const float rect_x = q.cos_a * dx + q.sin_a * dy;
+        const float rect_y = -q.sin_a * dx + q.cos_a * dy;
+        if (fabsf(rect_x) > q.half_width || fabsf(rect_y) > q.half_height) return;
+        const float norm_x = (rect_x + q.half_width) * q.inv_width;
+        const float norm_y = (rect_y + q.half_height) * q.inv_height;
+        const float sx = source.cols == 1 ? 0.0f : norm_x * q.fcols_m1;
+        const float sy = source.rows == 1 ? 0.0f : norm_y * q.frows_m1;
+        if (!interpolate<PIX, KIND>(source, sx, sy, m, ZG_BORDER_MIRROR, sample)) return;
+    }
+    const size_t di = (size_t)r * self.stride + (size_t)c;
+    if constexpr (PIX == ZG_PIXEL_RGBA_U8) {
+        if (q.blend != 0) {
+            Vec d = P::load(self.data, di);
+            blend_normal_u8(d, sample);
+            P::store(self.data, di, d);
+            return;
+        }
+    }
+    P::store(self.data, di, sample);
+}
+
+static int insert_impl(const zg_image *self, const zg_image *source, const float rect[4], float angle, float cos_a, float sin_a,
+                       const zg_method *method, int blend_mode, hipStream_t s) {
+    int rc;
+    if ((rc = check_image(self, "self")) || (rc = check_image(source, "source")) || (rc = check_method(method))) return rc;
+    ZG_REQUIRE(self->pixel == source->pixel, ZG_ERR_UNSUPPORTED, "insert: source and destination pixel types must match");
+    ZG_REQUIRE(blend_mode == 0 || blend_mode == 1, ZG_ERR_UNSUPPORTED, "insert: only Blending.none and Blending.normal");
+    ZG_REQUIRE(rect != nullptr, ZG_ERR_INVALID_ARGUMENT, "insert: null rect");
+    if (source->rows == 0 || source->cols == 0 || self->rows == 0 || self->cols == 0) return ZG_OK;
+    const float frows = (float)source->rows, fcols = (float)source->cols;
+    const float rect_width = rect_w(rect), rect_height = rect_h(rect), eps = 1e-6f;
+    InsertParams q{};
+    q.blend = blend_mode;
+    if (std::fabs(angle) < eps && std::fabs(rect_width - fcols) < eps && std::fabs(rect_height - frows) < eps) {
+        q.aligned = 1;
+        q.dst_top = (int)std::round(rect[1]);
+        q.dst_left = (int)std::round(rect[0]);
+        q.min_r = std::max(0, q.dst_top);
+        q.max_r = (int)std::min<long long>(self->rows, (long long)q.dst_top + source->rows);
+        q.min_c = std::max(0, q.dst_left);
+        q.max_c = (int)std::min<long long>(self->cols, (long long)q.dst_left + source->cols);
+    } else {
+        q.cx = (rect[0] + rect[2]) * 0.5f; q.cy = (rect[1] + rect[3]) * 0.5f;
+        q.cos_a = cos_a; q.sin_a = sin_a;
+        q.inv_width = 1.0f / rect_width; q.inv_height = 1.0f / rect_height;
+        q.half_width = rect_width * 0.5f; q.half_height = rect_height * 0.5f;
+        q.fcols_m1 = fcols - 1; q.frows_m1 = frows - 1;
+        const float abs_cos = std::fabs(cos_a), abs_sin = std::fabs(sin_a);
+        const float bound_hw = q.half_width * abs_cos + q.half_height * abs_sin;
+        const float bound_hh = q.half_width * abs_sin + q.half_height * abs_cos;
+        q.min_r = (q.cy - bound_hh < 0) ? 0 : (int)std::floor(q.cy - bound_hh);
+        q.max_r = (int)std::min<double>(self->rows, (double)std::ceil(q.cy + bound_hh) + 1);
+        q.min_c = (q.cx - bound_hw < 0) ? 0 : (int)std::floor(q.cx - bound_hw);
+        q.max_c = (int)std::min<double>(self->cols, (double)std::ceil(q.cx + bound_hw) + 1);
+    }
+    if (q.min_r >= q.max_r || q.min_c >= q.max_c) return ZG_OK;
+    LutHolder lut;
+    if ((rc = device_lanczos_lut(method, s, lut))) return rc;
+    const MethodArg m{method->kind, method->b, method->c, lut.dev};
+    const dim3 grid(ceil_div((unsigned)(q.max_c - q.min_c), 64), ceil_div((unsigned)(q.max_r - q.min_r), 4));
+    rc = dispatch_pixel(self->pixel, [&](auto tag) -> int {
+        constexpr int PIX = decltype(tag)::value;
+#define ZG_INS(K) case K: hipLaunchKernelGGL((k_insert<PIX, K>), grid, dim3(256), 0, s, dimg(self), dimg(source), q, m); break;
+        switch (method->kind) {
+            ZG_INS(ZG_INTERP_NEAREST) ZG_INS(ZG_INTERP_BILINEAR) ZG_INS(ZG_INTERP_BICUBIC)
+            ZG_INS(ZG_INTERP_CATMULL_ROM) ZG_INS(ZG_INTERP_MITCHELL) ZG_INS(ZG_INTERP_LANCZOS)
+        }
+#undef ZG_INS
+        ZG_HIP(hipGetLastError());
+        return ZG_OK;
+    });
+    release_lut(lut, s);
+    return rc;
+}
+
+} // namespace zg
+
+using namespace zg;
+
+// host-pointer wrappers: stage, run on the default stream, copy back
+#define ZG_HOST2(call)                                                   \
+    HostStage a, b;                                                      \
+    int rc;                                                              \
+    if ((rc = a.upload(src, true, false))) return rc;                    \
+    if ((rc = b.upload(dst, false, true))) return rc;                    \
+    if ((rc = (call))) return rc;                                        \
+    ZG_HIP(hipStreamSynchronize(nullptr));                               \
+    return b.finish();
+
+extern "C" {
+
+int zg_resize(const zg_image *src, const zg_image *dst, const zg_method *method, zg_stream stream) {
+    return resize_impl(src, dst, method, as_stream(stream));
+}
+int zg_resize_host(const zg_image *src, const zg_image *dst, const zg_method *method) {
+    ZG_HOST2(resize_impl(&a.dev, &b.dev, method, nullptr))
+}
+
+int zg_letterbox(const zg_image *src, const zg_image *dst, const zg_method *method, uint32_t rect_out[4], zg_stream stream) {
+    return letterbox_impl(src, dst, method, rect_out, as_stream(stream));
+}
+int zg_letterbox_host(const zg_image *src, const zg_image *dst, const zg_method *method, uint32_t rect_out[4]) {
+    ZG_HOST2(letterbox_impl(&a.dev, &b.dev, method, rect_out, nullptr))
+}
+
+int zg_warp(const zg_image *src, const zg_image *dst, int kind, const float *m, const zg_method *method, zg_stream stream) {
+    return warp_impl(src, dst, kind, m, method, as_stream(stream));
+}
+int zg_warp_host(const zg_image *src, const zg_image *dst, int kind, const float *m, const zg_method *method) {
+    ZG_HOST2(warp_impl(&a.dev, &b.dev, kind, m, method, nullptr))
+}
+
+int zg_rotate_into(const zg_image *src, const zg_image *dst, float angle, float cos_a, float sin_a,
+                   const zg_method *method, int border, zg_stream stream) {
+    return rotate_into_impl(src, dst, angle, cos_a, sin_a, method, border, as_stream(stream));
+}
+int zg_rotate_into_host(const zg_image *src, const zg_image *dst, float angle, float cos_a, float sin_a,
+                        const zg_method *method, int border) {
+    ZG_HOST2(rotate_into_impl(&a.dev, &b.dev, angle, cos_a, sin_a, method, border, nullptr))
+}
+
+int zg_rotate_bounds(uint32_t rows, uint32_t cols, float angle, float cos_a, float sin_a, uint32_t *out_rows, uint32_t *out_cols) {
+    ZG_REQUIRE(out_rows && out_cols, ZG_ERR_INVALID_ARGUMENT, "rotateBounds: null output");
+    switch (orthogonal_case(angle)) {
+    case 0: case 2: *out_rows = rows; *out_cols = cols; return ZG_OK;
+    case 1: case 3: *out_rows = cols; *out_cols = rows; return ZG_OK;
+    }
+    const float cos_abs = std::fabs(cos_a), sin_abs = std::fabs(sin_a), w = (float)cols, h = (float)rows;
+    *out_cols = (uint32_t)std::ceil(w * cos_abs + h * sin_abs);
+    *out_rows = (uint32_t)std::ceil(h * cos_abs + w * sin_abs);
+    return ZG_OK;
+}
+
+int zg_extract(const zg_image *src, const zg_image *dst, const float rect[4], float angle, float cos_a, float sin_a,
+               const zg_method *method, int border, zg_stream stream) {
+    return extract_impl(src, dst, rect, angle, cos_a, sin_a, method, border, as_stream(stream));
+}
+int zg_extract_host(const zg_image *src, const zg_image *dst, const float rect[4], float angle, float cos_a, float sin_a,
+                    const zg_method *method, int border) {
+    ZG_HOST2(extract_impl(&a.dev, &b.dev, rect, angle, cos_a, sin_a, method, border, nullptr))
+}
+
+int zg_crop_dims(const float rect[4], uint32_t *out_rows, uint32_t *out_cols) {
+    ZG_REQUIRE(rect && out_rows && out_cols, ZG_ERR_INVALID_ARGUMENT, "crop: null argument");
+    *out_rows = (uint32_t)std::round(rect_h(rect));
+    *out_cols = (uint32_t)std::round(rect_w(rect));
+    return ZG_OK;
+}
+static int crop_impl(const zg_image *src, const zg_image *dst, const float rect[4], hipStream_t s) {
+    ZG_REQUIRE(rect != nullptr, ZG_ERR_INVALID_ARGUMENT, "crop: null rect");
+    uint32_t r, c;
+    zg_crop_dims(rect, &r, &c);
+    ZG_REQUIRE(dst && dst->rows == r && dst->cols == c, ZG_ERR_DIMENSION_MISMATCH, "crop: destination must be %ux%u", r, c);
+    const zg_method nearest{ZG_INTERP_NEAREST, 0, 0, nullptr};
+    return extract_impl(src, dst, rect, 0.0f, 1.0f, 0.0f, &nearest, ZG_BORDER_ZERO, s);
+}
+int zg_crop(const zg_image *src, const zg_image *dst, const float rect[4], zg_stream stream) {
+    return crop_impl(src, dst, rect, as_stream(stream));
+}
+int zg_crop_host(const zg_image *src, const zg_image *dst, const float rect[4]) {
+    ZG_HOST2(crop_impl(&a.dev, &b.dev, rect, nullptr))
+}
+
+int zg_insert(const zg_image *self, const zg_image *source, const float rect[4], float angle, float cos_a, float sin_a,
+              const zg_method *method, int blend_mode, zg_stream stream) {
+    return insert_impl(self, source, rect, angle, cos_a, sin_a, method, blend_mode, as_stream(stream));
+}
+int zg_insert_host(const zg_image *self, const zg_image *source, const float rect[4], float angle, float cos_a, float sin_a,
+                   const zg_method *method, int blend_mode) {
+    HostStage a, b;
+    int rc;
+    if ((rc = a.upload(self, true, true))) return rc;
+    if ((rc = b.upload(source, true, false))) return rc;
+    if ((rc = insert_impl(&a.dev, &b.dev, rect, angle, cos_a, sin_a, method, blend_mode, nullptr))) return rc;
+    ZG_HIP(hipStreamSynchronize(nullptr));
+    return a.finish();
+}
+
+} // extern "C"

@@ -1,0 +1,250 @@
+// resize_planes.hip — Image(Rgb(u8) / Rgba(u8)).resize: the reference's per-plane u8 resizers.
+//
+// Replaces reference src/image/interpolation.zig:111-186 (split -> plane kernel -> merge) and the plane
+// kernels src/image/channel_ops.zig:144-190 (bilinear, fx = trunc(frac*256), no rounding offset), :193-214
+// (nearest, clamp not mirror), :217-435 (bicubic / Catmull-Rom / Mitchell in 8.8 integers) and :438-493
+// (Lanczos3, f32 weights from @sin).
+//
+// Every one of those kernels is separable in its *coordinates*: the source indices and tap weights of an
+// output pixel depend only on its column (x taps) and its row (y taps). The host builds those two small
+// tables with the reference's exact f32 / integer arithmetic (including Zig-side @sin for Lanczos, which a
+// Zig caller can therefore keep bit-faithful), and the device kernel is pure integer (or f32 mul/add)
+// accumulation over interleaved pixels: channels are independent, so no split / merge pass exists here.
+// Per output pixel the kernel reads T x T source pixels and writes one: that is the algorithmic traffic.
+#include "zg_common.h"
+#include "zg_hostmath.h"
+
+#include <cmath>
+#include <cstring>
+#include <list>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace zg {
+
+enum : int { RC_NEAREST = 0, RC_BILINEAR = 1, RC_CUBIC_INT = 2, RC_LANCZOS = 3 };
+
+// One axis of taps: for destination index d, source indices idx[d*T + k] and weights w[d*T + k]
+// (int32, or f32 bits for Lanczos).
+struct AxisTable {
+    const int32_t *idx;
+    const int32_t *w;
+};
+
+template <int PIX, int CLS, int T>
+__global__ __launch_bounds__(256) void k_resize_planes(DImg src, DImg dst, AxisTable tx, AxisTable ty, int tiles_x) {
+    using P = Px<PIX>;
+    using Vec = typename P::Vec;
+    constexpr int C = P::C;
+    const int nwg = gridDim.x, per_xcd = nwg >> 3;
+    int wg = blockIdx.x;
+    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    const int tyi = wg / tiles_x, txi = wg - tyi * tiles_x;
+    const int c = txi * 64 + (int)(threadIdx.x & 63);
+    const int r = __builtin_amdgcn_readfirstlane(tyi * 4 + (int)(threadIdx.x >> 6)); // one row per wave
+    if (r >= dst.rows || c >= dst.cols) return;
+
+    int xi[T], yi[T];
+#pragma unroll
+    for (int k = 0; k < T; ++k) { xi[k] = tx.idx[c * T + k]; yi[k] = ty.idx[r * T + k]; }
+
+    Vec out;
+    if constexpr (CLS == RC_NEAREST) {
+        out = P::load(src.data, (size_t)yi[0] * src.stride + (size_t)xi[0]);
+    } else if constexpr (CLS == RC_BILINEAR) {
+        const int fx = tx.w[c * T + 1], fy = ty.w[r * T + 1]; // w = {256 - f, f}
+        const Vec tl = P::load(src.data, (size_t)yi[0] * src.stride + (size_t)xi[0]);
+        const Vec tr = P::load(src.data, (size_t)yi[0] * src.stride + (size_t)xi[1]);
+        const Vec bl = P::load(src.data, (size_t)yi[1] * src.stride + (size_t)xi[0]);
+        const Vec br = P::load(src.data, (size_t)yi[1] * src.stride + (size_t)xi[1]);
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            const int top = (int)tl[ch] * (256 - fx) + (int)tr[ch] * fx;
+            const int bottom = (int)bl[ch] * (256 - fx) + (int)br[ch] * fx;
+            const int result = (top * (256 - fy) + bottom * fy) >> 16; // @divTrunc(.., 65536), operand >= 0
+            out[ch] = (uint8_t)result;                                  // <= 255 by construction
+        }
+    } else if constexpr (CLS == RC_CUBIC_INT) {
+        int wx[T], wy[T];
+#pragma unroll
+        for (int k = 0; k < T; ++k) { wx[k] = tx.w[c * T + k]; wy[k] = ty.w[r * T + k]; }
+        int sum[C], weight_sum = 0;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) sum[ch] = 0;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                const int w = (wx[i] * wy[j]) / 256; // @divTrunc: signed, toward zero
+                const Vec p = P::load(src.data, (size_t)yi[j] * src.stride + (size_t)xi[i]);
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) sum[ch] += (int)p[ch] * w;
+                weight_sum += w;
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) out[ch] = clamp_u8_i32(weight_sum != 0 ? sum[ch] / weight_sum : 0);
+    } else {
+        float wx[T], wy[T];
+#pragma unroll
+        for (int k = 0; k < T; ++k) { wx[k] = __int_as_float(tx.w[c * T + k]); wy[k] = __int_as_float(ty.w[r * T + k]); }
+        float sum[C], weight_sum = 0;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) sum[ch] = 0;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                const float w = wx[i] * wy[j];
+                const Vec p = P::load(src.data, (size_t)yi[j] * src.stride + (size_t)xi[i]);
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    const float prod = (float)p[ch] * w;
+                    sum[ch] = sum[ch] + prod;
+                }
+                weight_sum = weight_sum + w;
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) out[ch] = clamp_u8_f32(weight_sum != 0 ? sum[ch] / weight_sum : 0.0f);
+    }
+    P::store(dst.data, (size_t)r * dst.stride + (size_t)c, out);
+}
+
+// ---- host-side tap tables (channel_ops.zig arithmetic, verbatim) --------------------------------------
+static int32_t k_bicubic_i(int32_t t) {
+    const int32_t at = t < 0 ? -t : t;
+    if (at <= 256) { const int32_t t2 = at * at / 256, t3 = t2 * at / 256; return 256 - 2 * t2 + t3; }
+    if (at <= 512) { const int32_t t2 = at * at / 256, t3 = t2 * at / 256; return 4 * 256 - 8 * at + 5 * t2 - t3; }
+    return 0;
+}
+static int32_t k_catmull_i(int32_t t) {
+    const int32_t at = t < 0 ? -t : t;
+    if (at <= 256) { const int32_t t2 = at * at / 256, t3 = t2 * at / 256; return 256 - (5 * t2) / 2 + (3 * t3) / 2; }
+    if (at <= 512) { const int32_t t2 = at * at / 256, t3 = t2 * at / 256; return 2 * 256 - 4 * at + (5 * t2) / 2 - t3 / 2; }
+    return 0;
+}
+static int32_t k_mitchell_i(int32_t t) {
+    const int64_t at = t < 0 ? -(int64_t)t : t, s = 256, s2 = s * s, s3 = s2 * s;
+    if (at < s) { const int64_t at2 = at * at, at3 = at2 * at; return (int32_t)((21 * at3 - 36 * at2 * s + 16 * s3) / (18 * s2)); }
+    if (at < 2 * s) { const int64_t at2 = at * at, at3 = at2 * at; return (int32_t)((-7 * at3 + 36 * at2 * s - 60 * at * s2 + 32 * s3) / (18 * s2)); }
+    return 0;
+}
+static float k_lanczos_plane(float x) { // channel_ops.zig:446-454
+    if (x == 0) return 1.0f;
+    const float a = 3.0f;
+    if (std::fabs(x) >= a) return 0.0f;
+    const float pi_x = 3.14159265358979323846f * x;
+    return (a * hostmath::sin_f32(pi_x) * hostmath::sin_f32(pi_x / a)) / (pi_x * pi_x);
+}
+
+static void build_axis(int kind, uint32_t src_n, uint32_t dst_n, int taps, std::vector<int32_t> &idx, std::vector<int32_t> &w) {
+    idx.assign((size_t)dst_n * taps, 0);
+    w.assign((size_t)dst_n * taps, 0);
+    const float ratio = (float)src_n / (float)dst_n;
+    for (uint32_t d = 0; d < dst_n; ++d) {
+        const float sf = ((float)d + 0.5f) * ratio - 0.5f;
+        if (kind == ZG_INTERP_NEAREST) { // @max(0, @min(n - 1, @as(u32, @round(s))))
+            uint32_t i = (uint32_t)std::round(sf);
+            if (i > src_n - 1) i = src_n - 1;
+            idx[d] = (int32_t)i;
+            continue;
+        }
+        const float fl = std::floor(sf);
+        const int base = (int)fl;
+        if (kind == ZG_INTERP_BILINEAR) {
+            const int32_t f = (int32_t)std::trunc((sf - fl) * 256.0f);
+            idx[d * 2 + 0] = resolve_index(base, (int)src_n, ZG_BORDER_MIRROR);
+            idx[d * 2 + 1] = resolve_index(base + 1, (int)src_n, ZG_BORDER_MIRROR);
+            w[d * 2 + 0] = 256 - f;
+            w[d * 2 + 1] = f;
+        } else if (kind == ZG_INTERP_LANCZOS) {
+            const float f = sf - fl;
+            for (int k = 0; k < 6; ++k) {
+                idx[d * 6 + k] = resolve_index(base + k - 2, (int)src_n, ZG_BORDER_MIRROR);
+                const float wk = k_lanczos_plane((float)(k - 2) - f);
+                int32_t bits;
+                std::memcpy(&bits, &wk, 4);
+                w[d * 6 + k] = bits;
+            }
+        } else {
+            const int32_t f = (int32_t)std::trunc((sf - fl) * 256.0f);
+            for (int k = 0; k < 4; ++k) {
+                idx[d * 4 + k] = resolve_index(base + k - 1, (int)src_n, ZG_BORDER_MIRROR);
+                const int32_t t = k * 256 - 256 - f;
+                w[d * 4 + k] = kind == ZG_INTERP_BICUBIC ? k_bicubic_i(t) : (kind == ZG_INTERP_CATMULL_ROM ? k_catmull_i(t) : k_mitchell_i(t));
+            }
+        }
+    }
+}
+
+// Device-resident tables, cached per (device, kind, src_n, dst_n): repeated resizes of the same geometry
+// (video frames, batches) upload nothing and are graph-capturable after the first call.
+struct AxisBuf { int32_t *dev = nullptr; size_t n = 0; };
+static std::mutex g_cache_mu;
+static std::map<std::tuple<int, int, uint32_t, uint32_t>, AxisBuf> g_cache;
+static std::list<std::tuple<int, int, uint32_t, uint32_t>> g_cache_order;
+
+static int axis_table(int kind, uint32_t src_n, uint32_t dst_n, int taps, AxisTable &out) {
+    int dev = 0;
+    ZG_HIP(hipGetDevice(&dev));
+    const auto key = std::make_tuple(dev, kind, src_n, dst_n);
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    auto it = g_cache.find(key);
+    if (it == g_cache.end()) {
+        std::vector<int32_t> idx, w;
+        build_axis(kind, src_n, dst_n, taps, idx, w);
+        AxisBuf buf;
+        buf.n = idx.size();
+        ZG_HIP(hipMalloc((void **)&buf.dev, 2 * buf.n * sizeof(int32_t)));
+        ZG_HIP(hipMemcpy(buf.dev, idx.data(), buf.n * sizeof(int32_t), hipMemcpyHostToDevice));
+        ZG_HIP(hipMemcpy(buf.dev + buf.n, w.data(), buf.n * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (g_cache.size() >= 64) { // bounded: drop the oldest geometry
+            const auto old = g_cache_order.front();
+            g_cache_order.pop_front();
+            (void)hipFree(g_cache[old].dev);
+            g_cache.erase(old);
+        }
+        it = g_cache.emplace(key, buf).first;
+        g_cache_order.push_back(key);
+    }
+    out.idx = it->second.dev;
+    out.w = it->second.dev + it->second.n;
+    return ZG_OK;
+}
+
+template <int PIX, int CLS, int T>
+static int launch_planes(const zg_image *src, const zg_image *dst, const AxisTable &tx, const AxisTable &ty, hipStream_t s) {
+    const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, 4);
+    hipLaunchKernelGGL((k_resize_planes<PIX, CLS, T>), dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, dimg(src), dimg(dst), tx, ty, tiles_x);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+template <int PIX>
+static int resize_planes_pix(const zg_image *src, const zg_image *dst, int kind, const AxisTable &tx, const AxisTable &ty, hipStream_t s) {
+    switch (kind) {
+    case ZG_INTERP_NEAREST: return launch_planes<PIX, RC_NEAREST, 1>(src, dst, tx, ty, s);
+    case ZG_INTERP_BILINEAR: return launch_planes<PIX, RC_BILINEAR, 2>(src, dst, tx, ty, s);
+    case ZG_INTERP_LANCZOS: return launch_planes<PIX, RC_LANCZOS, 6>(src, dst, tx, ty, s);
+    default: return launch_planes<PIX, RC_CUBIC_INT, 4>(src, dst, tx, ty, s);
+    }
+}
+
+// Image(Rgb(u8) / Rgba(u8)).resize for differing sizes; caller (resize_impl) has validated the images.
+int resize_planes_impl(const zg_image *src, const zg_image *dst, const zg_method *method, hipStream_t s) {
+    const int kind = method->kind;
+    const int taps = kind == ZG_INTERP_NEAREST ? 1 : (kind == ZG_INTERP_BILINEAR ? 2 : (kind == ZG_INTERP_LANCZOS ? 6 : 4));
+    AxisTable tx{}, ty{};
+    int rc;
+    if ((rc = axis_table(kind, src->cols, dst->cols, taps, tx))) return rc;
+    if ((rc = axis_table(kind, src->rows, dst->rows, taps, ty))) return rc;
+    if (src->pixel == ZG_PIXEL_RGB_U8) return resize_planes_pix<ZG_PIXEL_RGB_U8>(src, dst, kind, tx, ty, s);
+    return resize_planes_pix<ZG_PIXEL_RGBA_U8>(src, dst, kind, tx, ty, s);
+}
+
+} // namespace zg

@@ -1,0 +1,196 @@
+// zg_sample.h — device-side point sampling: Image(T).interpolate for every pixel layout.
+//
+// Replaces reference src/image/interpolation.zig:72-84 (dispatch + finite/range guard), :306-311 (nearest),
+// :313-407 (bilinear: fixed-point for u8 fields, lerpFloat for f32 fields), :426-519 (kernel interpolation)
+// and the kernels :222-300. Arithmetic order, rounding and the absence of FMA follow the reference exactly;
+// the only table (Lanczos3, built at comptime with Zig's @sin there) comes in from the host.
+#pragma once
+#include "zg_common.h"
+
+#pragma clang fp contract(off)
+
+namespace zg {
+
+struct MethodArg {
+    int kind;          // zg_interp
+    float b, c;        // Mitchell
+    const float *lut;  // device pointer, 1025-entry Lanczos3 table (nullptr unless kind == lanczos)
+};
+
+// resolveIndex on a 64-bit index (sampling coordinates can be astronomically large near a homography's
+// horizon; the reference resolves them in isize). 32-bit fast path for everything realistic.
+__device__ inline int resolve_index64(long long idx, int length, int border) {
+    if (idx >= 0 && idx < (long long)length) return (int)idx;
+    if (idx > -(1ll << 30) && idx < (1ll << 30)) return resolve_index((int)idx, length, border);
+    switch (border) {
+    case ZG_BORDER_ZERO: return -1;
+    case ZG_BORDER_REPLICATE:
+        if (length == 0) return -1;
+        return idx < 0 ? 0 : length - 1;
+    case ZG_BORDER_MIRROR: {
+        if (length <= 0) return -1;
+        if (length == 1) return 0;
+        const long long period = 2ll * (length - 1);
+        long long m = idx % period;
+        if (m < 0) m += period;
+        return (int)(m >= length ? period - m : m);
+    }
+    default: {
+        if (length == 0) return -1;
+        long long m = idx % (long long)length;
+        if (m < 0) m += length;
+        return (int)m;
+    }
+    }
+}
+
+// An integral-valued float coordinate (already floored / rounded) plus a small tap offset.
+struct BaseIdx {
+    long long wide;
+    int narrow;
+    bool is_narrow;
+    __device__ explicit BaseIdx(float integral) {
+        is_narrow = fabsf(integral) < 1.0e9f;
+        narrow = is_narrow ? (int)integral : 0;
+        wide = is_narrow ? 0 : (long long)integral;
+    }
+    __device__ int resolve(int offset, int length, int border) const {
+        if (is_narrow) return resolve_index(narrow + offset, length, border);
+        return resolve_index64(wide + offset, length, border);
+    }
+};
+
+// ---- kernels (interpolation.zig:222-300) ----------------------------------------------------
+__device__ inline float bicubic_kernel(float t) {
+    const float at = fabsf(t);
+    if (at <= 1) return 1 - 2 * at * at + at * at * at;
+    if (at <= 2) return 4 - 8 * at + 5 * at * at - at * at * at;
+    return 0;
+}
+__device__ inline float catmull_rom_kernel(float x) {
+    const float ax = fabsf(x);
+    if (ax <= 1) return 1.5f * ax * ax * ax - 2.5f * ax * ax + 1;
+    if (ax <= 2) return -0.5f * ax * ax * ax + 2.5f * ax * ax - 4 * ax + 2;
+    return 0;
+}
+__device__ inline float mitchell_kernel(float x, float m_b, float m_c) {
+    const float ax = fabsf(x), ax2 = ax * ax, ax3 = ax2 * ax;
+    if (ax < 1) return ((12 - 9 * m_b - 6 * m_c) * ax3 + (-18 + 12 * m_b + 6 * m_c) * ax2 + (6 - 2 * m_b)) / 6;
+    if (ax < 2)
+        return ((-m_b - 6 * m_c) * ax3 + (6 * m_b + 30 * m_c) * ax2 + (-12 * m_b - 48 * m_c) * ax + (8 * m_b + 24 * m_c)) / 6;
+    return 0;
+}
+__device__ inline float lanczos3_kernel_lut(const float *lut, float x) {
+    const float ax = fabsf(x);
+    if (ax >= 3.0f) return 0;
+    const float step = (float)(1024.0 / 3.0);
+    const float pos = ax * step;
+    const int idx = (int)truncf(pos);
+    const float frac = pos - (float)idx;
+    return lut[idx] * (1.0f - frac) + lut[idx + 1] * frac;
+}
+
+template <int KIND> __device__ inline float eval_kernel(const MethodArg &m, float t) {
+    if constexpr (KIND == ZG_INTERP_BICUBIC) return bicubic_kernel(t);
+    else if constexpr (KIND == ZG_INTERP_CATMULL_ROM) return catmull_rom_kernel(t);
+    else if constexpr (KIND == ZG_INTERP_MITCHELL) return mitchell_kernel(t, m.b, m.c);
+    else return lanczos3_kernel_lut(m.lut, t);
+}
+
+// ---- interpolate ---------------------------------------------------------------------------
+// Returns false for the reference's `null` (caller stores a zeroed pixel).
+template <int PIX, int KIND>
+__device__ inline bool interpolate(const DImg &img, float x, float y, const MethodArg &m, int border,
+                                   typename Px<PIX>::Vec &out) {
+    using P = Px<PIX>;
+    using Vec = typename P::Vec;
+    using Elem = typename P::Elem;
+    constexpr int C = P::C;
+    constexpr bool IS_F = std::is_same<Elem, float>::value;
+
+    if (!isfinite(x) || !isfinite(y)) return false;
+    const float range_limit = 4611686018427387904.0f; // @floatFromInt(maxInt(isize) / 2)
+    if (fabsf(x) > range_limit || fabsf(y) > range_limit) return false;
+
+    if constexpr (KIND == ZG_INTERP_NEAREST) {
+        const int col = BaseIdx(roundf(x)).resolve(0, img.cols, border);
+        if (col < 0) return false;
+        const int row = BaseIdx(roundf(y)).resolve(0, img.rows, border);
+        if (row < 0) return false;
+        out = P::load(img.data, (size_t)row * img.stride + (size_t)col);
+        return true;
+    } else if constexpr (KIND == ZG_INTERP_BILINEAR) {
+        const float fl = floorf(x), ft = floorf(y);
+        const BaseIdx left(fl), top(ft);
+        const int r0 = top.resolve(0, img.rows, border), r1 = top.resolve(1, img.rows, border);
+        const int c0 = left.resolve(0, img.cols, border), c1 = left.resolve(1, img.cols, border);
+        if (border == ZG_BORDER_MIRROR && (r0 < 0 || r1 < 0 || c0 < 0 || c1 < 0)) return false;
+        Vec tl = P::zero(), tr = P::zero(), bl = P::zero(), br = P::zero();
+        if (r0 >= 0 && c0 >= 0) tl = P::load(img.data, (size_t)r0 * img.stride + (size_t)c0);
+        if (r0 >= 0 && c1 >= 0) tr = P::load(img.data, (size_t)r0 * img.stride + (size_t)c1);
+        if (r1 >= 0 && c0 >= 0) bl = P::load(img.data, (size_t)r1 * img.stride + (size_t)c0);
+        if (r1 >= 0 && c1 >= 0) br = P::load(img.data, (size_t)r1 * img.stride + (size_t)c1);
+        const float lr = x - fl, tb = y - ft; // as(f32, left) == floorf(x) for every finite in-range x
+        if constexpr (IS_F) {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch)
+                out[ch] = (1 - tb) * ((1 - lr) * tl[ch] + lr * tr[ch]) + tb * ((1 - lr) * bl[ch] + lr * br[ch]);
+        } else {
+            const int fx = (int)roundf(lr * 256), fy = (int)roundf(tb * 256);
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) {
+                const int top_val = (int)tl[ch] * (256 - fx) + (int)tr[ch] * fx;
+                const int bottom_val = (int)bl[ch] * (256 - fx) + (int)br[ch] * fx;
+                const int result = (top_val * (256 - fy) + bottom_val * fy + 32768) / 65536; // >= 0: trunc == floor
+                out[ch] = clamp_u8_i32(result);
+            }
+        }
+        return true;
+    } else {
+        constexpr int R = KIND == ZG_INTERP_LANCZOS ? 3 : 2;
+        constexpr int W = 2 * R;
+        const float flx = floorf(x), fly = floorf(y);
+        const BaseIdx ix(flx), iy(fly);
+        const float fx = x - flx, fy = y - fly;
+        float xw[W], yw[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            xw[i] = eval_kernel<KIND>(m, (float)(i - (R - 1)) - fx);
+            yw[i] = eval_kernel<KIND>(m, (float)(i - (R - 1)) - fy);
+        }
+        int cols_idx[W];
+#pragma unroll
+        for (int i = 0; i < W; ++i) cols_idx[i] = ix.resolve(i - (R - 1), img.cols, border);
+        float sums[C];
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) sums[ch] = 0;
+        float weight_sum = 0;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const int py = iy.resolve(j - (R - 1), img.rows, border);
+            if (py < 0) continue;
+            const size_t rowoff = (size_t)py * img.stride;
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                if (cols_idx[i] < 0) continue;
+                const Vec p = P::load(img.data, rowoff + (size_t)cols_idx[i]);
+                const float weight = xw[i] * yw[j];
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                    const float prod = (float)p[ch] * weight;
+                    sums[ch] = sums[ch] + prod;
+                }
+                weight_sum = weight_sum + weight;
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            const float val = weight_sum != 0 ? sums[ch] / weight_sum : 0.0f;
+            if constexpr (IS_F) out[ch] = val;
+            else out[ch] = clamp_u8_f32(val);
+        }
+        return true;
+    }
+}
+
+} // namespace zg
