@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--ring", type=int, default=4, help="distinct (src, dst) frame pairs to rotate through")
     ap.add_argument("--eager", action="store_true", help="launch every step from Python instead of replaying a HIP graph")
+    ap.add_argument("--scatter-gather", action="store_true",
+                    help="N>1 only: also time BASELINE configs[4] end to end (RCCL scatter -> blur+resize -> gather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     return ap.parse_args()
@@ -156,10 +158,8 @@ def main():
     run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from zignal_amd import sharding
+    elapsed = sharding.max_over_ranks(elapsed, torch.device("cuda", local_rank))  # the slowest rank is the clock
 
     pixels = ROWS * COLS
     value = world * pixels * args.steps / elapsed / 1e6
@@ -205,10 +205,51 @@ def main():
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
 
+    if world > 1 and args.scatter_gather:
+        # Not the headline: BASELINE configs[4] end to end — rank 0 holds the batch, shards fan out over RCCL/xGMI
+        # (grouped send/recv), every rank runs blur+resize on its shard, results are gathered back.
+        try:
+            sg = scatter_gather_leg(zg, torch, sharding, rank, world, local_rank)
+            if rank == 0:
+                result["scatter_gather_config5"] = sg
+        except Exception as e:
+            if rank == 0:
+                result["scatter_gather_config5"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def scatter_gather_leg(zg, torch, sharding, rank, world, local_rank, frames_per_gpu=16):
+    import ctypes as C
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    n, rows, cols = frames_per_gpu * world, 1080, 1920
+    batch = torch.randint(0, 256, (n, rows, cols, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+    lib = zg.lib()
+    m = zg.Interpolation.bilinear._c()
+
+    def once():
+        mine = sharding.scatter_frames(batch, n, (rows, cols, 4), torch.uint8, dev)
+        out = torch.empty((mine.shape[0], 540, 960, 4), dtype=torch.uint8, device=dev)
+        rc = lib.zg_batch_blur_resize(C.c_void_p(mine.data_ptr()), int(mine.shape[0]), rows, cols, 3, C.c_float(SIGMA),
+                                      C.c_void_p(out.data_ptr()), 540, 960, C.byref(m), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, lib.zg_last_error()
+        return sharding.gather_frames(out, n)
+
+    once()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        once()
+    torch.cuda.synchronize()
+    dist.barrier()
+    sec = sharding.max_over_ranks((time.perf_counter() - t0) / reps, dev)
+    return {"frames": n, "seconds": round(sec, 6), "Mpixels/s_end_to_end": round(n * rows * cols / sec / 1e6, 1),
+            "note": "includes the xGMI scatter of 8.3 MB/frame and gather of 2.1 MB/frame; kernel-only rate is `value`"}
 
 
 def _time_kernel(torch, fn, n=50, warm=5):
@@ -225,29 +266,81 @@ def _time_kernel(torch, fn, n=50, warm=5):
 
 
 def extras(zg, torch, np):
-    """Secondary numbers (not the headline): the other halves of the metric on their own configs."""
+    """Secondary numbers (not the headline): the other configurations of BASELINE.json, each with its
+    algorithmic bytes so the same roofline arithmetic applies. Ring-rotated buffers, HIP events."""
     out = {}
-    try:
+    I = zg.Interpolation
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:  # an extra must never take the headline down
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+
+    def rate(ms, px, bytes_alg):
+        return {"ms": round(ms, 5), "Mpixels/s": round(px / ms / 1e3, 1), "GB/s_algorithmic": round(bytes_alg / ms / 1e6, 1),
+                "frac_of_8TB/s": round(bytes_alg / ms / 1e6 / HBM_PEAK_GBS, 4)}
+
+    def u8_frames(n, shape):
+        return [torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda") for _ in range(n)]
+
+    def blur_u8():
         ring = 8
-        srcs = [torch.randint(0, 256, (ROWS, COLS, 4), dtype=torch.uint8, device="cuda") for _ in range(ring)]
-        dsts = [torch.empty_like(s) for s in srcs]
-        im = [(zg.Image(s), zg.Image(d)) for s, d in zip(srcs, dsts)]
+        im = [(zg.Image(s), zg.Image(torch.empty_like(s))) for s in u8_frames(ring, (ROWS, COLS, 4))]
         ms = _time_kernel(torch, lambda i: im[i % ring][0].gaussian_blur(SIGMA, out=im[i % ring][1]))
-        out["gaussian_blur_rgba_u8_4096"] = {"ms": round(ms, 5), "Mpixels/s": round(ROWS * COLS / ms / 1e3, 1),
-                                             "GB/s_algorithmic(8B/px)": round(8 * ROWS * COLS / ms / 1e6, 1)}
-    except Exception as e:  # an extra must never take the headline down
-        out["gaussian_blur_rgba_u8_4096"] = {"error": str(e)}
-    try:
+        return rate(ms, ROWS * COLS, 8 * ROWS * COLS)  # 4 B read + 4 B written per pixel
+
+    def resize_u8():
         ring = 8
-        srcs = [torch.randint(0, 256, (ROWS, COLS, 4), dtype=torch.uint8, device="cuda") for _ in range(ring)]
-        dsts = [torch.empty((1024, 1024, 4), dtype=torch.uint8, device="cuda") for _ in range(ring)]
-        im = [(zg.Image(s), zg.Image(d)) for s, d in zip(srcs, dsts)]
-        ms = _time_kernel(torch, lambda i: im[i % ring][0].resize(im[i % ring][1], zg.Interpolation.bilinear))
-        out["resize_bilinear_rgba_u8_4096_to_1024"] = {
-            "ms": round(ms, 5), "Mpixels/s(source)": round(ROWS * COLS / ms / 1e3, 1),
-            "GB/s_algorithmic(20B/out-px)": round(20 * 1024 * 1024 / ms / 1e6, 1)}
-    except Exception as e:
-        out["resize_bilinear_rgba_u8_4096_to_1024"] = {"error": str(e)}
+        im = [(zg.Image(s), zg.Image(torch.empty((1024, 1024, 4), dtype=torch.uint8, device="cuda"))) for s in u8_frames(ring, (ROWS, COLS, 4))]
+        ms = _time_kernel(torch, lambda i: im[i % ring][0].resize(im[i % ring][1], I.bilinear))
+        r = rate(ms, ROWS * COLS, 20 * 1024 * 1024)  # 4 taps x 4 B + 4 B per OUTPUT pixel (strict)
+        r["GB/s_sector_basis"] = round((ROWS * COLS * 4 // 2 + 4 * 1024 * 1024) / ms / 1e6, 1)  # rows 1,2 mod 4 are touched whole
+        return r
+
+    def oklab():
+        ring = 8
+        im = [(zg.Image(s), zg.Image(torch.empty((ROWS, COLS, 3), dtype=torch.float32, device="cuda"))) for s in u8_frames(ring, (ROWS, COLS, 4))]
+        ms = _time_kernel(torch, lambda i: im[i % ring][0].convert(zg.CS_OKLAB, np.float32, out=im[i % ring][1]))
+        return rate(ms, ROWS * COLS, 16 * ROWS * COLS)  # 4 B read + 12 B written
+
+    def warp(kind):
+        from oracle import pyoracle as oracle  # host-side 4-point solve only (f64, a few flops)
+        hmat = oracle.homography_from_4pts([(0, 0), (4095, 0), (0, 4095), (4095, 4095)],
+                                           [(200, 120), (3900, 60), (90, 3980), (4000, 4050)])
+        tr = zg.ProjectiveTransform(hmat)
+        ring = 4
+        if kind == "u8":
+            srcs, bpp = u8_frames(ring, (ROWS, COLS, 4)), 8
+        else:
+            srcs, bpp = [torch.rand((ROWS, COLS, 4), dtype=torch.float32, device="cuda") for _ in range(ring)], 32
+        im = [(zg.Image(s), zg.Image(torch.empty_like(s))) for s in srcs]
+        ms = _time_kernel(torch, lambda i: im[i % ring][0].warp(tr, im[i % ring][1], I.bicubic), n=20, warm=3)
+        return rate(ms, ROWS * COLS, bpp * ROWS * COLS)
+
+    def batch():
+        import ctypes as C
+        n, rows, cols = 64, 1080, 1920
+        src = torch.randint(0, 256, (n, rows, cols, 4), dtype=torch.uint8, device="cuda")
+        dst = torch.empty((n, 540, 960, 4), dtype=torch.uint8, device="cuda")
+        m = I.bilinear._c()
+        lib = zg.lib()
+
+        def run(_):
+            rc = lib.zg_batch_blur_resize(C.c_void_p(src.data_ptr()), n, rows, cols, 3, C.c_float(SIGMA), C.c_void_p(dst.data_ptr()),
+                                          540, 960, C.byref(m), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0, lib.zg_last_error()
+        ms = _time_kernel(torch, run, n=10, warm=2)
+        r = rate(ms, n * rows * cols, n * 10368000)  # fused bound: 8 294 400 read + 2 073 600 written per frame
+        r["frames"] = n
+        return r
+
+    leg("config2b_gaussian_blur_rgba_u8_4096", blur_u8)
+    leg("config3_resize_bilinear_rgba_u8_4096_to_1024", resize_u8)
+    leg("config3_convert_rgba_u8_to_oklab_f32_4096", oklab)
+    leg("config4_warp_projective_bicubic_rgba_u8_4096", lambda: warp("u8"))
+    leg("config4_warp_projective_bicubic_rgba_f32_4096", lambda: warp("f32"))
+    leg("config5_batch_blur_resize_64x1080p_rgba_u8", batch)
     return out
 
 
