@@ -1,0 +1,76 @@
+// Known-answer tests of the C++ host mirror, transcribed from the reference's own unit tests
+// (paths relative to /root/reference/src). Needs a GPU: built by build(), run by tests/test_cpp_mirror.py.
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../zignal_amd/cpp/zignal_hip.hpp"
+
+using namespace zignal;
+
+static int failures = 0;
+#define EXPECT(cond) do { if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
+
+int main() {
+    if (zg_init(0) != ZG_OK) { std::printf("no gfx950 device: %s\n", zg_last_error()); return 77; }
+
+    { // image/tests/filters.zig:370-398 "convolve identity kernel"
+        auto image = Image<uint8_t>::init(3, 3), result = Image<uint8_t>::init(3, 3);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) image.at(r, c) = (uint8_t)(r * 3 + c + 10);
+        const float identity[3][3] = {{0, 0, 0}, {0, 1, 0}, {0, 0, 0}};
+        image.convolve(result, identity, BorderMode::zero);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) EXPECT(image.at(r, c) == result.at(r, c));
+    }
+    { // image/tests/filters.zig:602-632 "stride bug in f32 separable convolution"
+        auto base = Image<float>::init(5, 5), out = Image<float>::init(3, 3);
+        for (int r = 0; r < 5; ++r) for (int c = 0; c < 5; ++c) base.at(r, c) = (float)(r * 10 + c);
+        auto view = base.view({1, 1, 4, 4});
+        view.convolveSeparable(out, {1.0f}, {1.0f}, BorderMode::zero);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) EXPECT(view.at(r, c) == out.at(r, c));
+    }
+    { // image.zig:962, :970
+        auto a = Image<float>::init(4, 4), b = Image<float>::init(4, 5);
+        bool threw = false;
+        try { a.gaussianBlur(b, 1.0f); } catch (const DimensionMismatch &) { threw = true; }
+        EXPECT(threw);
+        threw = false;
+        try { a.gaussianBlur(a, -1.0f); } catch (const InvalidArgument &) { threw = true; }
+        EXPECT(threw);
+    }
+    { // image/tests/interpolation.zig:422-449 via resize semantics; image/tests/resize.zig:140-161
+        auto src = Image<uint8_t>::init(1, 1), out = Image<uint8_t>::init(10, 10);
+        src.at(0, 0) = 128;
+        auto rect = src.letterbox(out, Interpolation::nearest());
+        EXPECT(rect.width() == 10 && rect.height() == 10);
+        for (int r = 0; r < 10; ++r) for (int c = 0; c < 10; ++c) EXPECT(out.at(r, c) == 128);
+    }
+    { // image/tests/transforms.zig:231-278 "extract rotated rectangle basic and 90deg"
+        auto image = Image<uint8_t>::init(5, 5), out = Image<uint8_t>::init(3, 3);
+        for (int r = 0; r < 5; ++r) for (int c = 0; c < 5; ++c) image.at(r, c) = (uint8_t)(r * 10 + c);
+        image.extract(out, {1, 1, 3, 3}, 0.0f, Interpolation::nearest(), BorderMode::mirror);
+        EXPECT(out.at(0, 0) == 11 && out.at(1, 1) == 22 && out.at(2, 2) == 33 && out.at(0, 2) == 13);
+        image.extract(out, {1, 1, 3, 3}, 3.14159265358979f / 2, Interpolation::nearest(), BorderMode::mirror);
+        EXPECT(out.at(0, 0) == 13 && out.at(0, 2) == 33 && out.at(2, 0) == 11 && out.at(1, 1) == 22);
+    }
+    { // image/tests/transforms.zig:427-456 flips; color.zig:1556-1562 grey
+        uint8_t d[6] = {1, 2, 3, 4, 5, 6};
+        auto im = Image<uint8_t>::initFromSlice(2, 3, d);
+        im.flipLeftRight();
+        EXPECT(d[0] == 3 && d[2] == 1 && d[3] == 6 && d[5] == 4);
+        auto rgb = Image<Rgb<uint8_t>>::init(1, 2);
+        rgb.at(0, 0) = {128, 128, 128};
+        rgb.at(0, 1) = {255, 0, 0};
+        auto gray = rgb.convert<uint8_t>();
+        EXPECT(gray.at(0, 0) == 128 && gray.at(0, 1) == 54);
+        auto lab = rgb.convert<Oklab<float>>();
+        EXPECT(std::fabs(lab.at(0, 1).l - 0.628f) < 4e-3f);
+    }
+    { // image/tests/resize.zig:258-298 "scale image"
+        auto img = Image<uint8_t>::init(100, 100);
+        EXPECT(img.scale(0.5f, Interpolation::bilinear()).rows == 50);
+        bool threw = false;
+        try { img.scale(0.0f, Interpolation::bilinear()); } catch (const InvalidArgument &) { threw = true; }
+        EXPECT(threw);
+    }
+    std::printf(failures ? "%d FAILED\n" : "cpp mirror ok\n", failures);
+    return failures ? 1 : 0;
+}

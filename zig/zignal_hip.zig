@@ -1,0 +1,240 @@
+//! zignal_hip.zig — the Zig side of the drop-in: `Image(T)` whose hot-path methods call libzignal_hip.so.
+//!
+//! NOT COMPILED IN THIS REPOSITORY'S CI: the build image has no Zig toolchain (the reference needs Zig
+//! >= 0.17.0-dev.1441, build.zig.zon:5). It is kept thin on purpose — extern declarations of the C ABI in
+//! include/zignal_hip.h plus method bodies that forward — and mirrors, signature for signature, the methods
+//! of reference src/image.zig that it replaces (line numbers cited per method). Everything that depends on
+//! Zig's own maths (@exp for Gaussian taps, @cos/@sin for rotations, std.math.pow for the sRGB table, @sin
+//! for the Lanczos table) is computed HERE, in Zig, and handed to the library as plain numbers, so results
+//! keep Zig's bit patterns.
+//!
+//! Use: in build.zig add `exe.linkSystemLibrary("zignal_hip")` (+ library path), and
+//! `const Image = @import("zignal_hip.zig").Image;` in place of zignal's Image for the hot path.
+const std = @import("std");
+const zignal = @import("zignal");
+
+pub const BorderMode = zignal.BorderMode; // ordinals == zg_border
+pub const Interpolation = zignal.Interpolation; // tag ordinals == zg_interp
+const Rectangle = zignal.Rectangle;
+const Point = zignal.Point;
+
+// ---- C ABI (include/zignal_hip.h) -----------------------------------------------------------------
+pub const c = struct {
+    pub const ZgImage = extern struct { data: ?*anyopaque, stride: usize, rows: u32, cols: u32, pixel: i32 };
+    pub const ZgMethod = extern struct { kind: i32, b: f32, c: f32, lanczos_lut: ?[*]const f32 };
+    pub extern fn zg_init(device: c_int) c_int;
+    pub extern fn zg_last_error() [*:0]const u8;
+    pub extern fn zg_conv_separable_host(src: *const ZgImage, dst: *const ZgImage, kx: [*]const f32, nkx: u32, ky: [*]const f32, nky: u32, border: c_int) c_int;
+    pub extern fn zg_convolve_host(src: *const ZgImage, dst: *const ZgImage, kernel: [*]const f32, kh: u32, kw: u32, border: c_int) c_int;
+    pub extern fn zg_box_blur_host(src: *const ZgImage, dst: *const ZgImage, radius: u32) c_int;
+    pub extern fn zg_resize_host(src: *const ZgImage, dst: *const ZgImage, method: *const ZgMethod) c_int;
+    pub extern fn zg_letterbox_host(src: *const ZgImage, dst: *const ZgImage, method: *const ZgMethod, rect_out: *[4]u32) c_int;
+    pub extern fn zg_warp_host(src: *const ZgImage, dst: *const ZgImage, kind: c_int, m: [*]const f32, method: *const ZgMethod) c_int;
+    pub extern fn zg_rotate_into_host(src: *const ZgImage, dst: *const ZgImage, angle: f32, cos_a: f32, sin_a: f32, method: *const ZgMethod, border: c_int) c_int;
+    pub extern fn zg_extract_host(src: *const ZgImage, dst: *const ZgImage, rect: *const [4]f32, angle: f32, cos_a: f32, sin_a: f32, method: *const ZgMethod, border: c_int) c_int;
+    pub extern fn zg_insert_host(self: *const ZgImage, source: *const ZgImage, rect: *const [4]f32, angle: f32, cos_a: f32, sin_a: f32, method: *const ZgMethod, blend_mode: c_int) c_int;
+    pub extern fn zg_flip_left_right_host(img: *const ZgImage) c_int;
+    pub extern fn zg_flip_top_bottom_host(img: *const ZgImage) c_int;
+    pub extern fn zg_convert_host(src: *const ZgImage, src_space: c_int, dst: *const ZgImage, dst_space: c_int, srgb_lut: ?[*]const f32) c_int;
+};
+
+pub const Pixel = enum(i32) { u8 = 0, f32 = 1, rgb_u8 = 2, rgba_u8 = 3, rgb_f32 = 4, rgba_f32 = 5 };
+
+fn pixelOf(comptime T: type) Pixel {
+    return switch (T) {
+        u8, zignal.Gray(u8) => .u8,
+        f32, zignal.Gray(f32) => .f32,
+        zignal.Rgb(u8) => .rgb_u8,
+        zignal.Rgba(u8) => .rgba_u8,
+        zignal.Rgb(f32), zignal.Oklab(f32), zignal.Xyz(f32) => .rgb_f32,
+        zignal.Rgba(f32) => .rgba_f32,
+        else => @compileError("zignal_hip: pixel type " ++ @typeName(T) ++ " is not on the GPU hot path"),
+    };
+}
+
+fn check(status: c_int) !void {
+    return switch (status) {
+        0 => {},
+        1 => error.DimensionMismatch,
+        2 => error.InvalidArgument,
+        3 => error.OutOfMemory,
+        else => error.HipFailure,
+    };
+}
+
+fn methodOf(m: Interpolation, lut: ?[*]const f32) c.ZgMethod {
+    return switch (m) {
+        .mitchell => |p| .{ .kind = 4, .b = p.b, .c = p.c, .lanczos_lut = null },
+        .lanczos => .{ .kind = 5, .b = 0, .c = 0, .lanczos_lut = lut },
+        else => .{ .kind = @intFromEnum(std.meta.activeTag(m)), .b = 0, .c = 0, .lanczos_lut = null },
+    };
+}
+
+/// gammaToLinear(i / 255) for all 256 levels with Zig's own std.math.pow (reference src/color.zig:1252-1258).
+fn srgbLut() [256]f32 {
+    var lut: [256]f32 = undefined;
+    for (&lut, 0..) |*v, i| {
+        const cc = @as(f32, @floatFromInt(i)) / 255;
+        v.* = if (cc > 0.04045) std.math.pow(f32, (cc + 0.055) / 1.055, 2.4) else cc / 12.92;
+    }
+    return lut;
+}
+
+/// Drop-in for zignal.Image(T) on the hot path. Fields and non-hot-path methods are zignal's own.
+pub fn Image(comptime T: type) type {
+    return struct {
+        const Self = @This();
+        const Base = zignal.Image(T);
+        base: Base,
+
+        fn desc(img: Base) c.ZgImage {
+            return .{ .data = @ptrCast(img.data.ptr), .stride = img.stride, .rows = img.rows, .cols = img.cols, .pixel = @intFromEnum(pixelOf(T)) };
+        }
+
+        /// reference src/image.zig:935-951
+        pub fn convolveSeparable(self: Self, out: Self, allocator: std.mem.Allocator, kernel_x: []const f32, kernel_y: []const f32, border: BorderMode) !void {
+            _ = allocator; // scratch lives on the device
+            if (!self.base.hasSameShape(out.base)) return error.DimensionMismatch;
+            try check(c.zg_conv_separable_host(&desc(self.base), &desc(out.base), kernel_x.ptr, @intCast(kernel_x.len), kernel_y.ptr, @intCast(kernel_y.len), @intFromEnum(border)));
+        }
+
+        /// reference src/image.zig:954-994 — taps built here with Zig's @exp, then the separable kernel.
+        pub fn gaussianBlur(self: Self, out: Self, allocator: std.mem.Allocator, sigma: f32) !void {
+            if (!self.base.hasSameShape(out.base)) return error.DimensionMismatch;
+            if (sigma == 0) return self.base.copy(out.base);
+            if (sigma < 0) return error.InvalidSigma;
+            const radius: usize = @ceil(3.0 * sigma);
+            const kernel = try allocator.alloc(f32, 2 * radius + 1);
+            defer allocator.free(kernel);
+            var sum: f32 = 0;
+            for (kernel, 0..) |*k, i| {
+                const x = @as(f32, @floatFromInt(i)) - @as(f32, @floatFromInt(radius));
+                k.* = @exp(-(x * x) / (2.0 * sigma * sigma));
+                sum += k.*;
+            }
+            for (kernel) |*k| k.* /= sum;
+            try self.convolveSeparable(out, allocator, kernel, kernel, .mirror);
+        }
+
+        /// reference src/image.zig:917-932 — `kernel` is a comptime-sized 2-D array as in the reference.
+        pub fn convolve(self: Self, out: Self, allocator: std.mem.Allocator, kernel: anytype, border: BorderMode) !void {
+            _ = allocator;
+            if (!self.base.hasSameShape(out.base)) return error.DimensionMismatch;
+            const kh = kernel.len;
+            const kw = kernel[0].len;
+            var flat: [kh * kw]f32 = undefined;
+            inline for (0..kh) |r| inline for (0..kw) |cc| {
+                flat[r * kw + cc] = zignal.meta.as(f32, kernel[r][cc]);
+            };
+            try check(c.zg_convolve_host(&desc(self.base), &desc(out.base), &flat, kh, kw, @intFromEnum(border)));
+        }
+
+        /// reference src/image.zig:635-648
+        pub fn boxBlur(self: Self, out: Self, allocator: std.mem.Allocator, radius: u32) !void {
+            _ = allocator;
+            if (!self.base.hasSameShape(out.base)) return error.DimensionMismatch;
+            try check(c.zg_box_blur_host(&desc(self.base), &desc(out.base), radius));
+        }
+
+        /// reference src/image.zig:523-525 (void: never fails; a HIP failure is a programming error here)
+        pub fn resize(self: Self, out: Self, allocator: std.mem.Allocator, method: Interpolation) void {
+            _ = allocator;
+            check(c.zg_resize_host(&desc(self.base), &desc(out.base), &methodOf(method, null))) catch unreachable;
+        }
+
+        /// reference src/image.zig:530-541
+        pub fn scale(self: Self, allocator: std.mem.Allocator, factor: f32, method: Interpolation) !Self {
+            if (factor <= 0) return error.InvalidScaleFactor;
+            const new_rows: u32 = @round(@as(f32, @floatFromInt(self.base.rows)) * factor);
+            const new_cols: u32 = @round(@as(f32, @floatFromInt(self.base.cols)) * factor);
+            if (new_rows == 0 or new_cols == 0) return error.InvalidDimensions;
+            const scaled: Self = .{ .base = try .init(allocator, new_rows, new_cols) };
+            self.resize(scaled, allocator, method);
+            return scaled;
+        }
+
+        /// reference src/image.zig:546-548
+        pub fn letterbox(self: Self, out: Self, allocator: std.mem.Allocator, method: Interpolation) Rectangle(u32) {
+            _ = allocator;
+            var r: [4]u32 = undefined;
+            check(c.zg_letterbox_host(&desc(self.base), &desc(out.base), &methodOf(method, null), &r)) catch unreachable;
+            return .init(r[0], r[1], r[2], r[3]);
+        }
+
+        /// reference src/image.zig:621-623 — `transform` is a Similarity / Affine / ProjectiveTransform(f32).
+        pub fn warp(self: Self, out: Self, transform: anytype, method: Interpolation) void {
+            const Tr = @TypeOf(transform);
+            if (@hasField(Tr, "bias")) {
+                const m = [6]f32{ transform.matrix.items[0][0], transform.matrix.items[0][1], transform.matrix.items[1][0], transform.matrix.items[1][1], transform.bias.items[0][0], transform.bias.items[1][0] };
+                check(c.zg_warp_host(&desc(self.base), &desc(out.base), 1, &m, &methodOf(method, null))) catch unreachable;
+            } else {
+                var m: [9]f32 = undefined;
+                inline for (0..3) |r| inline for (0..3) |cc| {
+                    m[r * 3 + cc] = transform.matrix.items[r][cc];
+                };
+                check(c.zg_warp_host(&desc(self.base), &desc(out.base), 2, &m, &methodOf(method, null))) catch unreachable;
+            }
+        }
+
+        /// reference src/image.zig:566-568 — @cos / @sin evaluated in Zig.
+        pub fn rotateInto(self: Self, out: Self, angle: f32, method: Interpolation, border: BorderMode) void {
+            check(c.zg_rotate_into_host(&desc(self.base), &desc(out.base), angle, @cos(angle), @sin(angle), &methodOf(method, null), @intFromEnum(border))) catch unreachable;
+        }
+
+        /// reference src/image.zig:558-562
+        pub fn rotate(self: Self, allocator: std.mem.Allocator, angle: f32, method: Interpolation, border: BorderMode) !Self {
+            const bounds = self.base.rotateBounds(angle); // pure host arithmetic, stays zignal's
+            const rotated: Self = .{ .base = try .init(allocator, bounds.rows, bounds.cols) };
+            self.rotateInto(rotated, angle, method, border);
+            return rotated;
+        }
+
+        /// reference src/image.zig:593-595
+        pub fn extract(self: Self, out: Self, rect: Rectangle(f32), angle: f32, method: Interpolation, border: BorderMode) void {
+            const r = [4]f32{ rect.l, rect.t, rect.r, rect.b };
+            check(c.zg_extract_host(&desc(self.base), &desc(out.base), &r, angle, @cos(angle), @sin(angle), &methodOf(method, null), @intFromEnum(border))) catch unreachable;
+        }
+
+        /// reference src/image.zig:582-584
+        pub fn crop(self: Self, allocator: std.mem.Allocator, rectangle: Rectangle(f32)) !Self {
+            const chip_rows: u32 = @round(rectangle.height());
+            const chip_cols: u32 = @round(rectangle.width());
+            const chip: Self = .{ .base = try .init(allocator, chip_rows, chip_cols) };
+            self.extract(chip, rectangle, 0, .nearest, .zero);
+            return chip;
+        }
+
+        /// reference src/image.zig:606-608 (Blending.none and .normal on the device; other modes stay on the CPU)
+        pub fn insert(self: *Self, source: anytype, rect: Rectangle(f32), angle: f32, method: Interpolation, blend_mode: zignal.Blending) void {
+            if (blend_mode != .none and blend_mode != .normal) return self.base.insert(source.base, rect, angle, method, blend_mode);
+            const r = [4]f32{ rect.l, rect.t, rect.r, rect.b };
+            check(c.zg_insert_host(&desc(self.base), &desc(source.base), &r, angle, @cos(angle), @sin(angle), &methodOf(method, null), @intFromEnum(blend_mode))) catch unreachable;
+        }
+
+        /// reference src/image/transforms.zig:28-44
+        pub fn flipLeftRight(self: Self) void {
+            check(c.zg_flip_left_right_host(&desc(self.base))) catch unreachable;
+        }
+        pub fn flipTopBottom(self: Self) void {
+            check(c.zg_flip_top_bottom_host(&desc(self.base))) catch unreachable;
+        }
+
+        /// reference src/image.zig:396-407 — colour spaces on the GPU path: gray, rgb, rgba, oklab, xyz, ycbcr.
+        pub fn convertInto(self: Self, comptime Target: type, out: Image(Target)) void {
+            const lut = srgbLut();
+            const src_space: c_int = switch (pixelOf(T)) { .u8, .f32 => 0, .rgb_u8, .rgb_f32 => 1, .rgba_u8, .rgba_f32 => 2 };
+            const dst_space: c_int = comptime if (Target == u8 or Target == f32) 0 else switch (Target.space) {
+                .gray => 0, .rgb => 1, .rgba => 2, .oklab => 3, .xyz => 4, .ycbcr => 5,
+                else => @compileError("colour space not on the GPU hot path"),
+            };
+            check(c.zg_convert_host(&desc(self.base), src_space, &Image(Target).desc(out.base), dst_space, &lut)) catch unreachable;
+        }
+
+        /// reference src/image.zig:418-422
+        pub fn convert(self: Self, allocator: std.mem.Allocator, comptime Target: type) !Image(Target) {
+            const result: Image(Target) = .{ .base = try .init(allocator, self.base.rows, self.base.cols) };
+            self.convertInto(Target, result);
+            return result;
+        }
+    };
+}
