@@ -348,3 +348,31 @@ def test_config5_batch_pipeline(oracle):
     for i in range(n):
         want = oracle.resize(oracle.gaussian_blur(frames[i], 0.6), (540, 960), om(oracle, I.bilinear))
         assert_bits_equal(got[i], want, f"config5 frame {i}")
+
+
+@pytest.mark.parametrize("case", ["half_sigma1", "third_bicubic", "odd_cols", "f32"])
+def test_batch_pipeline_paths(oracle, case):
+    """Every dispatch path of zg_batch_blur_resize equals gaussianBlur followed by resize, frame by frame."""
+    import ctypes as C
+    n = 3
+    if case == "half_sigma1":      # fused blur + 2:1 bilinear, 7 taps, zero-sum alpha handled like any channel
+        rows, cols, orows, ocols, sigma, m, kind = 66, 320, 33, 160, 1.0, I.bilinear, "rgba_u8"
+    elif case == "third_bicubic":  # batched blur, then per-frame plane resize
+        rows, cols, orows, ocols, sigma, m, kind = 60, 256, 20, 100, 0.6, I.bicubic, "rgba_u8"
+    elif case == "odd_cols":       # cols % 4 != 0: general per-frame path
+        rows, cols, orows, ocols, sigma, m, kind = 31, 131, 16, 65, 0.6, I.bilinear, "rgba_u8"
+    else:
+        rows, cols, orows, ocols, sigma, m, kind = 40, 72, 20, 36, 0.6, I.bilinear, "rgba_f32"
+    frames = np.stack([synth(oracle, kind, 70 + i, rows, cols) for i in range(n)])
+    t_in = torch.from_numpy(frames).cuda()
+    t_out = torch.zeros((n, orows, ocols, 4), dtype=t_in.dtype, device="cuda")
+    mm = m._c()
+    pixel = 3 if kind == "rgba_u8" else 5
+    rc = zg.lib().zg_batch_blur_resize(C.c_void_p(t_in.data_ptr()), n, rows, cols, pixel, C.c_float(sigma), C.c_void_p(t_out.data_ptr()),
+                                       orows, ocols, C.byref(mm), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, zg.lib().zg_last_error()
+    torch.cuda.synchronize()
+    got = t_out.cpu().numpy()
+    for i in range(n):
+        want = oracle.resize(oracle.gaussian_blur(frames[i], sigma), (orows, ocols), om(oracle, m))
+        assert_bits_equal(got[i], want, f"batch {case} frame {i}")

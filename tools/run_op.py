@@ -1,0 +1,31 @@
+"""Run one op a few times on the GPU (for rocprofv3 passes). usage: python tools/run_op.py blur_u8|blur_f32|resize|warp_u8|warp_f32|oklab [n]"""
+import sys
+sys.path.insert(0, ".")
+import numpy as np, torch
+import zignal_amd as zg
+
+op = sys.argv[1]
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+I = zg.Interpolation
+R = 4096
+if op == "blur_u8":
+    s = zg.Image(torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")); d = zg.Image(torch.empty_like(s.data))
+    f = lambda: s.gaussian_blur(0.6, out=d)
+elif op == "blur_f32":
+    s = zg.Image(torch.rand((R, R, 4), dtype=torch.float32, device="cuda")); d = zg.Image(torch.empty_like(s.data))
+    f = lambda: s.gaussian_blur(0.6, out=d)
+elif op == "resize":
+    s = zg.Image(torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")); d = zg.Image(torch.empty((1024, 1024, 4), dtype=torch.uint8, device="cuda"))
+    f = lambda: s.resize(d, I.bilinear)
+elif op in ("warp_u8", "warp_f32"):
+    from oracle import pyoracle as oracle
+    h = oracle.homography_from_4pts([(0, 0), (4095, 0), (0, 4095), (4095, 4095)], [(200, 120), (3900, 60), (90, 3980), (4000, 4050)])
+    t = torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda") if op == "warp_u8" else torch.rand((R, R, 4), dtype=torch.float32, device="cuda")
+    s = zg.Image(t); d = zg.Image(torch.empty_like(t)); tr = zg.ProjectiveTransform(h)
+    f = lambda: s.warp(tr, d, I.bicubic)
+elif op == "oklab":
+    s = zg.Image(torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")); d = zg.Image(torch.empty((R, R, 3), dtype=torch.float32, device="cuda"))
+    f = lambda: s.convert(zg.CS_OKLAB, np.float32, out=d)
+for _ in range(n):
+    f()
+torch.cuda.synchronize()

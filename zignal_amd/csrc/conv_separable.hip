@@ -533,6 +533,8 @@ static int run_sep(const zg_image *src, const zg_image *dst, const SepPlan &p, i
     return launch_two_pass<PIX, MODE>(src, dst, p, border, s);
 }
 
+int try_sep_rgba8(const zg_image *src, const zg_image *dst, const int32_t *ix, const int32_t *iy, int nk, int border, hipStream_t s);
+
 static int conv_separable_impl(const zg_image *src, const zg_image *dst, const float *kx, uint32_t nkx,
                                const float *ky, uint32_t nky, int border, hipStream_t s) {
     int rc;
@@ -579,6 +581,10 @@ static int conv_separable_impl(const zg_image *src, const zg_image *dst, const f
         const bool fits = mx < (1 << 23) && my < (1 << 23) && max_temp < (1 << 23) &&
                           max_temp * say < (int64_t)INT32_MAX - 65536;
         p.mode = fits ? MODE_I24 : MODE_I64;
+        if (src->pixel == ZG_PIXEL_RGBA_U8 && p.nkx == p.nky) { // small non-negative taps: packed-u16, 4 px / lane
+            const int rc8 = try_sep_rgba8(src, dst, p.ix.data(), p.iy.data(), p.nkx, border, s);
+            if (rc8 >= 0) return rc8;
+        }
     }
 
     return dispatch_pixel(src->pixel, [&](auto tag) -> int {
