@@ -253,16 +253,37 @@ def scatter_gather_leg(zg, torch, sharding, rank, world, local_rank, frames_per_
 
 
 def _time_kernel(torch, fn, n=50, warm=5):
+    """Mean ms per call of fn(i): the n calls are captured into one HIP graph and replayed (so microsecond kernels are
+    not timed through Python launch overhead); eager launches if capture is not possible."""
     for i in range(warm):
         fn(i)
     torch.cuda.synchronize()
+    graph = None
+    try:
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            fn(0)
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for i in range(n):
+                    fn(i)
+        graph.replay()
+        torch.cuda.synchronize()
+    except Exception:
+        graph = None
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3 if graph is not None else 1
     a.record()
-    for i in range(n):
-        fn(i)
+    for _ in range(reps):
+        if graph is not None:
+            graph.replay()
+        else:
+            for i in range(n):
+                fn(i)
     b.record()
     torch.cuda.synchronize()
-    return a.elapsed_time(b) / n
+    return a.elapsed_time(b) / (n * reps)
 
 
 def extras(zg, torch, np):

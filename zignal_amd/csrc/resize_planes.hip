@@ -6,9 +6,11 @@
 // (Lanczos3, f32 weights from @sin).
 //
 // Every one of those kernels is separable in its *coordinates*: the source indices and tap weights of an
-// output pixel depend only on its column (x taps) and its row (y taps). The host builds those two small
-// tables with the reference's exact f32 / integer arithmetic (including Zig-side @sin for Lanczos, which a
-// Zig caller can therefore keep bit-faithful), and the device kernel is pure integer (or f32 mul/add)
+// output pixel depend only on its column (x taps) and its row (y taps). For nearest / bilinear / the three
+// integer cubics the taps are plain IEEE f32 and integer arithmetic and are recomputed per lane in registers
+// (a table load in front of the pixel gathers would double the dependent memory latency of this few-microsecond
+// kernel: 9.7 -> see profiles). Lanczos weights need sin, so the host builds two small tables for it with the
+// reference's arithmetic and caches them per geometry. The device kernel is pure integer (or f32 mul / add)
 // accumulation over interleaved pixels: channels are independent, so no split / merge pass exists here.
 // Per output pixel the kernel reads T x T source pixels and writes one: that is the algorithmic traffic.
 #include "zg_common.h"
@@ -35,8 +37,59 @@ struct AxisTable {
     const int32_t *w;
 };
 
-template <int PIX, int CLS, int T>
-__global__ __launch_bounds__(256) void k_resize_planes(DImg src, DImg dst, AxisTable tx, AxisTable ty, int tiles_x) {
+// Integer 8.8 kernels of channel_ops.zig:217-435 (device copies of the host functions below).
+__device__ inline int dk_bicubic(int t) {
+    const int at = t < 0 ? -t : t;
+    if (at <= 256) { const int t2 = at * at / 256, t3 = t2 * at / 256; return 256 - 2 * t2 + t3; }
+    if (at <= 512) { const int t2 = at * at / 256, t3 = t2 * at / 256; return 4 * 256 - 8 * at + 5 * t2 - t3; }
+    return 0;
+}
+__device__ inline int dk_catmull(int t) {
+    const int at = t < 0 ? -t : t;
+    if (at <= 256) { const int t2 = at * at / 256, t3 = t2 * at / 256; return 256 - (5 * t2) / 2 + (3 * t3) / 2; }
+    if (at <= 512) { const int t2 = at * at / 256, t3 = t2 * at / 256; return 2 * 256 - 4 * at + (5 * t2) / 2 - t3 / 2; }
+    return 0;
+}
+__device__ inline int dk_mitchell(int t) {
+    const long long at = t < 0 ? -(long long)t : t, s = 256, s2 = s * s, s3 = s2 * s;
+    if (at < s) { const long long at2 = at * at, at3 = at2 * at; return (int)((21 * at3 - 36 * at2 * s + 16 * s3) / (18 * s2)); }
+    if (at < 2 * s) { const long long at2 = at * at, at3 = at2 * at; return (int)((-7 * at3 + 36 * at2 * s - 60 * at * s2 + 32 * s3) / (18 * s2)); }
+    return 0;
+}
+
+// Taps of one axis for destination index d, computed in registers with the reference's f32 / integer arithmetic
+// (s = (d + 0.5) * ratio - 0.5; mirror indices; f = trunc(frac * 256)). Plain IEEE mul / sub / floor / trunc, so the
+// device reproduces the host bit for bit and no table load sits in front of the pixel gathers.
+template <int CLS, int KIND, int T>
+__device__ inline void axis_taps(int d, float ratio, int n, int (&idx)[T], int (&w)[T]) {
+    const float sf = ((float)d + 0.5f) * ratio - 0.5f;
+    if constexpr (CLS == RC_NEAREST) {
+        unsigned i = (unsigned)(int)roundf(sf);
+        if (i > (unsigned)(n - 1)) i = (unsigned)(n - 1);
+        idx[0] = (int)i;
+        w[0] = 0;
+    } else {
+        const float fl = floorf(sf);
+        const int base = (int)fl;
+        const int f = (int)truncf((sf - fl) * 256.0f);
+        if constexpr (CLS == RC_BILINEAR) {
+            idx[0] = resolve_index(base, n, ZG_BORDER_MIRROR);
+            idx[1] = resolve_index(base + 1, n, ZG_BORDER_MIRROR);
+            w[0] = 256 - f;
+            w[1] = f;
+        } else {
+#pragma unroll
+            for (int k = 0; k < T; ++k) {
+                idx[k] = resolve_index(base + k - 1, n, ZG_BORDER_MIRROR);
+                const int t = k * 256 - 256 - f;
+                w[k] = KIND == ZG_INTERP_BICUBIC ? dk_bicubic(t) : (KIND == ZG_INTERP_CATMULL_ROM ? dk_catmull(t) : dk_mitchell(t));
+            }
+        }
+    }
+}
+
+template <int PIX, int CLS, int KIND, int T>
+__global__ __launch_bounds__(256) void k_resize_planes(DImg src, DImg dst, AxisTable tx, AxisTable ty, float ratio_x, float ratio_y, int tiles_x) {
     using P = Px<PIX>;
     using Vec = typename P::Vec;
     constexpr int C = P::C;
@@ -48,15 +101,20 @@ __global__ __launch_bounds__(256) void k_resize_planes(DImg src, DImg dst, AxisT
     const int r = __builtin_amdgcn_readfirstlane(tyi * 4 + (int)(threadIdx.x >> 6)); // one row per wave
     if (r >= dst.rows || c >= dst.cols) return;
 
-    int xi[T], yi[T];
+    int xi[T], yi[T], wxi[T], wyi[T];
+    if constexpr (CLS == RC_LANCZOS) { // f32 weights need sin: host tables (channel_ops.zig:446-454)
 #pragma unroll
-    for (int k = 0; k < T; ++k) { xi[k] = tx.idx[c * T + k]; yi[k] = ty.idx[r * T + k]; }
+        for (int k = 0; k < T; ++k) { xi[k] = tx.idx[c * T + k]; yi[k] = ty.idx[r * T + k]; wxi[k] = tx.w[c * T + k]; wyi[k] = ty.w[r * T + k]; }
+    } else {
+        axis_taps<CLS, KIND, T>(c, ratio_x, src.cols, xi, wxi);
+        axis_taps<CLS, KIND, T>(r, ratio_y, src.rows, yi, wyi);
+    }
 
     Vec out;
     if constexpr (CLS == RC_NEAREST) {
         out = P::load(src.data, (size_t)yi[0] * src.stride + (size_t)xi[0]);
     } else if constexpr (CLS == RC_BILINEAR) {
-        const int fx = tx.w[c * T + 1], fy = ty.w[r * T + 1]; // w = {256 - f, f}
+        const int fx = wxi[1], fy = wyi[1]; // w = {256 - f, f}
         const Vec tl = P::load(src.data, (size_t)yi[0] * src.stride + (size_t)xi[0]);
         const Vec tr = P::load(src.data, (size_t)yi[0] * src.stride + (size_t)xi[1]);
         const Vec bl = P::load(src.data, (size_t)yi[1] * src.stride + (size_t)xi[0]);
@@ -71,7 +129,7 @@ __global__ __launch_bounds__(256) void k_resize_planes(DImg src, DImg dst, AxisT
     } else if constexpr (CLS == RC_CUBIC_INT) {
         int wx[T], wy[T];
 #pragma unroll
-        for (int k = 0; k < T; ++k) { wx[k] = tx.w[c * T + k]; wy[k] = ty.w[r * T + k]; }
+        for (int k = 0; k < T; ++k) { wx[k] = wxi[k]; wy[k] = wyi[k]; }
         int sum[C], weight_sum = 0;
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) sum[ch] = 0;
@@ -91,7 +149,7 @@ __global__ __launch_bounds__(256) void k_resize_planes(DImg src, DImg dst, AxisT
     } else {
         float wx[T], wy[T];
 #pragma unroll
-        for (int k = 0; k < T; ++k) { wx[k] = __int_as_float(tx.w[c * T + k]); wy[k] = __int_as_float(ty.w[r * T + k]); }
+        for (int k = 0; k < T; ++k) { wx[k] = __int_as_float(wxi[k]); wy[k] = __int_as_float(wyi[k]); }
         float sum[C], weight_sum = 0;
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) sum[ch] = 0;
@@ -217,10 +275,12 @@ static int axis_table(int kind, uint32_t src_n, uint32_t dst_n, int taps, AxisTa
     return ZG_OK;
 }
 
-template <int PIX, int CLS, int T>
+template <int PIX, int CLS, int KIND, int T>
 static int launch_planes(const zg_image *src, const zg_image *dst, const AxisTable &tx, const AxisTable &ty, hipStream_t s) {
     const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, 4);
-    hipLaunchKernelGGL((k_resize_planes<PIX, CLS, T>), dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, dimg(src), dimg(dst), tx, ty, tiles_x);
+    const float ratio_x = (float)src->cols / (float)dst->cols, ratio_y = (float)src->rows / (float)dst->rows;
+    hipLaunchKernelGGL((k_resize_planes<PIX, CLS, KIND, T>), dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, dimg(src), dimg(dst), tx, ty,
+                       ratio_x, ratio_y, tiles_x);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -228,10 +288,12 @@ static int launch_planes(const zg_image *src, const zg_image *dst, const AxisTab
 template <int PIX>
 static int resize_planes_pix(const zg_image *src, const zg_image *dst, int kind, const AxisTable &tx, const AxisTable &ty, hipStream_t s) {
     switch (kind) {
-    case ZG_INTERP_NEAREST: return launch_planes<PIX, RC_NEAREST, 1>(src, dst, tx, ty, s);
-    case ZG_INTERP_BILINEAR: return launch_planes<PIX, RC_BILINEAR, 2>(src, dst, tx, ty, s);
-    case ZG_INTERP_LANCZOS: return launch_planes<PIX, RC_LANCZOS, 6>(src, dst, tx, ty, s);
-    default: return launch_planes<PIX, RC_CUBIC_INT, 4>(src, dst, tx, ty, s);
+    case ZG_INTERP_NEAREST: return launch_planes<PIX, RC_NEAREST, ZG_INTERP_NEAREST, 1>(src, dst, tx, ty, s);
+    case ZG_INTERP_BILINEAR: return launch_planes<PIX, RC_BILINEAR, ZG_INTERP_BILINEAR, 2>(src, dst, tx, ty, s);
+    case ZG_INTERP_LANCZOS: return launch_planes<PIX, RC_LANCZOS, ZG_INTERP_LANCZOS, 6>(src, dst, tx, ty, s);
+    case ZG_INTERP_BICUBIC: return launch_planes<PIX, RC_CUBIC_INT, ZG_INTERP_BICUBIC, 4>(src, dst, tx, ty, s);
+    case ZG_INTERP_CATMULL_ROM: return launch_planes<PIX, RC_CUBIC_INT, ZG_INTERP_CATMULL_ROM, 4>(src, dst, tx, ty, s);
+    default: return launch_planes<PIX, RC_CUBIC_INT, ZG_INTERP_MITCHELL, 4>(src, dst, tx, ty, s);
     }
 }
 
@@ -241,8 +303,10 @@ int resize_planes_impl(const zg_image *src, const zg_image *dst, const zg_method
     const int taps = kind == ZG_INTERP_NEAREST ? 1 : (kind == ZG_INTERP_BILINEAR ? 2 : (kind == ZG_INTERP_LANCZOS ? 6 : 4));
     AxisTable tx{}, ty{};
     int rc;
-    if ((rc = axis_table(kind, src->cols, dst->cols, taps, tx))) return rc;
-    if ((rc = axis_table(kind, src->rows, dst->rows, taps, ty))) return rc;
+    if (kind == ZG_INTERP_LANCZOS) { // the only kernel whose weights need a transcendental: tables from the host
+        if ((rc = axis_table(kind, src->cols, dst->cols, taps, tx))) return rc;
+        if ((rc = axis_table(kind, src->rows, dst->rows, taps, ty))) return rc;
+    }
     if (src->pixel == ZG_PIXEL_RGB_U8) return resize_planes_pix<ZG_PIXEL_RGB_U8>(src, dst, kind, tx, ty, s);
     return resize_planes_pix<ZG_PIXEL_RGBA_U8>(src, dst, kind, tx, ty, s);
 }

@@ -147,11 +147,14 @@ __host__ __device__ inline int resolve_index(int idx, int length, int border) {
 
 // ---- meta.clamp (reference src/meta.zig:110-135) ---------------------------------------------
 // float -> u8: trunc(clamp(round(f64(v)), 0, 255)); rounding an f32 in f64 equals roundf in f32.
+// Evaluated as clamp-then-round, which is the same function: u = min(max(v, 0), 255) (NaN -> 255 like the reference's
+// @min), then trunc(u) + (frac >= 0.5) — for u >= 0 that is round-half-away, and u <= 255 keeps the result in range.
 __device__ inline uint8_t clamp_u8_f32(float v) {
-    float r = roundf(v);                 // half away from zero (@round)
-    r = fminf(r, 255.0f);                // @min returns the non-NaN operand, as fminf
-    r = fmaxf(0.0f, r);
-    return (uint8_t)(int)r;
+    float u = fmaxf(v, 0.0f);            // negative values round to <= 0 and clamp to 0 anyway; fmaxf(NaN, 0) = 0 ...
+    u = (v != v) ? 255.0f : fminf(u, 255.0f); // ... but the reference maps NaN to 255 (std.math.clamp via @min / @max)
+    const float t = truncf(u);
+    const int r = (int)t + ((u - t) >= 0.5f ? 1 : 0);
+    return (uint8_t)r;
 }
 __device__ inline uint8_t clamp_u8_i32(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 

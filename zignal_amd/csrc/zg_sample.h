@@ -46,17 +46,17 @@ __device__ inline int resolve_index64(long long idx, int length, int border) {
 
 // An integral-valued float coordinate (already floored / rounded) plus a small tap offset.
 struct BaseIdx {
-    long long wide;
+    float value; // integral-valued
     int narrow;
     bool is_narrow;
     __device__ explicit BaseIdx(float integral) {
+        value = integral;
         is_narrow = fabsf(integral) < 1.0e9f;
         narrow = is_narrow ? (int)integral : 0;
-        wide = is_narrow ? 0 : (long long)integral;
     }
     __device__ int resolve(int offset, int length, int border) const {
         if (is_narrow) return resolve_index(narrow + offset, length, border);
-        return resolve_index64(wide + offset, length, border);
+        return resolve_index64((long long)value + offset, length, border); // f32 -> i64 only on this cold path
     }
 };
 
@@ -90,6 +90,21 @@ __device__ inline float lanczos3_kernel_lut(const float *lut, float x) {
     return lut[idx] * (1.0f - frac) + lut[idx + 1] * frac;
 }
 
+// Taps of a radius-2 kernel sit at t = (i - 1) - f with f in [0, 1): |t| is in [1, 2] for i = 0, 3 and in [0, 1] for
+// i = 1, 2, so for the two kernels whose branches are closed intervals (`<= 1`, `<= 2`) the branch taken is known per
+// tap — except i = 0 at f == 0 (|t| == 1 takes the inner branch in the reference), where both polynomials evaluate to
+// exactly +0. Evaluating only the polynomial that applies halves the weight arithmetic; the result is bit-identical.
+template <int KIND> __device__ inline float cubic_tap_weight(int i, float t) {
+    const float at = fabsf(t);
+    if constexpr (KIND == ZG_INTERP_BICUBIC) {
+        if (i == 1 || i == 2) return 1 - 2 * at * at + at * at * at;
+        return 4 - 8 * at + 5 * at * at - at * at * at;
+    } else {
+        if (i == 1 || i == 2) return 1.5f * at * at * at - 2.5f * at * at + 1;
+        return -0.5f * at * at * at + 2.5f * at * at - 4 * at + 2;
+    }
+}
+
 template <int KIND> __device__ inline float eval_kernel(const MethodArg &m, float t) {
     if constexpr (KIND == ZG_INTERP_BICUBIC) return bicubic_kernel(t);
     else if constexpr (KIND == ZG_INTERP_CATMULL_ROM) return catmull_rom_kernel(t);
@@ -108,9 +123,8 @@ __device__ inline bool interpolate(const DImg &img, float x, float y, const Meth
     constexpr int C = P::C;
     constexpr bool IS_F = std::is_same<Elem, float>::value;
 
-    if (!isfinite(x) || !isfinite(y)) return false;
     const float range_limit = 4611686018427387904.0f; // @floatFromInt(maxInt(isize) / 2)
-    if (fabsf(x) > range_limit || fabsf(y) > range_limit) return false;
+    if (!(fabsf(x) <= range_limit) || !(fabsf(y) <= range_limit)) return false; // also rejects NaN and +-inf
 
     if constexpr (KIND == ZG_INTERP_NEAREST) {
         const int col = BaseIdx(roundf(x)).resolve(0, img.cols, border);
@@ -122,14 +136,23 @@ __device__ inline bool interpolate(const DImg &img, float x, float y, const Meth
     } else if constexpr (KIND == ZG_INTERP_BILINEAR) {
         const float fl = floorf(x), ft = floorf(y);
         const BaseIdx left(fl), top(ft);
-        const int r0 = top.resolve(0, img.rows, border), r1 = top.resolve(1, img.rows, border);
-        const int c0 = left.resolve(0, img.cols, border), c1 = left.resolve(1, img.cols, border);
-        if (border == ZG_BORDER_MIRROR && (r0 < 0 || r1 < 0 || c0 < 0 || c1 < 0)) return false;
         Vec tl = P::zero(), tr = P::zero(), bl = P::zero(), br = P::zero();
-        if (r0 >= 0 && c0 >= 0) tl = P::load(img.data, (size_t)r0 * img.stride + (size_t)c0);
-        if (r0 >= 0 && c1 >= 0) tr = P::load(img.data, (size_t)r0 * img.stride + (size_t)c1);
-        if (r1 >= 0 && c0 >= 0) bl = P::load(img.data, (size_t)r1 * img.stride + (size_t)c0);
-        if (r1 >= 0 && c1 >= 0) br = P::load(img.data, (size_t)r1 * img.stride + (size_t)c1);
+        if (left.is_narrow && top.is_narrow && left.narrow >= 0 && left.narrow + 1 < img.cols && top.narrow >= 0 &&
+            top.narrow + 1 < img.rows) { // all four neighbours inside: no index resolution, four independent loads
+            const size_t o = (size_t)top.narrow * img.stride + (size_t)left.narrow;
+            tl = P::load(img.data, o);
+            tr = P::load(img.data, o + 1);
+            bl = P::load(img.data, o + img.stride);
+            br = P::load(img.data, o + img.stride + 1);
+        } else {
+            const int r0 = top.resolve(0, img.rows, border), r1 = top.resolve(1, img.rows, border);
+            const int c0 = left.resolve(0, img.cols, border), c1 = left.resolve(1, img.cols, border);
+            if (border == ZG_BORDER_MIRROR && (r0 < 0 || r1 < 0 || c0 < 0 || c1 < 0)) return false;
+            if (r0 >= 0 && c0 >= 0) tl = P::load(img.data, (size_t)r0 * img.stride + (size_t)c0);
+            if (r0 >= 0 && c1 >= 0) tr = P::load(img.data, (size_t)r0 * img.stride + (size_t)c1);
+            if (r1 >= 0 && c0 >= 0) bl = P::load(img.data, (size_t)r1 * img.stride + (size_t)c0);
+            if (r1 >= 0 && c1 >= 0) br = P::load(img.data, (size_t)r1 * img.stride + (size_t)c1);
+        }
         const float lr = x - fl, tb = y - ft; // as(f32, left) == floorf(x) for every finite in-range x
         if constexpr (IS_F) {
 #pragma unroll
@@ -155,32 +178,61 @@ __device__ inline bool interpolate(const DImg &img, float x, float y, const Meth
         float xw[W], yw[W];
 #pragma unroll
         for (int i = 0; i < W; ++i) {
-            xw[i] = eval_kernel<KIND>(m, (float)(i - (R - 1)) - fx);
-            yw[i] = eval_kernel<KIND>(m, (float)(i - (R - 1)) - fy);
+            if constexpr (KIND == ZG_INTERP_BICUBIC || KIND == ZG_INTERP_CATMULL_ROM) {
+                xw[i] = cubic_tap_weight<KIND>(i, (float)(i - (R - 1)) - fx);
+                yw[i] = cubic_tap_weight<KIND>(i, (float)(i - (R - 1)) - fy);
+            } else {
+                xw[i] = eval_kernel<KIND>(m, (float)(i - (R - 1)) - fx);
+                yw[i] = eval_kernel<KIND>(m, (float)(i - (R - 1)) - fy);
+            }
         }
-        int cols_idx[W];
-#pragma unroll
-        for (int i = 0; i < W; ++i) cols_idx[i] = ix.resolve(i - (R - 1), img.cols, border);
         float sums[C];
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) sums[ch] = 0;
         float weight_sum = 0;
+        const int bx = ix.narrow - (R - 1), by = iy.narrow - (R - 1);
+        if (ix.is_narrow && iy.is_narrow && bx >= 0 && bx + W <= img.cols && by >= 0 && by + W <= img.rows) {
+            // the whole W x W window is inside the image (every pixel but a thin rim): straight-line code, all
+            // W*W gathers independent and in flight together, same accumulation order as the general path
+            Vec px[W][W];
 #pragma unroll
-        for (int j = 0; j < W; ++j) {
-            const int py = iy.resolve(j - (R - 1), img.rows, border);
-            if (py < 0) continue;
-            const size_t rowoff = (size_t)py * img.stride;
+            for (int j = 0; j < W; ++j)
 #pragma unroll
-            for (int i = 0; i < W; ++i) {
-                if (cols_idx[i] < 0) continue;
-                const Vec p = P::load(img.data, rowoff + (size_t)cols_idx[i]);
-                const float weight = xw[i] * yw[j];
+                for (int i = 0; i < W; ++i) px[j][i] = P::load(img.data, (size_t)(by + j) * img.stride + (size_t)(bx + i));
 #pragma unroll
-                for (int ch = 0; ch < C; ++ch) {
-                    const float prod = (float)p[ch] * weight;
-                    sums[ch] = sums[ch] + prod;
+            for (int j = 0; j < W; ++j) {
+#pragma unroll
+                for (int i = 0; i < W; ++i) {
+                    const float weight = xw[i] * yw[j];
+#pragma unroll
+                    for (int ch = 0; ch < C; ++ch) {
+                        const float prod = (float)px[j][i][ch] * weight;
+                        sums[ch] = sums[ch] + prod;
+                    }
+                    weight_sum = weight_sum + weight;
                 }
-                weight_sum = weight_sum + weight;
+            }
+        } else {
+            int cols_idx[W];
+#pragma unroll
+            for (int i = 0; i < W; ++i) cols_idx[i] = ix.resolve(i - (R - 1), img.cols, border);
+#pragma unroll 1
+            for (int j = 0; j < W; ++j) {
+                const int py = iy.resolve(j - (R - 1), img.rows, border);
+                if (py < 0) continue;
+                const size_t rowoff = (size_t)py * img.stride;
+#pragma unroll
+                for (int i = 0; i < W; ++i) {
+                    if (cols_idx[i] < 0) continue;
+                    const Vec p = P::load(img.data, rowoff + (size_t)cols_idx[i]);
+                    const float weight = xw[i] * yw[j];
+#pragma unroll
+                    for (int ch = 0; ch < C; ++ch) {
+                        const float prod = (float)p[ch] * weight;
+                        sums[ch] = sums[ch] + prod;
+                    }
+                    weight_sum = weight_sum + weight;
+                }
             }
         }
 #pragma unroll
