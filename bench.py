@@ -356,6 +356,14 @@ def extras(zg, torch, np):
         r["frames"] = n
         return r
 
+    def blur_planes():
+        ring = 8
+        im = [(zg.Image(torch.rand((ROWS, COLS), dtype=torch.float32, device="cuda")), zg.Image(torch.empty((ROWS, COLS), dtype=torch.float32, device="cuda")))
+              for _ in range(ring)]
+        ms = _time_kernel(torch, lambda i: im[i % ring][0].gaussian_blur(SIGMA, out=im[i % ring][1]))
+        return rate(ms, ROWS * COLS, 8 * ROWS * COLS)  # one f32 plane: 4 B read + 4 B written per pixel
+
+    leg("config2a_gaussian_blur_one_f32_plane_4096", blur_planes)
     leg("config2b_gaussian_blur_rgba_u8_4096", blur_u8)
     leg("config3_resize_bilinear_rgba_u8_4096_to_1024", resize_u8)
     leg("config3_convert_rgba_u8_to_oklab_f32_4096", oklab)

@@ -80,11 +80,11 @@ template <int MODE, typename TapsT> __device__ inline auto tap(const TapsT &t, i
 
 constexpr int TW = 64;  // tile width = one wavefront of columns; tile height = 4 waves x RPT rows
 
-// Tuning variant (A/B on hardware through ZG_SEP_VARIANT; the default is what measured best):
-//   RPT      output rows per thread (tile height = 4 * RPT)
-//   PERSIST  persistent workgroups that prefetch tile t+1 into registers while convolving tile t
-//   NT       non-temporal stores for the output
-struct SepVariant { int rpt; bool persist; bool nt; };
+// Kernel shape parameters (measured on MI355X, profiles/r01_sep_variant_sweep.txt):
+//   RPT      output rows per thread (tile height = 4 * RPT); 4 for 16-byte pixels, 8 otherwise
+//   PERSIST  persistent workgroups that prefetch tile t+1 into registers while convolving tile t (measured slower; kept
+//            selectable for future geometries)
+//   NT       non-temporal stores for the output (always on; non-temporal LOADS measured slower)
 
 // Tile staging shared by the persistent kernel: load one (TH+2H) x (TW+2H) source tile into registers
 // (every load issued back to back), and later spill those registers to LDS.
@@ -425,19 +425,6 @@ static int persistent_grid(const void *kernel) {
     return grid;
 }
 
-static SepVariant sep_variant() {
-    static const SepVariant v = [] {
-        SepVariant d{8, false, false};
-        if (const char *e = getenv("ZG_SEP_VARIANT")) { // e.g. "8p" "4n" "8": rows per thread, p = persistent, n = nt stores
-            d.rpt = atoi(e);
-            d.persist = strchr(e, 'p') != nullptr;
-            d.nt = strchr(e, 'n') != nullptr;
-        }
-        return d;
-    }();
-    return v;
-}
-
 template <int PIX, int NK, int MODE, bool SKIP, int RPT, bool PERSIST, bool NT>
 static int launch_fused_v(const zg_image *src, const zg_image *dst, const SepPlan &p, int border, hipStream_t s) {
     TapsArg<NK> kx, ky;
@@ -457,20 +444,6 @@ static int launch_fused_v(const zg_image *src, const zg_image *dst, const SepPla
 
 template <int PIX, int NK, int MODE, bool SKIP>
 static int launch_fused(const zg_image *src, const zg_image *dst, const SepPlan &p, int border, hipStream_t s) {
-#ifdef ZG_SEP_TUNE
-    const SepVariant v = sep_variant();
-    if (NK == 5 && (PIX == ZG_PIXEL_RGBA_F32 || PIX == ZG_PIXEL_RGBA_U8) && !SKIP) {
-        if (v.rpt == 4 && !v.persist && !v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 4, false, false>(src, dst, p, border, s);
-        if (v.rpt == 4 && !v.persist && v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 4, false, true>(src, dst, p, border, s);
-        if (v.rpt == 4 && v.persist && !v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 4, true, false>(src, dst, p, border, s);
-        if (v.rpt == 8 && !v.persist && v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 8, false, true>(src, dst, p, border, s);
-        if (v.rpt == 8 && v.persist && !v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 8, true, false>(src, dst, p, border, s);
-        if (v.rpt == 8 && v.persist && v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 8, true, true>(src, dst, p, border, s);
-        if (v.rpt == 16 && !v.persist && !v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 16, false, false>(src, dst, p, border, s);
-        if (v.rpt == 16 && !v.persist && v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 16, false, true>(src, dst, p, border, s);
-        if (v.rpt == 2 && !v.persist && !v.nt) return launch_fused_v<PIX, NK, MODE, SKIP, 2, false, false>(src, dst, p, border, s);
-    }
-#endif
     // measured on MI355X (profiles/r01_sep_variant_sweep.txt): 16-byte pixels like many small tiles (more
     // workgroups per CU overlap each other's load and compute phases); every type likes streaming stores.
     if constexpr (Px<PIX>::BYTES >= 12) return launch_fused_v<PIX, NK, MODE, SKIP, 4, false, true>(src, dst, p, border, s);
@@ -534,6 +507,8 @@ static int run_sep(const zg_image *src, const zg_image *dst, const SepPlan &p, i
 }
 
 int try_sep_rgba8(const zg_image *src, const zg_image *dst, const int32_t *ix, const int32_t *iy, int nk, int border, hipStream_t s);
+int try_sep_f32x4(const zg_image *src, const zg_image *dst, const float *fx, const float *fy, int nk, uint32_t skipx, uint32_t skipy,
+                  int border, hipStream_t s);
 
 static int conv_separable_impl(const zg_image *src, const zg_image *dst, const float *kx, uint32_t nkx,
                                const float *ky, uint32_t nky, int border, hipStream_t s) {
@@ -557,6 +532,10 @@ static int conv_separable_impl(const zg_image *src, const zg_image *dst, const f
         p.fy.assign(ky, ky + nky);
         for (uint32_t i = 0; i < nkx && i < 32; ++i) if (std::fabs(kx[i]) < 1e-10f) p.skipx |= 1u << i;
         for (uint32_t i = 0; i < nky && i < 32; ++i) if (std::fabs(ky[i]) < 1e-10f) p.skipy |= 1u << i;
+        if (src->pixel == ZG_PIXEL_F32 && p.nkx == p.nky) { // single-channel planes: four pixels per lane
+            const int rc4 = try_sep_f32x4(src, dst, p.fx.data(), p.fy.data(), p.nkx, p.skipx, p.skipy, border, s);
+            if (rc4 >= 0) return rc4;
+        }
     } else {
         // scaleKernelToInt (convolution.zig:303-309): @round(k * 256) -> i32
         p.ix.resize(nkx);
