@@ -204,6 +204,8 @@ def main():
             result["extras"] = extras(zg, torch, np)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
+            if not args.no_extras:
+                cpu_extras(result["extras"])
 
     if world > 1 and args.scatter_gather:
         # Not the headline: BASELINE configs[4] end to end — rank 0 holds the batch, shards fan out over RCCL/xGMI
@@ -250,6 +252,45 @@ def scatter_gather_leg(zg, torch, sharding, rank, world, local_rank, frames_per_
     sec = sharding.max_over_ranks((time.perf_counter() - t0) / reps, dev)
     return {"frames": n, "seconds": round(sec, 6), "Mpixels/s_end_to_end": round(n * rows * cols / sec / 1e6, 1),
             "note": "includes the xGMI scatter of 8.3 MB/frame and gather of 2.1 MB/frame; kernel-only rate is `value`"}
+
+
+def cpu_extras(extras_out):
+    """The oracle ('port', one host thread) on a bounded sample of each extra configuration, so every GPU figure has the
+    reference's CPU path beside it. Samples are strips of the same workload; rates are per source pixel like the GPU's."""
+    import numpy as np
+    from oracle import pyoracle as oracle  # baseline leg only
+
+    def timed(fn, px):
+        fn()
+        t0 = time.perf_counter()
+        fn()
+        return round(px / (time.perf_counter() - t0) / 1e6, 2)
+
+    def put(name, value, sample):
+        if name in extras_out and isinstance(extras_out[name], dict):
+            extras_out[name]["cpu_port_Mpixels/s"] = value
+            extras_out[name]["cpu_sample"] = sample
+
+    try:
+        native = True
+        oracle.lib(native=True)
+    except Exception:
+        native = False
+    bil = oracle.method(oracle.BILINEAR)
+    bic = oracle.method(oracle.BICUBIC)
+    u8 = oracle.synth_u8(2, (512, COLS, 4))
+    put("config2b_gaussian_blur_rgba_u8_4096", timed(lambda: oracle.gaussian_blur(u8, SIGMA, native=native), 512 * COLS), "512 x 4096 strip")
+    src = oracle.synth_u8(3, (1024, COLS, 4))
+    put("config3_resize_bilinear_rgba_u8_4096_to_1024", timed(lambda: oracle.resize(src, (256, 1024), bil), 1024 * COLS), "1024 x 4096 -> 256 x 1024")
+    put("config3_convert_rgba_u8_to_oklab_f32_4096", timed(lambda: oracle.convert(u8, oracle.CS_RGBA, oracle.CS_OKLAB, np.float32, 3), 512 * COLS), "512 x 4096 strip")
+    hmat = oracle.homography_from_4pts([(0, 0), (4095, 0), (0, 4095), (4095, 4095)], [(200, 120), (3900, 60), (90, 3980), (4000, 4050)])
+    full_u8 = oracle.synth_u8(4, (ROWS, COLS, 4))
+    put("config4_warp_projective_bicubic_rgba_u8_4096", timed(lambda: oracle.warp(full_u8, (128, COLS), oracle.PROJECTIVE, hmat, bic), 128 * COLS), "first 128 output rows")
+    full_f32 = oracle.synth_f32(4, (ROWS, COLS, 4))
+    put("config4_warp_projective_bicubic_rgba_f32_4096", timed(lambda: oracle.warp(full_f32, (128, COLS), oracle.PROJECTIVE, hmat, bic), 128 * COLS), "first 128 output rows")
+    frame = oracle.synth_u8(5, (1080, 1920, 4))
+    put("config5_batch_blur_resize_64x1080p_rgba_u8",
+        timed(lambda: oracle.resize(oracle.gaussian_blur(frame, SIGMA, native=native), (540, 960), bil), 1080 * 1920), "one 1080p frame")
 
 
 def _time_kernel(torch, fn, n=50, warm=5):

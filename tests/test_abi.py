@@ -71,3 +71,69 @@ def test_gaussian_kernel_matches_reference_taps():
 def test_library_taps_equal_oracle_taps(oracle):
     for sigma in (0.3, 0.5, 0.6, 1.0, 1.7, 2.5, 4.0):
         assert np.array_equal(zg.gaussian_kernel(sigma), oracle.gaussian_kernel(sigma))
+
+
+# ---- argument validation happens before any HIP call, so it is testable without a GPU -----------------------
+def _img(rows, cols, pixel, data=0x1000, stride=None):
+    return L.ZgImage(data, cols if stride is None else stride, rows, cols, pixel)
+
+
+def _status(fn, *args):
+    return fn(*args)
+
+
+def test_error_convention_without_a_gpu():
+    lib = zg.lib()
+    k = (ctypes.c_float * 3)(0.25, 0.5, 0.25)
+    a, b = _img(4, 4, L.PIXEL_U8), _img(4, 5, L.PIXEL_U8)
+    # error.DimensionMismatch (src/image.zig:947, :962, :927, :636)
+    assert lib.zg_conv_separable(ctypes.byref(a), ctypes.byref(b), k, 3, k, 3, 0, None) == L.ERR_DIMENSION_MISMATCH
+    assert lib.zg_gaussian_blur(ctypes.byref(a), ctypes.byref(b), ctypes.c_float(1.0), None) == L.ERR_DIMENSION_MISMATCH
+    assert lib.zg_convolve(ctypes.byref(a), ctypes.byref(b), k, 1, 3, 0, None) == L.ERR_DIMENSION_MISMATCH
+    assert lib.zg_box_blur(ctypes.byref(a), ctypes.byref(b), 1, None) == L.ERR_DIMENSION_MISMATCH
+    # error.InvalidSigma (src/image.zig:970)
+    assert lib.zg_gaussian_blur(ctypes.byref(a), ctypes.byref(a), ctypes.c_float(-0.5), None) == L.ERR_INVALID_ARGUMENT
+    assert b"InvalidSigma" in lib.zg_last_error()
+    # malformed descriptors
+    assert lib.zg_conv_separable(ctypes.byref(_img(4, 4, 99)), ctypes.byref(a), k, 3, k, 3, 0, None) == L.ERR_INVALID_ARGUMENT
+    assert lib.zg_conv_separable(ctypes.byref(_img(4, 4, L.PIXEL_U8, stride=3)), ctypes.byref(a), k, 3, k, 3, 0, None) == L.ERR_INVALID_ARGUMENT
+    assert lib.zg_conv_separable(ctypes.byref(_img(4, 4, L.PIXEL_U8, data=None)), ctypes.byref(a), k, 3, k, 3, 0, None) == L.ERR_INVALID_ARGUMENT
+    assert lib.zg_conv_separable(ctypes.byref(a), ctypes.byref(a), k, 3, k, 3, 7, None) == L.ERR_INVALID_ARGUMENT  # border
+    assert lib.zg_conv_separable(ctypes.byref(a), ctypes.byref(a), k, 0, k, 3, 0, None) == L.ERR_INVALID_ARGUMENT  # empty kernel
+    misaligned = _img(4, 4, L.PIXEL_RGBA_F32, data=0x1004)
+    assert lib.zg_conv_separable(ctypes.byref(misaligned), ctypes.byref(misaligned), k, 3, k, 3, 0, None) == L.ERR_INVALID_ARGUMENT
+    # pixel types must agree; unsupported combinations say so
+    f = _img(4, 4, L.PIXEL_F32)
+    assert lib.zg_conv_separable(ctypes.byref(a), ctypes.byref(f), k, 3, k, 3, 0, None) == L.ERR_INVALID_ARGUMENT
+    m = L.ZgMethod(9, 0, 0, None)
+    assert lib.zg_resize(ctypes.byref(a), ctypes.byref(b), ctypes.byref(m), None) == L.ERR_INVALID_ARGUMENT
+    rgb = _img(4, 4, L.PIXEL_RGB_U8)
+    assert lib.zg_convert(ctypes.byref(a), L.CS_RGB, ctypes.byref(rgb), L.CS_RGB, None, None) == L.ERR_INVALID_ARGUMENT  # layout != space
+    assert lib.zg_convert(ctypes.byref(rgb), L.CS_RGB, ctypes.byref(rgb), L.CS_OKLAB, None, None) == L.ERR_UNSUPPORTED   # Oklab needs floats
+    # empty images are legal and do nothing (Image.empty)
+    e = _img(0, 0, L.PIXEL_U8, data=None)
+    assert lib.zg_conv_separable(ctypes.byref(e), ctypes.byref(e), k, 3, k, 3, 0, None) == L.OK
+    assert lib.zg_flip_left_right(ctypes.byref(e), None) == L.OK
+
+
+def test_crop_and_rotate_bounds_host_arithmetic():
+    lib = zg.lib()
+    r, c = ctypes.c_uint32(), ctypes.c_uint32()
+    rect = (ctypes.c_float * 4)(1.2, 2.6, 11.7, 9.4)  # l, t, r, b -> round(height), round(width)
+    assert lib.zg_crop_dims(rect, ctypes.byref(r), ctypes.byref(c)) == 0 and (r.value, c.value) == (7, 11)  # 6.8 -> 7, 10.5 -> 11 (half away)
+    import math
+    for angle, want in ((0.0, (3, 4)), (math.pi / 2, (4, 3)), (math.pi, (3, 4)), (3 * math.pi / 2, (4, 3)), (2 * math.pi, (3, 4))):
+        lib.zg_rotate_bounds(3, 4, ctypes.c_float(angle), ctypes.c_float(math.cos(angle)), ctypes.c_float(math.sin(angle)), ctypes.byref(r), ctypes.byref(c))
+        assert (r.value, c.value) == want  # tests/transforms.zig:160-229
+    lib.zg_rotate_bounds(10, 10, ctypes.c_float(math.pi / 4), ctypes.c_float(math.cos(math.pi / 4)), ctypes.c_float(math.sin(math.pi / 4)), ctypes.byref(r), ctypes.byref(c))
+    assert r.value > 10 and c.value > 10
+
+
+def test_python_mirror_validation():
+    img = zg.Image(np.zeros((4, 4), np.uint8))
+    with pytest.raises(zg.InvalidArgument):
+        img.scale(-1.0)
+    with pytest.raises(zg.DimensionMismatch):
+        img.copy(zg.Image(np.zeros((4, 5), np.uint8)))
+    assert img.view((10, 10, 20, 20)).rows == 0  # no overlap -> Image.empty
+    assert np.array_equal(img.copy().data, img.data)

@@ -158,7 +158,7 @@ int try_sep_f32x4(const zg_image *src, const zg_image *dst, const float *fx, con
     if (src->pixel != ZG_PIXEL_F32 || (nk != 3 && nk != 5 && nk != 7 && nk != 9)) return -1;
     if (src->cols % 4 || src->stride % 4 || dst->stride % 4 || ((uintptr_t)src->data & 15) || ((uintptr_t)dst->data & 15)) return -1;
     if (src->cols < 64) return -1;
-    switch (nk) {
+    switch (nk) { // RPT 4 measured best on MI355X (RPT 1 / 2 / 4 / 8: 47.1 / 36.5 / 34.9 / 40.0 us per 4096^2 plane)
     case 3: return launch_f32x4<3, 4>(src, dst, fx, fy, skipx, skipy, border, s);
     case 5: return launch_f32x4<5, 4>(src, dst, fx, fy, skipx, skipy, border, s);
     case 7: return launch_f32x4<7, 4>(src, dst, fx, fy, skipx, skipy, border, s);

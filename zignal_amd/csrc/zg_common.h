@@ -171,6 +171,6 @@ struct HostStage {
     int finish();         // D2H if writeback
 };
 
-int check_image(const zg_image *im, const char *name);
+int check_image(const zg_image *im, const char *name, bool device_pointer = true);
 
 } // namespace zg

@@ -23,13 +23,18 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line) {
     return ZG_ERR_HIP;
 }
 
-int check_image(const zg_image *im, const char *name) {
+int check_image(const zg_image *im, const char *name, bool device_pointer) {
     ZG_REQUIRE(im != nullptr, ZG_ERR_INVALID_ARGUMENT, "%s: null image descriptor", name);
     ZG_REQUIRE(pixel_valid(im->pixel), ZG_ERR_INVALID_ARGUMENT, "%s: invalid pixel type %d", name, im->pixel);
     if (im->rows == 0 || im->cols == 0) return ZG_OK; // Image.empty is legal
     ZG_REQUIRE(im->data != nullptr, ZG_ERR_INVALID_ARGUMENT, "%s: null data", name);
     ZG_REQUIRE(im->stride >= im->cols, ZG_ERR_INVALID_ARGUMENT, "%s: stride %zu < cols %u", name, im->stride, im->cols);
     ZG_REQUIRE(im->rows <= 0x3fffffffu && im->cols <= 0x3fffffffu, ZG_ERR_INVALID_ARGUMENT, "%s: image too large", name);
+    if (!device_pointer) return ZG_OK; // host pixels are staged with hipMemcpy2D: any alignment
+    // kernels move whole pixels with one instruction: the first pixel must be naturally aligned (it always is for an
+    // allocation or a view of one; only a hand-built pointer can violate it)
+    const size_t align = im->pixel == ZG_PIXEL_RGBA_F32 ? 16 : (im->pixel == ZG_PIXEL_U8 || im->pixel == ZG_PIXEL_RGB_U8 ? 1 : 4);
+    ZG_REQUIRE(((uintptr_t)im->data % align) == 0, ZG_ERR_INVALID_ARGUMENT, "%s: data pointer is not %zu-byte aligned", name, align);
     return ZG_OK;
 }
 
@@ -38,7 +43,7 @@ HostStage::~HostStage() {
 }
 
 int HostStage::upload(const zg_image *h, bool copy_in, bool write_back) {
-    int rc = check_image(h, "host image");
+    int rc = check_image(h, "host image", false);
     if (rc) return rc;
     host = h;
     writeback = write_back;
