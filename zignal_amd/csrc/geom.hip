@@ -14,6 +14,9 @@
 // Every coordinate is computed in f32 with the reference's operation order and no FMA; cos/sin of the angle
 // are host-supplied scalars. A wave covers 64 consecutive destination pixels of one row (coalesced stores);
 // the source side is a gather served by L1/L2 (neighbouring lanes read neighbouring source pixels).
+// Measured and rejected: staging each workgroup's source bounding box in LDS (wave/LDS min-max reduction, coalesced
+// rectangle load, taps via ds_read_b128) — 268-284 us vs 236 us for the direct gather on the 4096^2 RGBA f32 bicubic
+// warp: the reduction, two extra barriers and a dependent load phase cost more than the L1 traffic they remove.
 #include "zg_common.h"
 #include "zg_hostmath.h"
 #include "zg_sample.h"
