@@ -404,6 +404,13 @@ def extras(zg, torch, np):
         ms = _time_kernel(torch, lambda i: im[i % ring][0].gaussian_blur(SIGMA, out=im[i % ring][1]))
         return rate(ms, ROWS * COLS, 8 * ROWS * COLS)  # one f32 plane: 4 B read + 4 B written per pixel
 
+    def sobel():
+        ring = 8
+        im = [(zg.Image(s), zg.Image(torch.empty((ROWS, COLS), dtype=torch.uint8, device="cuda"))) for s in u8_frames(ring, (ROWS, COLS, 4))]
+        ms = _time_kernel(torch, lambda i: im[i % ring][0].sobel(out=im[i % ring][1]))
+        return rate(ms, ROWS * COLS, 5 * ROWS * COLS)  # 4 B read + 1 B written per pixel (fused)
+
+    leg("next_sobel_rgba_u8_4096", sobel)
     leg("config2a_gaussian_blur_one_f32_plane_4096", blur_planes)
     leg("config2b_gaussian_blur_rgba_u8_4096", blur_u8)
     leg("config3_resize_bilinear_rgba_u8_4096_to_1024", resize_u8)

@@ -229,6 +229,21 @@ ZG_API int zg_convert(const zg_image *src, int src_space, const zg_image *dst, i
 ZG_API int zg_convert_host(const zg_image *src, int src_space, const zg_image *dst, int dst_space,
                            const float *srgb_lut);
 
+/* ---- next rows of the scope table (callers of the path) ------------------------ */
+
+/* Image(T).sobel (src/image.zig:1001-1010 -> src/image/edges.zig:33-70): grey f32, two 3x3 f32 convolutions
+ * (.replicate), sqrt(gx^2 + gy^2) / 4 truncated to u8 — fused into one kernel. dst is Image(u8). */
+ZG_API int zg_sobel(const zg_image *src, const zg_image *dst, zg_stream stream);
+ZG_API int zg_sobel_host(const zg_image *src, const zg_image *dst);
+
+/* ImagePyramid.build (src/image/pyramid.zig:31-102) is gaussianBlur + resize(.bilinear) per level; these two give the
+ * per-level arithmetic. scale = pow(scale_factor, level): zg_pyramid_scale is the library's restatement of Zig's
+ * std.math.pow; a Zig caller passes its own value to zg_pyramid_level. A level below 8 x 8 truncates the pyramid;
+ * the level is blurred only when *out_sigma > 0.5. */
+ZG_API float zg_pyramid_scale(float scale_factor, uint32_t level);
+ZG_API int zg_pyramid_level(uint32_t rows, uint32_t cols, float scale, float blur_sigma,
+                            uint32_t *out_rows, uint32_t *out_cols, float *out_sigma);
+
 /* ---- batch (config: N frames, gaussianBlur(sigma) then bilinear resize) ----------------- */
 
 /* Semantics of the `pipeline` recipe [blur gaussian, resize] (src/cli/pipeline.zig:153-179)

@@ -327,3 +327,26 @@ def synth_f32(seed: int, shape) -> np.ndarray:
     n = int(np.prod(shape))
     u = splitmix64_bytes(seed, 4 * n).view(np.uint32)
     return ((u >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)).reshape(shape)
+
+
+def sobel(src):
+    out = np.empty(src.shape[:2], np.uint8)
+    s, d = as_image(src), as_image(out)
+    _check(lib().zo_sobel(C.byref(s), C.byref(d)), "sobel")
+    return out
+
+
+def pyramid(source, n_levels, scale_factor, blur_sigma):
+    """ImagePyramid.build (pyramid.zig:31-102) composed from the oracle's own gaussian_blur and resize."""
+    l = lib()
+    l.zo_pyramid_scale.restype = C.c_float
+    levels = [source]
+    for i in range(1, n_levels):
+        scale = l.zo_pyramid_scale(C.c_float(scale_factor), i)
+        r, c, sig = C.c_uint32(), C.c_uint32(), C.c_float()
+        stop = l.zo_pyramid_level(source.shape[0], source.shape[1], C.c_float(scale), C.c_float(blur_sigma), C.byref(r), C.byref(c), C.byref(sig))
+        if stop:
+            break
+        base = gaussian_blur(source, sig.value) if sig.value > 0.5 else source
+        levels.append(resize(base, (r.value, c.value), method(BILINEAR)))
+    return levels

@@ -1,0 +1,101 @@
+"""ImagePyramid.build and Image.sobel. Oracle pins (CPU) cite the reference's tests; the GPU
+tests compare the product with the oracle bit for bit."""
+import numpy as np
+import pytest
+
+import zignal_amd as zg
+from tests.util import ALL_TYPES, assert_bits_equal, synth
+
+
+# ---- oracle pins (reference src/image/tests/filters.zig:548-570, src/image/pyramid.zig:176-276) ----------------
+def test_oracle_sobel_vertical_edge(oracle):
+    img = np.zeros((5, 5), np.uint8)
+    img[:, 2:] = 255
+    e = oracle.sobel(img)
+    assert e[2, 2] > 200 and e[2, 0] < 50
+    assert e[2, 2] == 255  # |gx| = 4 * 255 at the edge -> 1020 / 4 = 255
+
+
+def test_oracle_pyramid_basic(oracle):
+    r, c = np.mgrid[0:640, 0:480]
+    img = ((r + c) % 256).astype(np.uint8)
+    levels = oracle.pyramid(img, 5, 1.5, 1.0)
+    assert len(levels) == 5 and levels[0].shape == (640, 480)
+    for i in range(1, 5):
+        assert levels[i].shape[0] < levels[i - 1].shape[0] and levels[i].shape[1] < levels[i - 1].shape[1]
+        scale = 1.5 ** i
+        assert abs(640 / levels[i].shape[0] - scale) < 1.0 and abs(480 / levels[i].shape[1] - scale) < 1.0
+
+
+def test_oracle_pyramid_truncation_and_size(oracle):
+    levels = oracle.pyramid(np.zeros((32, 32), np.uint8), 10, 2.0, 1.0)
+    assert len(levels) < 10 and min(levels[-1].shape) >= 8
+    levels = oracle.pyramid(np.zeros((256, 256), np.uint8), 4, 1.5, 1.0)
+    total = sum(l.shape[0] * l.shape[1] for l in levels)
+    assert 65536 < total < 2 * 65536
+    l = oracle.lib()
+    l.zo_pyramid_scale.restype = __import__("ctypes").c_float
+    for lvl, want in ((0, 1.0), (1, 1.2), (2, 1.44), (3, 1.728)):
+        assert abs(l.zo_pyramid_scale(__import__("ctypes").c_float(1.2), lvl) - want) < 0.01
+
+
+def test_library_pyramid_arithmetic_matches_oracle(oracle):
+    import ctypes as C
+    lib, l = zg.lib(), oracle.lib()
+    l.zo_pyramid_scale.restype = C.c_float
+    for sf in (1.2, 1.5, 2.0, 1.1):
+        for lvl in range(0, 12):
+            a, b = lib.zg_pyramid_scale(C.c_float(sf), lvl), l.zo_pyramid_scale(C.c_float(sf), lvl)
+            assert a == b
+            r1, c1, s1, r2, c2, s2 = C.c_uint32(), C.c_uint32(), C.c_float(), C.c_uint32(), C.c_uint32(), C.c_float()
+            lib.zg_pyramid_level(1080, 1920, C.c_float(a), C.c_float(1.6), C.byref(r1), C.byref(c1), C.byref(s1))
+            l.zo_pyramid_level(1080, 1920, C.c_float(b), C.c_float(1.6), C.byref(r2), C.byref(c2), C.byref(s2))
+            assert (r1.value, c1.value) == (r2.value, c2.value) and (s1.value == s2.value or (s1.value != s1.value and s2.value != s2.value))
+
+
+# ---- GPU parity ----------------------------------------------------------------------------------------------------
+torch = pytest.importorskip("torch")
+
+
+def dev(a):
+    return zg.Image(torch.from_numpy(np.ascontiguousarray(a)).cuda())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ALL_TYPES)
+def test_sobel_parity(oracle, kind):
+    for shape in ((1, 1), (5, 5), (3, 70), (67, 129), (256, 300)):
+        src = synth(oracle, kind, 80, *shape)
+        if src.dtype == np.float32 and kind == "f32":
+            src = src * np.float32(255)
+        out = dev(src).sobel()
+        torch.cuda.synchronize()
+        assert_bits_equal(out.to_numpy(), oracle.sobel(src), f"sobel {kind} {shape}")
+    img = np.zeros((5, 5), np.uint8)
+    img[:, 2:] = 255
+    e = zg.Image(img).sobel().data  # host layer; tests/filters.zig:548-570
+    assert e[2, 2] > 200 and e[2, 0] < 50
+    with pytest.raises(zg.DimensionMismatch):
+        zg.Image(img).sobel(out=zg.Image(np.zeros((5, 6), np.uint8)))
+
+
+@pytest.mark.gpu
+def test_sobel_4k(oracle):
+    src = oracle.synth_u8(81, (2048, 4096, 4))
+    out = dev(src).sobel()
+    torch.cuda.synchronize()
+    assert_bits_equal(out.to_numpy(), oracle.sobel(src), "sobel 2048x4096 rgba")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ("u8", "rgba_u8", "f32", "rgb_u8"))
+def test_pyramid_parity(oracle, kind):
+    src = synth(oracle, kind, 82, 480, 640)
+    for n, sf, sigma in ((5, 1.5, 1.0), (8, 1.2, 1.6), (10, 2.0, 1.0)):
+        want = oracle.pyramid(src, n, sf, sigma)
+        pyr = zg.ImagePyramid.build(dev(src), n, sf, sigma)
+        torch.cuda.synchronize()
+        assert pyr.n_levels == len(want)
+        for i, (g, w) in enumerate(zip(pyr.levels, want)):
+            assert_bits_equal(g.to_numpy(), w, f"pyramid {kind} ({n},{sf},{sigma}) level {i}")
+    assert zg.ImagePyramid.build(dev(np.zeros((32, 32), np.uint8)), 10, 2.0, 1.0).n_levels < 10  # pyramid.zig:236-252

@@ -35,6 +35,7 @@ pub const c = struct {
     pub extern fn zg_insert_host(self: *const ZgImage, source: *const ZgImage, rect: *const [4]f32, angle: f32, cos_a: f32, sin_a: f32, method: *const ZgMethod, blend_mode: c_int) c_int;
     pub extern fn zg_flip_left_right_host(img: *const ZgImage) c_int;
     pub extern fn zg_flip_top_bottom_host(img: *const ZgImage) c_int;
+    pub extern fn zg_sobel_host(src: *const ZgImage, dst: *const ZgImage) c_int;
     pub extern fn zg_convert_host(src: *const ZgImage, src_space: c_int, dst: *const ZgImage, dst_space: c_int, srgb_lut: ?[*]const f32) c_int;
 };
 
@@ -134,6 +135,13 @@ pub fn Image(comptime T: type) type {
             _ = allocator;
             if (!self.base.hasSameShape(out.base)) return error.DimensionMismatch;
             try check(c.zg_box_blur_host(&desc(self.base), &desc(out.base), radius));
+        }
+
+        /// reference src/image.zig:1001-1010 (fused grey -> Sobel x/y -> magnitude on the device)
+        pub fn sobel(self: Self, out: Image(u8), allocator: std.mem.Allocator) !void {
+            _ = allocator;
+            if (self.base.rows != out.base.rows or self.base.cols != out.base.cols) return error.DimensionMismatch;
+            try check(c.zg_sobel_host(&desc(self.base), &Image(u8).desc(out.base)));
         }
 
         /// reference src/image.zig:523-525 (void: never fails; a HIP failure is a programming error here)

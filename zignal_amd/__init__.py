@@ -6,8 +6,8 @@ surface on top of it. There is no CPU fallback: importing works without a GPU, c
 """
 from ._lib import (BORDER_MIRROR, BORDER_REPLICATE, BORDER_WRAP, BORDER_ZERO, CS_GRAY, CS_OKLAB, CS_RGB,
                    CS_RGBA, CS_XYZ, CS_YCBCR, DimensionMismatch, InvalidArgument, ZignalError, lib)
-from .image import (AffineTransform, Blending, BorderMode, Image, Interpolation, ProjectiveTransform,
+from .image import (AffineTransform, Blending, BorderMode, Image, ImagePyramid, Interpolation, ProjectiveTransform,
                     SimilarityTransform, gaussian_kernel)
 
-__all__ = ["Image", "Interpolation", "BorderMode", "Blending", "ProjectiveTransform", "AffineTransform",
+__all__ = ["Image", "ImagePyramid", "Interpolation", "BorderMode", "Blending", "ProjectiveTransform", "AffineTransform",
            "SimilarityTransform", "gaussian_kernel", "DimensionMismatch", "InvalidArgument", "ZignalError", "lib"]

@@ -100,10 +100,14 @@ _SIGNATURES = {
     "zg_set_border": [_IMG, _U32P, C.c_void_p, C.c_void_p],
     "zg_convert": [_IMG, C.c_int, _IMG, C.c_int, _F32P, C.c_void_p],
     "zg_convert_host": [_IMG, C.c_int, _IMG, C.c_int, _F32P],
+    "zg_sobel": [_IMG, _IMG, C.c_void_p],
+    "zg_sobel_host": [_IMG, _IMG],
+    "zg_pyramid_scale": [C.c_float, C.c_uint32],
+    "zg_pyramid_level": [C.c_uint32, C.c_uint32, C.c_float, C.c_float, _U32P, _U32P, _F32P],
     "zg_batch_blur_resize": [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_float,
                              C.c_void_p, C.c_uint32, C.c_uint32, _METHOD, C.c_void_p],
 }
-_RESTYPES = {"zg_last_error": C.c_char_p, "zg_shutdown": None, "zg_pixel_size": C.c_size_t}
+_RESTYPES = {"zg_last_error": C.c_char_p, "zg_shutdown": None, "zg_pixel_size": C.c_size_t, "zg_pyramid_scale": C.c_float}
 
 # every symbol include/zignal_hip.h declares; tests check the library exports all of them
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -111,6 +111,12 @@ template <typename T> class Image {
         const zg_image s = desc(), d = out.desc();
         check(zg_box_blur_host(&s, &d, radius));
     }
+    Image<uint8_t> sobel() const {                                                       // image.zig:1001 (out allocated here)
+        auto out = Image<uint8_t>::init(rows, cols);
+        const zg_image s = desc(), d = out.desc();
+        check(zg_sobel_host(&s, &d));
+        return out;
+    }
     // ---- resampling ----
     void resize(const Image &out, Interpolation method) const {                          // image.zig:523
         const zg_image s = desc(), d = out.desc(); const zg_method m = method.c_method();

@@ -356,6 +356,16 @@ class Image:
         self._call("flip_top_bottom", C.byref(s))
         return self
 
+    # ---- callers of the path -----------------------------------------------------
+    def sobel(self, out: Optional["Image"] = None) -> "Image":
+        """Image.sobel (image.zig:1001-1010): gradient magnitude as Image(u8), one fused kernel."""
+        if out is None:
+            out = self._like(dtype=torch.uint8 if self.on_device else np.uint8, channels=1)
+        self._same_side(out)
+        s, d = self._desc(), out._desc()
+        self._call("sobel", C.byref(s), C.byref(d))
+        return out
+
     # ---- colour -----------------------------------------------------------------------------
     def convert(self, dst_space: int, dtype=np.float32, src_space: Optional[int] = None,
                 out: Optional["Image"] = None, srgb_lut=None) -> "Image":
@@ -399,6 +409,45 @@ def gaussian_kernel(sigma: float) -> np.ndarray:
     out = np.empty(n, np.float32)
     lib.zg_gaussian_kernel(C.c_float(sigma), out.ctypes.data_as(C.POINTER(C.c_float)), n)
     return out
+
+
+class ImagePyramid:
+    """ImagePyramid(T) (reference src/image/pyramid.zig:11-170): level 0 is the source itself, level i is the source
+    blurred with sigma_i = blur_sigma * sqrt(scale_i^2 - 1) (only if > 0.5) and resized bilinearly to trunc(dim / scale_i),
+    scale_i = pow(scale_factor, i); a level below 8 x 8 truncates the pyramid. Pure composition of gaussianBlur + resize."""
+
+    def __init__(self, levels, scale_factor: float, blur_sigma: float):
+        self.levels, self.scale_factor, self.blur_sigma = levels, scale_factor, blur_sigma
+
+    @property
+    def n_levels(self) -> int:
+        return len(self.levels)
+
+    @staticmethod
+    def build(source: "Image", n_levels: int, scale_factor: float, blur_sigma: float) -> "ImagePyramid":
+        assert n_levels > 0 and scale_factor > 1.0 and blur_sigma > 0
+        lib = L.lib()
+        levels = [source]
+        for i in range(1, n_levels):
+            scale = lib.zg_pyramid_scale(C.c_float(scale_factor), i)
+            r, c, sigma = C.c_uint32(), C.c_uint32(), C.c_float()
+            L.check(lib.zg_pyramid_level(source.rows, source.cols, C.c_float(scale), C.c_float(blur_sigma),
+                                         C.byref(r), C.byref(c), C.byref(sigma)))
+            if r.value < 8 or c.value < 8:
+                break
+            base = source.gaussian_blur(sigma.value) if sigma.value > 0.5 else source
+            levels.append(base.resize((r.value, c.value), Interpolation.bilinear))
+        return ImagePyramid(levels, scale_factor, blur_sigma)
+
+    @staticmethod
+    def build_default(source: "Image") -> "ImagePyramid":
+        return ImagePyramid.build(source, 8, 1.2, 1.6)
+
+    def get_scale(self, level: int) -> float:
+        return L.lib().zg_pyramid_scale(C.c_float(self.scale_factor), level)
+
+    def total_pixels(self) -> int:
+        return sum(l.rows * l.cols for l in self.levels)
 
 
 class ProjectiveTransform:
