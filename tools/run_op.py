@@ -1,4 +1,4 @@
-"""Run one op a few times on the GPU (for rocprofv3 passes). usage: python tools/run_op.py blur_u8|blur_f32|resize|warp_u8|warp_f32|oklab [n]"""
+"""Run one op a few times on the GPU (for rocprofv3 passes). usage: python tools/run_op.py blur_u8|blur_f32|resize|warp_u8|warp_f32|oklab|box_u8|box_rgba8|blur17_u8|blur17_f32|blur11_u8|conv3_u8|conv3_f32 [n]"""
 import sys
 sys.path.insert(0, ".")
 import numpy as np, torch
@@ -26,6 +26,18 @@ elif op in ("warp_u8", "warp_f32"):
 elif op == "oklab":
     s = zg.Image(torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")); d = zg.Image(torch.empty((R, R, 3), dtype=torch.float32, device="cuda"))
     f = lambda: s.convert(zg.CS_OKLAB, np.float32, out=d)
+elif op in ("box_u8", "box_rgba8"):
+    t = torch.randint(0, 256, (R, R, 4) if op == "box_rgba8" else (R, R), dtype=torch.uint8, device="cuda")
+    s = zg.Image(t); d = zg.Image(torch.empty_like(t))
+    f = lambda: s.box_blur(2, out=d)
+elif op in ("blur17_u8", "blur17_f32", "blur11_u8"):
+    t = torch.rand((R, R, 4), dtype=torch.float32, device="cuda") if op.endswith("f32") else torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")
+    s = zg.Image(t); d = zg.Image(torch.empty_like(t))
+    f = lambda: s.gaussian_blur(1.5 if "11" in op else 2.5, out=d)
+elif op in ("conv3_u8", "conv3_f32"):
+    t = torch.rand((R, R, 4), dtype=torch.float32, device="cuda") if op.endswith("f32") else torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")
+    s = zg.Image(t); d = zg.Image(torch.empty_like(t)); k3 = np.full((3, 3), 1 / 9, np.float32)
+    f = lambda: s.convolve(k3, 1, out=d)
 for _ in range(n):
     f()
 torch.cuda.synchronize()

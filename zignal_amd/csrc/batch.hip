@@ -57,7 +57,7 @@ int zg_batch_blur_resize(const void *src_frames, uint32_t n_frames, uint32_t row
     void *scratch = nullptr;
     int rc = ZG_OK;
     if (!taps.empty()) { // batched blur of every frame in one launch, then the reference's resize per frame
-        ZG_HIP(hipMallocAsync(&scratch, (size_t)n_frames * in_px * ps, s));
+        if ((rc = scratch_alloc(&scratch, (size_t)n_frames * in_px * ps, s))) return rc;
         const Rgba8Batch b{src_frames, scratch, n_frames, rows, cols, cols, cols, in_px, in_px, false};
         rc = try_sep_rgba8_batch(b, taps.data(), taps.data(), (int)taps.size(), ZG_BORDER_MIRROR, s);
         if (rc >= 0) {
@@ -66,16 +66,15 @@ int zg_batch_blur_resize(const void *src_frames, uint32_t n_frames, uint32_t row
                 zg_image dst{(char *)dst_frames + (size_t)i * out_px * ps, out_cols, out_rows, out_cols, pixel};
                 rc = resize_impl(&tmp, &dst, method, s);
             }
-            (void)hipFreeAsync(scratch, s);
+            scratch_free(scratch, s);
             return rc;
         }
-        (void)hipFreeAsync(scratch, s);
+        scratch_free(scratch, s);
         scratch = nullptr;
     }
 
     // general path: two scratch frames so frame i+1's blur may start while frame i's resize still reads its scratch
-    ZG_HIP(hipMallocAsync(&scratch, 2 * in_px * ps, s));
-    rc = ZG_OK;
+    if ((rc = scratch_alloc(&scratch, 2 * in_px * ps, s))) return rc;
     for (uint32_t i = 0; i < n_frames && rc == ZG_OK; ++i) {
         zg_image src{(char *)src_frames + (size_t)i * in_px * ps, cols, rows, cols, pixel};
         zg_image tmp{(char *)scratch + (size_t)(i & 1) * in_px * ps, cols, rows, cols, pixel};
@@ -83,7 +82,7 @@ int zg_batch_blur_resize(const void *src_frames, uint32_t n_frames, uint32_t row
         rc = zg_gaussian_blur(&src, &tmp, sigma, stream);
         if (rc == ZG_OK) rc = resize_impl(&tmp, &dst, method, s);
     }
-    (void)hipFreeAsync(scratch, s);
+    scratch_free(scratch, s);
     return rc;
 }
 

@@ -6,9 +6,12 @@
 // for bit; the window and its area are clipped at the borders and the mean goes through meta.clamp for u8.
 // All SAT planes are complete before any output is written, so src may alias dst as in the reference.
 //
-//   k_sat_rows   one wave per 64 rows: 64x64 tiles staged through LDS (coalesced loads / stores), each lane
+//   k_sat_rows   one wave per (64 rows, channel): 64x64 tiles staged through LDS (coalesced, loads batched), each lane
 //                scans its row of the tile sequentially and carries the running sum to the next tile.
-//   k_sat_cols   one thread per (column, channel): sequential accumulation down the rows, coalesced across lanes.
+//   k_sat_cols   one thread per (column, channel): sequential accumulation down the rows, coalesced across lanes,
+//                16 rows prefetched ahead of the chain.
+// The two scans are sequential f32 chains by contract (the reference's rounding order), so their parallelism is capped
+// at rows x channels and columns x channels chains; they are latency-bound, not bandwidth-bound.
 //   k_box_mean   one thread per pixel: four SAT taps, divide by the clipped area, clamp.
 #include "zg_common.h"
 
@@ -18,51 +21,94 @@ namespace zg {
 
 int copy_impl(const zg_image *src, const zg_image *dst, hipStream_t s);
 
+// Row pass. The running sum along a row is a sequential f32 chain (f32 addition is not associative and the reference's
+// rounding must be reproduced), so the parallelism is rows x channels. One wave owns 64 rows of one channel: per chunk
+// of 64 columns it loads the 64 x 64 tile (lanes = consecutive columns: coalesced; the next chunk's loads are issued
+// before this chunk is processed), transposes through LDS, each lane runs its row's 64-step chain in registers carrying
+// the sum across chunks, and the results go back out transposed (coalesced again).
 template <int PIX>
 __global__ __launch_bounds__(64) void k_sat_rows(DImg src, float *sat) { // sat: [C][rows][cols]
     using P = Px<PIX>;
+    using Elem = typename P::Elem;
     constexpr int C = P::C;
     __shared__ float tile[64][65];
     const int lane = threadIdx.x;
     const int r0 = blockIdx.x * 64;
     const int ch = blockIdx.y;
     const size_t plane = (size_t)src.rows * src.cols;
+    const Elem *base = (const Elem *)src.data;
+    const int nrows = min(64, src.rows - r0);
+
+    auto fetch = [&](int c0, float (&v)[64]) {
+        // addresses are clamped into the image instead of predicating the loads: a predicated load makes the compiler
+        // wait for each one before issuing the next (measured 14 us per chunk); rows / columns past the edge are never stored
+        const int c = min(c0 + lane, src.cols - 1);
+#pragma unroll
+        for (int i = 0; i < 64; ++i) v[i] = (float)base[((size_t)(r0 + min(i, nrows - 1)) * src.stride + c) * C + ch];
+    };
+
+    float cur[64], nxt[64];
+    fetch(0, cur);
     float run = 0.0f; // lane = row within the strip
     for (int c0 = 0; c0 < src.cols; c0 += 64) {
-        for (int i = 0; i < 64; ++i) { // row i of the strip, 64 consecutive columns
-            const int r = r0 + i, c = c0 + lane;
-            float v = 0.0f;
-            if (r < src.rows && c < src.cols) {
-                const typename P::Elem *p = (const typename P::Elem *)src.data + ((size_t)r * src.stride + c) * C + ch;
-                v = (float)*p;
-            }
-            tile[i][lane] = v;
+        fetch(c0 + 64, nxt); // clamped: harmless past the last chunk
+#pragma unroll
+        for (int i = 0; i < 64; ++i) tile[i][lane] = cur[i];
+        __syncthreads();
+        float rowv[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) rowv[j] = tile[lane][j];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) { // the chain values produced by columns past the edge are never stored
+            run = run + rowv[j];
+            rowv[j] = run;
+        }
+#pragma unroll
+        for (int j = 0; j < 64; ++j) tile[lane][j] = rowv[j];
+        __syncthreads();
+        const int c = c0 + lane;
+        if (c < src.cols) {
+            float *o = sat + (size_t)ch * plane + (size_t)r0 * src.cols + c;
+#pragma unroll
+            for (int i = 0; i < 64; ++i)
+                if (i < nrows) o[(size_t)i * src.cols] = tile[i][lane];
         }
         __syncthreads();
-        const int ncols = min(64, src.cols - c0);
-        for (int j = 0; j < ncols; ++j) {
-            run = run + tile[lane][j];
-            tile[lane][j] = run;
-        }
-        __syncthreads();
-        for (int i = 0; i < 64; ++i) {
-            const int r = r0 + i, c = c0 + lane;
-            if (r < src.rows && c < src.cols) sat[(size_t)ch * plane + (size_t)r * src.cols + c] = tile[i][lane];
-        }
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 64; ++i) cur[i] = nxt[i];
     }
 }
 
-__global__ __launch_bounds__(256) void k_sat_cols(float *sat, int rows, int cols) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+// Column pass: sat[r][c] += sat[r-1][c], a sequential chain down each column (coalesced across lanes). Rows are taken
+// 32 at a time with the following 32 already in flight, so the chain runs at add latency rather than memory latency.
+__global__ __launch_bounds__(64) void k_sat_cols(float *sat, int rows, int cols) {
+    constexpr int G = 32;
+    const int c = blockIdx.x * 64 + threadIdx.x;
     const int ch = blockIdx.y;
     if (c >= cols) return;
     float *p = sat + (size_t)ch * rows * cols + c;
-    float prev = p[0];
-    for (int r = 1; r < rows; ++r) {
-        const float cur = p[(size_t)r * cols] + prev; // dst[curr] += dst[prev]
-        p[(size_t)r * cols] = cur;
-        prev = cur;
+    auto fetch = [&](int r, float (&v)[G]) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) v[i] = p[(size_t)min(r + i, rows - 1) * cols]; // clamped, not predicated (see k_sat_rows)
+    };
+    float prev = 0.0f;
+    auto chain_store = [&](int r, float (&v)[G]) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            if (r + i < rows) {
+                if (r + i > 0) v[i] = v[i] + prev; // dst[curr] += dst[prev], rows 1..
+                prev = v[i];
+                p[(size_t)(r + i) * cols] = v[i];
+            }
+        }
+    };
+    float a[G], b[G];
+    fetch(0, a);
+    for (int r = 0; r < rows; r += 2 * G) {
+        fetch(r + G, b);
+        chain_store(r, a);
+        fetch(r + 2 * G, a);
+        chain_store(r + G, b);
     }
 }
 
@@ -104,16 +150,16 @@ static int box_blur_impl(const zg_image *src, const zg_image *dst, uint32_t radi
     ZG_REQUIRE(radius < (1u << 30), ZG_ERR_INVALID_ARGUMENT, "boxBlur: radius too large");
     const int C = pixel_channels(src->pixel);
     float *sat = nullptr;
-    ZG_HIP(hipMallocAsync((void **)&sat, (size_t)C * src->rows * src->cols * sizeof(float), s));
+    if ((rc = scratch_alloc((void **)&sat, (size_t)C * src->rows * src->cols * sizeof(float), s))) return rc;
     rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
         hipLaunchKernelGGL((k_sat_rows<PIX>), dim3(ceil_div(src->rows, 64), (unsigned)C), dim3(64), 0, s, dimg(src), sat);
-        hipLaunchKernelGGL(k_sat_cols, dim3(ceil_div(src->cols, 256), (unsigned)C), dim3(256), 0, s, sat, (int)src->rows, (int)src->cols);
+        hipLaunchKernelGGL(k_sat_cols, dim3(ceil_div(src->cols, 64), (unsigned)C), dim3(64), 0, s, sat, (int)src->rows, (int)src->cols);
         hipLaunchKernelGGL((k_box_mean<PIX>), dim3(ceil_div(dst->cols, 256), dst->rows), dim3(256), 0, s, (const float *)sat, dimg(dst), (int)radius);
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     });
-    ZG_HIP(hipFreeAsync(sat, s));
+    scratch_free(sat, s);
     return rc;
 }
 

@@ -326,8 +326,18 @@ __global__ __launch_bounds__(256) void k_sep_fused(DImg src, DImg dst, TapsArg<N
 }
 
 // ---- general two-pass fallback ----------------------------------------------------------------
+// The temp plane of the two-pass path holds C lanes of Temp per pixel ([rows][cols][C], 3-channel pixels padded to 4
+// lanes) so that one pixel of temps moves with one 4/16-byte access.
+template <typename T, int C> struct TempVec { typedef T type __attribute__((ext_vector_type(C == 3 ? 4 : C))); };
+template <int C> constexpr int temp_lanes() { return C == 3 ? 4 : C; }
+
+// Up to MAX_TAPS taps travel as a kernel argument (1 KB): no table upload, no synchronisation, graph-capturable.
+struct TapsBig {
+    union { float f[MAX_TAPS]; int32_t i[MAX_TAPS]; };
+};
+
 template <int PIX, int MODE>
-__global__ __launch_bounds__(256) void k_sep_h(DImg src, typename Arith<MODE>::Temp *temp, const void *taps,
+__global__ __launch_bounds__(256) void k_sep_h(DImg src, typename Arith<MODE>::Temp *temp, TapsBig taps,
                                                int nk, int border) {
     using P = Px<PIX>;
     using Vec = typename P::Vec;
@@ -343,26 +353,29 @@ __global__ __launch_bounds__(256) void k_sep_h(DImg src, typename Arith<MODE>::T
     const size_t row = (size_t)r * src.stride;
     for (int i = 0; i < nk; ++i) {
         if constexpr (MODE == MODE_F32) {
-            const float k = ((const float *)taps)[i];
+            const float k = taps.f[i];
             if (interior && fabsf(k) < 1e-10f) continue;
             const int gc = resolve_index(c + i - h, src.cols, border);
             Vec v = P::zero();
             if (gc >= 0) v = P::load(src.data, row + gc);
             for (int ch = 0; ch < C; ++ch) acc[ch] = A::mac(acc[ch], v[ch], k);
         } else {
-            const int32_t k = ((const int32_t *)taps)[i];
+            const int32_t k = taps.i[i];
             const int gc = resolve_index(c + i - h, src.cols, border);
             Vec v = P::zero();
             if (gc >= 0) v = P::load(src.data, row + gc);
             for (int ch = 0; ch < C; ++ch) acc[ch] = A::mac(acc[ch], (int32_t)v[ch], k);
         }
     }
-    typename A::Temp *t = temp + ((size_t)r * src.cols + c) * C;
-    for (int ch = 0; ch < C; ++ch) t[ch] = A::to_temp(acc[ch]);
+    using TV = typename TempVec<typename A::Temp, C>::type;
+    TV tv;
+#pragma unroll
+    for (int ch = 0; ch < temp_lanes<C>(); ++ch) tv[ch] = ch < C ? A::to_temp(acc[ch < C ? ch : 0]) : (typename A::Temp)0;
+    ((TV *)temp)[(size_t)r * src.cols + c] = tv;
 }
 
 template <int PIX, int MODE>
-__global__ __launch_bounds__(256) void k_sep_v(const typename Arith<MODE>::Temp *temp, DImg dst, const void *taps,
+__global__ __launch_bounds__(256) void k_sep_v(const typename Arith<MODE>::Temp *temp, DImg dst, TapsBig taps,
                                                int nk, int border) {
     using P = Px<PIX>;
     using Vec = typename P::Vec;
@@ -375,21 +388,22 @@ __global__ __launch_bounds__(256) void k_sep_v(const typename Arith<MODE>::Temp 
     const bool interior = (dst.rows > 2 * h) && r >= h && r < dst.rows - h;
     typename A::Acc acc[C];
     for (int ch = 0; ch < C; ++ch) acc[ch] = 0;
+    using TV = typename TempVec<typename A::Temp, C>::type;
     for (int i = 0; i < nk; ++i) {
         const int gr = resolve_index(r + i - h, dst.rows, border);
+        TV tv;
+#pragma unroll
+        for (int ch = 0; ch < temp_lanes<C>(); ++ch) tv[ch] = (typename A::Temp)0;
+        if (gr >= 0) tv = ((const TV *)temp)[(size_t)gr * dst.cols + c];
         if constexpr (MODE == MODE_F32) {
-            const float k = ((const float *)taps)[i];
+            const float k = taps.f[i];
             if (interior && fabsf(k) < 1e-10f) continue;
-            for (int ch = 0; ch < C; ++ch) {
-                const float v = gr >= 0 ? temp[((size_t)gr * dst.cols + c) * C + ch] : 0.0f;
-                acc[ch] = A::mac(acc[ch], v, k);
-            }
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) acc[ch] = A::mac(acc[ch], tv[ch], k);
         } else {
-            const int32_t k = ((const int32_t *)taps)[i];
-            for (int ch = 0; ch < C; ++ch) {
-                const int32_t v = gr >= 0 ? temp[((size_t)gr * dst.cols + c) * C + ch] : 0;
-                acc[ch] = A::mac(acc[ch], v, k);
-            }
+            const int32_t k = taps.i[i];
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) acc[ch] = A::mac(acc[ch], tv[ch], k);
         }
     }
     Vec o;
@@ -476,24 +490,17 @@ template <int PIX, int MODE>
 static int launch_two_pass(const zg_image *src, const zg_image *dst, const SepPlan &p, int border, hipStream_t s) {
     using Temp = typename Arith<MODE>::Temp;
     constexpr int C = Px<PIX>::C;
-    const size_t temp_bytes = (size_t)src->rows * src->cols * C * sizeof(Temp);
-    const size_t tap_bytes = (size_t)(p.nkx + p.nky) * 4;
-    char *scratch = nullptr;
-    ZG_HIP(hipMallocAsync((void **)&scratch, temp_bytes + tap_bytes, s));
-    Temp *temp = (Temp *)scratch;
-    void *dkx = scratch + temp_bytes;
-    void *dky = scratch + temp_bytes + (size_t)p.nkx * 4;
-    const void *hx = MODE == MODE_F32 ? (const void *)p.fx.data() : (const void *)p.ix.data();
-    const void *hy = MODE == MODE_F32 ? (const void *)p.fy.data() : (const void *)p.iy.data();
-    // pageable host memory: hipMemcpyAsync copies out of the source before returning
-    ZG_HIP(hipMemcpyAsync(dkx, hx, (size_t)p.nkx * 4, hipMemcpyHostToDevice, s));
-    ZG_HIP(hipMemcpyAsync(dky, hy, (size_t)p.nky * 4, hipMemcpyHostToDevice, s));
-    ZG_HIP(hipStreamSynchronize(s)); // taps live in caller-owned vectors
+    const size_t temp_bytes = (size_t)src->rows * src->cols * temp_lanes<C>() * sizeof(Temp);
+    Temp *temp = nullptr;
+    if (int rc = scratch_alloc((void **)&temp, temp_bytes, s)) return rc;
+    TapsBig tx, ty;
+    for (int i = 0; i < p.nkx; ++i) { if constexpr (MODE == MODE_F32) tx.f[i] = p.fx[i]; else tx.i[i] = p.ix[i]; }
+    for (int i = 0; i < p.nky; ++i) { if constexpr (MODE == MODE_F32) ty.f[i] = p.fy[i]; else ty.i[i] = p.iy[i]; }
     const dim3 grid(ceil_div(src->cols, 256), src->rows);
-    hipLaunchKernelGGL((k_sep_h<PIX, MODE>), grid, dim3(256), 0, s, dimg(src), temp, dkx, p.nkx, border);
-    hipLaunchKernelGGL((k_sep_v<PIX, MODE>), grid, dim3(256), 0, s, temp, dimg(dst), dky, p.nky, border);
+    hipLaunchKernelGGL((k_sep_h<PIX, MODE>), grid, dim3(256), 0, s, dimg(src), temp, tx, p.nkx, border);
+    hipLaunchKernelGGL((k_sep_v<PIX, MODE>), grid, dim3(256), 0, s, temp, dimg(dst), ty, p.nky, border);
     ZG_HIP(hipGetLastError());
-    ZG_HIP(hipFreeAsync(scratch, s));
+    scratch_free(temp, s);
     return ZG_OK;
 }
 

@@ -173,4 +173,8 @@ struct HostStage {
 
 int check_image(const zg_image *im, const char *name, bool device_pointer = true);
 
+// stream-ordered scratch from the device's default pool (zg_runtime.cpp)
+int scratch_alloc(void **out, size_t bytes, hipStream_t s);
+void scratch_free(void *p, hipStream_t s);
+
 } // namespace zg

@@ -38,6 +38,29 @@ int check_image(const zg_image *im, const char *name, bool device_pointer) {
     return ZG_OK;
 }
 
+// Scratch for the multi-kernel ops (two-pass separable temp, integral image, batch intermediates): stream-ordered from
+// the device's default pool. The pool's release threshold is raised once so that a freed scratch block stays mapped for
+// the next call instead of going back to the driver at every synchronisation point (a 256 MB remap costs milliseconds).
+int scratch_alloc(void **out, size_t bytes, hipStream_t s) {
+    static thread_local int tuned_device = -1;
+    int dev = 0;
+    ZG_HIP(hipGetDevice(&dev));
+    if (tuned_device != dev) {
+        hipMemPool_t pool;
+        ZG_HIP(hipDeviceGetDefaultMemPool(&pool, dev));
+        uint64_t keep = ~(uint64_t)0;
+        ZG_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+        tuned_device = dev;
+    }
+    *out = nullptr;
+    ZG_HIP(hipMallocAsync(out, bytes, s));
+    return ZG_OK;
+}
+
+void scratch_free(void *p, hipStream_t s) {
+    if (p) (void)hipFreeAsync(p, s);
+}
+
 HostStage::~HostStage() {
     if (dev.data) (void)hipFree(dev.data);
 }
