@@ -152,17 +152,51 @@ def test_gaussian_blur_host_and_device_layers(oracle, kind, sigma):
 
 
 # ---- BASELINE.json configs[1]: 5x5 Gaussian on 4096x4096 RGBA -------------------------------------
-@pytest.mark.parametrize("kind", ("rgba_f32", "rgba_u8"))
+@pytest.mark.parametrize("kind", ("u8", "rgb_u8"))
+@pytest.mark.parametrize("border", BORDERS)
+def test_byte_stream_fast_path(oracle, kind, border):
+    """Grey / Rgb u8 rows whose byte length is a multiple of 16 run on the 16-bytes-per-lane kernel (conv_sep_bytes.hip):
+    non-negative integer taps summing to <= 257, 3..9 taps; tile seams at 1024 bytes, edges resolved per pixel."""
+    rng = np.random.default_rng(11)
+    for n in (3, 5, 7, 9):
+        t = rng.integers(0, 60, n)
+        t[n // 2] += 256 - t.sum()  # taps sum to 256 like every Gaussian the reference builds
+        k = (t / 256.0).astype(np.float32)
+        for (rows, cols) in ((9, 272), (70, 1040), (33, 2064), (5, 352)):
+            img = synth(oracle, kind, 300 + n, rows, cols)
+            assert_bits_equal(run_dev(img, k, k, border), oracle.conv_separable(img, k, k, border),
+                              f"{kind} {rows}x{cols} taps={n} border={border}")
+    # saturating kernel (sum 257 on both axes: 255 * 257 * 257 overflows u8 -> the clamped variant) on a white-ish frame
+    k = (np.array([86, 85, 86]) / 256.0).astype(np.float32)
+    img = np.maximum(synth(oracle, kind, 9, 40, 528), 250)
+    assert_bits_equal(run_dev(img, k, k, border), oracle.conv_separable(img, k, k, border), f"{kind} clamp border={border}")
+    # 16-byte aligned view inside a larger frame, into a view
+    base = synth(oracle, kind, 10, 64, 1088)
+    v = base[7:50, 16:16 + 1040]
+    src = zg.Image(torch.from_numpy(base).cuda()).view((16, 7, 16 + 1040, 50))
+    dst_base = torch.zeros((64, 1088) + base.shape[2:], dtype=torch.uint8, device="cuda")
+    dst = zg.Image(dst_base).view((32, 3, 32 + 1040, 46))
+    kk = (np.array([20, 60, 96, 60, 20]) / 256.0).astype(np.float32)
+    src.convolve_separable(kk, kk, border, out=dst)
+    torch.cuda.synchronize()
+    want = oracle.conv_separable(np.ascontiguousarray(v), kk, kk, border)
+    got = dst_base.cpu().numpy()
+    assert_bits_equal(got[3:46, 32:32 + 1040], want, f"{kind} view border={border}")
+    got[3:46, 32:32 + 1040] = 0
+    assert not got.any(), "pixels outside the destination view were written"
+
+
+@pytest.mark.parametrize("kind", ("rgba_f32", "rgba_u8", "u8", "rgb_u8"))
 def test_config2_full_size(oracle, kind):
     img = synth(oracle, kind, 2, 4096, 4096)
     out = dev(img).gaussian_blur(0.6)
     torch.cuda.synchronize()
     got = out.to_numpy()
     # size-independent property: a normalised kernel leaves a constant frame constant (u8 taps sum to 256)
-    const = np.full_like(img[:64, :64], 77 if kind == "rgba_u8" else np.float32(0.5))
+    const = np.full_like(img[:64, :512], 77 if kind != "rgba_f32" else np.float32(0.5))
     cout = dev(const).gaussian_blur(0.6)
     torch.cuda.synchronize()
-    if kind == "rgba_u8":
+    if kind != "rgba_f32":
         assert np.all(cout.to_numpy() == 77)
     # full comparison against the oracle (a few seconds of CPU)
     assert_bits_equal(got, oracle.gaussian_blur(img, 0.6), f"4096^2 {kind}")

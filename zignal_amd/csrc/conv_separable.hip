@@ -514,6 +514,7 @@ static int run_sep(const zg_image *src, const zg_image *dst, const SepPlan &p, i
 }
 
 int try_sep_rgba8(const zg_image *src, const zg_image *dst, const int32_t *ix, const int32_t *iy, int nk, int border, hipStream_t s);
+int try_sep_bytes(const zg_image *src, const zg_image *dst, const int32_t *ix, const int32_t *iy, int nk, int border, hipStream_t s);
 int try_sep_f32x4(const zg_image *src, const zg_image *dst, const float *fx, const float *fy, int nk, uint32_t skipx, uint32_t skipy,
                   int border, hipStream_t s);
 
@@ -567,9 +568,9 @@ static int conv_separable_impl(const zg_image *src, const zg_image *dst, const f
         const bool fits = mx < (1 << 23) && my < (1 << 23) && max_temp < (1 << 23) &&
                           max_temp * say < (int64_t)INT32_MAX - 65536;
         p.mode = fits ? MODE_I24 : MODE_I64;
-        if (src->pixel == ZG_PIXEL_RGBA_U8 && p.nkx == p.nky) { // small non-negative taps: packed-u16, 4 px / lane
-            const int rc8 = try_sep_rgba8(src, dst, p.ix.data(), p.iy.data(), p.nkx, border, s);
-            if (rc8 >= 0) return rc8;
+        if (p.nkx == p.nky) { // small non-negative taps: packed-u16 arithmetic on the row as a byte stream, 16 bytes / lane
+            const int rcb = try_sep_bytes(src, dst, p.ix.data(), p.iy.data(), p.nkx, border, s);
+            if (rcb >= 0) return rcb;
         }
     }
 
