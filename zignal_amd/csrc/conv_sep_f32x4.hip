@@ -31,33 +31,38 @@ template <int NK, int RPT> struct StageF4 {
     f32x4 main_v[RW];
     f32x4 extra_v;
 
-    __device__ static f32x4 load_unit(const DImg &src, int x0, int y0, int border, int r, int u) {
+    // tile row r, unit u: pixels x0 - 4 + 4u .. +3 of image row y0 - H + r. Units are all inside or all outside the row
+    // (cols % 4 == 0); outside ones (and rows the zero border drops) become 0 here and the pixels of them that the taps
+    // can reach are filled in by patch_edges. The load itself is unconditional from a clamped address: predicated loads
+    // would be issued one at a time.
+    __device__ static __forceinline__ f32x4 load_unit(const DImg &src, int x0, int y0, int border, int r, int u) {
         const int gr = resolve_index(y0 - H + r, src.rows, border);
         const int gx = x0 - 4 + 4 * u;
-        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (gr >= 0) {
-            const float *row = (const float *)src.data + (size_t)gr * src.stride;
-            if (gx >= 0 && gx + 4 <= src.cols) {
-                v = *(const f32x4 *)(row + gx);
-            } else {
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int gc = resolve_index(gx + p, src.cols, border);
-                    if (gc >= 0) v[p] = row[gc];
-                }
-            }
-        }
+        const bool ok = gr >= 0 && gx >= 0 && gx + 4 <= src.cols;
+        const float *row = (const float *)src.data + (size_t)max(gr, 0) * src.stride;
+        f32x4 v = *(const f32x4 *)(row + min(max(gx, 0), src.cols - 4)); // 16-byte aligned by the preconditions
+        if (!ok) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         return v;
     }
-    __device__ void load(const DImg &src, int x0, int y0, int border, int lx, int wave) {
+    __device__ __forceinline__ void load(const DImg &src, int x0, int y0, int border, int lx, int wave) {
 #pragma unroll
-        for (int k = 0; k < RW; ++k) {
-            const int r = wave + 4 * k;
-            if (r < LH) main_v[k] = load_unit(src, x0, y0, border, r, lx);
+        for (int k = 0; k < RW; ++k) main_v[k] = load_unit(src, x0, y0, border, min(wave + 4 * k, LH - 1), lx);
+        const int e = min((int)threadIdx.x, NEXTRA - 1); // lanes past NEXTRA load a duplicate and do not spill it
+        extra_v = load_unit(src, x0, y0, border, e >> 1, 64 + (e & 1));
+    }
+    // Border rule for the columns: the H pixels left of column 0 and right of the last column, where this tile covers
+    // them, one pixel per lane straight from global memory into the LDS tile (edge tiles only).
+    __device__ static void patch_edges(f32x4 *tile, const DImg &src, int x0, int y0, int border) {
+        for (int idx = (int)threadIdx.x; idx < LH * 2 * H; idx += 256) {
+            const int r = idx / (2 * H), k = idx - r * (2 * H);
+            const int px = k < H ? -1 - k : src.cols + (k - H);
+            const int t = px - (x0 - 4); // pixel position in the tile row
+            if (t < 0 || t >= F4_UNITS * 4) continue;
+            const int gr = resolve_index(y0 - H + r, src.rows, border);
+            const int gc = resolve_index(px, src.cols, border);
+            if (gr < 0 || gc < 0) continue; // zero border: already 0
+            ((float *)tile)[(size_t)r * F4_UNITS * 4 + t] = ((const float *)src.data)[(size_t)gr * src.stride + gc];
         }
-        const int e = (int)threadIdx.x;
-        extra_v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        if (e < NEXTRA) extra_v = load_unit(src, x0, y0, border, e >> 1, 64 + (e & 1));
     }
     __device__ void spill(f32x4 *tile, int lx, int wave) const {
 #pragma unroll
@@ -89,6 +94,10 @@ __global__ __launch_bounds__(256) void k_sep_f32x4(DImg src, DImg dst, TapsF32<N
     Stage st;
     st.load(src, x0, y0, border, lx, wave);
     st.spill(tile, lx, wave);
+    if (x0 == 0 || x0 + F4_TW + 4 > src.cols) { // workgroup-uniform: this tile sees the left or right border
+        __syncthreads();
+        Stage::patch_edges(tile, src, x0, y0, border);
+    }
     __syncthreads();
 
     const int gx = x0 + 4 * lx;

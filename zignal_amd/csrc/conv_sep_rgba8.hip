@@ -19,7 +19,8 @@
 
 namespace zg {
 
-// Register staging of one (4*RPT + 2H) x 66-unit source tile: all loads first, LDS writes later.
+// Register staging of one (4*RPT + 2H) x 66-unit source tile: all loads first, LDS writes later. Single frames now run
+// on the byte-stream kernel (conv_sep_bytes.hip, same arithmetic); this one keeps the batched and blur+half-resize forms.
 template <int NK, int RPT> struct Stage8 {
     static constexpr int H = NK / 2;
     static constexpr int LH = 4 * RPT + 2 * H;
@@ -28,34 +29,38 @@ template <int NK, int RPT> struct Stage8 {
     u32x4 main_v[RW];
     u32x4 extra_v;
 
-    __device__ static u32x4 load_unit(const DImg &src, int x0, int y0, int border, int r, int u) {
-        // tile row r, unit u: pixels x0 - 4 + 4u .. +3 of image row y0 - H + r
+    // tile row r, unit u: pixels x0 - 4 + 4u .. +3 of image row y0 - H + r. Units are all inside or all outside the row
+    // (cols % 4 == 0); outside ones (and rows the zero border drops) become 0 here and the pixels of them that the taps
+    // can reach are filled in by patch_edges. The load itself is unconditional from a clamped address: predicated loads
+    // would be issued one at a time.
+    __device__ static __forceinline__ u32x4 load_unit(const DImg &src, int x0, int y0, int border, int r, int u) {
         const int gr = resolve_index(y0 - H + r, src.rows, border);
         const int gx = x0 - 4 + 4 * u;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (gr >= 0) {
-            const uint32_t *row = (const uint32_t *)src.data + (size_t)gr * src.stride;
-            if (gx >= 0 && gx + 4 <= src.cols) {
-                v = *(const u32x4 *)(row + gx); // 16-byte aligned by the preconditions
-            } else {
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int gc = resolve_index(gx + p, src.cols, border);
-                    if (gc >= 0) v[p] = row[gc];
-                }
-            }
-        }
+        const bool ok = gr >= 0 && gx >= 0 && gx + 4 <= src.cols;
+        const uint32_t *row = (const uint32_t *)src.data + (size_t)max(gr, 0) * src.stride;
+        u32x4 v = *(const u32x4 *)(row + min(max(gx, 0), src.cols - 4)); // 16-byte aligned by the preconditions
+        if (!ok) v = u32x4{0u, 0u, 0u, 0u};
         return v;
     }
-    __device__ void load(const DImg &src, int x0, int y0, int border, int lx, int wave) {
+    __device__ __forceinline__ void load(const DImg &src, int x0, int y0, int border, int lx, int wave) {
 #pragma unroll
-        for (int k = 0; k < RW; ++k) {
-            const int r = wave + 4 * k;
-            if (r < LH) main_v[k] = load_unit(src, x0, y0, border, r, lx);
+        for (int k = 0; k < RW; ++k) main_v[k] = load_unit(src, x0, y0, border, min(wave + 4 * k, LH - 1), lx);
+        const int e = min((int)threadIdx.x, NEXTRA - 1); // lanes past NEXTRA load a duplicate and do not spill it
+        extra_v = load_unit(src, x0, y0, border, e >> 1, 64 + (e & 1));
+    }
+    // Border rule for the columns: the H pixels left of column 0 and right of the last column, where this tile covers
+    // them, one pixel per lane straight from global memory into the LDS tile (edge tiles only).
+    __device__ static void patch_edges(u32x4 *tile, const DImg &src, int x0, int y0, int border) {
+        for (int idx = (int)threadIdx.x; idx < LH * 2 * H; idx += 256) {
+            const int r = idx / (2 * H), k = idx - r * (2 * H);
+            const int px = k < H ? -1 - k : src.cols + (k - H);
+            const int t = px - (x0 - 4); // pixel position in the tile row
+            if (t < 0 || t >= R8_UNITS * 4) continue;
+            const int gr = resolve_index(y0 - H + r, src.rows, border);
+            const int gc = resolve_index(px, src.cols, border);
+            if (gr < 0 || gc < 0) continue; // zero border: already 0
+            ((uint32_t *)tile)[(size_t)r * R8_UNITS * 4 + t] = ((const uint32_t *)src.data)[(size_t)gr * src.stride + gc];
         }
-        const int e = (int)threadIdx.x;
-        extra_v = u32x4{0u, 0u, 0u, 0u};
-        if (e < NEXTRA) extra_v = load_unit(src, x0, y0, border, e >> 1, 64 + (e & 1));
     }
     __device__ void spill(u32x4 *tile, int lx, int wave) const {
 #pragma unroll
@@ -198,6 +203,10 @@ __global__ __launch_bounds__(256) void k_sep_rgba8(DImg src, DImg dst, size_t sr
     Stage st;
     st.load(src, tx * R8_TW, ty * TH, border, lx, wave);
     st.spill(tile, lx, wave);
+    if (tx == 0 || tx * R8_TW + R8_TW + 4 > src.cols) { // workgroup-uniform: this tile sees the left or right border
+        __syncthreads();
+        Stage::patch_edges(tile, src, tx * R8_TW, ty * TH, border);
+    }
     __syncthreads();
     convolve_tile8<NK, RPT, NT, CLAMP, DOWN2>(tile, dst, kx, ky, tx * R8_TW, ty * TH, lx, wave);
 }
