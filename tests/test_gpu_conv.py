@@ -200,3 +200,8 @@ def test_config2_full_size(oracle, kind):
         assert np.all(cout.to_numpy() == 77)
     # full comparison against the oracle (a few seconds of CPU)
     assert_bits_equal(got, oracle.gaussian_blur(img, 0.6), f"4096^2 {kind}")
+    if kind == "rgba_u8":  # the 3- and 7-tap forms of the large-frame kernel variant
+        for sigma in (0.3, 1.0):
+            out = dev(img).gaussian_blur(sigma)
+            torch.cuda.synchronize()
+            assert_bits_equal(out.to_numpy(), oracle.gaussian_blur(img, sigma), f"4096^2 {kind} sigma={sigma}")
