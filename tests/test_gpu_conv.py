@@ -186,6 +186,37 @@ def test_byte_stream_fast_path(oracle, kind, border):
     assert not got.any(), "pixels outside the destination view were written"
 
 
+@pytest.mark.parametrize("kind", ("u8", "rgb_u8", "rgba_u8"))
+@pytest.mark.parametrize("border", BORDERS)
+def test_long_kernels_packed_two_pass(oracle, kind, border):
+    """11..65-tap (and unequal / even-length) non-negative kernels on 16-byte-multiple rows: conv_sep_bytes2.hip."""
+    rng = np.random.default_rng(12)
+
+    def taps(n):
+        t = rng.integers(0, 256 // n + 1, n)
+        t[n // 2] += 255 - t.sum()
+        assert 0 <= t.min() and t.max() <= 255
+        return (t / 256.0).astype(np.float32)
+
+    for nx, ny in ((11, 11), (13, 13), (17, 17), (35, 35), (65, 65), (3, 21), (20, 6), (1, 33)):
+        kx, ky = taps(nx), taps(ny)
+        for (rows, cols) in ((9, 272), (70, 1040), (45, 352)):
+            img = synth(oracle, kind, 500 + nx, rows, cols)
+            assert_bits_equal(run_dev(img, kx, ky, border), oracle.conv_separable(img, kx, ky, border),
+                              f"{kind} {rows}x{cols} taps=({nx},{ny}) border={border}")
+    # the Gaussians an ORB pyramid asks for (sigma = 1.6 * sqrt(1.2^(2i) - 1), pyramid.zig:76-85)
+    img = synth(oracle, kind, 77, 96, 528)
+    for level in (2, 3, 5, 7):
+        sigma = float(np.float32(1.6) * np.sqrt(np.float32(1.2 ** level) ** 2 - np.float32(1.0)))
+        out = dev(img).gaussian_blur(sigma)
+        torch.cuda.synchronize()
+        assert_bits_equal(out.to_numpy(), oracle.gaussian_blur(img, sigma), f"{kind} pyramid level {level} sigma={sigma}")
+    # saturating taps (sum 257 both ways) on a near-white frame: the clamped column pass
+    k = np.zeros(11, np.float32); k[[0, 5, 10]] = np.array([86, 85, 86], np.float32) / 256
+    img = np.maximum(synth(oracle, kind, 9, 40, 528), 250)
+    assert_bits_equal(run_dev(img, k, k, border), oracle.conv_separable(img, k, k, border), f"{kind} clamp border={border}")
+
+
 @pytest.mark.parametrize("kind", ("rgba_f32", "rgba_u8", "u8", "rgb_u8"))
 def test_config2_full_size(oracle, kind):
     img = synth(oracle, kind, 2, 4096, 4096)
@@ -201,7 +232,7 @@ def test_config2_full_size(oracle, kind):
     # full comparison against the oracle (a few seconds of CPU)
     assert_bits_equal(got, oracle.gaussian_blur(img, 0.6), f"4096^2 {kind}")
     if kind == "rgba_u8":  # the 3- and 7-tap forms of the large-frame kernel variant
-        for sigma in (0.3, 1.0):
+        for sigma in (0.3, 1.0, 2.5):  # 2.5: 17 taps, the packed two-pass path
             out = dev(img).gaussian_blur(sigma)
             torch.cuda.synchronize()
             assert_bits_equal(out.to_numpy(), oracle.gaussian_blur(img, sigma), f"4096^2 {kind} sigma={sigma}")

@@ -20,8 +20,10 @@ run("blur 0.6 rgb_u8", (R, R, 3), torch.uint8, blur(0.6), 6)
 run("blur 0.6 rgb_f32", (R, R, 3), torch.float32, blur(0.6), 24)
 run("blur 0.6 rgba_u8", (R, R, 4), torch.uint8, blur(0.6), 8)
 run("blur 1.0 rgba_u8 (7 taps)", (R, R, 4), torch.uint8, blur(1.0), 8)
-run("blur 1.5 rgba_u8 (11 taps, general fused)", (R, R, 4), torch.uint8, blur(1.5), 8)
-run("blur 2.5 rgba_u8 (17 taps, two-pass)", (R, R, 4), torch.uint8, blur(2.5), 8)
+run("blur 1.5 rgba_u8 (11 taps)", (R, R, 4), torch.uint8, blur(1.5), 8)
+run("blur 2.5 rgba_u8 (17 taps)", (R, R, 4), torch.uint8, blur(2.5), 8)
+run("blur 2.5 u8 plane (17 taps)", (R, R), torch.uint8, blur(2.5), 2)
+run("blur 5.5 u8 plane (35 taps, ORB level 7)", (R, R), torch.uint8, blur(5.5), 2)
 run("blur 2.5 rgba_f32 (17 taps, two-pass)", (R, R, 4), torch.float32, blur(2.5), 32)
 run("blur 1.0 rgba_f32 (7 taps)", (R, R, 4), torch.float32, blur(1.0), 32)
 k3 = np.full((3, 3), 1 / 9, np.float32)

@@ -1,0 +1,262 @@
+// conv_sep_bytes2.hip — Image(u8 / Rgb(u8) / Rgba(u8)).convolveSeparable / gaussianBlur for LONG non-negative integer
+// kernels (the 11..65-tap Gaussians ImagePyramid builds: sigma = blur_sigma * sqrt(scale^2 - 1), reference
+// src/image/pyramid.zig:76-85), as two packed passes over the row as a byte stream.
+//
+// Same arithmetic contract as conv_separable.hip (reference src/image/convolution.zig:441-647, u8 path):
+// temp = sum src*kx (exact), out = divClampU8(65536, sum temp*ky), every channel with the same taps, tap j of an n-tap
+// kernel reading offset j - n/2. With taps in [0,255] summing to <= 257 the temp fits u16, so
+//   k_rows_u16   byte stream -> u16 temp plane (2 bytes per source byte, in HBM). A wave stages one row segment in LDS
+//                (its own buffer: no workgroup barrier) and walks the taps FOUR AT A TIME in a run-time loop: with the
+//                half width padded to a multiple of 4 (zero taps) every group's byte offset SP*(4g - hpad) is a whole
+//                number of dwords, so the window of a group is a few aligned LDS dwords and all byte-pair extraction
+//                (v_perm) and packed multiply-adds (v_pk_mad_u16) inside the group are compile-time. One kernel per
+//                pixel stride, any tap count. Lanes own the dwords l, l+64, l+128, l+192 of the 1024-byte tile so that
+//                dword-granular LDS reads hit consecutive banks.
+//   k_cols_u16   u16 temp -> bytes. A lane owns four adjacent bytes (two packed pairs) of 32 output rows as u32
+//                accumulators and streams the 32 + n - 1 temp rows past them once; the taps slide through 32 SGPRs, so
+//                each (row, output) step is four v_mad_u32_u16 with a scalar tap. No LDS, no window registers.
+// Border rule: columns in k_rows_u16 (edge tiles patch the out-of-row bytes of their LDS row), rows in k_cols_u16 (the
+// source row index of each streamed temp row is resolved on the scalar unit).
+//
+// Preconditions (else the general two-pass kernels run): u8 pixel types, row length and strides multiples of 16 bytes,
+// 16-byte aligned bases, row >= 256 bytes, taps as above, both tap counts <= 65.
+#include "zg_common.h"
+#include "zg_u8pack.h"
+
+namespace zg {
+
+constexpr int B2_HMAX = 32;  // padded half width of the row pass (a multiple of 4)
+constexpr int B2_NKMAX = 65; // longest kernel
+constexpr int B2_R = 32;     // output rows per lane in the column pass
+constexpr int B2_LEFT = 32;  // LDS halo dwords left of the tile (128 bytes >= hpad * SP)
+constexpr int B2_ROW = B2_LEFT + 256 + 36; // + right halo: hpad * SP <= 128 bytes and the 3 * SP + 3 bytes a group overshoots
+
+struct TapsRows { uint32_t kk[4 * (B2_HMAX / 2 + 1)]; }; // tap | tap << 16, index = offset + hpad, zero padded
+struct TapsCols { uint32_t k[B2_NKMAX + 2 * B2_R]; };    // k[B2_R + j] = tap j, zeros around
+
+template <int S, int NW> __device__ __forceinline__ u16x2 window_pair(const uint32_t (&w)[NW]) { // bytes (S, S + 1) of the window
+    constexpr int d = S >> 2, o = S & 3;
+    if constexpr (o == 0) return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, w[d], 0x0c010c00u));
+    else if constexpr (o == 1) return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, w[d], 0x0c020c01u));
+    else if constexpr (o == 2) return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, w[d], 0x0c030c02u));
+    else return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w[d + 1], w[d], 0x0c040c03u));
+}
+
+template <int SP>
+__global__ __launch_bounds__(256) void k_rows_u16(DImg src, uint32_t *temp, TapsRows taps, int hpad, int ngroups, int border,
+                                                  int tiles_x, int rows_per_wave) {
+    constexpr int NW = SP == 1 ? 2 : 4; // window dwords of a group: 4 output bytes + 3 * SP bytes of tap reach
+    __shared__ uint32_t lds[4][B2_ROW];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int xb0 = tx * 1024;
+    const int row_bytes = src.cols * SP;
+    uint32_t *buf = lds[wave];
+    const bool edge = xb0 == 0 || xb0 + 1024 + hpad * SP + 16 > row_bytes; // this tile's taps reach past a row end
+
+    for (int rr = 0; rr < rows_per_wave; ++rr) {
+        const int y = (ty * 4 + wave) * rows_per_wave + rr; // wave-uniform
+        if (y >= src.rows) break;
+        const uint8_t *row = (const uint8_t *)src.data + (size_t)y * src.stride * SP;
+        // stage bytes xb0 - 128 .. xb0 + 1024 + 144 of the row: 64 main units and 17 halo units of 16 bytes; units are all
+        // inside or all outside the row (length % 16 == 0), outside ones are zeroed here and patched below
+        {
+            const int gb = xb0 + 16 * lane;
+            u32x4 v = *(const u32x4 *)(row + min(gb, row_bytes - 16));
+            if (gb + 16 > row_bytes) v = u32x4{0u, 0u, 0u, 0u};
+            const int hu = min(lane, 16);                              // halo unit: 0..7 left, 8..16 right
+            const int hb = hu < 8 ? xb0 - 128 + 16 * hu : xb0 + 1024 + 16 * (hu - 8);
+            u32x4 h = *(const u32x4 *)(row + min(max(hb, 0), row_bytes - 16));
+            if (hb < 0 || hb + 16 > row_bytes) h = u32x4{0u, 0u, 0u, 0u};
+            *(u32x4 *)(buf + B2_LEFT + 4 * lane) = v;
+            if (lane < 17) *(u32x4 *)(buf + (hu < 8 ? 4 * hu : B2_LEFT + 256 + 4 * (hu - 8))) = h;
+        }
+        if (edge) { // border rule for the columns, one byte per lane
+            const int reach = hpad * SP + 16;
+            for (int k = lane; k < 2 * reach; k += 64) {
+                const int b = k < reach ? -1 - k : row_bytes + (k - reach); // byte position in the row's stream
+                const int t = b - (xb0 - 128);                               // byte position in the LDS row
+                if (t < 0 || t >= B2_ROW * 4) continue;
+                const int px = b >= 0 ? b / SP : -((SP - 1 - b) / SP); // floor
+                const int gc = resolve_index(px, src.cols, border);
+                if (gc < 0) continue; // zero border: already 0
+                ((uint8_t *)buf)[t] = row[gc * SP + (b - px * SP)];
+            }
+        }
+        __builtin_amdgcn_wave_barrier(); // LDS is in order within a wave; this only stops the compiler from reordering
+
+        u16x2 acc[4][2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = u16x2{0, 0};
+        for (int g = 0; g < ngroups; ++g) {
+            const uint32_t k0 = taps.kk[4 * g], k1 = taps.kk[4 * g + 1], k2 = taps.kk[4 * g + 2], k3 = taps.kk[4 * g + 3];
+            const int cdw = (SP * (4 * g - hpad)) / 4; // exact: SP == 4 or hpad % 4 == 0
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                uint32_t w[NW];
+#pragma unroll
+                for (int j = 0; j < NW; ++j) w[j] = buf[B2_LEFT + lane + 64 * m + cdw + j];
+                // output bytes (0,1) and (2,3) of this dword; tap t reads SP * t bytes further on
+                acc[m][0] += window_pair<0, NW>(w) * __builtin_bit_cast(u16x2, k0);
+                acc[m][1] += window_pair<2, NW>(w) * __builtin_bit_cast(u16x2, k0);
+                acc[m][0] += window_pair<SP, NW>(w) * __builtin_bit_cast(u16x2, k1);
+                acc[m][1] += window_pair<2 + SP, NW>(w) * __builtin_bit_cast(u16x2, k1);
+                acc[m][0] += window_pair<2 * SP, NW>(w) * __builtin_bit_cast(u16x2, k2);
+                acc[m][1] += window_pair<2 + 2 * SP, NW>(w) * __builtin_bit_cast(u16x2, k2);
+                acc[m][0] += window_pair<3 * SP, NW>(w) * __builtin_bit_cast(u16x2, k3);
+                acc[m][1] += window_pair<2 + 3 * SP, NW>(w) * __builtin_bit_cast(u16x2, k3);
+            }
+        }
+        __builtin_amdgcn_wave_barrier(); // the next row's staging must not overtake these reads
+
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        uint32_t *trow = temp + ((size_t)y * row_bytes + xb0) / 2; // two bytes of the stream per packed u32
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int b = xb0 + 4 * (lane + 64 * m);
+            if (b < row_bytes)
+                *(u32x2 *)(trow + 2 * (lane + 64 * m)) = u32x2{__builtin_bit_cast(uint32_t, acc[m][0]), __builtin_bit_cast(uint32_t, acc[m][1])};
+        }
+    }
+}
+
+template <bool CLAMP, bool INSIDE>
+__device__ __forceinline__ void cols_strip(const uint32_t *temp, uint8_t *dst, size_t dst_pitch, int rows, int row_bytes,
+                                           const TapsCols &taps, int nk, int half, int border, int tx, int ty) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const int xd = tx * 256 + (int)threadIdx.x; // this lane's dword of the row (4 bytes, 2 packed temp pairs)
+    const bool live = xd * 4 < row_bytes;
+    const int xdc = live ? xd : 0;
+    const int y0 = ty * B2_R;
+    const size_t trow = (size_t)row_bytes / 2;
+
+    uint32_t acc[B2_R][4];
+#pragma unroll
+    for (int o = 0; o < B2_R; ++o) acc[o][0] = acc[o][1] = acc[o][2] = acc[o][3] = 32768u; // divClampU8's rounding term
+    const int nrows_in = B2_R + nk - 1;
+    // Scalar instructions share the SIMD's issue slots with vector ones, so the per-row bookkeeping is kept minimal:
+    // strips whose 32 + nk - 1 rows all lie inside the image skip the border resolution, and the "is this tap inside
+    // the kernel" test is made once per 4 rows x 4 outputs.
+    const uint32_t *tcol = temp + 2 * (size_t)xdc;
+    const uint32_t *next_row = tcol + (size_t)(INSIDE ? y0 - half : 0) * trow; // INSIDE: a running pointer, one add per row
+    auto fetch = [&](int r) -> u32x2 { // temp row y0 - half + r; called with r = 0, 1, 2, ... in order
+        if constexpr (INSIDE) { // rows past the strip's last (prefetch overshoot) fall in the temp plane's slack rows
+            const u32x2 p = *(const u32x2 *)next_row;
+            next_row += trow;
+            return p;
+        } else {
+            const int gr = resolve_index(y0 - half + min(r, nrows_in - 1), rows, border); // scalar
+            u32x2 p = *(const u32x2 *)(tcol + (size_t)max(gr, 0) * trow);
+            if (gr < 0) p = u32x2{0u, 0u};
+            return p;
+        }
+    };
+    // rows are taken eight at a time with the next eight already in flight
+    u32x2 cur[8], nxt[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cur[i] = fetch(i);
+    for (int r0 = 0; r0 < nrows_in; r0 += 8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) nxt[i] = fetch(r0 + 8 + i);
+        // the taps of this chunk: output row o takes k[r - o] from temp row r = r0 + i, i.e. entry 32 + i - o of the
+        // 40-entry slice of the zero-padded tap table that starts at r0 (scalar loads, compile-time indices below).
+        // Rows past the last one and outputs outside the kernel's reach meet zero taps or are skipped.
+        uint32_t kw[40];
+#pragma unroll
+        for (int c = 0; c < 40; ++c) kw[c] = taps.k[r0 + c];
+#pragma unroll
+        for (int ib = 0; ib < 8; ib += 4) {
+#pragma unroll
+            for (int ob = 0; ob < B2_R; ob += 4) {
+                // rows r0+ib .. +3 against outputs ob .. +3: some tap index r - o in [0, nk)?
+                if (r0 + ib + 3 >= ob && r0 + ib - ob - 3 < nk) {
+#pragma unroll
+                    for (int i = ib; i < ib + 4; ++i) {
+#pragma unroll
+                        for (int o = ob; o < ob + 4; ++o) {
+                            const uint32_t k = __builtin_amdgcn_readfirstlane(kw[32 + i - o]);
+                            acc[o][0] = mad_lo16(cur[i][0], k, acc[o][0]);
+                            acc[o][1] = mad_hi16(cur[i][0], k, acc[o][1]);
+                            acc[o][2] = mad_lo16(cur[i][1], k, acc[o][2]);
+                            acc[o][3] = mad_hi16(cur[i][1], k, acc[o][3]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+    }
+    if (!live) return;
+#pragma unroll
+    for (int o = 0; o < B2_R; ++o) {
+        const int y = y0 + o;
+        if (y >= rows) break;
+        uint32_t out;
+        if constexpr (CLAMP) {
+            uint32_t v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const uint32_t t = acc[o][c] >> 16; v[c] = t > 255u ? 255u : t; }
+            out = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+        } else { // host proved acc < 2^24: the value is byte 2
+            out = __builtin_amdgcn_perm(acc[o][1], acc[o][0], 0x0c0c0602u) | __builtin_amdgcn_perm(acc[o][3], acc[o][2], 0x06020c0cu);
+        }
+        *(uint32_t *)(dst + (size_t)y * dst_pitch + 4 * (size_t)xd) = out;
+    }
+}
+
+template <bool CLAMP>
+__global__ __launch_bounds__(256) void k_cols_u16(const uint32_t *temp, uint8_t *dst, size_t dst_pitch, int rows, int row_bytes,
+                                                  TapsCols taps, int nk, int half, int border, int tiles_x) {
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * B2_R;
+    if (y0 - half >= 0 && y0 - half + B2_R + nk - 1 <= rows) // workgroup-uniform: every streamed row is inside the image
+        cols_strip<CLAMP, true>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
+    else
+        cols_strip<CLAMP, false>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
+}
+
+// Returns -1 when the preconditions do not hold (caller falls back to the general kernels).
+int try_sep_bytes2(const zg_image *src, const zg_image *dst, const int32_t *ix, int nkx, const int32_t *iy, int nky, int border, hipStream_t s) {
+    if (src->pixel != ZG_PIXEL_U8 && src->pixel != ZG_PIXEL_RGB_U8 && src->pixel != ZG_PIXEL_RGBA_U8) return -1;
+    if (nkx < 1 || nky < 1 || nkx > B2_NKMAX || nky > B2_NKMAX) return -1;
+    const size_t sp = pixel_size(src->pixel);
+    if ((src->cols * sp) % 16 || (src->stride * sp) % 16 || (dst->stride * sp) % 16 || ((uintptr_t)src->data & 15) || ((uintptr_t)dst->data & 15)) return -1;
+    if (src->cols * sp < 256 || (uint64_t)src->cols * sp > 0x3fffffffu) return -1;
+    int64_t sx = 0, sy = 0;
+    for (int i = 0; i < nkx; ++i) { if (ix[i] < 0 || ix[i] > 255) return -1; sx += ix[i]; }
+    for (int i = 0; i < nky; ++i) { if (iy[i] < 0 || iy[i] > 255) return -1; sy += iy[i]; }
+    if (sx > 257 || sy > 257) return -1; // temp must fit u16: 255 * 257 = 65535
+    const bool clamp = sx * sy * 255 + 32768 >= 256 * 65536; // only then can (acc >> 16) exceed 255
+
+    // row pass taps: tap j reads offset j - nkx / 2; the padded window starts at offset -hpad
+    const int halfx = nkx / 2, halfy = nky / 2;
+    // (4-byte pixels keep every group dword-aligned whatever hpad is; 1- and 3-byte pixels need hpad % 4 == 0)
+    const int hpad = sp == 4 ? halfx : std::max(4, (halfx + 3) / 4 * 4);
+    const int ngroups = (2 * hpad + 4) / 4; // taps at offsets -hpad .. +hpad, four per group
+    TapsRows tr{};
+    for (int j = 0; j < nkx; ++j) tr.kk[j - halfx + hpad] = (uint32_t)ix[j] | ((uint32_t)ix[j] << 16);
+    TapsCols tc{};
+    for (int j = 0; j < nky; ++j) tc.k[B2_R + j] = (uint32_t)iy[j];
+
+    const int row_bytes = (int)(src->cols * sp);
+    uint32_t *temp = nullptr;
+    // + 16 slack rows: the column pass prefetches up to 15 rows past a strip's last one (their taps are zero)
+    if (int rc = scratch_alloc((void **)&temp, ((size_t)src->rows + 16) * row_bytes * 2, s)) return rc;
+    const int tiles_x = (int)ceil_div((uint32_t)row_bytes, 1024u);
+    const int rows_per_wave = 4;
+    const dim3 grid_rows((unsigned)(tiles_x * ceil_div(src->rows, 4u * rows_per_wave)));
+    if (sp == 1) hipLaunchKernelGGL((k_rows_u16<1>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave);
+    else if (sp == 3) hipLaunchKernelGGL((k_rows_u16<3>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave);
+    else hipLaunchKernelGGL((k_rows_u16<4>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave);
+    const dim3 grid_cols((unsigned)(tiles_x * ceil_div(src->rows, (uint32_t)B2_R)));
+    if (clamp) hipLaunchKernelGGL((k_cols_u16<true>), grid_cols, dim3(256), 0, s, (const uint32_t *)temp, (uint8_t *)dst->data, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x);
+    else hipLaunchKernelGGL((k_cols_u16<false>), grid_cols, dim3(256), 0, s, (const uint32_t *)temp, (uint8_t *)dst->data, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x);
+    const hipError_t e = hipGetLastError();
+    scratch_free(temp, s);
+    ZG_HIP(e);
+    return ZG_OK;
+}
+
+} // namespace zg

@@ -515,6 +515,7 @@ static int run_sep(const zg_image *src, const zg_image *dst, const SepPlan &p, i
 
 int try_sep_rgba8(const zg_image *src, const zg_image *dst, const int32_t *ix, const int32_t *iy, int nk, int border, hipStream_t s);
 int try_sep_bytes(const zg_image *src, const zg_image *dst, const int32_t *ix, const int32_t *iy, int nk, int border, hipStream_t s);
+int try_sep_bytes2(const zg_image *src, const zg_image *dst, const int32_t *ix, int nkx, const int32_t *iy, int nky, int border, hipStream_t s);
 int try_sep_f32x4(const zg_image *src, const zg_image *dst, const float *fx, const float *fy, int nk, uint32_t skipx, uint32_t skipy,
                   int border, hipStream_t s);
 
@@ -572,6 +573,9 @@ static int conv_separable_impl(const zg_image *src, const zg_image *dst, const f
             const int rcb = try_sep_bytes(src, dst, p.ix.data(), p.iy.data(), p.nkx, border, s);
             if (rcb >= 0) return rcb;
         }
+        // longer (or unequal) non-negative kernels: two packed passes through a u16 temp plane
+        const int rcb2 = try_sep_bytes2(src, dst, p.ix.data(), p.nkx, p.iy.data(), p.nky, border, s);
+        if (rcb2 >= 0) return rcb2;
     }
 
     return dispatch_pixel(src->pixel, [&](auto tag) -> int {
