@@ -18,7 +18,7 @@ U8, F32, RGB_U8, RGBA_U8, RGB_F32, RGBA_F32 = range(6)
 ZERO, REPLICATE, MIRROR, WRAP = range(4)
 NEAREST, BILINEAR, BICUBIC, CATMULL_ROM, MITCHELL, LANCZOS = range(6)
 SIMILARITY, AFFINE, PROJECTIVE = range(3)
-CS_GRAY, CS_RGB, CS_RGBA, CS_OKLAB, CS_XYZ, CS_YCBCR = range(6)
+CS_GRAY, CS_RGB, CS_RGBA, CS_OKLAB, CS_XYZ, CS_YCBCR, CS_HSL, CS_HSV, CS_LAB, CS_LCH, CS_LMS, CS_OKLCH, CS_XYB = range(13)
 
 
 class ZoImage(C.Structure):
@@ -294,6 +294,18 @@ def convert(src, src_space, dst_space, dst_dtype, dst_channels, out=None, srgb_l
         lut = srgb_lut.ctypes.data_as(C.POINTER(C.c_float))
     _check(lib().zo_convert(C.byref(s), src_space, C.byref(d), dst_space, lut), "convert")
     return out
+
+
+def color_to(values, from_space: int, to_space: int, dtype=np.float64) -> np.ndarray:
+    """<Space>(T).to(target) on one colour (fields in declaration order), T = f64 (default) or f32."""
+    ct, fn = (C.c_double, lib().zo_color_to_f64) if dtype == np.float64 else (C.c_float, lib().zo_color_to_f32)
+    fn.argtypes = [C.c_int, C.POINTER(ct), C.c_int, C.POINTER(ct)]
+    fn.restype = None
+    vals = list(values) + [0] * (4 - len(values))
+    a, o = (ct * 4)(*vals), (ct * 4)()
+    fn(from_space, a, to_space, o)
+    n = 1 if to_space == CS_GRAY else (4 if to_space == CS_RGBA else 3)
+    return np.array(list(o)[:n], dtype)
 
 
 def homography_from_4pts(from_pts, to_pts) -> np.ndarray:

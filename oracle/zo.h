@@ -25,7 +25,8 @@ enum { ZO_U8 = 0, ZO_F32 = 1, ZO_RGB_U8 = 2, ZO_RGBA_U8 = 3, ZO_RGB_F32 = 4, ZO_
 enum { ZO_ZERO = 0, ZO_REPLICATE = 1, ZO_MIRROR = 2, ZO_WRAP = 3 };
 enum { ZO_NEAREST = 0, ZO_BILINEAR = 1, ZO_BICUBIC = 2, ZO_CATMULL_ROM = 3, ZO_MITCHELL = 4, ZO_LANCZOS = 5 };
 enum { ZO_SIMILARITY = 0, ZO_AFFINE = 1, ZO_PROJECTIVE = 2 };
-enum { ZO_CS_GRAY = 0, ZO_CS_RGB = 1, ZO_CS_RGBA = 2, ZO_CS_OKLAB = 3, ZO_CS_XYZ = 4, ZO_CS_YCBCR = 5 };
+enum { ZO_CS_GRAY = 0, ZO_CS_RGB = 1, ZO_CS_RGBA = 2, ZO_CS_OKLAB = 3, ZO_CS_XYZ = 4, ZO_CS_YCBCR = 5,
+       ZO_CS_HSL = 6, ZO_CS_HSV = 7, ZO_CS_LAB = 8, ZO_CS_LCH = 9, ZO_CS_LMS = 10, ZO_CS_OKLCH = 11, ZO_CS_XYB = 12 };
 
 typedef struct zo_image {
     void *data;
@@ -58,6 +59,13 @@ ZO_API float zo_powf(float x, float y);
 ZO_API float zo_cbrtf(float x);
 ZO_API float zo_sinf(float x);
 ZO_API float zo_cosf(float x);
+ZO_API float zo_atanf(float x);
+ZO_API float zo_atan2f(float y, float x);
+ZO_API double zo_pow64(double x, double y);
+
+/* colorspaces.c — <Space>(T).to(target) for every float colour space (src/color.zig), fields in declaration order */
+ZO_API void zo_color_to_f32(int from, const float in[4], int to, float out[4]);
+ZO_API void zo_color_to_f64(int from, const double in[4], int to, double out[4]);
 
 /* conv.c */
 ZO_API int zo_gaussian_kernel(float sigma, float *taps, uint32_t capacity);
