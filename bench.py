@@ -410,7 +410,29 @@ def extras(zg, torch, np):
         ms = _time_kernel(torch, lambda i: im[i % ring][0].sobel(out=im[i % ring][1]))
         return rate(ms, ROWS * COLS, 5 * ROWS * COLS)  # 4 B read + 1 B written per pixel (fused)
 
+    def lab(forward):
+        ring = 4
+        if forward:
+            im = [(zg.Image(s), zg.Image(torch.empty((ROWS, COLS, 3), dtype=torch.float32, device="cuda"))) for s in u8_frames(ring, (ROWS, COLS, 4))]
+            ms = _time_kernel(torch, lambda i: im[i % ring][0].convert(zg.CS_LAB, np.float32, out=im[i % ring][1]), n=20, warm=3)
+        else:
+            labs = [zg.Image(s).convert(zg.CS_LAB, np.float32) for s in u8_frames(ring, (ROWS, COLS, 4))]
+            im = [(l, zg.Image(torch.empty((ROWS, COLS, 4), dtype=torch.uint8, device="cuda"))) for l in labs]
+            ms = _time_kernel(torch, lambda i: im[i % ring][0].convert(zg.CS_RGBA, np.uint8, src_space=zg.CS_LAB, out=im[i % ring][1]), n=20, warm=3)
+        return rate(ms, ROWS * COLS, 16 * ROWS * COLS)  # 4 B + 12 B per pixel either way
+
+    def pyramid_blur():
+        # the blur of ORB pyramid level 3 on a grey frame: sigma = 1.6 * sqrt(1.2^6 - 1) = 2.25 (15 taps), packed two-pass path
+        ring = 4
+        im = [(zg.Image(torch.randint(0, 256, (ROWS, COLS), dtype=torch.uint8, device="cuda")), zg.Image(torch.empty((ROWS, COLS), dtype=torch.uint8, device="cuda")))
+              for _ in range(ring)]
+        ms = _time_kernel(torch, lambda i: im[i % ring][0].gaussian_blur(2.2528, out=im[i % ring][1]), n=20, warm=3)
+        return rate(ms, ROWS * COLS, 2 * ROWS * COLS)
+
     leg("next_sobel_rgba_u8_4096", sobel)
+    leg("next_pyramid_level3_blur_u8_4096", pyramid_blur)
+    leg("next_convert_rgba_u8_to_lab_f32_4096", lambda: lab(True))
+    leg("next_convert_lab_f32_to_rgba_u8_4096", lambda: lab(False))
     leg("config2a_gaussian_blur_one_f32_plane_4096", blur_planes)
     leg("config2b_gaussian_blur_rgba_u8_4096", blur_u8)
     leg("config3_resize_bilinear_rgba_u8_4096_to_1024", resize_u8)

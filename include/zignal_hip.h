@@ -75,13 +75,20 @@ typedef enum zg_transform_kind { /* src/geometry/transforms.zig:10,118,197 */
     ZG_TRANSFORM_PROJECTIVE = 2  /* m = row-major 3x3                       */
 } zg_transform_kind;
 
-typedef enum zg_colorspace { /* subset of src/color.zig ColorSpace used on the image path */
-    ZG_CS_GRAY = 0,
+typedef enum zg_colorspace { /* src/color.zig ColorSpace (the ordinals are this library's, not Zig's) */
+    ZG_CS_GRAY = 0,  /* Image(u8) / Image(f32) scalars */
     ZG_CS_RGB = 1,
     ZG_CS_RGBA = 2,
     ZG_CS_OKLAB = 3,
     ZG_CS_XYZ = 4,
-    ZG_CS_YCBCR = 5
+    ZG_CS_YCBCR = 5, /* u8 (16.16 fixed point) and float forms */
+    ZG_CS_HSL = 6,   /* 6..12: float-only colour types, three f32 fields in the struct's declaration order */
+    ZG_CS_HSV = 7,
+    ZG_CS_LAB = 8,
+    ZG_CS_LCH = 9,
+    ZG_CS_LMS = 10,
+    ZG_CS_OKLCH = 11,
+    ZG_CS_XYB = 12
 } zg_colorspace;
 
 /* Mirrors Image(T) (src/image.zig:97-103) plus the pixel tag that T carries at comptime. */
@@ -221,7 +228,10 @@ ZG_API int zg_set_border(const zg_image *img, const uint32_t rect[4], const void
 
 /* Image(T).convertInto (src/image.zig:396-407 -> convertColor src/color.zig:108-151).
  * The pixel layout comes from the images, the colour space from the arguments, e.g.
- * (RGBA_U8, ZG_CS_RGBA) -> (RGB_F32, ZG_CS_OKLAB) is Image(Rgba(u8)).convert(Oklab(f32)).
+ * (RGBA_U8, ZG_CS_RGBA) -> (RGB_F32, ZG_CS_OKLAB) is Image(Rgba(u8)).convert(Oklab(f32)). Any pair of colour spaces is
+ * accepted (color.zig:350-948 routing tables, :987-1532 conversion functions): three-field colour types live in
+ * RGB_F32 / RGB_U8 pixels, Rgba in RGBA_*, scalars in U8 / F32; float-only types (Hsl, Hsv, Lab, Lch, Lms, Oklab,
+ * Oklch, Xyb, Xyz) need f32 pixels (ZG_ERR_UNSUPPORTED otherwise).
  * srgb_lut: optional 256-entry host table of gammaToLinear(i/255) (color.zig:1252-1258), so a
  * Zig caller can supply values made with Zig's std.math.pow; NULL -> the library's own. */
 ZG_API int zg_convert(const zg_image *src, int src_space, const zg_image *dst, int dst_space,

@@ -232,7 +232,8 @@ static int convert_pixel(int src_space, int sf, const uint8_t su[4], const float
 
 int zo_convert(const zo_image *src, int src_space, const zo_image *dst, int dst_space, const float *srgb_lut) {
     const int legacy_src = src_space == ZO_CS_GRAY || src_space == ZO_CS_RGB || src_space == ZO_CS_RGBA;
-    if (legacy_src && dst_space <= ZO_CS_YCBCR) return convert_legacy(src, src_space, dst, dst_space, srgb_lut); /* honours srgb_lut */
+    const int float_ycbcr = dst_space == ZO_CS_YCBCR && (zo_is_float(src->pixel) || zo_is_float(dst->pixel));
+    if (legacy_src && dst_space <= ZO_CS_YCBCR && !float_ycbcr) return convert_legacy(src, src_space, dst, dst_space, srgb_lut); /* honours srgb_lut */
     if (src->rows != dst->rows || src->cols != dst->cols) return 1;
     if (src_space < 0 || src_space > ZO_CS_XYB || dst_space < 0 || dst_space > ZO_CS_XYB) return 5;
     const int sf = zo_is_float(src->pixel), df = zo_is_float(dst->pixel);

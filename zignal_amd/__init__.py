@@ -4,8 +4,8 @@ The product is `libzignal_hip.so` (hand-written HIP kernels behind the C ABI in
 include/zignal_hip.h); this package is the thin host-side mirror of the reference's `Image(T)`
 surface on top of it. There is no CPU fallback: importing works without a GPU, calling does not.
 """
-from ._lib import (BORDER_MIRROR, BORDER_REPLICATE, BORDER_WRAP, BORDER_ZERO, CS_GRAY, CS_OKLAB, CS_RGB,
-                   CS_RGBA, CS_XYZ, CS_YCBCR, DimensionMismatch, InvalidArgument, ZignalError, lib)
+from ._lib import (BORDER_MIRROR, BORDER_REPLICATE, BORDER_WRAP, BORDER_ZERO, CS_GRAY, CS_HSL, CS_HSV, CS_LAB, CS_LCH, CS_LMS, CS_OKLAB, CS_OKLCH, CS_RGB,
+                   CS_RGBA, CS_XYB, CS_XYZ, CS_YCBCR, DimensionMismatch, InvalidArgument, ZignalError, lib)
 from .image import (AffineTransform, Blending, BorderMode, Image, ImagePyramid, Interpolation, ProjectiveTransform,
                     SimilarityTransform, gaussian_kernel)
 

@@ -16,7 +16,7 @@ PIXEL_U8, PIXEL_F32, PIXEL_RGB_U8, PIXEL_RGBA_U8, PIXEL_RGB_F32, PIXEL_RGBA_F32 
 BORDER_ZERO, BORDER_REPLICATE, BORDER_MIRROR, BORDER_WRAP = range(4)
 INTERP_NEAREST, INTERP_BILINEAR, INTERP_BICUBIC, INTERP_CATMULL_ROM, INTERP_MITCHELL, INTERP_LANCZOS = range(6)
 TRANSFORM_SIMILARITY, TRANSFORM_AFFINE, TRANSFORM_PROJECTIVE = range(3)
-CS_GRAY, CS_RGB, CS_RGBA, CS_OKLAB, CS_XYZ, CS_YCBCR = range(6)
+CS_GRAY, CS_RGB, CS_RGBA, CS_OKLAB, CS_XYZ, CS_YCBCR, CS_HSL, CS_HSV, CS_LAB, CS_LCH, CS_LMS, CS_OKLCH, CS_XYB = range(13)
 
 OK, ERR_DIMENSION_MISMATCH, ERR_INVALID_ARGUMENT, ERR_OUT_OF_MEMORY, ERR_HIP, ERR_UNSUPPORTED = range(6)
 

@@ -15,6 +15,7 @@
 // port of Go's Pow); like the oracle's it is parity-unpinned against real Zig at the last ulp.
 #include "zg_common.h"
 #include "zg_hostmath.h"
+#include "zg_devmath.h"
 
 #include <cmath>
 #include <mutex>
@@ -22,112 +23,6 @@
 #pragma clang fp contract(off)
 
 namespace zg {
-
-// ---- device maths -------------------------------------------------------------------------------------
-__device__ inline float dev_cbrtf(float x) { // Zig std.math.cbrt cbrt32 == musl cbrtf
-    const uint32_t B1 = 709958130u, B2 = 642849266u;
-    uint32_t u = __float_as_uint(x);
-    uint32_t hx = u & 0x7fffffffu;
-    if (hx >= 0x7f800000u) return x + x;
-    if (hx < 0x00800000u) {
-        if (hx == 0) return x;
-        u = __float_as_uint(x * 0x1p24f);
-        hx = u & 0x7fffffffu;
-        hx = hx / 3 + B2;
-    } else {
-        hx = hx / 3 + B1;
-    }
-    u &= 0x80000000u;
-    u |= hx;
-    double t = (double)__uint_as_float(u);
-    double r = t * t * t;
-    t = t * ((double)x + x + r) / (x + r + r);
-    r = t * t * t;
-    t = t * ((double)x + x + r) / (x + r + r);
-    return (float)t;
-}
-
-__device__ inline float dev_scalbnf(float x, int n) {
-    float y = x;
-    if (n > 127) {
-        y *= 0x1p127f; n -= 127;
-        if (n > 127) { y *= 0x1p127f; n -= 127; if (n > 127) n = 127; }
-    } else if (n < -126) {
-        y *= 0x1p-126f * 0x1p24f; n += 126 - 24;
-        if (n < -126) { y *= 0x1p-126f * 0x1p24f; n += 126 - 24; if (n < -126) n = -126; }
-    }
-    return y * __uint_as_float((uint32_t)(0x7f + n) << 23);
-}
-__device__ inline float dev_expf(float x) { // musl expf
-    const float ln2hi = 6.9314575195e-1f, ln2lo = 1.4286067653e-6f, invln2 = 1.4426950216e+0f;
-    const float P1 = 1.6666625440e-1f, P2 = -2.7667332906e-3f;
-    uint32_t hx = __float_as_uint(x);
-    const int sign = (int)(hx >> 31);
-    hx &= 0x7fffffffu;
-    if (hx >= 0x42aeac50u) {
-        if (hx > 0x7f800000u) return x;
-        if (hx >= 0x42b17218u && !sign) return x * 0x1p127f;
-        if (sign && hx >= 0x42cff1b5u) return 0.0f;
-    }
-    float hi, lo;
-    int k;
-    if (hx > 0x3eb17218u) {
-        if (hx > 0x3f851592u) k = (int)(invln2 * x + (sign ? -0.5f : 0.5f));
-        else k = 1 - sign - sign;
-        hi = x - (float)k * ln2hi;
-        lo = (float)k * ln2lo;
-        x = hi - lo;
-    } else if (hx > 0x39000000u) {
-        k = 0; hi = x; lo = 0;
-    } else {
-        return 1 + x;
-    }
-    const float xx = x * x;
-    const float c = x - xx * (P1 + xx * P2);
-    const float y = 1 + (x * c / (2 - c) - lo + hi);
-    return k == 0 ? y : dev_scalbnf(y, k);
-}
-__device__ inline float dev_logf(float x) { // musl logf
-    const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
-    const float Lg1 = 0xaaaaaa.0p-24f, Lg2 = 0xccce13.0p-25f, Lg3 = 0x91e9ee.0p-25f, Lg4 = 0xf89e26.0p-26f;
-    uint32_t ix = __float_as_uint(x);
-    int k = 0;
-    if (ix < 0x00800000u || (ix >> 31)) {
-        if ((ix << 1) == 0) return -1 / (x * x);
-        if (ix >> 31) return (x - x) / 0.0f;
-        k -= 25; x *= 0x1p25f; ix = __float_as_uint(x);
-    } else if (ix >= 0x7f800000u) {
-        return x;
-    } else if (ix == 0x3f800000u) {
-        return 0;
-    }
-    ix += 0x3f800000u - 0x3f3504f3u;
-    k += (int)(ix >> 23) - 0x7f;
-    ix = (ix & 0x007fffffu) + 0x3f3504f3u;
-    x = __uint_as_float(ix);
-    const float f = x - 1.0f, s = f / (2.0f + f), z = s * s, w = z * z;
-    const float t1 = w * (Lg2 + w * Lg4), t2 = z * (Lg1 + w * Lg3), R = t2 + t1;
-    const float hfsq = 0.5f * f * f, dk = (float)k;
-    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
-}
-// pow(x, 2.4) for finite x > 0 the way Zig's std.math.pow computes it: yi = 2, yf = 0.4.
-__device__ inline float dev_pow_2p4(float x) {
-    if (x == 1) return 1;
-    if (!(x > 0) || !isfinite(x)) return powf(x, 2.4f); // outside the sRGB domain: defer
-    const float yf = 2.4f - 2.0f; // modf(|y|).fpart in f32 = 0.4000001, not 0.4f
-    float a1 = dev_expf(yf * dev_logf(x));
-    int xe;
-    float x1 = frexpf(x, &xe);
-    int ae = 0;
-    // i = 2: bit 0 clear -> square; then i = 1: multiply
-    x1 *= x1; xe <<= 1;
-    if (x1 < 0.5f) { x1 += x1; xe -= 1; }
-    a1 *= x1; ae += xe;
-    return dev_scalbnf(a1, ae);
-}
-__device__ inline float dev_gamma_to_linear(float c) { // color.zig:1252-1258
-    return c > 0.04045f ? dev_pow_2p4((c + 0.055f) / 1.055f) : c / 12.92f;
-}
 
 __device__ inline float clamp01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
 __device__ inline uint8_t unit_to_u8(float v) { return (uint8_t)(int)roundf(255.0f * clamp01(v)); }
@@ -282,19 +177,30 @@ static int device_srgb_lut(const float *host_lut, hipStream_t s, const float **o
 static int space_channels(int space) { return space == ZG_CS_GRAY ? 1 : (space == ZG_CS_RGBA ? 4 : 3); }
 
 int copy_impl(const zg_image *src, const zg_image *dst, hipStream_t s);
+int convert_spaces_impl(const zg_image *src, int src_space, const zg_image *dst, int dst_space, const float *srgb_lut_dev, hipStream_t s);
 
 static int convert_impl(const zg_image *src, int src_space, const zg_image *dst, int dst_space, const float *srgb_lut, hipStream_t s) {
     int rc;
     if ((rc = check_image(src, "src")) || (rc = check_image(dst, "dst"))) return rc;
     ZG_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, ZG_ERR_DIMENSION_MISMATCH, "convert: shapes differ");
-    ZG_REQUIRE(src_space == ZG_CS_GRAY || src_space == ZG_CS_RGB || src_space == ZG_CS_RGBA, ZG_ERR_UNSUPPORTED,
-               "convert: source colour space %d is not on the image hot path", src_space);
-    ZG_REQUIRE(dst_space >= ZG_CS_GRAY && dst_space <= ZG_CS_YCBCR, ZG_ERR_INVALID_ARGUMENT, "convert: invalid destination space %d", dst_space);
+    ZG_REQUIRE(src_space >= ZG_CS_GRAY && src_space <= ZG_CS_XYB, ZG_ERR_INVALID_ARGUMENT, "convert: invalid source space %d", src_space);
+    ZG_REQUIRE(dst_space >= ZG_CS_GRAY && dst_space <= ZG_CS_XYB, ZG_ERR_INVALID_ARGUMENT, "convert: invalid destination space %d", dst_space);
     ZG_REQUIRE(pixel_channels(src->pixel) == space_channels(src_space), ZG_ERR_INVALID_ARGUMENT, "convert: source layout does not match its colour space");
     ZG_REQUIRE(pixel_channels(dst->pixel) == space_channels(dst_space), ZG_ERR_INVALID_ARGUMENT, "convert: destination layout does not match its colour space");
     const bool df = pixel_is_float(dst->pixel), sf = pixel_is_float(src->pixel);
+    const bool fast_pair = (src_space == ZG_CS_GRAY || src_space == ZG_CS_RGB || src_space == ZG_CS_RGBA) && dst_space <= ZG_CS_YCBCR &&
+                           !(dst_space == ZG_CS_YCBCR && (df || sf));
+    if (!fast_pair) { // every other pair of colour spaces: the route-walking kernel (colorspaces.hip)
+        if (src->rows == 0 || src->cols == 0) return ZG_OK;
+        if (src_space == dst_space && src->pixel == dst->pixel) return copy_impl(src, dst, s);
+        const float *lut_dev = nullptr; // gammaToLinear(u8 / 255): the caller's table if given, else the library's
+        float *lut_owned = nullptr;
+        if (!sf && (rc = device_srgb_lut(srgb_lut, s, &lut_dev, &lut_owned))) return rc;
+        rc = convert_spaces_impl(src, src_space, dst, dst_space, lut_dev, s);
+        if (lut_owned) (void)hipFreeAsync(lut_owned, s);
+        return rc;
+    }
     if (dst_space == ZG_CS_XYZ || dst_space == ZG_CS_OKLAB) ZG_REQUIRE(df, ZG_ERR_UNSUPPORTED, "convert: Xyz / Oklab need a float destination");
-    if (dst_space == ZG_CS_YCBCR) ZG_REQUIRE(!df && !sf, ZG_ERR_UNSUPPORTED, "convert: Ycbcr path is u8 -> u8");
     if (src->rows == 0 || src->cols == 0) return ZG_OK;
     if (src_space == dst_space && src->pixel == dst->pixel) return copy_impl(src, dst, s); // T == TargetType
 

@@ -1,0 +1,283 @@
+// zg_devmath.h — Zig std / compiler-rt f32 maths restated for the device (the algorithms Zig ports from musl and Go),
+// used where a reference value flows through @exp / @log / std.math.pow / cbrt / atan2 / @sin / @cos on the image path
+// (colour conversion). Same restatement as the oracle's zigmath.c / colorspaces.c, written independently here; like
+// those it is parity-unpinned against real Zig at the last ulp. No FMA contraction.
+#pragma once
+#include "zg_common.h"
+
+#pragma clang fp contract(off)
+
+namespace zg {
+
+__device__ inline float dev_cbrtf(float x) { // Zig std.math.cbrt cbrt32 == musl cbrtf
+    const uint32_t B1 = 709958130u, B2 = 642849266u;
+    uint32_t u = __float_as_uint(x);
+    uint32_t hx = u & 0x7fffffffu;
+    if (hx >= 0x7f800000u) return x + x;
+    if (hx < 0x00800000u) {
+        if (hx == 0) return x;
+        u = __float_as_uint(x * 0x1p24f);
+        hx = u & 0x7fffffffu;
+        hx = hx / 3 + B2;
+    } else {
+        hx = hx / 3 + B1;
+    }
+    u &= 0x80000000u;
+    u |= hx;
+    double t = (double)__uint_as_float(u);
+    double r = t * t * t;
+    t = t * ((double)x + x + r) / (x + r + r);
+    r = t * t * t;
+    t = t * ((double)x + x + r) / (x + r + r);
+    return (float)t;
+}
+
+__device__ inline float dev_scalbnf(float x, int n) {
+    float y = x;
+    if (n > 127) {
+        y *= 0x1p127f; n -= 127;
+        if (n > 127) { y *= 0x1p127f; n -= 127; if (n > 127) n = 127; }
+    } else if (n < -126) {
+        y *= 0x1p-126f * 0x1p24f; n += 126 - 24;
+        if (n < -126) { y *= 0x1p-126f * 0x1p24f; n += 126 - 24; if (n < -126) n = -126; }
+    }
+    return y * __uint_as_float((uint32_t)(0x7f + n) << 23);
+}
+__device__ inline float dev_expf(float x) { // musl expf
+    const float ln2hi = 6.9314575195e-1f, ln2lo = 1.4286067653e-6f, invln2 = 1.4426950216e+0f;
+    const float P1 = 1.6666625440e-1f, P2 = -2.7667332906e-3f;
+    uint32_t hx = __float_as_uint(x);
+    const int sign = (int)(hx >> 31);
+    hx &= 0x7fffffffu;
+    if (hx >= 0x42aeac50u) {
+        if (hx > 0x7f800000u) return x;
+        if (hx >= 0x42b17218u && !sign) return x * 0x1p127f;
+        if (sign && hx >= 0x42cff1b5u) return 0.0f;
+    }
+    float hi, lo;
+    int k;
+    if (hx > 0x3eb17218u) {
+        if (hx > 0x3f851592u) k = (int)(invln2 * x + (sign ? -0.5f : 0.5f));
+        else k = 1 - sign - sign;
+        hi = x - (float)k * ln2hi;
+        lo = (float)k * ln2lo;
+        x = hi - lo;
+    } else if (hx > 0x39000000u) {
+        k = 0; hi = x; lo = 0;
+    } else {
+        return 1 + x;
+    }
+    const float xx = x * x;
+    const float c = x - xx * (P1 + xx * P2);
+    const float y = 1 + (x * c / (2 - c) - lo + hi);
+    return k == 0 ? y : dev_scalbnf(y, k);
+}
+__device__ inline float dev_logf(float x) { // musl logf
+    const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+    const float Lg1 = 0xaaaaaa.0p-24f, Lg2 = 0xccce13.0p-25f, Lg3 = 0x91e9ee.0p-25f, Lg4 = 0xf89e26.0p-26f;
+    uint32_t ix = __float_as_uint(x);
+    int k = 0;
+    if (ix < 0x00800000u || (ix >> 31)) {
+        if ((ix << 1) == 0) return -1 / (x * x);
+        if (ix >> 31) return (x - x) / 0.0f;
+        k -= 25; x *= 0x1p25f; ix = __float_as_uint(x);
+    } else if (ix >= 0x7f800000u) {
+        return x;
+    } else if (ix == 0x3f800000u) {
+        return 0;
+    }
+    ix += 0x3f800000u - 0x3f3504f3u;
+    k += (int)(ix >> 23) - 0x7f;
+    ix = (ix & 0x007fffffu) + 0x3f3504f3u;
+    x = __uint_as_float(ix);
+    const float f = x - 1.0f, s = f / (2.0f + f), z = s * s, w = z * z;
+    const float t1 = w * (Lg2 + w * Lg4), t2 = z * (Lg1 + w * Lg3), R = t2 + t1;
+    const float hfsq = 0.5f * f * f, dk = (float)k;
+    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+}
+// pow(x, 2.4) for finite x > 0 the way Zig's std.math.pow computes it: yi = 2, yf = 0.4.
+__device__ inline float dev_pow_2p4(float x) {
+    if (x == 1) return 1;
+    if (!(x > 0) || !isfinite(x)) return powf(x, 2.4f); // outside the sRGB domain: defer
+    const float yf = 2.4f - 2.0f; // modf(|y|).fpart in f32 = 0.4000001, not 0.4f
+    float a1 = dev_expf(yf * dev_logf(x));
+    int xe;
+    float x1 = frexpf(x, &xe);
+    int ae = 0;
+    // i = 2: bit 0 clear -> square; then i = 1: multiply
+    x1 *= x1; xe <<= 1;
+    if (x1 < 0.5f) { x1 += x1; xe -= 1; }
+    a1 *= x1; ae += xe;
+    return dev_scalbnf(a1, ae);
+}
+__device__ inline float dev_gamma_to_linear(float c) { // color.zig:1252-1258
+    return c > 0.04045f ? dev_pow_2p4((c + 0.055f) / 1.055f) : c / 12.92f;
+}
+
+
+// std.math.pow(f32, x, y) for finite x > 0 and finite y > 0 (Go's algorithm: x^yi by squaring on the frexp mantissa,
+// x^yf = exp(yf * log(x)) with yf in (-0.5, 0.5]); other arguments defer to the runtime's powf (never reached by the
+// sRGB / Lab transfer functions, whose arguments are positive).
+__device__ inline float dev_powf(float x, float y) {
+    if (y == 0 || x == 1) return 1;
+    if (y == 1) return x;
+    if (!(x > 0) || !isfinite(x) || !(y > 0) || !isfinite(y)) return powf(x, y);
+    if (y == 0.5f) return sqrtf(x);
+    float yi = truncf(y), yf = y - yi;
+    float a1 = 1.0f;
+    int ae = 0;
+    if (yf != 0) {
+        if (yf > 0.5f) { yf -= 1; yi += 1; }
+        a1 = dev_expf(yf * dev_logf(x));
+    }
+    int xe;
+    float x1 = frexpf(x, &xe);
+    int i = (int)yi;
+    while (i != 0) {
+        if (xe < -(1 << 9) || (1 << 9) < xe) { ae += xe; break; }
+        if (i & 1) { a1 *= x1; ae += xe; }
+        x1 *= x1;
+        xe <<= 1;
+        if (x1 < 0.5f) { x1 += x1; xe -= 1; }
+        i >>= 1;
+    }
+    return dev_scalbnf(a1, ae);
+}
+
+__device__ inline float dev_atanf(float x) { // std.math.atan(f32) == musl atanf
+    const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    const float aT0 = 3.3333328366e-01f, aT1 = -1.9999158382e-01f, aT2 = 1.4253635705e-01f, aT3 = -1.0648017377e-01f, aT4 = 6.1687607318e-02f;
+    uint32_t ix = __float_as_uint(x);
+    const uint32_t sign = ix >> 31;
+    ix &= 0x7fffffffu;
+    if (ix >= 0x4c800000u) { // |x| >= 2^26
+        if (ix > 0x7f800000u) return x;
+        const float z = atanhi[3] + 0x1p-120f;
+        return sign ? -z : z;
+    }
+    int id;
+    if (ix < 0x3ee00000u) { // |x| < 0.4375
+        if (ix < 0x39800000u) return x;
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000u) {
+            if (ix < 0x3f300000u) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }
+            else { id = 1; x = (x - 1.0f) / (x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000u) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
+            else { id = 3; x = -1.0f / x; }
+        }
+    }
+    float z = x * x;
+    const float w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * aT4));
+    const float s2 = w * (aT1 + w * aT3);
+    if (id < 0) return x - x * (s1 + s2);
+    const float hi = id == 0 ? atanhi[0] : (id == 1 ? atanhi[1] : (id == 2 ? atanhi[2] : atanhi[3]));
+    const float lo = id == 0 ? atanlo[0] : (id == 1 ? atanlo[1] : (id == 2 ? atanlo[2] : atanlo[3]));
+    z = hi - ((x * (s1 + s2) - lo) - x);
+    return sign ? -z : z;
+}
+
+__device__ inline float dev_atan2f(float y, float x) { // std.math.atan2(f32) == musl atan2f
+    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    if (x != x || y != y) return x + y;
+    uint32_t ix = __float_as_uint(x), iy = __float_as_uint(y);
+    if (ix == 0x3f800000u) return dev_atanf(y);
+    const uint32_t m = ((iy >> 31) & 1u) | ((ix >> 30) & 2u);
+    ix &= 0x7fffffffu;
+    iy &= 0x7fffffffu;
+    if (iy == 0) return m == 0 || m == 1 ? y : (m == 2 ? pi : -pi);
+    if (ix == 0) return (m & 1u) ? -pi / 2 : pi / 2;
+    if (ix == 0x7f800000u) {
+        if (iy == 0x7f800000u) return m == 0 ? pi / 4 : (m == 1 ? -pi / 4 : (m == 2 ? 3 * pi / 4 : -3 * pi / 4));
+        return m == 0 ? 0.0f : (m == 1 ? -0.0f : (m == 2 ? pi : -pi));
+    }
+    if (ix + (26u << 23) < iy || iy == 0x7f800000u) return (m & 1u) ? -pi / 2 : pi / 2;
+    float z;
+    if ((m & 2u) && iy + (26u << 23) < ix) z = 0.0f;
+    else z = dev_atanf(fabsf(y / x));
+    switch (m) {
+    case 0: return z;
+    case 1: return -z;
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+    }
+}
+
+// @sin / @cos on f32 == musl sinf / cosf: polynomial kernels and argument reduction in f64
+__device__ inline float dev_k_sindf(double x) {
+    const double S1 = -0x15555554cbac77.0p-55, S2 = 0x111110896efbb2.0p-59, S3 = -0x1a00f9e2cae774.0p-65, S4 = 0x16cd878c3b46a7.0p-71;
+    const double z = x * x, w = z * z, r = S3 + z * S4, s = z * x;
+    return (float)((x + s * (S1 + z * S2)) + s * w * r);
+}
+__device__ inline float dev_k_cosdf(double x) {
+    const double C0 = -0x1ffffffd0c5e81.0p-54, C1 = 0x155553e1053a42.0p-57, C2 = -0x16c087e80f1e27.0p-62, C3 = 0x199342e0ee5069.0p-68;
+    const double z = x * x, w = z * z, r = C2 + z * C3;
+    return (float)(((1.0 + z * C0) + w * C1) + (w * z) * r);
+}
+__device__ inline int dev_rem_pio2f(float x, double *y) { // |x| < 2^28 * pi/2 (hue angles are < 2 pi); larger: plain remainder
+    const double toint = 1.5 / 2.220446049250313e-16, invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079631090164184570e+00,
+                 pio2_1t = 1.58932547735281966916e-08;
+    const uint32_t ix = __float_as_uint(x) & 0x7fffffffu;
+    if (ix < 0x4dc90fdbu) {
+        const double fn = (double)x * invpio2 + toint - toint;
+        *y = x - fn * pio2_1 - fn * pio2_1t;
+        return (int)fn;
+    }
+    const double q = nearbyint((double)x * invpio2);
+    *y = (double)x - q * 1.5707963267948966;
+    return (int)fmod(q, 4.0);
+}
+__device__ inline float dev_sinf(float x) {
+    const double p1 = 1 * 1.5707963267948966, p2 = 2 * 1.5707963267948966, p3 = 3 * 1.5707963267948966, p4 = 4 * 1.5707963267948966;
+    uint32_t ix = __float_as_uint(x);
+    const int sign = (int)(ix >> 31);
+    ix &= 0x7fffffffu;
+    if (ix <= 0x3f490fdau) return ix < 0x39800000u ? x : dev_k_sindf(x);
+    if (ix <= 0x407b53d1u) {
+        if (ix <= 0x4016cbe3u) return sign ? -dev_k_cosdf(x + p1) : dev_k_cosdf(x - p1);
+        return dev_k_sindf(sign ? -(x + p2) : -(x - p2));
+    }
+    if (ix <= 0x40e231d5u) {
+        if (ix <= 0x40afeddfu) return sign ? dev_k_cosdf(x + p3) : -dev_k_cosdf(x - p3);
+        return dev_k_sindf(sign ? x + p4 : x - p4);
+    }
+    if (ix >= 0x7f800000u) return x - x;
+    double y;
+    const int n = dev_rem_pio2f(x, &y);
+    switch (n & 3) {
+    case 0: return dev_k_sindf(y);
+    case 1: return dev_k_cosdf(y);
+    case 2: return dev_k_sindf(-y);
+    default: return -dev_k_cosdf(y);
+    }
+}
+__device__ inline float dev_cosf(float x) {
+    const double p1 = 1 * 1.5707963267948966, p2 = 2 * 1.5707963267948966, p3 = 3 * 1.5707963267948966, p4 = 4 * 1.5707963267948966;
+    uint32_t ix = __float_as_uint(x);
+    const int sign = (int)(ix >> 31);
+    ix &= 0x7fffffffu;
+    if (ix <= 0x3f490fdau) return ix < 0x39800000u ? 1.0f : dev_k_cosdf(x);
+    if (ix <= 0x407b53d1u) {
+        if (ix > 0x4016cbe3u) return -dev_k_cosdf(sign ? x + p2 : x - p2);
+        return sign ? dev_k_sindf(x + p1) : dev_k_sindf(p1 - x);
+    }
+    if (ix <= 0x40e231d5u) {
+        if (ix > 0x40afeddfu) return dev_k_cosdf(sign ? x + p4 : x - p4);
+        return sign ? dev_k_sindf(-x - p3) : dev_k_sindf(x - p3);
+    }
+    if (ix >= 0x7f800000u) return x - x;
+    double y;
+    const int n = dev_rem_pio2f(x, &y);
+    switch (n & 3) {
+    case 0: return dev_k_cosdf(y);
+    case 1: return dev_k_sindf(-y);
+    case 2: return -dev_k_cosdf(y);
+    default: return dev_k_sindf(y);
+    }
+}
+
+} // namespace zg

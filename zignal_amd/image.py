@@ -369,10 +369,12 @@ class Image:
     # ---- colour -----------------------------------------------------------------------------
     def convert(self, dst_space: int, dtype=np.float32, src_space: Optional[int] = None,
                 out: Optional["Image"] = None, srgb_lut=None) -> "Image":
-        """Image.convert (image.zig:418): e.g. rgba_u8.convert(CS_OKLAB, np.float32)."""
+        """Image.convert (image.zig:418): e.g. rgba_u8.convert(CS_OKLAB, np.float32), lab_f32.convert(CS_RGB, np.uint8,
+        src_space=CS_LAB). A three-channel source is Rgb unless src_space says otherwise (the colour space is part of
+        the Zig pixel type; here it travels beside the array)."""
         if src_space is None:
             src_space = {1: L.CS_GRAY, 3: L.CS_RGB, 4: L.CS_RGBA}[1 if self.data.ndim == 2 else self.data.shape[2]]
-        ch = {L.CS_GRAY: 1, L.CS_RGB: 3, L.CS_RGBA: 4, L.CS_OKLAB: 3, L.CS_XYZ: 3, L.CS_YCBCR: 3}[dst_space]
+        ch = 1 if dst_space == L.CS_GRAY else (4 if dst_space == L.CS_RGBA else 3)
         if out is None:
             if self.on_device:
                 tdtype = {np.uint8: torch.uint8, np.float32: torch.float32}[np.dtype(dtype).type]
