@@ -293,7 +293,7 @@ def cpu_extras(extras_out):
         timed(lambda: oracle.resize(oracle.gaussian_blur(frame, SIGMA, native=native), (540, 960), bil), 1080 * 1920), "one 1080p frame")
 
 
-def _time_kernel(torch, fn, n=50, warm=5):
+def _time_kernel(torch, fn, n=50, warm=5, capture=True):
     """Mean ms per call of fn(i): the n calls are captured into one HIP graph and replayed (so microsecond kernels are
     not timed through Python launch overhead); eager launches if capture is not possible."""
     for i in range(warm):
@@ -301,6 +301,8 @@ def _time_kernel(torch, fn, n=50, warm=5):
     torch.cuda.synchronize()
     graph = None
     try:
+        if not capture:
+            raise RuntimeError("eager timing requested")
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
             fn(0)
@@ -429,7 +431,16 @@ def extras(zg, torch, np):
         ms = _time_kernel(torch, lambda i: im[i % ring][0].gaussian_blur(2.2528, out=im[i % ring][1]), n=20, warm=3)
         return rate(ms, ROWS * COLS, 2 * ROWS * COLS)
 
+    def canny():
+        # the whole detector (grey, Gaussian, Sobel, NMS, hysteresis to its fixed point); it synchronises the stream,
+        # so it is timed eagerly, launch gaps and the flag read-backs included
+        ring = 4
+        im = [(zg.Image(s), zg.Image(torch.empty((ROWS, COLS), dtype=torch.uint8, device="cuda"))) for s in u8_frames(ring, (ROWS, COLS, 4))]
+        ms = _time_kernel(torch, lambda i: im[i % ring][0].canny(1.4, 50, 150, out=im[i % ring][1]), n=8, warm=2, capture=False)
+        return rate(ms, ROWS * COLS, 5 * ROWS * COLS)
+
     leg("next_sobel_rgba_u8_4096", sobel)
+    leg("next_canny_rgba_u8_4096", canny)
     leg("next_pyramid_level3_blur_u8_4096", pyramid_blur)
     leg("next_convert_rgba_u8_to_lab_f32_4096", lambda: lab(True))
     leg("next_convert_lab_f32_to_rgba_u8_4096", lambda: lab(False))

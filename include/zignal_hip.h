@@ -246,6 +246,13 @@ ZG_API int zg_convert_host(const zg_image *src, int src_space, const zg_image *d
 ZG_API int zg_sobel(const zg_image *src, const zg_image *dst, zg_stream stream);
 ZG_API int zg_sobel_host(const zg_image *src, const zg_image *dst);
 
+/* Image(T).canny (src/image.zig:1047-1063 -> src/image/edges.zig:212-277): grey -> the detector's own Gaussian
+ * (.replicate; sigma == 0 skips it) -> Sobel gradients -> non-maximum suppression -> double threshold + hysteresis.
+ * dst is Image(u8), 0 or 255. error.InvalidParameter / InvalidSigma / InvalidThreshold -> ZG_ERR_INVALID_ARGUMENT.
+ * Hysteresis iterates to a fixed point: the call synchronises `stream` (it cannot be captured into a graph). */
+ZG_API int zg_canny(const zg_image *src, const zg_image *dst, float sigma, float low_threshold, float high_threshold, zg_stream stream);
+ZG_API int zg_canny_host(const zg_image *src, const zg_image *dst, float sigma, float low_threshold, float high_threshold);
+
 /* ImagePyramid.build (src/image/pyramid.zig:31-102) is gaussianBlur + resize(.bilinear) per level; these two give the
  * per-level arithmetic. scale = pow(scale_factor, level): zg_pyramid_scale is the library's restatement of Zig's
  * std.math.pow; a Zig caller passes its own value to zg_pyramid_level. A level below 8 x 8 truncates the pyramid;

@@ -348,6 +348,13 @@ def sobel(src):
     return out
 
 
+def canny(src, sigma, low, high):
+    out = np.empty(src.shape[:2], np.uint8)
+    s, d = as_image(src), as_image(out)
+    _check(lib().zo_canny(C.byref(s), C.byref(d), C.c_float(sigma), C.c_float(low), C.c_float(high)), "canny")
+    return out
+
+
 def pyramid(source, n_levels, scale_factor, blur_sigma):
     """ImagePyramid.build (pyramid.zig:31-102) composed from the oracle's own gaussian_blur and resize."""
     l = lib()

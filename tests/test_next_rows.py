@@ -99,3 +99,92 @@ def test_pyramid_parity(oracle, kind):
         for i, (g, w) in enumerate(zip(pyr.levels, want)):
             assert_bits_equal(g.to_numpy(), w, f"pyramid {kind} ({n},{sf},{sigma}) level {i}")
     assert zg.ImagePyramid.build(dev(np.zeros((32, 32), np.uint8)), 10, 2.0, 1.0).n_levels < 10  # pyramid.zig:236-252
+
+
+# ---- Canny (image.zig:1047-1063 -> edges.zig:212-277) ---------------------------------------------------------------
+def test_canny_reference_known_answers_oracle(oracle):  # tests/filters.zig:1182-1300
+    img = np.zeros((10, 10), np.uint8)
+    img[:, 5:] = 255
+    edges = oracle.canny(img, 1.0, 50, 100)
+    assert edges.shape == img.shape and (edges[:, 4:7] > 0).any()
+    assert set(np.unique(edges).tolist()) <= {0, 255}
+    rgb = np.zeros((8, 8, 3), np.uint8)
+    rgb[:, :4] = (255, 0, 0)
+    rgb[:, 4:] = (0, 255, 0)
+    assert (oracle.canny(rgb, 1.0, 30, 90)[:, 3:6] > 0).any()
+    ramp = (np.arange(5)[:, None] * 10 + np.arange(5)[None, :]).astype(np.uint8)
+    oracle.canny(ramp, 0, 50, 100)  # sigma == 0 is valid (no blur)
+    for bad in ((-1, 50, 100), (1.0, -1, 100), (1.0, 50, -1), (1.0, 100, 50), (float("nan"), 50, 100), (1.0, float("nan"), 100),
+                (1.0, 50, float("nan")), (float("inf"), 50, 100), (1.0, float("inf"), 100), (1.0, 50, float("inf")), (float("-inf"), 50, 100)):
+        with pytest.raises(RuntimeError):
+            oracle.canny(ramp, *bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ("u8", "f32", "rgb_u8", "rgba_u8", "rgb_f32", "rgba_f32"))
+def test_canny_gpu_parity(oracle, kind):
+    import torch
+    import zignal_amd as zg
+    from tests.util import assert_bits_equal, synth
+
+    def blobs(rows, cols, seed):  # smooth structure with long connected edges, so hysteresis has chains to follow across tiles
+        rng = np.random.default_rng(seed)
+        y, x = np.mgrid[0:rows, 0:cols].astype(np.float32)
+        f = np.zeros((rows, cols), np.float32)
+        for _ in range(12):
+            cy, cx, s = rng.uniform(0, rows), rng.uniform(0, cols), rng.uniform(8, 60)
+            f += rng.uniform(-1, 1) * np.exp(-((y - cy) ** 2 + (x - cx) ** 2) / (2 * s * s))
+        f = (f - f.min()) / (f.max() - f.min() + 1e-9)
+        return f
+
+    for (rows, cols, sigma, lo, hi) in ((10, 10, 1.0, 50, 100), (97, 211, 1.4, 10, 30), (300, 517, 0.0, 5, 12), (2, 9, 1.0, 5, 10), (130, 70, 2.5, 2, 6)):
+        base = blobs(rows, cols, rows + cols)
+        if kind == "u8":
+            img = (base * 255).astype(np.uint8)
+        elif kind == "f32":
+            img = base
+        else:
+            noise = synth(oracle, kind, 3, rows, cols)
+            ch = noise.shape[2]
+            if noise.dtype == np.uint8:
+                img = np.clip(base[..., None] * 255 * np.array([1.0, 0.8, 0.6, 1.0])[:ch] + noise * 0.02, 0, 255).astype(np.uint8)
+            else:
+                img = (base[..., None] * np.array([1.0, 0.8, 0.6, 1.0], np.float32)[:ch] + noise * np.float32(0.02)).astype(np.float32)
+        want = oracle.canny(img, sigma, lo, hi)
+        got = zg.Image(torch.from_numpy(np.ascontiguousarray(img)).cuda()).canny(sigma, lo, hi)
+        torch.cuda.synchronize()
+        assert_bits_equal(got.to_numpy(), want, f"canny {kind} {rows}x{cols} sigma={sigma}")
+        if rows >= 97:
+            assert want.any(), "test image produced no edges"
+    host = zg.Image(img).canny(sigma, lo, hi).data
+    assert_bits_equal(host, want, "canny host layer")
+    with pytest.raises(zg.InvalidArgument):
+        zg.Image(img).canny(-1, 5, 10)
+    with pytest.raises(zg.InvalidArgument):
+        zg.Image(img).canny(1, 10, 5)
+    with pytest.raises(zg.InvalidArgument):
+        zg.Image(img).canny(float("nan"), 5, 10)
+    with pytest.raises(zg.DimensionMismatch):
+        zg.Image(img).canny(1, 5, 10, out=zg.Image(np.zeros((3, 3), np.uint8)))
+
+
+@pytest.mark.gpu
+def test_canny_long_chain_across_tiles(oracle):
+    """A one-pixel spiral whose only strong pixel is at one end: hysteresis must follow it through every tile."""
+    import torch
+    import zignal_amd as zg
+    from tests.util import assert_bits_equal
+    n = 256
+    img = np.zeros((n, n), np.uint8)
+    lo_v, hi_v = 40, 255
+    r0, r1, c0, c1 = 4, n - 5, 4, n - 5
+    while r1 - r0 > 16:
+        img[r0, c0:c1] = lo_v; img[r0:r1, c1] = lo_v; img[r1, c0 + 8:c1 + 1] = lo_v; img[r0 + 8:r1 + 1, c0 + 8] = lo_v
+        r0 += 8; c0 += 8; r1 -= 8; c1 -= 8
+        img[r0, c0:c0 + 1] = lo_v
+    img[4, 4:12] = hi_v
+    want = oracle.canny(img, 0.0, 20, 600)
+    got = zg.Image(torch.from_numpy(img).cuda()).canny(0.0, 20, 600)
+    torch.cuda.synchronize()
+    assert_bits_equal(got.to_numpy(), want, "canny spiral")
+    assert (want > 0).sum() > 500

@@ -36,6 +36,7 @@ pub const c = struct {
     pub extern fn zg_flip_left_right_host(img: *const ZgImage) c_int;
     pub extern fn zg_flip_top_bottom_host(img: *const ZgImage) c_int;
     pub extern fn zg_sobel_host(src: *const ZgImage, dst: *const ZgImage) c_int;
+    pub extern fn zg_canny_host(src: *const ZgImage, dst: *const ZgImage, sigma: f32, low_threshold: f32, high_threshold: f32) c_int;
     pub extern fn zg_convert_host(src: *const ZgImage, src_space: c_int, dst: *const ZgImage, dst_space: c_int, srgb_lut: ?[*]const f32) c_int;
 };
 
@@ -142,6 +143,17 @@ pub fn Image(comptime T: type) type {
             _ = allocator;
             if (self.base.rows != out.base.rows or self.base.cols != out.base.cols) return error.DimensionMismatch;
             try check(c.zg_sobel_host(&desc(self.base), &Image(u8).desc(out.base)));
+        }
+
+        /// reference src/image.zig:1047-1063. The reference's distinct errors are decided here, before the device call,
+        /// so callers keep matching on error.InvalidParameter / InvalidSigma / InvalidThreshold (edges.zig:221-227).
+        pub fn canny(self: Self, out: Image(u8), allocator: std.mem.Allocator, sigma: f32, low_threshold: f32, high_threshold: f32) !void {
+            _ = allocator;
+            if (self.base.rows != out.base.rows or self.base.cols != out.base.cols) return error.DimensionMismatch;
+            if (!std.math.isFinite(sigma) or !std.math.isFinite(low_threshold) or !std.math.isFinite(high_threshold)) return error.InvalidParameter;
+            if (sigma < 0) return error.InvalidSigma;
+            if (low_threshold < 0 or high_threshold < 0 or low_threshold >= high_threshold) return error.InvalidThreshold;
+            try check(c.zg_canny_host(&desc(self.base), &Image(u8).desc(out.base), sigma, low_threshold, high_threshold));
         }
 
         /// reference src/image.zig:523-525 (void: never fails; a HIP failure is a programming error here)

@@ -117,6 +117,11 @@ template <typename T> class Image {
         check(zg_sobel_host(&s, &d));
         return out;
     }
+    void canny(const Image<uint8_t> &out, float sigma, float low_threshold, float high_threshold) const {   // image.zig:1047
+        if (rows != out.rows || cols != out.cols) throw DimensionMismatch(1, "canny");
+        const zg_image s = desc(), d = out.desc();
+        check(zg_canny_host(&s, &d, sigma, low_threshold, high_threshold));
+    }
     // ---- resampling ----
     void resize(const Image &out, Interpolation method) const {                          // image.zig:523
         const zg_image s = desc(), d = out.desc(); const zg_method m = method.c_method();

@@ -9,6 +9,7 @@
 #include "zg_hostmath.h"
 
 #include <cmath>
+#include <vector>
 
 #pragma clang fp contract(off)
 
@@ -85,6 +86,211 @@ static int sobel_impl(const zg_image *src, const zg_image *dst, hipStream_t s) {
     });
 }
 
+
+// ---- Canny (src/image.zig:1047-1063 -> src/image/edges.zig:212-277) --------------------------------------------------
+// grey plane as(f32, convertColor(u8, px)) -> the detector's own Gaussian (.replicate) -> Sobel gradients -> magnitude ->
+// non-maximum suppression -> double threshold + hysteresis. The reference materialises six full planes and walks a BFS
+// queue; here: one grey kernel, the library's separable convolution, ONE fused kernel for gradients + magnitude + NMS +
+// classification (a 2-pixel halo of the blurred plane in LDS; its output is a single byte per pixel: 0 none, 1 weak, 2
+// strong), and hysteresis as monotone label propagation (weak pixels 8-adjacent to a strong one become strong), iterated
+// to a fixed point inside each tile in LDS and across tiles by relaunching until a pass changes nothing. The fixed point
+// is the BFS's reachable set, so the edge map is identical whatever the order.
+
+template <int PIX> __device__ inline float canny_gray(typename Px<PIX>::Vec v) { // as(f32, convertColor(u8, px)), edges.zig:231-240
+    if constexpr (PIX == ZG_PIXEL_F32) { // scalar float -> u8 in f64 (color.zig:114-118)
+        double d = (double)v[0];
+        d = d < 0.0 ? 0.0 : (d > 1.0 ? 1.0 : d);
+        return (float)(int)round(d * 255.0);
+    } else return sobel_gray<PIX>(v);
+}
+
+template <int PIX>
+__global__ __launch_bounds__(256) void k_canny_gray(DImg src, float *gray) {
+    using P = Px<PIX>;
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= src.cols) return;
+    gray[(size_t)r * src.cols + c] = canny_gray<PIX>(P::load(src.data, (size_t)r * src.stride + (size_t)c));
+}
+
+// blurred plane -> state plane. Tile 64 x 4 outputs; magnitudes are needed one pixel around it, blurred values two.
+__global__ __launch_bounds__(256) void k_canny_nms(const float *blur, uint8_t *state, int rows, int cols, float low, float high, int tiles_x) {
+    __shared__ float b[8][68];
+    __shared__ float gxs[6][66], gys[6][66], mag[6][66];
+    const int nwg = gridDim.x, per_xcd = nwg >> 3;
+    int wg = blockIdx.x;
+    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
+    const int x0 = tx * 64, y0 = ty * 4;
+    for (int i = threadIdx.x; i < 8 * 68; i += 256) {
+        const int r = i / 68, c = i - r * 68;
+        int gr = y0 - 2 + r, gc = x0 - 2 + c; // .replicate of the 3x3 convolutions (and harmless clamping beyond it)
+        gr = gr < 0 ? 0 : (gr > rows - 1 ? rows - 1 : gr);
+        gc = gc < 0 ? 0 : (gc > cols - 1 ? cols - 1 : gc);
+        b[r][c] = blur[(size_t)gr * cols + gc];
+    }
+    __syncthreads();
+    const float kx[9] = {-1, 0, 1, -2, 0, 2, -1, 0, 1}, ky[9] = {-1, -2, -1, 0, 0, 0, 1, 2, 1};
+    for (int i = threadIdx.x; i < 6 * 66; i += 256) { // gradients of pixel (y0 - 1 + r, x0 - 1 + c)
+        const int r = i / 66, c = i - r * 66;
+        // a pixel outside the image never contributes (NMS skips the border ring), but its window must still be the
+        // clamped one so that in-image neighbours read what the reference computed: recentre on the clamped position
+        int pr = y0 - 1 + r, pc = x0 - 1 + c;
+        pr = pr < 0 ? 0 : (pr > rows - 1 ? rows - 1 : pr);
+        pc = pc < 0 ? 0 : (pc > cols - 1 ? cols - 1 : pc);
+        float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                int wr = pr - 1 + j, wc = pc - 1 + k; // window position, replicate-clamped, then into tile coordinates
+                wr = wr < 0 ? 0 : (wr > rows - 1 ? rows - 1 : wr);
+                wc = wc < 0 ? 0 : (wc > cols - 1 ? cols - 1 : wc);
+                const float p = b[wr - (y0 - 2)][wc - (x0 - 2)];
+                const float px = p * kx[j * 3 + k], py = p * ky[j * 3 + k];
+                ax = ax + px;
+                ay = ay + py;
+            }
+        gxs[r][c] = ax;
+        gys[r][c] = ay;
+        const float sx = ax * ax, sy = ay * ay;
+        mag[r][c] = sqrtf(sx + sy);
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int c = x0 + lx, r = y0 + ly;
+    if (c >= cols || r >= rows) return;
+    uint8_t st = 0;
+    if (rows >= 3 && cols >= 3 && r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1) { // edges.zig:710-715
+        const float K = 0.414213562f; // tan(22.5 deg)
+        const float gx = gxs[ly + 1][lx + 1], gy = gys[ly + 1][lx + 1];
+        const float ax = fabsf(gx), ay = fabsf(gy);
+        int dr1, dc1, dr2, dc2;
+        if (ay <= K * ax) { dr1 = 0; dc1 = -1; dr2 = 0; dc2 = 1; }
+        else if (ax <= K * ay) { dr1 = -1; dc1 = 0; dr2 = 1; dc2 = 0; }
+        else if (gx * gy > 0) { dr1 = -1; dc1 = 1; dr2 = 1; dc2 = -1; }
+        else { dr1 = -1; dc1 = -1; dr2 = 1; dc2 = 1; }
+        const float m = mag[ly + 1][lx + 1], n1 = mag[ly + 1 + dr1][lx + 1 + dc1], n2 = mag[ly + 1 + dr2][lx + 1 + dc2];
+        if (m >= n1 && m >= n2) st = m >= high ? 2 : (m >= low ? 1 : 0); // edges.zig:541, :566
+    }
+    state[(size_t)r * cols + c] = st;
+}
+
+// One hysteresis pass: every 64 x 16 tile (+ 1-pixel halo) runs to its local fixed point in LDS. Only 1 -> 2 transitions
+// exist, so concurrent tiles reading each other's halo see either value of a pixel and the iteration is monotone.
+__global__ __launch_bounds__(256) void k_canny_hysteresis(uint8_t *state, int rows, int cols, int tiles_x, int *changed) {
+    __shared__ uint8_t t[18][66];
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int x0 = tx * 64, y0 = ty * 16;
+    for (int i = threadIdx.x; i < 18 * 66; i += 256) {
+        const int r = i / 66, c = i - r * 66;
+        const int gr = y0 - 1 + r, gc = x0 - 1 + c;
+        t[r][c] = (gr >= 0 && gr < rows && gc >= 0 && gc < cols) ? state[(size_t)gr * cols + gc] : (uint8_t)0;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, ly4 = (threadIdx.x >> 6) * 4; // four rows per thread
+    bool any = false;
+    for (;;) {
+        bool mine = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = ly4 + k + 1, c = lx + 1;
+            if (t[r][c] == 1) {
+                const bool strong = t[r - 1][c - 1] == 2 || t[r - 1][c] == 2 || t[r - 1][c + 1] == 2 || t[r][c - 1] == 2 || t[r][c + 1] == 2 ||
+                                    t[r + 1][c - 1] == 2 || t[r + 1][c] == 2 || t[r + 1][c + 1] == 2;
+                if (strong) { t[r][c] = 2; mine = true; }
+            }
+        }
+        any |= mine;
+        if (!__syncthreads_or(mine)) break;
+    }
+    if (any) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = y0 + ly4 + k, c = x0 + lx;
+            if (r < rows && c < cols && t[ly4 + k + 1][lx + 1] == 2) state[(size_t)r * cols + c] = 2;
+        }
+        *changed = 1; // benign same-value race
+    }
+}
+
+__global__ __launch_bounds__(256) void k_canny_emit(const uint8_t *state, DImg dst) { // out = 255 on edges, 0 elsewhere (edges.zig:511-515)
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= dst.cols) return;
+    ((uint8_t *)dst.data)[(size_t)r * dst.stride + c] = state[(size_t)r * dst.cols + c] == 2 ? 255 : 0;
+}
+
+static int canny_impl(const zg_image *src, const zg_image *dst, float sigma, float low, float high, zg_stream stream) {
+    hipStream_t s = as_stream(stream);
+    int rc;
+    if ((rc = check_image(src, "src")) || (rc = check_image(dst, "dst"))) return rc;
+    ZG_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, ZG_ERR_DIMENSION_MISMATCH, "canny: %ux%u vs %ux%u",
+               src->rows, src->cols, dst->rows, dst->cols);
+    ZG_REQUIRE(dst->pixel == ZG_PIXEL_U8, ZG_ERR_INVALID_ARGUMENT, "canny: the output is Image(u8)");
+    ZG_REQUIRE(std::isfinite(sigma) && std::isfinite(low) && std::isfinite(high), ZG_ERR_INVALID_ARGUMENT, "canny: InvalidParameter (non-finite)");
+    ZG_REQUIRE(sigma >= 0, ZG_ERR_INVALID_ARGUMENT, "canny: InvalidSigma (%g)", (double)sigma);
+    ZG_REQUIRE(low >= 0 && high >= 0 && low < high, ZG_ERR_INVALID_ARGUMENT, "canny: InvalidThreshold (low %g, high %g)", (double)low, (double)high);
+    if (src->rows == 0 || src->cols == 0) return ZG_OK;
+    const uint32_t rows = src->rows, cols = src->cols;
+    const size_t n = (size_t)rows * cols;
+
+    // scratch: grey f32 | blurred f32 | state u8 | pass flags
+    constexpr int PASSES = 4;
+    char *scratch = nullptr;
+    const size_t state_off = 2 * n * sizeof(float), flags_off = (state_off + n + 15) / 16 * 16;
+    if ((rc = scratch_alloc((void **)&scratch, flags_off + PASSES * sizeof(int), s))) return rc;
+    float *gray = (float *)scratch, *blur = gray + n;
+    uint8_t *state = (uint8_t *)(scratch + state_off);
+    int *flags = (int *)(scratch + flags_off);
+
+    rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
+        constexpr int PIX = decltype(tag)::value;
+        hipLaunchKernelGGL((k_canny_gray<PIX>), dim3(ceil_div(cols, 256), rows), dim3(256), 0, s, dimg(src), gray);
+        ZG_HIP(hipGetLastError());
+        return ZG_OK;
+    });
+    const float *blurred = gray;
+    if (rc == ZG_OK && sigma != 0) { // blurGaussian (edges.zig:663-687): its own taps, .replicate
+        const size_t radius = (size_t)std::ceil(3.0f * sigma), ks = 2 * radius + 1;
+        if (ks > 255) { scratch_free(scratch, s); ZG_REQUIRE(false, ZG_ERR_UNSUPPORTED, "canny: sigma %g needs %zu taps (255 supported)", (double)sigma, ks); }
+        std::vector<float> k(ks);
+        float sum = 0;
+        for (size_t i = 0; i < ks; ++i) {
+            const float x = (float)i - (float)radius;
+            k[i] = hostmath::exp_f32(-(x * x) / (2.0f * sigma * sigma));
+            sum += k[i];
+        }
+        for (size_t i = 0; i < ks; ++i) k[i] /= sum;
+        const zg_image gi{gray, cols, rows, cols, ZG_PIXEL_F32}, bi{blur, cols, rows, cols, ZG_PIXEL_F32};
+        rc = zg_conv_separable(&gi, &bi, k.data(), (uint32_t)ks, k.data(), (uint32_t)ks, ZG_BORDER_REPLICATE, stream);
+        blurred = blur;
+    }
+    if (rc == ZG_OK) {
+        const int tiles_x = (int)ceil_div(cols, 64), tiles_y = (int)ceil_div(rows, 4);
+        hipLaunchKernelGGL(k_canny_nms, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, blurred, state, (int)rows, (int)cols, low, high, tiles_x);
+        const int hy = (int)ceil_div(rows, 16);
+        // passes go out four at a time; the stream is synchronised to read whether the last one still changed anything
+        // (zg_canny therefore cannot be captured into a graph)
+        int host_flags[PASSES];
+        for (;;) {
+            if (hipMemsetAsync(flags, 0, PASSES * sizeof(int), s) != hipSuccess) { rc = ZG_ERR_HIP; break; }
+            for (int p = 0; p < PASSES; ++p)
+                hipLaunchKernelGGL(k_canny_hysteresis, dim3((unsigned)(tiles_x * hy)), dim3(256), 0, s, state, (int)rows, (int)cols, tiles_x, flags + p);
+            if (hipMemcpyAsync(host_flags, flags, sizeof host_flags, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+                set_error("canny: reading the hysteresis flags failed");
+                rc = ZG_ERR_HIP;
+                break;
+            }
+            if (!host_flags[PASSES - 1]) break;
+        }
+        if (rc == ZG_OK) {
+            hipLaunchKernelGGL(k_canny_emit, dim3(ceil_div(cols, 256), rows), dim3(256), 0, s, (const uint8_t *)state, dimg(dst));
+            if (hipGetLastError() != hipSuccess) rc = ZG_ERR_HIP;
+        }
+    }
+    scratch_free(scratch, s);
+    return rc;
+}
+
 } // namespace zg
 
 using namespace zg;
@@ -99,6 +305,20 @@ int zg_sobel_host(const zg_image *src, const zg_image *dst) {
     if ((rc = a.upload(src, true, false))) return rc;
     if ((rc = b.upload(dst, false, true))) return rc;
     if ((rc = sobel_impl(&a.dev, &b.dev, nullptr))) return rc;
+    ZG_HIP(hipStreamSynchronize(nullptr));
+    return b.finish();
+}
+
+int zg_canny(const zg_image *src, const zg_image *dst, float sigma, float low_threshold, float high_threshold, zg_stream stream) {
+    return canny_impl(src, dst, sigma, low_threshold, high_threshold, stream);
+}
+
+int zg_canny_host(const zg_image *src, const zg_image *dst, float sigma, float low_threshold, float high_threshold) {
+    HostStage a, b;
+    int rc;
+    if ((rc = a.upload(src, true, false))) return rc;
+    if ((rc = b.upload(dst, false, true))) return rc;
+    if ((rc = canny_impl(&a.dev, &b.dev, sigma, low_threshold, high_threshold, nullptr))) return rc;
     ZG_HIP(hipStreamSynchronize(nullptr));
     return b.finish();
 }

@@ -366,6 +366,16 @@ class Image:
         self._call("sobel", C.byref(s), C.byref(d))
         return out
 
+    def canny(self, sigma: float, low_threshold: float, high_threshold: float, out: Optional["Image"] = None) -> "Image":
+        """Image.canny (image.zig:1047-1063): binary edge map (0 / 255) as Image(u8). Raises InvalidArgument for the
+        reference's InvalidParameter / InvalidSigma / InvalidThreshold. Synchronises the stream (hysteresis fixed point)."""
+        if out is None:
+            out = self._like(dtype=torch.uint8 if self.on_device else np.uint8, channels=1)
+        self._same_side(out)
+        s, d = self._desc(), out._desc()
+        self._call("canny", C.byref(s), C.byref(d), C.c_float(sigma), C.c_float(low_threshold), C.c_float(high_threshold))
+        return out
+
     # ---- colour -----------------------------------------------------------------------------
     def convert(self, dst_space: int, dtype=np.float32, src_space: Optional[int] = None,
                 out: Optional["Image"] = None, srgb_lut=None) -> "Image":
