@@ -253,6 +253,15 @@ ZG_API int zg_sobel_host(const zg_image *src, const zg_image *dst);
 ZG_API int zg_canny(const zg_image *src, const zg_image *dst, float sigma, float low_threshold, float high_threshold, zg_stream stream);
 ZG_API int zg_canny_host(const zg_image *src, const zg_image *dst, float sigma, float low_threshold, float high_threshold);
 
+/* Image(T).motionBlur (src/image.zig:1077-1091 -> src/image/motion_blur.zig). `.linear` (:65-236): distance 0 copies;
+ * |sin| or |cos| < 0.001 is the separable convolution with a uniform kernel (.replicate); anything else averages
+ * bilinear samples along the motion line. cos_a / sin_a are @cos(angle) / @sin(angle) as the caller's maths library
+ * computes them. `.radial_zoom` / `.radial_spin` (:240-440): spin = 0 / 1; centre normalised to [0, 1]. */
+ZG_API int zg_motion_blur_linear(const zg_image *src, const zg_image *dst, float angle, float cos_a, float sin_a, uint32_t distance, zg_stream stream);
+ZG_API int zg_motion_blur_linear_host(const zg_image *src, const zg_image *dst, float angle, float cos_a, float sin_a, uint32_t distance);
+ZG_API int zg_motion_blur_radial(const zg_image *src, const zg_image *dst, float center_x, float center_y, float strength, int spin, zg_stream stream);
+ZG_API int zg_motion_blur_radial_host(const zg_image *src, const zg_image *dst, float center_x, float center_y, float strength, int spin);
+
 /* ImagePyramid.build (src/image/pyramid.zig:31-102) is gaussianBlur + resize(.bilinear) per level; these two give the
  * per-level arithmetic. scale = pow(scale_factor, level): zg_pyramid_scale is the library's restatement of Zig's
  * std.math.pow; a Zig caller passes its own value to zg_pyramid_level. A level below 8 x 8 truncates the pyramid;

@@ -138,3 +138,113 @@ ZO_API int zo_canny(const zo_image *src, const zo_image *out, float sigma, float
     free(queue); free(gray); free(blur); free(gx); free(gy); free(mag); free(g8); free(nms);
     return 0;
 }
+
+/*
+ * Motion blur (src/image.zig:1077-1091 -> src/image/motion_blur.zig), SURVEY §8f rank 4.
+ *   linear   :65-236   distance 0: copy; |sin| < 0.001 / |cos| < 0.001: convolveSeparable(uniform 1/n taps, identity,
+ *                      .replicate); else per pixel, per field: samples t = -d/2, -d/2 + 1, ... <= d/2 along
+ *                      (cos, sin), in-bounds ones bilinearly interpolated (x1/y1 clamped), mean; no sample: the pixel
+ *   radial   :240-440  zoom: samples on the ray through the centre, scale 1 + t * amount * 0.1; spin: on the circle,
+ *                      angle + t * amount; 8 + trunc(strength * 24) samples, t in [-0.5, 0.5]
+ * cos_a / sin_a: @cos(angle) / @sin(angle) as the caller computes them. Integer fields: @round, clamp, @trunc.
+ */
+static float mb_get(const zo_image *im, size_t r, size_t c, int ch) {
+    const int n = zo_channels(im->pixel);
+    if (zo_is_float(im->pixel)) return ((const float *)im->data)[(r * im->stride + c) * n + ch];
+    return (float)((const uint8_t *)im->data)[(r * im->stride + c) * n + ch];
+}
+static void mb_put(const zo_image *im, size_t r, size_t c, int ch, float v) {
+    const int n = zo_channels(im->pixel);
+    if (zo_is_float(im->pixel)) ((float *)im->data)[(r * im->stride + c) * n + ch] = v;
+    else ((uint8_t *)im->data)[(r * im->stride + c) * n + ch] = (uint8_t)truncf(fmaxf(0.0f, fminf(255.0f, roundf(v))));
+}
+static int mb_sample(const zo_image *im, float sx, float sy, int ch, float *value) { /* bounds check + bilinear, :136-158 */
+    if (!(sx >= 0 && sx < (float)im->cols && sy >= 0 && sy < (float)im->rows)) return 0;
+    const size_t x0 = (size_t)floorf(sx), y0 = (size_t)floorf(sy);
+    const size_t x1 = x0 + 1 < im->cols - 1 ? x0 + 1 : im->cols - 1, y1 = y0 + 1 < im->rows - 1 ? y0 + 1 : im->rows - 1;
+    const float fx = sx - (float)x0, fy = sy - (float)y0;
+    const float v00 = mb_get(im, y0, x0, ch), v10 = mb_get(im, y0, x1, ch), v01 = mb_get(im, y1, x0, ch), v11 = mb_get(im, y1, x1, ch);
+    const float v0 = v00 * (1 - fx) + v10 * fx;
+    const float v1 = v01 * (1 - fx) + v11 * fx;
+    *value = v0 * (1 - fy) + v1 * fy;
+    return 1;
+}
+
+ZO_API int zo_motion_blur_linear(const zo_image *src, const zo_image *dst, float angle, float cos_a, float sin_a, uint32_t distance) {
+    if (src->rows != dst->rows || src->cols != dst->cols) return 1;
+    if (src->pixel != dst->pixel) return 2;
+    const int n = zo_channels(src->pixel);
+    if (distance == 0) {
+        for (size_t r = 0; r < src->rows; ++r)
+            memcpy((char *)dst->data + r * dst->stride * zo_pixel_size(dst->pixel), (const char *)src->data + r * src->stride * zo_pixel_size(src->pixel),
+                   (size_t)src->cols * zo_pixel_size(src->pixel));
+        return 0;
+    }
+    const float half_dist = (float)distance / 2.0f;
+    if (fabsf(sin_a) < 0.001f || fabsf(cos_a) < 0.001f) {
+        float *k = (float *)malloc(distance * sizeof(float));
+        const float weight = 1.0f / (float)distance, identity = 1.0f;
+        for (uint32_t i = 0; i < distance; ++i) k[i] = weight;
+        const int rc = fabsf(sin_a) < 0.001f ? zo_conv_separable(src, dst, k, distance, &identity, 1, ZO_REPLICATE)
+                                             : zo_conv_separable(src, dst, &identity, 1, k, distance, ZO_REPLICATE);
+        free(k);
+        return rc;
+    }
+    for (size_t r = 0; r < src->rows; ++r)
+        for (size_t c = 0; c < src->cols; ++c)
+            for (int ch = 0; ch < n; ++ch) {
+                float sum = 0, count = 0, t = -half_dist;
+                for (uint32_t it = 0; it < distance + 2; ++it) {
+                    if (t > half_dist) break;
+                    float v;
+                    if (mb_sample(src, (float)c + t * cos_a, (float)r + t * sin_a, ch, &v)) { sum += v; count += 1; }
+                    t += 1.0f;
+                }
+                mb_put(dst, r, c, ch, count > 0 ? sum / count : mb_get(src, r, c, ch));
+            }
+    return 0;
+}
+
+ZO_API int zo_motion_blur_radial(const zo_image *src, const zo_image *dst, float center_x, float center_y, float strength, int spin) {
+    if (src->rows != dst->rows || src->cols != dst->cols) return 1;
+    if (src->pixel != dst->pixel) return 2;
+    const int n = zo_channels(src->pixel);
+    if (strength == 0) {
+        for (size_t r = 0; r < src->rows; ++r)
+            memcpy((char *)dst->data + r * dst->stride * zo_pixel_size(dst->pixel), (const char *)src->data + r * src->stride * zo_pixel_size(src->pixel),
+                   (size_t)src->cols * zo_pixel_size(src->pixel));
+        return 0;
+    }
+    if (src->rows == 0 || src->cols == 0) return 0;
+    const float cx = center_x * (float)(src->cols - 1), cy = center_y * (float)(src->rows - 1);
+    const float s = fmaxf(0.0f, fminf(1.0f, strength));
+    const size_t num_samples = 8 + (size_t)truncf(s * 24.0f);
+    for (size_t r = 0; r < src->rows; ++r)
+        for (size_t c = 0; c < src->cols; ++c) {
+            const float dx = (float)c - cx, dy = (float)r - cy;
+            const float dist = sqrtf(dx * dx + dy * dy), ang = zo_atan2f(dy, dx);
+            const float max_distance = sqrtf(cx * cx + cy * cy);
+            const float blur_amount = spin ? s * 0.5f : (dist / max_distance) * s * 20;
+            for (int ch = 0; ch < n; ++ch) {
+                float sum = 0;
+                size_t count = 0;
+                for (size_t k = 0; k < num_samples; ++k) {
+                    const float t = ((float)k - (float)(num_samples - 1) / 2.0f) / (float)(num_samples - 1);
+                    float sx, sy;
+                    if (!spin) {
+                        const float scale = 1.0f + t * blur_amount * 0.1f;
+                        sx = cx + dx * scale;
+                        sy = cy + dy * scale;
+                    } else {
+                        const float new_angle = ang + t * blur_amount;
+                        sx = cx + dist * zo_cosf(new_angle);
+                        sy = cy + dist * zo_sinf(new_angle);
+                    }
+                    float v;
+                    if (mb_sample(src, sx, sy, ch, &v)) { sum += v; count += 1; }
+                }
+                mb_put(dst, r, c, ch, count > 0 ? sum / (float)count : mb_get(src, r, c, ch));
+            }
+        }
+    return 0;
+}

@@ -355,6 +355,21 @@ def canny(src, sigma, low, high):
     return out
 
 
+def motion_blur_linear(src, angle, distance, cos_sin=None):
+    out = np.empty_like(src)
+    ca, sa = cos_sin if cos_sin is not None else (float(np.cos(np.float32(angle), dtype=np.float32)), float(np.sin(np.float32(angle), dtype=np.float32)))
+    s, d = as_image(src), as_image(out)
+    _check(lib().zo_motion_blur_linear(C.byref(s), C.byref(d), C.c_float(angle), C.c_float(ca), C.c_float(sa), C.c_uint32(distance)), "motion_blur_linear")
+    return out
+
+
+def motion_blur_radial(src, center_x, center_y, strength, spin):
+    out = np.empty_like(src)
+    s, d = as_image(src), as_image(out)
+    _check(lib().zo_motion_blur_radial(C.byref(s), C.byref(d), C.c_float(center_x), C.c_float(center_y), C.c_float(strength), int(bool(spin))), "motion_blur_radial")
+    return out
+
+
 def pyramid(source, n_levels, scale_factor, blur_sigma):
     """ImagePyramid.build (pyramid.zig:31-102) composed from the oracle's own gaussian_blur and resize."""
     l = lib()

@@ -188,3 +188,63 @@ def test_canny_long_chain_across_tiles(oracle):
     torch.cuda.synchronize()
     assert_bits_equal(got.to_numpy(), want, "canny spiral")
     assert (want > 0).sum() > 500
+
+
+# ---- motion blur (image.zig:1077-1091 -> motion_blur.zig), SURVEY §8f rank 4 ------------------------------------------
+def test_motion_blur_reference_known_answers_oracle(oracle):  # tests/filters.zig:969-1160
+    import math
+    img = np.zeros((5, 7), np.uint8)
+    img[:, 3:] = 255
+    b = oracle.motion_blur_linear(img, 0.0, 3)
+    assert 0 < b[2, 3] < 255 and abs(int(b[0, 3]) - int(b[4, 3])) < 10
+    img = np.zeros((7, 5), np.uint8)
+    img[3:, :] = 255
+    b = oracle.motion_blur_linear(img, math.pi / 2, 3)
+    assert 0 < b[3, 2] < 255 and abs(int(b[3, 0]) - int(b[3, 4])) < 10
+    spot = np.zeros((5, 5), np.uint8)
+    spot[2, 2] = 255
+    b = oracle.motion_blur_linear(spot, math.pi / 4, 3)
+    assert b[1, 1] > 0 and b[2, 2] > 0 and b[3, 3] > 0
+    pat = np.arange(9, dtype=np.uint8).reshape(3, 3)
+    assert (oracle.motion_blur_linear(pat, 0.0, 0) == pat).all()
+    assert (oracle.motion_blur_radial(pat, 0.5, 0.5, 0.0, False) == pat).all()
+    rgb = np.zeros((5, 5, 3), np.uint8)
+    rgb[2, 2] = (255, 128, 64)
+    b = oracle.motion_blur_linear(rgb, 0.0, 3)
+    assert b[2, 2, 0] > b[2, 2, 1] > b[2, 2, 2] and b[2, 1, 0] > 0
+    r, c = np.mgrid[0:7, 0:7]
+    d = np.sqrt((c - 3.0) ** 2 + (r - 3.0) ** 2)
+    ring = np.where((d > 1.5) & (d < 2.5), 255, 0).astype(np.uint8)
+    z = oracle.motion_blur_radial(ring, 0.5, 0.5, 0.5, False)
+    assert abs(int(ring[3, 3]) - int(z[3, 3])) < 20
+    pt = np.zeros((7, 7), np.uint8)
+    pt[2, 4] = 255
+    sp = oracle.motion_blur_radial(pt, 0.5, 0.5, 0.5, True)
+    assert sp[2, 4] > 0 and (sp > 0).sum() > 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ALL_TYPES)
+def test_motion_blur_gpu_parity(oracle, kind):
+    import math
+    import torch
+
+    def dev(a):
+        return zg.Image(torch.from_numpy(np.ascontiguousarray(a)).cuda())
+
+    img = synth(oracle, kind, 21, 61, 93)
+    for angle, distance in ((0.0, 3), (0.0, 10), (math.pi / 2, 7), (math.pi / 4, 3), (0.3, 8), (2.0, 30), (-1.1, 5), (0.7, 1), (0.0, 0), (0.0005, 4)):
+        want = oracle.motion_blur_linear(img, angle, distance)
+        got = dev(img).motion_blur_linear(angle, distance)
+        torch.cuda.synchronize()
+        assert_bits_equal(got.to_numpy(), want, f"linear {kind} angle={angle} d={distance}")
+    for cx, cy, strength, spin in ((0.5, 0.5, 0.5, False), (0.5, 0.5, 0.5, True), (0.2, 0.9, 1.0, False), (0.2, 0.9, 0.3, True), (0.0, 0.0, 0.7, False),
+                                   (0.0, 0.0, 0.7, True), (1.3, -0.2, 2.5, False), (0.5, 0.5, 0.0, True), (0.4, 0.6, -0.5, False)):
+        want = oracle.motion_blur_radial(img, cx, cy, strength, spin)
+        got = dev(img).motion_blur_radial(cx, cy, strength, spin)
+        torch.cuda.synchronize()
+        assert_bits_equal(got.to_numpy(), want, f"radial {kind} c=({cx},{cy}) s={strength} spin={spin}")
+    host = zg.Image(img).motion_blur_linear(0.3, 8).data
+    assert_bits_equal(host, oracle.motion_blur_linear(img, 0.3, 8), "motion blur host layer")
+    with pytest.raises(zg.DimensionMismatch):
+        zg.Image(img).motion_blur_linear(0.3, 8, out=zg.Image(np.zeros((3, 3) + img.shape[2:], img.dtype)))

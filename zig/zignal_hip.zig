@@ -36,9 +36,13 @@ pub const c = struct {
     pub extern fn zg_flip_left_right_host(img: *const ZgImage) c_int;
     pub extern fn zg_flip_top_bottom_host(img: *const ZgImage) c_int;
     pub extern fn zg_sobel_host(src: *const ZgImage, dst: *const ZgImage) c_int;
+    pub extern fn zg_motion_blur_linear_host(src: *const ZgImage, dst: *const ZgImage, angle: f32, cos_a: f32, sin_a: f32, distance: u32) c_int;
+    pub extern fn zg_motion_blur_radial_host(src: *const ZgImage, dst: *const ZgImage, center_x: f32, center_y: f32, strength: f32, spin: c_int) c_int;
     pub extern fn zg_canny_host(src: *const ZgImage, dst: *const ZgImage, sigma: f32, low_threshold: f32, high_threshold: f32) c_int;
     pub extern fn zg_convert_host(src: *const ZgImage, src_space: c_int, dst: *const ZgImage, dst_space: c_int, srgb_lut: ?[*]const f32) c_int;
 };
+
+pub const MotionBlur = zignal.MotionBlur; // the reference's union, re-exported
 
 pub const Pixel = enum(i32) { u8 = 0, f32 = 1, rgb_u8 = 2, rgba_u8 = 3, rgb_f32 = 4, rgba_f32 = 5 };
 
@@ -143,6 +147,17 @@ pub fn Image(comptime T: type) type {
             _ = allocator;
             if (self.base.rows != out.base.rows or self.base.cols != out.base.cols) return error.DimensionMismatch;
             try check(c.zg_sobel_host(&desc(self.base), &Image(u8).desc(out.base)));
+        }
+
+        /// reference src/image.zig:1077-1091 (MotionBlur is the reference's own union, src/image/motion_blur.zig:12-56)
+        pub fn motionBlur(self: Self, out: Self, allocator: std.mem.Allocator, motion: MotionBlur) !void {
+            _ = allocator;
+            if (!self.base.hasSameShape(out.base)) return error.DimensionMismatch;
+            switch (motion) {
+                .linear => |p| try check(c.zg_motion_blur_linear_host(&desc(self.base), &desc(out.base), p.angle, @cos(p.angle), @sin(p.angle), @intCast(p.distance))),
+                .radial_zoom => |p| try check(c.zg_motion_blur_radial_host(&desc(self.base), &desc(out.base), p.center_x, p.center_y, p.strength, 0)),
+                .radial_spin => |p| try check(c.zg_motion_blur_radial_host(&desc(self.base), &desc(out.base), p.center_x, p.center_y, p.strength, 1)),
+            }
         }
 
         /// reference src/image.zig:1047-1063. The reference's distinct errors are decided here, before the device call,

@@ -122,6 +122,16 @@ template <typename T> class Image {
         const zg_image s = desc(), d = out.desc();
         check(zg_canny_host(&s, &d, sigma, low_threshold, high_threshold));
     }
+    void motionBlurLinear(const Image &out, float angle, uint32_t distance) const {     // image.zig:1077 (.linear)
+        if (!hasSameShape(out)) throw DimensionMismatch(1, "motionBlur");
+        const zg_image s = desc(), d = out.desc();
+        check(zg_motion_blur_linear_host(&s, &d, angle, std::cos(angle), std::sin(angle), distance));
+    }
+    void motionBlurRadial(const Image &out, float center_x, float center_y, float strength, bool spin) const {   // (.radial_zoom / .radial_spin)
+        if (!hasSameShape(out)) throw DimensionMismatch(1, "motionBlur");
+        const zg_image s = desc(), d = out.desc();
+        check(zg_motion_blur_radial_host(&s, &d, center_x, center_y, strength, spin ? 1 : 0));
+    }
     // ---- resampling ----
     void resize(const Image &out, Interpolation method) const {                          // image.zig:523
         const zg_image s = desc(), d = out.desc(); const zg_method m = method.c_method();

@@ -376,6 +376,25 @@ class Image:
         self._call("canny", C.byref(s), C.byref(d), C.c_float(sigma), C.c_float(low_threshold), C.c_float(high_threshold))
         return out
 
+    def motion_blur_linear(self, angle: float, distance: int, out: Optional["Image"] = None,
+                           cos_sin: Optional[Tuple[float, float]] = None) -> "Image":
+        """Image.motionBlur(.{ .linear = .{ .angle, .distance } }) (image.zig:1077, motion_blur.zig:65-236)."""
+        out = self._like() if out is None else self._wrap(out)
+        self._same_side(out)
+        ca, sa = cos_sin if cos_sin is not None else _cos_sin(angle)
+        s, d = self._desc(), out._desc()
+        self._call("motion_blur_linear", C.byref(s), C.byref(d), C.c_float(angle), C.c_float(ca), C.c_float(sa), C.c_uint32(int(distance)))
+        return out
+
+    def motion_blur_radial(self, center_x: float, center_y: float, strength: float, spin: bool = False,
+                           out: Optional["Image"] = None) -> "Image":
+        """Image.motionBlur(.{ .radial_zoom / .radial_spin = .{ .center_x, .center_y, .strength } }) (motion_blur.zig:240-440)."""
+        out = self._like() if out is None else self._wrap(out)
+        self._same_side(out)
+        s, d = self._desc(), out._desc()
+        self._call("motion_blur_radial", C.byref(s), C.byref(d), C.c_float(center_x), C.c_float(center_y), C.c_float(strength), int(bool(spin)))
+        return out
+
     # ---- colour -----------------------------------------------------------------------------
     def convert(self, dst_space: int, dtype=np.float32, src_space: Optional[int] = None,
                 out: Optional["Image"] = None, srgb_lut=None) -> "Image":
