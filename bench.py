@@ -362,6 +362,15 @@ def extras(zg, torch, np):
         r["GB/s_sector_basis"] = round((ROWS * COLS * 4 // 2 + 4 * 1024 * 1024) / ms / 1e6, 1)  # rows 1,2 mod 4 are touched whole
         return r
 
+    def resize_dense(sr, dr):
+        # a dense case for the same kernel: every source byte is a tap (2:1) or every destination byte is new (1:2),
+        # so the strict algorithmic bytes are what DRAM has to move
+        ring = 2
+        im = [(zg.Image(torch.randint(0, 256, (sr, sr, 4), dtype=torch.uint8, device="cuda")), zg.Image(torch.empty((dr, dr, 4), dtype=torch.uint8, device="cuda")))
+              for _ in range(ring)]
+        ms = _time_kernel(torch, lambda i: im[i % ring][0].resize(im[i % ring][1], I.bilinear), n=20, warm=3)
+        return rate(ms, dr * dr, 4 * sr * sr + 4 * dr * dr)
+
     def oklab():
         ring = 8
         im = [(zg.Image(s), zg.Image(torch.empty((ROWS, COLS, 3), dtype=torch.float32, device="cuda"))) for s in u8_frames(ring, (ROWS, COLS, 4))]
@@ -447,6 +456,8 @@ def extras(zg, torch, np):
     leg("config2a_gaussian_blur_one_f32_plane_4096", blur_planes)
     leg("config2b_gaussian_blur_rgba_u8_4096", blur_u8)
     leg("config3_resize_bilinear_rgba_u8_4096_to_1024", resize_u8)
+    leg("resize_bilinear_rgba_u8_8192_to_4096", lambda: resize_dense(8192, 4096))
+    leg("resize_bilinear_rgba_u8_2048_to_4096", lambda: resize_dense(2048, 4096))
     leg("config3_convert_rgba_u8_to_oklab_f32_4096", oklab)
     leg("config4_warp_projective_bicubic_rgba_u8_4096", lambda: warp("u8"))
     leg("config4_warp_projective_bicubic_rgba_f32_4096", lambda: warp("f32"))

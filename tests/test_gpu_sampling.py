@@ -37,7 +37,7 @@ def sync(img):
 def test_resize_parity(oracle, kind, mname):
     m = METHODS[mname]
     for (sr, sc), (dr, dc) in (((37, 53), (19, 71)), ((16, 16), (64, 48)), ((1, 1), (5, 7)), ((9, 4), (9, 4)),
-                               ((64, 64), (16, 16)), ((3, 50), (11, 2))):
+                               ((64, 64), (16, 16)), ((3, 50), (11, 2)), ((70, 301), (33, 260)), ((40, 60), (50, 512))):
         src = synth(oracle, kind, 20, sr, sc)
         want = oracle.resize(src, (dr, dc), om(oracle, m))
         assert_bits_equal(sync(dev(src).resize((dr, dc), m)), want, f"resize {kind} {mname} {sr}x{sc}->{dr}x{dc}")

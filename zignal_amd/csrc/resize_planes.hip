@@ -275,10 +275,87 @@ static int axis_table(int kind, uint32_t src_n, uint32_t dst_n, int taps, AxisTa
     return ZG_OK;
 }
 
+// Bilinear Rgba(u8), the pixel type and method BASELINE's resize is quoted on: same arithmetic as the RC_BILINEAR branch
+// above (channel_ops.zig:144-190) with the per-pixel overheads taken out:
+//   * the mirror rule is only evaluated by lanes whose taps leave the image (everything else is base, base + 1);
+//   * the two horizontal taps of a row are adjacent pixels, so they come from ONE 8-byte load;
+//   * NPX = 4 (upscales and mild downscales, where neighbouring destination pixels read neighbouring source pixels):
+//     four destination pixels per lane, the row taps computed once, one 16-byte store.
+//     For strong downscales NPX = 4 is slower (12.2 us against 8.8 us for 4096^2 -> 1024^2: the lanes of one gather
+//     instruction then sit 256 bytes apart instead of 16), so those keep one pixel per lane.
+__device__ inline void bilinear_taps(int d, float ratio, int n, int &i0, int &i1, int &f) {
+    const float sf = ((float)d + 0.5f) * ratio - 0.5f;
+    const float fl = floorf(sf);
+    const int base = (int)fl;
+    f = (int)truncf((sf - fl) * 256.0f);
+    i0 = base;
+    i1 = base + 1;
+    if (base < 0 || base + 1 >= n) { i0 = resolve_index(base, n, ZG_BORDER_MIRROR); i1 = resolve_index(base + 1, n, ZG_BORDER_MIRROR); }
+}
+__device__ inline uint32_t bilinear_rgba8(uint32_t tl, uint32_t tr, uint32_t bl, uint32_t br, int fx, int fy) {
+    uint32_t px = 0;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        const int a = (int)((tl >> (8 * ch)) & 0xffu), b = (int)((tr >> (8 * ch)) & 0xffu);
+        const int c = (int)((bl >> (8 * ch)) & 0xffu), d = (int)((br >> (8 * ch)) & 0xffu);
+        const int top = a * (256 - fx) + b * fx;
+        const int bottom = c * (256 - fx) + d * fx;
+        px |= (uint32_t)((top * (256 - fy) + bottom * fy) >> 16) << (8 * ch); // @divTrunc(.., 65536), operand >= 0, <= 255
+    }
+    return px;
+}
+template <int NPX>
+__global__ __launch_bounds__(256) void k_resize_bilinear_rgba8(DImg src, DImg dst, float ratio_x, float ratio_y, int tiles_x) {
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int nwg = gridDim.x, per_xcd = nwg >> 3;
+    int wg = blockIdx.x;
+    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    const int tyi = wg / tiles_x, txi = wg - tyi * tiles_x;
+    const int c0 = (txi * 64 + (int)(threadIdx.x & 63)) * NPX;
+    const int r = __builtin_amdgcn_readfirstlane(tyi * 4 + (int)(threadIdx.x >> 6)); // one row per wave
+    if (r >= dst.rows || c0 >= dst.cols) return;
+    int y0, y1, fy;
+    bilinear_taps(r, ratio_y, src.rows, y0, y1, fy);
+    const uint32_t *row0 = (const uint32_t *)src.data + (size_t)y0 * src.stride, *row1 = (const uint32_t *)src.data + (size_t)y1 * src.stride;
+    uint32_t out[NPX];
+    int x0[NPX], x1[NPX], fx[NPX];
+    u32x2 p0[NPX], p1[NPX];
+#pragma unroll
+    for (int p = 0; p < NPX; ++p) {
+        bilinear_taps(c0 + p, ratio_x, src.cols, x0[p], x1[p], fx[p]);
+        const int xp = min(x0[p], src.cols - 2); // the pair (xp, xp + 1) is always inside the row (cols >= 2)
+        p0[p] = *(const u32x2 *)(row0 + xp);     // 4-byte aligned 8-byte loads
+        p1[p] = *(const u32x2 *)(row1 + xp);
+    }
+#pragma unroll
+    for (int p = 0; p < NPX; ++p) {
+        uint32_t tl = p0[p][0], tr = p0[p][1], bl = p1[p][0], br = p1[p][1];
+        if (x1[p] != x0[p] + 1 || x0[p] > src.cols - 2) { tl = row0[x0[p]]; tr = row0[x1[p]]; bl = row1[x0[p]]; br = row1[x1[p]]; } // mirrored taps
+        out[p] = bilinear_rgba8(tl, tr, bl, br, fx[p], fy);
+    }
+    uint32_t *o = (uint32_t *)dst.data + (size_t)r * dst.stride + c0;
+    if constexpr (NPX == 4) *(u32x4 *)o = u32x4{out[0], out[1], out[2], out[3]}; // dst.cols % 4 == 0, 16-byte aligned rows
+    else o[0] = out[0];
+}
+
 template <int PIX, int CLS, int KIND, int T>
 static int launch_planes(const zg_image *src, const zg_image *dst, const AxisTable &tx, const AxisTable &ty, hipStream_t s) {
     const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, 4);
     const float ratio_x = (float)src->cols / (float)dst->cols, ratio_y = (float)src->rows / (float)dst->rows;
+    if constexpr (PIX == ZG_PIXEL_RGBA_U8 && CLS == RC_BILINEAR) {
+        if (src->cols >= 2) {
+            const bool x4 = ratio_x <= 1.5f && dst->cols % 4 == 0 && dst->stride % 4 == 0 && ((uintptr_t)dst->data & 15) == 0;
+            if (x4) {
+                const int tx4 = (int)ceil_div(dst->cols, 256);
+                hipLaunchKernelGGL(k_resize_bilinear_rgba8<4>, dim3((unsigned)(tx4 * tiles_y)), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx4);
+            } else {
+                hipLaunchKernelGGL(k_resize_bilinear_rgba8<1>, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x);
+            }
+            ZG_HIP(hipGetLastError());
+            return ZG_OK;
+        }
+    }
     hipLaunchKernelGGL((k_resize_planes<PIX, CLS, KIND, T>), dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, dimg(src), dimg(dst), tx, ty,
                        ratio_x, ratio_y, tiles_x);
     ZG_HIP(hipGetLastError());
