@@ -22,51 +22,121 @@ struct Kernel2D {
 };
 
 // MODE: 0 = f32, 1 = u8 with i32 accumulate (host proved it exact), 2 = u8 with i64 accumulate
-template <int PIX, int MODE>
+//
+// One workgroup per 64 x 16 output tile. The (16 + kh - 1) x (64 + kw - 1) source tile is staged in LDS once — the
+// border rule is evaluated per staged pixel (and not at all for tiles whose halo lies inside the image), with
+// unpredicated loads from a clamped address — and every lane then produces four vertically adjacent outputs, reading
+// each tile pixel of its columns once for all four (a tile row j feeds output o with kernel row j - o). For a given
+// output the taps are still accumulated ky-major, kx ascending, so the f32 sums are the reference's bit for bit.
+// KH / KW > 0: compile-time kernel size (3x3, 5x5, 7x7: fully unrolled, weights in SGPRs); 0: run-time size up to 15x15.
+constexpr int C2_TW = 64, C2_TH = 16, C2_RPT = 4;
+
+template <int PIX, int MODE, int KH, int KW>
 __global__ __launch_bounds__(256) void k_conv2d(DImg src, DImg dst, Kernel2D k, int border, int tiles_x) {
     using P = Px<PIX>;
     using Vec = typename P::Vec;
     constexpr int C = P::C;
+    constexpr int MAXK = KH > 0 ? KH : 15, MAXKW = KW > 0 ? KW : 15;
+    constexpr int LW = C2_TW + MAXKW - 1, LH = C2_TH + MAXK - 1;
+    __shared__ Vec tile[LH * LW];
+    const int kh = KH > 0 ? KH : k.kh, kw = KW > 0 ? KW : k.kw;
+    const int hh = kh / 2, hw = kw / 2;
+    const int lw = C2_TW + kw - 1, lh = C2_TH + kh - 1;
+
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
     if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
     const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
-    const int c = tx * 64 + (int)(threadIdx.x & 63);
-    const int r = ty * 4 + (int)(threadIdx.x >> 6);
-    if (c >= dst.cols || r >= dst.rows) return;
-    const int hh = k.kh / 2, hw = k.kw / 2;
+    const int x0 = tx * C2_TW, y0 = ty * C2_TH;
+
+    const bool inside = x0 - hw >= 0 && x0 - hw + lw <= src.cols && y0 - hh >= 0 && y0 - hh + lh <= src.rows; // workgroup-uniform
+    for (int i = threadIdx.x; i < lh * lw; i += 256) {
+        const int tr = i / lw, tc = i - tr * lw;
+        int gr = y0 - hh + tr, gc = x0 - hw + tc;
+        bool ok = true;
+        if (!inside) {
+            gr = resolve_index(gr, src.rows, border);
+            gc = resolve_index(gc, src.cols, border);
+            ok = gr >= 0 && gc >= 0;
+            gr = max(gr, 0);
+            gc = max(gc, 0);
+        }
+        Vec v = P::load(src.data, (size_t)gr * src.stride + (size_t)gc);
+        if (!ok) v = P::zero();
+        tile[tr * LW + tc] = v;
+    }
+    __syncthreads();
+
+    const int lx = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = x0 + lx, r0 = y0 + wave * C2_RPT;
     using Acc = typename std::conditional<MODE == 0, float, typename std::conditional<MODE == 1, int32_t, int64_t>::type>::type;
-    Acc acc[C];
+    Acc acc[C2_RPT][C];
 #pragma unroll
-    for (int ch = 0; ch < C; ++ch) acc[ch] = 0;
-    for (int ky = 0; ky < k.kh; ++ky) {
-        const int gr = resolve_index(r + ky - hh, src.rows, border);
-        for (int kx = 0; kx < k.kw; ++kx) {
-            const int gc = gr < 0 ? -1 : resolve_index(c + kx - hw, src.cols, border);
-            Vec v = P::zero();
-            if (gr >= 0 && gc >= 0) v = P::load(src.data, (size_t)gr * src.stride + (size_t)gc);
-            if constexpr (MODE == 0) {
-                const float w = k.f[ky * k.kw + kx];
+    for (int o = 0; o < C2_RPT; ++o)
 #pragma unroll
-                for (int ch = 0; ch < C; ++ch) { const float p = v[ch] * w; acc[ch] = acc[ch] + p; }
-            } else {
-                const int32_t w = k.i[ky * k.kw + kx];
+        for (int ch = 0; ch < C; ++ch) acc[o][ch] = 0;
+
+    auto tap = [&](int o, int ky, int kx, const Vec &v) {
+        if constexpr (MODE == 0) {
+            const float w = k.f[ky * kw + kx];
 #pragma unroll
-                for (int ch = 0; ch < C; ++ch) acc[ch] += (Acc)v[ch] * (Acc)w;
+            for (int ch = 0; ch < C; ++ch) { const float p = v[ch] * w; acc[o][ch] = acc[o][ch] + p; }
+        } else {
+            const int32_t w = k.i[ky * kw + kx];
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) acc[o][ch] += (Acc)v[ch] * (Acc)w;
+        }
+    };
+    if constexpr (KH > 0) {
+#pragma unroll
+        for (int j = 0; j < C2_RPT + KH - 1; ++j)
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx) {
+                const Vec v = tile[(wave * C2_RPT + j) * LW + lx + kx];
+#pragma unroll
+                for (int o = 0; o < C2_RPT; ++o)
+                    if (j - o >= 0 && j - o < KH) tap(o, j - o, kx, v);
+            }
+    } else {
+        for (int j = 0; j < C2_RPT + kh - 1; ++j)
+            for (int kx = 0; kx < kw; ++kx) {
+                const Vec v = tile[(wave * C2_RPT + j) * LW + lx + kx];
+#pragma unroll
+                for (int o = 0; o < C2_RPT; ++o)
+                    if (j - o >= 0 && j - o < kh) tap(o, j - o, kx, v); // wave-uniform
+            }
+    }
+    if (c >= dst.cols) return;
+#pragma unroll
+    for (int o = 0; o < C2_RPT; ++o) {
+        const int r = r0 + o;
+        if (r >= dst.rows) break;
+        Vec out;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            if constexpr (MODE == 0) out[ch] = acc[o][ch];
+            else { // divClampU8(256): symmetric rounding divide, clamp
+                const Acc a = acc[o][ch];
+                if (a < 0) out[ch] = 0; // (a - 128) / 256 truncates to <= 0
+                else { const Acc q = (a + 128) >> 8; out[ch] = (uint8_t)(q > 255 ? 255 : q); }
             }
         }
+        P::store(dst.data, (size_t)r * dst.stride + (size_t)c, out);
     }
-    Vec o;
-#pragma unroll
-    for (int ch = 0; ch < C; ++ch) {
-        if constexpr (MODE == 0) o[ch] = acc[ch];
-        else { // divClampU8(256): symmetric rounding divide, clamp
-            const Acc a = acc[ch];
-            if (a < 0) o[ch] = 0; // (a - 128) / 256 truncates to <= 0
-            else { const Acc q = (a + 128) >> 8; o[ch] = (uint8_t)(q > 255 ? 255 : q); }
-        }
-    }
-    P::store(dst.data, (size_t)r * dst.stride + (size_t)c, o);
+}
+
+template <int PIX, int MODE>
+static int launch_conv2d(const zg_image *src, const zg_image *dst, const Kernel2D &k, int border, hipStream_t s) {
+    const int tiles_x = (int)ceil_div(dst->cols, C2_TW), tiles_y = (int)ceil_div(dst->rows, C2_TH);
+    const dim3 grid((unsigned)(tiles_x * tiles_y));
+#define ZG_C2(KH, KW) hipLaunchKernelGGL((k_conv2d<PIX, MODE, KH, KW>), grid, dim3(256), 0, s, dimg(src), dimg(dst), k, border, tiles_x)
+    if (k.kh == 3 && k.kw == 3) ZG_C2(3, 3);
+    else if (k.kh == 5 && k.kw == 5) ZG_C2(5, 5);
+    else if (k.kh == 7 && k.kw == 7) ZG_C2(7, 7);
+    else ZG_C2(0, 0);
+#undef ZG_C2
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
 }
 
 static int convolve_impl(const zg_image *src, const zg_image *dst, const float *kernel, uint32_t kh, uint32_t kw, int border, hipStream_t s) {
@@ -97,18 +167,11 @@ static int convolve_impl(const zg_image *src, const zg_image *dst, const float *
         }
         mode = (255 * sum_abs < (int64_t)INT32_MAX - 256) ? 1 : 2;
     }
-    const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, 4);
-    const dim3 grid((unsigned)(tiles_x * tiles_y));
+    ZG_REQUIRE(kh <= 15 && kw <= 15, ZG_ERR_INVALID_ARGUMENT, "convolve: kernel %ux%u (each side at most 15)", kh, kw);
     return dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
-        if constexpr (std::is_same<typename Px<PIX>::Elem, float>::value) {
-            hipLaunchKernelGGL((k_conv2d<PIX, 0>), grid, dim3(256), 0, s, dimg(src), dimg(dst), k, border, tiles_x);
-        } else {
-            if (mode == 1) hipLaunchKernelGGL((k_conv2d<PIX, 1>), grid, dim3(256), 0, s, dimg(src), dimg(dst), k, border, tiles_x);
-            else hipLaunchKernelGGL((k_conv2d<PIX, 2>), grid, dim3(256), 0, s, dimg(src), dimg(dst), k, border, tiles_x);
-        }
-        ZG_HIP(hipGetLastError());
-        return ZG_OK;
+        if constexpr (std::is_same<typename Px<PIX>::Elem, float>::value) return launch_conv2d<PIX, 0>(src, dst, k, border, s);
+        else return mode == 1 ? launch_conv2d<PIX, 1>(src, dst, k, border, s) : launch_conv2d<PIX, 2>(src, dst, k, border, s);
     });
 }
 
