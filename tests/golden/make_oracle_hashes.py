@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Regenerates tests/golden/oracle_hashes.json: SHA-256 of the CPU oracle's outputs on seeded inputs, one per operation.
+
+These are REGRESSION pins of the oracle itself (so that a later edit to oracle/ cannot silently change what the GPU is
+compared against); they are NOT reference-derived. The reference-derived pins are the known answers transcribed from the
+reference's own unit tests (tests/test_oracle_*.py, tests/golden/color_zig_roundtrip_f64.json).
+
+usage: python tests/golden/make_oracle_hashes.py   (from the repository root, after building oracle/)"""
+import hashlib
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle as o  # noqa: E402
+
+
+def h(a) -> str:
+    a = np.ascontiguousarray(a)
+    return hashlib.sha256(str(a.dtype).encode() + str(a.shape).encode() + a.tobytes()).hexdigest()[:32]
+
+
+def cases():
+    u8 = o.synth_u8(11, (61, 93, 4))
+    f32 = o.synth_f32(12, (61, 93, 4))
+    g8 = o.synth_u8(13, (61, 93))
+    gf = o.synth_f32(14, (61, 93))
+    bil, bic, lan = o.method(o.BILINEAR), o.method(o.BICUBIC), o.method(o.LANCZOS)
+    hm = o.homography_from_4pts([(0, 0), (92, 0), (0, 60), (92, 60)], [(3, 2), (88, 5), (1, 57), (90, 60)])
+    yield "gaussian_blur_0.6_rgba_u8", o.gaussian_blur(u8, 0.6)
+    yield "gaussian_blur_0.6_rgba_f32", o.gaussian_blur(f32, 0.6)
+    yield "gaussian_blur_2.5_u8", o.gaussian_blur(g8, 2.5)
+    yield "gaussian_blur_1.0_f32", o.gaussian_blur(gf, 1.0)
+    k = o.gaussian_kernel(1.0)
+    for b in (o.ZERO, o.REPLICATE, o.MIRROR, o.WRAP):
+        yield f"conv_separable_border{b}_rgba_u8", o.conv_separable(u8, k, k, b)
+    yield "convolve_3x3_rgba_f32", o.convolve(f32, np.full((3, 3), 1 / 9, np.float32), o.MIRROR)
+    yield "box_blur_r2_rgba_u8", o.box_blur(u8, 2)
+    yield "resize_bilinear_rgba_u8", o.resize(u8, (23, 41), bil)
+    yield "resize_bicubic_rgba_u8", o.resize(u8, (90, 130), bic)
+    yield "resize_lanczos_f32", o.resize(gf, (30, 50), lan)
+    yield "warp_projective_bicubic_rgba_u8", o.warp(u8, (61, 93), o.PROJECTIVE, hm, bic)
+    yield "warp_projective_bilinear_rgba_f32", o.warp(f32, (61, 93), o.PROJECTIVE, hm, bil)
+    for name in ("OKLAB", "XYZ", "LAB", "LCH", "OKLCH", "XYB", "HSL", "HSV", "LMS"):
+        yield f"convert_rgba_u8_to_{name.lower()}_f32", o.convert(u8, o.CS_RGBA, getattr(o, "CS_" + name), np.float32, 3)
+    lab = o.convert(u8, o.CS_RGBA, o.CS_LAB, np.float32, 3)
+    yield "convert_lab_f32_to_rgb_u8", o.convert(lab, o.CS_LAB, o.CS_RGB, np.uint8, 3)
+    yield "convert_rgba_u8_to_ycbcr_u8", o.convert(u8, o.CS_RGBA, o.CS_YCBCR, np.uint8, 3)
+    yield "sobel_rgba_u8", o.sobel(u8)
+    yield "canny_u8", o.canny(g8, 1.0, 20, 60)
+    yield "motion_blur_linear_rgba_u8", o.motion_blur_linear(u8, 0.3, 8)
+    yield "motion_blur_spin_f32", o.motion_blur_radial(gf, 0.4, 0.6, 0.5, True)
+
+
+if __name__ == "__main__":
+    out = {name: h(arr) for name, arr in cases()}
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_hashes.json")
+    json.dump(out, open(path, "w"), indent=1, sort_keys=True)
+    print(f"wrote {len(out)} hashes to {path}")
