@@ -448,8 +448,15 @@ def extras(zg, torch, np):
         ms = _time_kernel(torch, lambda i: im[i % ring][0].canny(1.4, 50, 150, out=im[i % ring][1]), n=8, warm=2, capture=False)
         return rate(ms, ROWS * COLS, 5 * ROWS * COLS)
 
+    def shen():
+        ring = 2
+        im = [(zg.Image(s), zg.Image(torch.empty((ROWS, COLS), dtype=torch.uint8, device="cuda"))) for s in u8_frames(ring, (ROWS, COLS, 4))]
+        ms = _time_kernel(torch, lambda i: im[i % ring][0].shen_castan(out=im[i % ring][1]), n=4, warm=1, capture=False)
+        return rate(ms, ROWS * COLS, 5 * ROWS * COLS)
+
     leg("next_sobel_rgba_u8_4096", sobel)
     leg("next_canny_rgba_u8_4096", canny)
+    leg("next_shen_castan_rgba_u8_4096", shen)
     leg("next_pyramid_level3_blur_u8_4096", pyramid_blur)
     leg("next_convert_rgba_u8_to_lab_f32_4096", lambda: lab(True))
     leg("next_convert_lab_f32_to_rgba_u8_4096", lambda: lab(False))

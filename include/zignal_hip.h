@@ -253,6 +253,15 @@ ZG_API int zg_sobel_host(const zg_image *src, const zg_image *dst);
 ZG_API int zg_canny(const zg_image *src, const zg_image *dst, float sigma, float low_threshold, float high_threshold, zg_stream stream);
 ZG_API int zg_canny_host(const zg_image *src, const zg_image *dst, float sigma, float low_threshold, float high_threshold);
 
+/* Image(T).shenCastan (src/image.zig:1015-1027 -> src/image/edges.zig:83-196; options src/image/ShenCastan.zig:9-45:
+ * smooth 0.9, window_size 7, high_ratio 0.99, low_rel 0.5, hysteresis true, use_nms false by default). dst is Image(u8),
+ * 0 or 255. InvalidBParameter / WindowSizeMustBeOdd / WindowSizeTooSmall / InvalidThreshold -> ZG_ERR_INVALID_ARGUMENT.
+ * With hysteresis the call synchronises `stream` (fixed-point iteration), as zg_canny does. */
+ZG_API int zg_shen_castan(const zg_image *src, const zg_image *dst, float smooth, uint32_t window_size, float high_ratio, float low_rel,
+                          int hysteresis, int use_nms, zg_stream stream);
+ZG_API int zg_shen_castan_host(const zg_image *src, const zg_image *dst, float smooth, uint32_t window_size, float high_ratio, float low_rel,
+                               int hysteresis, int use_nms);
+
 /* Image(T).motionBlur (src/image.zig:1077-1091 -> src/image/motion_blur.zig). `.linear` (:65-236): distance 0 copies;
  * |sin| or |cos| < 0.001 is the separable convolution with a uniform kernel (.replicate); anything else averages
  * bilinear samples along the motion line. cos_a / sin_a are @cos(angle) / @sin(angle) as the caller's maths library

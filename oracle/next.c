@@ -248,3 +248,165 @@ ZO_API int zo_motion_blur_radial(const zo_image *src, const zo_image *dst, float
         }
     return 0;
 }
+
+/*
+ * Shen-Castan (src/image.zig:1015-1027 -> src/image/edges.zig:83-196, options src/image/ShenCastan.zig:9-45):
+ *   grey (as canny) -> ISEF smoothing, rows then columns, each a forward + backward first-order recursion  :283-349
+ *   -> BLI = (smoothed - grey >= 0) -> zero crossings (forward neighbours, or any 4-neighbour for NMS)       :356-415
+ *   -> adaptive gradient |mean1 - mean0| of the window split by BLI, from three integral images             :417-497
+ *   -> high threshold = first histogram bin whose cumulative count reaches floor(total * high_ratio)         :137-166
+ *   -> optional NMS on central differences of the smoothed plane :582-661 -> strong-only emit or hysteresis :179-195
+ * Returns 1 dimension mismatch, 2 bad output type, 3 invalid option (InvalidBParameter / WindowSizeMustBeOdd /
+ * WindowSizeTooSmall / InvalidThreshold).
+ */
+int zo_integral_plane_f32(const float *src, size_t src_stride, float *sat, uint32_t rows, uint32_t cols);
+
+static void isef_1d(float *data, size_t n, size_t stride, float b, float *temp) { /* edges.zig:283-305 on a strided line */
+    if (n == 0) return;
+    const float a = 1.0f - b;
+    temp[0] = b * data[0];
+    for (size_t i = 1; i < n; ++i) temp[i] = b * data[i * stride] + a * temp[i - 1];
+    data[(n - 1) * stride] = temp[n - 1];
+    if (n > 1)
+        for (size_t i = n - 1; i-- > 0;) data[i * stride] = b * temp[i] + a * data[(i + 1) * stride];
+}
+static float sc_sat_sum(const float *sat, size_t stride, size_t r1, size_t c1, size_t r2, size_t c2) { /* integral.zig:85-90 */
+    return sat[r2 * stride + c2] - (c1 > 0 ? sat[r2 * stride + (c1 - 1)] : 0) - (r1 > 0 ? sat[(r1 - 1) * stride + c2] : 0) +
+           ((r1 > 0 && c1 > 0) ? sat[(r1 - 1) * stride + (c1 - 1)] : 0);
+}
+
+ZO_API int zo_shen_castan(const zo_image *src, const zo_image *out, float smooth, uint32_t window_size, float high_ratio, float low_rel,
+                          int hysteresis, int use_nms) {
+    if (src->rows != out->rows || src->cols != out->cols) return 1;
+    if (out->pixel != ZO_U8) return 2;
+    if (!(smooth > 0 && smooth < 1)) return 3;
+    if (window_size % 2 == 0 || window_size < 3) return 3;
+    if (!(high_ratio > 0 && high_ratio < 1) || !(low_rel > 0 && low_rel < 1)) return 3;
+    const size_t rows = src->rows, cols = src->cols, n = rows * cols;
+    if (n == 0) return 0;
+    float *gray = (float *)malloc(n * 4), *sm = (float *)malloc(n * 4), *grad = (float *)calloc(n, 4), *tmp = (float *)malloc((rows > cols ? rows : cols) * 4);
+    float *sat_g = (float *)malloc(n * 4), *sat_m = (float *)malloc(n * 4), *sat_gm = (float *)malloc(n * 4), *plane = (float *)malloc(n * 4);
+    uint8_t *g8 = (uint8_t *)malloc(n), *bli = (uint8_t *)malloc(n), *edges = (uint8_t *)calloc(n, 1), *nms = (uint8_t *)calloc(n, 1);
+    {
+        zo_image g = {g8, cols, (uint32_t)rows, (uint32_t)cols, ZO_U8};
+        const int ch = zo_channels(src->pixel);
+        zo_convert(src, ch == 1 ? ZO_CS_GRAY : (ch == 4 ? ZO_CS_RGBA : ZO_CS_RGB), &g, ZO_CS_GRAY, NULL);
+        for (size_t i = 0; i < n; ++i) gray[i] = (float)g8[i];
+    }
+    memcpy(sm, gray, n * 4);
+    for (size_t r = 0; r < rows; ++r) isef_1d(sm + r * cols, cols, 1, smooth, tmp);
+    for (size_t c = 0; c < cols; ++c) isef_1d(sm + c, rows, cols, smooth, tmp);
+    for (size_t i = 0; i < n; ++i) bli[i] = (sm[i] - gray[i]) >= 0 ? 1 : 0;
+    /* zero crossings */
+    if (!use_nms) {
+        for (size_t r = 0; r < rows; ++r)
+            for (size_t c = 0; c < cols; ++c) {
+                const uint8_t ce = bli[r * cols + c];
+                int mark = 0;
+                if (!mark && c + 1 < cols) mark = ce != bli[r * cols + c + 1];
+                if (!mark && r + 1 < rows) mark = ce != bli[(r + 1) * cols + c];
+                if (!mark && r + 1 < rows && c + 1 < cols) mark = ce != bli[(r + 1) * cols + c + 1];
+                if (!mark && r + 1 < rows && c > 0) mark = ce != bli[(r + 1) * cols + c - 1];
+                if (mark) edges[r * cols + c] = 255;
+            }
+    } else if (rows >= 3 && cols >= 3) {
+        for (size_t r = 1; r + 1 < rows; ++r)
+            for (size_t c = 1; c + 1 < cols; ++c) {
+                const uint8_t ce = bli[r * cols + c];
+                if (ce != bli[r * cols + c - 1] || ce != bli[r * cols + c + 1] || ce != bli[(r - 1) * cols + c] || ce != bli[(r + 1) * cols + c])
+                    edges[r * cols + c] = 255;
+            }
+    } else {
+        for (size_t r = 0; r < rows; ++r)
+            for (size_t c = 0; c < cols; ++c) {
+                const uint8_t ce = bli[r * cols + c];
+                int mark = 0;
+                if (!mark && c > 0) mark = ce != bli[r * cols + c - 1];
+                if (!mark && c + 1 < cols) mark = ce != bli[r * cols + c + 1];
+                if (!mark && r > 0) mark = ce != bli[(r - 1) * cols + c];
+                if (!mark && r + 1 < rows) mark = ce != bli[(r + 1) * cols + c];
+                if (mark) edges[r * cols + c] = 255;
+            }
+    }
+    /* adaptive gradients from three integral images */
+    zo_integral_plane_f32(gray, cols, sat_g, (uint32_t)rows, (uint32_t)cols);
+    for (size_t i = 0; i < n; ++i) plane[i] = (float)bli[i];
+    zo_integral_plane_f32(plane, cols, sat_m, (uint32_t)rows, (uint32_t)cols);
+    for (size_t i = 0; i < n; ++i) plane[i] = gray[i] * (float)bli[i];
+    zo_integral_plane_f32(plane, cols, sat_gm, (uint32_t)rows, (uint32_t)cols);
+    const size_t hw = window_size / 2;
+    for (size_t r = 0; r < rows; ++r)
+        for (size_t c = 0; c < cols; ++c) {
+            if (edges[r * cols + c] == 0) continue;
+            const size_t r1 = r > hw ? r - hw : 0, r2 = r + hw < rows - 1 ? r + hw : rows - 1;
+            const size_t c1 = c > hw ? c - hw : 0, c2 = c + hw < cols - 1 ? c + hw : cols - 1;
+            const float area = (float)((r2 - r1 + 1) * (c2 - c1 + 1));
+            const float count1 = sc_sat_sum(sat_m, cols, r1, c1, r2, c2), count0 = area - count1;
+            if (count0 > 0 && count1 > 0) {
+                const float sum1 = sc_sat_sum(sat_gm, cols, r1, c1, r2, c2), sum_total = sc_sat_sum(sat_g, cols, r1, c1, r2, c2);
+                const float sum0 = sum_total - sum1;
+                const float mean0 = sum0 / count0, mean1 = sum1 / count1;
+                grad[r * cols + c] = fabsf(mean1 - mean0);
+            }
+        }
+    /* thresholds */
+    size_t hist[256] = {0}, total = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (edges[i] == 0) continue;
+        float g = grad[i];
+        if (g < 0) g = 0;
+        if (g > 255) g = 255;
+        hist[(size_t)roundf(g)] += 1;
+        total += 1;
+    }
+    uint8_t *o = (uint8_t *)out->data;
+    for (size_t r = 0; r < rows; ++r) memset(o + r * out->stride, 0, cols);
+    int rc = 0;
+    if (total != 0) {
+        const size_t target = (size_t)floorf((float)total * high_ratio);
+        size_t cum = 0, idx = 0;
+        while (idx < 256 && cum < target) { cum += hist[idx]; idx += 1; }
+        const float t_high = (float)(idx < 255 ? idx : 255), t_low = low_rel * t_high;
+        const uint8_t *cand = edges;
+        if (use_nms) {
+            cand = nms;
+            if (rows >= 3 && cols >= 3) {
+                const float K = 0.414213562f;
+                for (size_t r = 1; r + 1 < rows; ++r)
+                    for (size_t c = 1; c + 1 < cols; ++c) {
+                        if (edges[r * cols + c] == 0) continue;
+                        const float gx = 0.5f * (sm[r * cols + c + 1] - sm[r * cols + c - 1]), gy = 0.5f * (sm[(r + 1) * cols + c] - sm[(r - 1) * cols + c]);
+                        const float ax = fabsf(gx), ay = fabsf(gy);
+                        int dr1, dc1, dr2, dc2;
+                        if (ay <= K * ax) { dr1 = 0; dc1 = -1; dr2 = 0; dc2 = 1; }
+                        else if (ax <= K * ay) { dr1 = -1; dc1 = 0; dr2 = 1; dc2 = 0; }
+                        else if (gx * gy > 0) { dr1 = -1; dc1 = 1; dr2 = 1; dc2 = -1; }
+                        else { dr1 = -1; dc1 = -1; dr2 = 1; dc2 = 1; }
+                        const float m = grad[r * cols + c], n1 = grad[(r + dr1) * cols + (c + dc1)], n2 = grad[(r + dr2) * cols + (c + dc2)];
+                        if (m >= n1 && m >= n2) nms[r * cols + c] = 255;
+                    }
+            }
+        }
+        if (!hysteresis) {
+            for (size_t r = 0; r < rows; ++r)
+                for (size_t c = 0; c < cols; ++c) o[r * out->stride + c] = (cand[r * cols + c] > 0 && grad[r * cols + c] >= t_high) ? 255 : 0;
+        } else { /* applyHysteresis, edges.zig:499-576 */
+            size_t *queue = (size_t *)malloc(n * sizeof(size_t)), push = 0, pop = 0;
+            for (size_t r = 0; r < rows; ++r)
+                for (size_t c = 0; c < cols; ++c)
+                    if (cand[r * cols + c] > 0 && grad[r * cols + c] >= t_high) { o[r * out->stride + c] = 255; queue[push++] = r * cols + c; }
+            while (pop < push) {
+                const size_t cur = queue[pop++], r = cur / cols, c = cur % cols;
+                const size_t r0 = r > 0 ? r - 1 : 0, r1 = r + 2 < rows ? r + 2 : rows, c0 = c > 0 ? c - 1 : 0, c1 = c + 2 < cols ? c + 2 : cols;
+                for (size_t nr = r0; nr < r1; ++nr)
+                    for (size_t nc = c0; nc < c1; ++nc) {
+                        if ((nr == r && nc == c) || o[nr * out->stride + nc] > 0) continue;
+                        if (cand[nr * cols + nc] > 0 && grad[nr * cols + nc] >= t_low) { o[nr * out->stride + nc] = 255; queue[push++] = nr * cols + nc; }
+                    }
+            }
+            free(queue);
+        }
+    }
+    free(gray); free(sm); free(grad); free(tmp); free(sat_g); free(sat_m); free(sat_gm); free(plane); free(g8); free(bli); free(edges); free(nms);
+    return rc;
+}

@@ -355,6 +355,14 @@ def canny(src, sigma, low, high):
     return out
 
 
+def shen_castan(src, smooth=0.9, window_size=7, high_ratio=0.99, low_rel=0.5, hysteresis=True, use_nms=False):
+    out = np.empty(src.shape[:2], np.uint8)
+    s, d = as_image(src), as_image(out)
+    _check(lib().zo_shen_castan(C.byref(s), C.byref(d), C.c_float(smooth), C.c_uint32(window_size), C.c_float(high_ratio), C.c_float(low_rel),
+                                int(bool(hysteresis)), int(bool(use_nms))), "shen_castan")
+    return out
+
+
 def motion_blur_linear(src, angle, distance, cos_sin=None):
     out = np.empty_like(src)
     ca, sa = cos_sin if cos_sin is not None else (float(np.cos(np.float32(angle), dtype=np.float32)), float(np.sin(np.float32(angle), dtype=np.float32)))

@@ -248,3 +248,70 @@ def test_motion_blur_gpu_parity(oracle, kind):
     assert_bits_equal(host, oracle.motion_blur_linear(img, 0.3, 8), "motion blur host layer")
     with pytest.raises(zg.DimensionMismatch):
         zg.Image(img).motion_blur_linear(0.3, 8, out=zg.Image(np.zeros((3, 3) + img.shape[2:], img.dtype)))
+
+
+# ---- Shen-Castan (image.zig:1015-1027 -> edges.zig:83-196) --------------------------------------------------------------
+def _sc_square():
+    img = np.tile((np.arange(50) * 2).astype(np.uint8), (50, 1))
+    img[15:35, 15:35] = 200
+    return img
+
+
+def test_shen_castan_reference_known_answers_oracle(oracle):  # tests/shen_castan.zig:10-130, 60-86
+    e = oracle.shen_castan(_sc_square(), 0.8, 7, 0.9, 0.3)
+    assert 0 < (e > 0).sum() < 500 and set(np.unique(e).tolist()) <= {0, 255}
+    img = np.zeros((50, 50), np.uint8)
+    for c in range(25):
+        img[:, c] = min(c * 10, 200)
+    img[:, 25:] = 240
+    e = oracle.shen_castan(img, 0.85, 7, 0.8, 0.3)
+    assert (e[10:40, 24:27] > 0).any()
+    r, c = np.mgrid[0:40, 0:40]
+    circ = np.where(np.sqrt((r - 20.0) ** 2 + (c - 20.0) ** 2) <= 10, 200, 50 + (r + c) // 2).astype(np.uint8)
+    assert (oracle.shen_castan(circ, 0.7, 7, 0.9) > 0).any() and (oracle.shen_castan(circ, 0.9, 7, 0.9) > 0).any()
+    for bad in (dict(smooth=0.0), dict(smooth=1.0), dict(smooth=-0.5), dict(high_ratio=0.0), dict(high_ratio=1.0), dict(low_rel=0.0),
+                dict(window_size=6), dict(window_size=1)):
+        with pytest.raises(RuntimeError):
+            oracle.shen_castan(img, **bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ("u8", "f32", "rgb_u8", "rgba_u8", "rgba_f32"))
+def test_shen_castan_gpu_parity(oracle, kind):
+    import torch
+
+    def frame(rows, cols, seed):
+        rng = np.random.default_rng(seed)
+        y, x = np.mgrid[0:rows, 0:cols].astype(np.float32)
+        f = np.zeros((rows, cols), np.float32)
+        for _ in range(10):
+            cy, cx, s = rng.uniform(0, rows), rng.uniform(0, cols), rng.uniform(4, 40)
+            f += rng.uniform(-1, 1) * np.exp(-((y - cy) ** 2 + (x - cx) ** 2) / (2 * s * s))
+        f += (x > cols * 0.6) * 0.4
+        f = (f - f.min()) / (f.max() - f.min() + 1e-9)
+        if kind == "u8":
+            return (f * 255).astype(np.uint8)
+        if kind == "f32":
+            return f.astype(np.float32)
+        ch = 3 if kind.startswith("rgb_") else 4
+        w = np.array([1.0, 0.7, 0.4, 1.0], np.float32)[:ch]
+        if kind.endswith("u8"):
+            return (f[..., None] * 255 * w).astype(np.uint8)
+        return (f[..., None] * w).astype(np.float32)
+
+    cases = [((50, 50), dict(smooth=0.8, window_size=7, high_ratio=0.9, low_rel=0.3)),
+             ((97, 211), dict()),
+             ((97, 211), dict(use_nms=True, high_ratio=0.9)),
+             ((130, 70), dict(hysteresis=False, high_ratio=0.8, window_size=3)),
+             ((300, 517), dict(smooth=0.7, window_size=11, high_ratio=0.95, low_rel=0.2, use_nms=True)),
+             ((2, 9), dict(high_ratio=0.5)), ((2, 9), dict(high_ratio=0.5, use_nms=True)), ((1, 1), dict())]
+    for (rows, cols), opts in cases:
+        img = _sc_square() if (rows, cols) == (50, 50) and kind == "u8" else frame(rows, cols, rows * 7 + cols)
+        want = oracle.shen_castan(img, **opts)
+        got = zg.Image(torch.from_numpy(np.ascontiguousarray(img)).cuda()).shen_castan(**opts)
+        torch.cuda.synchronize()
+        assert_bits_equal(got.to_numpy(), want, f"shenCastan {kind} {rows}x{cols} {opts}")
+    assert_bits_equal(zg.Image(img).shen_castan().data, oracle.shen_castan(img), "shenCastan host layer")
+    for bad in (dict(smooth=0.0), dict(smooth=1.0), dict(high_ratio=1.0), dict(low_rel=0.0), dict(window_size=6), dict(window_size=1)):
+        with pytest.raises(zg.InvalidArgument):
+            zg.Image(img).shen_castan(**bad)

@@ -38,6 +38,7 @@ pub const c = struct {
     pub extern fn zg_sobel_host(src: *const ZgImage, dst: *const ZgImage) c_int;
     pub extern fn zg_motion_blur_linear_host(src: *const ZgImage, dst: *const ZgImage, angle: f32, cos_a: f32, sin_a: f32, distance: u32) c_int;
     pub extern fn zg_motion_blur_radial_host(src: *const ZgImage, dst: *const ZgImage, center_x: f32, center_y: f32, strength: f32, spin: c_int) c_int;
+    pub extern fn zg_shen_castan_host(src: *const ZgImage, dst: *const ZgImage, smooth: f32, window_size: u32, high_ratio: f32, low_rel: f32, hysteresis: c_int, use_nms: c_int) c_int;
     pub extern fn zg_canny_host(src: *const ZgImage, dst: *const ZgImage, sigma: f32, low_threshold: f32, high_threshold: f32) c_int;
     pub extern fn zg_convert_host(src: *const ZgImage, src_space: c_int, dst: *const ZgImage, dst_space: c_int, srgb_lut: ?[*]const f32) c_int;
 };
@@ -147,6 +148,15 @@ pub fn Image(comptime T: type) type {
             _ = allocator;
             if (self.base.rows != out.base.rows or self.base.cols != out.base.cols) return error.DimensionMismatch;
             try check(c.zg_sobel_host(&desc(self.base), &Image(u8).desc(out.base)));
+        }
+
+        /// reference src/image.zig:1015-1027; `opts.validate()` runs here so the reference's four distinct errors survive
+        pub fn shenCastan(self: Self, out: Image(u8), allocator: std.mem.Allocator, opts: zignal.ShenCastan) !void {
+            _ = allocator;
+            if (self.base.rows != out.base.rows or self.base.cols != out.base.cols) return error.DimensionMismatch;
+            try opts.validate();
+            try check(c.zg_shen_castan_host(&desc(self.base), &Image(u8).desc(out.base), opts.smooth, @intCast(opts.window_size), opts.high_ratio, opts.low_rel,
+                @intFromBool(opts.hysteresis), @intFromBool(opts.use_nms)));
         }
 
         /// reference src/image.zig:1077-1091 (MotionBlur is the reference's own union, src/image/motion_blur.zig:12-56)

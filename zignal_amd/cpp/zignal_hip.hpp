@@ -122,6 +122,12 @@ template <typename T> class Image {
         const zg_image s = desc(), d = out.desc();
         check(zg_canny_host(&s, &d, sigma, low_threshold, high_threshold));
     }
+    struct ShenCastan { float smooth = 0.9f; uint32_t window_size = 7; float high_ratio = 0.99f, low_rel = 0.5f; bool hysteresis = true, use_nms = false; }; // ShenCastan.zig:9-32
+    void shenCastan(const Image<uint8_t> &out, const ShenCastan &o = {}) const {         // image.zig:1015
+        if (rows != out.rows || cols != out.cols) throw DimensionMismatch(1, "shenCastan");
+        const zg_image s = desc(), d = out.desc();
+        check(zg_shen_castan_host(&s, &d, o.smooth, o.window_size, o.high_ratio, o.low_rel, o.hysteresis ? 1 : 0, o.use_nms ? 1 : 0));
+    }
     void motionBlurLinear(const Image &out, float angle, uint32_t distance) const {     // image.zig:1077 (.linear)
         if (!hasSameShape(out)) throw DimensionMismatch(1, "motionBlur");
         const zg_image s = desc(), d = out.desc();

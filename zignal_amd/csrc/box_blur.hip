@@ -139,6 +139,19 @@ __global__ __launch_bounds__(256) void k_box_mean(const float *sat, DImg dst, in
     P::store(dst.data, (size_t)r * dst.stride + (size_t)c, o);
 }
 
+// Integral image(s) of `src` (Image(T).Integral.compute, integral.zig:95-140): one f32 plane of rows x cols per channel,
+// planar, in the reference's association order. Also used by the Shen-Castan detector (edges.hip).
+int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s) {
+    const int C = pixel_channels(src->pixel);
+    return dispatch_pixel(src->pixel, [&](auto tag) -> int {
+        constexpr int PIX = decltype(tag)::value;
+        hipLaunchKernelGGL((k_sat_rows<PIX>), dim3(ceil_div(src->rows, 64), (unsigned)C), dim3(64), 0, s, dimg(src), sat);
+        hipLaunchKernelGGL(k_sat_cols, dim3(ceil_div(src->cols, 64), (unsigned)C), dim3(64), 0, s, sat, (int)src->rows, (int)src->cols);
+        ZG_HIP(hipGetLastError());
+        return ZG_OK;
+    });
+}
+
 static int box_blur_impl(const zg_image *src, const zg_image *dst, uint32_t radius, hipStream_t s) {
     int rc;
     if ((rc = check_image(src, "src")) || (rc = check_image(dst, "dst"))) return rc;

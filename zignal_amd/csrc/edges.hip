@@ -291,6 +291,301 @@ static int canny_impl(const zg_image *src, const zg_image *dst, float sigma, flo
     return rc;
 }
 
+
+// ---- Shen-Castan (src/image.zig:1015-1027 -> src/image/edges.zig:83-196) -----------------------------------------------
+// grey -> ISEF smoothing (rows, then columns; each a forward and a backward first-order recursion, edges.zig:283-349) ->
+// BLI = (smoothed - grey >= 0) -> zero crossings -> adaptive gradient from three integral images (grey, BLI, grey * BLI)
+// -> percentile threshold from a 256-bin histogram -> optional NMS -> strong-only emit or hysteresis.
+// The recursions and the integral images are sequential f32 chains by contract (the reference's rounding order), one
+// chain per row / column: they run as one lane per chain with LDS transposes (rows) or coalesced strided walks (columns),
+// latency-bound like boxBlur's SAT. The histogram, its percentile and the thresholds stay on the device (integer atomics
+// and a one-workgroup kernel), so nothing but the hysteresis fixed-point test synchronises the stream.
+
+int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s); // box_blur.hip
+
+// Forward recursion along rows: temp[0] = b x[0]; temp[i] = b x[i] + a temp[i-1]. One wave per 64 rows, 64-column chunks
+// transposed through LDS (lanes = columns for the coalesced global side, lanes = rows for the chain).
+__global__ __launch_bounds__(64) void k_isef_rows_fwd(const float *in, float *temp, int rows, int cols, float b) {
+    __shared__ float tile[64][65];
+    const int lane = threadIdx.x, r0 = blockIdx.x * 64;
+    const int nrows = min(64, rows - r0);
+    const float a = 1.0f - b;
+    float run = 0.0f;
+    for (int c0 = 0; c0 < cols; c0 += 64) {
+        const int c = min(c0 + lane, cols - 1); // clamped, unpredicated loads (see box_blur.hip)
+#pragma unroll 16
+        for (int i = 0; i < 64; ++i) tile[i][lane] = in[(size_t)(r0 + min(i, nrows - 1)) * cols + c];
+        __syncthreads();
+        const int ncols = min(64, cols - c0);
+        for (int j = 0; j < ncols; ++j) {
+            const float x = tile[lane][j];
+            const float bx = b * x;
+            if (c0 + j == 0) run = bx;
+            else { const float ar = a * run; run = bx + ar; }
+            tile[lane][j] = run;
+        }
+        __syncthreads();
+        if (c0 + lane < cols)
+#pragma unroll 16
+            for (int i = 0; i < 64; ++i)
+                if (i < nrows) temp[(size_t)(r0 + i) * cols + c0 + lane] = tile[i][lane];
+        __syncthreads();
+    }
+}
+// Backward recursion along rows: out[n-1] = temp[n-1]; out[i] = b temp[i] + a out[i+1].
+__global__ __launch_bounds__(64) void k_isef_rows_bwd(const float *temp, float *out, int rows, int cols, float b) {
+    __shared__ float tile[64][65];
+    const int lane = threadIdx.x, r0 = blockIdx.x * 64;
+    const int nrows = min(64, rows - r0);
+    const float a = 1.0f - b;
+    float run = 0.0f;
+    for (int c0 = (cols - 1) / 64 * 64; c0 >= 0; c0 -= 64) {
+        const int c = min(c0 + lane, cols - 1);
+#pragma unroll 16
+        for (int i = 0; i < 64; ++i) tile[i][lane] = temp[(size_t)(r0 + min(i, nrows - 1)) * cols + c];
+        __syncthreads();
+        const int ncols = min(64, cols - c0);
+        for (int j = ncols - 1; j >= 0; --j) {
+            const float t = tile[lane][j];
+            if (c0 + j == cols - 1) run = t;
+            else { const float bt = b * t, ar = a * run; run = bt + ar; }
+            tile[lane][j] = run;
+        }
+        __syncthreads();
+        if (c0 + lane < cols)
+#pragma unroll 16
+            for (int i = 0; i < 64; ++i)
+                if (i < nrows) out[(size_t)(r0 + i) * cols + c0 + lane] = tile[i][lane];
+        __syncthreads();
+    }
+}
+// The same two recursions down / up the columns, in place on `data` with `temp` between them: one lane per column,
+// coalesced across lanes, sixteen rows loaded ahead of the chain.
+__global__ __launch_bounds__(64) void k_isef_cols(float *data, float *temp, int rows, int cols, float b) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= cols) return;
+    const float a = 1.0f - b;
+    float run = 0.0f;
+    for (int r0 = 0; r0 < rows; r0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = data[(size_t)min(r0 + i, rows - 1) * cols + c];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (r0 + i < rows) {
+                const float bx = b * v[i];
+                if (r0 + i == 0) run = bx;
+                else { const float ar = a * run; run = bx + ar; }
+                temp[(size_t)(r0 + i) * cols + c] = run;
+            }
+        }
+    }
+    for (int r0 = (rows - 1) / 16 * 16; r0 >= 0; r0 -= 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = temp[(size_t)min(r0 + i, rows - 1) * cols + c];
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
+            if (r0 + i < rows) {
+                if (r0 + i == rows - 1) run = v[i];
+                else { const float bt = b * v[i], ar = a * run; run = bt + ar; }
+                data[(size_t)(r0 + i) * cols + c] = run;
+            }
+        }
+    }
+}
+
+// BLI, grey * BLI and the zero-crossing candidates (edges.zig:111-128, 356-415). FORWARD: east / south / south-east /
+// south-west neighbours; otherwise (NMS mode) any 4-neighbour, interior pixels only when the image is at least 3 x 3.
+__global__ __launch_bounds__(256) void k_sc_bli(const float *gray, const float *sm, uint8_t *bli, float *gm, uint8_t *cand, int rows, int cols, int forward) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (c >= cols || r >= rows) return;
+    auto B = [&](int rr, int cc) -> int { const size_t i = (size_t)rr * cols + cc; return (sm[i] - gray[i]) >= 0 ? 1 : 0; };
+    const int ce = B(r, c);
+    const size_t idx = (size_t)r * cols + c;
+    bli[idx] = (uint8_t)ce;
+    gm[idx] = gray[idx] * (float)ce;
+    bool mark = false;
+    if (forward) {
+        if (!mark && c + 1 < cols) mark = ce != B(r, c + 1);
+        if (!mark && r + 1 < rows) mark = ce != B(r + 1, c);
+        if (!mark && r + 1 < rows && c + 1 < cols) mark = ce != B(r + 1, c + 1);
+        if (!mark && r + 1 < rows && c > 0) mark = ce != B(r + 1, c - 1);
+    } else if (rows >= 3 && cols >= 3) {
+        if (r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1) mark = ce != B(r, c - 1) || ce != B(r, c + 1) || ce != B(r - 1, c) || ce != B(r + 1, c);
+    } else {
+        if (!mark && c > 0) mark = ce != B(r, c - 1);
+        if (!mark && c + 1 < cols) mark = ce != B(r, c + 1);
+        if (!mark && r > 0) mark = ce != B(r - 1, c);
+        if (!mark && r + 1 < rows) mark = ce != B(r + 1, c);
+    }
+    cand[idx] = mark ? 255 : 0;
+}
+
+__device__ inline float sc_sat_sum(const float *sat, int cols, int r1, int c1, int r2, int c2) { // integral.zig:85-90, in that order
+    const float a = sat[(size_t)r2 * cols + c2];
+    const float b = c1 > 0 ? sat[(size_t)r2 * cols + (c1 - 1)] : 0.0f;
+    const float c = r1 > 0 ? sat[(size_t)(r1 - 1) * cols + c2] : 0.0f;
+    const float d = (r1 > 0 && c1 > 0) ? sat[(size_t)(r1 - 1) * cols + (c1 - 1)] : 0.0f;
+    return ((a - b) - c) + d;
+}
+// adaptive gradient at the candidates (edges.zig:462-496) + the histogram of its rounded values (:139-150)
+__global__ __launch_bounds__(256) void k_sc_gradient(const uint8_t *cand, const float *sat_g, const float *sat_m, const float *sat_gm, float *grad,
+                                                     unsigned int *hist, int rows, int cols, int hw) {
+    __shared__ unsigned int lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (c < cols && r < rows) {
+        const size_t idx = (size_t)r * cols + c;
+        float g = 0.0f;
+        if (cand[idx] != 0) {
+            const int r1 = r > hw ? r - hw : 0, r2 = min(r + hw, rows - 1), c1 = c > hw ? c - hw : 0, c2 = min(c + hw, cols - 1);
+            const float area = (float)((size_t)(r2 - r1 + 1) * (size_t)(c2 - c1 + 1));
+            const float count1 = sc_sat_sum(sat_m, cols, r1, c1, r2, c2), count0 = area - count1;
+            if (count0 > 0 && count1 > 0) {
+                const float sum1 = sc_sat_sum(sat_gm, cols, r1, c1, r2, c2), sum_total = sc_sat_sum(sat_g, cols, r1, c1, r2, c2);
+                const float sum0 = sum_total - sum1;
+                const float mean0 = sum0 / count0, mean1 = sum1 / count1;
+                g = fabsf(mean1 - mean0);
+            }
+            float hgv = g;
+            if (hgv < 0) hgv = 0;
+            if (hgv > 255) hgv = 255;
+            atomicAdd(&lh[(int)roundf(hgv)], 1u);
+        }
+        grad[idx] = g;
+    }
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+// thr[0] = t_high, thr[1] = t_low (edges.zig:160-166); one workgroup
+__global__ void k_sc_thresholds(const unsigned int *hist, float *thr, float high_ratio, float low_rel) {
+    if (threadIdx.x != 0) return;
+    unsigned long long total = 0;
+    for (int i = 0; i < 256; ++i) total += hist[i];
+    const unsigned long long target = (unsigned long long)floorf((float)total * high_ratio);
+    unsigned long long cum = 0;
+    int idx = 0;
+    while (idx < 256 && cum < target) { cum += hist[idx]; idx += 1; }
+    const float t_high = (float)min(idx, 255);
+    thr[0] = t_high;
+    thr[1] = low_rel * t_high;
+}
+// NMS on central differences of the smoothed plane (edges.zig:582-661)
+__global__ __launch_bounds__(256) void k_sc_nms(const float *sm, const float *grad, const uint8_t *cand, uint8_t *out, int rows, int cols) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (c >= cols || r >= rows) return;
+    const size_t idx = (size_t)r * cols + c;
+    uint8_t keep = 0;
+    if (rows >= 3 && cols >= 3 && r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1 && cand[idx] != 0) {
+        const float K = 0.414213562f;
+        const float gx = 0.5f * (sm[idx + 1] - sm[idx - 1]), gy = 0.5f * (sm[idx + cols] - sm[idx - cols]);
+        const float ax = fabsf(gx), ay = fabsf(gy);
+        int dr1, dc1, dr2, dc2;
+        if (ay <= K * ax) { dr1 = 0; dc1 = -1; dr2 = 0; dc2 = 1; }
+        else if (ax <= K * ay) { dr1 = -1; dc1 = 0; dr2 = 1; dc2 = 0; }
+        else if (gx * gy > 0) { dr1 = -1; dc1 = 1; dr2 = 1; dc2 = -1; }
+        else { dr1 = -1; dc1 = -1; dr2 = 1; dc2 = 1; }
+        const float m = grad[idx], n1 = grad[(size_t)(r + dr1) * cols + (c + dc1)], n2 = grad[(size_t)(r + dr2) * cols + (c + dc2)];
+        if (m >= n1 && m >= n2) keep = 255;
+    }
+    out[idx] = keep;
+}
+// 0 none / 1 weak / 2 strong against the device-resident thresholds; without hysteresis only strong survives
+__global__ __launch_bounds__(256) void k_sc_classify(const uint8_t *cand, const float *grad, const float *thr, uint8_t *state, int rows, int cols, int hysteresis) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (c >= cols || r >= rows) return;
+    const size_t idx = (size_t)r * cols + c;
+    const float g = grad[idx];
+    uint8_t st = 0;
+    if (cand[idx] != 0) st = g >= thr[0] ? 2 : ((hysteresis && g >= thr[1]) ? 1 : 0);
+    state[idx] = st;
+}
+
+static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smooth, uint32_t window_size, float high_ratio, float low_rel, int hysteresis,
+                            int use_nms, zg_stream stream) {
+    hipStream_t s = as_stream(stream);
+    int rc;
+    if ((rc = check_image(src, "src")) || (rc = check_image(dst, "dst"))) return rc;
+    ZG_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, ZG_ERR_DIMENSION_MISMATCH, "shenCastan: %ux%u vs %ux%u", src->rows, src->cols,
+               dst->rows, dst->cols);
+    ZG_REQUIRE(dst->pixel == ZG_PIXEL_U8, ZG_ERR_INVALID_ARGUMENT, "shenCastan: the output is Image(u8)");
+    ZG_REQUIRE(smooth > 0 && smooth < 1, ZG_ERR_INVALID_ARGUMENT, "shenCastan: InvalidBParameter (smooth %g not in (0, 1))", (double)smooth);
+    ZG_REQUIRE(window_size % 2 == 1, ZG_ERR_INVALID_ARGUMENT, "shenCastan: WindowSizeMustBeOdd (%u)", window_size);
+    ZG_REQUIRE(window_size >= 3, ZG_ERR_INVALID_ARGUMENT, "shenCastan: WindowSizeTooSmall (%u)", window_size);
+    ZG_REQUIRE(high_ratio > 0 && high_ratio < 1 && low_rel > 0 && low_rel < 1, ZG_ERR_INVALID_ARGUMENT, "shenCastan: InvalidThreshold (high_ratio %g, low_rel %g)",
+               (double)high_ratio, (double)low_rel);
+    if (src->rows == 0 || src->cols == 0) return ZG_OK;
+    const uint32_t rows = src->rows, cols = src->cols;
+    const size_t n = (size_t)rows * cols, nf = (n + 3) / 4 * 4;
+
+    // scratch: f32 planes grey | smoothed | temp (ISEF) then grey*BLI | gradient | three SATs; u8 planes BLI | candidates | NMS | state;
+    // histogram (256) | thresholds (2) | pass flags
+    constexpr int PASSES = 4;
+    char *scratch = nullptr;
+    const size_t f32_bytes = 7 * nf * sizeof(float), u8_off = f32_bytes, small_off = (u8_off + 4 * nf + 255) / 256 * 256;
+    if ((rc = scratch_alloc((void **)&scratch, small_off + 4096, s))) return rc;
+    float *gray = (float *)scratch, *sm = gray + nf, *temp = sm + nf, *grad = temp + nf, *sat_g = grad + nf, *sat_m = sat_g + nf, *sat_gm = sat_m + nf;
+    uint8_t *bli = (uint8_t *)(scratch + u8_off), *cand = bli + nf, *nms = cand + nf, *state = nms + nf;
+    unsigned int *hist = (unsigned int *)(scratch + small_off);
+    float *thr = (float *)(hist + 256);
+    int *flags = (int *)(thr + 2);
+
+    rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
+        constexpr int PIX = decltype(tag)::value;
+        hipLaunchKernelGGL((k_canny_gray<PIX>), dim3(ceil_div(cols, 256), rows), dim3(256), 0, s, dimg(src), gray);
+        ZG_HIP(hipGetLastError());
+        return ZG_OK;
+    });
+    const dim3 g64(ceil_div(cols, 64), ceil_div(rows, 4));
+    if (rc == ZG_OK) {
+        hipLaunchKernelGGL(k_isef_rows_fwd, dim3(ceil_div(rows, 64)), dim3(64), 0, s, (const float *)gray, temp, (int)rows, (int)cols, smooth);
+        hipLaunchKernelGGL(k_isef_rows_bwd, dim3(ceil_div(rows, 64)), dim3(64), 0, s, (const float *)temp, sm, (int)rows, (int)cols, smooth);
+        hipLaunchKernelGGL(k_isef_cols, dim3(ceil_div(cols, 64)), dim3(64), 0, s, sm, temp, (int)rows, (int)cols, smooth);
+        hipLaunchKernelGGL(k_sc_bli, g64, dim3(256), 0, s, (const float *)gray, (const float *)sm, bli, temp /* grey * BLI */, cand, (int)rows, (int)cols, use_nms ? 0 : 1);
+        if (hipGetLastError() != hipSuccess) rc = ZG_ERR_HIP;
+    }
+    if (rc == ZG_OK) {
+        const zg_image gi{gray, cols, rows, cols, ZG_PIXEL_F32}, mi{bli, cols, rows, cols, ZG_PIXEL_U8}, gmi{temp, cols, rows, cols, ZG_PIXEL_F32};
+        if ((rc = sat_planes_impl(&gi, sat_g, s)) == ZG_OK && (rc = sat_planes_impl(&mi, sat_m, s)) == ZG_OK) rc = sat_planes_impl(&gmi, sat_gm, s);
+    }
+    if (rc == ZG_OK) {
+        if (hipMemsetAsync(hist, 0, 256 * sizeof(unsigned int), s) != hipSuccess) rc = ZG_ERR_HIP;
+        hipLaunchKernelGGL(k_sc_gradient, g64, dim3(256), 0, s, (const uint8_t *)cand, (const float *)sat_g, (const float *)sat_m, (const float *)sat_gm, grad, hist,
+                           (int)rows, (int)cols, (int)(window_size / 2));
+        hipLaunchKernelGGL(k_sc_thresholds, dim3(1), dim3(64), 0, s, (const unsigned int *)hist, thr, high_ratio, low_rel);
+        const uint8_t *final_cand = cand;
+        if (use_nms) {
+            hipLaunchKernelGGL(k_sc_nms, g64, dim3(256), 0, s, (const float *)sm, (const float *)grad, (const uint8_t *)cand, nms, (int)rows, (int)cols);
+            final_cand = nms;
+        }
+        hipLaunchKernelGGL(k_sc_classify, g64, dim3(256), 0, s, final_cand, (const float *)grad, (const float *)thr, state, (int)rows, (int)cols, hysteresis ? 1 : 0);
+        if (hipGetLastError() != hipSuccess) rc = ZG_ERR_HIP;
+    }
+    if (rc == ZG_OK && hysteresis) {
+        const int tiles_x = (int)ceil_div(cols, 64), hy = (int)ceil_div(rows, 16);
+        int host_flags[PASSES];
+        for (;;) { // as in canny: four passes per synchronisation
+            if (hipMemsetAsync(flags, 0, PASSES * sizeof(int), s) != hipSuccess) { rc = ZG_ERR_HIP; break; }
+            for (int p = 0; p < PASSES; ++p)
+                hipLaunchKernelGGL(k_canny_hysteresis, dim3((unsigned)(tiles_x * hy)), dim3(256), 0, s, state, (int)rows, (int)cols, tiles_x, flags + p);
+            if (hipMemcpyAsync(host_flags, flags, sizeof host_flags, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+                set_error("shenCastan: reading the hysteresis flags failed");
+                rc = ZG_ERR_HIP;
+                break;
+            }
+            if (!host_flags[PASSES - 1]) break;
+        }
+    }
+    if (rc == ZG_OK) {
+        hipLaunchKernelGGL(k_canny_emit, dim3(ceil_div(cols, 256), rows), dim3(256), 0, s, (const uint8_t *)state, dimg(dst));
+        if (hipGetLastError() != hipSuccess) rc = ZG_ERR_HIP;
+    }
+    scratch_free(scratch, s);
+    return rc;
+}
+
 } // namespace zg
 
 using namespace zg;
@@ -319,6 +614,22 @@ int zg_canny_host(const zg_image *src, const zg_image *dst, float sigma, float l
     if ((rc = a.upload(src, true, false))) return rc;
     if ((rc = b.upload(dst, false, true))) return rc;
     if ((rc = canny_impl(&a.dev, &b.dev, sigma, low_threshold, high_threshold, nullptr))) return rc;
+    ZG_HIP(hipStreamSynchronize(nullptr));
+    return b.finish();
+}
+
+int zg_shen_castan(const zg_image *src, const zg_image *dst, float smooth, uint32_t window_size, float high_ratio, float low_rel, int hysteresis,
+                   int use_nms, zg_stream stream) {
+    return shen_castan_impl(src, dst, smooth, window_size, high_ratio, low_rel, hysteresis, use_nms, stream);
+}
+
+int zg_shen_castan_host(const zg_image *src, const zg_image *dst, float smooth, uint32_t window_size, float high_ratio, float low_rel, int hysteresis,
+                        int use_nms) {
+    HostStage a, b;
+    int rc;
+    if ((rc = a.upload(src, true, false))) return rc;
+    if ((rc = b.upload(dst, false, true))) return rc;
+    if ((rc = shen_castan_impl(&a.dev, &b.dev, smooth, window_size, high_ratio, low_rel, hysteresis, use_nms, nullptr))) return rc;
     ZG_HIP(hipStreamSynchronize(nullptr));
     return b.finish();
 }

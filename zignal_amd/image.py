@@ -376,6 +376,17 @@ class Image:
         self._call("canny", C.byref(s), C.byref(d), C.c_float(sigma), C.c_float(low_threshold), C.c_float(high_threshold))
         return out
 
+    def shen_castan(self, smooth: float = 0.9, window_size: int = 7, high_ratio: float = 0.99, low_rel: float = 0.5,
+                    hysteresis: bool = True, use_nms: bool = False, out: Optional["Image"] = None) -> "Image":
+        """Image.shenCastan (image.zig:1015-1027) with the reference's ShenCastan option defaults; binary edge map as Image(u8)."""
+        if out is None:
+            out = self._like(dtype=torch.uint8 if self.on_device else np.uint8, channels=1)
+        self._same_side(out)
+        s, d = self._desc(), out._desc()
+        self._call("shen_castan", C.byref(s), C.byref(d), C.c_float(smooth), C.c_uint32(int(window_size)), C.c_float(high_ratio), C.c_float(low_rel),
+                   int(bool(hysteresis)), int(bool(use_nms)))
+        return out
+
     def motion_blur_linear(self, angle: float, distance: int, out: Optional["Image"] = None,
                            cos_sin: Optional[Tuple[float, float]] = None) -> "Image":
         """Image.motionBlur(.{ .linear = .{ .angle, .distance } }) (image.zig:1077, motion_blur.zig:65-236)."""
