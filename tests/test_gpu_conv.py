@@ -217,6 +217,30 @@ def test_long_kernels_packed_two_pass(oracle, kind, border):
     assert_bits_equal(run_dev(img, k, k, border), oracle.conv_separable(img, k, k, border), f"{kind} clamp border={border}")
 
 
+@pytest.mark.parametrize("kind", ("f32", "rgb_f32", "rgba_f32"))
+@pytest.mark.parametrize("border", BORDERS)
+def test_long_kernels_f32_two_pass(oracle, kind, border):
+    """11..65-tap (and unequal / even-length) kernels on f32 rows whose length is a multiple of 4 elements: conv_sep_f32long.hip."""
+    rng = np.random.default_rng(13)
+    for nx, ny in ((11, 11), (13, 13), (17, 17), (35, 35), (65, 65), (3, 21), (20, 6), (1, 33)):
+        kx = (rng.random(nx).astype(np.float32) - np.float32(0.3))
+        ky = (rng.random(ny).astype(np.float32) - np.float32(0.3))
+        for (rows, cols) in ((9, 272), (70, 1040), (45, 352)):
+            if (rows, cols) != (45, 352) and (nx, ny) in ((35, 35), (65, 65), (20, 6)) and border in (BORDERS[0], BORDERS[3]):
+                continue
+            img = synth(oracle, kind, 600 + nx, rows, cols)
+            assert_bits_equal(run_dev(img, kx, ky, border), oracle.conv_separable(img, kx, ky, border),
+                              f"{kind} {rows}x{cols} taps=({nx},{ny}) border={border}")
+    # pyramid / canny sigmas, and non-finite pixels: a tap outside the kernel must not exist (inf * 0 would be NaN)
+    img = synth(oracle, kind, 78, 96, 528)
+    img[40, 100] = np.inf
+    img[41, 300] = -0.0
+    for sigma in (1.4, 2.25, 4.0):
+        out = dev(img).gaussian_blur(sigma)
+        torch.cuda.synchronize()
+        assert_bits_equal(out.to_numpy(), oracle.gaussian_blur(img, sigma), f"{kind} sigma={sigma}")
+
+
 @pytest.mark.parametrize("kind", ("rgba_f32", "rgba_u8", "u8", "rgb_u8"))
 def test_config2_full_size(oracle, kind):
     img = synth(oracle, kind, 2, 4096, 4096)

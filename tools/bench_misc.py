@@ -24,7 +24,8 @@ run("blur 1.5 rgba_u8 (11 taps)", (R, R, 4), torch.uint8, blur(1.5), 8)
 run("blur 2.5 rgba_u8 (17 taps)", (R, R, 4), torch.uint8, blur(2.5), 8)
 run("blur 2.5 u8 plane (17 taps)", (R, R), torch.uint8, blur(2.5), 2)
 run("blur 5.5 u8 plane (35 taps, ORB level 7)", (R, R), torch.uint8, blur(5.5), 2)
-run("blur 2.5 rgba_f32 (17 taps, two-pass)", (R, R, 4), torch.float32, blur(2.5), 32)
+run("blur 2.5 f32 plane (17 taps)", (R, R), torch.float32, blur(2.5), 8)
+run("blur 2.5 rgba_f32 (17 taps)", (R, R, 4), torch.float32, blur(2.5), 32)
 run("blur 1.0 rgba_f32 (7 taps)", (R, R, 4), torch.float32, blur(1.0), 32)
 k3 = np.full((3, 3), 1 / 9, np.float32)
 run("convolve 3x3 rgba_u8", (R, R, 4), torch.uint8, lambda a, b: a.convolve(k3, 1, out=b), 8)

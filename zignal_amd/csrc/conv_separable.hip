@@ -515,6 +515,7 @@ static int run_sep(const zg_image *src, const zg_image *dst, const SepPlan &p, i
 
 int try_sep_rgba8(const zg_image *src, const zg_image *dst, const int32_t *ix, const int32_t *iy, int nk, int border, hipStream_t s);
 int try_sep_bytes(const zg_image *src, const zg_image *dst, const int32_t *ix, const int32_t *iy, int nk, int border, hipStream_t s);
+int try_sep_f32long(const zg_image *src, const zg_image *dst, const float *fx, int nkx, const float *fy, int nky, int border, hipStream_t s);
 int try_sep_bytes2(const zg_image *src, const zg_image *dst, const int32_t *ix, int nkx, const int32_t *iy, int nky, int border, hipStream_t s);
 int try_sep_f32x4(const zg_image *src, const zg_image *dst, const float *fx, const float *fy, int nk, uint32_t skipx, uint32_t skipy,
                   int border, hipStream_t s);
@@ -544,6 +545,10 @@ static int conv_separable_impl(const zg_image *src, const zg_image *dst, const f
         if (src->pixel == ZG_PIXEL_F32 && p.nkx == p.nky) { // single-channel planes: four pixels per lane
             const int rc4 = try_sep_f32x4(src, dst, p.fx.data(), p.fy.data(), p.nkx, p.skipx, p.skipy, border, s);
             if (rc4 >= 0) return rc4;
+        }
+        if (!(p.nkx == p.nky && p.nkx <= 9 && (p.nkx & 1))) { // long (or unequal) kernels: two coalesced passes through an f32 temp plane
+            const int rcl = try_sep_f32long(src, dst, p.fx.data(), p.nkx, p.fy.data(), p.nky, border, s);
+            if (rcl >= 0) return rcl;
         }
     } else {
         // scaleKernelToInt (convolution.zig:303-309): @round(k * 256) -> i32
