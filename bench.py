@@ -454,7 +454,15 @@ def extras(zg, torch, np):
         ms = _time_kernel(torch, lambda i: im[i % ring][0].shen_castan(out=im[i % ring][1]), n=4, warm=1, capture=False)
         return rate(ms, ROWS * COLS, 5 * ROWS * COLS)
 
+    def pyramid_build():
+        # ImagePyramid.build(source, 8, 1.2, 1.6) — ORB's default — on a grey frame: seven blur + resize levels from the
+        # original (sigma up to 5.5: 35 taps), launched from Python; output pixels = sum of the level sizes
+        src = zg.Image(torch.randint(0, 256, (ROWS, COLS), dtype=torch.uint8, device="cuda"))
+        ms = _time_kernel(torch, lambda i: zg.ImagePyramid.build_default(src), n=6, warm=2, capture=False)
+        return rate(ms, ROWS * COLS, 2 * ROWS * COLS)
+
     leg("next_sobel_rgba_u8_4096", sobel)
+    leg("next_pyramid_build_default_u8_4096", pyramid_build)
     leg("next_canny_rgba_u8_4096", canny)
     leg("next_shen_castan_rgba_u8_4096", shen)
     leg("next_pyramid_level3_blur_u8_4096", pyramid_blur)
