@@ -1,0 +1,138 @@
+#!/usr/bin/env python
+"""Randomised GPU-vs-oracle parity sweep: random shapes (biased to tile seams), pixel types, parameters, views.
+usage: python tools/fuzz_parity.py [seconds] [seed]   — exits non-zero on the first mismatch, printing the case."""
+import math
+import sys
+import time
+
+sys.path.insert(0, ".")
+import numpy as np
+import torch
+
+import zignal_amd as zg
+from oracle import pyoracle as o
+
+KINDS = ("u8", "f32", "rgb_u8", "rgba_u8", "rgb_f32", "rgba_f32")
+SEAMS = (1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 272, 352, 511, 512, 513, 1023, 1024, 1025, 1040)
+
+
+def synth(rng, kind, rows, cols):
+    ch = {"u8": (), "f32": (), "rgb_u8": (3,), "rgba_u8": (4,), "rgb_f32": (3,), "rgba_f32": (4,)}[kind]
+    if kind.endswith("u8"):
+        return rng.integers(0, 256, (rows, cols) + ch, dtype=np.uint8)
+    return rng.random((rows, cols) + ch, dtype=np.float32)
+
+
+def dim(rng, cap):
+    return int(rng.choice([d for d in SEAMS if d <= cap])) if rng.random() < 0.6 else int(rng.integers(1, cap + 1))
+
+
+def dev(a):
+    return zg.Image(torch.from_numpy(np.ascontiguousarray(a)).cuda())
+
+
+def same(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
+
+
+def case(rng):
+    kind = str(rng.choice(KINDS))
+    op = str(rng.choice(["blur", "sep", "conv2d", "box", "resize", "warp", "rotate", "convert", "sobel", "canny", "shen", "motion", "insert_flip"]))
+    rows, cols = dim(rng, 300), dim(rng, 1100)
+    img = synth(rng, kind, rows, cols)
+    border = int(rng.integers(0, 4))
+    I = zg.Interpolation
+    methods = [(I.nearest, o.NEAREST), (I.bilinear, o.BILINEAR), (I.bicubic, o.BICUBIC), (I.catmull_rom, o.CATMULL_ROM), (I.lanczos, o.LANCZOS)]
+    if op == "blur":
+        sigma = float(rng.choice([0.3, 0.6, 1.0, 1.4, 2.25, 3.3, 5.5]))
+        return f"blur {kind} {rows}x{cols} sigma={sigma}", dev(img).gaussian_blur(sigma), o.gaussian_blur(img, sigma)
+    if op == "sep":
+        nx, ny = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        if rng.random() < 0.5:  # non-negative, normalised (the packed u8 paths)
+            kx = rng.random(nx).astype(np.float32); kx /= kx.sum()
+            ky = rng.random(ny).astype(np.float32); ky /= ky.sum()
+        else:
+            kx = (rng.random(nx).astype(np.float32) - np.float32(0.3)); ky = (rng.random(ny).astype(np.float32) - np.float32(0.3))
+        return f"sep {kind} {rows}x{cols} n=({nx},{ny}) b={border}", dev(img).convolve_separable(kx, ky, border), o.conv_separable(img, kx, ky, border)
+    if op == "conv2d":
+        kh, kw = int(rng.integers(1, 10)), int(rng.integers(1, 10))
+        k = (rng.random((kh, kw)).astype(np.float32) - np.float32(0.3)) / np.float32(kh * kw * 0.3)
+        return f"conv2d {kind} {rows}x{cols} {kh}x{kw} b={border}", dev(img).convolve(k, border), o.convolve(img, k, border)
+    if op == "box":
+        rad = int(rng.integers(0, 9))
+        return f"box {kind} {rows}x{cols} r={rad}", dev(img).box_blur(rad), o.box_blur(img, rad)
+    if op == "resize":
+        m, om = methods[int(rng.integers(0, len(methods)))]
+        dr, dc = dim(rng, 200), dim(rng, 600)
+        return f"resize {kind} {rows}x{cols}->{dr}x{dc} {om}", dev(img).resize((dr, dc), m), o.resize(img, (dr, dc), o.method(om))
+    if op == "warp":
+        m, om = methods[int(rng.integers(0, 3))]
+        pts = [(0, 0), (cols - 1, 0), (0, rows - 1), (cols - 1, rows - 1)]
+        to = [(x + float(rng.uniform(-0.1, 0.1)) * cols, y + float(rng.uniform(-0.1, 0.1)) * rows) for x, y in pts]
+        if rows < 2 or cols < 2:
+            return None
+        h = o.homography_from_4pts(pts, to)
+        return (f"warp {kind} {rows}x{cols} {om}", dev(img).warp(zg.ProjectiveTransform(h), (rows, cols), m),
+                o.warp(img, (rows, cols), o.PROJECTIVE, h, o.method(om)))
+    if op == "rotate":
+        m, om = methods[int(rng.integers(0, 3))]
+        ang = float(rng.choice([0.0, math.pi / 2, math.pi, 0.3, -1.2, 2.5]))
+        cs = o.cos_sin(ang)  # both sides get the same @cos / @sin values (a Zig caller passes Zig's)
+        return f"rotate {kind} {rows}x{cols} a={ang} {om}", dev(img).rotate(ang, m, border, cos_sin=cs), o.rotate(img, ang, o.method(om), border)
+    if op == "convert":
+        if kind in ("u8", "f32"):
+            return None
+        spaces = ["OKLAB", "XYZ", "LAB", "LCH", "OKLCH", "XYB", "HSL", "HSV", "LMS", "YCBCR"]
+        sp = getattr(zg, "CS_" + str(rng.choice(spaces)))
+        ss = zg.CS_RGBA if kind.startswith("rgba") else zg.CS_RGB
+        return f"convert {kind} -> {sp}", dev(img).convert(sp, np.float32), o.convert(img, ss, sp, np.float32, 3)
+    if op == "sobel":
+        return f"sobel {kind} {rows}x{cols}", dev(img).sobel(), o.sobel(img)
+    if op == "canny":
+        sg = float(rng.choice([0.0, 1.0, 1.4])); lo = float(rng.uniform(1, 40)); hi = lo + float(rng.uniform(1, 80))
+        return f"canny {kind} {rows}x{cols} {sg} {lo} {hi}", dev(img).canny(sg, lo, hi), o.canny(img, sg, lo, hi)
+    if op == "shen":
+        kw = dict(smooth=float(rng.uniform(0.5, 0.95)), window_size=int(rng.choice([3, 5, 7, 11])), high_ratio=float(rng.uniform(0.5, 0.99)),
+                  low_rel=float(rng.uniform(0.1, 0.9)), hysteresis=bool(rng.integers(0, 2)), use_nms=bool(rng.integers(0, 2)))
+        return f"shen {kind} {rows}x{cols} {kw}", dev(img).shen_castan(**kw), o.shen_castan(img, **kw)
+    if op == "motion":
+        if rng.random() < 0.5:
+            ang, d = float(rng.choice([0.0, math.pi / 2, 0.4, 2.2, -0.9])), int(rng.integers(0, 25))
+            return f"motion linear {kind} {rows}x{cols} {ang} {d}", dev(img).motion_blur_linear(ang, d), o.motion_blur_linear(img, ang, d)
+        cx, cy, st, spin = float(rng.uniform(-0.2, 1.2)), float(rng.uniform(-0.2, 1.2)), float(rng.uniform(0, 1.3)), bool(rng.integers(0, 2))
+        return f"motion radial {kind} {rows}x{cols} {cx} {cy} {st} {spin}", dev(img).motion_blur_radial(cx, cy, st, spin), o.motion_blur_radial(img, cx, cy, st, spin)
+    if op == "insert_flip":
+        d = dev(img.copy())
+        d.flip_left_right()
+        return f"flip_lr {kind} {rows}x{cols}", d, img[:, ::-1]
+    return None
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+    rng = np.random.default_rng(seed)
+    t0, n, by_op = time.time(), 0, {}
+    while time.time() - t0 < budget:
+        try:
+            c = case(rng)
+        except (zg.ZignalError, RuntimeError) as e:  # both sides must agree that a case is invalid: re-raise if only one did
+            print("skipped (error raised):", type(e).__name__, str(e)[:100])
+            continue
+        if c is None:
+            continue
+        name, got, want = c
+        torch.cuda.synchronize()
+        g = got.to_numpy() if hasattr(got, "to_numpy") else got
+        if not same(g, want):
+            diff = np.argwhere(np.ascontiguousarray(g).view(np.uint8).reshape(-1) != np.ascontiguousarray(want).view(np.uint8).reshape(-1))
+            print(f"MISMATCH after {n} cases (seed {seed}): {name}; first differing byte {diff[0] if len(diff) else '?'} of {g.nbytes}")
+            sys.exit(1)
+        n += 1
+        by_op[name.split()[0]] = by_op.get(name.split()[0], 0) + 1
+    print(f"fuzz parity: {n} cases bit-identical in {time.time() - t0:.0f} s (seed {seed}); per op {by_op}")
+
+
+if __name__ == "__main__":
+    main()
