@@ -212,8 +212,11 @@ ZG_API int zg_flip_top_bottom(const zg_image *img, zg_stream stream);
 ZG_API int zg_flip_left_right_host(const zg_image *img);
 ZG_API int zg_flip_top_bottom_host(const zg_image *img);
 
-/* Image(T).insert (src/image.zig:606 -> src/image/transforms.zig:293-378) with blend mode
- * `.none` (store) or `.normal` alpha compositing for RGBA sources. self is modified in place. */
+/* Image(T).insert (src/image.zig:606 -> src/image/transforms.zig:293-378). blend_mode is the ordinal of the reference's
+ * Blending enum (src/blending.zig:8-22: none 0, normal 1, multiply 2, screen 3, overlay 4, soft_light 5, hard_light 6,
+ * color_dodge 7, color_burn 8, darken 9, lighten 10, difference 11, exclusion 12); anything but `.none` composites
+ * Rgba(u8) sources with blendColors (blending.zig:27-157), other pixel types store the sample (assignPixel,
+ * image.zig:67-94). self is modified in place. */
 ZG_API int zg_insert(const zg_image *self, const zg_image *source, const float rect[4], float angle,
                      float cos_a, float sin_a, const zg_method *method, int blend_mode, zg_stream stream);
 ZG_API int zg_insert_host(const zg_image *self, const zg_image *source, const float rect[4], float angle,

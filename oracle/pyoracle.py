@@ -274,6 +274,13 @@ def insert(self_img, source, rect, angle, m: ZoMethod, blend_mode=0):
     return self_img
 
 
+def blend_rgba_u8(base, overlay, mode: int):
+    """Rgba(u8).blend(overlay, mode) (blending.zig:27-157)."""
+    b = (C.c_uint8 * 4)(*[int(v) for v in base]); ov = (C.c_uint8 * 4)(*[int(v) for v in overlay])
+    lib().zo_blend_rgba_u8(b, ov, int(mode))
+    return tuple(b)
+
+
 def srgb_to_linear_lut() -> np.ndarray:
     out = np.empty(256, np.float32)
     lib().zo_srgb_to_linear_lut(out.ctypes.data_as(C.POINTER(C.c_float)))

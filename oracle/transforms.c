@@ -211,28 +211,56 @@ int zo_crop(const zo_image *src, const zo_image *dst, const float rect[4]) {
     return zo_extract(src, dst, rect, 0, 1.0f, 0.0f, &nearest, ZO_ZERO);
 }
 
-/* Rgba(u8).blend(overlay, .normal) — src/blending.zig:27-157 */
-static void blend_normal_u8(uint8_t *base, const uint8_t *overlay) {
+/* Rgba(u8).blend(overlay, mode) — blendColors, src/blending.zig:27-157. mode: the Blending ordinal (none 0, normal 1,
+ * multiply 2, screen 3, overlay 4, soft_light 5, hard_light 6, color_dodge 7, color_burn 8, darken 9, lighten 10,
+ * difference 11, exclusion 12). f32 per channel in the reference's operation order (left-associative vector products). */
+static float blend_channel(int mode, float b, float o) {
+    switch (mode) {
+    case 1: return o;
+    case 2: return b * o;
+    case 3: return 1.0f - (1.0f - b) * (1.0f - o);
+    case 4: return b < 0.5f ? (2.0f * b) * o : 1.0f - (2.0f * (1.0f - b)) * (1.0f - o);
+    case 5: return o <= 0.5f ? b - ((1.0f - 2.0f * o) * b) * (1.0f - b) : b + (2.0f * o - 1.0f) * (sqrtf(b) - b);
+    case 6: return o < 0.5f ? (2.0f * o) * b : 1.0f - (2.0f * (1.0f - o)) * (1.0f - b);
+    case 7: { const float r = b / (1.0f - o); return b == 0.0f ? 0.0f : (o >= 1.0f ? 1.0f : fminf(1.0f, r)); }
+    case 8: { const float r = 1.0f - (1.0f - b) / o; return b >= 1.0f ? 1.0f : (o <= 0.0f ? 0.0f : fmaxf(0.0f, r)); }
+    case 9: return fminf(b, o);
+    case 10: return fmaxf(b, o);
+    case 11: return fabsf(b - o);
+    case 12: return (b + o) - (2.0f * b) * o;
+    }
+    return o;
+}
+static void blend_u8(uint8_t *base, const uint8_t *overlay, int mode) {
+    if (mode == 0) { memcpy(base, overlay, 4); return; }
     if (overlay[3] == 0) return;
-    if (base[3] == 0 || overlay[3] == 255) { memcpy(base, overlay, 4); return; }
-    float b[4], o[4];
+    if (base[3] == 0) { memcpy(base, overlay, 4); return; }
+    if (mode == 1 && overlay[3] == 255) { memcpy(base, overlay, 4); return; }
+    float b[4], o[4], out[4];
     for (int i = 0; i < 4; ++i) { b[i] = (float)base[i] / 255; o[i] = (float)overlay[i] / 255; }
-    const float result_a = o[3] + b[3] * (1.0f - o[3]);
-    if (result_a <= 0) { memset(base, 0, 4); return; }
-    const float base_weight = b[3] * (1.0f - o[3]);
-    const float inv = 1.0f / result_a;
-    float out[4];
-    for (int i = 0; i < 3; ++i) out[i] = (o[i] * o[3] + b[i] * base_weight) * inv;
-    out[3] = result_a;
+    float blended[3];
+    for (int i = 0; i < 3; ++i) blended[i] = blend_channel(mode, b[i], o[i]);
+    if (overlay[3] == 255) {
+        for (int i = 0; i < 3; ++i) out[i] = blended[i];
+        out[3] = 1.0f;
+    } else {
+        const float result_a = o[3] + b[3] * (1.0f - o[3]);
+        if (result_a <= 0) { memset(base, 0, 4); return; }
+        const float base_weight = b[3] * (1.0f - o[3]);
+        const float inv = 1.0f / result_a;
+        for (int i = 0; i < 3; ++i) out[i] = (blended[i] * o[3] + b[i] * base_weight) * inv;
+        out[3] = result_a;
+    }
     for (int i = 0; i < 4; ++i) { /* Rgba(f32).as(u8): @round(255 * clamp(v, 0, 1)) */
         float v = out[i] < 0 ? 0 : (out[i] > 1 ? 1 : out[i]);
         base[i] = (uint8_t)roundf(255 * v);
     }
 }
+ZO_API void zo_blend_rgba_u8(uint8_t base[4], const uint8_t overlay[4], int mode) { blend_u8(base, overlay, mode); }
 
 /* assignPixel (image.zig:67-94) restricted to same-typed source and destination */
 static void assign_pixel(const zo_image *self, char *dest, const char *sample, int blend_mode) {
-    if (self->pixel == ZO_RGBA_U8 && blend_mode != 0) blend_normal_u8((uint8_t *)dest, (const uint8_t *)sample);
+    if (self->pixel == ZO_RGBA_U8 && blend_mode != 0) blend_u8((uint8_t *)dest, (const uint8_t *)sample, blend_mode);
     else memcpy(dest, sample, zo_pixel_size(self->pixel));
 }
 

@@ -191,7 +191,7 @@ def test_insert_parity(oracle, kind):
              ((-8, 30, 30, 70), -0.3, "bicubic"), ((50, 50, 90, 90), 1.0, "bilinear")]
     for rect, angle, mname in cases:
         cs = oracle.cos_sin(angle)
-        for blend in ((0, 1) if kind == "rgba_u8" else (0,)):
+        for blend in (range(13) if kind == "rgba_u8" else (0, 1)):  # every Blending mode (only Rgba(u8) sources composite)
             want = oracle.insert(canvas.copy(), source, rect, angle, om(oracle, METHODS[mname]), blend)
             got = dev(canvas.copy()).insert(dev(source), rect, angle, METHODS[mname], blend, cos_sin=cs)
             assert_bits_equal(sync(got), want, f"insert {kind} {rect} blend={blend}")
@@ -203,6 +203,21 @@ def test_insert_blend_known_answer():  # tests/transforms.zig:382-406
     assert np.array_equal(sync(dev(base).insert(dev(overlay), (0, 0, 1, 1), 0.0, I.nearest, 0)), overlay)
     a = 128 / 255
     assert sync(dev(base).insert(dev(overlay), (0, 0, 1, 1), 0.0, I.nearest, 1))[0, 0].tolist() == [round(255 * a), 0, round(255 * (1 - a)), 255]
+
+
+def test_insert_every_blend_mode_all_alpha_cases(oracle):
+    """blendColors (blending.zig:27-157) over the whole alpha / value lattice: a 256 x 256 canvas whose (row, col) sweep base
+    and overlay values, inserted 1:1, for every mode; alpha combinations include 0, 255 and both partial."""
+    v = np.arange(256, dtype=np.int32)
+    for ba, oa in ((255, 255), (255, 128), (200, 100), (0, 180), (90, 0), (1, 254)):
+        canvas = np.zeros((256, 256, 4), np.uint8)
+        canvas[..., 0] = v[:, None]; canvas[..., 1] = 255 - v[:, None]; canvas[..., 2] = (v[:, None] * 7) % 256; canvas[..., 3] = ba
+        over = np.zeros((256, 256, 4), np.uint8)
+        over[..., 0] = v[None, :]; over[..., 1] = (v[None, :] * 3) % 256; over[..., 2] = 255 - v[None, :]; over[..., 3] = oa
+        for mode in range(13):
+            want = oracle.insert(canvas.copy(), over, (0, 0, 256, 256), 0.0, om(oracle, I.nearest), mode)
+            got = dev(canvas.copy()).insert(dev(over), (0, 0, 256, 256), 0.0, I.nearest, mode)
+            assert_bits_equal(sync(got), want, f"blend mode {mode} base a={ba} overlay a={oa}")
 
 
 # ---- convolve (2-D) and boxBlur ----------------------------------------------------------------------

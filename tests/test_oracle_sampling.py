@@ -362,3 +362,27 @@ def test_zig_math_restatements_track_libm(oracle):
         assert abs(l.zo_cbrtf(float(x)) - float(x) ** (1 / 3)) < 2e-7 * max(1.0, float(x) ** (1 / 3))
         assert abs(l.zo_powf(float(x), 2.4) - float(x) ** 2.4) <= 3e-6 * max(float(x) ** 2.4, 1e-3)
         assert abs(l.zo_logf(float(x)) - math.log(float(x))) < 1e-6 * max(1.0, abs(math.log(float(x))))
+
+
+# ---- blending.zig:198-421 -------------------------------------------------------------------------------------------
+def test_blend_modes_known_answers(oracle):
+    B = oracle.blend_rgba_u8
+    NONE, NORMAL, MULTIPLY, SCREEN, OVERLAY, SOFT, HARD, DODGE, BURN, DARKEN, LIGHTEN, DIFF, EXCL = range(13)
+    r = B((100, 100, 100, 255), (200, 200, 200, 128), NORMAL)  # :198-206
+    assert all(140 < c < 160 for c in r[:3])
+    assert B((255, 255, 255, 255), (128, 128, 128, 255), MULTIPLY)[:3] == (128, 128, 128)  # :208-218
+    assert B((0, 0, 0, 255), (128, 128, 128, 255), SCREEN)[:3] == (128, 128, 128)  # :220-230
+    assert B((100, 100, 100, 255), (200, 200, 200, 0), NORMAL) == (100, 100, 100, 255)  # :232-243
+    r = B((100, 100, 100, 128), (200, 200, 200, 128), NORMAL)  # :245-257
+    assert 190 <= r[3] <= 192 and 130 < r[0] < 170
+    r = B((0, 0, 0, 0), (200, 150, 100, 180), NORMAL)  # :259-273
+    assert r[3] == 180 and abs(r[0] - 200) <= 1 and abs(r[1] - 150) <= 1 and abs(r[2] - 100) <= 1
+    m = B((100, 100, 100, 200), (50, 50, 50, 100), MULTIPLY)  # :275-296
+    s = B((100, 100, 100, 200), (50, 50, 50, 100), SCREEN)
+    assert abs(m[3] - 221) <= 2 and abs(s[3] - 221) <= 2 and m[0] < s[0]
+    for mode in (MULTIPLY, SCREEN, EXCL):  # :298-318 hidden base colour
+        assert B((25, 75, 125, 0), (200, 150, 100, 180), mode) == (200, 150, 100, 180)
+    assert B((100, 100, 100, 255), (200, 200, 200, 255), NONE)[:3] == (200, 200, 200)  # :346-354
+    assert B((100, 200, 100, 255), (200, 100, 100, 255), DARKEN)[:3] == (100, 100, 100)  # :391-398
+    assert B((100, 200, 100, 255), (200, 100, 100, 255), LIGHTEN)[:3] == (200, 200, 100)  # :400-407
+    assert B((200, 100, 50, 255), (50, 200, 200, 255), DIFF)[:3] == (150, 100, 150)  # :409-416

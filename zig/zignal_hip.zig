@@ -249,9 +249,8 @@ pub fn Image(comptime T: type) type {
             return chip;
         }
 
-        /// reference src/image.zig:606-608 (Blending.none and .normal on the device; other modes stay on the CPU)
+        /// reference src/image.zig:606-608 (all thirteen Blending modes on the device)
         pub fn insert(self: *Self, source: anytype, rect: Rectangle(f32), angle: f32, method: Interpolation, blend_mode: zignal.Blending) void {
-            if (blend_mode != .none and blend_mode != .normal) return self.base.insert(source.base, rect, angle, method, blend_mode);
             const r = [4]f32{ rect.l, rect.t, rect.r, rect.b };
             check(c.zg_insert_host(&desc(self.base), &desc(source.base), &r, angle, @cos(angle), @sin(angle), &methodOf(method, null), @intFromEnum(blend_mode))) catch unreachable;
         }

@@ -380,21 +380,45 @@ struct InsertParams {
     int blend;
 };
 
-// Rgba(u8).blend(overlay, .normal) — reference src/blending.zig:27-157
-__device__ inline void blend_normal_u8(typename Px<ZG_PIXEL_RGBA_U8>::Vec &base, typename Px<ZG_PIXEL_RGBA_U8>::Vec overlay) {
+// Rgba(u8).blend(overlay, mode) — blendColors, reference src/blending.zig:27-157; mode = the Blending ordinal (none 0 ...
+// exclusion 12). f32 per channel in the reference's operation order (its vector products are left-associative).
+__device__ inline float blend_channel(int mode, float b, float o) {
+    switch (mode) {
+    case 1: return o;
+    case 2: return b * o;
+    case 3: return 1.0f - (1.0f - b) * (1.0f - o);
+    case 4: return b < 0.5f ? (2.0f * b) * o : 1.0f - (2.0f * (1.0f - b)) * (1.0f - o);
+    case 5: return o <= 0.5f ? b - ((1.0f - 2.0f * o) * b) * (1.0f - b) : b + (2.0f * o - 1.0f) * (sqrtf(b) - b);
+    case 6: return o < 0.5f ? (2.0f * o) * b : 1.0f - (2.0f * (1.0f - o)) * (1.0f - b);
+    case 7: { const float r = b / (1.0f - o); return b == 0.0f ? 0.0f : (o >= 1.0f ? 1.0f : fminf(1.0f, r)); }
+    case 8: { const float r = 1.0f - (1.0f - b) / o; return b >= 1.0f ? 1.0f : (o <= 0.0f ? 0.0f : fmaxf(0.0f, r)); }
+    case 9: return fminf(b, o);
+    case 10: return fmaxf(b, o);
+    case 11: return fabsf(b - o);
+    case 12: return (b + o) - (2.0f * b) * o;
+    }
+    return o;
+}
+__device__ inline void blend_u8(typename Px<ZG_PIXEL_RGBA_U8>::Vec &base, typename Px<ZG_PIXEL_RGBA_U8>::Vec overlay, int mode) {
     if (overlay[3] == 0) return;
-    if (base[3] == 0 || overlay[3] == 255) { base = overlay; return; }
-    float b[4], o[4];
+    if (base[3] == 0 || (mode == 1 && overlay[3] == 255)) { base = overlay; return; }
+    float b[4], o[4], out[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { b[i] = (float)base[i] / 255.0f; o[i] = (float)overlay[i] / 255.0f; }
-    const float result_a = o[3] + b[3] * (1.0f - o[3]);
-    if (result_a <= 0) { base = Px<ZG_PIXEL_RGBA_U8>::zero(); return; }
-    const float base_weight = b[3] * (1.0f - o[3]);
-    const float inv = 1.0f / result_a;
-    float out[4];
+    float blended[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) out[i] = (o[i] * o[3] + b[i] * base_weight) * inv;
-    out[3] = result_a;
+    for (int i = 0; i < 3; ++i) blended[i] = blend_channel(mode, b[i], o[i]);
+    if (overlay[3] == 255) {
+        out[0] = blended[0]; out[1] = blended[1]; out[2] = blended[2]; out[3] = 1.0f;
+    } else {
+        const float result_a = o[3] + b[3] * (1.0f - o[3]);
+        if (result_a <= 0) { base = Px<ZG_PIXEL_RGBA_U8>::zero(); return; }
+        const float base_weight = b[3] * (1.0f - o[3]);
+        const float inv = 1.0f / result_a;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out[i] = (blended[i] * o[3] + b[i] * base_weight) * inv;
+        out[3] = result_a;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float v = out[i] < 0.0f ? 0.0f : (out[i] > 1.0f ? 1.0f : out[i]);
@@ -428,7 +452,7 @@ __global__ __launch_bounds__(256) void k_insert(DImg self, DImg source, InsertPa
     if constexpr (PIX == ZG_PIXEL_RGBA_U8) {
         if (q.blend != 0) {
             Vec d = P::load(self.data, di);
-            blend_normal_u8(d, sample);
+            blend_u8(d, sample, q.blend);
             P::store(self.data, di, d);
             return;
         }
@@ -441,7 +465,7 @@ static int insert_impl(const zg_image *self, const zg_image *source, const float
     int rc;
     if ((rc = check_image(self, "self")) || (rc = check_image(source, "source")) || (rc = check_method(method))) return rc;
     ZG_REQUIRE(self->pixel == source->pixel, ZG_ERR_UNSUPPORTED, "insert: source and destination pixel types must match");
-    ZG_REQUIRE(blend_mode == 0 || blend_mode == 1, ZG_ERR_UNSUPPORTED, "insert: only Blending.none and Blending.normal");
+    ZG_REQUIRE(blend_mode >= 0 && blend_mode <= 12, ZG_ERR_INVALID_ARGUMENT, "insert: invalid Blending ordinal %d", blend_mode);
     ZG_REQUIRE(rect != nullptr, ZG_ERR_INVALID_ARGUMENT, "insert: null rect");
     if (source->rows == 0 || source->cols == 0 || self->rows == 0 || self->cols == 0) return ZG_OK;
     const float frows = (float)source->rows, fcols = (float)source->cols;

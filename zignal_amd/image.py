@@ -61,7 +61,9 @@ class BorderMode:
 
 
 class Blending:
-    none, normal = 0, 1
+    """reference src/blending.zig:8-22 (same ordinals)."""
+    (none, normal, multiply, screen, overlay, soft_light, hard_light, color_dodge, color_burn, darken, lighten,
+     difference, exclusion) = range(13)
 
 
 _PIXEL_BY_LAYOUT = {
