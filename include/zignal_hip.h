@@ -216,7 +216,8 @@ ZG_API int zg_flip_top_bottom_host(const zg_image *img);
  * Blending enum (src/blending.zig:8-22: none 0, normal 1, multiply 2, screen 3, overlay 4, soft_light 5, hard_light 6,
  * color_dodge 7, color_burn 8, darken 9, lighten 10, difference 11, exclusion 12); anything but `.none` composites
  * Rgba(u8) sources with blendColors (blending.zig:27-157), other pixel types store the sample (assignPixel,
- * image.zig:67-94). self is modified in place. */
+ * image.zig:67-94). source may have a different pixel type than self (`source: anytype`): samples are then converted with
+ * convertColor, and Rgba(u8) samples composite through Rgba(u8) whatever self's type. self is modified in place. */
 ZG_API int zg_insert(const zg_image *self, const zg_image *source, const float rect[4], float angle,
                      float cos_a, float sin_a, const zg_method *method, int blend_mode, zg_stream stream);
 ZG_API int zg_insert_host(const zg_image *self, const zg_image *source, const float rect[4], float angle,

@@ -258,15 +258,30 @@ static void blend_u8(uint8_t *base, const uint8_t *overlay, int mode) {
 }
 ZO_API void zo_blend_rgba_u8(uint8_t base[4], const uint8_t overlay[4], int mode) { blend_u8(base, overlay, mode); }
 
-/* assignPixel (image.zig:67-94) restricted to same-typed source and destination */
-static void assign_pixel(const zo_image *self, char *dest, const char *sample, int blend_mode) {
-    if (self->pixel == ZO_RGBA_U8 && blend_mode != 0) blend_u8((uint8_t *)dest, (const uint8_t *)sample, blend_mode);
-    else memcpy(dest, sample, zo_pixel_size(self->pixel));
+int zo_convert(const zo_image *src, int src_space, const zo_image *dst, int dst_space, const float *srgb_lut);
+/* convertColor between image pixel types (color.zig:108-151): the colour space follows the channel count */
+static void convert_px(int spix, const void *s, int dpix, void *d) {
+    const zo_image si = {(void *)s, 1, 1, 1, spix}, di = {d, 1, 1, 1, dpix};
+    const int sc = zo_channels(spix), dc = zo_channels(dpix);
+    zo_convert(&si, sc == 1 ? ZO_CS_GRAY : (sc == 4 ? ZO_CS_RGBA : ZO_CS_RGB), &di, dc == 1 ? ZO_CS_GRAY : (dc == 4 ? ZO_CS_RGBA : ZO_CS_RGB), NULL);
+}
+/* assignPixel (image.zig:67-94): Rgba(u8) samples with a blend mode composite through Rgba(u8) (the destination is
+ * converted to Rgba, blended, converted back); otherwise the sample is converted to the destination type and stored. */
+static void assign_pixel(const zo_image *self, char *dest, int spix, const char *sample, int blend_mode) {
+    if (spix == ZO_RGBA_U8 && blend_mode != 0) {
+        if (self->pixel == ZO_RGBA_U8) { blend_u8((uint8_t *)dest, (const uint8_t *)sample, blend_mode); return; }
+        uint8_t rgba[4];
+        convert_px(self->pixel, dest, ZO_RGBA_U8, rgba);
+        blend_u8(rgba, (const uint8_t *)sample, blend_mode);
+        convert_px(ZO_RGBA_U8, rgba, self->pixel, dest);
+        return;
+    }
+    if (spix == self->pixel) memcpy(dest, sample, zo_pixel_size(self->pixel));
+    else convert_px(spix, sample, self->pixel, dest);
 }
 
 int zo_insert(const zo_image *self, const zo_image *source, const float rect[4], float angle, float cos_a, float sin_a,
               const zo_method *m, int blend_mode) {
-    if (self->pixel != source->pixel) return 5;
     if (source->rows == 0 || source->cols == 0) return 0;
     const float frows = (float)source->rows, fcols = (float)source->cols;
     const float rect_width = rect_w(rect), rect_height = rect_h(rect);
@@ -278,7 +293,7 @@ int zo_insert(const zo_image *self, const zo_image *source, const float rect[4],
             for (size_t c = 0; c < source->cols; ++c) {
                 const int64_t x = (int64_t)dst_left + (int64_t)c;
                 if (y < 0 || x < 0 || y >= self->rows || x >= self->cols) continue;
-                assign_pixel(self, px_at(self, (size_t)y, (size_t)x), px_at(source, r, c), blend_mode);
+                assign_pixel(self, px_at(self, (size_t)y, (size_t)x), source->pixel, px_at(source, r, c), blend_mode);
             }
         }
         return 0;
@@ -307,7 +322,7 @@ int zo_insert(const zo_image *self, const zo_image *source, const float rect[4],
             const float sx = source->cols == 1 ? 0 : norm_x * (fcols - 1);
             const float sy = source->rows == 1 ? 0 : norm_y * (frows - 1);
             char px[16];
-            if (zo_interpolate(source, sx, sy, m, ZO_MIRROR, px)) assign_pixel(self, px_at(self, r, c), px, blend_mode);
+            if (zo_interpolate(source, sx, sy, m, ZO_MIRROR, px)) assign_pixel(self, px_at(self, r, c), source->pixel, px, blend_mode);
         }
     }
     return 0;

@@ -205,6 +205,27 @@ def test_insert_blend_known_answer():  # tests/transforms.zig:382-406
     assert sync(dev(base).insert(dev(overlay), (0, 0, 1, 1), 0.0, I.nearest, 1))[0, 0].tolist() == [round(255 * a), 0, round(255 * (1 - a)), 255]
 
 
+@pytest.mark.parametrize("skind", ALL_TYPES)
+def test_insert_mixed_types(oracle, skind):
+    """insert's source is `anytype` (transforms.zig:293): differing types go through assignPixel's convertColor, and Rgba(u8)
+    sources with a blend mode composite through Rgba(u8) whatever the destination type (image.zig:67-94)."""
+    source = synth(oracle, skind, 47, 23, 31)
+    if skind == "rgba_u8":
+        source[..., 3] = (source[..., 3].astype(np.int32) * 3 % 256).astype(np.uint8)  # a spread of alphas incl. small ones
+        source[0:4, 0:6, 3] = 0
+        source[4:8, 0:6, 3] = 255
+    for dkind in ALL_TYPES:
+        if dkind == skind:
+            continue
+        canvas = synth(oracle, dkind, 46, 64, 70)
+        for rect, angle, mname in (((10, 12, 41, 35), 0.0, "nearest"), ((5.5, 8.25, 60, 50), 0.4, "bilinear"), ((-6, 30, 40, 75), -0.7, "bicubic")):
+            cs = oracle.cos_sin(angle)
+            for blend in ((0, 1, 2, 7, 12) if skind == "rgba_u8" else (0, 1)):
+                want = oracle.insert(canvas.copy(), source, rect, angle, om(oracle, METHODS[mname]), blend)
+                got = dev(canvas.copy()).insert(dev(source), rect, angle, METHODS[mname], blend, cos_sin=cs)
+                assert_bits_equal(sync(got), want, f"insert {skind} -> {dkind} {rect} blend={blend}")
+
+
 def test_insert_every_blend_mode_all_alpha_cases(oracle):
     """blendColors (blending.zig:27-157) over the whole alpha / value lattice: a 256 x 256 canvas whose (row, col) sweep base
     and overlay values, inserted 1:1, for every mode; alpha combinations include 0, 255 and both partial."""

@@ -378,6 +378,8 @@ struct InsertParams {
     int min_r, max_r, min_c, max_c;
     float cx, cy, cos_a, sin_a, inv_width, inv_height, half_width, half_height, fcols_m1, frows_m1;
     int blend;
+    uint8_t *mask; // mixed-type insert: one byte per pixel of the bounding box, set where a sample was produced (else null)
+    int mask_w;
 };
 
 // Rgba(u8).blend(overlay, mode) — blendColors, reference src/blending.zig:27-157; mode = the Blending ordinal (none 0 ...
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(256) void k_insert(DImg self, DImg source, InsertPa
         if (!interpolate<PIX, KIND>(source, sx, sy, m, ZG_BORDER_MIRROR, sample)) return;
     }
     const size_t di = (size_t)r * self.stride + (size_t)c;
+    if (q.mask) q.mask[(size_t)(r - q.min_r) * q.mask_w + (c - q.min_c)] = 1;
     if constexpr (PIX == ZG_PIXEL_RGBA_U8) {
         if (q.blend != 0) {
             Vec d = P::load(self.data, di);
@@ -460,11 +463,81 @@ __global__ __launch_bounds__(256) void k_insert(DImg self, DImg source, InsertPa
     P::store(self.data, di, sample);
 }
 
+// convertColor between the six image pixel types (color.zig:108-151 with the scalar / Rgb / Rgba rules of :365-390, :484-512,
+// :1031-1047): what assignPixel applies when source and destination types differ.
+template <int SPIX, int DPIX> __device__ inline typename Px<DPIX>::Vec convert_px(typename Px<SPIX>::Vec sv) {
+    using SP = Px<SPIX>;
+    using DP = Px<DPIX>;
+    constexpr bool SF = std::is_same<typename SP::Elem, float>::value, DF = std::is_same<typename DP::Elem, float>::value;
+    constexpr int SC = SP::C, DC = DP::C;
+    typename DP::Vec d = DP::zero();
+    auto u8_of = [](float v) -> uint8_t { const float c = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); return (uint8_t)(int)roundf(255.0f * c); };
+    if constexpr (DC == 1) {
+        if constexpr (SC == 1) { // scalar <-> scalar (:113-119)
+            if constexpr (SF == DF) d[0] = sv[0];
+            else if constexpr (!SF) d[0] = (float)sv[0] / 255.0f;
+            else { double v = (double)sv[0]; v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v); d[0] = (uint8_t)(int)round(v * 255.0); }
+        } else if constexpr (!SF) { // colour(u8) -> luminance, BT.709 16.16 fixed point
+            const int y0 = (13933 * (int)sv[0] + 46871 * (int)sv[1] + 4732 * (int)sv[2] + 32768) >> 16;
+            const int y = y0 < 0 ? 0 : (y0 > 255 ? 255 : y0);
+            if constexpr (DF) d[0] = (float)y / 255.0f; else d[0] = (uint8_t)y;
+        } else {
+            float y = 0.2126f * sv[0] + 0.7152f * sv[1] + 0.0722f * sv[2];
+            y = y < 0.0f ? 0.0f : (y > 1.0f ? 1.0f : y);
+            if constexpr (DF) d[0] = y; else d[0] = u8_of(y);
+        }
+    } else if constexpr (SC == 1) { // scalar -> colour: Gray(Src).as(DestT), replicated, opaque
+        typename DP::Elem g;
+        if constexpr (SF == DF) g = sv[0];
+        else if constexpr (!SF) g = (float)sv[0] / 255.0f;
+        else g = u8_of(sv[0]);
+        d[0] = g; d[1] = g; d[2] = g;
+        if constexpr (DC == 4) d[3] = DF ? (typename DP::Elem)1 : (typename DP::Elem)255;
+    } else { // colour -> colour: component type first (.as), then Rgb <-> Rgba
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if constexpr (SF == DF) d[i] = sv[i];
+            else if constexpr (!SF) d[i] = (float)sv[i] / 255.0f;
+            else d[i] = u8_of(sv[i]);
+        }
+        if constexpr (DC == 4) {
+            if constexpr (SC == 4) {
+                if constexpr (SF == DF) d[3] = sv[3];
+                else if constexpr (!SF) d[3] = (float)sv[3] / 255.0f;
+                else d[3] = u8_of(sv[3]);
+            } else d[3] = DF ? (typename DP::Elem)1 : (typename DP::Elem)255;
+        }
+    }
+    return d;
+}
+
+// assignPixel (image.zig:67-94) for differing source / destination types, over the samples of the bounding box:
+// Rgba(u8) samples with a blend mode composite through Rgba(u8); everything else is convertColor(Dest, sample).
+template <int SPIX, int DPIX>
+__global__ __launch_bounds__(256) void k_insert_assign(DImg self, const void *samples, const uint8_t *mask, int min_r, int max_r, int min_c, int max_c, int blend) {
+    using SP = Px<SPIX>;
+    using DP = Px<DPIX>;
+    const int c = min_c + (int)(blockIdx.x * 64 + (threadIdx.x & 63)), r = min_r + (int)(blockIdx.y * 4 + (threadIdx.x >> 6));
+    if (c >= max_c || r >= max_r) return;
+    const size_t bi = (size_t)(r - min_r) * (max_c - min_c) + (c - min_c);
+    if (!mask[bi]) return;
+    const typename SP::Vec sample = SP::load(samples, bi);
+    const size_t di = (size_t)r * self.stride + (size_t)c;
+    if constexpr (SPIX == ZG_PIXEL_RGBA_U8) {
+        if (blend != 0) {
+            typename SP::Vec d = convert_px<DPIX, ZG_PIXEL_RGBA_U8>(DP::load(self.data, di));
+            blend_u8(d, sample, blend);
+            DP::store(self.data, di, convert_px<ZG_PIXEL_RGBA_U8, DPIX>(d));
+            return;
+        }
+    }
+    DP::store(self.data, di, convert_px<SPIX, DPIX>(sample));
+}
+
 static int insert_impl(const zg_image *self, const zg_image *source, const float rect[4], float angle, float cos_a, float sin_a,
                        const zg_method *method, int blend_mode, hipStream_t s) {
     int rc;
     if ((rc = check_image(self, "self")) || (rc = check_image(source, "source")) || (rc = check_method(method))) return rc;
-    ZG_REQUIRE(self->pixel == source->pixel, ZG_ERR_UNSUPPORTED, "insert: source and destination pixel types must match");
     ZG_REQUIRE(blend_mode >= 0 && blend_mode <= 12, ZG_ERR_INVALID_ARGUMENT, "insert: invalid Blending ordinal %d", blend_mode);
     ZG_REQUIRE(rect != nullptr, ZG_ERR_INVALID_ARGUMENT, "insert: null rect");
     if (source->rows == 0 || source->cols == 0 || self->rows == 0 || self->cols == 0) return ZG_OK;
@@ -499,9 +572,27 @@ static int insert_impl(const zg_image *self, const zg_image *source, const float
     if ((rc = device_lanczos_lut(method, s, lut))) return rc;
     const MethodArg m{method->kind, method->b, method->c, lut.dev};
     const dim3 grid(ceil_div((unsigned)(q.max_c - q.min_c), 64), ceil_div((unsigned)(q.max_r - q.min_r), 4));
-    rc = dispatch_pixel(self->pixel, [&](auto tag) -> int {
+    // Differing types (the reference's `source: anytype`): sample in the SOURCE type into a scratch copy of the bounding box
+    // with the kernels below (blend off, a mask of the pixels that got a sample), then assignPixel converts / composites.
+    const bool mixed = self->pixel != source->pixel;
+    const int bw = q.max_c - q.min_c, bh = q.max_r - q.min_r;
+    zg_image target = *self;
+    char *scratch = nullptr;
+    if (mixed) {
+        const size_t sps = pixel_size(source->pixel), samples_bytes = ((size_t)bw * bh * sps + 15) / 16 * 16;
+        if ((rc = scratch_alloc((void **)&scratch, samples_bytes + (size_t)bw * bh, s))) { release_lut(lut, s); return rc; }
+        q.mask = (uint8_t *)(scratch + samples_bytes);
+        q.mask_w = bw;
+        q.blend = 0;
+        if (hipMemsetAsync(q.mask, 0, (size_t)bw * bh, s) != hipSuccess) { scratch_free(scratch, s); release_lut(lut, s); ZG_HIP(hipErrorUnknown); }
+        // a view of the scratch addressed with self's coordinates: pixel (min_r, min_c) is scratch[0], row pitch = box width
+        target.pixel = source->pixel;
+        target.stride = (size_t)bw;
+        target.data = scratch - ((ptrdiff_t)q.min_r * bw + q.min_c) * (ptrdiff_t)sps;
+    }
+    rc = dispatch_pixel(source->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
-#define ZG_INS(K) case K: hipLaunchKernelGGL((k_insert<PIX, K>), grid, dim3(256), 0, s, dimg(self), dimg(source), q, m); break;
+#define ZG_INS(K) case K: hipLaunchKernelGGL((k_insert<PIX, K>), grid, dim3(256), 0, s, dimg(&target), dimg(source), q, m); break;
         switch (method->kind) {
             ZG_INS(ZG_INTERP_NEAREST) ZG_INS(ZG_INTERP_BILINEAR) ZG_INS(ZG_INTERP_BICUBIC)
             ZG_INS(ZG_INTERP_CATMULL_ROM) ZG_INS(ZG_INTERP_MITCHELL) ZG_INS(ZG_INTERP_LANCZOS)
@@ -510,6 +601,22 @@ static int insert_impl(const zg_image *self, const zg_image *source, const float
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     });
+    if (mixed) {
+        if (rc == ZG_OK)
+            rc = dispatch_pixel(source->pixel, [&](auto stag) -> int {
+                constexpr int SPIX = decltype(stag)::value;
+                return dispatch_pixel(self->pixel, [&](auto dtag) -> int {
+                    constexpr int DPIX = decltype(dtag)::value;
+                    if constexpr (SPIX != DPIX) {
+                        hipLaunchKernelGGL((k_insert_assign<SPIX, DPIX>), grid, dim3(256), 0, s, dimg(self), (const void *)scratch, (const uint8_t *)q.mask, q.min_r,
+                                           q.max_r, q.min_c, q.max_c, blend_mode);
+                        ZG_HIP(hipGetLastError());
+                    }
+                    return ZG_OK;
+                });
+            });
+        scratch_free(scratch, s);
+    }
     release_lut(lut, s);
     return rc;
 }
