@@ -79,10 +79,11 @@ __global__ __launch_bounds__(64) void k_sat_rows(DImg src, float *sat) { // sat:
     }
 }
 
-// Column pass: sat[r][c] += sat[r-1][c], a sequential chain down each column (coalesced across lanes). Rows are taken
-// 32 at a time with the following 32 already in flight, so the chain runs at add latency rather than memory latency.
+// Column pass: sat[r][c] += sat[r-1][c], a sequential chain down each column (coalesced across lanes). Only columns x
+// channels / 64 waves exist, so the achieved bandwidth is (bytes in flight) / latency: rows are taken 128 at a time with
+// the following 128 already in flight (32 rows: 177 us, 128 rows: 157 us per 4096^2 plane; scalar row addressing: 195 us).
 __global__ __launch_bounds__(64) void k_sat_cols(float *sat, int rows, int cols) {
-    constexpr int G = 32;
+    constexpr int G = 128;
     const int c = blockIdx.x * 64 + threadIdx.x;
     const int ch = blockIdx.y;
     if (c >= cols) return;
@@ -139,13 +140,59 @@ __global__ __launch_bounds__(256) void k_box_mean(const float *sat, DImg dst, in
     P::store(dst.data, (size_t)r * dst.stride + (size_t)c, o);
 }
 
+// Row pass for sources whose row sums are exact in f32 — integer-valued elements with cols * max < 2^24 (every u8 pixel type,
+// and the detectors' grey / mask planes): each partial sum is then an integer below 2^24, every association gives the
+// same bits as the reference's left-to-right loop, and the row becomes a parallel prefix sum (one workgroup per row and
+// channel, 1024 columns per step) at memory speed instead of a 4096-step chain (316 us -> see DESIGN.md).
+template <int PIX>
+__global__ __launch_bounds__(256) void k_sat_rows_exact(DImg src, float *sat) { // sat: [C][rows][cols]
+    using P = Px<PIX>;
+    using Elem = typename P::Elem;
+    constexpr int C = P::C;
+    __shared__ float wsum[4];
+    const int r = blockIdx.x, ch = blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const Elem *row = (const Elem *)src.data + (size_t)r * src.stride * C + ch;
+    float *out = sat + ((size_t)ch * src.rows + r) * src.cols;
+    float carry = 0.0f;
+    for (int c0 = 0; c0 < src.cols; c0 += 1024) {
+        const int c = c0 + 4 * t;
+        float p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] = (float)row[(size_t)min(c + k, src.cols - 1) * C]; // clamped, unpredicated
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (c + k >= src.cols) p[k] = 0.0f;
+        p[1] += p[0]; p[2] += p[1]; p[3] += p[2];
+        float x = p[3]; // inclusive scan of the per-thread totals across the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float y = __shfl_up(x, d);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        float base = carry + (x - p[3]);
+        if (w > 0) base += wsum[0];
+        if (w > 1) base += wsum[1];
+        if (w > 2) base += wsum[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (c + k < src.cols) out[c + k] = base + p[k];
+        carry += ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+        __syncthreads();
+    }
+}
+
 // Integral image(s) of `src` (Image(T).Integral.compute, integral.zig:95-140): one f32 plane of rows x cols per channel,
 // planar, in the reference's association order. Also used by the Shen-Castan detector (edges.hip).
-int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s) {
+// `integer_valued`: the caller knows every element is an integer in [0, 255] (always true for u8 pixels), which makes the
+// row sums exact and lets the row pass run as a parallel scan.
+int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer_valued) {
     const int C = pixel_channels(src->pixel);
+    const bool exact_rows = (integer_valued || !pixel_is_float(src->pixel)) && src->cols <= 65536; // 65536 * 255 < 2^24
     return dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
-        hipLaunchKernelGGL((k_sat_rows<PIX>), dim3(ceil_div(src->rows, 64), (unsigned)C), dim3(64), 0, s, dimg(src), sat);
+        if (exact_rows) hipLaunchKernelGGL((k_sat_rows_exact<PIX>), dim3(src->rows, (unsigned)C), dim3(256), 0, s, dimg(src), sat);
+        else hipLaunchKernelGGL((k_sat_rows<PIX>), dim3(ceil_div(src->rows, 64), (unsigned)C), dim3(64), 0, s, dimg(src), sat);
         hipLaunchKernelGGL(k_sat_cols, dim3(ceil_div(src->cols, 64), (unsigned)C), dim3(64), 0, s, sat, (int)src->rows, (int)src->cols);
         ZG_HIP(hipGetLastError());
         return ZG_OK;
@@ -164,14 +211,13 @@ static int box_blur_impl(const zg_image *src, const zg_image *dst, uint32_t radi
     const int C = pixel_channels(src->pixel);
     float *sat = nullptr;
     if ((rc = scratch_alloc((void **)&sat, (size_t)C * src->rows * src->cols * sizeof(float), s))) return rc;
-    rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
-        constexpr int PIX = decltype(tag)::value;
-        hipLaunchKernelGGL((k_sat_rows<PIX>), dim3(ceil_div(src->rows, 64), (unsigned)C), dim3(64), 0, s, dimg(src), sat);
-        hipLaunchKernelGGL(k_sat_cols, dim3(ceil_div(src->cols, 64), (unsigned)C), dim3(64), 0, s, sat, (int)src->rows, (int)src->cols);
-        hipLaunchKernelGGL((k_box_mean<PIX>), dim3(ceil_div(dst->cols, 256), dst->rows), dim3(256), 0, s, (const float *)sat, dimg(dst), (int)radius);
-        ZG_HIP(hipGetLastError());
-        return ZG_OK;
-    });
+    if ((rc = sat_planes_impl(src, sat, s, false)) == ZG_OK)
+        rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
+            constexpr int PIX = decltype(tag)::value;
+            hipLaunchKernelGGL((k_box_mean<PIX>), dim3(ceil_div(dst->cols, 256), dst->rows), dim3(256), 0, s, (const float *)sat, dimg(dst), (int)radius);
+            ZG_HIP(hipGetLastError());
+            return ZG_OK;
+        });
     scratch_free(sat, s);
     return rc;
 }

@@ -329,7 +329,7 @@ static int canny_impl(const zg_image *src, const zg_image *dst, float sigma, flo
 // latency-bound like boxBlur's SAT. The histogram, its percentile and the thresholds stay on the device (integer atomics
 // and a one-workgroup kernel), so nothing but the hysteresis fixed-point test synchronises the stream.
 
-int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s); // box_blur.hip
+int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer_valued); // box_blur.hip
 
 // Forward recursion along rows: temp[0] = b x[0]; temp[i] = b x[i] + a temp[i-1]. One wave per 64 rows, 64-column chunks
 // transposed through LDS (lanes = columns for the coalesced global side, lanes = rows for the chain).
@@ -390,36 +390,51 @@ __global__ __launch_bounds__(64) void k_isef_rows_bwd(const float *temp, float *
 // The same two recursions down / up the columns, in place on `data` with `temp` between them: one lane per column,
 // coalesced across lanes, sixteen rows loaded ahead of the chain.
 __global__ __launch_bounds__(64) void k_isef_cols(float *data, float *temp, int rows, int cols, float b) {
+    constexpr int G = 64; // rows per step, the next step's rows already in flight (bandwidth here = bytes in flight / latency)
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= cols) return;
     const float a = 1.0f - b;
     float run = 0.0f;
-    for (int r0 = 0; r0 < rows; r0 += 16) {
-        float v[16];
+    float v[G], w[G];
+    auto fetch = [&](const float *p, int r0, float (&x)[G]) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = data[(size_t)min(r0 + i, rows - 1) * cols + c];
+        for (int i = 0; i < G; ++i) x[i] = p[(size_t)min(max(r0 + i, 0), rows - 1) * cols + c]; // clamped, unpredicated
+    };
+    auto down = [&](int r0, float (&x)[G]) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < G; ++i) {
             if (r0 + i < rows) {
-                const float bx = b * v[i];
+                const float bx = b * x[i];
                 if (r0 + i == 0) run = bx;
                 else { const float ar = a * run; run = bx + ar; }
                 temp[(size_t)(r0 + i) * cols + c] = run;
             }
         }
+    };
+    fetch(data, 0, v);
+    for (int r0 = 0; r0 < rows; r0 += 2 * G) {
+        fetch(data, r0 + G, w);
+        down(r0, v);
+        fetch(data, r0 + 2 * G, v);
+        down(r0 + G, w);
     }
-    for (int r0 = (rows - 1) / 16 * 16; r0 >= 0; r0 -= 16) {
-        float v[16];
+    auto up = [&](int r0, float (&x)[G]) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = temp[(size_t)min(r0 + i, rows - 1) * cols + c];
-#pragma unroll
-        for (int i = 15; i >= 0; --i) {
-            if (r0 + i < rows) {
-                if (r0 + i == rows - 1) run = v[i];
-                else { const float bt = b * v[i], ar = a * run; run = bt + ar; }
+        for (int i = G - 1; i >= 0; --i) {
+            if (r0 + i < rows && r0 + i >= 0) {
+                if (r0 + i == rows - 1) run = x[i];
+                else { const float bt = b * x[i], ar = a * run; run = bt + ar; }
                 data[(size_t)(r0 + i) * cols + c] = run;
             }
         }
+    };
+    const int top = (rows - 1) / G * G; // first row of the last step
+    fetch(temp, top, v);
+    for (int r0 = top; r0 >= 0; r0 -= 2 * G) {
+        fetch(temp, r0 - G, w);
+        up(r0, v);
+        fetch(temp, r0 - 2 * G, v);
+        up(r0 - G, w);
     }
 }
 
@@ -585,7 +600,8 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
     }
     if (rc == ZG_OK) {
         const zg_image gi{gray, cols, rows, cols, ZG_PIXEL_F32}, mi{bli, cols, rows, cols, ZG_PIXEL_U8}, gmi{temp, cols, rows, cols, ZG_PIXEL_F32};
-        if ((rc = sat_planes_impl(&gi, sat_g, s)) == ZG_OK && (rc = sat_planes_impl(&mi, sat_m, s)) == ZG_OK) rc = sat_planes_impl(&gmi, sat_gm, s);
+        // grey is as(f32, u8), BLI is 0 / 1, grey * BLI is their product: integer-valued planes, exact row sums
+        if ((rc = sat_planes_impl(&gi, sat_g, s, true)) == ZG_OK && (rc = sat_planes_impl(&mi, sat_m, s, true)) == ZG_OK) rc = sat_planes_impl(&gmi, sat_gm, s, true);
     }
     if (rc == ZG_OK) {
         if (hipMemsetAsync(hist, 0, 256 * sizeof(unsigned int), s) != hipSuccess) rc = ZG_ERR_HIP;
