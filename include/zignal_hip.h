@@ -75,6 +75,12 @@ typedef enum zg_transform_kind { /* src/geometry/transforms.zig:10,118,197 */
     ZG_TRANSFORM_PROJECTIVE = 2  /* m = row-major 3x3                       */
 } zg_transform_kind;
 
+typedef enum zg_blending { /* src/blending.zig:8-22 */
+    ZG_BLEND_NONE = 0, ZG_BLEND_NORMAL = 1, ZG_BLEND_MULTIPLY = 2, ZG_BLEND_SCREEN = 3, ZG_BLEND_OVERLAY = 4, ZG_BLEND_SOFT_LIGHT = 5,
+    ZG_BLEND_HARD_LIGHT = 6, ZG_BLEND_COLOR_DODGE = 7, ZG_BLEND_COLOR_BURN = 8, ZG_BLEND_DARKEN = 9, ZG_BLEND_LIGHTEN = 10,
+    ZG_BLEND_DIFFERENCE = 11, ZG_BLEND_EXCLUSION = 12
+} zg_blending;
+
 typedef enum zg_colorspace { /* src/color.zig ColorSpace (the ordinals are this library's, not Zig's) */
     ZG_CS_GRAY = 0,  /* Image(u8) / Image(f32) scalars */
     ZG_CS_RGB = 1,
