@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Randomised GPU-vs-oracle parity sweep: random shapes (biased to tile seams), pixel types, parameters, views.
-usage: python tools/fuzz_parity.py [seconds] [seed]   — exits non-zero on the first mismatch, printing the case."""
+usage: python tools/fuzz_parity.py [seconds] [seed] [max_rows max_cols]   — exits non-zero on the first mismatch, printing the case."""
 import math
 import sys
 import time
@@ -13,7 +13,9 @@ import zignal_amd as zg
 from oracle import pyoracle as o
 
 KINDS = ("u8", "f32", "rgb_u8", "rgba_u8", "rgb_f32", "rgba_f32")
-SEAMS = (1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 272, 352, 511, 512, 513, 1023, 1024, 1025, 1040)
+SEAMS = (1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 272, 352, 511, 512, 513, 1023, 1024, 1025, 1040,
+         2047, 2048, 2049, 2064, 4095, 4096, 4097, 4112)
+MAX_ROWS, MAX_COLS = 300, 1100  # overridden by argv[3], argv[4]
 
 
 def synth(rng, kind, rows, cols):
@@ -39,7 +41,7 @@ def same(a, b):
 def case(rng):
     kind = str(rng.choice(KINDS))
     op = str(rng.choice(["blur", "sep", "conv2d", "box", "resize", "warp", "rotate", "convert", "sobel", "canny", "shen", "motion", "insert_flip"]))
-    rows, cols = dim(rng, 300), dim(rng, 1100)
+    rows, cols = dim(rng, MAX_ROWS), dim(rng, MAX_COLS)
     img = synth(rng, kind, rows, cols)
     border = int(rng.integers(0, 4))
     I = zg.Interpolation
@@ -110,8 +112,11 @@ def case(rng):
 
 
 def main():
+    global MAX_ROWS, MAX_COLS
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+    if len(sys.argv) > 4:
+        MAX_ROWS, MAX_COLS = int(sys.argv[3]), int(sys.argv[4])
     rng = np.random.default_rng(seed)
     t0, n, by_op = time.time(), 0, {}
     while time.time() - t0 < budget:
