@@ -33,6 +33,16 @@ def dev(a):
     return zg.Image(torch.from_numpy(np.ascontiguousarray(a)).cuda())
 
 
+def dev_view(rng, a):
+    """The same pixels as a view into a larger device frame (stride > cols, arbitrary — possibly unaligned — origin)."""
+    rows, cols = a.shape[:2]
+    top, left, bottom, right = (int(rng.integers(0, 6)) for _ in range(4))
+    big = np.zeros((rows + top + bottom, cols + left + right) + a.shape[2:], a.dtype)
+    big[...] = 123 if a.dtype == np.uint8 else 0.5
+    big[top:top + rows, left:left + cols] = a
+    return zg.Image(torch.from_numpy(big).cuda()).view((left, top, left + cols, top + rows))
+
+
 def same(a, b):
     a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
     return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
@@ -40,15 +50,17 @@ def same(a, b):
 
 def case(rng):
     kind = str(rng.choice(KINDS))
-    op = str(rng.choice(["blur", "sep", "conv2d", "box", "resize", "warp", "rotate", "convert", "sobel", "canny", "shen", "motion", "insert_flip"]))
+    op = str(rng.choice(["blur", "sep", "conv2d", "box", "resize", "warp", "rotate", "convert", "sobel", "canny", "shen", "motion", "insert_flip", "letterbox_extract"]))
     rows, cols = dim(rng, MAX_ROWS), dim(rng, MAX_COLS)
     img = synth(rng, kind, rows, cols)
     border = int(rng.integers(0, 4))
+    use_view = rng.random() < 0.3
+    D = (lambda a: dev_view(rng, a)) if use_view else dev
     I = zg.Interpolation
     methods = [(I.nearest, o.NEAREST), (I.bilinear, o.BILINEAR), (I.bicubic, o.BICUBIC), (I.catmull_rom, o.CATMULL_ROM), (I.lanczos, o.LANCZOS)]
     if op == "blur":
         sigma = float(rng.choice([0.3, 0.6, 1.0, 1.4, 2.25, 3.3, 5.5]))
-        return f"blur {kind} {rows}x{cols} sigma={sigma}", dev(img).gaussian_blur(sigma), o.gaussian_blur(img, sigma)
+        return f"blur {kind} {rows}x{cols} sigma={sigma}", D(img).gaussian_blur(sigma), o.gaussian_blur(img, sigma)
     if op == "sep":
         nx, ny = int(rng.integers(1, 40)), int(rng.integers(1, 40))
         if rng.random() < 0.5:  # non-negative, normalised (the packed u8 paths)
@@ -56,18 +68,18 @@ def case(rng):
             ky = rng.random(ny).astype(np.float32); ky /= ky.sum()
         else:
             kx = (rng.random(nx).astype(np.float32) - np.float32(0.3)); ky = (rng.random(ny).astype(np.float32) - np.float32(0.3))
-        return f"sep {kind} {rows}x{cols} n=({nx},{ny}) b={border}", dev(img).convolve_separable(kx, ky, border), o.conv_separable(img, kx, ky, border)
+        return f"sep {kind} {rows}x{cols} n=({nx},{ny}) b={border}", D(img).convolve_separable(kx, ky, border), o.conv_separable(img, kx, ky, border)
     if op == "conv2d":
         kh, kw = int(rng.integers(1, 10)), int(rng.integers(1, 10))
         k = (rng.random((kh, kw)).astype(np.float32) - np.float32(0.3)) / np.float32(kh * kw * 0.3)
-        return f"conv2d {kind} {rows}x{cols} {kh}x{kw} b={border}", dev(img).convolve(k, border), o.convolve(img, k, border)
+        return f"conv2d {kind} {rows}x{cols} {kh}x{kw} b={border}", D(img).convolve(k, border), o.convolve(img, k, border)
     if op == "box":
         rad = int(rng.integers(0, 9))
-        return f"box {kind} {rows}x{cols} r={rad}", dev(img).box_blur(rad), o.box_blur(img, rad)
+        return f"box {kind} {rows}x{cols} r={rad}", D(img).box_blur(rad), o.box_blur(img, rad)
     if op == "resize":
         m, om = methods[int(rng.integers(0, len(methods)))]
         dr, dc = dim(rng, 200), dim(rng, 600)
-        return f"resize {kind} {rows}x{cols}->{dr}x{dc} {om}", dev(img).resize((dr, dc), m), o.resize(img, (dr, dc), o.method(om))
+        return f"resize {kind} {rows}x{cols}->{dr}x{dc} {om}", D(img).resize((dr, dc), m), o.resize(img, (dr, dc), o.method(om))
     if op == "warp":
         m, om = methods[int(rng.integers(0, 3))]
         pts = [(0, 0), (cols - 1, 0), (0, rows - 1), (cols - 1, rows - 1)]
@@ -75,39 +87,72 @@ def case(rng):
         if rows < 2 or cols < 2:
             return None
         h = o.homography_from_4pts(pts, to)
-        return (f"warp {kind} {rows}x{cols} {om}", dev(img).warp(zg.ProjectiveTransform(h), (rows, cols), m),
+        return (f"warp {kind} {rows}x{cols} {om}", D(img).warp(zg.ProjectiveTransform(h), (rows, cols), m),
                 o.warp(img, (rows, cols), o.PROJECTIVE, h, o.method(om)))
     if op == "rotate":
         m, om = methods[int(rng.integers(0, 3))]
         ang = float(rng.choice([0.0, math.pi / 2, math.pi, 0.3, -1.2, 2.5]))
         cs = o.cos_sin(ang)  # both sides get the same @cos / @sin values (a Zig caller passes Zig's)
-        return f"rotate {kind} {rows}x{cols} a={ang} {om}", dev(img).rotate(ang, m, border, cos_sin=cs), o.rotate(img, ang, o.method(om), border)
+        return f"rotate {kind} {rows}x{cols} a={ang} {om}", D(img).rotate(ang, m, border, cos_sin=cs), o.rotate(img, ang, o.method(om), border)
     if op == "convert":
         if kind in ("u8", "f32"):
             return None
         spaces = ["OKLAB", "XYZ", "LAB", "LCH", "OKLCH", "XYB", "HSL", "HSV", "LMS", "YCBCR"]
         sp = getattr(zg, "CS_" + str(rng.choice(spaces)))
         ss = zg.CS_RGBA if kind.startswith("rgba") else zg.CS_RGB
-        return f"convert {kind} -> {sp}", dev(img).convert(sp, np.float32), o.convert(img, ss, sp, np.float32, 3)
+        return f"convert {kind} -> {sp}", D(img).convert(sp, np.float32), o.convert(img, ss, sp, np.float32, 3)
     if op == "sobel":
-        return f"sobel {kind} {rows}x{cols}", dev(img).sobel(), o.sobel(img)
+        return f"sobel {kind} {rows}x{cols}", D(img).sobel(), o.sobel(img)
     if op == "canny":
         sg = float(rng.choice([0.0, 1.0, 1.4])); lo = float(rng.uniform(1, 40)); hi = lo + float(rng.uniform(1, 80))
-        return f"canny {kind} {rows}x{cols} {sg} {lo} {hi}", dev(img).canny(sg, lo, hi), o.canny(img, sg, lo, hi)
+        return f"canny {kind} {rows}x{cols} {sg} {lo} {hi}", D(img).canny(sg, lo, hi), o.canny(img, sg, lo, hi)
     if op == "shen":
         kw = dict(smooth=float(rng.uniform(0.5, 0.95)), window_size=int(rng.choice([3, 5, 7, 11])), high_ratio=float(rng.uniform(0.5, 0.99)),
                   low_rel=float(rng.uniform(0.1, 0.9)), hysteresis=bool(rng.integers(0, 2)), use_nms=bool(rng.integers(0, 2)))
-        return f"shen {kind} {rows}x{cols} {kw}", dev(img).shen_castan(**kw), o.shen_castan(img, **kw)
+        return f"shen {kind} {rows}x{cols} {kw}", D(img).shen_castan(**kw), o.shen_castan(img, **kw)
     if op == "motion":
         if rng.random() < 0.5:
             ang, d = float(rng.choice([0.0, math.pi / 2, 0.4, 2.2, -0.9])), int(rng.integers(0, 25))
-            return f"motion linear {kind} {rows}x{cols} {ang} {d}", dev(img).motion_blur_linear(ang, d), o.motion_blur_linear(img, ang, d)
+            return f"motion linear {kind} {rows}x{cols} {ang} {d}", D(img).motion_blur_linear(ang, d), o.motion_blur_linear(img, ang, d)
         cx, cy, st, spin = float(rng.uniform(-0.2, 1.2)), float(rng.uniform(-0.2, 1.2)), float(rng.uniform(0, 1.3)), bool(rng.integers(0, 2))
-        return f"motion radial {kind} {rows}x{cols} {cx} {cy} {st} {spin}", dev(img).motion_blur_radial(cx, cy, st, spin), o.motion_blur_radial(img, cx, cy, st, spin)
+        return f"motion radial {kind} {rows}x{cols} {cx} {cy} {st} {spin}", D(img).motion_blur_radial(cx, cy, st, spin), o.motion_blur_radial(img, cx, cy, st, spin)
     if op == "insert_flip":
-        d = dev(img.copy())
-        d.flip_left_right()
-        return f"flip_lr {kind} {rows}x{cols}", d, img[:, ::-1]
+        if rng.random() < 0.3:
+            d = dev(img.copy())
+            d.flip_left_right()
+            return f"flip_lr {kind} {rows}x{cols}", d, img[:, ::-1]
+        skind = str(rng.choice(KINDS))
+        source = synth(rng, skind, dim(rng, 80), dim(rng, 120))
+        m, om = methods[int(rng.integers(0, 3))]
+        ang = float(rng.choice([0.0, 0.0, 0.35, -1.1]))
+        l, t = float(rng.uniform(-20, cols)), float(rng.uniform(-20, rows))
+        if ang == 0.0 and rng.random() < 0.5:
+            rect = (round(l), round(t), round(l) + source.shape[1], round(t) + source.shape[0])  # the 1:1 fast path
+        else:
+            rect = (l, t, l + float(rng.uniform(2, 150)), t + float(rng.uniform(2, 100)))
+        blend = int(rng.integers(0, 13))
+        cs = o.cos_sin(ang)
+        want = o.insert(img.copy(), source, rect, ang, o.method(om), blend)
+        got = D(img.copy()).insert(dev(source), rect, ang, m, blend, cos_sin=cs)
+        return f"insert {skind}->{kind} {rows}x{cols} rect={rect} a={ang} blend={blend} view={use_view}", got, want
+    if op == "letterbox_extract":
+        m, om = methods[int(rng.integers(0, 3))]
+        if rng.random() < 0.5:
+            dr, dc = dim(rng, 200), dim(rng, 300)
+            want = np.zeros((dr, dc) + img.shape[2:], img.dtype)
+            wrect = o.letterbox(img, want, o.method(om))
+            got, grect = D(img).letterbox((dr, dc), m)
+            assert tuple(grect) == tuple(wrect), f"letterbox rect {grect} != {wrect}"
+            return f"letterbox {kind} {rows}x{cols}->{dr}x{dc}", got, want
+        dr, dc = dim(rng, 120), dim(rng, 160)
+        ang = float(rng.choice([0.0, 0.5, -2.0]))
+        rect = (float(rng.uniform(-10, cols)), float(rng.uniform(-10, rows)), float(rng.uniform(0, cols + 20)), float(rng.uniform(0, rows + 20)))
+        rect = (min(rect[0], rect[2]), min(rect[1], rect[3]), max(rect[0], rect[2]) + 1, max(rect[1], rect[3]) + 1)
+        cs = o.cos_sin(ang)
+        out = np.empty((dr, dc) + img.shape[2:], img.dtype)
+        want = o.extract(img, out, rect, ang, o.method(om), border)
+        got = D(img).extract(rect, ang, (dr, dc), m, border, cos_sin=cs)
+        return f"extract {kind} {rows}x{cols} rect={rect} a={ang}", got, want
     return None
 
 
