@@ -288,6 +288,9 @@ ZG_API int zg_motion_blur_radial_host(const zg_image *src, const zg_image *dst, 
 ZG_API float zg_pyramid_scale(float scale_factor, uint32_t level);
 ZG_API int zg_pyramid_level(uint32_t rows, uint32_t cols, float scale, float blur_sigma,
                             uint32_t *out_rows, uint32_t *out_cols, float *out_sigma);
+/* One level in one call (pyramid.zig:76-92): gaussianBlur(source, sigma) when sigma > 0.5 (scratch inside), then
+ * resize(.bilinear) into `level` (pre-allocated with zg_pyramid_level's dimensions). Device pointers. */
+ZG_API int zg_pyramid_build_level(const zg_image *source, const zg_image *level, float sigma, zg_stream stream);
 
 /* ---- batch (config: N frames, gaussianBlur(sigma) then bilinear resize) ----------------- */
 

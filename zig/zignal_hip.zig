@@ -35,6 +35,8 @@ pub const c = struct {
     pub extern fn zg_insert_host(self: *const ZgImage, source: *const ZgImage, rect: *const [4]f32, angle: f32, cos_a: f32, sin_a: f32, method: *const ZgMethod, blend_mode: c_int) c_int;
     pub extern fn zg_flip_left_right_host(img: *const ZgImage) c_int;
     pub extern fn zg_flip_top_bottom_host(img: *const ZgImage) c_int;
+    /// ImagePyramid.build's loop body (src/image/pyramid.zig:76-92) for device-resident images: blur when sigma > 0.5, then bilinear resize
+    pub extern fn zg_pyramid_build_level(source: *const ZgImage, level: *const ZgImage, sigma: f32, stream: ?*anyopaque) c_int;
     pub extern fn zg_sobel_host(src: *const ZgImage, dst: *const ZgImage) c_int;
     pub extern fn zg_motion_blur_linear_host(src: *const ZgImage, dst: *const ZgImage, angle: f32, cos_a: f32, sin_a: f32, distance: u32) c_int;
     pub extern fn zg_motion_blur_radial_host(src: *const ZgImage, dst: *const ZgImage, center_x: f32, center_y: f32, strength: f32, spin: c_int) c_int;

@@ -111,6 +111,7 @@ _SIGNATURES = {
     "zg_motion_blur_radial": [_IMG, _IMG, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p],
     "zg_motion_blur_radial_host": [_IMG, _IMG, C.c_float, C.c_float, C.c_float, C.c_int],
     "zg_pyramid_scale": [C.c_float, C.c_uint32],
+    "zg_pyramid_build_level": [_IMG, _IMG, C.c_float, C.c_void_p],
     "zg_pyramid_level": [C.c_uint32, C.c_uint32, C.c_float, C.c_float, _U32P, _U32P, _F32P],
     "zg_batch_blur_resize": [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_float,
                              C.c_void_p, C.c_uint32, C.c_uint32, _METHOD, C.c_void_p],

@@ -677,6 +677,24 @@ int zg_shen_castan_host(const zg_image *src, const zg_image *dst, float smooth, 
 // CALLER's maths library computes it (a Zig host passes std.math.pow's value); zg_pyramid_scale is the library's own.
 float zg_pyramid_scale(float scale_factor, uint32_t level) { return hostmath::pow_f32(scale_factor, (float)level); }
 
+// One level of ImagePyramid.build (pyramid.zig:76-92) in a single call: blur the ORIGINAL with `sigma` when sigma > 0.5
+// (library scratch holds the blurred copy), then bilinear resize into `level`. `sigma` is zg_pyramid_level's output.
+int zg_pyramid_build_level(const zg_image *source, const zg_image *level, float sigma, zg_stream stream) {
+    int rc;
+    if ((rc = check_image(source, "source")) || (rc = check_image(level, "level"))) return rc;
+    ZG_REQUIRE(source->pixel == level->pixel, ZG_ERR_INVALID_ARGUMENT, "pyramid level: pixel types differ");
+    const zg_method bilinear{ZG_INTERP_BILINEAR, 0.0f, 0.0f, nullptr};
+    if (!(sigma > 0.5f) || source->rows == 0 || source->cols == 0) return zg_resize(source, level, &bilinear, stream);
+    hipStream_t s = as_stream(stream);
+    void *blurred = nullptr;
+    if ((rc = scratch_alloc(&blurred, (size_t)source->rows * source->cols * pixel_size(source->pixel), s))) return rc;
+    const zg_image tmp{blurred, source->cols, source->rows, source->cols, source->pixel};
+    rc = zg_gaussian_blur(source, &tmp, sigma, stream);
+    if (rc == ZG_OK) rc = zg_resize(&tmp, level, &bilinear, stream);
+    scratch_free(blurred, s);
+    return rc;
+}
+
 int zg_pyramid_level(uint32_t rows, uint32_t cols, float scale, float blur_sigma, uint32_t *out_rows, uint32_t *out_cols, float *out_sigma) {
     ZG_REQUIRE(out_rows && out_cols && out_sigma, ZG_ERR_INVALID_ARGUMENT, "pyramid level: null output");
     ZG_REQUIRE(scale > 0, ZG_ERR_INVALID_ARGUMENT, "pyramid level: scale must be positive");

@@ -479,8 +479,14 @@ class ImagePyramid:
                                          C.byref(r), C.byref(c), C.byref(sigma)))
             if r.value < 8 or c.value < 8:
                 break
-            base = source.gaussian_blur(sigma.value) if sigma.value > 0.5 else source
-            levels.append(base.resize((r.value, c.value), Interpolation.bilinear))
+            if source.on_device:  # one C call per level: blur (library scratch) + bilinear resize
+                lvl = source._like(r.value, c.value)
+                sd, ld = source._desc(), lvl._desc()
+                L.check(lib.zg_pyramid_build_level(C.byref(sd), C.byref(ld), C.c_float(sigma.value), source._stream()))
+                levels.append(lvl)
+            else:
+                base = source.gaussian_blur(sigma.value) if sigma.value > 0.5 else source
+                levels.append(base.resize((r.value, c.value), Interpolation.bilinear))
         return ImagePyramid(levels, scale_factor, blur_sigma)
 
     @staticmethod
