@@ -256,6 +256,20 @@ ZG_API int zg_convert_host(const zg_image *src, int src_space, const zg_image *d
 ZG_API int zg_sobel(const zg_image *src, const zg_image *dst, zg_stream stream);
 ZG_API int zg_sobel_host(const zg_image *src, const zg_image *dst);
 
+/* Image(T).sharpen (src/image.zig:785-801 -> Integral.sharpen, src/image/integral.zig:273-426): 2 * original - boxBlur
+ * with the same integral image; radius 0 copies. */
+ZG_API int zg_sharpen(const zg_image *src, const zg_image *dst, uint32_t radius, zg_stream stream);
+ZG_API int zg_sharpen_host(const zg_image *src, const zg_image *dst, uint32_t radius);
+/* Image(T).integral (src/image.zig:628-630 -> Integral.compute, integral.zig:95-140): one f32 summed-area plane of
+ * rows x cols per channel, channel-major in `planes` (channels * rows * cols floats, packed), in the reference's
+ * summation order. */
+ZG_API int zg_integral(const zg_image *src, float *planes, zg_stream stream);
+ZG_API int zg_integral_host(const zg_image *src, float *planes);
+/* Image(T).invert (src/image.zig:494-513), in place: 255 - v / 1 - v per colour channel, alpha kept; Image(f32) is
+ * rejected as in the reference (ZG_ERR_UNSUPPORTED). */
+ZG_API int zg_invert(const zg_image *img, zg_stream stream);
+ZG_API int zg_invert_host(const zg_image *img);
+
 /* Image(T).canny (src/image.zig:1047-1063 -> src/image/edges.zig:212-277): grey -> the detector's own Gaussian
  * (.replicate; sigma == 0 skips it) -> Sobel gradients -> non-maximum suppression -> double threshold + hysteresis.
  * dst is Image(u8), 0 or 255. error.InvalidParameter / InvalidSigma / InvalidThreshold -> ZG_ERR_INVALID_ARGUMENT.

@@ -274,6 +274,27 @@ def insert(self_img, source, rect, angle, m: ZoMethod, blend_mode=0):
     return self_img
 
 
+def sharpen(src, radius):
+    out = np.empty_like(src)
+    s, d = as_image(src), as_image(out)
+    _check(lib().zo_sharpen(C.byref(s), C.byref(d), C.c_uint32(radius)), "sharpen")
+    return out
+
+
+def integral(src):
+    ch = 1 if src.ndim == 2 else src.shape[2]
+    planes = np.empty((ch,) + src.shape[:2], np.float32)
+    s = as_image(src)
+    _check(lib().zo_integral(C.byref(s), planes.ctypes.data_as(C.POINTER(C.c_float))), "integral")
+    return planes
+
+
+def invert(img):
+    s = as_image(img)
+    _check(lib().zo_invert(C.byref(s)), "invert")
+    return img
+
+
 def blend_rgba_u8(base, overlay, mode: int):
     """Rgba(u8).blend(overlay, mode) (blending.zig:27-157)."""
     b = (C.c_uint8 * 4)(*[int(v) for v in base]); ov = (C.c_uint8 * 4)(*[int(v) for v in overlay])

@@ -77,6 +77,9 @@ ZO_API int zo_convolve(const zo_image *src, const zo_image *dst, const float *ke
 /* integral.c */
 ZO_API int zo_integral_plane_f32(const float *src, size_t src_stride, float *sat, uint32_t rows, uint32_t cols);
 ZO_API int zo_box_blur(const zo_image *src, const zo_image *dst, uint32_t radius);
+ZO_API int zo_sharpen(const zo_image *src, const zo_image *dst, uint32_t radius);
+ZO_API int zo_integral(const zo_image *src, float *planes);
+ZO_API int zo_invert(const zo_image *img);
 
 /* interp.c */
 typedef struct zo_method { int32_t kind; float b, c; const float *lanczos_lut; } zo_method;

@@ -258,6 +258,31 @@ def test_convolve_parity(oracle, kind):
     assert_bits_equal(sync(dev(src).convolve(big, 1)), oracle.convolve(src, big, 1), f"conv2d wide {kind}")
 
 
+@pytest.mark.parametrize("kind", ALL_TYPES)
+def test_sharpen_integral_invert_parity(oracle, kind):
+    for (rows, cols) in ((1, 1), (5, 5), (37, 53), (70, 1100)):
+        img = synth(oracle, kind, 61, rows, cols)
+        for radius in (0, 1, 3, 40):
+            assert_bits_equal(sync(dev(img).sharpen(radius)), oracle.sharpen(img, radius), f"sharpen {kind} {rows}x{cols} r={radius}")
+        got = dev(img).integral()
+        torch.cuda.synchronize()
+        assert_bits_equal(got.cpu().numpy(), oracle.integral(img), f"integral {kind} {rows}x{cols}")
+        if kind != "f32":
+            assert_bits_equal(sync(dev(img.copy()).invert()), oracle.invert(img.copy()), f"invert {kind} {rows}x{cols}")
+    host = synth(oracle, kind, 62, 9, 17)
+    assert_bits_equal(zg.Image(host).sharpen(2).data, oracle.sharpen(host, 2), "sharpen host layer")
+    assert_bits_equal(zg.Image(host).integral(), oracle.integral(host), "integral host layer")
+    if kind == "f32":
+        with pytest.raises(zg.ZignalError):
+            zg.Image(host.copy()).invert()
+    else:
+        assert_bits_equal(zg.Image(host.copy()).invert().data, oracle.invert(host.copy()), "invert host layer")
+    # a view: stride != cols on the source side
+    base = synth(oracle, kind, 63, 40, 60)
+    v = zg.Image(torch.from_numpy(base).cuda()).view((5, 3, 45, 33))
+    assert_bits_equal(sync(v.sharpen(2)), oracle.sharpen(np.ascontiguousarray(base[3:33, 5:45]), 2), "sharpen view")
+
+
 def test_convolve_known_answers():  # tests/filters.zig:370-398, 571-600, 701-744, 1302-1342
     ident = [[0, 0, 0], [0, 1, 0], [0, 0, 0]]
     img = (np.arange(9, dtype=np.uint8) + 10).reshape(3, 3)

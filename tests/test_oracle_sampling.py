@@ -386,3 +386,27 @@ def test_blend_modes_known_answers(oracle):
     assert B((100, 200, 100, 255), (200, 100, 100, 255), DARKEN)[:3] == (100, 100, 100)  # :391-398
     assert B((100, 200, 100, 255), (200, 100, 100, 255), LIGHTEN)[:3] == (200, 200, 100)  # :400-407
     assert B((200, 100, 50, 255), (50, 200, 200, 255), DIFF)[:3] == (150, 100, 150)  # :409-416
+
+
+# ---- tests/filters.zig:16-52 (invert), :277-370 (sharpen); tests/integral.zig:11-68 ------------------------------------
+def test_invert_sharpen_integral_known_answers(oracle):
+    g = np.array([[0, 255], [100, 128]], np.uint8)
+    assert oracle.invert(g.copy()).tolist() == [[255, 0], [155, 127]]
+    assert oracle.invert(np.array([[[0, 128, 255]]], np.uint8)).tolist() == [[[255, 127, 0]]]
+    assert oracle.invert(np.array([[[0, 128, 255, 64]]], np.uint8)).tolist() == [[[255, 127, 0, 64]]]  # alpha kept
+    edge = np.where(np.arange(5)[None, :] < 2, 64, 192).astype(np.uint8).repeat(5, 0).reshape(5, 5)
+    sh = oracle.sharpen(edge, 1)
+    assert sh[2, 0] <= 64 and sh[2, 4] >= 192
+    pat = (np.arange(9) + 10).astype(np.uint8).reshape(3, 3)
+    assert (oracle.sharpen(pat, 0) == pat).all()
+    assert (oracle.sharpen(np.full((4, 4), 100, np.uint8), 1) == 100).all()
+    rgba = np.full((3, 3, 4), (64, 64, 64, 255), np.uint8)
+    rgba[1, 1] = (192, 192, 192, 255)
+    assert (oracle.sharpen(rgba, 1)[1, 1, :3] >= 192).all()
+    ones = np.ones((21, 13), np.uint8)
+    want = (np.arange(1, 22)[:, None] * np.arange(1, 14)[None, :]).astype(np.float32)
+    assert (oracle.integral(ones)[0] == want).all()
+    big = np.ones((25, 20), np.uint8)
+    assert (oracle.integral(np.ascontiguousarray(big[3:10, 2:8]))[0] == (np.arange(1, 8)[:, None] * np.arange(1, 7)[None, :])).all()
+    planes = oracle.integral(np.ones((21, 13, 4), np.uint8))
+    assert planes.shape == (4, 21, 13) and all((planes[ch] == want).all() for ch in range(4))

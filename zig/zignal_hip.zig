@@ -37,6 +37,9 @@ pub const c = struct {
     pub extern fn zg_flip_top_bottom_host(img: *const ZgImage) c_int;
     /// ImagePyramid.build's loop body (src/image/pyramid.zig:76-92) for device-resident images: blur when sigma > 0.5, then bilinear resize
     pub extern fn zg_pyramid_build_level(source: *const ZgImage, level: *const ZgImage, sigma: f32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_sharpen_host(src: *const ZgImage, dst: *const ZgImage, radius: u32) c_int;
+    pub extern fn zg_integral_host(src: *const ZgImage, planes: [*]f32) c_int;
+    pub extern fn zg_invert_host(img: *const ZgImage) c_int;
     pub extern fn zg_sobel_host(src: *const ZgImage, dst: *const ZgImage) c_int;
     pub extern fn zg_motion_blur_linear_host(src: *const ZgImage, dst: *const ZgImage, angle: f32, cos_a: f32, sin_a: f32, distance: u32) c_int;
     pub extern fn zg_motion_blur_radial_host(src: *const ZgImage, dst: *const ZgImage, center_x: f32, center_y: f32, strength: f32, spin: c_int) c_int;
@@ -143,6 +146,19 @@ pub fn Image(comptime T: type) type {
             _ = allocator;
             if (!self.base.hasSameShape(out.base)) return error.DimensionMismatch;
             try check(c.zg_box_blur_host(&desc(self.base), &desc(out.base), radius));
+        }
+
+        /// reference src/image.zig:785-801
+        pub fn sharpen(self: Self, out: Self, allocator: std.mem.Allocator, radius: usize) !void {
+            _ = allocator;
+            if (!self.base.hasSameShape(out.base)) return error.DimensionMismatch;
+            try check(c.zg_sharpen_host(&desc(self.base), &desc(out.base), @intCast(radius)));
+        }
+
+        /// reference src/image.zig:494-513 (in place; Image(f32) is a compile error there and stays one here)
+        pub fn invert(self: Self) void {
+            if (T == f32) @compileError("invert() requires pixel types with an invert() method or u8 grayscale pixels");
+            check(c.zg_invert_host(&desc(self.base))) catch unreachable;
         }
 
         /// reference src/image.zig:1001-1010 (fused grey -> Sobel x/y -> magnitude on the device)

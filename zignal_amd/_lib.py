@@ -100,6 +100,12 @@ _SIGNATURES = {
     "zg_set_border": [_IMG, _U32P, C.c_void_p, C.c_void_p],
     "zg_convert": [_IMG, C.c_int, _IMG, C.c_int, _F32P, C.c_void_p],
     "zg_convert_host": [_IMG, C.c_int, _IMG, C.c_int, _F32P],
+    "zg_sharpen": [_IMG, _IMG, C.c_uint32, C.c_void_p],
+    "zg_sharpen_host": [_IMG, _IMG, C.c_uint32],
+    "zg_integral": [_IMG, _F32P, C.c_void_p],
+    "zg_integral_host": [_IMG, _F32P],
+    "zg_invert": [_IMG, C.c_void_p],
+    "zg_invert_host": [_IMG],
     "zg_sobel": [_IMG, _IMG, C.c_void_p],
     "zg_sobel_host": [_IMG, _IMG],
     "zg_canny": [_IMG, _IMG, C.c_float, C.c_float, C.c_float, C.c_void_p],

@@ -111,6 +111,12 @@ template <typename T> class Image {
         const zg_image s = desc(), d = out.desc();
         check(zg_box_blur_host(&s, &d, radius));
     }
+    void sharpen(const Image &out, uint32_t radius) const {                               // image.zig:785
+        if (!hasSameShape(out)) throw DimensionMismatch(1, "sharpen");
+        const zg_image s = desc(), d = out.desc();
+        check(zg_sharpen_host(&s, &d, radius));
+    }
+    void invert() const { const zg_image s = desc(); check(zg_invert_host(&s)); }        // image.zig:494 (in place)
     Image<uint8_t> sobel() const {                                                       // image.zig:1001 (out allocated here)
         auto out = Image<uint8_t>::init(rows, cols);
         const zg_image s = desc(), d = out.desc();

@@ -113,8 +113,9 @@ __global__ __launch_bounds__(64) void k_sat_cols(float *sat, int rows, int cols)
     }
 }
 
-template <int PIX>
-__global__ __launch_bounds__(256) void k_box_mean(const float *sat, DImg dst, int radius) {
+// SHARPEN: Integral.sharpen (integral.zig:273-323, 325-426): 2 * original - blurred instead of the mean itself.
+template <int PIX, bool SHARPEN>
+__global__ __launch_bounds__(256) void k_box_mean(const float *sat, DImg src, DImg dst, int radius) {
     using P = Px<PIX>;
     using Vec = typename P::Vec;
     constexpr int C = P::C;
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(256) void k_box_mean(const float *sat, DImg dst, in
     const int r1 = max(r - radius, 0), r2 = (int)min((long long)r + radius, (long long)rows - 1);
     const int c1 = max(c - radius, 0), c2 = (int)min((long long)c + radius, (long long)cols - 1);
     const float area = (float)((long long)(r2 - r1 + 1) * (long long)(c2 - c1 + 1));
-    Vec o;
+    Vec o, orig = P::zero();
+    if constexpr (SHARPEN) orig = P::load(src.data, (size_t)r * src.stride + (size_t)c);
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) {
         const float *s = sat + (size_t)ch * rows * cols;
@@ -133,7 +135,12 @@ __global__ __launch_bounds__(256) void k_box_mean(const float *sat, DImg dst, in
         const float d = r1 > 0 ? s[(size_t)(r1 - 1) * cols + c2] : 0.0f;
         const float e = (r1 > 0 && c1 > 0) ? s[(size_t)(r1 - 1) * cols + (c1 - 1)] : 0.0f;
         const float sum = a - b - d + e; // ((a - b) - d) + e, integral.zig:87-90
-        const float val = sum / area;
+        float val = sum / area;
+        if constexpr (SHARPEN) {
+            const float original = (float)orig[ch];
+            const float twice = 2 * original;
+            val = twice - val;
+        }
         if constexpr (std::is_same<typename P::Elem, float>::value) o[ch] = val;
         else o[ch] = clamp_u8_f32(val);
     }
@@ -199,12 +206,12 @@ int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer
     });
 }
 
-static int box_blur_impl(const zg_image *src, const zg_image *dst, uint32_t radius, hipStream_t s) {
+static int box_blur_impl(const zg_image *src, const zg_image *dst, uint32_t radius, bool sharpen, hipStream_t s) {
     int rc;
     if ((rc = check_image(src, "src")) || (rc = check_image(dst, "dst"))) return rc;
-    ZG_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, ZG_ERR_DIMENSION_MISMATCH, "boxBlur: %ux%u vs %ux%u",
+    ZG_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, ZG_ERR_DIMENSION_MISMATCH, "%s: %ux%u vs %ux%u", sharpen ? "sharpen" : "boxBlur",
                src->rows, src->cols, dst->rows, dst->cols);
-    ZG_REQUIRE(src->pixel == dst->pixel, ZG_ERR_INVALID_ARGUMENT, "boxBlur: pixel types differ");
+    ZG_REQUIRE(src->pixel == dst->pixel, ZG_ERR_INVALID_ARGUMENT, "boxBlur / sharpen: pixel types differ");
     if (radius == 0) return copy_impl(src, dst, s); // image.zig:639-642
     if (src->rows == 0 || src->cols == 0) return ZG_OK;
     ZG_REQUIRE(radius < (1u << 30), ZG_ERR_INVALID_ARGUMENT, "boxBlur: radius too large");
@@ -214,7 +221,8 @@ static int box_blur_impl(const zg_image *src, const zg_image *dst, uint32_t radi
     if ((rc = sat_planes_impl(src, sat, s, false)) == ZG_OK)
         rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
             constexpr int PIX = decltype(tag)::value;
-            hipLaunchKernelGGL((k_box_mean<PIX>), dim3(ceil_div(dst->cols, 256), dst->rows), dim3(256), 0, s, (const float *)sat, dimg(dst), (int)radius);
+            if (sharpen) hipLaunchKernelGGL((k_box_mean<PIX, true>), dim3(ceil_div(dst->cols, 256), dst->rows), dim3(256), 0, s, (const float *)sat, dimg(src), dimg(dst), (int)radius);
+            else hipLaunchKernelGGL((k_box_mean<PIX, false>), dim3(ceil_div(dst->cols, 256), dst->rows), dim3(256), 0, s, (const float *)sat, dimg(src), dimg(dst), (int)radius);
             ZG_HIP(hipGetLastError());
             return ZG_OK;
         });
@@ -229,7 +237,7 @@ using namespace zg;
 extern "C" {
 
 int zg_box_blur(const zg_image *src, const zg_image *dst, uint32_t radius, zg_stream stream) {
-    return box_blur_impl(src, dst, radius, as_stream(stream));
+    return box_blur_impl(src, dst, radius, false, as_stream(stream));
 }
 
 int zg_box_blur_host(const zg_image *src, const zg_image *dst, uint32_t radius) {
@@ -237,9 +245,47 @@ int zg_box_blur_host(const zg_image *src, const zg_image *dst, uint32_t radius) 
     int rc;
     if ((rc = a.upload(src, true, false))) return rc;
     if ((rc = b.upload(dst, false, true))) return rc;
-    if ((rc = box_blur_impl(&a.dev, &b.dev, radius, nullptr))) return rc;
+    if ((rc = box_blur_impl(&a.dev, &b.dev, radius, false, nullptr))) return rc;
     ZG_HIP(hipStreamSynchronize(nullptr));
     return b.finish();
+}
+
+int zg_sharpen(const zg_image *src, const zg_image *dst, uint32_t radius, zg_stream stream) {
+    return box_blur_impl(src, dst, radius, true, as_stream(stream));
+}
+
+int zg_sharpen_host(const zg_image *src, const zg_image *dst, uint32_t radius) {
+    HostStage a, b;
+    int rc;
+    if ((rc = a.upload(src, true, false))) return rc;
+    if ((rc = b.upload(dst, false, true))) return rc;
+    if ((rc = box_blur_impl(&a.dev, &b.dev, radius, true, nullptr))) return rc;
+    ZG_HIP(hipStreamSynchronize(nullptr));
+    return b.finish();
+}
+
+// Image(T).integral (image.zig:628-630 -> integral.zig:95-140): planes[ch] is a rows x cols f32 image, ch-major in `planes`.
+int zg_integral(const zg_image *src, float *planes, zg_stream stream) {
+    int rc;
+    if ((rc = check_image(src, "src"))) return rc;
+    ZG_REQUIRE(planes != nullptr || src->rows == 0 || src->cols == 0, ZG_ERR_INVALID_ARGUMENT, "integral: null output");
+    if (src->rows == 0 || src->cols == 0) return ZG_OK;
+    return sat_planes_impl(src, planes, as_stream(stream), false);
+}
+
+int zg_integral_host(const zg_image *src, float *planes) {
+    HostStage a;
+    int rc;
+    if ((rc = a.upload(src, true, false))) return rc;
+    if (src->rows == 0 || src->cols == 0) return ZG_OK;
+    const size_t bytes = (size_t)pixel_channels(src->pixel) * src->rows * src->cols * sizeof(float);
+    ZG_REQUIRE(planes != nullptr, ZG_ERR_INVALID_ARGUMENT, "integral: null output");
+    float *dev = nullptr;
+    ZG_HIP(hipMalloc((void **)&dev, bytes));
+    rc = sat_planes_impl(&a.dev, dev, nullptr, false);
+    if (rc == ZG_OK && hipMemcpy(planes, dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = ZG_ERR_HIP;
+    (void)hipFree(dev);
+    return rc;
 }
 
 } // extern "C"

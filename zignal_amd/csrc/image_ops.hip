@@ -101,6 +101,37 @@ static int flip_impl(const zg_image *img, bool lr, hipStream_t s) {
     return ZG_OK;
 }
 
+// Image(T).invert (image.zig:494-513): u8 scalars 255 - v; colour structs through their .invert() (color.zig:328-331,
+// 441-444): max - channel with max = 255 / 1.0, Rgba keeps alpha. Image(f32) has no invert in the reference (compile error).
+template <int PIX>
+__global__ __launch_bounds__(256) void k_invert(DImg img) {
+    using P = Px<PIX>;
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= img.cols) return;
+    const size_t i = (size_t)r * img.stride + (size_t)c;
+    typename P::Vec v = P::load(img.data, i);
+    constexpr int N = P::C == 4 ? 3 : P::C;
+#pragma unroll
+    for (int ch = 0; ch < N; ++ch) {
+        if constexpr (std::is_same<typename P::Elem, float>::value) v[ch] = 1.0f - v[ch];
+        else v[ch] = (uint8_t)(255 - v[ch]);
+    }
+    P::store(img.data, i, v);
+}
+
+static int invert_impl(const zg_image *img, hipStream_t s) {
+    int rc;
+    if ((rc = check_image(img, "img"))) return rc;
+    ZG_REQUIRE(img->pixel != ZG_PIXEL_F32, ZG_ERR_UNSUPPORTED, "invert: Image(f32) has no invert() in the reference (u8 scalars and colour structs only)");
+    if (img->rows == 0 || img->cols == 0) return ZG_OK;
+    return dispatch_pixel(img->pixel, [&](auto tag) -> int {
+        constexpr int PIX = decltype(tag)::value;
+        hipLaunchKernelGGL((k_invert<PIX>), dim3(ceil_div(img->cols, 256), img->rows), dim3(256), 0, s, dimg(img));
+        ZG_HIP(hipGetLastError());
+        return ZG_OK;
+    });
+}
+
 } // namespace zg
 
 using namespace zg;
@@ -118,6 +149,16 @@ int zg_set_border(const zg_image *img, const uint32_t rect[4], const void *pixel
     if ((rc = check_image(img, "img"))) return rc;
     ZG_REQUIRE(rect, ZG_ERR_INVALID_ARGUMENT, "setBorder: null rect");
     return set_border_impl(img, rect, pixel_value, as_stream(stream));
+}
+
+int zg_invert(const zg_image *img, zg_stream stream) { return invert_impl(img, as_stream(stream)); }
+int zg_invert_host(const zg_image *img) {
+    HostStage a;
+    int rc;
+    if ((rc = a.upload(img, true, true))) return rc;
+    if ((rc = invert_impl(&a.dev, nullptr))) return rc;
+    ZG_HIP(hipStreamSynchronize(nullptr));
+    return a.finish();
 }
 
 int zg_flip_left_right(const zg_image *img, zg_stream stream) { return flip_impl(img, true, as_stream(stream)); }

@@ -237,6 +237,32 @@ class Image:
         self._call("box_blur", C.byref(s), C.byref(d), int(radius))
         return out
 
+    def sharpen(self, radius: int, out: Optional["Image"] = None) -> "Image":
+        """Image.sharpen (image.zig:785-801): 2 * original - boxBlur(radius)."""
+        out = self._like() if out is None else self._wrap(out)
+        self._same_side(out)
+        s, d = self._desc(), out._desc()
+        self._call("sharpen", C.byref(s), C.byref(d), int(radius))
+        return out
+
+    def integral(self):
+        """Image.integral (image.zig:628-630): the summed-area planes, shape (channels, rows, cols) f32 (same side as self)."""
+        ch = 1 if self.data.ndim == 2 else int(self.data.shape[2])
+        s = self._desc()
+        if self.on_device:
+            planes = torch.empty((ch, self.rows, self.cols), dtype=torch.float32, device=self.data.device)
+            L.check(L.lib().zg_integral(C.byref(s), C.cast(C.c_void_p(planes.data_ptr()), C.POINTER(C.c_float)), self._stream()))
+        else:
+            planes = np.empty((ch, self.rows, self.cols), np.float32)
+            L.check(L.lib().zg_integral_host(C.byref(s), planes.ctypes.data_as(C.POINTER(C.c_float))))
+        return planes
+
+    def invert(self) -> "Image":
+        """Image.invert (image.zig:494-513), in place."""
+        s = self._desc()
+        self._call("invert", C.byref(s))
+        return self
+
     # ---- resampling -------------------------------------------------------------------------
     def resize(self, size_or_out, method: Interpolation = Interpolation.bilinear) -> "Image":
         """Image.resize (image.zig:523): `size_or_out` is (rows, cols) or a pre-allocated Image."""
