@@ -378,10 +378,7 @@ def extras(zg, torch, np):
         return rate(ms, ROWS * COLS, 16 * ROWS * COLS)  # 4 B read + 12 B written
 
     def warp(kind):
-        from oracle import pyoracle as oracle  # host-side 4-point solve only (f64, a few flops)
-        hmat = oracle.homography_from_4pts([(0, 0), (4095, 0), (0, 4095), (4095, 4095)],
-                                           [(200, 120), (3900, 60), (90, 3980), (4000, 4050)])
-        tr = zg.ProjectiveTransform(hmat)
+        tr = zg.ProjectiveTransform.from_points([(0, 0), (4095, 0), (0, 4095), (4095, 4095)], [(200, 120), (3900, 60), (90, 3980), (4000, 4050)])
         ring = 4
         if kind == "u8":
             srcs, bpp = u8_frames(ring, (ROWS, COLS, 4)), 8

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Randomised GPU-vs-oracle parity sweep: random shapes (biased to tile seams), pixel types, parameters, views.
-usage: python tools/fuzz_parity.py [seconds] [seed] [max_rows max_cols]   — exits non-zero on the first mismatch, printing the case."""
+usage: python tests/fuzz_parity.py [seconds] [seed] [max_rows max_cols]   — exits non-zero on the first mismatch, printing the case."""
 import math
 import sys
 import time

@@ -18,10 +18,9 @@ elif op == "resize":
     s = zg.Image(torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")); d = zg.Image(torch.empty((1024, 1024, 4), dtype=torch.uint8, device="cuda"))
     f = lambda: s.resize(d, I.bilinear)
 elif op in ("warp_u8", "warp_f32"):
-    from oracle import pyoracle as oracle
-    h = oracle.homography_from_4pts([(0, 0), (4095, 0), (0, 4095), (4095, 4095)], [(200, 120), (3900, 60), (90, 3980), (4000, 4050)])
+    tr = zg.ProjectiveTransform.from_points([(0, 0), (4095, 0), (0, 4095), (4095, 4095)], [(200, 120), (3900, 60), (90, 3980), (4000, 4050)])
     t = torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda") if op == "warp_u8" else torch.rand((R, R, 4), dtype=torch.float32, device="cuda")
-    s = zg.Image(t); d = zg.Image(torch.empty_like(t)); tr = zg.ProjectiveTransform(h)
+    s = zg.Image(t); d = zg.Image(torch.empty_like(t))
     f = lambda: s.warp(tr, d, I.bicubic)
 elif op == "oklab":
     s = zg.Image(torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")); d = zg.Image(torch.empty((R, R, 3), dtype=torch.float32, device="cuda"))

@@ -533,6 +533,20 @@ class ProjectiveTransform:
     def __init__(self, matrix):
         self.matrix = np.asarray(matrix, np.float32).reshape(3, 3)
 
+    @staticmethod
+    def from_points(from_points, to_points) -> "ProjectiveTransform":
+        """ProjectiveTransform.init with four correspondences (geometry/transforms.zig:242-263): the 8 x 8 system solved on
+        the host in f64 (h22 = 1), then .as(f32). Host-side set-up, as in the reference."""
+        f, t = np.asarray(from_points, np.float64).reshape(4, 2), np.asarray(to_points, np.float64).reshape(4, 2)
+        a, b = np.zeros((8, 8)), np.zeros(8)
+        for i in range(4):
+            fx, fy, tx, ty = f[i, 0], f[i, 1], t[i, 0], t[i, 1]
+            a[2 * i] = (fx, fy, 1, 0, 0, 0, -tx * fx, -tx * fy)
+            a[2 * i + 1] = (0, 0, 0, fx, fy, 1, -ty * fx, -ty * fy)
+            b[2 * i], b[2 * i + 1] = tx, ty
+        h = np.linalg.solve(a, b)
+        return ProjectiveTransform(np.append(h, 1.0).astype(np.float32))
+
     def coefficients(self):
         return self.matrix.reshape(9)
 
