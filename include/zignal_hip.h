@@ -270,6 +270,21 @@ ZG_API int zg_integral_host(const zg_image *src, float *planes);
 ZG_API int zg_invert(const zg_image *img, zg_stream stream);
 ZG_API int zg_invert_host(const zg_image *img);
 
+/* Image(u8) binarisation and binary morphology (src/image.zig:845-914 -> src/image/binary.zig). Image(u8) only
+ * (ZG_ERR_UNSUPPORTED otherwise, a compile error in the reference).
+ * thresholdOtsu (:38-84): out = src > t ? 255 : 0; *threshold_out (host pointer, may be NULL) receives t, which
+ * synchronises `stream`. thresholdAdaptiveMean (:86-118): out = src > windowMean(radius) - c; radius 0 is
+ * error.InvalidRadius -> ZG_ERR_INVALID_ARGUMENT. zg_morph (:121-281): op 0 dilate, 1 erode, 2 open, 3 close; kernel is a
+ * host array of kernel_rows x kernel_cols bytes (non-zero = on; odd sizes, else error.InvalidKernelSize); src may alias dst. */
+ZG_API int zg_threshold_otsu(const zg_image *src, const zg_image *dst, uint8_t *threshold_out, zg_stream stream);
+ZG_API int zg_threshold_otsu_host(const zg_image *src, const zg_image *dst, uint8_t *threshold_out);
+ZG_API int zg_threshold_adaptive_mean(const zg_image *src, const zg_image *dst, uint32_t radius, float c, zg_stream stream);
+ZG_API int zg_threshold_adaptive_mean_host(const zg_image *src, const zg_image *dst, uint32_t radius, float c);
+ZG_API int zg_morph(const zg_image *src, const zg_image *dst, const uint8_t *kernel, uint32_t kernel_rows, uint32_t kernel_cols,
+                    uint32_t iterations, int op, zg_stream stream);
+ZG_API int zg_morph_host(const zg_image *src, const zg_image *dst, const uint8_t *kernel, uint32_t kernel_rows, uint32_t kernel_cols,
+                         uint32_t iterations, int op);
+
 /* Image(T).canny (src/image.zig:1047-1063 -> src/image/edges.zig:212-277): grey -> the detector's own Gaussian
  * (.replicate; sigma == 0 skips it) -> Sobel gradients -> non-maximum suppression -> double threshold + hysteresis.
  * dst is Image(u8), 0 or 255. error.InvalidParameter / InvalidSigma / InvalidThreshold -> ZG_ERR_INVALID_ARGUMENT.

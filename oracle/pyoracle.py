@@ -274,6 +274,32 @@ def insert(self_img, source, rect, angle, m: ZoMethod, blend_mode=0):
     return self_img
 
 
+def threshold_otsu(src):
+    out = np.empty_like(src)
+    t = C.c_uint8(0)
+    s, d = as_image(src), as_image(out)
+    _check(lib().zo_threshold_otsu(C.byref(s), C.byref(d), C.byref(t)), "threshold_otsu")
+    return out, t.value
+
+
+def threshold_adaptive_mean(src, radius, c):
+    out = np.empty_like(src)
+    s, d = as_image(src), as_image(out)
+    _check(lib().zo_threshold_adaptive_mean(C.byref(s), C.byref(d), C.c_uint32(radius), C.c_float(c)), "threshold_adaptive_mean")
+    return out
+
+
+MORPH_DILATE, MORPH_ERODE, MORPH_OPEN, MORPH_CLOSE = range(4)
+
+
+def morph(src, kernel, iterations, op):
+    out = np.empty_like(src)
+    k = np.ascontiguousarray(kernel, np.uint8)
+    s, d = as_image(src), as_image(out)
+    _check(lib().zo_morph(C.byref(s), C.byref(d), k.ctypes.data_as(C.POINTER(C.c_uint8)), k.shape[0], k.shape[1], C.c_uint32(iterations), int(op)), "morph")
+    return out
+
+
 def sharpen(src, radius):
     out = np.empty_like(src)
     s, d = as_image(src), as_image(out)

@@ -315,3 +315,80 @@ def test_shen_castan_gpu_parity(oracle, kind):
     for bad in (dict(smooth=0.0), dict(smooth=1.0), dict(high_ratio=1.0), dict(low_rel=0.0), dict(window_size=6), dict(window_size=1)):
         with pytest.raises(zg.InvalidArgument):
             zg.Image(img).shen_castan(**bad)
+
+
+# ---- binary.zig: Otsu / adaptive-mean thresholds, binary morphology (image.zig:845-914) ---------------------------------
+def test_binary_reference_known_answers_oracle(oracle):  # tests/binary.zig:7-175
+    out, t = oracle.threshold_otsu(np.array([[10, 10, 10, 10], [200, 200, 200, 200]], np.uint8))
+    assert 5 <= t <= 50 and out.tolist() == [[0] * 4, [255] * 4]
+    img = np.array([[50, 50, 50], [50, 200, 50], [50, 50, 50]], np.uint8)
+    assert oracle.threshold_adaptive_mean(img, 1, 10.0).tolist() == [[0, 0, 0], [0, 255, 0], [0, 0, 0]]
+    with pytest.raises(RuntimeError):
+        oracle.threshold_adaptive_mean(img, 0, 0.0)  # error.InvalidRadius
+    box = np.ones((3, 3), np.uint8)
+    block = np.zeros((5, 5), np.uint8)
+    block[1:4, 1:4] = 255
+    dot = np.zeros((5, 5), np.uint8)
+    dot[2, 2] = 255
+    assert (oracle.morph(dot, box, 1, oracle.MORPH_DILATE) == block).all()
+    noisy = block.copy()
+    noisy[1, 4] = 255
+    assert (oracle.morph(noisy, box, 1, oracle.MORPH_OPEN) == block).all()
+    holed = block.copy()
+    holed[2, 2] = 0
+    assert (oracle.morph(holed, box, 1, oracle.MORPH_CLOSE) == block).all()
+    big = np.zeros((7, 7), np.uint8)
+    big[1:6, 1:6] = 255
+    e1, e2 = oracle.morph(big, box, 1, oracle.MORPH_ERODE), oracle.morph(big, box, 2, oracle.MORPH_ERODE)
+    assert e1[2:5, 2:5].all() and e1.sum() == 9 * 255 and e2.sum() == 255 and e2[3, 3] == 255
+    with pytest.raises(RuntimeError):
+        oracle.morph(big, np.ones((2, 3), np.uint8), 1, oracle.MORPH_DILATE)  # error.InvalidKernelSize
+
+
+@pytest.mark.gpu
+def test_binary_gpu_parity(oracle):
+    import torch
+
+    def dev(a):
+        return zg.Image(torch.from_numpy(np.ascontiguousarray(a)).cuda())
+
+    rng = np.random.default_rng(70)
+    for (rows, cols) in ((2, 4), (37, 53), (130, 517), (64, 64)):
+        img = synth(oracle, "u8", 71 + rows, rows, cols)
+        if rows > 30:  # a bimodal frame so that Otsu has something to find
+            img = np.where(synth(oracle, "u8", 5, rows, cols) > 128, 180 + img // 4, img // 3).astype(np.uint8)
+        want, wt = oracle.threshold_otsu(img)
+        got, gt = dev(img).threshold_otsu()
+        torch.cuda.synchronize()
+        assert gt == wt
+        assert_bits_equal(got.to_numpy(), want, f"otsu {rows}x{cols}")
+        for radius, c in ((1, 10.0), (3, -2.5), (50, 0.0)):
+            got = dev(img).threshold_adaptive_mean(radius, c)
+            torch.cuda.synchronize()
+            assert_bits_equal(got.to_numpy(), oracle.threshold_adaptive_mean(img, radius, c), f"adaptive {rows}x{cols} r={radius}")
+        mask = (img > 150).astype(np.uint8) * 255
+        for kshape in ((3, 3), (1, 5), (7, 3), (15, 15)):
+            k = (rng.random(kshape) > 0.3).astype(np.uint8)
+            k[kshape[0] // 2, kshape[1] // 2] = 1
+            for op in range(4):
+                for it in (0, 1, 2, 3):
+                    got = dev(mask)._morph(k, it, op, None)
+                    torch.cuda.synchronize()
+                    assert_bits_equal(got.to_numpy(), oracle.morph(mask, k, it, op), f"morph op={op} it={it} k={kshape} {rows}x{cols}")
+        # in place (the reference's tests call openBinary(image, ...) onto itself)
+        d = dev(mask)
+        d.open_binary(np.ones((3, 3), np.uint8), 1, out=d)
+        torch.cuda.synchronize()
+        assert_bits_equal(d.to_numpy(), oracle.morph(mask, np.ones((3, 3), np.uint8), 1, oracle.MORPH_OPEN), "open in place")
+        d = dev(mask)
+        d.erode_binary(np.ones((3, 3), np.uint8), 1, out=d)
+        torch.cuda.synchronize()
+        assert_bits_equal(d.to_numpy(), oracle.morph(mask, np.ones((3, 3), np.uint8), 1, oracle.MORPH_ERODE), "erode in place")
+    host, ht = zg.Image(img).threshold_otsu()
+    assert ht == wt and (host.data == want).all()
+    with pytest.raises(zg.InvalidArgument):
+        zg.Image(img).threshold_adaptive_mean(0, 0.0)
+    with pytest.raises(zg.InvalidArgument):
+        zg.Image(img).dilate_binary(np.ones((2, 3), np.uint8))
+    with pytest.raises(zg.ZignalError):
+        zg.Image(np.zeros((4, 4, 3), np.uint8)).threshold_otsu()

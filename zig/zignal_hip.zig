@@ -37,6 +37,9 @@ pub const c = struct {
     pub extern fn zg_flip_top_bottom_host(img: *const ZgImage) c_int;
     /// ImagePyramid.build's loop body (src/image/pyramid.zig:76-92) for device-resident images: blur when sigma > 0.5, then bilinear resize
     pub extern fn zg_pyramid_build_level(source: *const ZgImage, level: *const ZgImage, sigma: f32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_threshold_otsu_host(src: *const ZgImage, dst: *const ZgImage, threshold_out: ?*u8) c_int;
+    pub extern fn zg_threshold_adaptive_mean_host(src: *const ZgImage, dst: *const ZgImage, radius: u32, c: f32) c_int;
+    pub extern fn zg_morph_host(src: *const ZgImage, dst: *const ZgImage, kernel: [*]const u8, kernel_rows: u32, kernel_cols: u32, iterations: u32, op: c_int) c_int;
     pub extern fn zg_sharpen_host(src: *const ZgImage, dst: *const ZgImage, radius: u32) c_int;
     pub extern fn zg_integral_host(src: *const ZgImage, planes: [*]f32) c_int;
     pub extern fn zg_invert_host(img: *const ZgImage) c_int;

@@ -106,6 +106,12 @@ _SIGNATURES = {
     "zg_integral_host": [_IMG, _F32P],
     "zg_invert": [_IMG, C.c_void_p],
     "zg_invert_host": [_IMG],
+    "zg_threshold_otsu": [_IMG, _IMG, C.POINTER(C.c_uint8), C.c_void_p],
+    "zg_threshold_otsu_host": [_IMG, _IMG, C.POINTER(C.c_uint8)],
+    "zg_threshold_adaptive_mean": [_IMG, _IMG, C.c_uint32, C.c_float, C.c_void_p],
+    "zg_threshold_adaptive_mean_host": [_IMG, _IMG, C.c_uint32, C.c_float],
+    "zg_morph": [_IMG, _IMG, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p],
+    "zg_morph_host": [_IMG, _IMG, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int],
     "zg_sobel": [_IMG, _IMG, C.c_void_p],
     "zg_sobel_host": [_IMG, _IMG],
     "zg_canny": [_IMG, _IMG, C.c_float, C.c_float, C.c_float, C.c_void_p],

@@ -404,6 +404,46 @@ class Image:
         self._call("canny", C.byref(s), C.byref(d), C.c_float(sigma), C.c_float(low_threshold), C.c_float(high_threshold))
         return out
 
+    # ---- binarisation and binary morphology (image.zig:845-914 -> binary.zig; Image(u8) only) ------------------
+    def threshold_otsu(self, out: Optional["Image"] = None):
+        """Image.thresholdOtsu: returns (binary image, threshold)."""
+        out = self._like() if out is None else self._wrap(out)
+        self._same_side(out)
+        t = C.c_uint8(0)
+        s, d = self._desc(), out._desc()
+        self._call("threshold_otsu", C.byref(s), C.byref(d), C.byref(t))
+        return out, int(t.value)
+
+    def threshold_adaptive_mean(self, radius: int, c: float, out: Optional["Image"] = None) -> "Image":
+        """Image.thresholdAdaptiveMean (radius 0 raises InvalidArgument: the reference's InvalidRadius)."""
+        out = self._like() if out is None else self._wrap(out)
+        self._same_side(out)
+        s, d = self._desc(), out._desc()
+        self._call("threshold_adaptive_mean", C.byref(s), C.byref(d), C.c_uint32(int(radius)), C.c_float(c))
+        return out
+
+    def _morph(self, kernel, iterations: int, op: int, out) -> "Image":
+        out = self._like() if out is None else self._wrap(out)
+        self._same_side(out)
+        k = np.ascontiguousarray(kernel, np.uint8)
+        if k.ndim != 2:
+            raise L.InvalidArgument(L.ERR_INVALID_ARGUMENT, "morphology: the structuring element is a 2-D array")
+        s, d = self._desc(), out._desc()
+        self._call("morph", C.byref(s), C.byref(d), k.ctypes.data_as(C.POINTER(C.c_uint8)), int(k.shape[0]), int(k.shape[1]), int(iterations), op)
+        return out
+
+    def dilate_binary(self, kernel, iterations: int = 1, out: Optional["Image"] = None) -> "Image":
+        return self._morph(kernel, iterations, 0, out)
+
+    def erode_binary(self, kernel, iterations: int = 1, out: Optional["Image"] = None) -> "Image":
+        return self._morph(kernel, iterations, 1, out)
+
+    def open_binary(self, kernel, iterations: int = 1, out: Optional["Image"] = None) -> "Image":
+        return self._morph(kernel, iterations, 2, out)
+
+    def close_binary(self, kernel, iterations: int = 1, out: Optional["Image"] = None) -> "Image":
+        return self._morph(kernel, iterations, 3, out)
+
     def shen_castan(self, smooth: float = 0.9, window_size: int = 7, high_ratio: float = 0.99, low_rel: float = 0.5,
                     hysteresis: bool = True, use_nms: bool = False, out: Optional["Image"] = None) -> "Image":
         """Image.shenCastan (image.zig:1015-1027) with the reference's ShenCastan option defaults; binary edge map as Image(u8)."""
