@@ -270,6 +270,13 @@ ZG_API int zg_integral_host(const zg_image *src, float *planes);
 ZG_API int zg_invert(const zg_image *img, zg_stream stream);
 ZG_API int zg_invert_host(const zg_image *img);
 
+/* Image(T).autocontrast / equalize (src/image.zig:804-829 -> src/image/enhancement.zig), in place, for u8, Rgb(u8),
+ * Rgba(u8) (ZG_ERR_UNSUPPORTED otherwise). cutoff outside [0, 0.5) is error.InvalidCutoff -> ZG_ERR_INVALID_ARGUMENT. */
+ZG_API int zg_autocontrast(const zg_image *img, float cutoff, zg_stream stream);
+ZG_API int zg_autocontrast_host(const zg_image *img, float cutoff);
+ZG_API int zg_equalize(const zg_image *img, zg_stream stream);
+ZG_API int zg_equalize_host(const zg_image *img);
+
 /* Image(u8) binarisation and binary morphology (src/image.zig:845-914 -> src/image/binary.zig). Image(u8) only
  * (ZG_ERR_UNSUPPORTED otherwise, a compile error in the reference).
  * thresholdOtsu (:38-84): out = src > t ? 255 : 0; *threshold_out (host pointer, may be NULL) receives t, which

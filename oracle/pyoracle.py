@@ -300,6 +300,18 @@ def morph(src, kernel, iterations, op):
     return out
 
 
+def autocontrast(img, cutoff=0.0):
+    s = as_image(img)
+    _check(lib().zo_autocontrast(C.byref(s), C.c_float(cutoff)), "autocontrast")
+    return img
+
+
+def equalize(img):
+    s = as_image(img)
+    _check(lib().zo_equalize(C.byref(s)), "equalize")
+    return img
+
+
 def sharpen(src, radius):
     out = np.empty_like(src)
     s, d = as_image(src), as_image(out)

@@ -392,3 +392,39 @@ def test_binary_gpu_parity(oracle):
         zg.Image(img).dilate_binary(np.ones((2, 3), np.uint8))
     with pytest.raises(zg.ZignalError):
         zg.Image(np.zeros((4, 4, 3), np.uint8)).threshold_otsu()
+
+
+# ---- enhancement.zig: autocontrast / equalize (image.zig:804-829) ------------------------------------------------------
+def test_enhancement_oracle_hand_checked(oracle):
+    """No known answers in the reference for these two; the expected values below are worked by hand from
+    enhancement.zig:11-80 / :84-131 and histogram.zig:123-162."""
+    assert oracle.autocontrast(np.array([[50, 100], [150, 200]], np.uint8)).tolist() == [[0, 85], [170, 255]]
+    assert oracle.equalize(np.array([[10, 10], [20, 30]], np.uint8)).tolist() == [[0, 0], [127, 255]]  # cdf 2,3,4; (cdf-2)*255/2
+    flat = np.full((3, 3), 77, np.uint8)
+    assert (oracle.equalize(flat.copy()) == 77).all()  # denominator 0: identity table
+    assert (oracle.autocontrast(flat.copy()) == 0).all()  # min == max: range 1, clamped - min == 0
+    rgba = np.array([[[10, 20, 30, 40], [110, 220, 130, 140]]], np.uint8)
+    assert oracle.autocontrast(rgba.copy())[..., 3].tolist() == [[40, 140]]  # alpha untouched
+    with pytest.raises(RuntimeError):
+        oracle.autocontrast(flat.copy(), 0.5)  # error.InvalidCutoff
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ("u8", "rgb_u8", "rgba_u8"))
+def test_enhancement_gpu_parity(oracle, kind):
+    import torch
+    for (rows, cols) in ((1, 1), (5, 7), (130, 517), (64, 256)):
+        img = synth(oracle, kind, 81 + rows, rows, cols)
+        img = (img.astype(np.float32) * 0.6 + 30).astype(np.uint8)  # leave both tails empty so the cut-offs matter
+        for cutoff in (0.0, 0.02, 0.3, 0.49):
+            got = zg.Image(torch.from_numpy(img.copy()).cuda()).autocontrast(cutoff)
+            torch.cuda.synchronize()
+            assert_bits_equal(got.to_numpy(), oracle.autocontrast(img.copy(), cutoff), f"autocontrast {kind} {rows}x{cols} cutoff={cutoff}")
+        got = zg.Image(torch.from_numpy(img.copy()).cuda()).equalize()
+        torch.cuda.synchronize()
+        assert_bits_equal(got.to_numpy(), oracle.equalize(img.copy()), f"equalize {kind} {rows}x{cols}")
+    assert_bits_equal(zg.Image(img.copy()).equalize().data, oracle.equalize(img.copy()), "equalize host layer")
+    with pytest.raises(zg.InvalidArgument):
+        zg.Image(img.copy()).autocontrast(0.5)
+    with pytest.raises(zg.ZignalError):
+        zg.Image(np.zeros((4, 4), np.float32)).equalize()

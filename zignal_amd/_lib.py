@@ -106,6 +106,10 @@ _SIGNATURES = {
     "zg_integral_host": [_IMG, _F32P],
     "zg_invert": [_IMG, C.c_void_p],
     "zg_invert_host": [_IMG],
+    "zg_autocontrast": [_IMG, C.c_float, C.c_void_p],
+    "zg_autocontrast_host": [_IMG, C.c_float],
+    "zg_equalize": [_IMG, C.c_void_p],
+    "zg_equalize_host": [_IMG],
     "zg_threshold_otsu": [_IMG, _IMG, C.POINTER(C.c_uint8), C.c_void_p],
     "zg_threshold_otsu_host": [_IMG, _IMG, C.POINTER(C.c_uint8)],
     "zg_threshold_adaptive_mean": [_IMG, _IMG, C.c_uint32, C.c_float, C.c_void_p],

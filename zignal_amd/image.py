@@ -404,6 +404,18 @@ class Image:
         self._call("canny", C.byref(s), C.byref(d), C.c_float(sigma), C.c_float(low_threshold), C.c_float(high_threshold))
         return out
 
+    def autocontrast(self, cutoff: float = 0.0) -> "Image":
+        """Image.autocontrast (image.zig:804), in place."""
+        s = self._desc()
+        self._call("autocontrast", C.byref(s), C.c_float(cutoff))
+        return self
+
+    def equalize(self) -> "Image":
+        """Image.equalize (image.zig:824), in place."""
+        s = self._desc()
+        self._call("equalize", C.byref(s))
+        return self
+
     # ---- binarisation and binary morphology (image.zig:845-914 -> binary.zig; Image(u8) only) ------------------
     def threshold_otsu(self, out: Optional["Image"] = None):
         """Image.thresholdOtsu: returns (binary image, threshold)."""
