@@ -270,6 +270,15 @@ ZG_API int zg_integral_host(const zg_image *src, float *planes);
 ZG_API int zg_invert(const zg_image *img, zg_stream stream);
 ZG_API int zg_invert_host(const zg_image *img);
 
+/* Image(T).medianBlur / percentileBlur / minBlur / maxBlur / midpointBlur / alphaTrimmedMeanBlur (src/image.zig:653-783
+ * -> src/image/order_statistic_blur.zig) for u8 and all-u8 struct pixels, per channel. op 0: percentile (param in
+ * [0, 1]; median = 0.5 with ZG_BORDER_MIRROR, min = 0.0, max = 1.0), 1: midpoint, 2: alpha-trimmed mean (param = trim
+ * fraction in [0, 0.5)). InvalidPercentile / InvalidTrim -> ZG_ERR_INVALID_ARGUMENT, UnsupportedPixelType and radius > 15
+ * -> ZG_ERR_UNSUPPORTED. radius 0 copies. src may alias dst. */
+ZG_API int zg_order_statistic_blur(const zg_image *src, const zg_image *dst, uint32_t radius, int op, double param, int border,
+                                   zg_stream stream);
+ZG_API int zg_order_statistic_blur_host(const zg_image *src, const zg_image *dst, uint32_t radius, int op, double param, int border);
+
 /* Image(T).autocontrast / equalize (src/image.zig:804-829 -> src/image/enhancement.zig), in place, for u8, Rgb(u8),
  * Rgba(u8) (ZG_ERR_UNSUPPORTED otherwise). cutoff outside [0, 0.5) is error.InvalidCutoff -> ZG_ERR_INVALID_ARGUMENT. */
 ZG_API int zg_autocontrast(const zg_image *img, float cutoff, zg_stream stream);

@@ -300,6 +300,16 @@ def morph(src, kernel, iterations, op):
     return out
 
 
+OS_PERCENTILE, OS_MIDPOINT, OS_ALPHA_TRIMMED = range(3)
+
+
+def order_statistic_blur(src, radius, op, param=0.5, border=MIRROR):
+    out = np.empty_like(src)
+    s, d = as_image(src), as_image(out)
+    _check(lib().zo_order_statistic_blur(C.byref(s), C.byref(d), C.c_uint32(radius), int(op), C.c_double(param), int(border)), "order_statistic_blur")
+    return out
+
+
 def autocontrast(img, cutoff=0.0):
     s = as_image(img)
     _check(lib().zo_autocontrast(C.byref(s), C.c_float(cutoff)), "autocontrast")

@@ -56,6 +56,8 @@ def cases():
     yield "threshold_adaptive_mean_u8", o.threshold_adaptive_mean(g8, 3, 5.0)
     yield "morph_open_u8", o.morph((g8 > 128).astype(np.uint8) * 255, np.ones((3, 3), np.uint8), 2, o.MORPH_OPEN)
     yield "sharpen_rgba_u8", o.sharpen(u8, 2)
+    yield "median_blur_r2_rgba_u8", o.order_statistic_blur(u8, 2, o.OS_PERCENTILE, 0.5, o.MIRROR)
+    yield "alpha_trimmed_r1_u8", o.order_statistic_blur(g8, 1, o.OS_ALPHA_TRIMMED, 0.2, o.REPLICATE)
     yield "autocontrast_rgba_u8", o.autocontrast(u8.copy(), 0.02)
     yield "equalize_u8", o.equalize(g8.copy())
     yield "shen_castan_u8", o.shen_castan(g8, 0.8, 7, 0.9, 0.3)

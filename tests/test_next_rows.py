@@ -428,3 +428,55 @@ def test_enhancement_gpu_parity(oracle, kind):
         zg.Image(img.copy()).autocontrast(0.5)
     with pytest.raises(zg.ZignalError):
         zg.Image(np.zeros((4, 4), np.float32)).equalize()
+
+
+# ---- order_statistic_blur.zig: median / percentile / min / max / midpoint / alpha-trimmed mean (image.zig:653-783) ------
+def test_order_statistic_reference_known_answers_oracle(oracle):  # tests/filters.zig:817-960
+    z = np.zeros((5, 5), np.uint8)
+    z[2, 2] = 255
+    m = oracle.order_statistic_blur(z, 1, oracle.OS_PERCENTILE, 0.5, oracle.MIRROR)
+    assert m[2, 2] == 0 and m[2, 1] == 0 and m[1, 2] == 0
+    a = np.arange(9, dtype=np.uint8).reshape(3, 3)
+    mx = oracle.order_statistic_blur(a, 1, oracle.OS_PERCENTILE, 1.0, oracle.ZERO)
+    assert mx[1, 1] == 8 and mx[0, 0] == 4
+    rgb = np.tile(np.array([32, 64, 96], np.uint8), (3, 3, 1))
+    rgb[1, 1] = (255, 0, 0)
+    med = oracle.order_statistic_blur(rgb, 1, oracle.OS_PERCENTILE, 0.5, oracle.MIRROR)
+    assert med[1, 1].tolist() == [32, 64, 96] and med[0, 0].tolist() == [32, 64, 96]
+    assert oracle.order_statistic_blur(a, 1, oracle.OS_MIDPOINT, 0, oracle.REPLICATE)[1, 1] == 4
+    assert oracle.order_statistic_blur(a, 1, oracle.OS_ALPHA_TRIMMED, 0.12, oracle.REPLICATE)[1, 1] == 4
+    for bad in ((oracle.OS_ALPHA_TRIMMED, 0.5), (oracle.OS_ALPHA_TRIMMED, -0.1), (oracle.OS_PERCENTILE, 1.5)):
+        with pytest.raises(RuntimeError):
+            oracle.order_statistic_blur(a, 1, bad[0], bad[1], oracle.REPLICATE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ("u8", "rgb_u8", "rgba_u8"))
+def test_order_statistic_gpu_parity(oracle, kind):
+    import torch
+
+    def dev(a):
+        return zg.Image(torch.from_numpy(np.ascontiguousarray(a)).cuda())
+
+    for (rows, cols) in ((1, 1), (3, 3), (37, 53), (20, 140)):
+        img = synth(oracle, kind, 91 + rows, rows, cols)
+        for border in (0, 1, 2, 3):
+            for radius in (0, 1, 2, 4):
+                for op, param in ((0, 0.5), (0, 0.0), (0, 1.0), (0, 0.37), (1, 0.0), (2, 0.12), (2, 0.0), (2, 0.49)):
+                    if radius == 4 and (border in (0, 3)) and op == 0 and param == 0.37:
+                        continue
+                    want = oracle.order_statistic_blur(img, radius, op, param, border)
+                    got = dev(img)._order_stat(radius, op, param, border, None)
+                    torch.cuda.synchronize()
+                    assert_bits_equal(got.to_numpy(), want, f"order-stat {kind} {rows}x{cols} r={radius} op={op} p={param} border={border}")
+    d = dev(img)
+    d.median_blur(1, out=d)  # in place
+    torch.cuda.synchronize()
+    assert_bits_equal(d.to_numpy(), oracle.order_statistic_blur(img, 1, 0, 0.5, oracle.MIRROR), "median in place")
+    assert_bits_equal(zg.Image(img).median_blur(2).data, oracle.order_statistic_blur(img, 2, 0, 0.5, oracle.MIRROR), "median host layer")
+    with pytest.raises(zg.InvalidArgument):
+        zg.Image(img).percentile_blur(1, 1.5)
+    with pytest.raises(zg.InvalidArgument):
+        zg.Image(img).alpha_trimmed_mean_blur(1, 0.5)
+    with pytest.raises(zg.ZignalError):
+        zg.Image(np.zeros((4, 4), np.float32)).median_blur(1)

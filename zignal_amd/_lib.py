@@ -106,6 +106,8 @@ _SIGNATURES = {
     "zg_integral_host": [_IMG, _F32P],
     "zg_invert": [_IMG, C.c_void_p],
     "zg_invert_host": [_IMG],
+    "zg_order_statistic_blur": [_IMG, _IMG, C.c_uint32, C.c_int, C.c_double, C.c_int, C.c_void_p],
+    "zg_order_statistic_blur_host": [_IMG, _IMG, C.c_uint32, C.c_int, C.c_double, C.c_int],
     "zg_autocontrast": [_IMG, C.c_float, C.c_void_p],
     "zg_autocontrast_host": [_IMG, C.c_float],
     "zg_equalize": [_IMG, C.c_void_p],

@@ -404,6 +404,32 @@ class Image:
         self._call("canny", C.byref(s), C.byref(d), C.c_float(sigma), C.c_float(low_threshold), C.c_float(high_threshold))
         return out
 
+    # ---- order-statistic blurs (image.zig:653-783 -> order_statistic_blur.zig) -------------------------------
+    def _order_stat(self, radius, op, param, border, out):
+        out = self._like() if out is None else self._wrap(out)
+        self._same_side(out)
+        s, d = self._desc(), out._desc()
+        self._call("order_statistic_blur", C.byref(s), C.byref(d), C.c_uint32(int(radius)), int(op), C.c_double(param), int(border))
+        return out
+
+    def median_blur(self, radius: int, out: Optional["Image"] = None) -> "Image":
+        return self._order_stat(radius, 0, 0.5, BorderMode.mirror, out)
+
+    def percentile_blur(self, radius: int, percentile: float, border: int = BorderMode.mirror, out: Optional["Image"] = None) -> "Image":
+        return self._order_stat(radius, 0, percentile, border, out)
+
+    def min_blur(self, radius: int, border: int = BorderMode.mirror, out: Optional["Image"] = None) -> "Image":
+        return self._order_stat(radius, 0, 0.0, border, out)
+
+    def max_blur(self, radius: int, border: int = BorderMode.mirror, out: Optional["Image"] = None) -> "Image":
+        return self._order_stat(radius, 0, 1.0, border, out)
+
+    def midpoint_blur(self, radius: int, border: int = BorderMode.mirror, out: Optional["Image"] = None) -> "Image":
+        return self._order_stat(radius, 1, 0.0, border, out)
+
+    def alpha_trimmed_mean_blur(self, radius: int, trim_fraction: float, border: int = BorderMode.mirror, out: Optional["Image"] = None) -> "Image":
+        return self._order_stat(radius, 2, trim_fraction, border, out)
+
     def autocontrast(self, cutoff: float = 0.0) -> "Image":
         """Image.autocontrast (image.zig:804), in place."""
         s = self._desc()
