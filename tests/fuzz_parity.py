@@ -50,7 +50,7 @@ def same(a, b):
 
 def case(rng):
     kind = str(rng.choice(KINDS))
-    op = str(rng.choice(["blur", "sep", "conv2d", "box", "resize", "warp", "rotate", "convert", "sobel", "canny", "shen", "motion", "insert_flip", "letterbox_extract"]))
+    op = str(rng.choice(["blur", "sep", "conv2d", "box", "resize", "warp", "rotate", "convert", "sobel", "canny", "shen", "motion", "insert_flip", "letterbox_extract", "misc8"]))
     rows, cols = dim(rng, MAX_ROWS), dim(rng, MAX_COLS)
     img = synth(rng, kind, rows, cols)
     border = int(rng.integers(0, 4))
@@ -135,6 +135,43 @@ def case(rng):
         want = o.insert(img.copy(), source, rect, ang, o.method(om), blend)
         got = D(img.copy()).insert(dev(source), rect, ang, m, blend, cos_sin=cs)
         return f"insert {skind}->{kind} {rows}x{cols} rect={rect} a={ang} blend={blend} view={use_view}", got, want
+    if op == "misc8":  # the u8-family filters: sharpen / integral / invert, thresholds and morphology, enhancement, order statistics
+        which = int(rng.integers(0, 9))
+        u8kind = kind.endswith("u8")
+        if which == 0:
+            rad = int(rng.integers(0, 7))
+            return f"sharpen {kind} {rows}x{cols} r={rad}", D(img).sharpen(rad), o.sharpen(img, rad)
+        if which == 1:
+            got = D(img).integral()
+            return f"integral {kind} {rows}x{cols}", got.cpu().numpy(), o.integral(img)
+        if which == 2 and kind != "f32":
+            return f"invert {kind} {rows}x{cols}", D(img.copy()).invert(), o.invert(img.copy())
+        if not u8kind:
+            return None
+        if which == 3 and kind == "u8":
+            got, gt = D(img).threshold_otsu()
+            want, wt = o.threshold_otsu(img)
+            assert gt == wt, f"otsu threshold {gt} != {wt}"
+            return f"otsu {rows}x{cols}", got, want
+        if which == 4 and kind == "u8":
+            rad, cc = int(rng.integers(1, 9)), float(rng.uniform(-10, 10))
+            return f"adaptive {rows}x{cols} r={rad} c={cc}", D(img).threshold_adaptive_mean(rad, cc), o.threshold_adaptive_mean(img, rad, cc)
+        if which == 5 and kind == "u8":
+            k = (rng.random((int(rng.choice([1, 3, 5])), int(rng.choice([1, 3, 7])))) > 0.3).astype(np.uint8)
+            mop, it = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            mask = (img > 128).astype(np.uint8) * 255
+            return f"morph {rows}x{cols} op={mop} it={it} k={k.shape}", D(mask)._morph(k, it, mop, None), o.morph(mask, k, it, mop)
+        if which == 6:
+            if rng.random() < 0.5:
+                cut = float(rng.choice([0.0, 0.01, 0.2, 0.45]))
+                return f"autocontrast {kind} {rows}x{cols} {cut}", D(img.copy()).autocontrast(cut), o.autocontrast(img.copy(), cut)
+            return f"equalize {kind} {rows}x{cols}", D(img.copy()).equalize(), o.equalize(img.copy())
+        if which == 7 and rows * cols <= 40000:
+            rad, oop = int(rng.integers(0, 4)), int(rng.integers(0, 3))
+            param = float(rng.uniform(0, 1)) if oop == 0 else float(rng.uniform(0, 0.49))
+            return (f"orderstat {kind} {rows}x{cols} r={rad} op={oop} p={param} b={border}", D(img)._order_stat(rad, oop, param, border, None),
+                    o.order_statistic_blur(img, rad, oop, param, border))
+        return None
     if op == "letterbox_extract":
         m, om = methods[int(rng.integers(0, 3))]
         if rng.random() < 0.5:
