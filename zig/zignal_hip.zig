@@ -37,6 +37,9 @@ pub const c = struct {
     pub extern fn zg_flip_top_bottom_host(img: *const ZgImage) c_int;
     /// ImagePyramid.build's loop body (src/image/pyramid.zig:76-92) for device-resident images: blur when sigma > 0.5, then bilinear resize
     pub extern fn zg_pyramid_build_level(source: *const ZgImage, level: *const ZgImage, sigma: f32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_order_statistic_blur_host(src: *const ZgImage, dst: *const ZgImage, radius: u32, op: c_int, param: f64, border: c_int) c_int;
+    pub extern fn zg_autocontrast_host(img: *const ZgImage, cutoff: f32) c_int;
+    pub extern fn zg_equalize_host(img: *const ZgImage) c_int;
     pub extern fn zg_threshold_otsu_host(src: *const ZgImage, dst: *const ZgImage, threshold_out: ?*u8) c_int;
     pub extern fn zg_threshold_adaptive_mean_host(src: *const ZgImage, dst: *const ZgImage, radius: u32, c: f32) c_int;
     pub extern fn zg_morph_host(src: *const ZgImage, dst: *const ZgImage, kernel: [*]const u8, kernel_rows: u32, kernel_cols: u32, iterations: u32, op: c_int) c_int;
@@ -150,6 +153,64 @@ pub fn Image(comptime T: type) type {
             if (!self.base.hasSameShape(out.base)) return error.DimensionMismatch;
             try check(c.zg_box_blur_host(&desc(self.base), &desc(out.base), radius));
         }
+
+        /// reference src/image.zig:653-783: medianBlur / percentileBlur / minBlur / maxBlur share op 0, midpointBlur is op 1,
+        /// alphaTrimmedMeanBlur op 2 (InvalidPercentile / InvalidTrim are decided here so callers keep the reference's errors)
+        pub fn percentileBlur(self: Self, out: Self, allocator: std.mem.Allocator, radius: usize, percentile: f64, border: BorderMode) !void {
+            _ = allocator;
+            if (!self.base.hasSameShape(out.base)) return error.DimensionMismatch;
+            if (radius != 0 and (percentile < 0.0 or percentile > 1.0)) return error.InvalidPercentile;
+            try check(c.zg_order_statistic_blur_host(&desc(self.base), &desc(out.base), @intCast(radius), 0, percentile, @intFromEnum(border)));
+        }
+        pub fn medianBlur(self: Self, out: Self, allocator: std.mem.Allocator, radius: usize) !void {
+            return self.percentileBlur(out, allocator, radius, 0.5, .mirror);
+        }
+        pub fn midpointBlur(self: Self, out: Self, allocator: std.mem.Allocator, radius: usize, border: BorderMode) !void {
+            _ = allocator;
+            if (!self.base.hasSameShape(out.base)) return error.DimensionMismatch;
+            try check(c.zg_order_statistic_blur_host(&desc(self.base), &desc(out.base), @intCast(radius), 1, 0.0, @intFromEnum(border)));
+        }
+        pub fn alphaTrimmedMeanBlur(self: Self, out: Self, allocator: std.mem.Allocator, radius: usize, trim_fraction: f64, border: BorderMode) !void {
+            _ = allocator;
+            if (!self.base.hasSameShape(out.base)) return error.DimensionMismatch;
+            if (!std.math.isFinite(trim_fraction) or trim_fraction < 0.0 or trim_fraction >= 0.5) return error.InvalidTrim;
+            try check(c.zg_order_statistic_blur_host(&desc(self.base), &desc(out.base), @intCast(radius), 2, trim_fraction, @intFromEnum(border)));
+        }
+
+        /// reference src/image.zig:804-829 (in place)
+        pub fn autocontrast(self: Self, cutoff: f32) !void {
+            if (cutoff < 0 or cutoff >= 0.5) return error.InvalidCutoff;
+            try check(c.zg_autocontrast_host(&desc(self.base), cutoff));
+        }
+        pub fn equalize(self: Self) void {
+            check(c.zg_equalize_host(&desc(self.base))) catch unreachable;
+        }
+
+        /// reference src/image.zig:845-914 (Image(u8) only, as there)
+        pub fn thresholdOtsu(self: Self, out: Image(u8), allocator: std.mem.Allocator) !u8 {
+            _ = allocator;
+            if (comptime T != u8) @compileError("thresholdOtsu is only available for Image(u8)");
+            if (!self.base.hasSameShape(out.base)) return error.DimensionMismatch;
+            var t: u8 = 0;
+            try check(c.zg_threshold_otsu_host(&desc(self.base), &Image(u8).desc(out.base), &t));
+            return t;
+        }
+        pub fn thresholdAdaptiveMean(self: Self, out: Image(u8), allocator: std.mem.Allocator, radius: usize, cc: f32) !void {
+            _ = allocator;
+            if (comptime T != u8) @compileError("thresholdAdaptiveMean is only available for Image(u8)");
+            if (!self.base.hasSameShape(out.base)) return error.DimensionMismatch;
+            if (radius == 0) return error.InvalidRadius;
+            try check(c.zg_threshold_adaptive_mean_host(&desc(self.base), &Image(u8).desc(out.base), @intCast(radius), cc));
+        }
+        fn morph(self: Self, out: Image(u8), kernel: zignal.BinaryKernel, iterations: usize, op: c_int) !void {
+            if (comptime T != u8) @compileError("binary morphology is only available for Image(u8)");
+            if (!self.base.hasSameShape(out.base)) return error.DimensionMismatch;
+            try check(c.zg_morph_host(&desc(self.base), &Image(u8).desc(out.base), kernel.data.ptr, @intCast(kernel.rows), @intCast(kernel.cols), @intCast(iterations), op));
+        }
+        pub fn dilateBinary(self: Self, out: Image(u8), _: std.mem.Allocator, kernel: zignal.BinaryKernel, iterations: usize) !void { return self.morph(out, kernel, iterations, 0); }
+        pub fn erodeBinary(self: Self, out: Image(u8), _: std.mem.Allocator, kernel: zignal.BinaryKernel, iterations: usize) !void { return self.morph(out, kernel, iterations, 1); }
+        pub fn openBinary(self: Self, out: Image(u8), _: std.mem.Allocator, kernel: zignal.BinaryKernel, iterations: usize) !void { return self.morph(out, kernel, iterations, 2); }
+        pub fn closeBinary(self: Self, out: Image(u8), _: std.mem.Allocator, kernel: zignal.BinaryKernel, iterations: usize) !void { return self.morph(out, kernel, iterations, 3); }
 
         /// reference src/image.zig:785-801
         pub fn sharpen(self: Self, out: Self, allocator: std.mem.Allocator, radius: usize) !void {

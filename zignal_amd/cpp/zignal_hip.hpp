@@ -111,6 +111,12 @@ template <typename T> class Image {
         const zg_image s = desc(), d = out.desc();
         check(zg_box_blur_host(&s, &d, radius));
     }
+    void medianBlur(const Image &out, uint32_t radius) const {                            // image.zig:653
+        if (!hasSameShape(out)) throw DimensionMismatch(1, "medianBlur");
+        const zg_image s = desc(), d = out.desc();
+        check(zg_order_statistic_blur_host(&s, &d, radius, 0, 0.5, ZG_BORDER_MIRROR));
+    }
+    void equalize() const { const zg_image s = desc(); check(zg_equalize_host(&s)); }     // image.zig:824 (in place)
     void sharpen(const Image &out, uint32_t radius) const {                               // image.zig:785
         if (!hasSameShape(out)) throw DimensionMismatch(1, "sharpen");
         const zg_image s = desc(), d = out.desc();
