@@ -137,3 +137,17 @@ def test_python_mirror_validation():
         img.copy(zg.Image(np.zeros((4, 5), np.uint8)))
     assert img.view((10, 10, 20, 20)).rows == 0  # no overlap -> Image.empty
     assert np.array_equal(img.copy().data, img.data)
+
+
+def test_ctypes_signatures_match_header_arity():
+    """Every prototype in include/zignal_hip.h has the same number of parameters as its ctypes binding."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "zignal_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = re.findall(r"ZG_API\s+[\w\s\*]+?\b(zg_\w+)\s*\(([^;]*?)\)\s*;", hdr, flags=re.S)
+    assert len(protos) >= 70
+    for name, args in protos:
+        args = args.strip()
+        n = 0 if args in ("", "void") else len(args.split(","))
+        assert name in L._SIGNATURES, name
+        assert len(L._SIGNATURES[name]) == n, f"{name}: header has {n} parameters, _lib.py binds {len(L._SIGNATURES[name])}"
