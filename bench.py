@@ -91,11 +91,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # ZG_BENCH_SHARED_GPU=1 (test hook, never set by the driver): every rank uses cuda:0 and the few control-plane
+    # collectives run over gloo, so the N > 1 code path can be exercised on a one-GPU box. Rates measured that way mean nothing.
+    shared_gpu = os.environ.get("ZG_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     torch.cuda.set_device(local_rank)
     lib = zg.lib()
@@ -159,7 +167,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     from zignal_amd import sharding
-    elapsed = sharding.max_over_ranks(elapsed, torch.device("cuda", local_rank))  # the slowest rank is the clock
+    elapsed = sharding.max_over_ranks(elapsed, torch.device("cpu") if shared_gpu else torch.device("cuda", local_rank))  # the slowest rank is the clock
 
     pixels = ROWS * COLS
     value = world * pixels * args.steps / elapsed / 1e6
