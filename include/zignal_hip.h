@@ -304,14 +304,14 @@ ZG_API int zg_morph_host(const zg_image *src, const zg_image *dst, const uint8_t
 /* Image(T).canny (src/image.zig:1047-1063 -> src/image/edges.zig:212-277): grey -> the detector's own Gaussian
  * (.replicate; sigma == 0 skips it) -> Sobel gradients -> non-maximum suppression -> double threshold + hysteresis.
  * dst is Image(u8), 0 or 255. error.InvalidParameter / InvalidSigma / InvalidThreshold -> ZG_ERR_INVALID_ARGUMENT.
- * Hysteresis iterates to a fixed point: the call synchronises `stream` (it cannot be captured into a graph). */
+ * Hysteresis is connected-component labelling in a fixed number of launches: the call is asynchronous on `stream`. */
 ZG_API int zg_canny(const zg_image *src, const zg_image *dst, float sigma, float low_threshold, float high_threshold, zg_stream stream);
 ZG_API int zg_canny_host(const zg_image *src, const zg_image *dst, float sigma, float low_threshold, float high_threshold);
 
 /* Image(T).shenCastan (src/image.zig:1015-1027 -> src/image/edges.zig:83-196; options src/image/ShenCastan.zig:9-45:
  * smooth 0.9, window_size 7, high_ratio 0.99, low_rel 0.5, hysteresis true, use_nms false by default). dst is Image(u8),
  * 0 or 255. InvalidBParameter / WindowSizeMustBeOdd / WindowSizeTooSmall / InvalidThreshold -> ZG_ERR_INVALID_ARGUMENT.
- * With hysteresis the call synchronises `stream` (fixed-point iteration), as zg_canny does. */
+ * Asynchronous on `stream` with or without hysteresis (the thresholds never leave the device). */
 ZG_API int zg_shen_castan(const zg_image *src, const zg_image *dst, float smooth, uint32_t window_size, float high_ratio, float low_rel,
                           int hysteresis, int use_nms, zg_stream stream);
 ZG_API int zg_shen_castan_host(const zg_image *src, const zg_image *dst, float smooth, uint32_t window_size, float high_ratio, float low_rel,

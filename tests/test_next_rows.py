@@ -190,6 +190,33 @@ def test_canny_long_chain_across_tiles(oracle):
     assert (want > 0).sum() > 500
 
 
+@pytest.mark.gpu
+def test_edge_detectors_are_graph_capturable(oracle):
+    """Neither detector synchronises its stream: both record into one HIP graph, and the replay is still bit-exact."""
+    import torch
+    import zignal_amd as zg
+    from tests.util import assert_bits_equal
+    host = synth(oracle, "rgba_u8", 5, 150, 203)
+    src = zg.Image(torch.from_numpy(host).cuda())
+    out_c = zg.Image(torch.zeros((150, 203), dtype=torch.uint8, device="cuda"))
+    out_s = zg.Image(torch.zeros((150, 203), dtype=torch.uint8, device="cuda"))
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        src.canny(1.0, 40, 120, out=out_c)  # warm the scratch pool outside the capture
+        src.shen_castan(out=out_s)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            src.canny(1.0, 40, 120, out=out_c)
+            src.shen_castan(out=out_s)
+    out_c.data.zero_(); out_s.data.zero_()
+    torch.cuda.synchronize()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert_bits_equal(out_c.to_numpy(), oracle.canny(host, 1.0, 40, 120), "captured canny")
+    assert_bits_equal(out_s.to_numpy(), oracle.shen_castan(host), "captured shen-castan")
+
+
 # ---- motion blur (image.zig:1077-1091 -> motion_blur.zig), SURVEY §8f rank 4 ------------------------------------------
 def test_motion_blur_reference_known_answers_oracle(oracle):  # tests/filters.zig:969-1160
     import math

@@ -92,9 +92,8 @@ static int sobel_impl(const zg_image *src, const zg_image *dst, hipStream_t s) {
 // non-maximum suppression -> double threshold + hysteresis. The reference materialises six full planes and walks a BFS
 // queue; here: one grey kernel, the library's separable convolution, ONE fused kernel for gradients + magnitude + NMS +
 // classification (a 2-pixel halo of the blurred plane in LDS; its output is a single byte per pixel: 0 none, 1 weak, 2
-// strong), and hysteresis as monotone label propagation (weak pixels 8-adjacent to a strong one become strong), iterated
-// to a fixed point inside each tile in LDS and across tiles by relaunching until a pass changes nothing. The fixed point
-// is the BFS's reachable set, so the edge map is identical whatever the order.
+// strong), and hysteresis as connected-component labelling (see run_hysteresis): the BFS's reachable set, in a fixed
+// number of kernels.
 
 template <int PIX> __device__ inline float canny_gray(typename Px<PIX>::Vec v) { // as(f32, convertColor(u8, px)), edges.zig:231-240
     if constexpr (PIX == ZG_PIXEL_F32) { // scalar float -> u8 in f64 (color.zig:114-118)
@@ -175,91 +174,125 @@ __global__ __launch_bounds__(256) void k_canny_nms(const float *blur, uint8_t *s
     state[(size_t)r * cols + c] = st;
 }
 
-// One hysteresis pass: every 64 x 16 tile (+ 1-pixel halo) runs to its local fixed point in LDS. Only 1 -> 2 transitions
-// exist, so concurrent tiles reading each other's halo see either value of a pixel and the iteration is monotone.
-// A tile can only change if it or one of its eight neighbours changed in the previous pass (`prev`, one byte per tile;
-// null on the first pass): settled regions cost one flag test per workgroup.
-__global__ __launch_bounds__(256) void k_canny_hysteresis(uint8_t *state, int rows, int cols, int tiles_x, int tiles_y, const uint8_t *prev, uint8_t *cur,
-                                                          int *changed) {
-    __shared__ uint8_t t[18][66];
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    if (prev) {
-        bool live = false;
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int ny = ty + dy, nx = tx + dx;
-                if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) live |= prev[ny * tiles_x + nx] != 0;
-            }
-        if (!live) return; // workgroup-uniform
+// Hysteresis (edges.zig:499-576): a weak candidate becomes an edge iff it is 8-connected, through candidates, to a strong
+// one. The reference grows the set with a BFS queue; the set itself is "the connected components of the candidate mask
+// that contain a strong pixel", which a lock-free union-find labels in a fixed number of kernels (no convergence loop, no
+// host synchronisation, so the detectors stay asynchronous and graph-capturable):
+//   k_cc_init   every candidate points at the start of its horizontal run (inside a 64-pixel segment), everything else -1
+//   k_cc_union  runs are united across segment boundaries and with the candidates of the row below (SW / S / SE; the
+//               upward directions are the same pairs seen from the other side); roots only ever move to smaller
+//               indices (atomicMin), so the structure stays a forest whatever the interleaving
+//   k_cc_flag   every strong pixel marks its root; the emit kernel turns the weak pixels of marked roots into edges
+__device__ inline int cc_find(int *label, int x) {
+    int p = label[x];
+    while (p != x) { // path halving (plain stores: another lane can only have written a smaller ancestor)
+        const int gp = label[p];
+        if (gp != p) label[x] = gp;
+        x = p;
+        p = gp;
     }
-    const int x0 = tx * 64, y0 = ty * 16;
-    for (int i = threadIdx.x; i < 18 * 66; i += 256) {
-        const int r = i / 66, c = i - r * 66;
-        const int gr = y0 - 1 + r, gc = x0 - 1 + c;
-        t[r][c] = (gr >= 0 && gr < rows && gc >= 0 && gc < cols) ? state[(size_t)gr * cols + gc] : (uint8_t)0;
-    }
-    __syncthreads();
-    const int lx = threadIdx.x & 63, ly4 = (threadIdx.x >> 6) * 4; // four rows per thread
-    bool any = false;
+    return x;
+}
+__device__ inline void cc_unite(int *label, int a, int b) {
     for (;;) {
-        bool mine = false;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = ly4 + k + 1, c = lx + 1;
-            if (t[r][c] == 1) {
-                const bool strong = t[r - 1][c - 1] == 2 || t[r - 1][c] == 2 || t[r - 1][c + 1] == 2 || t[r][c - 1] == 2 || t[r][c + 1] == 2 ||
-                                    t[r + 1][c - 1] == 2 || t[r + 1][c] == 2 || t[r + 1][c + 1] == 2;
-                if (strong) { t[r][c] = 2; mine = true; }
-            }
-        }
-        any |= mine;
-        if (!__syncthreads_or(mine)) break;
-    }
-    if (any) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = y0 + ly4 + k, c = x0 + lx;
-            if (r < rows && c < cols && t[ly4 + k + 1][lx + 1] == 2) state[(size_t)r * cols + c] = 2;
-        }
-        cur[blockIdx.x] = 1; // benign same-value races
-        *changed = 1;
+        a = cc_find(label, a);
+        b = cc_find(label, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; } // a > b: hang a under b
+        const int old = atomicMin(&label[a], b);
+        if (old == a) return; // a was still a root: linked
+        a = old;              // someone re-rooted a in the meantime: retry from its new parent
     }
 }
-
-// Runs hysteresis passes on `state` until one changes nothing. `work` holds PASSES ints and two tile-flag arrays.
-static int run_hysteresis(uint8_t *state, uint32_t rows, uint32_t cols, char *work, hipStream_t s, const char *who) {
-    constexpr int PASSES = 4;
-    const int tiles_x = (int)ceil_div(cols, 64), tiles_y = (int)ceil_div(rows, 16), nt = tiles_x * tiles_y;
-    int *flags = (int *)work;
-    uint8_t *tf[2] = {(uint8_t *)(flags + PASSES), (uint8_t *)(flags + PASSES) + (size_t)(nt + 15) / 16 * 16};
-    int host_flags[PASSES];
-    int parity = 0;
-    bool first = true;
-    for (;;) { // passes go out four at a time; the stream is synchronised to read whether the last one still changed anything
-        if (hipMemsetAsync(flags, 0, PASSES * sizeof(int), s) != hipSuccess) return ZG_ERR_HIP;
-        for (int p = 0; p < PASSES; ++p) {
-            if (hipMemsetAsync(tf[parity], 0, (size_t)nt, s) != hipSuccess) return ZG_ERR_HIP;
-            hipLaunchKernelGGL(k_canny_hysteresis, dim3((unsigned)nt), dim3(256), 0, s, state, (int)rows, (int)cols, tiles_x, tiles_y,
-                               first ? (const uint8_t *)nullptr : (const uint8_t *)tf[parity ^ 1], tf[parity], flags + p);
-            first = false;
-            parity ^= 1;
-        }
-        if (hipMemcpyAsync(host_flags, flags, sizeof host_flags, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-            set_error("%s: reading the hysteresis flags failed", who);
-            return ZG_ERR_HIP;
-        }
-        if (!host_flags[PASSES - 1]) return ZG_OK;
+// One wave per 64-pixel row segment: a candidate starts under the first pixel of its horizontal run inside the segment
+// (ballot + count-leading-zeros, no memory traffic), so the union pass only has to stitch runs together.
+__global__ __launch_bounds__(256) void k_cc_init(const uint8_t *state, int *label, uint8_t *flag, int rows, int cols) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 64 + lane, r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return; // wave-uniform
+    const bool cand = c < cols && state[(size_t)r * cols + c] != 0;
+    const unsigned long long gaps = ~__ballot(cand) & ((1ull << lane) - 1); // non-candidates to my left
+    if (c >= cols) return;
+    const int start = gaps ? 64 - __clzll(gaps) : 0;
+    const int i = r * cols + c;
+    label[i] = cand ? i - (lane - start) : -1;
+    flag[i] = 0;
+}
+// Stitches runs: across a segment boundary (lane 0 with its W neighbour) and to the row below. Links the run structure
+// already implies are skipped: with S a candidate, SW and SE hang off S's run, and S itself is implied when W and SW are
+// both candidates (the pixel to the left makes the same link); without S, SW is implied by W and SE by E.
+__global__ __launch_bounds__(256) void k_cc_union(const uint8_t *state, int *label, int rows, int cols) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 64 + lane, r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (c >= cols || r >= rows) return;
+    const int i = r * cols + c;
+    if (!state[i]) return;
+    const bool w = c > 0 && state[i - 1], e = c + 1 < cols && state[i + 1];
+    if (lane == 0 && w) cc_unite(label, i, i - 1);
+    if (r + 1 >= rows) return;
+    const bool sw = c > 0 && state[i + cols - 1], so = state[i + cols], se = c + 1 < cols && state[i + cols + 1];
+    if (so) {
+        if (!(w && sw)) cc_unite(label, i, i + cols);
+    } else {
+        if (sw && !w) cc_unite(label, i, i + cols - 1);
+        if (se && !e) cc_unite(label, i, i + cols + 1);
     }
+}
+__global__ __launch_bounds__(256) void k_cc_flag(const uint8_t *state, int *label, uint8_t *flag, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && state[i] == 2) flag[cc_find(label, (int)i)] = 1;
+}
+// Labels the candidates of `state` and marks the roots of the components that hold a strong pixel; k_canny_emit then
+// resolves each weak pixel through its root. `work` holds an int label and a flag byte per pixel.
+static int run_hysteresis(uint8_t *state, uint32_t rows, uint32_t cols, char *work, hipStream_t s, const char *who) {
+    const size_t n = (size_t)rows * cols;
+    if (n > 0x7fffffffu) { set_error("%s: hysteresis labels are 32-bit (rows * cols must stay below 2^31)", who); return ZG_ERR_UNSUPPORTED; }
+    int *label = (int *)work;
+    uint8_t *flag = (uint8_t *)(label + n);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    const dim3 seg_grid(ceil_div(cols, 64), ceil_div(rows, 4));
+    hipLaunchKernelGGL(k_cc_init, seg_grid, dim3(256), 0, s, (const uint8_t *)state, label, flag, (int)rows, (int)cols);
+    hipLaunchKernelGGL(k_cc_union, seg_grid, dim3(256), 0, s, (const uint8_t *)state, label, (int)rows, (int)cols);
+    hipLaunchKernelGGL(k_cc_flag, dim3(nb), dim3(256), 0, s, (const uint8_t *)state, label, flag, n);
+    if (hipGetLastError() != hipSuccess) { set_error("%s: hysteresis launch failed", who); return ZG_ERR_HIP; }
+    return ZG_OK;
 }
 static size_t hysteresis_work_bytes(uint32_t rows, uint32_t cols) {
-    const size_t nt = (size_t)ceil_div(cols, 64) * ceil_div(rows, 16);
-    return 4 * sizeof(int) + 2 * ((nt + 15) / 16 * 16) + 64;
+    const size_t n = (size_t)rows * cols;
+    return n * sizeof(int) + n + 64;
 }
 
-__global__ __launch_bounds__(256) void k_canny_emit(const uint8_t *state, DImg dst) { // out = 255 on edges, 0 elsewhere (edges.zig:511-515)
-    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
-    if (c >= dst.cols) return;
-    ((uint8_t *)dst.data)[(size_t)r * dst.stride + c] = state[(size_t)r * dst.cols + c] == 2 ? 255 : 0;
+// out = 255 on edges, 0 elsewhere (edges.zig:511-515). A strong pixel is an edge; a weak one is an edge when hysteresis
+// ran (label != nullptr) and its component's root is flagged. Four pixels per lane; VEC moves them as one dword.
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_canny_emit(const uint8_t *state, int *label, const uint8_t *flag, DImg dst) {
+    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4, r = blockIdx.y;
+    if (c0 >= dst.cols) return;
+    const size_t i0 = (size_t)r * dst.cols + c0;
+    uint8_t *out = (uint8_t *)dst.data + (size_t)r * dst.stride + c0;
+    uint8_t st[4];
+    const int nvalid = dst.cols - c0 < 4 ? dst.cols - c0 : 4;
+    if (VEC) {
+        *(uint32_t *)st = *(const uint32_t *)(state + i0);
+    } else {
+        for (int j = 0; j < 4; ++j) st[j] = j < nvalid ? state[i0 + j] : 0;
+    }
+    uint8_t px[4];
+    for (int j = 0; j < 4; ++j) {
+        bool edge = st[j] == 2;
+        if (st[j] == 1 && label) edge = flag[cc_find(label, (int)(i0 + j))] != 0;
+        px[j] = edge ? 255 : 0;
+    }
+    if (VEC) {
+        *(uint32_t *)out = *(const uint32_t *)px;
+    } else {
+        for (int j = 0; j < nvalid; ++j) out[j] = px[j];
+    }
+}
+static int launch_emit(const uint8_t *state, int *label, const uint8_t *flag, const zg_image *dst, hipStream_t s) {
+    const dim3 grid(ceil_div(dst->cols, 1024), dst->rows);
+    const bool vec = dst->cols % 4 == 0 && dst->stride % 4 == 0 && (uintptr_t)dst->data % 4 == 0;
+    if (vec) hipLaunchKernelGGL(k_canny_emit<true>, grid, dim3(256), 0, s, state, label, flag, dimg(dst));
+    else hipLaunchKernelGGL(k_canny_emit<false>, grid, dim3(256), 0, s, state, label, flag, dimg(dst));
+    return hipGetLastError() == hipSuccess ? ZG_OK : ZG_ERR_HIP;
 }
 
 static int canny_impl(const zg_image *src, const zg_image *dst, float sigma, float low, float high, zg_stream stream) {
@@ -310,10 +343,7 @@ static int canny_impl(const zg_image *src, const zg_image *dst, float sigma, flo
         const int tiles_x = (int)ceil_div(cols, 64), tiles_y = (int)ceil_div(rows, 4);
         hipLaunchKernelGGL(k_canny_nms, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, blurred, state, (int)rows, (int)cols, low, high, tiles_x);
         rc = run_hysteresis(state, rows, cols, work, s, "canny");
-        if (rc == ZG_OK) {
-            hipLaunchKernelGGL(k_canny_emit, dim3(ceil_div(cols, 256), rows), dim3(256), 0, s, (const uint8_t *)state, dimg(dst));
-            if (hipGetLastError() != hipSuccess) rc = ZG_ERR_HIP;
-        }
+        if (rc == ZG_OK) rc = launch_emit(state, (int *)work, (const uint8_t *)((int *)work + n), dst, s);
     }
     scratch_free(scratch, s);
     return rc;
@@ -617,10 +647,7 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
         if (hipGetLastError() != hipSuccess) rc = ZG_ERR_HIP;
     }
     if (rc == ZG_OK && hysteresis) rc = run_hysteresis(state, rows, cols, work, s, "shenCastan");
-    if (rc == ZG_OK) {
-        hipLaunchKernelGGL(k_canny_emit, dim3(ceil_div(cols, 256), rows), dim3(256), 0, s, (const uint8_t *)state, dimg(dst));
-        if (hipGetLastError() != hipSuccess) rc = ZG_ERR_HIP;
-    }
+    if (rc == ZG_OK) rc = launch_emit(state, hysteresis ? (int *)work : nullptr, (const uint8_t *)((int *)work + n), dst, s);
     scratch_free(scratch, s);
     return rc;
 }

@@ -396,7 +396,7 @@ class Image:
 
     def canny(self, sigma: float, low_threshold: float, high_threshold: float, out: Optional["Image"] = None) -> "Image":
         """Image.canny (image.zig:1047-1063): binary edge map (0 / 255) as Image(u8). Raises InvalidArgument for the
-        reference's InvalidParameter / InvalidSigma / InvalidThreshold. Synchronises the stream (hysteresis fixed point)."""
+        reference's InvalidParameter / InvalidSigma / InvalidThreshold. Asynchronous on the current stream."""
         if out is None:
             out = self._like(dtype=torch.uint8 if self.on_device else np.uint8, channels=1)
         self._same_side(out)
