@@ -468,3 +468,129 @@ def pyramid(source, n_levels, scale_factor, blur_sigma):
         base = gaussian_blur(source, sig.value) if sig.value > 0.5 else source
         levels.append(resize(base, (r.value, c.value), method(BILINEAR)))
     return levels
+
+
+# ---- PNG (oracle/png.c; src/codecs/png.zig) -------------------------------------------------------
+
+class PngError(Exception):
+    """One of the reference's PNG errors; `.name` is the Zig error name (error.InvalidCrc -> "InvalidCrc")."""
+
+    def __init__(self, name: str):
+        super().__init__(name)
+        self.name = name
+
+
+class ZoPngHeader(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("bit_depth", C.c_uint8), ("color_type", C.c_uint8),
+                ("compression_method", C.c_uint8), ("filter_method", C.c_uint8), ("interlace_method", C.c_uint8),
+                ("has_gamma", C.c_uint8), ("has_srgb", C.c_uint8), ("srgb_intent", C.c_uint8), ("gamma", C.c_float)]
+
+
+class ZoPngLimits(C.Structure):
+    _fields_ = [("max_png_bytes", C.c_size_t), ("max_chunk_bytes", C.c_size_t), ("max_idat_bytes", C.c_size_t),
+                ("max_chunks", C.c_size_t), ("max_width", C.c_uint32), ("max_height", C.c_uint32),
+                ("max_pixels", C.c_uint64), ("max_decompressed_bytes", C.c_size_t)]
+
+
+def png_limits(**overrides) -> ZoPngLimits:
+    lim = ZoPngLimits()
+    lib().zo_png_default_limits(C.byref(lim))
+    for k, v in overrides.items():
+        setattr(lim, k, v)
+    return lim
+
+
+def _png_check(rc: int):
+    if rc != 0:
+        fn = lib().zo_png_error_name
+        fn.restype = C.c_char_p
+        raise PngError(fn(rc).decode())
+
+
+def _png_buf(data: bytes):
+    return (C.c_uint8 * max(1, len(data))).from_buffer_copy(data if len(data) else b"\0")
+
+
+def png_crc(data: bytes) -> int:
+    fn = lib().zo_png_crc
+    fn.restype = C.c_uint32
+    fn.argtypes = [C.c_void_p, C.c_size_t]
+    return fn(_png_buf(data), len(data))
+
+
+def png_paeth(a: int, b: int, c: int) -> int:
+    fn = lib().zo_png_paeth
+    fn.restype = C.c_uint8
+    return fn(a, b, c)
+
+
+def png_info(data: bytes, limits: ZoPngLimits | None = None) -> ZoPngHeader:
+    h = ZoPngHeader()
+    fn = lib().zo_png_info
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    _png_check(fn(_png_buf(data), len(data), C.byref(limits) if limits else None, C.byref(h)))
+    return h
+
+
+def png_decode_chunks(data: bytes, limits: ZoPngLimits | None = None):
+    """png.decode: (header, truncated, palette_len or -1, trns_len or -1)."""
+    h, t, pl, tl = ZoPngHeader(), C.c_int(0), C.c_int(0), C.c_int(0)
+    fn = lib().zo_png_decode_chunks
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p] + [C.c_void_p] * 4
+    _png_check(fn(_png_buf(data), len(data), C.byref(limits) if limits else None, C.byref(h), C.byref(t), C.byref(pl), C.byref(tl)))
+    return h, bool(t.value), pl.value, tl.value
+
+
+def png_decode_native(data: bytes, limits: ZoPngLimits | None = None):
+    """png.decode + png.toNativeImage: (pixels ndarray in the native type, truncated, header)."""
+    h, native, t, px = ZoPngHeader(), C.c_int(0), C.c_int(0), C.c_void_p()
+    fn = lib().zo_png_decode_native
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p] + [C.c_void_p] * 4
+    _png_check(fn(_png_buf(data), len(data), C.byref(limits) if limits else None, C.byref(h), C.byref(native), C.byref(px), C.byref(t)))
+    ch = {U8: 1, RGB_U8: 3, RGBA_U8: 4}[native.value]
+    n = h.height * h.width * ch
+    arr = np.frombuffer(C.string_at(px.value, n), np.uint8).copy()
+    free = lib().zo_png_free
+    free.argtypes = [C.c_void_p]
+    free(px)
+    return arr.reshape((h.height, h.width) if ch == 1 else (h.height, h.width, ch)), bool(t.value), h
+
+
+def png_load(data: bytes, kind: str, limits: ZoPngLimits | None = None) -> np.ndarray:
+    """png.loadFromBytes(T): the native image, converted with Image.convert when T differs (png.zig:1151-1186)."""
+    native, _, _ = png_decode_native(data, limits)
+    spaces = {1: CS_GRAY, 3: CS_RGB, 4: CS_RGBA}
+    ch = {"u8": 1, "rgb_u8": 3, "rgba_u8": 4}[kind]
+    nch = 1 if native.ndim == 2 else native.shape[2]
+    if nch == ch:
+        return native
+    return convert(native, spaces[nch], spaces[ch], np.uint8, ch)
+
+
+PNG_ADAPTIVE = -1
+
+
+def png_filter(img: np.ndarray, mode: int = PNG_ADAPTIVE) -> np.ndarray:
+    """filterScanlines / filterScanlinesAdaptive on an 8-bit u8 / rgb / rgba image: rows x (1 + row bytes)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    rows = img.shape[0]
+    bpp = 1 if img.ndim == 2 else img.shape[2]
+    rb = img.shape[1] * bpp
+    out = np.empty((rows, rb + 1), np.uint8)
+    fn = lib().zo_png_filter
+    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+    _png_check(fn(img.ctypes.data, rows, rb, bpp, mode, out.ctypes.data))
+    return out
+
+
+def png_encode_stored(img: np.ndarray, mode: int = PNG_ADAPTIVE) -> bytes:
+    im = as_image(np.ascontiguousarray(img))
+    out, n = C.c_void_p(), C.c_size_t(0)
+    fn = lib().zo_png_encode_stored
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    _png_check(fn(C.byref(im), mode, C.byref(out), C.byref(n)))
+    data = C.string_at(out.value, n.value)
+    free = lib().zo_png_free
+    free.argtypes = [C.c_void_p]
+    free(out)
+    return data

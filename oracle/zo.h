@@ -115,4 +115,32 @@ ZO_API void zo_srgb_to_linear_lut(float lut[256]);
 /* homography (geometry/transforms.zig:242-263, exact 4-point solve in f64 then cast) */
 ZO_API int zo_homography_from_4pts(const double from_xy[8], const double to_xy[8], float m_out[9]);
 
+/* png.c — src/codecs/png.zig (the host I/O edge of the path). Status codes are the reference's error
+ * set in the order of zo_png_error_name(); 0 = ok. */
+typedef struct zo_png_header { /* png.zig:135-149 */
+    uint32_t width, height;
+    uint8_t bit_depth, color_type, compression_method, filter_method, interlace_method;
+    uint8_t has_gamma, has_srgb, srgb_intent;
+    float gamma;
+} zo_png_header;
+typedef struct zo_png_limits { /* png.zig:23-41; 0 disables a limit */
+    size_t max_png_bytes, max_chunk_bytes, max_idat_bytes, max_chunks;
+    uint32_t max_width, max_height;
+    uint64_t max_pixels;
+    size_t max_decompressed_bytes;
+} zo_png_limits;
+ZO_API const char *zo_png_error_name(int code);
+ZO_API void zo_png_default_limits(zo_png_limits *l);
+ZO_API uint32_t zo_png_crc(const uint8_t *p, size_t n);
+ZO_API uint8_t zo_png_paeth(int a, int b, int c);
+ZO_API int zo_png_info(const uint8_t *png, size_t len, const zo_png_limits *limits, zo_png_header *out);
+ZO_API int zo_png_decode_chunks(const uint8_t *png, size_t len, const zo_png_limits *limits, zo_png_header *header_out, int *truncated_out,
+                                int *palette_len, int *trns_len);
+/* decode + toNativeImage: *pixels_out is malloc'd (rows * cols of the native pixel type ZO_U8 / ZO_RGB_U8 / ZO_RGBA_U8), free with zo_png_free */
+ZO_API int zo_png_decode_native(const uint8_t *png, size_t len, const zo_png_limits *limits, zo_png_header *header_out, int *native_out,
+                                uint8_t **pixels_out, int *truncated_out);
+ZO_API void zo_png_free(void *p);
+ZO_API int zo_png_filter(const uint8_t *raw, uint32_t rows, size_t row_bytes, int bpp, int mode, uint8_t *filtered);
+ZO_API int zo_png_encode_stored(const zo_image *img, int mode, uint8_t **out, size_t *out_len);
+
 #endif
