@@ -40,7 +40,9 @@ typedef enum zg_status {
     ZG_ERR_INVALID_ARGUMENT = 2,   /* error.InvalidSigma (:970), InvalidScaleFactor / InvalidDimensions (:531-536) */
     ZG_ERR_OUT_OF_MEMORY = 3,      /* error.OutOfMemory (device scratch) */
     ZG_ERR_HIP = 4,                /* HIP runtime error; see zg_last_error() */
-    ZG_ERR_UNSUPPORTED = 5         /* pixel type / op combination the reference rejects at comptime */
+    ZG_ERR_UNSUPPORTED = 5,        /* pixel type / op combination the reference rejects at comptime */
+    ZG_ERR_CODEC = 6               /* an error of the reference's codec error sets (src/codecs/png.zig); zg_last_error() STARTS WITH the
+                                      Zig error name, e.g. "InvalidCrc", "NonConsecutiveIdatChunks", "ImageTooLarge" */
 } zg_status;
 
 /* Pixel layouts. Element index is row*stride + col, stride in PIXELS (src/image.zig:426-430). */
@@ -345,6 +347,63 @@ ZG_API int zg_batch_blur_resize(const void *src_frames, uint32_t n_frames,
                                 uint32_t rows, uint32_t cols, int pixel, float sigma,
                                 void *dst_frames, uint32_t out_rows, uint32_t out_cols,
                                 const zg_method *method, zg_stream stream);
+
+/* ---- the host I/O edge: PNG (src/codecs/png.zig) -------------------------- */
+
+/* Where frames come from and go to. The entropy-coded layers stay on the host (the chunk layer with the reference's
+ * ordering rules and limits, zlib inflate / deflate, and de-filtering, which is a serial recurrence along and across
+ * rows); the per-pixel layers run on the device: sample unpacking (1/2/4/8/16 bit, palette, tRNS, Adam7 placement,
+ * conversion to the requested Image(T)) on the way in, filter selection and row filtering on the way out. */
+typedef struct zg_png_header { /* png.Header (png.zig:135-149) */
+    uint32_t width, height;
+    uint8_t bit_depth, color_type /* 0 grey, 2 rgb, 3 palette, 4 grey+alpha, 6 rgba */, compression_method, filter_method, interlace_method;
+    uint8_t has_gamma, has_srgb, srgb_intent;
+    float gamma;
+} zg_png_header;
+typedef struct zg_png_limits { /* png.DecodeLimits (png.zig:23-41); a zero disables that limit */
+    size_t max_png_bytes, max_chunk_bytes, max_idat_bytes, max_chunks;
+    uint32_t max_width, max_height;
+    uint64_t max_pixels;
+    size_t max_decompressed_bytes;
+} zg_png_limits;
+typedef struct zg_png_encode_options { /* png.EncodeOptions (png.zig:1296-1316) */
+    int filter;            /* ZG_PNG_FILTER_ADAPTIVE (the default), or a fixed FilterType 0 none, 1 sub, 2 up, 3 average, 4 paeth */
+    int compression_level; /* zlib level 0..9; negative = the library default (5, Z_FILTERED: the reference's "filtered" preset) */
+    int has_gamma;         /* write a gAMA chunk (ignored when srgb_intent >= 0, as in the reference) */
+    float gamma;
+    int srgb_intent;       /* 0..3 writes an sRGB chunk; negative = none */
+} zg_png_encode_options;
+#define ZG_PNG_FILTER_ADAPTIVE (-1)
+
+ZG_API void zg_png_default_limits(zg_png_limits *limits);                 /* DecodeLimits{} */
+ZG_API void zg_png_default_encode_options(zg_png_encode_options *options); /* EncodeOptions.default */
+/* png.getInfo (png.zig:308-410): header + gAMA / sRGB metadata, reading no further than the first IDAT. limits may be NULL. */
+ZG_API int zg_png_info(const uint8_t *png, size_t len, const zg_png_limits *limits, zg_png_header *out);
+/* png.decode (png.zig:629-794), the chunk layer only: validates every chunk (order, CRC, limits), and reports the header,
+ * the pixel type png.toNativeImage would produce (ZG_PIXEL_U8 / RGB_U8 / RGBA_U8, png.zig:852-1146) and whether the file
+ * is cut short (missing IEND). Nothing is inflated. */
+ZG_API int zg_png_probe(const uint8_t *png, size_t len, const zg_png_limits *limits, zg_png_header *header_out, int *native_pixel_out,
+                        int *truncated_out);
+/* png.loadFromBytes(T) (png.zig:1151-1186): decode into `dst` (rows x cols must equal the header's height x width, else
+ * ZG_ERR_DIMENSION_MISMATCH). dst's pixel type and dst_space name T exactly as in zg_convert: when T is not the native
+ * type the native image is converted with Image.convert. Cut pixel data decodes partially (whole rows kept, the rest
+ * zero) and sets *truncated_out (may be NULL). `png` is host memory; dst is device memory (zg_png_decode) or host memory
+ * (zg_png_decode_host). The host part (inflate, de-filter) completes before the call returns; the upload and the device
+ * kernels are ordered on `stream`. */
+ZG_API int zg_png_decode(const uint8_t *png, size_t len, const zg_png_limits *limits, const zg_image *dst, int dst_space, int *truncated_out,
+                         zg_stream stream);
+ZG_API int zg_png_decode_host(const uint8_t *png, size_t len, const zg_png_limits *limits, const zg_image *dst, int dst_space, int *truncated_out);
+/* filterScanlines / filterScanlinesAdaptive (png.zig:1265-1294, :1661-1719) on an 8-bit Image(u8 / Rgb / Rgba): writes
+ * rows * (1 + cols * channels) bytes to `filtered` (device memory): per row the filter byte, then the filtered bytes.
+ * Adaptive: per-row costs of all five filters in one pass, the reference's sampling state machine on the device, then
+ * the chosen filter per row. Asynchronous on `stream`. */
+ZG_API int zg_png_filter(const zg_image *src, int filter, uint8_t *filtered, zg_stream stream);
+/* png.encode(T) (png.zig:1400-1425): Image(u8) -> greyscale, Rgb -> RGB, Rgba -> RGBA, anything else (src_space as in
+ * zg_convert) is converted to Rgb first. *out is malloc'd host memory holding the file, release it with zg_png_free.
+ * options may be NULL (EncodeOptions.default). The device filters, the host deflates: the call synchronises `stream`. */
+ZG_API int zg_png_encode(const zg_image *src, int src_space, const zg_png_encode_options *options, uint8_t **out, size_t *out_len, zg_stream stream);
+ZG_API int zg_png_encode_host(const zg_image *src, int src_space, const zg_png_encode_options *options, uint8_t **out, size_t *out_len);
+ZG_API void zg_png_free(void *p);
 
 #ifdef __cplusplus
 }

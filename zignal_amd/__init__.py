@@ -5,9 +5,11 @@ include/zignal_hip.h); this package is the thin host-side mirror of the referenc
 surface on top of it. There is no CPU fallback: importing works without a GPU, calling does not.
 """
 from ._lib import (BORDER_MIRROR, BORDER_REPLICATE, BORDER_WRAP, BORDER_ZERO, CS_GRAY, CS_HSL, CS_HSV, CS_LAB, CS_LCH, CS_LMS, CS_OKLAB, CS_OKLCH, CS_RGB,
-                   CS_RGBA, CS_XYB, CS_XYZ, CS_YCBCR, DimensionMismatch, InvalidArgument, ZignalError, lib)
+                   CS_RGBA, CS_XYB, CS_XYZ, CS_YCBCR, CodecError, DimensionMismatch, InvalidArgument, ZignalError, lib)
 from .image import (AffineTransform, Blending, BorderMode, Image, ImagePyramid, Interpolation, ProjectiveTransform,
                     SimilarityTransform, gaussian_kernel)
 
 __all__ = ["Image", "ImagePyramid", "Interpolation", "BorderMode", "Blending", "ProjectiveTransform", "AffineTransform",
-           "SimilarityTransform", "gaussian_kernel", "DimensionMismatch", "InvalidArgument", "ZignalError", "lib"]
+           "SimilarityTransform", "gaussian_kernel", "DimensionMismatch", "InvalidArgument", "CodecError", "ZignalError", "lib", "png"]
+
+from . import png  # noqa: E402,F401

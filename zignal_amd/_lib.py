@@ -18,7 +18,7 @@ INTERP_NEAREST, INTERP_BILINEAR, INTERP_BICUBIC, INTERP_CATMULL_ROM, INTERP_MITC
 TRANSFORM_SIMILARITY, TRANSFORM_AFFINE, TRANSFORM_PROJECTIVE = range(3)
 CS_GRAY, CS_RGB, CS_RGBA, CS_OKLAB, CS_XYZ, CS_YCBCR, CS_HSL, CS_HSV, CS_LAB, CS_LCH, CS_LMS, CS_OKLCH, CS_XYB = range(13)
 
-OK, ERR_DIMENSION_MISMATCH, ERR_INVALID_ARGUMENT, ERR_OUT_OF_MEMORY, ERR_HIP, ERR_UNSUPPORTED = range(6)
+OK, ERR_DIMENSION_MISMATCH, ERR_INVALID_ARGUMENT, ERR_OUT_OF_MEMORY, ERR_HIP, ERR_UNSUPPORTED, ERR_CODEC = range(7)
 
 
 class ZgImage(C.Structure):
@@ -28,6 +28,26 @@ class ZgImage(C.Structure):
 
 class ZgMethod(C.Structure):
     _fields_ = [("kind", C.c_int32), ("b", C.c_float), ("c", C.c_float), ("lanczos_lut", C.c_void_p)]
+
+
+class ZgPngHeader(C.Structure):
+    """zg_png_header == png.Header (png.zig:135-149)."""
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("bit_depth", C.c_uint8), ("color_type", C.c_uint8),
+                ("compression_method", C.c_uint8), ("filter_method", C.c_uint8), ("interlace_method", C.c_uint8),
+                ("has_gamma", C.c_uint8), ("has_srgb", C.c_uint8), ("srgb_intent", C.c_uint8), ("gamma", C.c_float)]
+
+
+class ZgPngLimits(C.Structure):
+    """zg_png_limits == png.DecodeLimits (png.zig:23-41)."""
+    _fields_ = [("max_png_bytes", C.c_size_t), ("max_chunk_bytes", C.c_size_t), ("max_idat_bytes", C.c_size_t),
+                ("max_chunks", C.c_size_t), ("max_width", C.c_uint32), ("max_height", C.c_uint32),
+                ("max_pixels", C.c_uint64), ("max_decompressed_bytes", C.c_size_t)]
+
+
+class ZgPngEncodeOptions(C.Structure):
+    """zg_png_encode_options == png.EncodeOptions (png.zig:1296-1316)."""
+    _fields_ = [("filter", C.c_int), ("compression_level", C.c_int), ("has_gamma", C.c_int), ("gamma", C.c_float),
+                ("srgb_intent", C.c_int)]
 
 
 class ZignalError(RuntimeError):
@@ -42,6 +62,14 @@ class DimensionMismatch(ZignalError):
 
 class InvalidArgument(ZignalError, ValueError):
     """error.InvalidSigma / InvalidScaleFactor / InvalidDimensions."""
+
+
+class CodecError(ZignalError):
+    """An error of a codec's error set (src/codecs/png.zig); `.name` is the Zig error name, e.g. "InvalidCrc"."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(status, message)
+        self.name = message.split(" ", 1)[0]
 
 
 _lib = None
@@ -133,8 +161,19 @@ _SIGNATURES = {
     "zg_pyramid_level": [C.c_uint32, C.c_uint32, C.c_float, C.c_float, _U32P, _U32P, _F32P],
     "zg_batch_blur_resize": [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_float,
                              C.c_void_p, C.c_uint32, C.c_uint32, _METHOD, C.c_void_p],
+    "zg_png_default_limits": [C.POINTER(ZgPngLimits)],
+    "zg_png_default_encode_options": [C.POINTER(ZgPngEncodeOptions)],
+    "zg_png_info": [C.c_void_p, C.c_size_t, C.POINTER(ZgPngLimits), C.POINTER(ZgPngHeader)],
+    "zg_png_probe": [C.c_void_p, C.c_size_t, C.POINTER(ZgPngLimits), C.POINTER(ZgPngHeader), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "zg_png_decode": [C.c_void_p, C.c_size_t, C.POINTER(ZgPngLimits), _IMG, C.c_int, C.POINTER(C.c_int), C.c_void_p],
+    "zg_png_decode_host": [C.c_void_p, C.c_size_t, C.POINTER(ZgPngLimits), _IMG, C.c_int, C.POINTER(C.c_int)],
+    "zg_png_filter": [_IMG, C.c_int, C.c_void_p, C.c_void_p],
+    "zg_png_encode": [_IMG, C.c_int, C.POINTER(ZgPngEncodeOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p],
+    "zg_png_encode_host": [_IMG, C.c_int, C.POINTER(ZgPngEncodeOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
+    "zg_png_free": [C.c_void_p],
 }
-_RESTYPES = {"zg_last_error": C.c_char_p, "zg_shutdown": None, "zg_pixel_size": C.c_size_t, "zg_pyramid_scale": C.c_float}
+_RESTYPES = {"zg_last_error": C.c_char_p, "zg_shutdown": None, "zg_pixel_size": C.c_size_t, "zg_pyramid_scale": C.c_float,
+             "zg_png_default_limits": None, "zg_png_default_encode_options": None, "zg_png_free": None}
 
 # every symbol include/zignal_hip.h declares; tests check the library exports all of them
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -166,4 +205,6 @@ def check(status: int) -> None:
         raise InvalidArgument(status, msg)
     if status == ERR_OUT_OF_MEMORY:
         raise MemoryError(f"zignal_hip: {msg}")
+    if status == ERR_CODEC:
+        raise CodecError(status, msg)
     raise ZignalError(status, msg)

@@ -171,6 +171,30 @@ class Image:
             return self
         return Image(torch.from_numpy(np.ascontiguousarray(self.data)).to(device))
 
+    # ---- file I/O (reference src/image.zig:239-287 -> src/image/format.zig:14-81; PNG only here) ----------------------
+    @staticmethod
+    def load_from_bytes(data: bytes, kind: Optional[str] = None, device: Optional[str] = "cuda") -> "Image":
+        """Image(T).loadFromBytes: the format comes from the signature; `kind` names T ("u8" / "rgb_u8" / "rgba_u8", None
+        = the file's native type). JPEG / BMP / GIF are recognised and rejected (their codecs are not part of this build)."""
+        from . import png
+        data = bytes(data)
+        if data[:8] == bytes([137, 80, 78, 71, 13, 10, 26, 10]):
+            return png.load_from_bytes(data, kind, None, device)
+        raise L.ZignalError(L.ERR_UNSUPPORTED, "UnsupportedImageFormat (only PNG is decoded by this library)")
+
+    @staticmethod
+    def load(path: str, kind: Optional[str] = None, device: Optional[str] = "cuda") -> "Image":
+        """Image(T).load: detection from the file's first bytes, as ImageFormat.detectFromPath."""
+        with open(path, "rb") as f:
+            return Image.load_from_bytes(f.read(), kind, device)
+
+    def save(self, path: str) -> None:
+        """Image(T).save: the format comes from the extension (case-insensitive); anything but .png is UnsupportedImageFormat here."""
+        from . import png
+        if not path.lower().endswith(".png"):
+            raise L.ZignalError(L.ERR_UNSUPPORTED, "UnsupportedImageFormat (only .png is encoded by this library)")
+        png.save(self, path)
+
     # ---- container ops (reference src/image.zig:304-392) -------------------------------------
     def has_same_shape(self, other: "Image") -> bool:
         return self.rows == other.rows and self.cols == other.cols
