@@ -472,6 +472,30 @@ def extras(zg, torch, np):
         ms = _time_kernel(torch, lambda i: zg.ImagePyramid.build_default(src), n=6, warm=2, capture=False)
         return rate(ms, ROWS * COLS, 2 * ROWS * COLS)
 
+    def png_frame():
+        # photo-like content (smooth ramps + a little noise): uniform noise would measure nothing but deflate's worst case
+        yy, xx = torch.meshgrid(torch.arange(ROWS, device="cuda"), torch.arange(COLS, device="cuda"), indexing="ij")
+        smooth = torch.stack([(xx // 8) % 256, (yy // 8) % 256, ((xx + yy) // 16) % 256, torch.full_like(xx, 255)], -1)
+        return (smooth + torch.randint(0, 4, (ROWS, COLS, 4), device="cuda")).clamp(0, 255).to(torch.uint8)
+
+    def png_filter(mode):
+        # the device half of png.encode: filter costs + adaptive selection + row filtering (mode -1) or one fixed filter
+        src = zg.Image(png_frame())
+        ms = _time_kernel(torch, lambda i: zg.png.filter_scanlines(src, mode), n=10, warm=2, capture=False)
+        return rate(ms, ROWS * COLS, 8 * ROWS * COLS)  # 4 B read + 4 B (+ 1 per row) written per pixel
+
+    def png_files():
+        # whole files through the C ABI, wall clock: the host half (zlib inflate / deflate, de-filtering) dominates by design
+        import time as _t
+        src = zg.Image(png_frame())
+        t0 = _t.perf_counter(); data = zg.png.encode(src); t_enc = _t.perf_counter() - t0
+        best = 1e9
+        for _ in range(3):
+            t0 = _t.perf_counter(); zg.png.load_from_bytes(data); torch.cuda.synchronize(); best = min(best, _t.perf_counter() - t0)
+        return {"decode_ms": round(best * 1e3, 1), "decode_Mpixels/s": round(ROWS * COLS / best / 1e6, 1), "encode_ms": round(t_enc * 1e3, 1),
+                "encode_Mpixels/s": round(ROWS * COLS / t_enc / 1e6, 1), "file_MiB": round(len(data) / 2**20, 1),
+                "note": "host-bound: inflate + de-filter (decode), deflate level 5 (encode) on one core; device share < 1 ms"}
+
     leg("next_sobel_rgba_u8_4096", sobel)
     leg("next_pyramid_build_default_u8_4096", pyramid_build)
     leg("next_canny_rgba_u8_4096", canny)
@@ -479,6 +503,9 @@ def extras(zg, torch, np):
     leg("next_pyramid_level3_blur_u8_4096", pyramid_blur)
     leg("next_convert_rgba_u8_to_lab_f32_4096", lambda: lab(True))
     leg("next_convert_lab_f32_to_rgba_u8_4096", lambda: lab(False))
+    leg("io_png_filter_adaptive_rgba_u8_4096", lambda: png_filter(-1))
+    leg("io_png_filter_paeth_rgba_u8_4096", lambda: png_filter(4))
+    leg("io_png_file_rgba_u8_4096", png_files)
     leg("config2a_gaussian_blur_one_f32_plane_4096", blur_planes)
     leg("config2b_gaussian_blur_rgba_u8_4096", blur_u8)
     leg("config3_resize_bilinear_rgba_u8_4096_to_1024", resize_u8)

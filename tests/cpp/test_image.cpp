@@ -71,6 +71,24 @@ int main() {
         try { img.scale(0.0f, Interpolation::bilinear()); } catch (const InvalidArgument &) { threw = true; }
         EXPECT(threw);
     }
+    { // codecs/png.zig:2586-2642 round trip, :2073-2077 signature check
+        auto img = Image<Rgb<uint8_t>>::init(4, 4);
+        for (uint32_t r = 0; r < 4; ++r)
+            for (uint32_t c = 0; c < 4; ++c) img.at(r, c) = {(uint8_t)(r * 60 + c), (uint8_t)(255 - c * 40), (uint8_t)(r * c * 17)};
+        const std::vector<uint8_t> file = img.encodePng();
+        EXPECT(file.size() > 8 && file[0] == 137 && file[1] == 'P');
+        auto back = Image<Rgb<uint8_t>>::loadFromBytes(file.data(), file.size());
+        bool same = back.rows == 4 && back.cols == 4;
+        for (uint32_t r = 0; r < 4 && same; ++r)
+            for (uint32_t c = 0; c < 4; ++c) same = same && back.at(r, c).r == img.at(r, c).r && back.at(r, c).g == img.at(r, c).g && back.at(r, c).b == img.at(r, c).b;
+        EXPECT(same);
+        auto rgba = Image<Rgba<uint8_t>>::loadFromBytes(file.data(), file.size()); // loadFromBytes(T) converts (png.zig:1160-1184)
+        EXPECT(rgba.at(1, 2).a == 255 && rgba.at(1, 2).g == img.at(1, 2).g);
+        const uint8_t junk[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+        std::string name;
+        try { Image<uint8_t>::loadFromBytes(junk, 8); } catch (const CodecError &e) { name = e.name(); }
+        EXPECT(name == "InvalidPngSignature");
+    }
     std::printf(failures ? "%d FAILED\n" : "cpp mirror ok\n", failures);
     return failures ? 1 : 0;
 }

@@ -45,6 +45,25 @@ elif op in ("conv3_u8", "conv3_f32"):
     t = torch.rand((R, R, 4), dtype=torch.float32, device="cuda") if op.endswith("f32") else torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")
     s = zg.Image(t); d = zg.Image(torch.empty_like(t)); k3 = np.full((3, 3), 1 / 9, np.float32)
     f = lambda: s.convolve(k3, 1, out=d)
+elif op in ("png_filter", "png_filter_paeth", "png_decode", "png_encode"):
+    import time
+    yy, xx = torch.meshgrid(torch.arange(R, device="cuda"), torch.arange(R, device="cuda"), indexing="ij")
+    smooth = torch.stack([(xx // 8) % 256, (yy // 8) % 256, ((xx + yy) // 16) % 256, torch.full_like(xx, 255)], -1)
+    t = (smooth + torch.randint(0, 4, (R, R, 4), device="cuda")).clamp(0, 255).to(torch.uint8)  # photo-like: smooth + a little noise
+    s = zg.Image(t)
+    if op.startswith("png_filter"):
+        f = lambda: zg.png.filter_scanlines(s, 4 if op.endswith("paeth") else -1)
+    else:
+        t0 = time.perf_counter(); data = zg.png.encode(s); t1 = time.perf_counter()
+        print(f"encode {1e3 * (t1 - t0):.1f} ms, {len(data) / 2**20:.1f} MiB file from {t.numel() / 2**20:.0f} MiB of pixels")
+        if op == "png_decode":
+            def f():
+                t0 = time.perf_counter(); out = zg.png.load_from_bytes(data); torch.cuda.synchronize(); t1 = time.perf_counter()
+                print(f"decode {1e3 * (t1 - t0):.1f} ms")
+        else:
+            def f():
+                t0 = time.perf_counter(); zg.png.encode(s); t1 = time.perf_counter()
+                print(f"encode {1e3 * (t1 - t0):.1f} ms")
 for _ in range(n):
     f()
 torch.cuda.synchronize()

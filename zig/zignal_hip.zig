@@ -49,6 +49,19 @@ pub const c = struct {
     pub extern fn zg_sobel_host(src: *const ZgImage, dst: *const ZgImage) c_int;
     pub extern fn zg_motion_blur_linear_host(src: *const ZgImage, dst: *const ZgImage, angle: f32, cos_a: f32, sin_a: f32, distance: u32) c_int;
     pub extern fn zg_motion_blur_radial_host(src: *const ZgImage, dst: *const ZgImage, center_x: f32, center_y: f32, strength: f32, spin: c_int) c_int;
+    pub const ZgPngHeader = extern struct { width: u32, height: u32, bit_depth: u8, color_type: u8, compression_method: u8, filter_method: u8, interlace_method: u8, has_gamma: u8, has_srgb: u8, srgb_intent: u8, gamma: f32 };
+    pub const ZgPngLimits = extern struct { max_png_bytes: usize, max_chunk_bytes: usize, max_idat_bytes: usize, max_chunks: usize, max_width: u32, max_height: u32, max_pixels: u64, max_decompressed_bytes: usize };
+    pub const ZgPngEncodeOptions = extern struct { filter: c_int, compression_level: c_int, has_gamma: c_int, gamma: f32, srgb_intent: c_int };
+    pub extern fn zg_png_default_limits(limits: *ZgPngLimits) void;
+    pub extern fn zg_png_default_encode_options(options: *ZgPngEncodeOptions) void;
+    pub extern fn zg_png_info(png: [*]const u8, len: usize, limits: ?*const ZgPngLimits, out: *ZgPngHeader) c_int;
+    pub extern fn zg_png_probe(png: [*]const u8, len: usize, limits: ?*const ZgPngLimits, header_out: ?*ZgPngHeader, native_pixel_out: ?*c_int, truncated_out: ?*c_int) c_int;
+    pub extern fn zg_png_decode(png: [*]const u8, len: usize, limits: ?*const ZgPngLimits, dst: *const ZgImage, dst_space: c_int, truncated_out: ?*c_int, stream: ?*anyopaque) c_int;
+    pub extern fn zg_png_decode_host(png: [*]const u8, len: usize, limits: ?*const ZgPngLimits, dst: *const ZgImage, dst_space: c_int, truncated_out: ?*c_int) c_int;
+    pub extern fn zg_png_filter(src: *const ZgImage, filter: c_int, filtered: [*]u8, stream: ?*anyopaque) c_int;
+    pub extern fn zg_png_encode(src: *const ZgImage, src_space: c_int, options: ?*const ZgPngEncodeOptions, out: *?[*]u8, out_len: *usize, stream: ?*anyopaque) c_int;
+    pub extern fn zg_png_encode_host(src: *const ZgImage, src_space: c_int, options: ?*const ZgPngEncodeOptions, out: *?[*]u8, out_len: *usize) c_int;
+    pub extern fn zg_png_free(p: ?*anyopaque) void;
     pub extern fn zg_shen_castan_host(src: *const ZgImage, dst: *const ZgImage, smooth: f32, window_size: u32, high_ratio: f32, low_rel: f32, hysteresis: c_int, use_nms: c_int) c_int;
     pub extern fn zg_canny_host(src: *const ZgImage, dst: *const ZgImage, sigma: f32, low_threshold: f32, high_threshold: f32) c_int;
     pub extern fn zg_convert_host(src: *const ZgImage, src_space: c_int, dst: *const ZgImage, dst_space: c_int, srgb_lut: ?[*]const f32) c_int;
@@ -364,3 +377,67 @@ pub fn Image(comptime T: type) type {
         }
     };
 }
+
+/// PNG through the library (reference src/codecs/png.zig): the chunk layer, inflate / deflate and de-filtering run on the
+/// host inside libzignal_hip.so, unpacking / conversion / row filtering on the MI355X. The library reports the reference's
+/// error names as text (zg_last_error() starts with the name); `codecError` turns the common ones back into the error set
+/// a caller of png.zig already matches on, and keeps the rest as error.PngError.
+pub const png = struct {
+    pub const DecodeLimits = c.ZgPngLimits;
+    pub const Header = c.ZgPngHeader;
+
+    pub fn defaultLimits() DecodeLimits {
+        var l: DecodeLimits = undefined;
+        c.zg_png_default_limits(&l);
+        return l;
+    }
+
+    fn codecError() anyerror {
+        const msg = std.mem.span(c.zg_last_error());
+        const name = msg[0 .. std.mem.indexOfScalar(u8, msg, ' ') orelse msg.len];
+        const known = .{
+            .{ "InvalidPngSignature", error.InvalidPngSignature }, .{ "InvalidCrc", error.InvalidCrc },
+            .{ "ImageTooLarge", error.ImageTooLarge },             .{ "PngDataTooLarge", error.PngDataTooLarge },
+            .{ "TooManyChunks", error.TooManyChunks },             .{ "MissingHeader", error.MissingHeader },
+            .{ "MissingImageData", error.MissingImageData },       .{ "MissingPalette", error.MissingPalette },
+            .{ "InvalidChunkLength", error.InvalidChunkLength },   .{ "ReadFailed", error.ReadFailed },
+            .{ "InvalidFilterType", error.InvalidFilterType },     .{ "InvalidPaletteIndex", error.InvalidPaletteIndex },
+            .{ "NonConsecutiveIdatChunks", error.NonConsecutiveIdatChunks },
+        };
+        inline for (known) |entry| if (std.mem.eql(u8, name, entry[0])) return entry[1];
+        return error.PngError;
+    }
+
+    fn checkPng(status: c_int) !void {
+        if (status == 6) return codecError();
+        return check(status);
+    }
+
+    /// reference src/codecs/png.zig:308-410
+    pub fn getInfo(data: []const u8, limits: DecodeLimits) !Header {
+        var h: Header = undefined;
+        try checkPng(c.zg_png_info(data.ptr, data.len, &limits, &h));
+        return h;
+    }
+
+    /// reference src/codecs/png.zig:1151-1186
+    pub fn loadFromBytes(comptime T: type, allocator: std.mem.Allocator, data: []const u8, limits: DecodeLimits) !Image(T) {
+        var h: Header = undefined;
+        try checkPng(c.zg_png_probe(data.ptr, data.len, &limits, &h, null, null));
+        const out: Image(T) = .{ .base = try .init(allocator, h.height, h.width) };
+        errdefer out.base.deinit(allocator);
+        const space: c_int = switch (pixelOf(T)) { .u8, .f32 => 0, .rgb_u8, .rgb_f32 => 1, .rgba_u8, .rgba_f32 => 2 };
+        try checkPng(c.zg_png_decode_host(data.ptr, data.len, &limits, &Image(T).desc(out.base), space, null));
+        return out;
+    }
+
+    /// reference src/codecs/png.zig:1400-1425; the bytes are copied into `allocator`'s memory
+    pub fn encode(comptime T: type, allocator: std.mem.Allocator, image: Image(T), options: ?*const c.ZgPngEncodeOptions) ![]u8 {
+        var mem: ?[*]u8 = null;
+        var len: usize = 0;
+        const space: c_int = switch (pixelOf(T)) { .u8, .f32 => 0, .rgb_u8, .rgb_f32 => 1, .rgba_u8, .rgba_f32 => 2 };
+        try checkPng(c.zg_png_encode_host(&Image(T).desc(image.base), space, options, &mem, &len));
+        defer c.zg_png_free(mem);
+        return allocator.dupe(u8, mem.?[0..len]);
+    }
+};

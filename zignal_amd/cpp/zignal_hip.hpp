@@ -24,6 +24,11 @@ namespace zignal {
 struct Error : std::runtime_error { int status; Error(int s, const std::string &m) : std::runtime_error(m), status(s) {} };
 struct DimensionMismatch : Error { using Error::Error; };
 struct InvalidArgument : Error { using Error::Error; };
+// an error of a codec's error set (src/codecs/png.zig); name() is the Zig error name, e.g. "InvalidCrc"
+struct CodecError : Error {
+    using Error::Error;
+    std::string name() const { const std::string m = what(); return m.substr(0, m.find(' ')); }
+};
 
 inline void check(int status) {
     if (status == ZG_OK) return;
@@ -31,6 +36,7 @@ inline void check(int status) {
     if (status == ZG_ERR_DIMENSION_MISMATCH) throw DimensionMismatch(status, msg);
     if (status == ZG_ERR_INVALID_ARGUMENT) throw InvalidArgument(status, msg);
     if (status == ZG_ERR_OUT_OF_MEMORY) throw std::bad_alloc();
+    if (status == ZG_ERR_CODEC) throw CodecError(status, msg);
     throw Error(status, msg);
 }
 
@@ -208,6 +214,25 @@ template <typename T> class Image {
     template <typename Target> Image<Target> convert() const {                           // image.zig:418
         Image<Target> out = Image<Target>::init(rows, cols);
         convertInto(out);
+        return out;
+    }
+
+    // ---- file I/O (image.zig:239-287; PNG only: src/codecs/png.zig) ----
+    static Image loadFromBytes(const uint8_t *bytes, size_t len, const zg_png_limits *limits = nullptr) {   // png.zig:1151
+        zg_png_header h;
+        check(zg_png_probe(bytes, len, limits, &h, nullptr, nullptr));
+        Image out = init(h.height, h.width);
+        const zg_image d = out.desc();
+        check(zg_png_decode_host(bytes, len, limits, &d, PixelTraits<T>::space, nullptr));
+        return out;
+    }
+    std::vector<uint8_t> encodePng(const zg_png_encode_options *options = nullptr) const {                  // png.zig:1400
+        uint8_t *mem = nullptr;
+        size_t n = 0;
+        const zg_image s = desc();
+        check(zg_png_encode_host(&s, PixelTraits<T>::space, options, &mem, &n));
+        std::vector<uint8_t> out(mem, mem + n);
+        zg_png_free(mem);
         return out;
     }
 

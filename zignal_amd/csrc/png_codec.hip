@@ -409,6 +409,27 @@ template <int NATIVE> __global__ __launch_bounds__(256) void k_png_unpack(const 
     else *(uint32_t *)out = (uint32_t)r | (uint32_t)g << 8 | (uint32_t)b << 16 | (uint32_t)alpha << 24;
 }
 
+// 8-bit grey / rgb / rgba without tRNS, not interlaced: the de-filtered rows ARE the pixels; only the filter byte in front of
+// every row has to go. A byte-stream copy, 16 bytes per lane; the source rows start at odd addresses (row * (n + 1) + 1), so
+// they are read with unaligned dword loads, the destination is written with the widest aligned store its layout allows.
+struct __attribute__((packed)) U32U { uint32_t v; };
+__device__ inline uint32_t load_u32_unaligned(const uint8_t *p) { return ((const U32U *)p)->v; }
+__device__ inline void store_u32_unaligned(uint8_t *p, uint32_t v) { ((U32U *)p)->v = v; }
+template <int ALIGN> __global__ __launch_bounds__(256) void k_png_copy_rows(const uint8_t *scan, size_t row_bytes, uint8_t *dst, size_t dst_pitch) {
+    const size_t off = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (off >= row_bytes) return;
+    const uint8_t *src = scan + (size_t)blockIdx.y * (row_bytes + 1) + 1 + off;
+    uint8_t *out = dst + (size_t)blockIdx.y * dst_pitch + off;
+    if (off + 16 <= row_bytes) {
+        const uint32_t a = load_u32_unaligned(src), b = load_u32_unaligned(src + 4), c = load_u32_unaligned(src + 8), d = load_u32_unaligned(src + 12);
+        if constexpr (ALIGN == 16) *(uint4 *)out = make_uint4(a, b, c, d);
+        else if constexpr (ALIGN == 4) { ((uint32_t *)out)[0] = a; ((uint32_t *)out)[1] = b; ((uint32_t *)out)[2] = c; ((uint32_t *)out)[3] = d; }
+        else { store_u32_unaligned(out, a); store_u32_unaligned(out + 4, b); store_u32_unaligned(out + 8, c); store_u32_unaligned(out + 12, d); }
+    } else {
+        for (size_t i = 0; off + i < row_bytes; ++i) out[i] = src[i];
+    }
+}
+
 int natural_space(int pixel) { return pixel_channels(pixel) == 1 ? ZG_CS_GRAY : (pixel_channels(pixel) == 3 ? ZG_CS_RGB : ZG_CS_RGBA); }
 
 int decode_impl(const uint8_t *png, size_t len, const zg_png_limits *limits, const zg_image *dst, int dst_space, int *truncated_out, hipStream_t s) {
@@ -452,7 +473,15 @@ int decode_impl(const uint8_t *png, size_t len, const zg_png_limits *limits, con
     zg_image native_img{dev + (L.total + 63) / 64 * 64, f.header.width, f.header.height, f.header.width, native};
     const zg_image *target = direct ? dst : &native_img;
     const dim3 grid(ceil_div(f.header.width, 256), f.header.height);
-    switch (native) {
+    const bool plain_rows = !a.interlaced && a.bit_depth == 8 && a.trns_len < 0 && (a.color_type == 0 || a.color_type == 2 || a.color_type == 6);
+    if (plain_rows) {
+        const size_t row_bytes = L.pass[0].row_bytes, pitch = target->stride * pixel_size(native);
+        const dim3 cgrid(ceil_div((unsigned)((row_bytes + 15) / 16), 256), f.header.height);
+        const uintptr_t base = (uintptr_t)target->data;
+        if (base % 16 == 0 && pitch % 16 == 0) hipLaunchKernelGGL((k_png_copy_rows<16>), cgrid, dim3(256), 0, s, (const uint8_t *)dev, row_bytes, (uint8_t *)target->data, pitch);
+        else if (base % 4 == 0 && pitch % 4 == 0) hipLaunchKernelGGL((k_png_copy_rows<4>), cgrid, dim3(256), 0, s, (const uint8_t *)dev, row_bytes, (uint8_t *)target->data, pitch);
+        else hipLaunchKernelGGL((k_png_copy_rows<1>), cgrid, dim3(256), 0, s, (const uint8_t *)dev, row_bytes, (uint8_t *)target->data, pitch);
+    } else switch (native) {
     case ZG_PIXEL_U8: hipLaunchKernelGGL((k_png_unpack<ZG_PIXEL_U8>), grid, dim3(256), 0, s, (const uint8_t *)dev, a, dimg(target)); break;
     case ZG_PIXEL_RGB_U8: hipLaunchKernelGGL((k_png_unpack<ZG_PIXEL_RGB_U8>), grid, dim3(256), 0, s, (const uint8_t *)dev, a, dimg(target)); break;
     default: hipLaunchKernelGGL((k_png_unpack<ZG_PIXEL_RGBA_U8>), grid, dim3(256), 0, s, (const uint8_t *)dev, a, dimg(target)); break;
@@ -479,17 +508,53 @@ __device__ inline int d_predict(int filter, int left, int above, int ul, bool fi
 }
 __device__ inline uint32_t abs_i8(int residual) { const int v = (int8_t)(uint8_t)residual; return (uint32_t)(v < 0 ? -v : v); } // calculateFilterCost :1621-1631
 
-// One workgroup per row: the five filter costs (sum of |signed residual|) in one pass over the row and the one above.
-// A first row has no up / average / Paeth candidates (selectBestFilter skips them, :1645-1647): their cost is "infinite".
-template <int BPP> __global__ __launch_bounds__(256) void k_png_row_costs(DImg src, uint32_t *costs) {
+// Four consecutive bytes of the row byte stream per lane (left / upper-left come from BPP bytes earlier, read as unaligned
+// dwords; the first dword of a row, which has no complete left neighbour, and a ragged tail go byte by byte).
+template <int BPP> struct RowQuad {
+    uint32_t cur, left, above, ul;
+    int count;        // valid bytes (4, fewer in the tail)
+    bool first_row;
+    __device__ RowQuad(const uint8_t *cur_row, const uint8_t *up_row, int i, int n) {
+        first_row = up_row == nullptr;
+        count = n - i < 4 ? n - i : 4;
+        if (count == 4 && i >= BPP) {
+            cur = load_u32_unaligned(cur_row + i);
+            left = load_u32_unaligned(cur_row + i - BPP);
+            above = up_row ? load_u32_unaligned(up_row + i) : 0u;
+            ul = up_row ? load_u32_unaligned(up_row + i - BPP) : 0u;
+        } else {
+            cur = left = above = ul = 0;
+            for (int k = 0; k < count; ++k) {
+                const int j = i + k;
+                cur |= (uint32_t)cur_row[j] << (8 * k);
+                if (j >= BPP) left |= (uint32_t)cur_row[j - BPP] << (8 * k);
+                if (up_row) {
+                    above |= (uint32_t)up_row[j] << (8 * k);
+                    if (j >= BPP) ul |= (uint32_t)up_row[j - BPP] << (8 * k);
+                }
+            }
+        }
+    }
+    __device__ int residual(int filter, int k, int i) const {
+        const int sh = 8 * k;
+        return (int)((cur >> sh) & 0xff) - d_predict(filter, (left >> sh) & 0xff, (above >> sh) & 0xff, (ul >> sh) & 0xff, first_row, i + k < BPP);
+    }
+};
+
+// One workgroup per row: the five filter costs (sum of |signed residual|) in one pass over the row and the one above, then
+// selectBestFilter's pick (:1634-1658): the cheapest, ties to the lowest ordinal; a first row has no up / average / Paeth
+// candidates.
+template <int BPP> __global__ __launch_bounds__(256) void k_png_row_costs(DImg src, uint8_t *best) {
     const int y = blockIdx.x, n = src.cols * BPP;
     const uint8_t *cur = (const uint8_t *)src.data + (size_t)y * src.stride * BPP;
     const uint8_t *up = y ? cur - src.stride * BPP : nullptr;
     uint32_t c[5] = {0, 0, 0, 0, 0};
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int v = cur[i], left = i >= BPP ? cur[i - BPP] : 0, above = up ? up[i] : 0, ul = (up && i >= BPP) ? up[i - BPP] : 0;
+    for (int i = threadIdx.x * 4; i < n; i += 1024) {
+        const RowQuad<BPP> q(cur, up, i, n);
+        for (int k = 0; k < q.count; ++k) {
 #pragma unroll
-        for (int f = 0; f < 5; ++f) c[f] += abs_i8(v - d_predict(f, left, above, ul, up == nullptr, i < BPP));
+            for (int f = 0; f < 5; ++f) c[f] += abs_i8(q.residual(f, k, i));
+        }
     }
     __shared__ uint32_t part[5][4];
 #pragma unroll
@@ -499,55 +564,74 @@ template <int BPP> __global__ __launch_bounds__(256) void k_png_row_costs(DImg s
         if ((threadIdx.x & 63) == 0) part[f][threadIdx.x >> 6] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 5) {
-        const int f = threadIdx.x;
-        const uint32_t total = part[f][0] + part[f][1] + part[f][2] + part[f][3];
-        costs[(size_t)y * 5 + f] = (y == 0 && f >= 2) ? 0xffffffffu : total;
+    if (threadIdx.x == 0) {
+        uint32_t lowest = 0xffffffffu;
+        int pick = 0;
+        for (int f = 0; f < (y == 0 ? 2 : 5); ++f) {
+            const uint32_t total = part[f][0] + part[f][1] + part[f][2] + part[f][3];
+            if (total < lowest) { lowest = total; pick = f; } // strict: ties keep the lower ordinal (:1650-1654)
+        }
+        best[y] = (uint8_t)pick;
     }
 }
 // filterScanlinesAdaptive's row loop (:1675-1716): rows are analysed every `sample_rate` rows, while the choice is still
 // changing (streak == 0) and in the first / last three rows; otherwise the last choice is reused. Sequential by nature and
-// tiny (one comparison chain per row): one lane walks it.
-__global__ void k_png_select(const uint32_t *costs, int rows, uint8_t *filters) {
-    if (threadIdx.x | blockIdx.x) return;
-    const int sample_rate = rows > 512 ? 8 : 1;
+// tiny. One wave walks it: each lane fetches four rows' picks (one coalesced load per 256 rows), the chain itself runs on
+// wave-uniform values (readlane in, a lane-select out), i.e. on the scalar unit with no memory access inside it.
+__global__ __launch_bounds__(64) void k_png_select(const uint8_t *best, int rows, uint8_t *filters) {
+    const int lane = threadIdx.x;
+    const int sample_rate = rows > 512 ? 8 : 1, mask = sample_rate - 1;
     int last = 0, streak = 0;
-    for (int y = 0; y < rows; ++y) {
-        const bool analyze = y % sample_rate == 0 || streak == 0 || y < 3 || y >= rows - 3;
-        int pick = last;
-        if (analyze) {
-            uint32_t best = 0xffffffffu;
-            pick = 0;
-            for (int f = 0; f < 5; ++f) {
-                const uint32_t c = costs[(size_t)y * 5 + f];
-                if (c < best) { best = c; pick = f; } // strict: ties keep the lower ordinal (:1650-1654)
+    for (int base = 0; base < rows; base += 256) {
+        const int r0 = base + lane * 4;
+        uint32_t w = 0;
+        if (r0 + 4 <= rows) w = load_u32_unaligned(best + r0);
+        else for (int k = 0; r0 + k < rows; ++k) w |= (uint32_t)best[r0 + k] << (8 * k);
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const uint32_t wj = __builtin_amdgcn_readlane(w, j);
+            uint32_t r = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { // rows past the end (last block only) run on zeros; their results are never stored
+                const int y = base + j * 4 + k, pick = (int)((wj >> (8 * k)) & 0xff);
+                const bool analyze = (y & mask) == 0 || streak == 0 || y < 3 || y >= rows - 3;
+                const int grown = streak + 1 < sample_rate ? streak + 1 : sample_rate;
+                if (analyze) {
+                    streak = pick == last ? grown : 0;
+                    last = pick;
+                }
+                r |= (uint32_t)last << (8 * k);
             }
-            if (pick == last) streak = streak + 1 < sample_rate ? streak + 1 : sample_rate;
-            else { streak = 0; last = pick; }
+            mine = lane == j ? r : mine;
         }
-        filters[y] = (uint8_t)pick;
+        if (r0 + 4 <= rows) store_u32_unaligned(filters + r0, mine);
+        else for (int k = 0; r0 + k < rows; ++k) filters[r0 + k] = (uint8_t)(mine >> (8 * k));
     }
 }
 // filterRow (:1535-1618) for every byte of every row; `filters` == nullptr applies `fixed` to all rows.
 template <int BPP> __global__ __launch_bounds__(256) void k_png_filter_rows(DImg src, const uint8_t *filters, int fixed, uint8_t *out) {
-    const int i = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, n = src.cols * BPP;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, n = src.cols * BPP;
     if (i >= n) return;
     const uint8_t *cur = (const uint8_t *)src.data + (size_t)y * src.stride * BPP;
     const uint8_t *up = y ? cur - src.stride * BPP : nullptr;
     const int f = filters ? filters[y] : fixed;
-    const int left = i >= BPP ? cur[i - BPP] : 0, above = up ? up[i] : 0, ul = (up && i >= BPP) ? up[i - BPP] : 0;
     uint8_t *row = out + (size_t)y * (n + 1);
     if (i == 0) row[0] = (uint8_t)f;
-    row[1 + i] = (uint8_t)(cur[i] - d_predict(f, left, above, ul, up == nullptr, i < BPP));
+    const RowQuad<BPP> q(cur, up, i, n);
+    uint32_t packed = 0;
+    for (int k = 0; k < q.count; ++k) packed |= (uint32_t)(uint8_t)q.residual(f, k, i) << (8 * k);
+    if (q.count == 4) store_u32_unaligned(row + 1 + i, packed);
+    else for (int k = 0; k < q.count; ++k) row[1 + i + k] = (uint8_t)(packed >> (8 * k));
 }
 
-template <int BPP> int filter_launch(const zg_image *src, int filter, uint8_t *filtered, uint32_t *costs, uint8_t *choice, hipStream_t s) {
+template <int BPP> int filter_launch(const zg_image *src, int filter, uint8_t *filtered, uint8_t *best, uint8_t *choice, hipStream_t s) {
     const unsigned n = src->cols * BPP;
     if (filter == ZG_PNG_FILTER_ADAPTIVE) {
-        hipLaunchKernelGGL((k_png_row_costs<BPP>), dim3(src->rows), dim3(256), 0, s, dimg(src), costs);
-        hipLaunchKernelGGL(k_png_select, dim3(1), dim3(64), 0, s, (const uint32_t *)costs, (int)src->rows, choice);
+        hipLaunchKernelGGL((k_png_row_costs<BPP>), dim3(src->rows), dim3(256), 0, s, dimg(src), best);
+        hipLaunchKernelGGL(k_png_select, dim3(1), dim3(64), 0, s, (const uint8_t *)best, (int)src->rows, choice);
     }
-    hipLaunchKernelGGL((k_png_filter_rows<BPP>), dim3(ceil_div(n, 256), src->rows), dim3(256), 0, s, dimg(src),
+    hipLaunchKernelGGL((k_png_filter_rows<BPP>), dim3(ceil_div(ceil_div(n, 4), 256), src->rows), dim3(256), 0, s, dimg(src),
                        filter == ZG_PNG_FILTER_ADAPTIVE ? (const uint8_t *)choice : nullptr, filter, filtered);
     return hipGetLastError() == hipSuccess ? ZG_OK : ZG_ERR_HIP;
 }
@@ -559,15 +643,13 @@ int filter_impl(const zg_image *src, int filter, uint8_t *filtered, hipStream_t 
     ZG_REQUIRE(filter >= ZG_PNG_FILTER_ADAPTIVE && filter <= 4, ZG_ERR_INVALID_ARGUMENT, "png filter: unknown filter %d", filter);
     ZG_REQUIRE(filtered != nullptr, ZG_ERR_INVALID_ARGUMENT, "png filter: null output");
     if (src->rows == 0 || src->cols == 0) return ZG_OK;
-    char *work = nullptr;
-    const size_t cost_bytes = (size_t)src->rows * 5 * sizeof(uint32_t);
-    if (filter == ZG_PNG_FILTER_ADAPTIVE && (rc = scratch_alloc((void **)&work, cost_bytes + src->rows, s))) return rc;
-    uint32_t *costs = (uint32_t *)work;
-    uint8_t *choice = (uint8_t *)work + cost_bytes;
+    uint8_t *work = nullptr; // per row: selectBestFilter's pick, then the filter the state machine settles on
+    if (filter == ZG_PNG_FILTER_ADAPTIVE && (rc = scratch_alloc((void **)&work, (size_t)src->rows * 2, s))) return rc;
+    uint8_t *best = work, *choice = work + src->rows;
     switch (src->pixel) {
-    case ZG_PIXEL_U8: rc = filter_launch<1>(src, filter, filtered, costs, choice, s); break;
-    case ZG_PIXEL_RGB_U8: rc = filter_launch<3>(src, filter, filtered, costs, choice, s); break;
-    default: rc = filter_launch<4>(src, filter, filtered, costs, choice, s); break;
+    case ZG_PIXEL_U8: rc = filter_launch<1>(src, filter, filtered, best, choice, s); break;
+    case ZG_PIXEL_RGB_U8: rc = filter_launch<3>(src, filter, filtered, best, choice, s); break;
+    default: rc = filter_launch<4>(src, filter, filtered, best, choice, s); break;
     }
     if (work) scratch_free(work, s);
     return rc;
