@@ -594,3 +594,89 @@ def png_encode_stored(img: np.ndarray, mode: int = PNG_ADAPTIVE) -> bytes:
     free.argtypes = [C.c_void_p]
     free(out)
     return data
+
+
+# ---- JPEG (oracle/jpeg.c; src/codecs/jpeg.zig) ----------------------------------------------------
+
+class JpegError(Exception):
+    """One of the reference's JPEG errors; `.name` is the Zig error name."""
+
+    def __init__(self, name: str):
+        super().__init__(name)
+        self.name = name
+
+
+class ZoJpegHeader(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("precision", C.c_uint8), ("num_components", C.c_uint8),
+                ("progressive", C.c_uint8), ("subsampling", C.c_int8)]
+
+
+class ZoJpegLimits(C.Structure):
+    _fields_ = [("max_jpeg_bytes", C.c_size_t), ("max_marker_bytes", C.c_size_t), ("max_width", C.c_uint32), ("max_height", C.c_uint32),
+                ("max_pixels", C.c_uint64), ("max_blocks", C.c_size_t), ("max_scans", C.c_size_t)]
+
+
+def jpeg_limits(**overrides) -> ZoJpegLimits:
+    lim = ZoJpegLimits()
+    lib().zo_jpeg_default_limits(C.byref(lim))
+    for k, v in overrides.items():
+        setattr(lim, k, v)
+    return lim
+
+
+def _jpeg_check(rc: int):
+    if rc != 0:
+        fn = lib().zo_jpeg_error_name
+        fn.restype = C.c_char_p
+        raise JpegError(fn(rc).decode())
+
+
+def jpeg_info(data: bytes, limits: ZoJpegLimits | None = None) -> ZoJpegHeader:
+    h = ZoJpegHeader()
+    fn = lib().zo_jpeg_info
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    _jpeg_check(fn(_png_buf(data), len(data), C.byref(limits) if limits else None, C.byref(h)))
+    return h
+
+
+def jpeg_decode_state(data: bytes, limits: ZoJpegLimits | None = None):
+    """jpeg.decode: (header, scan_limit_reached) without rendering."""
+    h, lim_hit, native = ZoJpegHeader(), C.c_int(0), C.c_int(0)
+    fn = lib().zo_jpeg_decode_native
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p] + [C.c_void_p] * 4
+    _jpeg_check(fn(_png_buf(data), len(data), C.byref(limits) if limits else None, C.byref(h), C.byref(native), None, C.byref(lim_hit)))
+    return h, bool(lim_hit.value)
+
+
+def jpeg_decode_native(data: bytes, limits: ZoJpegLimits | None = None):
+    """jpeg.decode + jpeg.toNativeImage: (pixels, header, scan_limit_reached); pixels are (h, w) u8 or (h, w, 3) u8."""
+    h, lim_hit, native, px = ZoJpegHeader(), C.c_int(0), C.c_int(0), C.c_void_p()
+    fn = lib().zo_jpeg_decode_native
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p] + [C.c_void_p] * 4
+    _jpeg_check(fn(_png_buf(data), len(data), C.byref(limits) if limits else None, C.byref(h), C.byref(native), C.byref(px), C.byref(lim_hit)))
+    ch = 1 if native.value == U8 else 3
+    arr = np.frombuffer(C.string_at(px.value, h.height * h.width * ch), np.uint8).copy()
+    free = lib().zo_jpeg_free
+    free.argtypes = [C.c_void_p]
+    free(px)
+    return arr.reshape((h.height, h.width) if ch == 1 else (h.height, h.width, 3)), h, bool(lim_hit.value)
+
+
+def jpeg_load(data: bytes, kind: str, limits: ZoJpegLimits | None = None) -> np.ndarray:
+    """jpeg.loadFromBytes(T) (jpeg.zig:2825-2851)."""
+    native, _, _ = jpeg_decode_native(data, limits)
+    spaces = {1: CS_GRAY, 3: CS_RGB, 4: CS_RGBA}
+    ch = {"u8": 1, "rgb_u8": 3, "rgba_u8": 4}[kind]
+    nch = 1 if native.ndim == 2 else 3
+    if nch == ch:
+        return native
+    return convert(native, spaces[nch], spaces[ch], np.uint8, ch)
+
+
+def jpeg_idct8x8(block) -> np.ndarray:
+    b = np.ascontiguousarray(block, np.int32).reshape(64).copy()
+    fn = lib().zo_jpeg_idct8x8
+    fn.argtypes = [C.c_void_p]
+    fn.restype = None
+    fn(b.ctypes.data)
+    return b.reshape(8, 8)

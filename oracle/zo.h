@@ -143,4 +143,25 @@ ZO_API void zo_png_free(void *p);
 ZO_API int zo_png_filter(const uint8_t *raw, uint32_t rows, size_t row_bytes, int bpp, int mode, uint8_t *filtered);
 ZO_API int zo_png_encode_stored(const zo_image *img, int mode, uint8_t **out, size_t *out_len);
 
+/* jpeg.c — the decoder of src/codecs/jpeg.zig (baseline + progressive). Status codes follow zo_jpeg_error_name(); 0 = ok. */
+typedef struct zo_jpeg_header { /* jpeg.zig:61-74 */
+    uint32_t width, height;
+    uint8_t precision, num_components, progressive;
+    int8_t subsampling; /* 0 = 4:4:4, 1 = 4:2:2, 2 = 4:2:0, -1 = null (getInfo only) */
+} zo_jpeg_header;
+typedef struct zo_jpeg_limits { /* jpeg.zig:19-33; 0 disables a limit */
+    size_t max_jpeg_bytes, max_marker_bytes;
+    uint32_t max_width, max_height;
+    uint64_t max_pixels;
+    size_t max_blocks, max_scans;
+} zo_jpeg_limits;
+ZO_API const char *zo_jpeg_error_name(int code);
+ZO_API void zo_jpeg_default_limits(zo_jpeg_limits *l);
+ZO_API int zo_jpeg_info(const uint8_t *data, size_t len, const zo_jpeg_limits *limits, zo_jpeg_header *out);
+ZO_API void zo_jpeg_idct8x8(int32_t block[64]);
+/* decode (+ toNativeImage when pixels_out != NULL): *pixels_out is malloc'd rows * cols of ZO_U8 or ZO_RGB_U8; free with zo_jpeg_free */
+ZO_API int zo_jpeg_decode_native(const uint8_t *data, size_t len, const zo_jpeg_limits *limits, zo_jpeg_header *header_out, int *native_out,
+                                 uint8_t **pixels_out, int *scan_limit_reached_out);
+ZO_API void zo_jpeg_free(void *p);
+
 #endif
