@@ -405,6 +405,42 @@ ZG_API int zg_png_encode(const zg_image *src, int src_space, const zg_png_encode
 ZG_API int zg_png_encode_host(const zg_image *src, int src_space, const zg_png_encode_options *options, uint8_t **out, size_t *out_len);
 ZG_API void zg_png_free(void *p);
 
+/* ---- the host I/O edge: JPEG decode (src/codecs/jpeg.zig) -------------------- */
+
+/* Baseline (SOF0) and progressive (SOF2) DCT JPEG, one component (grey) or three (YCbCr at 4:4:4, 4:2:2, 4:1:1, 4:2:0).
+ * Host, inside the library: marker parsing with the reference's errors and limits, Huffman decoding of every scan into
+ * coefficient blocks (bit-serial by nature), including the reference's handling of restart markers and of cut streams
+ * (the blocks decoded so far are kept). Device: dequantisation, the integer IDCT, the level shift, chroma upsampling,
+ * YCbCr -> RGB, cropping to width x height and the conversion to the requested Image(T). Errors come back as
+ * ZG_ERR_CODEC with the Zig error name first in zg_last_error() ("InvalidHuffmanCode", "UnsupportedSamplingFactor", ...). */
+typedef struct zg_jpeg_header { /* jpeg.Header (jpeg.zig:61-74) */
+    uint32_t width, height;
+    uint8_t precision, num_components, progressive /* frame_type: 0 baseline, 1 progressive */;
+    int8_t subsampling; /* Subsampling (jpeg.zig:260-283): 0 yuv444, 1 yuv422, 2 yuv420, -1 null */
+} zg_jpeg_header;
+typedef struct zg_jpeg_limits { /* jpeg.DecodeLimits (jpeg.zig:19-33); a zero disables that limit */
+    size_t max_jpeg_bytes, max_marker_bytes;
+    uint32_t max_width, max_height;
+    uint64_t max_pixels;
+    size_t max_blocks, max_scans;
+} zg_jpeg_limits;
+ZG_API void zg_jpeg_default_limits(zg_jpeg_limits *limits);
+/* jpeg.getInfo (jpeg.zig:77-179): the first SOFn's header. The native pixel type of the file is ZG_PIXEL_U8 for one
+ * component and ZG_PIXEL_RGB_U8 otherwise (jpeg.toNativeImage, :2786-2821). limits may be NULL. */
+ZG_API int zg_jpeg_info(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, zg_jpeg_header *out);
+/* jpeg.decode (jpeg.zig:2035-2151) on the host only: every marker is parsed and validated, the scans of a progressive
+ * file are entropy-decoded (a baseline file stops at its SOS, as in the reference), nothing is rendered. Reports the frame
+ * header and JpegState.scan_limit_reached. */
+ZG_API int zg_jpeg_probe(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, zg_jpeg_header *header_out, int *scan_limit_reached_out);
+/* jpeg.loadFromBytes(T) (jpeg.zig:2825-2851): dst is rows x cols == height x width of the frame header
+ * (ZG_ERR_DIMENSION_MISMATCH otherwise); its pixel type and dst_space name T as in zg_convert (the native image goes
+ * through Image.convert when T differs). *scan_limit_reached_out (may be NULL) reports JpegState.scan_limit_reached.
+ * `jpeg` is host memory; dst is device memory (zg_jpeg_decode) or host memory (zg_jpeg_decode_host). */
+ZG_API int zg_jpeg_decode(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, const zg_image *dst, int dst_space,
+                          int *scan_limit_reached_out, zg_stream stream);
+ZG_API int zg_jpeg_decode_host(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, const zg_image *dst, int dst_space,
+                               int *scan_limit_reached_out);
+
 #ifdef __cplusplus
 }
 #endif

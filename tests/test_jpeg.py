@@ -1,0 +1,254 @@
+"""JPEG edge of the path (zg_jpeg_*, zignal_amd/csrc/jpeg_codec.hip) against the oracle (oracle/jpeg.c).
+
+CPU part: marker parsing, limits and the progressive entropy decoder are host code (zg_jpeg_probe / zg_jpeg_info): they must
+agree with the oracle's decode(), error name for error name, on hand-built streams and under random corruption. GPU part:
+decoded pixels, bit for bit, for every layout Pillow and our own coefficient-level writer can produce."""
+import struct
+
+import numpy as np
+import pytest
+
+import zignal_amd as zg
+from tests import jpeg_util as J
+from tests.test_oracle_jpeg import DHT, DQT, EOI, PROGRESSIVE, SCAN1, SIG, SOF2
+
+
+def outcome(fn, *a, **kw):
+    try:
+        return "ok", fn(*a, **kw)
+    except Exception as e:
+        if not hasattr(e, "name"):
+            raise
+        return "err", e.name
+
+
+def head(h):
+    return (h.width, h.height, h.precision, h.num_components, h.progressive)
+
+
+def sof(marker=0xC0, precision=8, h=8, w=8, comps=((1, 0x11, 0),)):
+    body = struct.pack(">BHHB", precision, h, w, len(comps)) + b"".join(bytes(c) for c in comps)
+    return bytes([0xFF, marker]) + struct.pack(">H", 2 + len(body)) + body
+
+
+def structural_cases():
+    sof0 = bytes([0xFF, 0xC0]) + SOF2[2:]
+    cases = [
+        (b"", {}), (b"\x89PNG\r\n", {}), (SIG, {}), (SIG + EOI, {}), (SIG + sof() + EOI, {}), (SIG + b"\x00\x00\x00", {}),
+        (SIG + sof(0xC1), {}), (SIG + sof(0xC3), {}), (SIG + bytes([0xFF, 0xCC, 0, 2]), {}), (SIG + bytes([0xFF, 0xDE, 0, 2]), {}),
+        (SIG + bytes([0xFF, 0xDC, 0, 2]), {}), (SIG + sof(precision=12), {}), (SIG + sof(precision=16), {}), (SIG + sof(precision=9), {}),
+        (SIG + sof(h=0), {}), (SIG + bytes([0xFF, 0xC0, 0, 5, 8, 0, 8]), {}), (SIG + sof(h=9000), {}),
+        (SIG + sof(comps=((1, 0x11, 0),) * 4), {}), (SIG + sof(comps=((1, 0x11, 0),) * 2), {}), (SIG + sof(comps=()), {}),
+        (SIG + sof(comps=((1, 0x22, 0), (2, 0x11, 1), (3, 0x12, 1))), {}), (SIG + sof(comps=((1, 0x12, 0), (2, 0x11, 1), (3, 0x11, 1))), {}),
+        (SIG + sof(comps=((1, 0x51, 0),)), {}), (SIG + sof(comps=((1, 0x41, 0), (2, 0x11, 1), (3, 0x11, 1))) + EOI, {}),
+        (SIG + sof(h=100, w=100), dict(max_pixels=9999)), (SIG + sof(h=100, w=100), dict(max_pixels=0, max_width=99)),
+        (SIG + bytes([0xFF, 0xC4, 0, 2]), {}), (SIG + bytes([0xFF, 0xC4, 0, 5, 0, 1, 2]), {}), (SIG + bytes([0xFF, 0xC4, 0, 19, 0]) + bytes([255] * 16), {}),
+        (SIG + bytes([0xFF, 0xC4, 0, 22, 0, 3]) + bytes(15) + bytes([1, 2, 3]), {}), (SIG + bytes([0xFF, 0xDB, 0, 2]), {}),
+        (SIG + bytes([0xFF, 0xDB, 0, 10, 0]) + bytes(7), {}), (SIG + bytes([0xFF, 0xDD, 0, 5, 0, 0, 0]), {}), (SIG + bytes([0xFF, 0xDD, 0, 4, 0, 7]) + EOI, {}),
+        (SIG + sof() + bytes([0xFF, 0xDA, 0, 8, 1, 1, 0, 1, 63, 0]), {}), (SIG + sof() + bytes([0xFF, 0xDA, 0, 8, 2, 1, 0, 0, 63, 0]), {}),
+        (SIG + sof(0xC2) + bytes([0xFF, 0xDA, 0, 8, 1, 1, 0, 0, 5, 0]), {}), (SIG + sof(0xC2) + bytes([0xFF, 0xDA, 0, 8, 1, 1, 0, 9, 5, 0]), {}),
+        (SIG + sof(0xC2) + bytes([0xFF, 0xDA, 0, 8, 0, 1, 0, 0, 0, 0]), {}), (SIG + sof(0xC2) + bytes([0xFF, 0xDA, 0, 4, 1, 1]), {}),
+        (SIG + bytes([0xFF, 0xDB, 0, 1]), {}), (SIG + bytes([0xFF, 0xDB, 0, 200, 0]), {}), (SIG + bytes([0xFF, 0xDB, 0]), {}),
+        (SIG + bytes([0xFF, 0x02, 0, 1]), {}), (SIG + bytes([0xFF, 0x02, 0, 4, 9, 9]) + sof() + EOI, {}), (SIG + bytes([0xFF, 0xF0]), {}),
+        (SIG + bytes([0xFF, 0xE0, 0, 0]) + EOI, {}), (SIG + bytes([0xFF, 0xD3, 0, 2]) + EOI, {}), (SIG + bytes([0xFF, 0xFE, 0, 9]) + EOI, {}),
+        (SIG, dict(max_jpeg_bytes=1)), (bytes([0xFF, 0xD8, 0xFF, 0xE0, 0x00, 0x04, 0x00, 0x00, 0xFF, 0xD9]), dict(max_jpeg_bytes=0, max_marker_bytes=2)),
+        (SIG + bytes([0xFF, 0xC0, 0x00, 0x0B, 0x08, 0x00, 0x10, 0x00, 0x10, 0x01, 0x01, 0x11, 0x00]) + EOI, dict(max_blocks=1)),
+        (PROGRESSIVE, {}), (PROGRESSIVE, dict(max_scans=2)), (PROGRESSIVE, dict(max_scans=0)), (PROGRESSIVE, dict(max_marker_bytes=100)),
+        (SIG + sof0 + sof0 + EOI, {}), (PROGRESSIVE[:-4], {}), (SIG + DQT + SOF2 + DHT + SCAN1[:-1], {}), (SIG + DQT + SOF2 + DHT + SCAN1 + EOI, {}),
+        (SIG + DQT + SOF2 + SCAN1 + EOI, {}),  # no Huffman table: MissingHuffmanTable from inside the scan
+        (SIG + DQT + DHT + SCAN1 + EOI, {}),   # SOS before SOF
+    ]
+    return cases
+
+
+def probe_both(oracle, data, limits):
+    want = outcome(oracle.jpeg_decode_state, data, oracle.jpeg_limits(**limits) if limits else None)
+    got = outcome(zg.jpeg.decode, data, zg.jpeg.decode_limits(**limits) if limits else None)
+    return want, got
+
+
+def same(want, got):
+    if want[0] != got[0]:
+        return False
+    if want[0] == "err":
+        return want[1] == got[1]
+    return head(want[1][0]) == head(got[1][0]) and want[1][1] == got[1][1]
+
+
+def test_marker_layer_matches_oracle_case_by_case(oracle):
+    seen = set()
+    for i, (data, limits) in enumerate(structural_cases()):
+        want, got = probe_both(oracle, data, limits)
+        assert same(want, got), (i, want, got)
+        seen.add(want[1] if want[0] == "err" else "ok")
+    assert len(seen) >= 25, seen  # the cases really do reach that many different outcomes
+
+
+def test_get_info_matches_oracle(oracle):
+    def info_tuple(h):
+        return head(h) + (h.subsampling,)
+    files = [J.pil_jpeg(J.test_image(20, 30), subsampling=s) for s in (0, 1, 2)] + [J.pil_jpeg(J.test_image(9, 5)[..., 0], progressive=True)]
+    files += [d for d, _ in structural_cases()]
+    for data in files:
+        for lim in ({}, dict(max_jpeg_bytes=40), dict(max_jpeg_bytes=0)):
+            want = outcome(oracle.jpeg_info, data, oracle.jpeg_limits(**lim) if lim else None)
+            got = outcome(zg.jpeg.get_info, data, zg.jpeg.decode_limits(**lim) if lim else None)
+            assert want[0] == got[0] and (want[1] == got[1] if want[0] == "err" else info_tuple(want[1]) == info_tuple(got[1])), (want, got)
+    base = files[2]
+    for cut in range(0, min(len(base), 700), 5):
+        want, got = outcome(oracle.jpeg_info, base[:cut]), outcome(zg.jpeg.get_info, base[:cut])
+        assert want[0] == got[0] and (want[1] == got[1] if want[0] == "err" else info_tuple(want[1]) == info_tuple(got[1])), cut
+
+
+def test_host_decoder_under_random_corruption(oracle):
+    """Byte flips and cuts of valid baseline and progressive files. For a progressive file jpeg.decode runs every scan's
+    entropy decoder, so this compares the product's host Huffman / refinement code with the oracle's on damaged streams too."""
+    rng = np.random.default_rng(31)
+    img = J.test_image(40, 56, seed=1)
+    bases = [J.pil_jpeg(img, quality=85, subsampling=2, progressive=True), J.pil_jpeg(img, quality=70, subsampling=0, progressive=True),
+             J.pil_jpeg(img[..., 0], quality=85, progressive=True), J.pil_jpeg(img, quality=85, subsampling=1),
+             J.pil_jpeg(img, quality=85, subsampling=2, progressive=True, restart_marker_blocks=2)]
+    n_err = n_ok = 0
+    for base in bases:
+        for _ in range(250):
+            data = bytearray(base)
+            if rng.integers(0, 3) == 0:
+                data = data[:int(rng.integers(0, len(data) + 1))]
+            else:
+                for _ in range(int(rng.integers(1, 4))):
+                    data[int(rng.integers(0, len(data)))] = int(rng.integers(0, 256))
+            want, got = probe_both(oracle, bytes(data), {})
+            assert same(want, got), (want, got)
+            n_err += want[0] == "err"
+            n_ok += want[0] == "ok"
+    assert n_err > 100 and n_ok > 100
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------------
+
+def decode_both(oracle, data, kind=None, limits=None):
+    want = outcome(lambda: oracle.jpeg_decode_native(data, oracle.jpeg_limits(**limits) if limits else None))
+    got = outcome(lambda: zg.jpeg.load_from_bytes(data, kind, zg.jpeg.decode_limits(**limits) if limits else None, return_scan_limit_reached=True))
+    return want, got
+
+
+def assert_same_decode(oracle, data, what, limits=None):
+    want, got = decode_both(oracle, data, limits=limits)
+    assert want[0] == got[0], (what, want[0], got[0], want[1] if want[0] == "err" else "", got[1] if got[0] == "err" else "")
+    if want[0] == "err":
+        assert want[1] == got[1], (what, want, got)
+        return want[1]
+    (wimg, _, whit), (gimg, ghit) = want[1], got[1]
+    g = gimg.to_numpy()
+    assert g.shape == wimg.shape and whit == ghit, what
+    if not np.array_equal(g, wimg):
+        bad = np.argwhere(g != wimg)
+        raise AssertionError(f"{what}: {len(bad)} differing samples, first at {bad[0].tolist()}: got {g[tuple(bad[0])]} want {wimg[tuple(bad[0])]}")
+    return "ok"
+
+
+PIL_CASES = [dict(subsampling=0), dict(subsampling=1), dict(subsampling=2), dict(subsampling=0, progressive=True), dict(subsampling=1, progressive=True),
+             dict(subsampling=2, progressive=True), dict(subsampling=2, optimize=True), dict(subsampling=2, quality=35), dict(subsampling=0, quality=100),
+             dict(subsampling=2, restart_marker_blocks=3), dict(subsampling=0, restart_marker_rows=1), dict(subsampling=1, progressive=True, restart_marker_blocks=5),
+             dict(subsampling=2, progressive=True, quality=60)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", PIL_CASES, ids=lambda k: "-".join(f"{a}{b}" for a, b in k.items()))
+def test_decode_parity_pillow_files(oracle, kw):
+    for (h, w) in ((1, 1), (8, 8), (9, 7), (16, 16), (33, 47), (64, 80), (100, 37), (130, 258)):
+        for smooth in (True, False):
+            img = J.test_image(h, w, seed=h + w, smooth=smooth)
+            assert_same_decode(oracle, J.pil_jpeg(img, **{"quality": 90, **kw}), (kw, h, w, smooth))
+        gkw = {k: v for k, v in {"quality": 90, **kw}.items() if k != "subsampling"}
+        assert_same_decode(oracle, J.pil_jpeg(J.test_image(h, w, seed=3)[..., 1], **gkw), ("grey", kw, h, w))
+
+
+@pytest.mark.gpu
+def test_decode_parity_coefficient_level_files(oracle):
+    """4:1:1, odd component ids (which change what the reference takes for a non-interleaved scan), 16-bit DQT, restart
+    intervals of every length, large coefficients (i32 wrap-around in the IDCT is part of the contract)."""
+    rng = np.random.default_rng(14)
+    outcomes = set()
+    for (lh, lv) in ((1, 1), (2, 1), (2, 2), (4, 1)):
+        for (h, w) in ((8, 8), (17, 50), (40, 33), (70, 130)):
+            for ids in ((1, 2, 3), (0, 1, 2), (7, 9, 200)):
+                comps = J.layout(lh, lv, ids)
+                co = J.random_coefficients(rng, comps, w, h)
+                for ri in (0, 1, 2, 5):
+                    data = J.write_baseline(w, h, comps, J.FLAT_Q, co, restart_interval=ri, dqt16=(ri == 5))
+                    outcomes.add(assert_same_decode(oracle, data, (lh, lv, h, w, ids, ri)))
+    big = J.random_coefficients(rng, J.YCC, 48, 32, density=0.6, dc_range=1023, ac_range=1023)
+    wide_q = {0: [255] * 64, 1: [65535] * 64}
+    outcomes.add(assert_same_decode(oracle, J.write_baseline(48, 32, J.YCC, wide_q, big, dqt16=True), "wrap-around"))
+    g = [(1, 1, 1, 0, 0, 0)]
+    for ri in (0, 4):
+        outcomes.add(assert_same_decode(oracle, J.write_baseline(30, 20, g, J.FLAT_Q, J.random_coefficients(rng, g, 30, 20), restart_interval=ri), ("grey", ri)))
+    assert "ok" in outcomes
+
+
+@pytest.mark.gpu
+def test_decode_known_answers_limits_and_cuts(oracle):
+    for data, limits in structural_cases():
+        assert_same_decode(oracle, data, "structural", limits or None)
+    img, hit = zg.jpeg.load_from_bytes(PROGRESSIVE, return_scan_limit_reached=True)  # jpeg.zig:3069-3116
+    assert (img.to_numpy() == 143).all() and not hit
+    img, hit = zg.jpeg.load_from_bytes(PROGRESSIVE, limits=zg.jpeg.decode_limits(max_scans=2), return_scan_limit_reached=True)
+    assert (img.to_numpy() == 142).all() and hit
+    assert (zg.jpeg.load_from_bytes(PROGRESSIVE[:-4]).to_numpy() == 142).all()
+    assert (zg.jpeg.load_from_bytes(SIG + DQT + SOF2 + DHT + SCAN1[:-1]).to_numpy() == 128).all()
+    assert (zg.jpeg.load_from_bytes(SIG + DQT + SOF2 + DHT + SCAN1 + EOI).to_numpy() == 140).all()
+    rng = np.random.default_rng(6)
+    pic = J.test_image(48, 64, seed=5)
+    seen = set()
+    for kw in (dict(subsampling=2), dict(subsampling=2, progressive=True), dict(subsampling=0, progressive=True, quality=60), dict(subsampling=1, optimize=True)):
+        data = J.pil_jpeg(pic, **{"quality": 88, **kw})
+        for cut in [len(data) - 1, len(data) - 2, len(data) - 3] + [int(c) for c in rng.integers(20, len(data), 25)]:
+            seen.add(assert_same_decode(oracle, data[:cut], (kw, cut)))
+        for _ in range(25):  # damage inside the entropy data
+            bad = bytearray(data)
+            at = int(rng.integers(data.index(b"\xFF\xDA") + 14, len(data) - 2))
+            bad[at] = int(rng.integers(0, 256))
+            seen.add(assert_same_decode(oracle, bytes(bad), (kw, "flip", at)))
+    assert "ok" in seen and len(seen) >= 2
+
+
+@pytest.mark.gpu
+def test_decode_targets(oracle):
+    import torch
+    data = J.pil_jpeg(J.test_image(37, 53, seed=2), quality=90, subsampling=2)
+    native = oracle.jpeg_decode_native(data)[0]
+    for kind in ("u8", "rgb_u8", "rgba_u8"):  # loadFromBytes(T): Image.convert of the native image
+        assert np.array_equal(zg.jpeg.load_from_bytes(data, kind).to_numpy(), oracle.jpeg_load(data, kind)), kind
+    gdata = J.pil_jpeg(J.test_image(37, 53, seed=2)[..., 0], quality=90)
+    for kind in ("u8", "rgb_u8", "rgba_u8"):
+        assert np.array_equal(zg.jpeg.load_from_bytes(gdata, kind).to_numpy(), oracle.jpeg_load(gdata, kind)), kind
+    host = zg.jpeg.load_from_bytes(data, device=None)  # zg_jpeg_decode_host
+    assert not host.on_device and np.array_equal(host.data, native)
+    big = zg.Image(torch.zeros((60, 80, 3), dtype=torch.uint8, device="cuda"))  # a strided destination
+    view = big.view((9, 5, 9 + 53, 5 + 37))
+    buf = (zg._lib.C.c_uint8 * len(data)).from_buffer_copy(data)
+    d = view._desc()
+    zg._lib.check(zg.lib().zg_jpeg_decode(buf, len(data), None, zg._lib.C.byref(d), zg.CS_RGB, None, view._stream()))
+    torch.cuda.synchronize()
+    out = big.to_numpy()
+    assert np.array_equal(out[5:42, 9:62], native)
+    out[5:42, 9:62] = 0
+    assert not out.any()
+    f32 = zg.Image(torch.zeros((37, 53, 3), dtype=torch.float32, device="cuda"))
+    d = f32._desc()
+    zg._lib.check(zg.lib().zg_jpeg_decode(buf, len(data), None, zg._lib.C.byref(d), zg.CS_RGB, None, f32._stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(f32.to_numpy().view(np.uint32), oracle.convert(native, oracle.CS_RGB, oracle.CS_RGB, np.float32, 3).view(np.uint32))
+    with pytest.raises(zg.DimensionMismatch):
+        bad = zg.Image(torch.zeros((37, 52, 3), dtype=torch.uint8, device="cuda"))
+        d = bad._desc()
+        zg._lib.check(zg.lib().zg_jpeg_decode(buf, len(data), None, zg._lib.C.byref(d), zg.CS_RGB, None, bad._stream()))
+    assert np.array_equal(zg.Image.load_from_bytes(data).to_numpy(), native)  # format detection by signature
+
+
+@pytest.mark.gpu
+def test_decode_large_frame(oracle):
+    img = J.test_image(1080, 1920, seed=9)
+    for kw in (dict(subsampling=2), dict(subsampling=0, progressive=True)):
+        assert_same_decode(oracle, J.pil_jpeg(img, **{"quality": 85, **kw}), ("1080p", kw))

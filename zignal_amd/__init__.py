@@ -10,6 +10,6 @@ from .image import (AffineTransform, Blending, BorderMode, Image, ImagePyramid, 
                     SimilarityTransform, gaussian_kernel)
 
 __all__ = ["Image", "ImagePyramid", "Interpolation", "BorderMode", "Blending", "ProjectiveTransform", "AffineTransform",
-           "SimilarityTransform", "gaussian_kernel", "DimensionMismatch", "InvalidArgument", "CodecError", "ZignalError", "lib", "png"]
+           "SimilarityTransform", "gaussian_kernel", "DimensionMismatch", "InvalidArgument", "CodecError", "ZignalError", "lib", "png", "jpeg"]
 
-from . import png  # noqa: E402,F401
+from . import jpeg, png  # noqa: E402,F401

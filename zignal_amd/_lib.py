@@ -50,6 +50,18 @@ class ZgPngEncodeOptions(C.Structure):
                 ("srgb_intent", C.c_int)]
 
 
+class ZgJpegHeader(C.Structure):
+    """zg_jpeg_header == jpeg.Header (jpeg.zig:61-74)."""
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("precision", C.c_uint8), ("num_components", C.c_uint8),
+                ("progressive", C.c_uint8), ("subsampling", C.c_int8)]
+
+
+class ZgJpegLimits(C.Structure):
+    """zg_jpeg_limits == jpeg.DecodeLimits (jpeg.zig:19-33)."""
+    _fields_ = [("max_jpeg_bytes", C.c_size_t), ("max_marker_bytes", C.c_size_t), ("max_width", C.c_uint32), ("max_height", C.c_uint32),
+                ("max_pixels", C.c_uint64), ("max_blocks", C.c_size_t), ("max_scans", C.c_size_t)]
+
+
 class ZignalError(RuntimeError):
     def __init__(self, status: int, message: str):
         super().__init__(f"zignal_hip status {status}: {message}")
@@ -171,9 +183,14 @@ _SIGNATURES = {
     "zg_png_encode": [_IMG, C.c_int, C.POINTER(ZgPngEncodeOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p],
     "zg_png_encode_host": [_IMG, C.c_int, C.POINTER(ZgPngEncodeOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
     "zg_png_free": [C.c_void_p],
+    "zg_jpeg_default_limits": [C.POINTER(ZgJpegLimits)],
+    "zg_jpeg_info": [C.c_void_p, C.c_size_t, C.POINTER(ZgJpegLimits), C.POINTER(ZgJpegHeader)],
+    "zg_jpeg_probe": [C.c_void_p, C.c_size_t, C.POINTER(ZgJpegLimits), C.POINTER(ZgJpegHeader), C.POINTER(C.c_int)],
+    "zg_jpeg_decode": [C.c_void_p, C.c_size_t, C.POINTER(ZgJpegLimits), _IMG, C.c_int, C.POINTER(C.c_int), C.c_void_p],
+    "zg_jpeg_decode_host": [C.c_void_p, C.c_size_t, C.POINTER(ZgJpegLimits), _IMG, C.c_int, C.POINTER(C.c_int)],
 }
 _RESTYPES = {"zg_last_error": C.c_char_p, "zg_shutdown": None, "zg_pixel_size": C.c_size_t, "zg_pyramid_scale": C.c_float,
-             "zg_png_default_limits": None, "zg_png_default_encode_options": None, "zg_png_free": None}
+             "zg_png_default_limits": None, "zg_png_default_encode_options": None, "zg_png_free": None, "zg_jpeg_default_limits": None}
 
 # every symbol include/zignal_hip.h declares; tests check the library exports all of them
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -1,0 +1,903 @@
+// jpeg_codec.hip — JPEG files -> device images (reference src/codecs/jpeg.zig).
+//
+//   host    markers, tables, limits and errors (jpeg.zig:2035-2151, :1314-1645) and Huffman decoding of every scan into
+//           coefficient blocks (:1196-1310, :1740-1952, :2397-2479): a bit-serial chain, one per scan. The reference's bit
+//           reader is kept as it is (:1660-1736): restart markers are swallowed by the filler and a restart boundary drops
+//           whatever was pre-fetched, so most files with restart intervals come out as the reference produces them — wrong.
+//   device  per block: dequantise, integer IDCT (:2204-2394), +128 on component 0 (:2498-2515); per pixel: the chroma taps
+//           of the file's layout, YCbCr -> RGB, crop (:2518-2784); then zg_convert when T is not the native type.
+// Coefficients travel as i32 (the reference's own storage type: streams that decode to nonsense must produce the same
+// nonsense, and i16 would saturate differently); chroma goes up compacted to one block per MCU.
+#include "zg_common.h"
+
+#include <string.h>
+#include <vector>
+
+namespace zg {
+namespace {
+
+int jpeg_fail(const char *zig_error, const char *where) {
+    set_error("%s (%s)", zig_error, where);
+    return ZG_ERR_CODEC;
+}
+#define JPEG_FAIL(name) return jpeg_fail(name, __func__)
+enum { kEndOfData = -1000 }; // error.UnexpectedEndOfData travelling inside the entropy decoder (it ends a scan quietly)
+
+inline bool over(uint64_t limit, uint64_t value) { return limit != 0 && value > limit; }
+inline unsigned be16(const uint8_t *p) { return (unsigned)p[0] << 8 | p[1]; }
+
+const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                             35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+// ---- entropy layer -------------------------------------------------------------------------------------------------------------
+struct Huffman { // HuffmanTable (:1648-1657)
+    bool present = false;
+    uint8_t fast_symbol[512], fast_length[512];
+    int32_t max_code[17];
+    uint16_t min_code[17], first_value[17];
+    uint8_t values[256];
+};
+
+class BitReader { // :1660-1736
+  public:
+    const uint8_t *data = nullptr;
+    size_t len = 0, pos = 0;
+    uint64_t window = 0;
+    int held = 0;
+
+    bool fill(int want) { // false = error.UnexpectedEndOfData
+        while (held <= 56 && held < want) {
+            if (pos >= len) return false;
+            uint64_t byte = data[pos++];
+            if (byte == 0xFF) {
+                for (;;) {
+                    if (pos >= len) return false;
+                    const uint8_t next = data[pos++];
+                    if (next == 0x00) break;           // a stuffed 0xFF
+                    if (next == 0xFF) continue;        // fill bytes
+                    if (next >= 0xD0 && next <= 0xD7) { // RSTn: skipped, the byte after it is data
+                        if (pos >= len) return false;
+                        byte = data[pos++];
+                        if (byte == 0xFF) continue;
+                        break;
+                    }
+                    pos -= 2; // any other marker ends the entropy data
+                    return false;
+                }
+            }
+            window |= byte << (56 - held);
+            held += 8;
+        }
+        return true;
+    }
+    bool peek(int n, uint32_t *out) {
+        if (n == 0) { *out = 0; return true; }
+        if (!fill(n)) return false;
+        *out = (uint32_t)(window >> (64 - n));
+        return true;
+    }
+    void drop(int n) {
+        if (n == 0) return;
+        window <<= n;
+        held -= n;
+    }
+    bool take(int n, uint32_t *out) {
+        if (!peek(n, out)) return false;
+        drop(n);
+        return true;
+    }
+    void flush() { window = 0; held = 0; }
+};
+
+struct FrameComponent { uint8_t id, h, v, tq; };
+struct ScanComponent { uint8_t id, dc, ac; };
+struct Scan { ScanComponent comp[4]; int n = 0, ss = 0, se = 0, ah = 0, al = 0; };
+
+struct Decoder {
+    zg_jpeg_header header{};
+    FrameComponent comp[4]{};
+    Huffman dc[4], ac[4];
+    bool have_q[4] = {false, false, false, false};
+    uint16_t q[4][64];
+    Scan baseline;
+    unsigned restart_interval = 0;
+    BitReader bits;
+    unsigned bw = 0, bh = 0, bwa = 0, bha = 0; // block_width / height, and the MCU-padded grid
+    size_t nblocks = 0;
+    bool allocated = false;
+    std::vector<int32_t> coef[3]; // per component, nblocks x 64 on the luma grid (the reference's block_storage[block][component])
+    int32_t dc_pred[4] = {0, 0, 0, 0};
+    bool scan_limit_reached = false;
+
+    int32_t *block(size_t id, size_t c) { return coef[c].data() + id * 64; }
+
+    // readCode (:1196-1236): 0 ok, kEndOfData, or a ZG status with the error set
+    int read_symbol(const Huffman &t, int *symbol) {
+        uint32_t index = 0;
+        if (!bits.peek(9, &index)) index = 0;
+        if (bits.held >= 9) {
+            const uint8_t v = t.fast_symbol[index];
+            if (v != 255) {
+                bits.drop(t.fast_length[index]);
+                *symbol = v;
+                return 0;
+            }
+        }
+        uint32_t code = 0;
+        int length = 0;
+        if (bits.held >= 9) {
+            bits.drop(9);
+            code = index;
+            length = 9;
+        }
+        while (length < 16) {
+            uint32_t bit;
+            if (!bits.take(1, &bit)) return kEndOfData;
+            code = ((code << 1) | bit) & 0xffff;
+            ++length;
+            if ((int32_t)code <= t.max_code[length]) {
+                *symbol = t.values[(size_t)t.first_value[length] + code - t.min_code[length]];
+                return 0;
+            }
+        }
+        JPEG_FAIL("InvalidHuffmanCode");
+    }
+    int read_extended(int magnitude, int32_t *out) { // readMagnitudeCoded (:1239-1252)
+        if (magnitude == 0) { *out = 0; return 0; }
+        uint32_t raw;
+        if (!bits.peek(magnitude, &raw)) return kEndOfData;
+        bits.drop(magnitude);
+        int32_t v = (int32_t)raw;
+        if (v < (int32_t)1 << (magnitude - 1)) v -= ((int32_t)1 << magnitude) - 1;
+        *out = v;
+        return 0;
+    }
+    int read_ac_run(const Huffman &t, int32_t *blk) { // decodeAC (:1255-1310)
+        int k = 1, rc, symbol;
+        while (k < 64) {
+            if ((rc = read_symbol(t, &symbol))) return rc;
+            if (symbol == 0) {
+                while (k < 64) blk[kZigzag[k++]] = 0;
+                return 0;
+            }
+            const int run = symbol >> 4, size = symbol & 15;
+            if (size == 0) {
+                if (run != 15) JPEG_FAIL("InvalidACCoefficient");
+                for (int i = 0; i < 16 && k < 64; ++i) blk[kZigzag[k++]] = 0;
+                continue;
+            }
+            for (int i = 0; i < run && k < 64; ++i) blk[kZigzag[k++]] = 0;
+            if (k >= 64) break;
+            int32_t value;
+            if ((rc = read_extended(size, &value))) return rc;
+            blk[kZigzag[k++]] = value;
+        }
+        return 0;
+    }
+
+    int decode_baseline_block(const ScanComponent &sc, int32_t *blk, int32_t *pred) { // decodeBlockBaseline (:1933-1952)
+        memset(blk, 0, 64 * sizeof(int32_t));
+        if (sc.dc > 3 || !dc[sc.dc].present) JPEG_FAIL("MissingHuffmanTable");
+        int rc, symbol;
+        if ((rc = read_symbol(dc[sc.dc], &symbol))) return rc;
+        if (symbol > 11) JPEG_FAIL("InvalidDCCoefficient");
+        int32_t diff;
+        if ((rc = read_extended(symbol, &diff))) return rc;
+        *pred = (int32_t)((uint32_t)*pred + (uint32_t)diff);
+        blk[0] = *pred;
+        if (sc.ac > 3 || !ac[sc.ac].present) JPEG_FAIL("MissingHuffmanTable");
+        return read_ac_run(ac[sc.ac], blk);
+    }
+
+    int refine_bit(int32_t *c, int32_t bit) { // one correction bit for an already non-zero coefficient
+        uint32_t u;
+        if (!bits.take(1, &u)) return kEndOfData;
+        if (u) *c = (int32_t)((uint32_t)*c + (uint32_t)(*c > 0 ? bit : -bit));
+        return 0;
+    }
+    int decode_progressive_block(const Scan &s, const ScanComponent &sc, int32_t *blk, int32_t *pred, uint32_t *eob_run) { // :1816-1930
+        int rc, symbol;
+        uint32_t u;
+        if (s.ss == 0) {
+            if (sc.dc > 3 || !dc[sc.dc].present) JPEG_FAIL("MissingHuffmanTable");
+            if (s.ah == 0) {
+                if ((rc = read_symbol(dc[sc.dc], &symbol))) return rc;
+                if (symbol > 11) JPEG_FAIL("InvalidDCCoefficient");
+                int32_t diff;
+                if ((rc = read_extended(symbol, &diff))) return rc;
+                *pred = (int32_t)((uint32_t)diff + (uint32_t)*pred);
+                blk[0] = (int32_t)((uint32_t)*pred << s.al);
+            } else {
+                if (!bits.take(1, &u)) return kEndOfData;
+                blk[0] = (int32_t)((uint32_t)blk[0] + (u << s.al));
+            }
+            return 0;
+        }
+        if (sc.ac > 3 || !ac[sc.ac].present) JPEG_FAIL("MissingHuffmanTable");
+        const Huffman &t = ac[sc.ac];
+        int k = s.ss;
+        if (s.ah == 0) { // first pass over this band
+            if (*eob_run == 0) {
+                while (k <= s.se && k < 64) {
+                    int32_t value = 0;
+                    if ((rc = read_symbol(t, &symbol))) return rc;
+                    const int run = symbol >> 4, size = symbol & 15;
+                    if (size == 0) {
+                        if (run < 15) {
+                            if (!bits.take(run, &u)) return kEndOfData;
+                            *eob_run = (1u << run) + u;
+                            break;
+                        }
+                    } else {
+                        if (size > 10) JPEG_FAIL("InvalidACCoefficient");
+                        if ((rc = read_extended(size, &value))) return rc;
+                    }
+                    for (int i = 0; i < run && k < 64; ++i) blk[kZigzag[k++]] = 0;
+                    if (k >= 64) break;
+                    blk[kZigzag[k++]] = (int32_t)((uint32_t)value << s.al);
+                }
+            }
+            if (*eob_run > 0) {
+                *eob_run -= 1;
+                while (k <= s.se && k < 64) blk[kZigzag[k++]] = 0;
+            }
+            return 0;
+        }
+        const int32_t bit = (int32_t)1 << s.al; // refinement pass
+        if (*eob_run == 0) {
+            while (k <= s.se && k < 64) {
+                int32_t value = 0;
+                if ((rc = read_symbol(t, &symbol))) return rc;
+                int run = symbol >> 4;
+                if ((symbol & 15) == 0) {
+                    if (run < 15) {
+                        *eob_run = 1u << run;
+                        if (!bits.take(run, &u)) return kEndOfData;
+                        *eob_run += u;
+                        break;
+                    }
+                } else {
+                    if (!bits.take(1, &u)) return kEndOfData;
+                    value = u == 1 ? bit : -bit;
+                }
+                while (k <= s.se && k < 64) {
+                    int32_t *c = &blk[kZigzag[k]];
+                    if (*c == 0) {
+                        if (run > 0) { --run; ++k; }
+                        else { *c = value; ++k; break; }
+                    } else {
+                        if ((rc = refine_bit(c, bit))) return rc;
+                        ++k;
+                    }
+                }
+            }
+        }
+        if (*eob_run > 0) {
+            for (; k <= s.se && k < 64; ++k) {
+                int32_t *c = &blk[kZigzag[k]];
+                if (*c != 0 && (rc = refine_bit(c, bit))) return rc;
+            }
+            *eob_run -= 1;
+        }
+        return 0;
+    }
+
+    void sampling_maxima(int *mh, int *mv) const {
+        *mh = *mv = 1;
+        for (int i = 0; i < header.num_components; ++i) {
+            if (comp[i].h > *mh) *mh = comp[i].h;
+            if (comp[i].v > *mv) *mv = comp[i].v;
+        }
+    }
+    // the frame component a scan component names, and how many of its blocks sit in one step of the scan grid
+    bool locate(const ScanComponent &sc, bool single, size_t *index, unsigned *vcount, unsigned *hcount) const {
+        for (int i = 0; i < header.num_components; ++i)
+            if (comp[i].id == sc.id) {
+                *index = (size_t)i;
+                *vcount = single ? 1 : comp[i].v;
+                *hcount = single ? 1 : comp[i].h;
+                return true;
+            }
+        return false; // the reference leaves the counts undefined here; nothing is decoded for such a component
+    }
+
+    int run_progressive_scan(const Scan &s) { // performProgressiveScan (:1740-1813)
+        if (!allocated) JPEG_FAIL("BlockStorageNotAllocated");
+        uint32_t eob_run = 0;
+        const bool single = s.n == 1 && s.comp[0].id == 1; // the reference's notion of a non-interleaved scan
+        int mh, mv;
+        sampling_maxima(&mh, &mv);
+        const unsigned ystep = single ? 1 : (unsigned)mv, xstep = single ? 1 : (unsigned)mh;
+        for (unsigned y = 0; y < bh; y += ystep)
+            for (unsigned x = 0; x < bw; x += xstep) {
+                const size_t mcu = (size_t)y * bwa + x;
+                if (restart_interval != 0 && mcu % ((size_t)restart_interval * ystep * xstep) == 0) {
+                    bits.flush();
+                    memset(dc_pred, 0, sizeof dc_pred);
+                    eob_run = 0;
+                }
+                for (int i = 0; i < s.n; ++i) {
+                    size_t ci;
+                    unsigned vcount, hcount;
+                    if (!locate(s.comp[i], single, &ci, &vcount, &hcount)) continue;
+                    for (unsigned v = 0; v < vcount; ++v)
+                        for (unsigned h = 0; h < hcount; ++h) {
+                            const size_t id = (size_t)(y + v) * bwa + (x + h);
+                            if (id >= nblocks) continue;
+                            (void)bits.fill(24);
+                            const int rc = decode_progressive_block(s, s.comp[i], block(id, ci), &dc_pred[ci], &eob_run);
+                            if (rc == kEndOfData) return ZG_OK; // a cut scan keeps what it decoded (:1799-1803)
+                            if (rc) return rc;
+                        }
+                }
+            }
+        return ZG_OK;
+    }
+    int run_baseline_scan() { // performBlockScan (:2397-2479)
+        if (!allocated) JPEG_FAIL("BlockStorageNotAllocated");
+        const Scan &s = baseline;
+        int mh, mv;
+        sampling_maxima(&mh, &mv);
+        const bool single = s.n == 1 && s.comp[0].id == 1;
+        const unsigned ystep = single ? 1 : (unsigned)mv, xstep = single ? 1 : (unsigned)mh;
+        int32_t pred[4] = {0, 0, 0, 0}, spare[64];
+        uint32_t since_restart = 0;
+        for (unsigned y = 0; y < bh; y += ystep)
+            for (unsigned x = 0; x < bw; x += xstep) {
+                if (restart_interval != 0 && since_restart == restart_interval) {
+                    memset(pred, 0, sizeof pred);
+                    since_restart = 0;
+                    bits.flush();
+                }
+                for (int i = 0; i < s.n; ++i) {
+                    size_t ci;
+                    unsigned vcount, hcount;
+                    if (!locate(s.comp[i], single, &ci, &vcount, &hcount)) continue;
+                    for (unsigned v = 0; v < vcount; ++v)
+                        for (unsigned h = 0; h < hcount; ++h) {
+                            const unsigned ax = x + h, ay = y + v;
+                            int32_t *blk = (ay < bh && ax < bw) ? block((size_t)ay * bwa + ax, ci) : spare; // padding blocks are decoded and dropped
+                            (void)bits.fill(24);
+                            const int rc = decode_baseline_block(s.comp[i], blk, &pred[ci]);
+                            if (rc == kEndOfData) return ZG_OK;
+                            if (rc) return rc;
+                        }
+                }
+                ++since_restart;
+            }
+        return ZG_OK;
+    }
+
+    // ---- segments ------------------------------------------------------------------------------------------------------------
+    int parse_frame(const uint8_t *d, size_t n, bool progressive, const zg_jpeg_limits &lim) { // parseSOF (:1314-1442)
+        if (allocated) JPEG_FAIL("DuplicateSOF");
+        header.progressive = progressive ? 1 : 0;
+        if (n < 6) JPEG_FAIL("InvalidSOF");
+        header.precision = d[0];
+        if (d[0] == 12) JPEG_FAIL("Unsupported12BitPrecision");
+        if (d[0] == 16) JPEG_FAIL("Unsupported16BitPrecision");
+        if (d[0] != 8) JPEG_FAIL("UnsupportedPrecision");
+        header.height = be16(d + 1);
+        header.width = be16(d + 3);
+        header.num_components = d[5];
+        if (header.width == 0 || header.height == 0) JPEG_FAIL("InvalidSOF");
+        if (over(lim.max_width, header.width) || over(lim.max_height, header.height)) JPEG_FAIL("ImageTooLarge");
+        const int nc = d[5];
+        if (nc == 4) JPEG_FAIL("UnsupportedComponentCount");
+        if (nc != 1 && nc != 3) JPEG_FAIL("InvalidComponentCount");
+        int mh = 0, mv = 0;
+        for (int i = 0; i < nc; ++i) {
+            const size_t at = 6 + (size_t)i * 3;
+            if (at + 3 > n) JPEG_FAIL("InvalidSOF");
+            comp[i] = FrameComponent{d[at], (uint8_t)(d[at + 1] >> 4), (uint8_t)(d[at + 1] & 15), d[at + 2]};
+            if (comp[i].h > mh) mh = comp[i].h;
+            if (comp[i].v > mv) mv = comp[i].v;
+        }
+        if (mh > 4 || mv > 4) JPEG_FAIL("UnsupportedSamplingFactor");
+        if (nc == 3) {
+            if (comp[1].h != comp[2].h || comp[1].v != comp[2].v) JPEG_FAIL("InvalidComponentCount");
+            const bool chroma_unit = comp[1].h == 1 && comp[1].v == 1;
+            const int lh = comp[0].h, lv = comp[0].v;
+            const bool known = (lh == 1 && lv == 1) || (lh == 2 && lv == 2) || (lh == 2 && lv == 1) || (lh == 4 && lv == 1);
+            if (!chroma_unit || !known) JPEG_FAIL("UnsupportedSamplingFactor");
+        }
+        const uint32_t mcu_w = 8u * (uint32_t)mh, mcu_h = 8u * (uint32_t)mv;
+        const uint32_t wa = (header.width + mcu_w - 1) / mcu_w * mcu_w, ha = (header.height + mcu_h - 1) / mcu_h * mcu_h;
+        bw = (header.width + 7) / 8;
+        bh = (header.height + 7) / 8;
+        bwa = wa / 8;
+        bha = ha / 8;
+        const uint64_t padded = (uint64_t)wa * ha;
+        if (over(lim.max_pixels, padded)) JPEG_FAIL("ImageTooLarge");
+        if (over(lim.max_blocks, padded / 64)) JPEG_FAIL("BlockMemoryLimitExceeded");
+        nblocks = (size_t)(padded / 64);
+        for (int i = 0; i < nc; ++i) coef[i].assign(nblocks * 64, 0);
+        allocated = true;
+        return ZG_OK;
+    }
+    int parse_huffman(const uint8_t *d, size_t n) { // parseDHT (:1445-1540)
+        if (n == 0) JPEG_FAIL("InvalidDHT");
+        size_t at = 0;
+        while (at < n) {
+            if (at + 17 > n) JPEG_FAIL("InvalidDHT");
+            const int cls = (d[at] >> 4) & 1, id = d[at] & 3;
+            const uint8_t *counts = d + at + 1;
+            at += 17;
+            unsigned total = 0;
+            for (int i = 0; i < 16; ++i) total += counts[i];
+            if (total > 256) JPEG_FAIL("InvalidHuffmanTable");
+            if (at + total > n) JPEG_FAIL("InvalidDHT");
+            Huffman t;
+            memset(t.values, 0, sizeof t.values);
+            memcpy(t.values, d + at, total);
+            at += total;
+            memset(t.fast_symbol, 255, sizeof t.fast_symbol);
+            memset(t.fast_length, 0, sizeof t.fast_length);
+            for (int i = 0; i < 17; ++i) { t.max_code[i] = -1; t.min_code[i] = 0; t.first_value[i] = 0; }
+            unsigned code = 0, next = 0;
+            for (int len = 1; len <= 16; ++len) {
+                const int count = counts[len - 1];
+                if (count > 0) { t.first_value[len] = (uint16_t)next; t.min_code[len] = (uint16_t)code; }
+                for (int j = 0; j < count; ++j) {
+                    if (code == (1u << len) - 1) JPEG_FAIL("InvalidHuffmanTable"); // the all-ones code is reserved
+                    const uint8_t symbol = t.values[next++];
+                    if (len <= 9) {
+                        const unsigned first = (code << (9 - len)) & 0xffff, span = 1u << (9 - len);
+                        for (unsigned k = 0; k < span; ++k) { t.fast_symbol[first + k] = symbol; t.fast_length[first + k] = (uint8_t)len; }
+                    }
+                    code = (code + 1) & 0xffff;
+                }
+                if (count > 0) t.max_code[len] = (int32_t)code - 1;
+                code = (code << 1) & 0xffff;
+            }
+            t.present = true;
+            (cls == 0 ? dc : ac)[id] = t;
+        }
+        return ZG_OK;
+    }
+    int parse_quant(const uint8_t *d, size_t n) { // parseDQT (:1543-1583)
+        if (n == 0) JPEG_FAIL("InvalidDQT");
+        size_t at = 0;
+        while (at < n) {
+            const int wide = (d[at] >> 4) & 15, id = d[at] & 3;
+            ++at;
+            const size_t width = wide == 0 ? 1 : 2;
+            if (at + 64 * width > n) JPEG_FAIL("InvalidDQT");
+            for (int i = 0; i < 64; ++i) q[id][kZigzag[i]] = width == 1 ? d[at + i] : (uint16_t)be16(d + at + 2 * i);
+            at += 64 * width;
+            have_q[id] = true;
+        }
+        return ZG_OK;
+    }
+    int parse_scan_header(const uint8_t *d, size_t n, Scan *s) { // parseSOS (:1586-1638)
+        if (n < 6) JPEG_FAIL("InvalidSOS");
+        const int nc = d[0];
+        if (!header.progressive && nc != header.num_components) JPEG_FAIL("InvalidSOS");
+        if (header.progressive && (nc == 0 || nc > header.num_components)) JPEG_FAIL("InvalidSOS");
+        size_t at = 1;
+        s->n = nc;
+        for (int i = 0; i < nc; ++i) {
+            if (at + 2 > n) JPEG_FAIL("InvalidSOS");
+            if (i < 4) s->comp[i] = ScanComponent{d[at], (uint8_t)(d[at + 1] >> 4), (uint8_t)(d[at + 1] & 15)};
+            at += 2;
+        }
+        if (at + 3 > n) JPEG_FAIL("InvalidSOS");
+        const int ss = d[at], se = d[at + 1], approx = d[at + 2];
+        if (!header.progressive) {
+            if (ss != 0 || se != 63 || approx != 0) JPEG_FAIL("InvalidSOS");
+        } else {
+            if (ss > 63 || se > 63 || se < ss) JPEG_FAIL("InvalidSOS");
+            if ((ss == 0 || se == 0) && !(ss == 0 && se == 0)) JPEG_FAIL("InvalidSOS"); // a DC scan is 0..0, an AC scan starts above 0
+        }
+        s->ss = ss; s->se = se; s->ah = approx >> 4; s->al = approx & 15;
+        return ZG_OK;
+    }
+
+    // decode (:2035-2151)
+    int read_stream(const uint8_t *d, size_t len, const zg_jpeg_limits &lim) {
+        if (len < 2 || d[0] != 0xFF || d[1] != 0xD8) JPEG_FAIL("InvalidJpegFile");
+        if (over(lim.max_jpeg_bytes, len)) JPEG_FAIL("JpegDataTooLarge");
+        size_t at = 2, marker_bytes = 0, scans = 0;
+        auto charge = [&](size_t n) { marker_bytes += n; return lim.max_marker_bytes != 0 && marker_bytes > lim.max_marker_bytes; };
+        while (at + 1 < len) {
+            if (d[at] != 0xFF) JPEG_FAIL("InvalidMarker");
+            const int m = d[at + 1];
+            const bool in_enum = (m >= 0xC0 && m <= 0xC4) || m == 0xCC || (m >= 0xD0 && m <= 0xDF) || (m >= 0xE0 && m <= 0xEF) || m == 0xFE; // Marker (:1045-1098)
+            if (!in_enum) { // skipped by its length
+                at += 2;
+                if (at + 2 > len) break;
+                const unsigned length = be16(d + at);
+                if (length < 2) JPEG_FAIL("InvalidMarker");
+                at += length;
+                continue;
+            }
+            switch (m) {
+            case 0xD8: at += 2; continue;
+            case 0xD9: at = len; continue; // EOI ends the loop
+            case 0xC1: JPEG_FAIL("UnsupportedExtendedSequential");
+            case 0xC3: JPEG_FAIL("UnsupportedLosslessJpeg");
+            case 0xCC: JPEG_FAIL("UnsupportedArithmeticCoding");
+            case 0xDE: JPEG_FAIL("UnsupportedHierarchicalJpeg");
+            case 0xDC: JPEG_FAIL("UnsupportedJpegVariant");
+            case 0xC0: case 0xC2: case 0xC4: case 0xDB: case 0xDD: { // readMarkerPayload (:2020-2033)
+                if (at + 4 > len) JPEG_FAIL("UnexpectedEndOfData");
+                const unsigned length = be16(d + at + 2);
+                if (length < 2) JPEG_FAIL("InvalidMarker");
+                const size_t end = at + 2 + length;
+                if (end > len) JPEG_FAIL("InvalidMarker");
+                if (charge(length)) JPEG_FAIL("MarkerDataLimitExceeded");
+                const uint8_t *payload = d + at + 4;
+                const size_t n = end - (at + 4);
+                at = end;
+                int rc = ZG_OK;
+                if (m == 0xC0 || m == 0xC2) rc = parse_frame(payload, n, m == 0xC2, lim);
+                else if (m == 0xC4) rc = parse_huffman(payload, n);
+                else if (m == 0xDB) rc = parse_quant(payload, n);
+                else {
+                    if (n != 2) JPEG_FAIL("InvalidDRI");
+                    restart_interval = be16(payload);
+                }
+                if (rc) return rc;
+                continue;
+            }
+            case 0xDA: { // processScanMarker (:1987-2018)
+                if (over(lim.max_scans, scans + 1)) { scan_limit_reached = true; at = len; continue; }
+                ++scans;
+                if (at + 4 > len) JPEG_FAIL("UnexpectedEndOfData");
+                const unsigned hl = be16(d + at + 2);
+                if (hl < 2) JPEG_FAIL("InvalidMarker");
+                const size_t end = at + 2 + hl;
+                if (end > len) JPEG_FAIL("InvalidMarker");
+                Scan s;
+                int rc = parse_scan_header(d + at + 4, end - (at + 4), &s);
+                if (rc) return rc;
+                size_t stop = end; // findScanEnd (:1955-1978): up to the next real marker; the very last byte of the buffer is never taken
+                while (stop + 1 < len) {
+                    if (d[stop] == 0xFF) {
+                        const uint8_t nb = d[stop + 1];
+                        if (nb == 0x00 || (nb >= 0xD0 && nb <= 0xD7)) { stop += 2; continue; }
+                        break;
+                    }
+                    ++stop;
+                }
+                bits = BitReader{};
+                bits.data = d + end;
+                bits.len = stop - end;
+                if (!header.progressive) {
+                    baseline = s;
+                    if (charge(stop - at)) JPEG_FAIL("MarkerDataLimitExceeded");
+                    return ZG_OK; // a baseline stream is one scan; its blocks are decoded by run_baseline_scan
+                }
+                if ((rc = run_progressive_scan(s))) return rc;
+                if (charge(stop - at)) JPEG_FAIL("MarkerDataLimitExceeded");
+                at = stop;
+                continue;
+            }
+            default: { // APPn, COM, and the enum's leftovers (RSTn, EXP): skipped by their length, unchecked (:2119-2139)
+                if (at + 4 > len) { at = len; continue; }
+                const unsigned length = be16(d + at + 2);
+                if (charge(length)) JPEG_FAIL("MarkerDataLimitExceeded");
+                at += 2 + (size_t)length;
+                continue;
+            }
+            }
+        }
+        if (header.progressive) return ZG_OK;
+        JPEG_FAIL("NoScanData");
+    }
+};
+
+// ---- device ----------------------------------------------------------------------------------------------------------------------
+// i32 arithmetic that wraps like the hardware does (a corrupt stream can drive the reference's i32 values anywhere)
+__device__ inline int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+__device__ inline int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+__device__ inline int32_t wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+
+// idct1D (:2209-2247): stb_image's butterfly; the constants are @round(x * 4096)
+__device__ inline void idct_1d(const int32_t s[8], int32_t x[4], int32_t t[4]) {
+    int32_t p2 = s[2], p3 = s[6];
+    int32_t p1 = wmul(wadd(p2, p3), 2217);
+    int32_t t2 = wadd(p1, wmul(p3, -7568)), t3 = wadd(p1, wmul(p2, 3135));
+    p2 = s[0]; p3 = s[4];
+    int32_t t0 = wmul(wadd(p2, p3), 4096), t1 = wmul(wsub(p2, p3), 4096);
+    x[0] = wadd(t0, t3); x[3] = wsub(t0, t3); x[1] = wadd(t1, t2); x[2] = wsub(t1, t2);
+    t0 = s[7]; t1 = s[5]; t2 = s[3]; t3 = s[1];
+    p3 = wadd(t0, t2);
+    int32_t p4 = wadd(t1, t3);
+    p1 = wadd(t0, t3); p2 = wadd(t1, t2);
+    const int32_t p5 = wmul(wadd(p3, p4), 4816);
+    t0 = wmul(t0, 1223); t1 = wmul(t1, 8410); t2 = wmul(t2, 12586); t3 = wmul(t3, 6149);
+    p1 = wadd(p5, wmul(p1, -3686)); p2 = wadd(p5, wmul(p2, -10498));
+    p3 = wmul(p3, -8035); p4 = wmul(p4, -1598);
+    t[3] = wadd(t3, wadd(p1, p4)); t[2] = wadd(t2, wadd(p2, p3)); t[1] = wadd(t1, wadd(p2, p4)); t[0] = wadd(t0, wadd(p1, p3));
+}
+
+struct QuantTable { uint16_t q[64]; };
+
+// Dequantise + IDCT + level shift for one component. 32 blocks per workgroup, 8 lanes per block: lane c of a block runs the
+// column pass for column c (results to LDS), then the row pass for row c. `blocks` is blocks_x * blocks_y x 64 coefficients in
+// natural order; `plane` is the component's sample plane (blocks_y * 8 rows of blocks_x * 8 i32 samples).
+__global__ __launch_bounds__(256) void k_jpeg_idct(const int32_t *blocks, QuantTable qt, unsigned nblocks, unsigned blocks_x, int32_t shift, int32_t *plane) {
+    __shared__ int32_t tile[32][72]; // row stride 8, block stride 72: the eight lanes of eight blocks hit 64 different banks
+    const unsigned local = threadIdx.x >> 3, lane = threadIdx.x & 7, b = blockIdx.x * 32 + local;
+    const bool live = b < nblocks;
+    int32_t s[8], x[4], t[4];
+    int32_t ac = 0;
+    if (live) {
+        const int32_t *src = blocks + (size_t)b * 64;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            s[r] = wmul(src[r * 8 + lane], (int32_t)qt.q[r * 8 + lane]); // dequantizeAllBlocks (:2482-2495)
+            if (r > 0 || lane > 0) ac |= s[r];
+        }
+    }
+    // every coefficient but the DC zero: the reference short-cuts to (dc + 4) >> 3 (:2259-2266)
+    ac |= __shfl_xor(ac, 1);
+    ac |= __shfl_xor(ac, 2);
+    ac |= __shfl_xor(ac, 4);
+    const int32_t dc = __shfl(live ? s[0] : 0, (int)(threadIdx.x & 63 & ~7u));
+    if (live && ac != 0) {
+        idct_1d(s, x, t);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = wadd(x[k], 512);
+        int32_t *col = &tile[local][lane];
+        col[0 * 8] = wadd(x[0], t[3]) >> 10; col[1 * 8] = wadd(x[1], t[2]) >> 10; col[2 * 8] = wadd(x[2], t[1]) >> 10; col[3 * 8] = wadd(x[3], t[0]) >> 10;
+        col[4 * 8] = wsub(x[3], t[0]) >> 10; col[5 * 8] = wsub(x[2], t[1]) >> 10; col[6 * 8] = wsub(x[1], t[2]) >> 10; col[7 * 8] = wsub(x[0], t[3]) >> 10;
+    }
+    __syncthreads();
+    if (!live) return;
+    int32_t o[8];
+    if (ac != 0) {
+        const int32_t *row = &tile[local][lane * 8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] = row[k];
+        idct_1d(s, x, t);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = wadd(x[k], 65536);
+        o[0] = wadd(x[0], t[3]) >> 17; o[1] = wadd(x[1], t[2]) >> 17; o[2] = wadd(x[2], t[1]) >> 17; o[3] = wadd(x[3], t[0]) >> 17;
+        o[4] = wsub(x[3], t[0]) >> 17; o[5] = wsub(x[2], t[1]) >> 17; o[6] = wsub(x[1], t[2]) >> 17; o[7] = wsub(x[0], t[3]) >> 17;
+    } else {
+        const int32_t flat = wadd(dc, 4) >> 3;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = flat;
+    }
+    const unsigned by = b / blocks_x, bx = b % blocks_x;
+    int32_t *dst = plane + ((size_t)by * 8 + lane) * ((size_t)blocks_x * 8) + (size_t)bx * 8;
+    *(int4 *)dst = make_int4(wadd(o[0], shift), wadd(o[1], shift), wadd(o[2], shift), wadd(o[3], shift));
+    *(int4 *)(dst + 4) = make_int4(wadd(o[4], shift), wadd(o[5], shift), wadd(o[6], shift), wadd(o[7], shift));
+}
+
+__device__ inline int32_t clamp255(int32_t v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ inline int32_t round_half_away(float v) { // @round, then the cast to i32
+    const float r = truncf(v);
+    return (int32_t)(fabsf(v - r) >= 0.5f ? r + copysignf(1.0f, v) : r);
+}
+// The chroma tap along one axis for luma sample i of the MCU (:2592-2595, :2700-2710): the position is clamped into the
+// MCU's own 8-sample chroma block, the weight is not (it goes negative at the leading edge).
+__device__ inline void chroma_tap(int i, float scale, int *c0, int *c1, float *w) {
+    const float at = ((float)i + 0.5f) * scale - 0.5f;
+    float f = floorf(at);
+    f = f < 0.0f ? 0.0f : (f > 7.0f ? 7.0f : f);
+    *c0 = (int)f;
+    *c1 = *c0 + 1 < 7 ? *c0 + 1 : 7;
+    *w = at - (float)*c0;
+}
+__device__ inline float lerp_fma(float a, float b, float t) { return __builtin_fmaf(b - a, t, a); } // std.math.lerp
+
+struct RenderArgs {
+    const int32_t *y, *cb, *cr; // sample planes
+    unsigned luma_pitch, chroma_pitch;
+    int components, mh, mv;     // luma sampling factors (chroma is 1 x 1)
+};
+// One lane per pixel of the cropped image: ycbcrToRgbAllBlocks (:2518-2749) + renderRgbBlocksToPixels (:2752-2784).
+template <int NATIVE> __global__ __launch_bounds__(256) void k_jpeg_render(RenderArgs a, DImg dst) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= dst.cols) return;
+    const int32_t Y = a.y[(size_t)y * a.luma_pitch + x];
+    uint8_t *out = (uint8_t *)dst.data + ((size_t)y * dst.stride + x) * Px<NATIVE>::BYTES;
+    if constexpr (NATIVE == ZG_PIXEL_U8) {
+        out[0] = (uint8_t)clamp255(Y); // convertColor(u8, Rgb{v, v, v}) == v
+    } else {
+        int32_t r, g, b;
+        if (a.mh == 1 && a.mv == 1) { // 4:4:4 (:2541-2564): chroma stays centred on zero, no clamping before the matrix
+            const int32_t Cb = a.cb[(size_t)y * a.chroma_pitch + x], Cr = a.cr[(size_t)y * a.chroma_pitch + x];
+            r = wadd(Y, wadd(wmul(91881, Cr), 32768) >> 16);
+            g = wsub(Y, wadd(wadd(wmul(22554, Cb), wmul(46802, Cr)), 32768) >> 16);
+            b = wadd(Y, wadd(wmul(116130, Cb), 32768) >> 16);
+        } else {
+            const int mcu_w = 8 * a.mh, mcu_h = 8 * a.mv;
+            const int mx = x / mcu_w, my = y / mcu_h, ix = x % mcu_w, iy = y % mcu_h;
+            const int32_t *cbp = a.cb + (size_t)my * 8 * a.chroma_pitch + (size_t)mx * 8, *crp = a.cr + (size_t)my * 8 * a.chroma_pitch + (size_t)mx * 8;
+            int cx0, cx1, cy0 = iy, cy1 = iy;
+            float wx, wy = 0.0f;
+            chroma_tap(ix, a.mh == 4 ? 0.25f : 0.5f, &cx0, &cx1, &wx);
+            int32_t Cb, Cr;
+            if (a.mv == 2) {
+                chroma_tap(iy, 0.5f, &cy0, &cy1, &wy);
+                const size_t r0 = (size_t)cy0 * a.chroma_pitch, r1 = (size_t)cy1 * a.chroma_pitch;
+                Cb = round_half_away(lerp_fma(lerp_fma((float)cbp[r0 + cx0], (float)cbp[r0 + cx1], wx), lerp_fma((float)cbp[r1 + cx0], (float)cbp[r1 + cx1], wx), wy));
+                Cr = round_half_away(lerp_fma(lerp_fma((float)crp[r0 + cx0], (float)crp[r0 + cx1], wx), lerp_fma((float)crp[r1 + cx0], (float)crp[r1 + cx1], wx), wy));
+            } else {
+                const size_t r0 = (size_t)iy * a.chroma_pitch;
+                Cb = round_half_away(lerp_fma((float)cbp[r0 + cx0], (float)cbp[r0 + cx1], wx));
+                Cr = round_half_away(lerp_fma((float)crp[r0 + cx0], (float)crp[r0 + cx1], wx));
+            }
+            // Ycbcr(u8){ clamp(Y), clamp(Cb + 128), clamp(Cr + 128) }.to(.rgb): color.zig:1057-1068
+            const int64_t yy = clamp255(Y), cb = (int64_t)clamp255(wadd(Cb, 128)) - 128, cr = (int64_t)clamp255(wadd(Cr, 128)) - 128;
+            r = (int32_t)((65536 * yy + 91881 * cr + 32768) >> 16);
+            g = (int32_t)((65536 * yy - 22554 * cb - 46802 * cr + 32768) >> 16);
+            b = (int32_t)((65536 * yy + 116130 * cb + 32768) >> 16);
+        }
+        out[0] = (uint8_t)clamp255(r); out[1] = (uint8_t)clamp255(g); out[2] = (uint8_t)clamp255(b);
+    }
+}
+
+int natural_space(int pixel) { return pixel == ZG_PIXEL_U8 ? ZG_CS_GRAY : ZG_CS_RGB; }
+
+int decode_impl(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, const zg_image *dst, int dst_space, int *scan_limit_reached_out, hipStream_t s) {
+    ZG_REQUIRE(jpeg != nullptr, ZG_ERR_INVALID_ARGUMENT, "jpeg: null data");
+    zg_jpeg_limits lim;
+    if (limits) lim = *limits; else zg_jpeg_default_limits(&lim);
+    int rc;
+    if ((rc = check_image(dst, "dst"))) return rc;
+    std::vector<Decoder> holder(1); // large (Huffman tables): keep it off the stack
+    Decoder &d = holder[0];
+    d.header.precision = 8;
+    if ((rc = d.read_stream(jpeg, len, lim))) return rc;
+    if (scan_limit_reached_out) *scan_limit_reached_out = d.scan_limit_reached ? 1 : 0;
+    if (!d.header.progressive && (rc = d.run_baseline_scan())) return rc;
+    if (!d.allocated) JPEG_FAIL("BlockStorageNotAllocated");
+    const int nc = d.header.num_components;
+    for (int c = 0; c < nc; ++c)
+        if (d.comp[c].tq > 3 || !d.have_q[d.comp[c].tq]) JPEG_FAIL("MissingQuantTable");
+    ZG_REQUIRE(dst->rows == d.header.height && dst->cols == d.header.width, ZG_ERR_DIMENSION_MISMATCH, "jpeg: the frame is %ux%u, dst is %ux%u",
+               d.header.height, d.header.width, dst->rows, dst->cols);
+
+    // chroma of a subsampled frame: only the block at each MCU's origin is ever read (:2573, :2627, :2680): compact it
+    const int mh = nc == 3 ? d.comp[0].h : 1, mv = nc == 3 ? d.comp[0].v : 1;
+    const bool subsampled = nc == 3 && !(mh == 1 && mv == 1);
+    const unsigned cbx = subsampled ? d.bwa / mh : d.bwa, cby = subsampled ? d.bha / mv : d.bha;
+    std::vector<int32_t> packed[2];
+    if (subsampled) {
+        for (int c = 0; c < 2; ++c) {
+            packed[c].resize((size_t)cbx * cby * 64);
+            for (unsigned y = 0; y < cby; ++y)
+                for (unsigned x = 0; x < cbx; ++x)
+                    memcpy(packed[c].data() + ((size_t)y * cbx + x) * 64, d.block((size_t)y * mv * d.bwa + (size_t)x * mh, (size_t)c + 1), 64 * sizeof(int32_t));
+        }
+    }
+    const size_t luma_coefs = d.nblocks * 64, chroma_coefs = nc == 3 ? (size_t)cbx * cby * 64 : 0;
+    const size_t coef_words = luma_coefs + 2 * chroma_coefs;
+    const int native = nc == 1 ? ZG_PIXEL_U8 : ZG_PIXEL_RGB_U8;
+    const bool direct = dst->pixel == native && dst_space == natural_space(native);
+    const size_t native_bytes = direct ? 0 : (size_t)d.header.width * d.header.height * pixel_size(native);
+    // scratch: coefficients | sample planes (same sizes) | native image when a conversion follows
+    int32_t *dev = nullptr;
+    if ((rc = scratch_alloc((void **)&dev, coef_words * 2 * sizeof(int32_t) + native_bytes + 256, s))) return rc;
+    hipError_t e = hipMemcpyAsync(dev, d.coef[0].data(), luma_coefs * sizeof(int32_t), hipMemcpyHostToDevice, s);
+    for (int c = 0; c < 2 && nc == 3 && e == hipSuccess; ++c)
+        e = hipMemcpyAsync(dev + luma_coefs + (size_t)c * chroma_coefs, subsampled ? packed[c].data() : d.coef[c + 1].data(), chroma_coefs * sizeof(int32_t),
+                           hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s); // the host vectors die with this call
+    if (e != hipSuccess) { scratch_free(dev, s); return hip_fail(e, "jpeg upload", __FILE__, __LINE__); }
+
+    int32_t *planes = dev + coef_words;
+    for (int c = 0; c < nc; ++c) {
+        QuantTable qt;
+        memcpy(qt.q, d.q[d.comp[c].tq], sizeof qt.q);
+        const unsigned bx = c == 0 ? d.bwa : cbx, count = c == 0 ? (unsigned)d.nblocks : cbx * cby;
+        const size_t off = c == 0 ? 0 : luma_coefs + (size_t)(c - 1) * chroma_coefs;
+        hipLaunchKernelGGL(k_jpeg_idct, dim3(ceil_div(count, 32)), dim3(256), 0, s, (const int32_t *)(dev + off), qt, count, bx, c == 0 ? 128 : 0, planes + off);
+    }
+    RenderArgs a{planes, planes + luma_coefs, planes + luma_coefs + chroma_coefs, d.bwa * 8, cbx * 8, nc, mh, mv};
+    zg_image native_img{(char *)(dev + coef_words * 2) + 128, d.header.width, d.header.height, d.header.width, native};
+    const zg_image *target = direct ? dst : &native_img;
+    const dim3 grid(ceil_div(d.header.width, 256), d.header.height);
+    if (native == ZG_PIXEL_U8) hipLaunchKernelGGL((k_jpeg_render<ZG_PIXEL_U8>), grid, dim3(256), 0, s, a, dimg(target));
+    else hipLaunchKernelGGL((k_jpeg_render<ZG_PIXEL_RGB_U8>), grid, dim3(256), 0, s, a, dimg(target));
+    rc = hipGetLastError() == hipSuccess ? ZG_OK : ZG_ERR_HIP;
+    if (rc == ZG_OK && !direct) rc = zg_convert(&native_img, natural_space(native), dst, dst_space, nullptr, (zg_stream)s); // Image.convert (:2831-2850)
+    scratch_free(dev, s);
+    return rc;
+}
+
+} // namespace
+} // namespace zg
+
+using namespace zg;
+
+extern "C" {
+
+void zg_jpeg_default_limits(zg_jpeg_limits *l) { // jpeg.zig:19-33
+    l->max_jpeg_bytes = l->max_marker_bytes = (size_t)100 * 1024 * 1024;
+    l->max_width = l->max_height = 8192;
+    l->max_pixels = 67108864ull;
+    l->max_blocks = 1048576;
+    l->max_scans = 64;
+}
+
+// jpeg.getInfo (:77-179): a forward-only hunt for the first SOFn; running out of bytes anywhere is error.EndOfStream.
+int zg_jpeg_info(const uint8_t *d, size_t len, const zg_jpeg_limits *limits, zg_jpeg_header *out) {
+    ZG_REQUIRE(d && out, ZG_ERR_INVALID_ARGUMENT, "jpeg info: null argument");
+    zg_jpeg_limits lim;
+    if (limits) lim = *limits; else zg_jpeg_default_limits(&lim);
+    if (len < 2) JPEG_FAIL("EndOfStream");
+    if (d[0] != 0xFF || d[1] != 0xD8) JPEG_FAIL("InvalidJpegFile");
+    size_t at = 2, seen = 2, markers = 0;
+    for (;;) {
+        for (;;) { // hunt for 0xFF
+            if (at >= len) JPEG_FAIL("EndOfStream");
+            const uint8_t byte = d[at++];
+            if (++seen > lim.max_jpeg_bytes) JPEG_FAIL("ImageTooLarge");
+            if (byte == 0xFF) break;
+        }
+        if (at >= len) JPEG_FAIL("EndOfStream");
+        int m = d[at++];
+        ++seen;
+        while (m == 0xFF) { // padding
+            if (at >= len) JPEG_FAIL("EndOfStream");
+            m = d[at++];
+            if (++seen > lim.max_jpeg_bytes) JPEG_FAIL("ImageTooLarge");
+        }
+        if (m == 0x00) continue;
+        if (++markers > 10000) JPEG_FAIL("ImageTooLarge");
+        if (m == 0x01 || (m >= 0xD0 && m <= 0xD8)) continue; // TEM, RSTn, SOI: no payload
+        if (m == 0xD9) JPEG_FAIL("MissingSOF");
+        if (len - at < 2) JPEG_FAIL("EndOfStream");
+        const unsigned length = be16(d + at);
+        at += 2;
+        seen += 2;
+        if (length < 2) JPEG_FAIL("InvalidMarker");
+        const bool sof = m >= 0xC0 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC;
+        const unsigned payload = length - 2;
+        if (sof) {
+            if (payload < 6) JPEG_FAIL("InvalidSOF");
+            if (seen + payload > lim.max_jpeg_bytes) JPEG_FAIL("ImageTooLarge");
+            if (len - at < 6) JPEG_FAIL("EndOfStream");
+            zg_jpeg_header h{};
+            h.precision = d[at];
+            h.height = be16(d + at + 1);
+            h.width = be16(d + at + 3);
+            h.num_components = d[at + 5];
+            h.progressive = m == 0xC2;
+            h.subsampling = -1;
+            if (h.num_components == 3 && payload - 6 >= 9) {
+                if (len - at < 15) JPEG_FAIL("EndOfStream");
+                const uint8_t luma = d[at + 7], cb = d[at + 10], cr = d[at + 13]; // the sampling byte of each component triple
+                if (cb == 0x11 && cr == 0x11) h.subsampling = luma == 0x11 ? 0 : (luma == 0x21 ? 1 : (luma == 0x22 ? 2 : -1));
+            }
+            *out = h;
+            return ZG_OK;
+        }
+        if (seen + payload > lim.max_jpeg_bytes) JPEG_FAIL("ImageTooLarge");
+        const size_t skip = len - at < payload ? len - at : payload;
+        at += skip;
+        seen += skip;
+    }
+}
+
+int zg_jpeg_probe(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, zg_jpeg_header *header_out, int *scan_limit_reached_out) {
+    ZG_REQUIRE(jpeg != nullptr, ZG_ERR_INVALID_ARGUMENT, "jpeg probe: null data");
+    zg_jpeg_limits lim;
+    if (limits) lim = *limits; else zg_jpeg_default_limits(&lim);
+    std::vector<Decoder> holder(1);
+    holder[0].header.precision = 8;
+    const int rc = holder[0].read_stream(jpeg, len, lim);
+    if (rc) return rc;
+    if (header_out) { *header_out = holder[0].header; header_out->subsampling = -1; }
+    if (scan_limit_reached_out) *scan_limit_reached_out = holder[0].scan_limit_reached ? 1 : 0;
+    return ZG_OK;
+}
+int zg_jpeg_decode(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, const zg_image *dst, int dst_space, int *scan_limit_reached_out, zg_stream stream) {
+    return decode_impl(jpeg, len, limits, dst, dst_space, scan_limit_reached_out, as_stream(stream));
+}
+int zg_jpeg_decode_host(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, const zg_image *dst, int dst_space, int *scan_limit_reached_out) {
+    HostStage d;
+    int rc;
+    if ((rc = d.upload(dst, false, true))) return rc;
+    if ((rc = decode_impl(jpeg, len, limits, &d.dev, dst_space, scan_limit_reached_out, nullptr))) return rc;
+    ZG_HIP(hipStreamSynchronize(nullptr));
+    return d.finish();
+}
+
+} // extern "C"

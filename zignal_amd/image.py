@@ -175,12 +175,14 @@ class Image:
     @staticmethod
     def load_from_bytes(data: bytes, kind: Optional[str] = None, device: Optional[str] = "cuda") -> "Image":
         """Image(T).loadFromBytes: the format comes from the signature; `kind` names T ("u8" / "rgb_u8" / "rgba_u8", None
-        = the file's native type). JPEG / BMP / GIF are recognised and rejected (their codecs are not part of this build)."""
-        from . import png
+        = the file's native type). BMP / GIF are not part of this build."""
+        from . import jpeg, png
         data = bytes(data)
         if data[:8] == bytes([137, 80, 78, 71, 13, 10, 26, 10]):
             return png.load_from_bytes(data, kind, None, device)
-        raise L.ZignalError(L.ERR_UNSUPPORTED, "UnsupportedImageFormat (only PNG is decoded by this library)")
+        if data[:2] == b"\xff\xd8":
+            return jpeg.load_from_bytes(data, kind, None, device)
+        raise L.ZignalError(L.ERR_UNSUPPORTED, "UnsupportedImageFormat (PNG and JPEG are decoded by this library)")
 
     @staticmethod
     def load(path: str, kind: Optional[str] = None, device: Optional[str] = "cuda") -> "Image":

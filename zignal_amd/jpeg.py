@@ -1,0 +1,80 @@
+"""zignal_amd.jpeg — host-side mirror of the reference's JPEG decoding surface (src/codecs/jpeg.zig) over zg_jpeg_*.
+
+Markers and Huffman decoding run on the host inside libzignal_hip.so; dequantisation, the IDCT, chroma upsampling, colour
+conversion and the conversion to the requested Image(T) run on the MI355X. Errors of the reference's error set surface as
+`CodecError` with `.name` == the Zig error name. (Encoding — jpeg.encode / save — is not part of this build.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+from .image import Image, torch
+
+_KINDS = {"u8": (L.PIXEL_U8, L.CS_GRAY, 1), "rgb_u8": (L.PIXEL_RGB_U8, L.CS_RGB, 3), "rgba_u8": (L.PIXEL_RGBA_U8, L.CS_RGBA, 4)}
+SUBSAMPLING = {0: "yuv444", 1: "yuv422", 2: "yuv420", -1: None}  # jpeg.Subsampling (jpeg.zig:260-283)
+
+
+def decode_limits(**overrides) -> L.ZgJpegLimits:
+    """jpeg.DecodeLimits{...}: the defaults (jpeg.zig:19-33) with the given fields replaced; 0 disables a limit."""
+    lim = L.ZgJpegLimits()
+    L.lib().zg_jpeg_default_limits(C.byref(lim))
+    for k, v in overrides.items():
+        if not hasattr(lim, k):
+            raise TypeError(f"DecodeLimits has no field {k}")
+        setattr(lim, k, v)
+    return lim
+
+
+def _buf(data: bytes):
+    data = bytes(data)
+    return (C.c_uint8 * max(1, len(data))).from_buffer_copy(data if data else b"\0"), len(data)
+
+
+def get_info(data: bytes, limits: Optional[L.ZgJpegLimits] = None) -> L.ZgJpegHeader:
+    """jpeg.getInfo (jpeg.zig:77-179)."""
+    buf, n = _buf(data)
+    h = L.ZgJpegHeader()
+    L.check(L.lib().zg_jpeg_info(buf, n, C.byref(limits) if limits is not None else None, C.byref(h)))
+    return h
+
+
+def decode(data: bytes, limits: Optional[L.ZgJpegLimits] = None):
+    """jpeg.decode (jpeg.zig:2035-2151), host only: (header, scan_limit_reached). Progressive scans are entropy-decoded."""
+    buf, n = _buf(data)
+    h, hit = L.ZgJpegHeader(), C.c_int(0)
+    L.check(L.lib().zg_jpeg_probe(buf, n, C.byref(limits) if limits is not None else None, C.byref(h), C.byref(hit)))
+    return h, bool(hit.value)
+
+
+def load_from_bytes(data: bytes, kind: Optional[str] = None, limits: Optional[L.ZgJpegLimits] = None, device: Optional[str] = "cuda",
+                    return_scan_limit_reached: bool = False):
+    """jpeg.loadFromBytes(T) (jpeg.zig:2825-2851). kind = "u8" | "rgb_u8" | "rgba_u8" names T; None keeps the file's native
+    type (u8 for one component, rgb_u8 otherwise). device=None decodes into host memory (zg_jpeg_decode_host)."""
+    try:  # dimensions only (to allocate the image): every check and limit is the decode's own, below
+        header = get_info(data, decode_limits(max_jpeg_bytes=2**62))
+        rows, cols, comps = header.height, header.width, header.num_components
+    except L.CodecError:
+        rows, cols, comps = 1, 1, 3  # no readable frame header: let the decode report what is wrong, in its own words
+    native = "u8" if comps == 1 else "rgb_u8"
+    _pixel, space, ch = _KINDS[kind or native]
+    rows, cols = max(rows, 1), max(cols, 1)
+    shape = (rows, cols) if ch == 1 else (rows, cols, ch)
+    out = Image(np.zeros(shape, np.uint8)) if device is None else Image(torch.zeros(shape, dtype=torch.uint8, device=device))
+    buf, n = _buf(data)
+    d, hit = out._desc(), C.c_int(0)
+    lim = C.byref(limits) if limits is not None else None
+    if out.on_device:
+        L.check(L.lib().zg_jpeg_decode(buf, n, lim, C.byref(d), space, C.byref(hit), out._stream()))
+    else:
+        L.check(L.lib().zg_jpeg_decode_host(buf, n, lim, C.byref(d), space, C.byref(hit)))
+    return (out, bool(hit.value)) if return_scan_limit_reached else out
+
+
+def load(path: str, kind: Optional[str] = None, limits: Optional[L.ZgJpegLimits] = None, device: Optional[str] = "cuda") -> Image:
+    """jpeg.load (jpeg.zig:2853-2858)."""
+    with open(path, "rb") as f:
+        return load_from_bytes(f.read(), kind, limits, device)
