@@ -496,6 +496,38 @@ def extras(zg, torch, np):
                 "encode_Mpixels/s": round(ROWS * COLS / t_enc / 1e6, 1), "file_MiB": round(len(data) / 2**20, 1),
                 "note": "host-bound: inflate + de-filter (decode), deflate level 5 (encode) on one core; device share < 1 ms"}
 
+    def jpeg_files():
+        # a photo-like 4096 x 4096 frame written by Pillow (4:2:0, quality 90), decoded through the C ABI: wall clock of the
+        # whole call (host Huffman decode, upload, device IDCT + chroma + colour), one caller and 16 callers on 16 streams
+        import io as _io
+        import time as _t
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            from PIL import Image as _PI
+        except ImportError:
+            return {"skipped": "Pillow is needed to write the test file"}
+        yy, xx = np.mgrid[0:ROWS, 0:COLS].astype(np.float32)
+        pic = np.stack([128 + 100 * np.sin(xx / 170) * np.cos(yy / 230), 128 + 90 * np.cos(xx / 110) * np.sin(yy / 130), 128 + 110 * np.sin((xx + yy) / 290)], -1)
+        pic = np.clip(pic + np.random.default_rng(0).normal(0, 4, pic.shape), 0, 255).astype(np.uint8)
+        buf = _io.BytesIO()
+        _PI.fromarray(pic).save(buf, "JPEG", quality=90, subsampling=2)
+        data = buf.getvalue()
+        zg.jpeg.load_from_bytes(data)
+        best = 1e9
+        for _ in range(3):
+            t0 = _t.perf_counter(); zg.jpeg.load_from_bytes(data); torch.cuda.synchronize(); best = min(best, _t.perf_counter() - t0)
+
+        def one(_):
+            with torch.cuda.stream(torch.cuda.Stream()):
+                zg.jpeg.load_from_bytes(data)
+                torch.cuda.current_stream().synchronize()
+        with ThreadPoolExecutor(16) as ex:
+            list(ex.map(one, range(16)))
+            t0 = _t.perf_counter(); list(ex.map(one, range(32))); par = _t.perf_counter() - t0
+        return {"decode_ms": round(best * 1e3, 1), "decode_Mpixels/s": round(ROWS * COLS / best / 1e6, 1),
+                "decode_16_threads_Mpixels/s": round(32 * ROWS * COLS / par / 1e6, 1), "file_MiB": round(len(data) / 2**20, 1),
+                "note": "host-bound: Huffman decoding is one serial chain per scan; device share (IDCT 3 planes + render) ~0.12 ms"}
+
     leg("next_sobel_rgba_u8_4096", sobel)
     leg("next_pyramid_build_default_u8_4096", pyramid_build)
     leg("next_canny_rgba_u8_4096", canny)
@@ -506,6 +538,7 @@ def extras(zg, torch, np):
     leg("io_png_filter_adaptive_rgba_u8_4096", lambda: png_filter(-1))
     leg("io_png_filter_paeth_rgba_u8_4096", lambda: png_filter(4))
     leg("io_png_file_rgba_u8_4096", png_files)
+    leg("io_jpeg_file_420_q90_4096", jpeg_files)
     leg("config2a_gaussian_blur_one_f32_plane_4096", blur_planes)
     leg("config2b_gaussian_blur_rgba_u8_4096", blur_u8)
     leg("config3_resize_bilinear_rgba_u8_4096_to_1024", resize_u8)

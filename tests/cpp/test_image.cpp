@@ -89,6 +89,25 @@ int main() {
         try { Image<uint8_t>::loadFromBytes(junk, 8); } catch (const CodecError &e) { name = e.name(); }
         EXPECT(name == "InvalidPngSignature");
     }
+    { // codecs/jpeg.zig:3055-3074: the reference's hand-built 8 x 8 progressive stream renders as a flat 143
+        std::vector<uint8_t> j = {0xFF, 0xD8, 0xFF, 0xDB, 0x00, 0x43, 0x00};
+        j.insert(j.end(), 64, 0x08);
+        const uint8_t rest[] = {0xFF, 0xC2, 0x00, 0x0B, 0x08, 0x00, 0x08, 0x00, 0x08, 0x01, 0x01, 0x11, 0x00,
+                                0xFF, 0xC4, 0x00, 0x14, 0x00, 0x01, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x02,
+                                0xFF, 0xDA, 0x00, 0x08, 0x01, 0x01, 0x00, 0x00, 0x00, 0x02, 0x7F,
+                                0xFF, 0xDA, 0x00, 0x08, 0x01, 0x01, 0x00, 0x00, 0x00, 0x21, 0xFF, 0x00,
+                                0xFF, 0xDA, 0x00, 0x08, 0x01, 0x01, 0x00, 0x00, 0x00, 0x10, 0xFF, 0x00, 0xFF, 0xD9};
+        j.insert(j.end(), rest, rest + sizeof rest);
+        auto img = Image<uint8_t>::loadFromBytes(j.data(), j.size());
+        bool flat = img.rows == 8 && img.cols == 8;
+        for (uint32_t r = 0; r < 8 && flat; ++r)
+            for (uint32_t c = 0; c < 8; ++c) flat = flat && img.at(r, c) == 143;
+        EXPECT(flat);
+        std::string name;
+        const uint8_t no_scan[] = {0xFF, 0xD8, 0xFF, 0xD9};
+        try { Image<uint8_t>::loadFromBytes(no_scan, 4); } catch (const CodecError &e) { name = e.name(); }
+        EXPECT(name == "NoScanData");
+    }
     std::printf(failures ? "%d FAILED\n" : "cpp mirror ok\n", failures);
     return failures ? 1 : 0;
 }

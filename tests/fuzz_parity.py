@@ -50,7 +50,7 @@ def same(a, b):
 
 def case(rng):
     kind = str(rng.choice(KINDS))
-    op = str(rng.choice(["blur", "sep", "conv2d", "box", "resize", "warp", "rotate", "convert", "sobel", "canny", "shen", "motion", "insert_flip", "letterbox_extract", "misc8"]))
+    op = str(rng.choice(["blur", "sep", "conv2d", "box", "resize", "warp", "rotate", "convert", "sobel", "canny", "shen", "motion", "insert_flip", "letterbox_extract", "misc8", "codec"]))
     rows, cols = dim(rng, MAX_ROWS), dim(rng, MAX_COLS)
     img = synth(rng, kind, rows, cols)
     border = int(rng.integers(0, 4))
@@ -58,6 +58,8 @@ def case(rng):
     D = (lambda a: dev_view(rng, a)) if use_view else dev
     I = zg.Interpolation
     methods = [(I.nearest, o.NEAREST), (I.bilinear, o.BILINEAR), (I.bicubic, o.BICUBIC), (I.catmull_rom, o.CATMULL_ROM), (I.lanczos, o.LANCZOS)]
+    if op == "codec":
+        return codec_case(rng)
     if op == "blur":
         sigma = float(rng.choice([0.3, 0.6, 1.0, 1.4, 2.25, 3.3, 5.5]))
         return f"blur {kind} {rows}x{cols} sigma={sigma}", D(img).gaussian_blur(sigma), o.gaussian_blur(img, sigma)
@@ -191,6 +193,69 @@ def case(rng):
         got = D(img).extract(rect, ang, (dr, dc), m, border, cos_sin=cs)
         return f"extract {kind} {rows}x{cols} rect={rect} a={ang}", got, want
     return None
+
+
+def codec_case(rng):
+    """PNG / JPEG files in, PNG filter streams out: random formats, sizes, and — half the time — a cut or a flipped byte.
+    Both sides must then fail with the same error name or produce the same pixels."""
+    from tests import jpeg_util as J
+    from tests import png_util as P
+    which = int(rng.integers(0, 4))
+    h, w = int(rng.integers(1, 90)), int(rng.integers(1, 140))
+    if which == 0:  # PNG filter stream (the device half of png.encode)
+        ch = int(rng.choice([1, 3, 4]))
+        rows = int(rng.choice([h, 513 + h]))
+        img = rng.integers(0, 256, (rows, w, ch), dtype=np.uint8)
+        if rng.random() < 0.5:
+            img[rows // 4:] = img[rows // 4]  # long runs where one filter keeps winning
+        img = img if ch > 1 else img[..., 0]
+        mode = int(rng.integers(-1, 5))
+        return f"pngfilter {img.shape} mode={mode}", zg.png.filter_scanlines(dev(img), mode).cpu().numpy(), o.png_filter(img, mode)
+    if which == 1:
+        ct, bd = [(P.GRAY, 1), (P.GRAY, 2), (P.GRAY, 4), (P.GRAY, 8), (P.GRAY, 16), (P.RGB, 8), (P.RGB, 16), (P.PALETTE, 1), (P.PALETTE, 2), (P.PALETTE, 4),
+                  (P.PALETTE, 8), (P.GRAY_ALPHA, 8), (P.GRAY_ALPHA, 16), (P.RGBA, 8), (P.RGBA, 16)][int(rng.integers(0, 15))]
+        plen = min(1 << bd, int(rng.integers(1, 257))) if ct == P.PALETTE else None
+        samples = P.random_samples(rng, h, w, bd, ct, plen)
+        trns = None
+        if rng.random() < 0.4 and ct in (P.GRAY, P.RGB, P.PALETTE):
+            trns = ([int(samples[0, 0, 0]) >> 8, int(samples[0, 0, 0]) & 255] if ct == P.GRAY else
+                    [b for c in samples[0, 0] for b in (int(c) >> 8, int(c) & 255)] if ct == P.RGB else rng.integers(0, 256, int(rng.integers(1, plen + 1))).tolist())
+        data = P.make_png(samples, bd, ct, int(rng.integers(0, 2)), filters=lambda y: int(rng.integers(0, 5)),
+                          palette=rng.integers(0, 256, (plen, 3)).tolist() if plen else None, trns=trns, idat_split=int(rng.integers(0, 2)) * 211)
+        load_g, load_o, tag = zg.png.load_from_bytes, o.png_decode_native, f"png ct={ct} bd={bd} {h}x{w}"
+    else:
+        pic = J.test_image(h, w, seed=int(rng.integers(0, 1000)), smooth=bool(rng.integers(0, 2)))
+        kw = dict(quality=int(rng.integers(20, 100)), subsampling=int(rng.integers(0, 3)), progressive=bool(rng.integers(0, 2)), optimize=bool(rng.integers(0, 2)))
+        if rng.random() < 0.2:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 9))
+        grey = rng.random() < 0.25
+        if grey:
+            kw.pop("subsampling")
+        data = J.pil_jpeg(pic[..., 0] if grey else pic, **kw)
+        load_g, load_o, tag = zg.jpeg.load_from_bytes, o.jpeg_decode_native, f"jpeg {kw} {h}x{w}"
+    damage = rng.random()
+    if damage < 0.25:
+        data = data[:int(rng.integers(0, len(data) + 1))]
+    elif damage < 0.5:
+        data = bytearray(data)
+        data[int(rng.integers(0, len(data)))] = int(rng.integers(0, 256))
+        data = bytes(data)
+    try:
+        want = load_o(data)[0]
+        want_err = None
+    except (o.PngError, o.JpegError) as e:
+        want, want_err = None, e.name
+    try:
+        got = load_g(data)
+        got_err = None
+    except zg.CodecError as e:
+        got, got_err = None, e.name
+    if want_err != got_err:
+        print(f"MISMATCH: {tag} (damage {damage:.2f}): oracle error {want_err}, product error {got_err}")
+        sys.exit(1)
+    if want_err is not None:
+        return f"codec-error {tag}", np.zeros(1, np.uint8), np.zeros(1, np.uint8)
+    return tag, got, want
 
 
 def main():

@@ -64,6 +64,26 @@ elif op in ("png_filter", "png_filter_paeth", "png_decode", "png_encode"):
             def f():
                 t0 = time.perf_counter(); zg.png.encode(s); t1 = time.perf_counter()
                 print(f"encode {1e3 * (t1 - t0):.1f} ms")
+elif op in ("jpeg420", "jpeg444", "jpeg420p"):
+    import io, time
+    from PIL import Image as PI
+    yy, xx = np.mgrid[0:R, 0:R].astype(np.float32)
+    pic = np.stack([128 + 100 * np.sin(xx / 170) * np.cos(yy / 230), 128 + 90 * np.cos(xx / 110) * np.sin(yy / 130), 128 + 110 * np.sin((xx + yy) / 290)], -1)
+    pic = np.clip(pic + np.random.default_rng(0).normal(0, 4, pic.shape), 0, 255).astype(np.uint8)
+    buf = io.BytesIO(); PI.fromarray(pic).save(buf, "JPEG", quality=90, subsampling=0 if op == "jpeg444" else 2, progressive=op.endswith("p")); data = buf.getvalue()
+    print(f"{op}: {len(data) / 2**20:.1f} MiB file")
+    from concurrent.futures import ThreadPoolExecutor
+    def one(_):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            out = zg.jpeg.load_from_bytes(data); torch.cuda.current_stream().synchronize()
+        return out
+    def f():
+        t0 = time.perf_counter(); out = zg.jpeg.load_from_bytes(data); torch.cuda.synchronize(); t1 = time.perf_counter()
+        print(f"decode {1e3 * (t1 - t0):.1f} ms")
+        for nt in (4, 16, 32):
+            with ThreadPoolExecutor(nt) as ex:
+                t0 = time.perf_counter(); list(ex.map(one, range(nt * 2))); t1 = time.perf_counter()
+            print(f"  {nt} threads: {nt * 2} files in {1e3 * (t1 - t0):.1f} ms = {nt * 2 * R * R / (t1 - t0) / 1e6:.0f} Mpixels/s")
 for _ in range(n):
     f()
 torch.cuda.synchronize()

@@ -62,6 +62,13 @@ pub const c = struct {
     pub extern fn zg_png_encode(src: *const ZgImage, src_space: c_int, options: ?*const ZgPngEncodeOptions, out: *?[*]u8, out_len: *usize, stream: ?*anyopaque) c_int;
     pub extern fn zg_png_encode_host(src: *const ZgImage, src_space: c_int, options: ?*const ZgPngEncodeOptions, out: *?[*]u8, out_len: *usize) c_int;
     pub extern fn zg_png_free(p: ?*anyopaque) void;
+    pub const ZgJpegHeader = extern struct { width: u32, height: u32, precision: u8, num_components: u8, progressive: u8, subsampling: i8 };
+    pub const ZgJpegLimits = extern struct { max_jpeg_bytes: usize, max_marker_bytes: usize, max_width: u32, max_height: u32, max_pixels: u64, max_blocks: usize, max_scans: usize };
+    pub extern fn zg_jpeg_default_limits(limits: *ZgJpegLimits) void;
+    pub extern fn zg_jpeg_info(jpeg: [*]const u8, len: usize, limits: ?*const ZgJpegLimits, out: *ZgJpegHeader) c_int;
+    pub extern fn zg_jpeg_probe(jpeg: [*]const u8, len: usize, limits: ?*const ZgJpegLimits, header_out: ?*ZgJpegHeader, scan_limit_reached_out: ?*c_int) c_int;
+    pub extern fn zg_jpeg_decode(jpeg: [*]const u8, len: usize, limits: ?*const ZgJpegLimits, dst: *const ZgImage, dst_space: c_int, scan_limit_reached_out: ?*c_int, stream: ?*anyopaque) c_int;
+    pub extern fn zg_jpeg_decode_host(jpeg: [*]const u8, len: usize, limits: ?*const ZgJpegLimits, dst: *const ZgImage, dst_space: c_int, scan_limit_reached_out: ?*c_int) c_int;
     pub extern fn zg_shen_castan_host(src: *const ZgImage, dst: *const ZgImage, smooth: f32, window_size: u32, high_ratio: f32, low_rel: f32, hysteresis: c_int, use_nms: c_int) c_int;
     pub extern fn zg_canny_host(src: *const ZgImage, dst: *const ZgImage, sigma: f32, low_threshold: f32, high_threshold: f32) c_int;
     pub extern fn zg_convert_host(src: *const ZgImage, src_space: c_int, dst: *const ZgImage, dst_space: c_int, srgb_lut: ?[*]const f32) c_int;
@@ -439,5 +446,57 @@ pub const png = struct {
         try checkPng(c.zg_png_encode_host(&Image(T).desc(image.base), space, options, &mem, &len));
         defer c.zg_png_free(mem);
         return allocator.dupe(u8, mem.?[0..len]);
+    }
+};
+
+/// JPEG decoding through the library (reference src/codecs/jpeg.zig): markers and Huffman decoding on the host inside
+/// libzignal_hip.so, dequantisation / IDCT / chroma / colour on the MI355X. Error names travel as text, as for `png`.
+pub const jpeg = struct {
+    pub const DecodeLimits = c.ZgJpegLimits;
+    pub const Header = c.ZgJpegHeader;
+
+    pub fn defaultLimits() DecodeLimits {
+        var l: DecodeLimits = undefined;
+        c.zg_jpeg_default_limits(&l);
+        return l;
+    }
+
+    fn codecError() anyerror {
+        const msg = std.mem.span(c.zg_last_error());
+        const name = msg[0 .. std.mem.indexOfScalar(u8, msg, ' ') orelse msg.len];
+        const known = .{
+            .{ "InvalidJpegFile", error.InvalidJpegFile },             .{ "InvalidMarker", error.InvalidMarker },
+            .{ "InvalidSOF", error.InvalidSOF },                       .{ "DuplicateSOF", error.DuplicateSOF },
+            .{ "InvalidSOS", error.InvalidSOS },                       .{ "NoScanData", error.NoScanData },
+            .{ "InvalidHuffmanCode", error.InvalidHuffmanCode },       .{ "MissingHuffmanTable", error.MissingHuffmanTable },
+            .{ "MissingQuantTable", error.MissingQuantTable },         .{ "ImageTooLarge", error.ImageTooLarge },
+            .{ "UnsupportedSamplingFactor", error.UnsupportedSamplingFactor },
+            .{ "UnsupportedComponentCount", error.UnsupportedComponentCount },
+            .{ "BlockMemoryLimitExceeded", error.BlockMemoryLimitExceeded },
+        };
+        inline for (known) |entry| if (std.mem.eql(u8, name, entry[0])) return entry[1];
+        return error.JpegError;
+    }
+
+    fn checkJpeg(status: c_int) !void {
+        if (status == 6) return codecError();
+        return check(status);
+    }
+
+    /// reference src/codecs/jpeg.zig:77-179
+    pub fn getInfo(data: []const u8, limits: DecodeLimits) !Header {
+        var h: Header = undefined;
+        try checkJpeg(c.zg_jpeg_info(data.ptr, data.len, &limits, &h));
+        return h;
+    }
+
+    /// reference src/codecs/jpeg.zig:2825-2851
+    pub fn loadFromBytes(comptime T: type, allocator: std.mem.Allocator, data: []const u8, limits: DecodeLimits) !Image(T) {
+        const h = try getInfo(data, limits);
+        const out: Image(T) = .{ .base = try .init(allocator, h.height, h.width) };
+        errdefer out.base.deinit(allocator);
+        const space: c_int = switch (pixelOf(T)) { .u8, .f32 => 0, .rgb_u8, .rgb_f32 => 1, .rgba_u8, .rgba_f32 => 2 };
+        try checkJpeg(c.zg_jpeg_decode_host(data.ptr, data.len, &limits, &Image(T).desc(out.base), space, null));
+        return out;
     }
 };

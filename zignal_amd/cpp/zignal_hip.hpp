@@ -217,13 +217,21 @@ template <typename T> class Image {
         return out;
     }
 
-    // ---- file I/O (image.zig:239-287; PNG only: src/codecs/png.zig) ----
-    static Image loadFromBytes(const uint8_t *bytes, size_t len, const zg_png_limits *limits = nullptr) {   // png.zig:1151
-        zg_png_header h;
-        check(zg_png_probe(bytes, len, limits, &h, nullptr, nullptr));
+    // ---- file I/O (image.zig:239-287: the format comes from the signature; src/codecs/png.zig, src/codecs/jpeg.zig) ----
+    static Image loadFromBytes(const uint8_t *bytes, size_t len) {                                          // image.zig:265
+        if (len >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) {                                             // jpeg.zig:2825
+            zg_jpeg_header h;
+            check(zg_jpeg_probe(bytes, len, nullptr, &h, nullptr));
+            Image out = init(h.height, h.width);
+            const zg_image d = out.desc();
+            check(zg_jpeg_decode_host(bytes, len, nullptr, &d, PixelTraits<T>::space, nullptr));
+            return out;
+        }
+        zg_png_header h;                                                                                    // png.zig:1151
+        check(zg_png_probe(bytes, len, nullptr, &h, nullptr, nullptr));
         Image out = init(h.height, h.width);
         const zg_image d = out.desc();
-        check(zg_png_decode_host(bytes, len, limits, &d, PixelTraits<T>::space, nullptr));
+        check(zg_png_decode_host(bytes, len, nullptr, &d, PixelTraits<T>::space, nullptr));
         return out;
     }
     std::vector<uint8_t> encodePng(const zg_png_encode_options *options = nullptr) const {                  // png.zig:1400

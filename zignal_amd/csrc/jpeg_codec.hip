@@ -10,6 +10,7 @@
 // nonsense, and i16 would saturate differently); chroma goes up compacted to one block per MCU.
 #include "zg_common.h"
 
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -89,6 +90,18 @@ class BitReader { // :1660-1736
     void flush() { window = 0; held = 0; }
 };
 
+// Coefficient storage: calloc'd so that pages nothing writes to (most of a subsampled chroma plane) are never materialised.
+struct ZeroedWords {
+    int32_t *p = nullptr;
+    ~ZeroedWords() { free(p); }
+    bool reset(size_t n) {
+        free(p);
+        p = (int32_t *)calloc(n ? n : 1, sizeof(int32_t));
+        return p != nullptr;
+    }
+    int32_t *data() { return p; }
+};
+
 struct FrameComponent { uint8_t id, h, v, tq; };
 struct ScanComponent { uint8_t id, dc, ac; };
 struct Scan { ScanComponent comp[4]; int n = 0, ss = 0, se = 0, ah = 0, al = 0; };
@@ -105,7 +118,7 @@ struct Decoder {
     unsigned bw = 0, bh = 0, bwa = 0, bha = 0; // block_width / height, and the MCU-padded grid
     size_t nblocks = 0;
     bool allocated = false;
-    std::vector<int32_t> coef[3]; // per component, nblocks x 64 on the luma grid (the reference's block_storage[block][component])
+    ZeroedWords coef[3]; // per component, nblocks x 64 on the luma grid (the reference's block_storage[block][component])
     int32_t dc_pred[4] = {0, 0, 0, 0};
     bool scan_limit_reached = false;
 
@@ -411,7 +424,8 @@ struct Decoder {
         if (over(lim.max_pixels, padded)) JPEG_FAIL("ImageTooLarge");
         if (over(lim.max_blocks, padded / 64)) JPEG_FAIL("BlockMemoryLimitExceeded");
         nblocks = (size_t)(padded / 64);
-        for (int i = 0; i < nc; ++i) coef[i].assign(nblocks * 64, 0);
+        for (int i = 0; i < nc; ++i)
+            if (!coef[i].reset(nblocks * 64)) { set_error("jpeg: out of host memory for %zu blocks", nblocks); return ZG_ERR_OUT_OF_MEMORY; }
         allocated = true;
         return ZG_OK;
     }
