@@ -64,6 +64,27 @@ def cases():
     yield "shen_castan_nms_rgba_u8", o.shen_castan(u8, 0.85, 5, 0.8, 0.4, True, True)
     yield "motion_blur_linear_rgba_u8", o.motion_blur_linear(u8, 0.3, 8)
     yield "motion_blur_spin_f32", o.motion_blur_radial(gf, 0.4, 0.6, 0.5, True)
+    # codecs: files built by the test-side writers from seeded samples (the pixels, not the compressed bytes, are hashed)
+    from tests import jpeg_util as J
+    from tests import png_util as P
+    rng = np.random.default_rng(77)
+    pal = rng.integers(0, 256, (16, 3)).tolist()
+    yield "png_rgba16_adam7", o.png_decode_native(P.make_png(rng.integers(0, 65536, (19, 23, 4)), 16, P.RGBA, 1, filters=4))[0]
+    yield "png_palette4_trns", o.png_decode_native(P.make_png(rng.integers(0, 16, (19, 23, 1)), 4, P.PALETTE, 0, filters=3, palette=pal, trns=[9, 8, 7]))[0]
+    yield "png_gray2_trns_adam7", o.png_decode_native(P.make_png(rng.integers(0, 4, (9, 31, 1)), 2, P.GRAY, 1, filters=1, trns=[0, 85]))[0]
+    yield "png_filter_adaptive_rgb", o.png_filter(o.synth_u8(15, (40, 33, 3)))
+    yield "png_filter_adaptive_tall_u8", o.png_filter(np.repeat(o.synth_u8(16, (75, 21)), 8, axis=0))
+    for name, (lh, lv) in (("444", (1, 1)), ("422", (2, 1)), ("420", (2, 2)), ("411", (4, 1))):
+        comps = J.layout(lh, lv)
+        yield f"jpeg_baseline_{name}", o.jpeg_decode_native(J.write_baseline(45, 37, comps, J.FLAT_Q, J.random_coefficients(rng, comps, 45, 37)))[0]
+    sig, eoi = bytes([0xFF, 0xD8]), bytes([0xFF, 0xD9])
+    prog = (sig + bytes([0xFF, 0xDB, 0x00, 0x43, 0x00]) + bytes([8] * 64) + bytes([0xFF, 0xC2, 0x00, 0x0B, 0x08, 0x00, 0x08, 0x00, 0x08, 0x01, 0x01, 0x11, 0x00])
+            + bytes([0xFF, 0xC4, 0x00, 0x14, 0x00, 0x01]) + bytes(15) + bytes([0x02]) + bytes([0xFF, 0xDA, 0x00, 0x08, 0x01, 0x01, 0x00, 0x00, 0x00, 0x02, 0x7F])
+            + bytes([0xFF, 0xDA, 0x00, 0x08, 0x01, 0x01, 0x00, 0x00, 0x00, 0x21, 0xFF, 0x00]) + eoi)
+    yield "jpeg_progressive_hand_built", o.jpeg_decode_native(prog)[0]
+    blk = np.zeros((8, 8), np.int32)
+    blk.flat[[0, 1, 8, 9, 17, 34, 63]] = [900, -310, 255, 77, -41, 19, -7]
+    yield "jpeg_idct_block", o.jpeg_idct8x8(blk)
 
 
 if __name__ == "__main__":
