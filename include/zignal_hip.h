@@ -440,6 +440,23 @@ ZG_API int zg_jpeg_decode(const uint8_t *jpeg, size_t len, const zg_jpeg_limits 
                           int *scan_limit_reached_out, zg_stream stream);
 ZG_API int zg_jpeg_decode_host(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, const zg_image *dst, int dst_space,
                                int *scan_limit_reached_out);
+/* jpeg.encode(T) (jpeg.zig:307-329): baseline SOF0 with the reference's fixed Huffman tables. Image(u8) becomes a one-component
+ * file, Rgb a YCbCr one at 4:4:4 / 4:2:2 / 4:2:0, any other T (src_space as in zg_convert) is converted to Rgb first.
+ * Device: colour conversion, edge replication, chroma averaging, the LLM forward DCT, reciprocal quantisation; host: the
+ * Huffman coder. The file is a deterministic function of pixels and options, byte for byte the reference's. *out is
+ * malloc'd host memory, release it with zg_jpeg_free. options may be NULL (EncodeOptions.default). A 0 x n image is
+ * error.InvalidImageDimensions, more than 65535 rows or columns error.ImageTooLarge (ZG_ERR_CODEC). Synchronises `stream`. */
+typedef struct zg_jpeg_encode_options { /* jpeg.EncodeOptions (jpeg.zig:284-290) */
+    int quality;            /* 1..100 (clamped), default 90 */
+    int subsampling;        /* 0 yuv444, 1 yuv422, 2 yuv420 (default) */
+    int density_dpi;        /* JFIF density, default 72 */
+    const uint8_t *comment; /* COM segment, or NULL */
+    size_t comment_len;
+} zg_jpeg_encode_options;
+ZG_API void zg_jpeg_default_encode_options(zg_jpeg_encode_options *options);
+ZG_API int zg_jpeg_encode(const zg_image *src, int src_space, const zg_jpeg_encode_options *options, uint8_t **out, size_t *out_len, zg_stream stream);
+ZG_API int zg_jpeg_encode_host(const zg_image *src, int src_space, const zg_jpeg_encode_options *options, uint8_t **out, size_t *out_len);
+ZG_API void zg_jpeg_free(void *p);
 
 #ifdef __cplusplus
 }

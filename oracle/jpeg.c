@@ -856,3 +856,250 @@ done:
     return rc;
 }
 ZO_API void zo_jpeg_free(void *p) { free(p); }
+
+/* ==== encoder (jpeg.zig:293-1043): baseline SOF0, the reference's own tables, LLM forward DCT, reciprocal quantisation ============
+ * The output is a deterministic function of the pixels and options (fixed Huffman tables), so files are compared byte for byte. */
+static const uint8_t Q_LUMA[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                                   18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+static const uint8_t Q_CHROMA[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                                     99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+/* jpeg.zig:358-391. The luma DC table carries the chroma table's code lengths (0 3 1 1 ...), not Annex K's (0 1 5 1 ...). */
+static const uint8_t BITS_DC[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+static const uint8_t VAL_DC[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+static const uint8_t BITS_AC_LUMA[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 125};
+static const uint8_t VAL_AC_LUMA[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1,
+    0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
+    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a,
+    0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
+    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3,
+    0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+static const uint8_t BITS_AC_CHROMA[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 119};
+static const uint8_t VAL_AC_CHROMA[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1,
+    0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36,
+    0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69,
+    0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a,
+    0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca,
+    0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
+typedef struct huff_enc { uint16_t code[256]; uint8_t size[256]; } huff_enc;
+static void build_enc(huff_enc *e, const uint8_t *bits, const uint8_t *vals) { /* buildHuffmanEncoder (:399-415) */
+    memset(e, 0, sizeof *e);
+    unsigned code = 0, k = 0;
+    for (int i = 0; i < 16; ++i) {
+        for (int j = 0; j < bits[i]; ++j) { e->code[vals[k]] = (uint16_t)code; e->size[vals[k]] = (uint8_t)(i + 1); code += 1; k += 1; }
+        code = (code << 1) & 0xffff;
+    }
+}
+typedef struct out_buf { uint8_t *p; size_t n, cap; int oom; uint32_t bit_buf; int bit_count; } out_buf;
+static void ob_byte(out_buf *o, uint8_t b) {
+    if (o->n == o->cap) {
+        const size_t nc = o->cap ? o->cap * 2 : 4096;
+        uint8_t *np = realloc(o->p, nc);
+        if (!np) { o->oom = 1; return; }
+        o->p = np; o->cap = nc;
+    }
+    o->p[o->n++] = b;
+}
+static void ob_bytes(out_buf *o, const void *src, size_t n) { for (size_t i = 0; i < n; ++i) ob_byte(o, ((const uint8_t *)src)[i]); }
+static void ob_segment(out_buf *o, int marker, const uint8_t *payload, size_t n) { /* writeSegment (:457-462) */
+    ob_byte(o, 0xFF); ob_byte(o, (uint8_t)marker);
+    ob_byte(o, (uint8_t)((n + 2) >> 8)); ob_byte(o, (uint8_t)(n + 2));
+    ob_bytes(o, payload, n);
+}
+static void ew_bits(out_buf *o, uint32_t code, int size) { /* EntropyWriter.writeBits (:431-440) */
+    if (size == 0) { return; }
+    o->bit_buf = (o->bit_buf << size) | (code & ((1u << size) - 1));
+    o->bit_count += size;
+    while (o->bit_count >= 8) {
+        const uint8_t b = (uint8_t)((o->bit_buf >> (o->bit_count - 8)) & 0xFF);
+        ob_byte(o, b);
+        if (b == 0xFF) ob_byte(o, 0x00);
+        o->bit_count -= 8;
+    }
+}
+static void scale_quant(int quality, uint8_t ql[64], uint8_t qc[64]) { /* scaleQuantTables (:464-476) */
+    const int q = quality < 1 ? 1 : (quality > 100 ? 100 : quality);
+    const int scale = q < 50 ? 5000 / q : 200 - q * 2;
+    for (int i = 0; i < 64; ++i) {
+        const int l = (Q_LUMA[i] * scale + 50) / 100, c = (Q_CHROMA[i] * scale + 50) / 100;
+        ql[i] = (uint8_t)(l < 1 ? 1 : (l > 255 ? 255 : l));
+        qc[i] = (uint8_t)(c < 1 ? 1 : (c > 255 ? 255 : c));
+    }
+}
+static int32_t descale(int64_t x, int n) { return (int32_t)((x + ((int64_t)1 << (n - 1))) >> n); }
+#define FIX13(x) ((int64_t)((x) * 8192.0 + 0.5))
+static void fdct_1d(const int64_t in[8], int32_t out[8], int first_pass) { /* one pass of fdct8x8_llm (:634-741) */
+    const int64_t tmp0 = in[0] + in[7], tmp7 = in[0] - in[7], tmp1 = in[1] + in[6], tmp6 = in[1] - in[6];
+    const int64_t tmp2 = in[2] + in[5], tmp5 = in[2] - in[5], tmp3 = in[3] + in[4], tmp4 = in[3] - in[4];
+    const int64_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    const int shift = first_pass ? 13 - 2 : 13 + 2;
+    if (first_pass) { out[0] = (int32_t)((tmp10 + tmp11) << 2); out[4] = (int32_t)((tmp10 - tmp11) << 2); }
+    else { out[0] = descale(tmp10 + tmp11, 2); out[4] = descale(tmp10 - tmp11, 2); }
+    const int64_t z1 = (tmp12 + tmp13) * FIX13(0.541196100);
+    out[2] = descale(z1 + tmp13 * FIX13(0.765366865), shift);
+    out[6] = descale(z1 + tmp12 * (-FIX13(1.847759065)), shift);
+    int64_t z1o = tmp4 + tmp7, z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;
+    const int64_t z5 = (z3 + z4) * FIX13(1.175875602);
+    const int64_t t4 = tmp4 * FIX13(0.298631336), t5 = tmp5 * FIX13(2.053119869), t6 = tmp6 * FIX13(3.072711026), t7 = tmp7 * FIX13(1.501321110);
+    z1o *= -FIX13(0.899976223); z2 *= -FIX13(2.562915447); z3 *= -FIX13(1.961570560); z4 *= -FIX13(0.390180644);
+    z3 += z5; z4 += z5;
+    out[7] = descale(t4 + z1o + z3, shift); out[5] = descale(t5 + z2 + z4, shift); out[3] = descale(t6 + z2 + z3, shift); out[1] = descale(t7 + z1o + z4, shift);
+}
+ZO_API void zo_jpeg_fdct8x8(const int32_t src[64], int32_t dst[64]) {
+    int32_t data[64];
+    for (int y = 0; y < 8; ++y) {
+        int64_t in[8];
+        for (int x = 0; x < 8; ++x) in[x] = src[y * 8 + x];
+        fdct_1d(in, data + y * 8, 1);
+    }
+    for (int x = 0; x < 8; ++x) {
+        int64_t in[8];
+        int32_t out[8];
+        for (int y = 0; y < 8; ++y) in[y] = data[y * 8 + x];
+        fdct_1d(in, out, 0);
+        for (int y = 0; y < 8; ++y) dst[y * 8 + x] = out[y];
+    }
+}
+static void build_recip(uint32_t out[64], const uint8_t q[64]) { /* buildQuantRecipLLM (:749-761) */
+    for (int i = 0; i < 64; ++i) {
+        double r = 16777216.0 / ((double)q[i] * 8.0);
+        if (r < 0.0) r = 0.0;
+        if (r > 4294967295.0) r = 4294967295.0;
+        out[i] = (uint32_t)round(r);
+    }
+}
+static int32_t quantize_recip(int32_t v, uint32_t recip) { /* quantizeWithRecip (:763-770) */
+    if (v == 0) return 0;
+    const int64_t a = v < 0 ? -(int64_t)v : v;
+    int64_t q = (a * (int64_t)recip + ((int64_t)1 << 23)) >> 24;
+    if (v < 0) q = -q;
+    return (int32_t)q;
+}
+static int magnitude_category(int32_t v) { int c = 0; uint32_t a = (uint32_t)(v < 0 ? -v : v); while (a) { a >>= 1; ++c; } return c; }
+static uint32_t magnitude_bits(int32_t v, int mag) { return mag == 0 ? 0 : (v >= 0 ? (uint32_t)v : (uint32_t)(((int32_t)1 << mag) - 1 + v)); }
+static void encode_block(const int32_t block[64], const uint32_t recip[64], out_buf *o, const huff_enc *dc, const huff_enc *ac, int32_t *prev_dc) { /* :771-817 */
+    int32_t dct[64], co[64];
+    zo_jpeg_fdct8x8(block, dct);
+    for (int i = 0; i < 64; ++i) co[i] = quantize_recip(dct[i], recip[i]);
+    const int32_t diff = co[0] - *prev_dc;
+    *prev_dc = co[0];
+    const int mag = magnitude_category(diff);
+    ew_bits(o, dc->code[mag], dc->size[mag]);
+    if (mag > 0) ew_bits(o, magnitude_bits(diff, mag), mag);
+    int run = 0;
+    for (int k = 1; k < 64; ++k) {
+        const int32_t v = co[ZIGZAG[k]];
+        if (v == 0) {
+            if (++run == 16) { ew_bits(o, ac->code[0xF0], ac->size[0xF0]); run = 0; } /* a ZRL as soon as sixteen zeros pile up, trailing ones included */
+        } else {
+            const int amag = magnitude_category(v), sym = (run << 4) | amag;
+            ew_bits(o, ac->code[sym & 0xff], ac->size[sym & 0xff]);
+            ew_bits(o, magnitude_bits(v, amag), amag);
+            run = 0;
+        }
+    }
+    if (run > 0) ew_bits(o, ac->code[0x00], ac->size[0x00]);
+}
+static void rgb_to_ycc(const uint8_t *p, uint8_t out[3]) { /* convertColor(Ycbcr, Rgb(u8)): color.zig:987-1009 */
+    const int64_t r = p[0], g = p[1], b = p[2];
+    out[0] = clamp_u8((19595 * r + 38470 * g + 7471 * b + 32768) >> 16);
+    out[1] = clamp_u8(((-11059 * r - 21710 * g + 32768 * b + 32768) >> 16) + 128);
+    out[2] = clamp_u8(((32768 * r - 27439 * g - 5329 * b + 32768) >> 16) + 128);
+}
+/* jpeg.encode (:307-329) for Image(u8) and Image(Rgb); subsampling 0 = 4:4:4, 1 = 4:2:2, 2 = 4:2:0; comment may be NULL.
+ * Status: 0 ok, 1 = error.InvalidImageDimensions, 2 = error.ImageTooLarge, 3 = out of memory / unsupported pixel type. */
+ZO_API int zo_jpeg_encode(const zo_image *img, int quality, int subsampling, int density_dpi, const uint8_t *comment, size_t comment_len, uint8_t **out, size_t *out_len) {
+    if (img->rows == 0 || img->cols == 0) return 1;
+    if (img->rows > 65535 || img->cols > 65535) return 2;
+    if (img->pixel != ZO_U8 && img->pixel != ZO_RGB_U8) return 3;
+    const int gray = img->pixel == ZO_U8;
+    const size_t rows = img->rows, cols = img->cols;
+    out_buf o;
+    memset(&o, 0, sizeof o);
+    ob_byte(&o, 0xFF); ob_byte(&o, 0xD8);
+    const uint8_t jfif[14] = {'J', 'F', 'I', 'F', 0, 1, 1, 1, (uint8_t)(density_dpi >> 8), (uint8_t)density_dpi, (uint8_t)(density_dpi >> 8), (uint8_t)density_dpi, 0, 0};
+    ob_segment(&o, 0xE0, jfif, sizeof jfif);
+    if (comment) ob_segment(&o, 0xFE, comment, comment_len);
+    uint8_t ql[64], qc[64], seg[2 * 65 + 4 * 200];
+    scale_quant(quality, ql, qc);
+    size_t n = 0;
+    seg[n++] = 0x00;
+    for (int i = 0; i < 64; ++i) seg[n++] = ql[ZIGZAG[i]];
+    if (!gray) { seg[n++] = 0x01; for (int i = 0; i < 64; ++i) seg[n++] = qc[ZIGZAG[i]]; }
+    ob_segment(&o, 0xDB, seg, n);
+    const uint8_t luma_factors = subsampling == 0 ? 0x11 : (subsampling == 1 ? 0x21 : 0x22);
+    n = 0;
+    seg[n++] = 8; seg[n++] = (uint8_t)(rows >> 8); seg[n++] = (uint8_t)rows; seg[n++] = (uint8_t)(cols >> 8); seg[n++] = (uint8_t)cols;
+    if (gray) { seg[n++] = 1; seg[n++] = 1; seg[n++] = 0x11; seg[n++] = 0; }
+    else { const uint8_t c[10] = {3, 1, luma_factors, 0, 2, 0x11, 1, 3, 0x11, 1}; memcpy(seg + n, c, 10); n += 10; }
+    ob_segment(&o, 0xC0, seg, n);
+    n = 0;
+    seg[n++] = 0x00; memcpy(seg + n, BITS_DC, 16); n += 16; memcpy(seg + n, VAL_DC, 12); n += 12;
+    seg[n++] = 0x10; memcpy(seg + n, BITS_AC_LUMA, 16); n += 16; memcpy(seg + n, VAL_AC_LUMA, 162); n += 162;
+    if (!gray) {
+        seg[n++] = 0x01; memcpy(seg + n, BITS_DC, 16); n += 16; memcpy(seg + n, VAL_DC, 12); n += 12;
+        seg[n++] = 0x11; memcpy(seg + n, BITS_AC_CHROMA, 16); n += 16; memcpy(seg + n, VAL_AC_CHROMA, 162); n += 162;
+    }
+    ob_segment(&o, 0xC4, seg, n);
+    if (gray) { const uint8_t s[6] = {1, 1, 0x00, 0, 63, 0}; ob_segment(&o, 0xDA, s, 6); }
+    else { const uint8_t s[10] = {3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0}; ob_segment(&o, 0xDA, s, 10); }
+
+    huff_enc dc_l, ac_l, dc_c, ac_c;
+    build_enc(&dc_l, BITS_DC, VAL_DC); build_enc(&ac_l, BITS_AC_LUMA, VAL_AC_LUMA);
+    build_enc(&dc_c, BITS_DC, VAL_DC); build_enc(&ac_c, BITS_AC_CHROMA, VAL_AC_CHROMA);
+    uint32_t rl[64], rc[64];
+    build_recip(rl, ql); build_recip(rc, qc);
+    const uint8_t *base = (const uint8_t *)img->data;
+    int32_t block[64];
+    if (gray) { /* encodeGrayscale (:977-1043): edge pixels replicate into the padding */
+        int32_t prev = 0;
+        for (size_t br = 0; br < (rows + 7) / 8; ++br)
+            for (size_t bc = 0; bc < (cols + 7) / 8; ++bc) {
+                for (size_t y = 0; y < 8; ++y) {
+                    const size_t iy = br * 8 + y < rows - 1 ? br * 8 + y : rows - 1;
+                    for (size_t x = 0; x < 8; ++x) {
+                        const size_t ix = bc * 8 + x < cols - 1 ? bc * 8 + x : cols - 1;
+                        block[y * 8 + x] = (int32_t)base[iy * img->stride + ix] - 128;
+                    }
+                }
+                encode_block(block, rl, &o, &dc_l, &ac_l, &prev);
+            }
+    } else { /* encodeBlocksRgb (:819-927) */
+        const size_t hm = subsampling == 0 ? 1 : 2, vm = subsampling == 2 ? 2 : 1, mw = 8 * hm, mh = 8 * vm;
+        int32_t py = 0, pcb = 0, pcr = 0;
+        uint8_t mcu[16][16][3];
+        for (size_t my = 0; my < (rows + mh - 1) / mh; ++my)
+            for (size_t mx = 0; mx < (cols + mw - 1) / mw; ++mx) {
+                for (size_t y = 0; y < mh; ++y) {
+                    const size_t iy = my * mh + y < rows - 1 ? my * mh + y : rows - 1;
+                    for (size_t x = 0; x < mw; ++x) {
+                        const size_t ix = mx * mw + x < cols - 1 ? mx * mw + x : cols - 1;
+                        rgb_to_ycc(base + (iy * img->stride + ix) * 3, mcu[y][x]);
+                    }
+                }
+                for (size_t vy = 0; vy < vm; ++vy)
+                    for (size_t hx = 0; hx < hm; ++hx) {
+                        for (size_t y = 0; y < 8; ++y)
+                            for (size_t x = 0; x < 8; ++x) block[y * 8 + x] = (int32_t)mcu[vy * 8 + y][hx * 8 + x][0] - 128;
+                        encode_block(block, rl, &o, &dc_l, &ac_l, &py);
+                    }
+                for (int c = 1; c <= 2; ++c) {
+                    for (size_t y = 0; y < 8; ++y)
+                        for (size_t x = 0; x < 8; ++x) {
+                            uint32_t sum = 0;
+                            for (size_t dy = 0; dy < vm; ++dy)
+                                for (size_t dx = 0; dx < hm; ++dx) sum += mcu[y * vm + dy][x * hm + dx][c];
+                            block[y * 8 + x] = (int32_t)(sum / (uint32_t)(hm * vm)) - 128;
+                        }
+                    encode_block(block, rc, &o, &dc_c, &ac_c, c == 1 ? &pcb : &pcr);
+                }
+            }
+    }
+    if (o.bit_count > 0) { const int pad = 8 - o.bit_count; ew_bits(&o, (1u << pad) - 1, pad); } /* flush (:441-446) */
+    ob_byte(&o, 0xFF); ob_byte(&o, 0xD9);
+    if (o.oom) { free(o.p); return 3; }
+    *out = o.p; *out_len = o.n;
+    return 0;
+}

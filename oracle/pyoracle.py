@@ -680,3 +680,33 @@ def jpeg_idct8x8(block) -> np.ndarray:
     fn.restype = None
     fn(b.ctypes.data)
     return b.reshape(8, 8)
+
+
+def jpeg_encode(img: np.ndarray, quality: int = 90, subsampling: int = 2, density_dpi: int = 72, comment: bytes | None = None) -> bytes:
+    """jpeg.encode(T) (jpeg.zig:307-329): u8 -> greyscale, Rgb -> YCbCr, any other T is converted to Rgb first."""
+    img = np.array(img, order="C", copy=True)  # a fresh copy: canonical strides even for 1-pixel-wide slices
+    if not (img.dtype == np.uint8 and (img.ndim == 2 or img.shape[2] == 3)):
+        src_space = {1: CS_GRAY, 3: CS_RGB, 4: CS_RGBA}[1 if img.ndim == 2 else img.shape[2]]
+        img = convert(img, src_space, CS_RGB, np.uint8, 3)
+    im = as_image(img)
+    out, n = C.c_void_p(), C.c_size_t(0)
+    fn = lib().zo_jpeg_encode
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    rc = fn(C.byref(im), quality, subsampling, density_dpi, comment, len(comment) if comment else 0, C.byref(out), C.byref(n))
+    if rc:
+        raise JpegError({1: "InvalidImageDimensions", 2: "ImageTooLarge"}.get(rc, "OutOfMemory"))
+    data = C.string_at(out.value, n.value)
+    free = lib().zo_jpeg_free
+    free.argtypes = [C.c_void_p]
+    free(out)
+    return data
+
+
+def jpeg_fdct8x8(block) -> np.ndarray:
+    b = np.ascontiguousarray(block, np.int32).reshape(64)
+    out = np.empty(64, np.int32)
+    fn = lib().zo_jpeg_fdct8x8
+    fn.argtypes = [C.c_void_p, C.c_void_p]
+    fn.restype = None
+    fn(b.ctypes.data, out.ctypes.data)
+    return out.reshape(8, 8)

@@ -252,3 +252,81 @@ def test_decode_large_frame(oracle):
     img = J.test_image(1080, 1920, seed=9)
     for kw in (dict(subsampling=2), dict(subsampling=0, progressive=True)):
         assert_same_decode(oracle, J.pil_jpeg(img, **{"quality": 85, **kw}), ("1080p", kw))
+
+
+# ---- encoder ---------------------------------------------------------------------------------------------------------------
+
+def test_oracle_encoder_reference_roundtrips(oracle):
+    """The reference's own encode -> decode tests (jpeg.zig:2860-3026) through the oracle: same images, options and PSNR bars."""
+    def psnr(a, b):
+        return 10 * np.log10(255.0 ** 2 / ((a.astype(np.float64) - b.astype(np.float64)) ** 2).mean())
+
+    def grad(rows, cols, blue):
+        y, x = np.mgrid[0:rows, 0:cols]
+        return np.stack([(x * 255) // (cols - 1), (y * 255) // (rows - 1), blue(x, y)], -1).astype(np.uint8)
+    cases = [(grad(16, 16, lambda x, y: ((x + y) * 255) // 30), dict(quality=85), 40.0),
+             (grad(19, 25, lambda x, y: ((x * y) * 255) // (24 * 18)), dict(quality=85, subsampling=1), 40.0),
+             (grad(64, 48, lambda x, y: ((x + 2 * y) * 255) // (47 + 2 * 63)), dict(quality=92, subsampling=2), 45.0),
+             (grad(37, 53, lambda x, y: ((2 * x + 3 * y) * 255) // (2 * 52 + 3 * 36)), dict(quality=85, subsampling=2), 35.0)]
+    for img, kw, bar in cases:
+        data = oracle.jpeg_encode(img, **kw)
+        assert psnr(img, oracle.jpeg_decode_native(data)[0]) > bar
+        assert psnr(img, J.pil_decode(data)) > bar - 3  # and libjpeg reads the file
+    yy, xx = np.mgrid[0:16, 0:16]
+    g = (((xx + yy) * 255) // 30).astype(np.uint8)
+    data = oracle.jpeg_encode(g, quality=85)
+    assert psnr(g, oracle.jpeg_decode_native(data)[0]) > 45 and oracle.jpeg_info(data).num_components == 1
+    with pytest.raises(oracle.JpegError) as e:
+        oracle.jpeg_encode(np.zeros((0, 4), np.uint8))
+    assert e.value.name == "InvalidImageDimensions"
+    # the forward DCT is the scaled-by-8 DCT-II to within rounding
+    rng = np.random.default_rng(1)
+    k = np.arange(8)
+    c = np.where(k == 0, np.sqrt(0.5), 1.0)
+    basis = 0.5 * c[None, :] * np.cos((2 * k[:, None] + 1) * k[None, :] * np.pi / 16)
+    blk = rng.integers(-128, 128, (8, 8))
+    assert np.abs(oracle.jpeg_fdct8x8(blk) - 8 * (basis.T @ blk @ basis)).max() <= 2.0
+
+
+@pytest.mark.gpu
+def test_encode_files_byte_for_byte(oracle):
+    import torch
+    rng = np.random.default_rng(12)
+    for (h, w) in ((1, 1), (7, 9), (8, 8), (16, 16), (33, 47), (64, 80), (100, 37), (130, 258)):
+        for smooth in (True, False):
+            img = J.test_image(h, w, seed=h * w, smooth=smooth)
+            for sub in (0, 1, 2):
+                for q in (int(rng.integers(1, 101)), 90):
+                    want = oracle.jpeg_encode(img, q, sub)
+                    got = zg.jpeg.encode(zg.Image(torch.from_numpy(img).cuda()), zg.jpeg.EncodeOptions(quality=q, subsampling=sub))
+                    assert got == want, (h, w, smooth, sub, q, len(got), len(want))
+            want = oracle.jpeg_encode(img[..., 1], 77)
+            got = zg.jpeg.encode(zg.Image(torch.from_numpy(img[..., 1].copy()).cuda()), zg.jpeg.EncodeOptions(quality=77))
+            assert got == want, ("grey", h, w, smooth)
+    img = J.test_image(45, 61, seed=8)
+    dev = zg.Image(torch.from_numpy(img).cuda())
+    opts = zg.jpeg.EncodeOptions(quality=60, subsampling=1, density_dpi=300, comment=b"made on an MI355X")
+    want = oracle.jpeg_encode(img, 60, 1, 300, b"made on an MI355X")
+    assert zg.jpeg.encode(dev, opts) == want and b"made on an MI355X" in want
+    assert zg.jpeg.encode(zg.Image(img), opts) == want                      # zg_jpeg_encode_host
+    big = zg.Image(torch.zeros((70, 90, 3), dtype=torch.uint8, device="cuda"))  # a view: stride != cols
+    big.data[11:56, 13:74] = torch.from_numpy(img).cuda()
+    assert zg.jpeg.encode(big.view((13, 11, 74, 56)), opts) == want
+    # any other T goes through Image.convert(Rgb): Rgba(u8), Rgb(f32), f32
+    rgba = rng.integers(0, 256, (20, 31, 4), dtype=np.uint8)
+    assert zg.jpeg.encode(zg.Image(torch.from_numpy(rgba).cuda())) == oracle.jpeg_encode(rgba)
+    f = rng.random((20, 31, 3), dtype=np.float32)
+    assert zg.jpeg.encode(zg.Image(torch.from_numpy(f).cuda())) == oracle.jpeg_encode(f)
+    g = rng.random((20, 31), dtype=np.float32)
+    assert zg.jpeg.encode(zg.Image(torch.from_numpy(g).cuda())) == oracle.jpeg_encode(g)
+    # round trip through our own decoder and a file on disk
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "x.JPG")
+        dev.save(path)
+        assert open(path, "rb").read() == oracle.jpeg_encode(img, 90, 2)
+        assert np.array_equal(zg.Image.load(path).to_numpy(), oracle.jpeg_decode_native(oracle.jpeg_encode(img, 90, 2))[0])
+    with pytest.raises(zg.CodecError) as e:
+        zg.jpeg.encode(zg.Image(torch.zeros((0, 5, 3), dtype=torch.uint8, device="cuda")))
+    assert e.value.name == "InvalidImageDimensions"

@@ -62,6 +62,11 @@ class ZgJpegLimits(C.Structure):
                 ("max_pixels", C.c_uint64), ("max_blocks", C.c_size_t), ("max_scans", C.c_size_t)]
 
 
+class ZgJpegEncodeOptions(C.Structure):
+    """zg_jpeg_encode_options == jpeg.EncodeOptions (jpeg.zig:284-290)."""
+    _fields_ = [("quality", C.c_int), ("subsampling", C.c_int), ("density_dpi", C.c_int), ("comment", C.c_char_p), ("comment_len", C.c_size_t)]
+
+
 class ZignalError(RuntimeError):
     def __init__(self, status: int, message: str):
         super().__init__(f"zignal_hip status {status}: {message}")
@@ -188,9 +193,13 @@ _SIGNATURES = {
     "zg_jpeg_probe": [C.c_void_p, C.c_size_t, C.POINTER(ZgJpegLimits), C.POINTER(ZgJpegHeader), C.POINTER(C.c_int)],
     "zg_jpeg_decode": [C.c_void_p, C.c_size_t, C.POINTER(ZgJpegLimits), _IMG, C.c_int, C.POINTER(C.c_int), C.c_void_p],
     "zg_jpeg_decode_host": [C.c_void_p, C.c_size_t, C.POINTER(ZgJpegLimits), _IMG, C.c_int, C.POINTER(C.c_int)],
+    "zg_jpeg_default_encode_options": [C.POINTER(ZgJpegEncodeOptions)],
+    "zg_jpeg_encode": [_IMG, C.c_int, C.POINTER(ZgJpegEncodeOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p],
+    "zg_jpeg_encode_host": [_IMG, C.c_int, C.POINTER(ZgJpegEncodeOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
+    "zg_jpeg_free": [C.c_void_p],
 }
 _RESTYPES = {"zg_last_error": C.c_char_p, "zg_shutdown": None, "zg_pixel_size": C.c_size_t, "zg_pyramid_scale": C.c_float,
-             "zg_png_default_limits": None, "zg_png_default_encode_options": None, "zg_png_free": None, "zg_jpeg_default_limits": None}
+             "zg_png_default_limits": None, "zg_png_default_encode_options": None, "zg_png_free": None, "zg_jpeg_default_limits": None, "zg_jpeg_default_encode_options": None, "zg_jpeg_free": None}
 
 # every symbol include/zignal_hip.h declares; tests check the library exports all of them
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

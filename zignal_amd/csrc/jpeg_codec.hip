@@ -10,6 +10,7 @@
 // nonsense, and i16 would saturate differently); chroma goes up compacted to one block per MCU.
 #include "zg_common.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -815,6 +816,305 @@ int decode_impl(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, c
     return rc;
 }
 
+// ==== encoder (jpeg.zig:293-1043) ================================================================================================
+// Device: RGB -> YCbCr (u8 fixed point), edge replication into the MCU padding, chroma box averaging, level shift, the LLM
+// forward DCT in the reference's integer form and its reciprocal quantisation: one i16 coefficient block per component block.
+// Host: the Huffman coder with the reference's fixed tables, which makes the whole file a deterministic function of the
+// pixels and options — files are compared with the oracle's byte for byte.
+__device__ inline int32_t descale64(int64_t x, int n) { return (int32_t)((x + ((int64_t)1 << (n - 1))) >> n); }
+__device__ inline void fdct_pass(const int64_t in[8], int32_t out[8], bool first) { // one pass of fdct8x8_llm (:634-741)
+    const int64_t tmp0 = in[0] + in[7], tmp7 = in[0] - in[7], tmp1 = in[1] + in[6], tmp6 = in[1] - in[6];
+    const int64_t tmp2 = in[2] + in[5], tmp5 = in[2] - in[5], tmp3 = in[3] + in[4], tmp4 = in[3] - in[4];
+    const int64_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    const int shift = first ? 11 : 15; // CONST_BITS -/+ PASS1_BITS
+    if (first) { out[0] = (int32_t)((tmp10 + tmp11) << 2); out[4] = (int32_t)((tmp10 - tmp11) << 2); }
+    else { out[0] = descale64(tmp10 + tmp11, 2); out[4] = descale64(tmp10 - tmp11, 2); }
+    const int64_t z1 = (tmp12 + tmp13) * 4433;
+    out[2] = descale64(z1 + tmp13 * 6270, shift);
+    out[6] = descale64(z1 + tmp12 * (-15137), shift);
+    int64_t z1o = tmp4 + tmp7, z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;
+    const int64_t z5 = (z3 + z4) * 9633;
+    const int64_t t4 = tmp4 * 2446, t5 = tmp5 * 16819, t6 = tmp6 * 25172, t7 = tmp7 * 12299;
+    z1o *= -7373; z2 *= -20995; z3 *= -16069; z4 *= -3196;
+    z3 += z5; z4 += z5;
+    out[7] = descale64(t4 + z1o + z3, shift); out[5] = descale64(t5 + z2 + z4, shift); out[3] = descale64(t6 + z2 + z3, shift); out[1] = descale64(t7 + z1o + z4, shift);
+}
+struct RecipTable { uint32_t r[64]; };
+struct ForwardArgs {
+    DImg src;          // Image(u8) (grey) or Image(Rgb(u8))
+    int component;     // 0 Y (or grey), 1 Cb, 2 Cr
+    int hm, vm;        // luma sampling factors of the frame
+    unsigned blocks_x, nblocks;
+};
+// convertColor(Ycbcr, Rgb(u8)) (color.zig:987-1009), one component of it
+__device__ inline int ycc_component(const uint8_t *p, int c) {
+    const int64_t r = p[0], g = p[1], b = p[2];
+    const int64_t v = c == 0 ? (19595 * r + 38470 * g + 7471 * b + 32768) >> 16
+                    : c == 1 ? ((-11059 * r - 21710 * g + 32768 * b + 32768) >> 16) + 128
+                             : ((32768 * r - 27439 * g - 5329 * b + 32768) >> 16) + 128;
+    return (int)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+template <bool GRAY> __global__ __launch_bounds__(256) void k_jpeg_forward(ForwardArgs a, RecipTable recip, int16_t *out) {
+    __shared__ int32_t tile[32][72];
+    const unsigned local = threadIdx.x >> 3, lane = threadIdx.x & 7, b = blockIdx.x * 32 + local;
+    const bool live = b < a.nblocks;
+    const int last_row = a.src.rows - 1, last_col = a.src.cols - 1;
+    int32_t res[8];
+    if (live) {
+        const unsigned by = b / a.blocks_x, bx = b % a.blocks_x;
+        int64_t in[8];
+        const uint8_t *base = (const uint8_t *)a.src.data;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            int v;
+            if (GRAY) {
+                const int iy = min((int)(by * 8 + lane), last_row), ix = min((int)(bx * 8) + x, last_col);
+                v = base[(size_t)iy * a.src.stride + ix];
+            } else if (a.component == 0) {
+                const int iy = min((int)(by * 8 + lane), last_row), ix = min((int)(bx * 8) + x, last_col);
+                v = ycc_component(base + ((size_t)iy * a.src.stride + ix) * 3, 0);
+            } else { // one chroma sample = the mean of the vm x hm pixels under it (each clamped into the image on its own)
+                int sum = 0;
+                for (int dy = 0; dy < a.vm; ++dy)
+                    for (int dx = 0; dx < a.hm; ++dx) {
+                        const int iy = min((int)((by * 8 + lane) * a.vm) + dy, last_row), ix = min((int)((bx * 8 + x) * a.hm) + dx, last_col);
+                        sum += ycc_component(base + ((size_t)iy * a.src.stride + ix) * 3, a.component);
+                    }
+                v = sum / (a.hm * a.vm);
+            }
+            in[x] = v - 128;
+        }
+        fdct_pass(in, res, true); // pass 1: along row `lane`
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[local][lane * 8 + k] = res[k];
+    }
+    __syncthreads();
+    if (live) {
+        int64_t in[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) in[r] = tile[local][r * 8 + lane];
+        fdct_pass(in, res, false); // pass 2: down column `lane`
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { // quantizeWithRecip (:763-770)
+            const int32_t v = res[r];
+            const int64_t mag = v < 0 ? -(int64_t)v : v;
+            int64_t q = (mag * (int64_t)recip.r[r * 8 + lane] + ((int64_t)1 << 23)) >> 24;
+            tile[local][r * 8 + lane] = (int32_t)(v < 0 ? -q : q);
+        }
+    }
+    __syncthreads();
+    if (live) { // row `lane` of the block: eight i16 = one 16-byte store
+        const int32_t *row = &tile[local][lane * 8];
+        uint4 packed;
+        packed.x = (uint32_t)(uint16_t)row[0] | (uint32_t)(uint16_t)row[1] << 16;
+        packed.y = (uint32_t)(uint16_t)row[2] | (uint32_t)(uint16_t)row[3] << 16;
+        packed.z = (uint32_t)(uint16_t)row[4] | (uint32_t)(uint16_t)row[5] << 16;
+        packed.w = (uint32_t)(uint16_t)row[6] | (uint32_t)(uint16_t)row[7] << 16;
+        *(uint4 *)(out + (size_t)b * 64 + lane * 8) = packed;
+    }
+}
+
+// The reference's tables (jpeg.zig:331-392). Its luma DC table uses the chroma table's code lengths (0 3 1 1 ...), not Annex K's.
+const uint8_t kQLuma[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                            18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+const uint8_t kQChroma[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                              99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+const uint8_t kBitsDc[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+const uint8_t kBitsAcLuma[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 125};
+const uint8_t kBitsAcChroma[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 119};
+const uint8_t kValAcLuma[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1,
+    0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
+    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a,
+    0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
+    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3,
+    0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+const uint8_t kValAcChroma[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1,
+    0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36,
+    0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69,
+    0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a,
+    0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca,
+    0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
+struct HuffmanCodes { // buildHuffmanEncoder (:399-415)
+    uint16_t code[256];
+    uint8_t size[256];
+    HuffmanCodes(const uint8_t *bits, const uint8_t *vals) {
+        memset(code, 0, sizeof code);
+        memset(size, 0, sizeof size);
+        unsigned next = 0, k = 0;
+        for (int len = 1; len <= 16; ++len) {
+            for (int j = 0; j < bits[len - 1]; ++j, ++k, ++next) { code[vals[k]] = (uint16_t)next; size[vals[k]] = (uint8_t)len; }
+            next = (next << 1) & 0xffff;
+        }
+    }
+};
+class EntropyWriter { // :417-447
+  public:
+    std::vector<uint8_t> bytes;
+    uint32_t window = 0;
+    int held = 0;
+    void put(uint32_t value, int n) {
+        if (n == 0) return;
+        window = (window << n) | (value & ((1u << n) - 1));
+        held += n;
+        while (held >= 8) {
+            const uint8_t b = (uint8_t)(window >> (held - 8));
+            bytes.push_back(b);
+            if (b == 0xFF) bytes.push_back(0x00);
+            held -= 8;
+        }
+    }
+    void finish() {
+        if (held > 0) { const int pad = 8 - held; put((1u << pad) - 1, pad); }
+    }
+};
+inline int bit_length(int32_t v) { int n = 0; for (uint32_t a = (uint32_t)(v < 0 ? -v : v); a; a >>= 1) ++n; return n; }
+inline uint32_t extra_bits(int32_t v, int n) { return v >= 0 ? (uint32_t)v : (uint32_t)(((int32_t)1 << n) - 1 + v); }
+void write_block(const int16_t *co, EntropyWriter *w, const HuffmanCodes &dc, const HuffmanCodes &ac, int32_t *prev_dc) { // encodeBlock (:771-817), after the quantiser
+    const int32_t diff = co[0] - *prev_dc;
+    *prev_dc = co[0];
+    const int n = bit_length(diff);
+    w->put(dc.code[n], dc.size[n]);
+    if (n > 0) w->put(extra_bits(diff, n), n);
+    int run = 0;
+    for (int k = 1; k < 64; ++k) {
+        const int32_t v = co[kZigzag[k]];
+        if (v == 0) {
+            if (++run == 16) { w->put(ac.code[0xF0], ac.size[0xF0]); run = 0; } // sixteen zeros make a ZRL at once, trailing zeros too
+            continue;
+        }
+        const int m = bit_length(v), symbol = (run << 4) | m;
+        w->put(ac.code[symbol], ac.size[symbol]);
+        w->put(extra_bits(v, m), m);
+        run = 0;
+    }
+    if (run > 0) w->put(ac.code[0x00], ac.size[0x00]);
+}
+void push_segment(std::vector<uint8_t> *f, int marker, const std::vector<uint8_t> &payload) { // writeSegment (:457-462)
+    f->push_back(0xFF);
+    f->push_back((uint8_t)marker);
+    f->push_back((uint8_t)((payload.size() + 2) >> 8));
+    f->push_back((uint8_t)(payload.size() + 2));
+    f->insert(f->end(), payload.begin(), payload.end());
+}
+
+int encode_impl(const zg_image *src, int src_space, const zg_jpeg_encode_options *options, uint8_t **out, size_t *out_len, hipStream_t s) {
+    ZG_REQUIRE(out && out_len, ZG_ERR_INVALID_ARGUMENT, "jpeg encode: null output");
+    *out = nullptr;
+    *out_len = 0;
+    zg_jpeg_encode_options opt;
+    if (options) opt = *options; else zg_jpeg_default_encode_options(&opt);
+    int rc;
+    if ((rc = check_image(src, "src"))) return rc;
+    if (src->rows == 0 || src->cols == 0) JPEG_FAIL("InvalidImageDimensions");
+    if (src->rows > 65535 || src->cols > 65535) JPEG_FAIL("ImageTooLarge");
+    ZG_REQUIRE(opt.subsampling >= 0 && opt.subsampling <= 2, ZG_ERR_INVALID_ARGUMENT, "jpeg encode: subsampling %d (0 yuv444, 1 yuv422, 2 yuv420)", opt.subsampling);
+    const bool gray = src->pixel == ZG_PIXEL_U8;                         // T == u8 (:321)
+    const bool direct = gray || (src->pixel == ZG_PIXEL_RGB_U8 && src_space == ZG_CS_RGB);
+    const int hm = gray || opt.subsampling == 0 ? 1 : 2, vm = !gray && opt.subsampling == 2 ? 2 : 1;
+    const unsigned mcus_x = ceil_div(src->cols, 8u * hm), mcus_y = ceil_div(src->rows, 8u * vm);
+    const unsigned lbx = mcus_x * hm, lby = mcus_y * vm;
+    const size_t luma_blocks = (size_t)lbx * lby, chroma_blocks = gray ? 0 : (size_t)mcus_x * mcus_y, total_blocks = luma_blocks + 2 * chroma_blocks;
+    const size_t rgb_bytes = direct ? 0 : ((size_t)src->rows * src->cols * 3 + 255) / 256 * 256;
+    char *dev = nullptr;
+    if ((rc = scratch_alloc((void **)&dev, rgb_bytes + total_blocks * 64 * sizeof(int16_t), s))) return rc;
+    zg_image rgb{dev, src->cols, src->rows, src->cols, ZG_PIXEL_RGB_U8};
+    if (!direct) rc = zg_convert(src, src_space, &rgb, ZG_CS_RGB, nullptr, (zg_stream)s); // image.convert(Rgb) (:323-327)
+    const zg_image *img = direct ? src : &rgb;
+    int16_t *coef = (int16_t *)(dev + rgb_bytes);
+
+    int quality = opt.quality < 1 ? 1 : (opt.quality > 100 ? 100 : opt.quality); // scaleQuantTables (:464-476)
+    const int scale = quality < 50 ? 5000 / quality : 200 - quality * 2;
+    uint8_t ql[64], qc[64];
+    RecipTable rl, rcq;
+    for (int i = 0; i < 64; ++i) {
+        const int l = (kQLuma[i] * scale + 50) / 100, c = (kQChroma[i] * scale + 50) / 100;
+        ql[i] = (uint8_t)(l < 1 ? 1 : (l > 255 ? 255 : l));
+        qc[i] = (uint8_t)(c < 1 ? 1 : (c > 255 ? 255 : c));
+        rl.r[i] = (uint32_t)round(16777216.0 / ((double)ql[i] * 8.0));   // buildQuantRecipLLM (:749-761)
+        rcq.r[i] = (uint32_t)round(16777216.0 / ((double)qc[i] * 8.0));
+    }
+    if (rc == ZG_OK) {
+        for (int c = 0; c < (gray ? 1 : 3); ++c) {
+            const ForwardArgs a{dimg(img), c, hm, vm, c == 0 ? lbx : mcus_x, (unsigned)(c == 0 ? luma_blocks : chroma_blocks)};
+            int16_t *dstc = coef + (c == 0 ? 0 : (luma_blocks + (size_t)(c - 1) * chroma_blocks)) * 64;
+            if (gray) hipLaunchKernelGGL((k_jpeg_forward<true>), dim3(ceil_div(a.nblocks, 32)), dim3(256), 0, s, a, rl, dstc);
+            else hipLaunchKernelGGL((k_jpeg_forward<false>), dim3(ceil_div(a.nblocks, 32)), dim3(256), 0, s, a, c == 0 ? rl : rcq, dstc);
+        }
+        if (hipGetLastError() != hipSuccess) rc = ZG_ERR_HIP;
+    }
+    std::vector<int16_t> host;
+    if (rc == ZG_OK) {
+        host.resize(total_blocks * 64);
+        hipError_t e = hipMemcpyAsync(host.data(), coef, host.size() * sizeof(int16_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = hip_fail(e, "jpeg download", __FILE__, __LINE__);
+    }
+    scratch_free(dev, s);
+    if (rc) return rc;
+
+    // the container (encodeRgb :929-975, encodeGrayscale :977-1043)
+    std::vector<uint8_t> file = {0xFF, 0xD8};
+    const uint8_t dh = (uint8_t)(opt.density_dpi >> 8), dl = (uint8_t)opt.density_dpi;
+    push_segment(&file, 0xE0, {'J', 'F', 'I', 'F', 0, 1, 1, 1, dh, dl, dh, dl, 0, 0});
+    if (opt.comment) push_segment(&file, 0xFE, std::vector<uint8_t>(opt.comment, opt.comment + opt.comment_len));
+    std::vector<uint8_t> seg = {0x00};
+    for (int i = 0; i < 64; ++i) seg.push_back(ql[kZigzag[i]]);
+    if (!gray) {
+        seg.push_back(0x01);
+        for (int i = 0; i < 64; ++i) seg.push_back(qc[kZigzag[i]]);
+    }
+    push_segment(&file, 0xDB, seg);
+    const uint8_t hi_r = (uint8_t)(src->rows >> 8), lo_r = (uint8_t)src->rows, hi_c = (uint8_t)(src->cols >> 8), lo_c = (uint8_t)src->cols;
+    if (gray) push_segment(&file, 0xC0, {8, hi_r, lo_r, hi_c, lo_c, 1, 1, 0x11, 0});
+    else push_segment(&file, 0xC0, {8, hi_r, lo_r, hi_c, lo_c, 3, 1, (uint8_t)(hm << 4 | vm), 0, 2, 0x11, 1, 3, 0x11, 1});
+    const uint8_t dc_vals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+    seg.assign(1, 0x00);
+    seg.insert(seg.end(), kBitsDc, kBitsDc + 16); seg.insert(seg.end(), dc_vals, dc_vals + 12);
+    seg.push_back(0x10);
+    seg.insert(seg.end(), kBitsAcLuma, kBitsAcLuma + 16); seg.insert(seg.end(), kValAcLuma, kValAcLuma + 162);
+    if (!gray) {
+        seg.push_back(0x01);
+        seg.insert(seg.end(), kBitsDc, kBitsDc + 16); seg.insert(seg.end(), dc_vals, dc_vals + 12);
+        seg.push_back(0x11);
+        seg.insert(seg.end(), kBitsAcChroma, kBitsAcChroma + 16); seg.insert(seg.end(), kValAcChroma, kValAcChroma + 162);
+    }
+    push_segment(&file, 0xC4, seg);
+    if (gray) push_segment(&file, 0xDA, {1, 1, 0x00, 0, 63, 0});
+    else push_segment(&file, 0xDA, {3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0});
+
+    const HuffmanCodes dc_codes(kBitsDc, dc_vals), ac_luma(kBitsAcLuma, kValAcLuma), ac_chroma(kBitsAcChroma, kValAcChroma);
+    EntropyWriter w;
+    w.bytes.reserve(total_blocks * 24);
+    int32_t pred[3] = {0, 0, 0};
+    const int16_t *cb = host.data() + luma_blocks * 64, *cr = cb + chroma_blocks * 64;
+    for (unsigned my = 0; my < mcus_y; ++my)
+        for (unsigned mx = 0; mx < mcus_x; ++mx) { // one MCU: its vm x hm luma blocks, then Cb, then Cr (:862-925)
+            for (int vy = 0; vy < vm; ++vy)
+                for (int hx = 0; hx < hm; ++hx)
+                    write_block(host.data() + ((size_t)(my * vm + vy) * lbx + (mx * hm + hx)) * 64, &w, dc_codes, ac_luma, &pred[0]);
+            if (!gray) {
+                write_block(cb + ((size_t)my * mcus_x + mx) * 64, &w, dc_codes, ac_chroma, &pred[1]);
+                write_block(cr + ((size_t)my * mcus_x + mx) * 64, &w, dc_codes, ac_chroma, &pred[2]);
+            }
+        }
+    w.finish();
+    file.insert(file.end(), w.bytes.begin(), w.bytes.end());
+    file.push_back(0xFF);
+    file.push_back(0xD9);
+    uint8_t *mem = (uint8_t *)malloc(file.size());
+    if (!mem) { set_error("jpeg encode: out of host memory"); return ZG_ERR_OUT_OF_MEMORY; }
+    memcpy(mem, file.data(), file.size());
+    *out = mem;
+    *out_len = file.size();
+    return ZG_OK;
+}
+
 } // namespace
 } // namespace zg
 
@@ -889,6 +1189,24 @@ int zg_jpeg_info(const uint8_t *d, size_t len, const zg_jpeg_limits *limits, zg_
         seen += skip;
     }
 }
+
+void zg_jpeg_default_encode_options(zg_jpeg_encode_options *o) { // EncodeOptions (jpeg.zig:284-290)
+    o->quality = 90;
+    o->subsampling = 2;
+    o->density_dpi = 72;
+    o->comment = nullptr;
+    o->comment_len = 0;
+}
+int zg_jpeg_encode(const zg_image *src, int src_space, const zg_jpeg_encode_options *options, uint8_t **out, size_t *out_len, zg_stream stream) {
+    return encode_impl(src, src_space, options, out, out_len, as_stream(stream));
+}
+int zg_jpeg_encode_host(const zg_image *src, int src_space, const zg_jpeg_encode_options *options, uint8_t **out, size_t *out_len) {
+    HostStage a;
+    int rc;
+    if ((rc = a.upload(src, true, false))) return rc;
+    return encode_impl(&a.dev, src_space, options, out, out_len, nullptr);
+}
+void zg_jpeg_free(void *p) { free(p); }
 
 int zg_jpeg_probe(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, zg_jpeg_header *header_out, int *scan_limit_reached_out) {
     ZG_REQUIRE(jpeg != nullptr, ZG_ERR_INVALID_ARGUMENT, "jpeg probe: null data");

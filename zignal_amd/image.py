@@ -191,11 +191,14 @@ class Image:
             return Image.load_from_bytes(f.read(), kind, device)
 
     def save(self, path: str) -> None:
-        """Image(T).save: the format comes from the extension (case-insensitive); anything but .png is UnsupportedImageFormat here."""
-        from . import png
-        if not path.lower().endswith(".png"):
-            raise L.ZignalError(L.ERR_UNSUPPORTED, "UnsupportedImageFormat (only .png is encoded by this library)")
-        png.save(self, path)
+        """Image(T).save: the format comes from the extension (case-insensitive); .bmp / .gif are UnsupportedImageFormat here."""
+        from . import jpeg, png
+        low = path.lower()
+        if low.endswith(".png"):
+            return png.save(self, path)
+        if low.endswith(".jpg") or low.endswith(".jpeg"):
+            return jpeg.save(self, path)
+        raise L.ZignalError(L.ERR_UNSUPPORTED, "UnsupportedImageFormat (.png and .jpg / .jpeg are encoded by this library)")
 
     # ---- container ops (reference src/image.zig:304-392) -------------------------------------
     def has_same_shape(self, other: "Image") -> bool:

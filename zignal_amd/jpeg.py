@@ -2,11 +2,13 @@
 
 Markers and Huffman decoding run on the host inside libzignal_hip.so; dequantisation, the IDCT, chroma upsampling, colour
 conversion and the conversion to the requested Image(T) run on the MI355X. Errors of the reference's error set surface as
-`CodecError` with `.name` == the Zig error name. (Encoding — jpeg.encode / save — is not part of this build.)
+`CodecError` with `.name` == the Zig error name. Encoding is the mirror image: colour conversion, chroma averaging, the forward
+DCT and quantisation on the device, the Huffman coder on the host; the file is byte for byte the reference's.
 """
 from __future__ import annotations
 
 import ctypes as C
+from dataclasses import dataclass
 from typing import Optional
 
 import numpy as np
@@ -78,3 +80,41 @@ def load(path: str, kind: Optional[str] = None, limits: Optional[L.ZgJpegLimits]
     """jpeg.load (jpeg.zig:2853-2858)."""
     with open(path, "rb") as f:
         return load_from_bytes(f.read(), kind, limits, device)
+
+
+YUV444, YUV422, YUV420 = 0, 1, 2  # jpeg.Subsampling
+
+
+@dataclass
+class EncodeOptions:
+    """jpeg.EncodeOptions (jpeg.zig:284-290)."""
+    quality: int = 90
+    subsampling: int = YUV420
+    density_dpi: int = 72
+    comment: Optional[bytes] = None
+
+    def _c(self) -> L.ZgJpegEncodeOptions:
+        return L.ZgJpegEncodeOptions(int(self.quality), int(self.subsampling), int(self.density_dpi), self.comment, len(self.comment) if self.comment else 0)
+
+
+def encode(image, options: Optional[EncodeOptions] = None, space: Optional[int] = None) -> bytes:
+    """jpeg.encode(T) (jpeg.zig:307-329): u8 -> one component, Rgb -> YCbCr, anything else goes through Rgb."""
+    image = Image._wrap(image)
+    if space is None:
+        space = {1: L.CS_GRAY, 3: L.CS_RGB, 4: L.CS_RGBA}[1 if image.data.ndim == 2 else int(image.data.shape[2])]
+    out, n = C.c_void_p(), C.c_size_t(0)
+    d, opt, lib = image._desc(), (options or EncodeOptions())._c(), L.lib()
+    if image.on_device:
+        L.check(lib.zg_jpeg_encode(C.byref(d), space, C.byref(opt), C.byref(out), C.byref(n), image._stream()))
+    else:
+        L.check(lib.zg_jpeg_encode_host(C.byref(d), space, C.byref(opt), C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out.value, n.value)
+    finally:
+        lib.zg_jpeg_free(out)
+
+
+def save(image, path: str, options: Optional[EncodeOptions] = None) -> None:
+    """jpeg.save (jpeg.zig:293-303): EncodeOptions{ .subsampling = .yuv420 } unless told otherwise."""
+    with open(path, "wb") as f:
+        f.write(encode(image, options))
