@@ -524,9 +524,15 @@ def extras(zg, torch, np):
         with ThreadPoolExecutor(16) as ex:
             list(ex.map(one, range(16)))
             t0 = _t.perf_counter(); list(ex.map(one, range(32))); par = _t.perf_counter() - t0
+        dev_pic = zg.Image(torch.from_numpy(pic).cuda())
+        zg.jpeg.encode(dev_pic)
+        enc = 1e9
+        for _ in range(2):
+            t0 = _t.perf_counter(); ours = zg.jpeg.encode(dev_pic); enc = min(enc, _t.perf_counter() - t0)
         return {"decode_ms": round(best * 1e3, 1), "decode_Mpixels/s": round(ROWS * COLS / best / 1e6, 1),
                 "decode_16_threads_Mpixels/s": round(32 * ROWS * COLS / par / 1e6, 1), "file_MiB": round(len(data) / 2**20, 1),
-                "note": "host-bound: Huffman decoding is one serial chain per scan; device share (IDCT 3 planes + render) ~0.12 ms"}
+                "encode_ms": round(enc * 1e3, 1), "encode_Mpixels/s": round(ROWS * COLS / enc / 1e6, 1), "encoded_MiB": round(len(ours) / 2**20, 1),
+                "note": "host-bound: Huffman decoding / coding is one serial chain; device share ~0.12 ms (IDCT 3 planes + render) / ~0.2 ms (forward DCT)"}
 
     leg("next_sobel_rgba_u8_4096", sobel)
     leg("next_pyramid_build_default_u8_4096", pyramid_build)

@@ -103,6 +103,21 @@ int main() {
         for (uint32_t r = 0; r < 8 && flat; ++r)
             for (uint32_t c = 0; c < 8; ++c) flat = flat && img.at(r, c) == 143;
         EXPECT(flat);
+        auto ramp = Image<Rgb<uint8_t>>::init(16, 16); // codecs/jpeg.zig:2860-2889: encode -> decode keeps PSNR above 40 dB
+        for (uint32_t r = 0; r < 16; ++r)
+            for (uint32_t c = 0; c < 16; ++c) ramp.at(r, c) = {(uint8_t)(c * 255 / 15), (uint8_t)(r * 255 / 15), (uint8_t)((r + c) * 255 / 30)};
+        zg_jpeg_encode_options jo;
+        zg_jpeg_default_encode_options(&jo);
+        jo.quality = 85;
+        const std::vector<uint8_t> jf = ramp.encodeJpeg(&jo);
+        auto back = Image<Rgb<uint8_t>>::loadFromBytes(jf.data(), jf.size());
+        double mse = 0;
+        for (uint32_t r = 0; r < 16; ++r)
+            for (uint32_t c = 0; c < 16; ++c) {
+                const double dr = (double)ramp.at(r, c).r - back.at(r, c).r, dg = (double)ramp.at(r, c).g - back.at(r, c).g, db = (double)ramp.at(r, c).b - back.at(r, c).b;
+                mse += dr * dr + dg * dg + db * db;
+            }
+        EXPECT(10.0 * std::log10(255.0 * 255.0 / (mse / (16 * 16 * 3))) > 40.0);
         std::string name;
         const uint8_t no_scan[] = {0xFF, 0xD8, 0xFF, 0xD9};
         try { Image<uint8_t>::loadFromBytes(no_scan, 4); } catch (const CodecError &e) { name = e.name(); }

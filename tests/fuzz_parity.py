@@ -200,8 +200,15 @@ def codec_case(rng):
     Both sides must then fail with the same error name or produce the same pixels."""
     from tests import jpeg_util as J
     from tests import png_util as P
-    which = int(rng.integers(0, 4))
+    which = int(rng.integers(0, 5))
     h, w = int(rng.integers(1, 90)), int(rng.integers(1, 140))
+    if which == 4:  # jpeg.encode: the whole file, byte for byte
+        grey = rng.random() < 0.3
+        pic = J.test_image(h, w, seed=int(rng.integers(0, 1000)), smooth=bool(rng.integers(0, 2)))
+        pic = pic[..., 0].copy() if grey else pic
+        q, sub = int(rng.integers(1, 101)), int(rng.integers(0, 3))
+        got = zg.jpeg.encode(dev(pic), zg.jpeg.EncodeOptions(quality=q, subsampling=sub))
+        return f"jpegenc {pic.shape} q={q} sub={sub}", np.frombuffer(got, np.uint8), np.frombuffer(o.jpeg_encode(pic, q, sub), np.uint8)
     if which == 0:  # PNG filter stream (the device half of png.encode)
         ch = int(rng.choice([1, 3, 4]))
         rows = int(rng.choice([h, 513 + h]))

@@ -82,6 +82,10 @@ def cases():
             + bytes([0xFF, 0xC4, 0x00, 0x14, 0x00, 0x01]) + bytes(15) + bytes([0x02]) + bytes([0xFF, 0xDA, 0x00, 0x08, 0x01, 0x01, 0x00, 0x00, 0x00, 0x02, 0x7F])
             + bytes([0xFF, 0xDA, 0x00, 0x08, 0x01, 0x01, 0x00, 0x00, 0x00, 0x21, 0xFF, 0x00]) + eoi)
     yield "jpeg_progressive_hand_built", o.jpeg_decode_native(prog)[0]
+    for name, sub in (("444", 0), ("422", 1), ("420", 2)):
+        yield f"jpeg_encode_{name}_q70", np.frombuffer(o.jpeg_encode(o.synth_u8(17, (37, 53, 3)), 70, sub), np.uint8)
+    yield "jpeg_encode_grey_q35", np.frombuffer(o.jpeg_encode(o.synth_u8(18, (37, 53)), 35), np.uint8)
+    yield "jpeg_fdct_block", o.jpeg_fdct8x8((o.synth_u8(19, (8, 8)).astype(np.int32) - 128))
     blk = np.zeros((8, 8), np.int32)
     blk.flat[[0, 1, 8, 9, 17, 34, 63]] = [900, -310, 255, 77, -41, 19, -7]
     yield "jpeg_idct_block", o.jpeg_idct8x8(blk)

@@ -77,10 +77,13 @@ elif op in ("jpeg420", "jpeg444", "jpeg420p"):
         with torch.cuda.stream(torch.cuda.Stream()):
             out = zg.jpeg.load_from_bytes(data); torch.cuda.current_stream().synchronize()
         return out
+    dev_pic = zg.Image(torch.from_numpy(pic).cuda())
     def f():
         t0 = time.perf_counter(); out = zg.jpeg.load_from_bytes(data); torch.cuda.synchronize(); t1 = time.perf_counter()
         print(f"decode {1e3 * (t1 - t0):.1f} ms")
-        for nt in (4, 16, 32):
+        t0 = time.perf_counter(); enc = zg.jpeg.encode(dev_pic, zg.jpeg.EncodeOptions(subsampling=0 if op == "jpeg444" else 2)); t1 = time.perf_counter()
+        print(f"encode {1e3 * (t1 - t0):.1f} ms, {len(enc) / 2**20:.1f} MiB")
+        for nt in (16,):
             with ThreadPoolExecutor(nt) as ex:
                 t0 = time.perf_counter(); list(ex.map(one, range(nt * 2))); t1 = time.perf_counter()
             print(f"  {nt} threads: {nt * 2} files in {1e3 * (t1 - t0):.1f} ms = {nt * 2 * R * R / (t1 - t0) / 1e6:.0f} Mpixels/s")

@@ -69,6 +69,11 @@ pub const c = struct {
     pub extern fn zg_jpeg_probe(jpeg: [*]const u8, len: usize, limits: ?*const ZgJpegLimits, header_out: ?*ZgJpegHeader, scan_limit_reached_out: ?*c_int) c_int;
     pub extern fn zg_jpeg_decode(jpeg: [*]const u8, len: usize, limits: ?*const ZgJpegLimits, dst: *const ZgImage, dst_space: c_int, scan_limit_reached_out: ?*c_int, stream: ?*anyopaque) c_int;
     pub extern fn zg_jpeg_decode_host(jpeg: [*]const u8, len: usize, limits: ?*const ZgJpegLimits, dst: *const ZgImage, dst_space: c_int, scan_limit_reached_out: ?*c_int) c_int;
+    pub const ZgJpegEncodeOptions = extern struct { quality: c_int, subsampling: c_int, density_dpi: c_int, comment: ?[*]const u8, comment_len: usize };
+    pub extern fn zg_jpeg_default_encode_options(options: *ZgJpegEncodeOptions) void;
+    pub extern fn zg_jpeg_encode(src: *const ZgImage, src_space: c_int, options: ?*const ZgJpegEncodeOptions, out: *?[*]u8, out_len: *usize, stream: ?*anyopaque) c_int;
+    pub extern fn zg_jpeg_encode_host(src: *const ZgImage, src_space: c_int, options: ?*const ZgJpegEncodeOptions, out: *?[*]u8, out_len: *usize) c_int;
+    pub extern fn zg_jpeg_free(p: ?*anyopaque) void;
     pub extern fn zg_shen_castan_host(src: *const ZgImage, dst: *const ZgImage, smooth: f32, window_size: u32, high_ratio: f32, low_rel: f32, hysteresis: c_int, use_nms: c_int) c_int;
     pub extern fn zg_canny_host(src: *const ZgImage, dst: *const ZgImage, sigma: f32, low_threshold: f32, high_threshold: f32) c_int;
     pub extern fn zg_convert_host(src: *const ZgImage, src_space: c_int, dst: *const ZgImage, dst_space: c_int, srgb_lut: ?[*]const f32) c_int;
@@ -498,5 +503,15 @@ pub const jpeg = struct {
         const space: c_int = switch (pixelOf(T)) { .u8, .f32 => 0, .rgb_u8, .rgb_f32 => 1, .rgba_u8, .rgba_f32 => 2 };
         try checkJpeg(c.zg_jpeg_decode_host(data.ptr, data.len, &limits, &Image(T).desc(out.base), space, null));
         return out;
+    }
+
+    /// reference src/codecs/jpeg.zig:307-329; the bytes are copied into `allocator`'s memory
+    pub fn encode(comptime T: type, allocator: std.mem.Allocator, image: Image(T), options: ?*const c.ZgJpegEncodeOptions) ![]u8 {
+        var mem: ?[*]u8 = null;
+        var len: usize = 0;
+        const space: c_int = switch (pixelOf(T)) { .u8, .f32 => 0, .rgb_u8, .rgb_f32 => 1, .rgba_u8, .rgba_f32 => 2 };
+        try checkJpeg(c.zg_jpeg_encode_host(&Image(T).desc(image.base), space, options, &mem, &len));
+        defer c.zg_jpeg_free(mem);
+        return allocator.dupe(u8, mem.?[0..len]);
     }
 };

@@ -234,6 +234,15 @@ template <typename T> class Image {
         check(zg_png_decode_host(bytes, len, nullptr, &d, PixelTraits<T>::space, nullptr));
         return out;
     }
+    std::vector<uint8_t> encodeJpeg(const zg_jpeg_encode_options *options = nullptr) const {                // jpeg.zig:307
+        uint8_t *mem = nullptr;
+        size_t n = 0;
+        const zg_image s = desc();
+        check(zg_jpeg_encode_host(&s, PixelTraits<T>::space, options, &mem, &n));
+        std::vector<uint8_t> out(mem, mem + n);
+        zg_jpeg_free(mem);
+        return out;
+    }
     std::vector<uint8_t> encodePng(const zg_png_encode_options *options = nullptr) const {                  // png.zig:1400
         uint8_t *mem = nullptr;
         size_t n = 0;
