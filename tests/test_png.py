@@ -248,7 +248,7 @@ def test_decode_into_views_host_images_and_float_targets(oracle):
         zg.Image(torch.from_numpy(want).cuda()).save(path)
         assert np.array_equal(zg.Image.load(path).to_numpy(), want)
         with pytest.raises(zg.ZignalError):
-            zg.Image(torch.from_numpy(want).cuda()).save(os.path.join(tmp, "x.jpg"))
+            zg.Image(torch.from_numpy(want).cuda()).save(os.path.join(tmp, "x.bmp"))
     with pytest.raises(zg.ZignalError):
         zg.Image.load_from_bytes(b"\xff\xd8\xff\xe0 not decoded here")
 

@@ -124,7 +124,7 @@ static int otsu_impl(const zg_image *src, const zg_image *dst, uint8_t *threshol
     hipLaunchKernelGGL(k_apply_threshold, dim3(ceil_div(src->cols, 256), src->rows), dim3(256), 0, s, dimg(src), dimg(dst), (const uint8_t *)thr);
     rc = hipGetLastError() == hipSuccess ? ZG_OK : ZG_ERR_HIP;
     if (rc == ZG_OK && threshold_host) { // the return value of the reference's method: needs the stream to finish
-        if (hipMemcpyAsync(threshold_host, thr, 1, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = ZG_ERR_HIP;
+        rc = download_pageable(threshold_host, thr, 1, s);
     }
     scratch_free(scratch, s);
     if (rc == ZG_ERR_HIP) set_error("thresholdOtsu: HIP failure");

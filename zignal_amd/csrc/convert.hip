@@ -154,8 +154,7 @@ static int device_srgb_lut(const float *host_lut, hipStream_t s, const float **o
     *owned = nullptr;
     if (host_lut) {
         ZG_HIP(hipMallocAsync((void **)owned, 256 * sizeof(float), s));
-        ZG_HIP(hipMemcpyAsync(*owned, host_lut, 256 * sizeof(float), hipMemcpyHostToDevice, s));
-        ZG_HIP(hipStreamSynchronize(s));
+        if (int rc = upload_pageable(*owned, host_lut, 256 * sizeof(float), s)) return rc;
         *out = *owned;
         return ZG_OK;
     }
@@ -167,7 +166,7 @@ static int device_srgb_lut(const float *host_lut, hipStream_t s, const float **o
     if (dev >= 0 && dev < 64 && !per_device[dev]) {
         float *p = nullptr;
         ZG_HIP(hipMalloc((void **)&p, 256 * sizeof(float)));
-        ZG_HIP(hipMemcpy(p, hostmath::srgb_u8_lut(), 256 * sizeof(float), hipMemcpyHostToDevice));
+        if (int rc = upload_pageable(p, hostmath::srgb_u8_lut(), 256 * sizeof(float), nullptr)) return rc;
         per_device[dev] = p;
     }
     *out = per_device[dev];

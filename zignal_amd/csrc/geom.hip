@@ -121,8 +121,7 @@ static int device_lanczos_lut(const zg_method *method, hipStream_t s, LutHolder 
     if (method->kind != ZG_INTERP_LANCZOS) return ZG_OK;
     if (method->lanczos_lut) {
         ZG_HIP(hipMallocAsync((void **)&h.owned, 1025 * sizeof(float), s));
-        ZG_HIP(hipMemcpyAsync(h.owned, method->lanczos_lut, 1025 * sizeof(float), hipMemcpyHostToDevice, s));
-        ZG_HIP(hipStreamSynchronize(s)); // the caller's table may be pageable / short-lived
+        if (int rc = upload_pageable(h.owned, method->lanczos_lut, 1025 * sizeof(float), s)) return rc; // the caller's table may be pageable / short-lived
         h.dev = h.owned;
         return ZG_OK;
     }
@@ -134,7 +133,7 @@ static int device_lanczos_lut(const zg_method *method, hipStream_t s, LutHolder 
     if (dev >= 0 && dev < 64 && !per_device[dev]) {
         float *p = nullptr;
         ZG_HIP(hipMalloc((void **)&p, 1025 * sizeof(float)));
-        ZG_HIP(hipMemcpy(p, hostmath::lanczos3_lut(), 1025 * sizeof(float), hipMemcpyHostToDevice));
+        if (int rc = upload_pageable(p, hostmath::lanczos3_lut(), 1025 * sizeof(float), nullptr)) return rc;
         per_device[dev] = p;
     }
     h.dev = per_device[dev];

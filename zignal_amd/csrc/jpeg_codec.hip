@@ -789,12 +789,10 @@ int decode_impl(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, c
     // scratch: coefficients | sample planes (same sizes) | native image when a conversion follows
     int32_t *dev = nullptr;
     if ((rc = scratch_alloc((void **)&dev, coef_words * 2 * sizeof(int32_t) + native_bytes + 256, s))) return rc;
-    hipError_t e = hipMemcpyAsync(dev, d.coef[0].data(), luma_coefs * sizeof(int32_t), hipMemcpyHostToDevice, s);
-    for (int c = 0; c < 2 && nc == 3 && e == hipSuccess; ++c)
-        e = hipMemcpyAsync(dev + luma_coefs + (size_t)c * chroma_coefs, subsampled ? packed[c].data() : d.coef[c + 1].data(), chroma_coefs * sizeof(int32_t),
-                           hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s); // the host vectors die with this call
-    if (e != hipSuccess) { scratch_free(dev, s); return hip_fail(e, "jpeg upload", __FILE__, __LINE__); }
+    rc = upload_pageable(dev, d.coef[0].data(), luma_coefs * sizeof(int32_t), s); // the host buffers die with this call
+    for (int c = 0; c < 2 && nc == 3 && rc == ZG_OK; ++c)
+        rc = upload_pageable(dev + luma_coefs + (size_t)c * chroma_coefs, subsampled ? packed[c].data() : d.coef[c + 1].data(), chroma_coefs * sizeof(int32_t), s);
+    if (rc) { scratch_free(dev, s); return rc; }
 
     int32_t *planes = dev + coef_words;
     for (int c = 0; c < nc; ++c) {
@@ -1051,9 +1049,7 @@ int encode_impl(const zg_image *src, int src_space, const zg_jpeg_encode_options
     std::vector<int16_t> host;
     if (rc == ZG_OK) {
         host.resize(total_blocks * 64);
-        hipError_t e = hipMemcpyAsync(host.data(), coef, host.size() * sizeof(int16_t), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) rc = hip_fail(e, "jpeg download", __FILE__, __LINE__);
+        rc = download_pageable(host.data(), coef, host.size() * sizeof(int16_t), s);
     }
     scratch_free(dev, s);
     if (rc) return rc;

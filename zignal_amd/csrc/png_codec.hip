@@ -455,10 +455,8 @@ int decode_impl(const uint8_t *png, size_t len, const zg_png_limits *limits, con
     const size_t native_bytes = direct ? 0 : (size_t)f.header.width * f.header.height * pixel_size(native);
     uint8_t *dev = nullptr;
     if ((rc = scratch_alloc((void **)&dev, L.total + 64 + native_bytes, s))) return rc;
-    // the scan data is pageable host memory that dies with this call: a synchronous copy into stream-ordered scratch
-    hipError_t e = hipMemcpyAsync(dev, scan.data(), L.total, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { scratch_free(dev, s); return hip_fail(e, "png upload", __FILE__, __LINE__); }
+    // the scan data is pageable host memory that dies with this call: a staged, synchronised copy into stream-ordered scratch
+    if ((rc = upload_pageable(dev, scan.data(), L.total, s))) { scratch_free(dev, s); return rc; }
 
     UnpackArgs a{};
     for (int p = 0; p < 7; ++p) a.pass[p] = L.pass[p < L.npass ? p : 0];
@@ -690,9 +688,7 @@ int encode_impl(const zg_image *src, int src_space, const zg_png_encode_options 
     std::vector<uint8_t> scan;
     if (rc == ZG_OK) {
         scan.resize(scan_bytes);
-        hipError_t e = hipMemcpyAsync(scan.data(), dev + rgb_bytes, scan_bytes, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) rc = hip_fail(e, "png download", __FILE__, __LINE__);
+        rc = download_pageable(scan.data(), dev + rgb_bytes, scan_bytes, s);
     }
     scratch_free(dev, s);
     if (rc) return rc;

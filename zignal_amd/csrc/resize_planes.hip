@@ -259,8 +259,8 @@ static int axis_table(int kind, uint32_t src_n, uint32_t dst_n, int taps, AxisTa
         AxisBuf buf;
         buf.n = idx.size();
         ZG_HIP(hipMalloc((void **)&buf.dev, 2 * buf.n * sizeof(int32_t)));
-        ZG_HIP(hipMemcpy(buf.dev, idx.data(), buf.n * sizeof(int32_t), hipMemcpyHostToDevice));
-        ZG_HIP(hipMemcpy(buf.dev + buf.n, w.data(), buf.n * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (int rc = upload_pageable(buf.dev, idx.data(), buf.n * sizeof(int32_t), nullptr)) return rc;
+        if (int rc = upload_pageable(buf.dev + buf.n, w.data(), buf.n * sizeof(int32_t), nullptr)) return rc;
         if (g_cache.size() >= 64) { // bounded: drop the oldest geometry
             const auto old = g_cache_order.front();
             g_cache_order.pop_front();

@@ -173,6 +173,15 @@ struct HostStage {
 
 int check_image(const zg_image *im, const char *name, bool device_pointer = true);
 
+// Host -> device copy of pageable memory that kernels may consume straight away: staged through a thread-local pinned buffer
+// in chunks and synchronised before returning (zg_runtime.cpp explains why the runtime's own pageable path is not used).
+int upload_pageable(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s);
+// rows of `width` bytes, `spitch` apart on the host, packed back to back on the device
+int upload_pageable_rows(void *dst_dev, const void *src_host, size_t spitch, size_t width, size_t rows, hipStream_t s);
+// the reverse trips: device memory (contiguous) into pageable host memory / into host rows `dpitch` apart
+int download_pageable(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s);
+int download_pageable_rows(void *dst_host, size_t dpitch, const void *src_dev, size_t width, size_t rows, hipStream_t s);
+
 // stream-ordered scratch from the device's default pool (zg_runtime.cpp)
 int scratch_alloc(void **out, size_t bytes, hipStream_t s);
 void scratch_free(void *p, hipStream_t s);
