@@ -88,7 +88,7 @@ struct PinnedStage {
     ~PinnedStage() { if (p) (void)hipHostFree(p); }
 };
 } // namespace
-static const size_t kStageBytes = (size_t)8 << 20;
+static const size_t kStageBytes = (size_t)8 << 20, kStageLimit = (size_t)4 << 20;
 static int stage_buffer(void **out) {
     static thread_local PinnedStage stage;
     if (!stage.p) {
@@ -100,7 +100,9 @@ static int stage_buffer(void **out) {
 }
 int upload_pageable_rows(void *dst_dev, const void *src_host, size_t spitch, size_t width, size_t rows, hipStream_t s) {
     if (width == 0 || rows == 0) return ZG_OK;
-    if (getenv("ZG_NO_PINNED_UPLOAD")) { // diagnostic switch: the runtime's own pageable path
+    // large transfers keep the runtime's own pipelined pageable path (tens of GB/s); the staging buffer is for the small ones,
+    // where the copy is a CPU write into device memory rather than a DMA (ZG_NO_PINNED_UPLOAD: diagnostic switch, never stage)
+    if (width * rows > kStageLimit || getenv("ZG_NO_PINNED_UPLOAD")) {
         ZG_HIP(hipMemcpy2DAsync(dst_dev, width, src_host, spitch, width, rows, hipMemcpyHostToDevice, s));
         ZG_HIP(hipStreamSynchronize(s));
         return ZG_OK;
@@ -129,6 +131,11 @@ int upload_pageable_rows(void *dst_dev, const void *src_host, size_t spitch, siz
     return ZG_OK;
 }
 int upload_pageable(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s) {
+    if (bytes > kStageLimit) {
+        ZG_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s));
+        ZG_HIP(hipStreamSynchronize(s));
+        return ZG_OK;
+    }
     const size_t row = (size_t)1 << 20; // as rows of 1 MiB plus a tail
     int rc = upload_pageable_rows(dst_dev, src_host, row, row, bytes / row, s);
     if (rc == ZG_OK && bytes % row) rc = upload_pageable_rows((char *)dst_dev + bytes / row * row, (const char *)src_host + bytes / row * row, bytes % row, bytes % row, 1, s);
@@ -136,7 +143,7 @@ int upload_pageable(void *dst_dev, const void *src_host, size_t bytes, hipStream
 }
 int download_pageable_rows(void *dst_host, size_t dpitch, const void *src_dev, size_t width, size_t rows, hipStream_t s) {
     if (width == 0 || rows == 0) return ZG_OK;
-    if (getenv("ZG_NO_PINNED_UPLOAD")) {
+    if (width * rows > kStageLimit || getenv("ZG_NO_PINNED_UPLOAD")) {
         ZG_HIP(hipMemcpy2DAsync(dst_host, dpitch, src_dev, width, width, rows, hipMemcpyDeviceToHost, s));
         ZG_HIP(hipStreamSynchronize(s));
         return ZG_OK;
@@ -165,6 +172,11 @@ int download_pageable_rows(void *dst_host, size_t dpitch, const void *src_dev, s
     return ZG_OK;
 }
 int download_pageable(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s) {
+    if (bytes > kStageLimit) {
+        ZG_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
+        ZG_HIP(hipStreamSynchronize(s));
+        return ZG_OK;
+    }
     const size_t row = (size_t)1 << 20;
     int rc = download_pageable_rows(dst_host, row, src_dev, row, bytes / row, s);
     if (rc == ZG_OK && bytes % row) rc = download_pageable_rows((char *)dst_host + bytes / row * row, bytes % row, (const char *)src_dev + bytes / row * row, bytes % row, 1, s);
