@@ -282,7 +282,6 @@ int zg_integral_host(const zg_image *src, float *planes) {
     ZG_REQUIRE(planes != nullptr, ZG_ERR_INVALID_ARGUMENT, "integral: null output");
     float *dev = nullptr;
     ZG_HIP(hipMalloc((void **)&dev, bytes));
-    ZG_HIP(hipMemset(dev, 0, bytes)); // see HostStage::upload: a fresh block is touched through the runtime before kernels write it
     rc = sat_planes_impl(&a.dev, dev, nullptr, false);
     if (rc == ZG_OK) rc = download_pageable(planes, dev, bytes, nullptr);
     (void)hipFree(dev);

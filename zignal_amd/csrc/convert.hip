@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void k_convert(DImg src, DImg dst, ConvertArgs
 static int device_srgb_lut(const float *host_lut, hipStream_t s, const float **out, float **owned) {
     *owned = nullptr;
     if (host_lut) {
-        ZG_HIP(hipMallocAsync((void **)owned, 256 * sizeof(float), s));
+        if (int rc = scratch_alloc((void **)owned, 256 * sizeof(float), s)) return rc;
         if (int rc = upload_pageable(*owned, host_lut, 256 * sizeof(float), s)) return rc;
         *out = *owned;
         return ZG_OK;
@@ -196,7 +196,7 @@ static int convert_impl(const zg_image *src, int src_space, const zg_image *dst,
         float *lut_owned = nullptr;
         if (!sf && (rc = device_srgb_lut(srgb_lut, s, &lut_dev, &lut_owned))) return rc;
         rc = convert_spaces_impl(src, src_space, dst, dst_space, lut_dev, s);
-        if (lut_owned) (void)hipFreeAsync(lut_owned, s);
+        if (lut_owned) scratch_free(lut_owned, s);
         return rc;
     }
     if (dst_space == ZG_CS_XYZ || dst_space == ZG_CS_OKLAB) ZG_REQUIRE(df, ZG_ERR_UNSUPPORTED, "convert: Xyz / Oklab need a float destination");
@@ -218,7 +218,7 @@ static int convert_impl(const zg_image *src, int src_space, const zg_image *dst,
             return ZG_OK;
         });
     });
-    if (owned) (void)hipFreeAsync(owned, s);
+    if (owned) scratch_free(owned, s);
     return rc;
 }
 

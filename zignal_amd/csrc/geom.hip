@@ -120,7 +120,7 @@ struct LutHolder {
 static int device_lanczos_lut(const zg_method *method, hipStream_t s, LutHolder &h) {
     if (method->kind != ZG_INTERP_LANCZOS) return ZG_OK;
     if (method->lanczos_lut) {
-        ZG_HIP(hipMallocAsync((void **)&h.owned, 1025 * sizeof(float), s));
+        if (int rc = scratch_alloc((void **)&h.owned, 1025 * sizeof(float), s)) return rc;
         if (int rc = upload_pageable(h.owned, method->lanczos_lut, 1025 * sizeof(float), s)) return rc; // the caller's table may be pageable / short-lived
         h.dev = h.owned;
         return ZG_OK;
@@ -140,7 +140,7 @@ static int device_lanczos_lut(const zg_method *method, hipStream_t s, LutHolder 
     return ZG_OK;
 }
 static void release_lut(LutHolder &h, hipStream_t s) {
-    if (h.owned) (void)hipFreeAsync(h.owned, s);
+    if (h.owned) scratch_free(h.owned, s);
     h.owned = nullptr;
 }
 

@@ -455,7 +455,7 @@ int decode_impl(const uint8_t *png, size_t len, const zg_png_limits *limits, con
     const size_t native_bytes = direct ? 0 : (size_t)f.header.width * f.header.height * pixel_size(native);
     uint8_t *dev = nullptr;
     if ((rc = scratch_alloc((void **)&dev, L.total + 64 + native_bytes, s))) return rc;
-    // the scan data is pageable host memory that dies with this call: a staged, synchronised copy into stream-ordered scratch
+    // the scan data is pageable host memory that dies with this call: a synchronised copy into scratch
     if ((rc = upload_pageable(dev, scan.data(), L.total, s))) { scratch_free(dev, s); return rc; }
 
     UnpackArgs a{};

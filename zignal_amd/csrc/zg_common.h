@@ -173,8 +173,7 @@ struct HostStage {
 
 int check_image(const zg_image *im, const char *name, bool device_pointer = true);
 
-// Host -> device copy of pageable memory that kernels may consume straight away: staged through a thread-local pinned buffer
-// in chunks and synchronised before returning (zg_runtime.cpp explains why the runtime's own pageable path is not used).
+// Pageable host memory -> device memory on stream s, synchronised before returning (zg_runtime.cpp).
 int upload_pageable(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s);
 // rows of `width` bytes, `spitch` apart on the host, packed back to back on the device
 int upload_pageable_rows(void *dst_dev, const void *src_host, size_t spitch, size_t width, size_t rows, hipStream_t s);
@@ -182,7 +181,7 @@ int upload_pageable_rows(void *dst_dev, const void *src_host, size_t spitch, siz
 int download_pageable(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s);
 int download_pageable_rows(void *dst_host, size_t dpitch, const void *src_dev, size_t width, size_t rows, hipStream_t s);
 
-// stream-ordered scratch from the device's default pool (zg_runtime.cpp)
+// scratch blocks from the library's caching allocator, ordered on stream s (zg_runtime.cpp)
 int scratch_alloc(void **out, size_t bytes, hipStream_t s);
 void scratch_free(void *p, hipStream_t s);
 

@@ -1,6 +1,10 @@
 // zg_runtime.cpp — runtime half of the C ABI: device selection, memory, streams, error text and
 // the host-pointer staging used by every zg_<op>_host entry point.
 #include "zg_common.h"
+#include <utility>
+#include <vector>
+#include <unordered_map>
+#include <mutex>
 #include <string.h>
 #include <stdlib.h>
 
@@ -40,151 +44,132 @@ int check_image(const zg_image *im, const char *name, bool device_pointer) {
     return ZG_OK;
 }
 
-// Scratch for the multi-kernel ops (two-pass separable temp, integral image, batch intermediates): stream-ordered from
-// the device's default pool. The pool's release threshold is raised once so that a freed scratch block stays mapped for
-// the next call instead of going back to the driver at every synchronisation point (a 256 MB remap costs milliseconds).
+// Scratch for the multi-kernel ops (two-pass separable temp, integral images, detector planes, codec staging): a small
+// caching allocator over hipMalloc. A block goes back to the cache at scratch_free together with an event recorded on the
+// stream that used it; the next scratch_alloc of a fitting size takes it, and waits for that event only when it runs on a
+// different stream (on the same stream, stream order already separates the two uses). Nothing is returned to the driver
+// while the library lives (a 256 MB remap costs milliseconds), beyond a cap of 64 cached blocks.
+// Why not hipMallocAsync / the device's default memory pool, which is this exact service: with the image's ROCm 7.2.0
+// runtime (a bare process; PyTorch processes load their own bundled runtime first) blocks from that pool lost data — the
+// first PNG / JPEG decode of a process read back zeros, 20 runs in 20 on an affected host, 0 in 20 with plain allocations,
+// 0 in 20 with the pool under PyTorch's bundled runtime. The pool is still used while a stream is being captured into a
+// graph, because there the allocation has to belong to the graph.
+namespace {
+struct CachedBlock {
+    void *p;
+    size_t bytes;
+    int device;
+    hipStream_t last;
+    hipEvent_t done;
+};
+std::mutex g_scratch_mu;
+std::vector<CachedBlock> g_scratch_free;                       // oldest first
+std::unordered_map<void *, std::pair<size_t, int>> g_scratch_live; // ptr -> (bytes, device)
+bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
+} // namespace
+
 int scratch_alloc(void **out, size_t bytes, hipStream_t s) {
-    static thread_local int tuned_device = -1;
+    *out = nullptr;
+    if (stream_is_capturing(s)) {
+        ZG_HIP(hipMallocAsync(out, bytes ? bytes : 1, s));
+        return ZG_OK;
+    }
     int dev = 0;
     ZG_HIP(hipGetDevice(&dev));
-    if (tuned_device != dev) {
-        hipMemPool_t pool;
-        ZG_HIP(hipDeviceGetDefaultMemPool(&pool, dev));
-        uint64_t keep = ~(uint64_t)0;
-        ZG_HIP(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
-        tuned_device = dev;
-        // Settle the pool's first pages before anything depends on them. On some hosts a block taken from a pool that has
-        // just grown was seen to lose what the first microseconds of work stored in it (the first zg_png_decode_host /
-        // zg_jpeg_decode_host of a fresh process read back zeros, only ever the first, only in processes that reach their
-        // first scratch use within a millisecond of creating the HIP context): the driver's clear of newly mapped memory is
-        // not ordered against user-queue work. One memset of a block that is then handed back to the pool (the release
-        // threshold above keeps it mapped) costs ~1 ms once per thread and device.
-        if (!getenv("ZG_NO_POOL_WARMUP")) {
-            void *warm = nullptr;
-            const size_t warm_bytes = (size_t)64 << 20;
-            if (hipMallocAsync(&warm, warm_bytes, s) == hipSuccess) {
-                (void)hipMemsetAsync(warm, 0, warm_bytes, s);
-                (void)hipFreeAsync(warm, s);
-                (void)hipStreamSynchronize(s);
-            } else {
-                (void)hipGetLastError();
-            }
+    const size_t unit = (size_t)1 << 20, need = (bytes + unit - 1) / unit * unit + (bytes == 0 ? unit : 0);
+    CachedBlock take{};
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        size_t best = g_scratch_free.size();
+        for (size_t i = 0; i < g_scratch_free.size(); ++i) { // best fit, never more than twice what is asked for
+            const CachedBlock &b = g_scratch_free[i];
+            if (b.device == dev && b.bytes >= need && b.bytes <= 2 * need && (best == g_scratch_free.size() || b.bytes < g_scratch_free[best].bytes)) best = i;
+        }
+        if (best != g_scratch_free.size()) {
+            take = g_scratch_free[best];
+            g_scratch_free.erase(g_scratch_free.begin() + (long)best);
         }
     }
-    *out = nullptr;
-    ZG_HIP(hipMallocAsync(out, bytes, s));
+    if (take.p) {
+        if (take.last != s) ZG_HIP(hipStreamWaitEvent(s, take.done, 0));
+        (void)hipEventDestroy(take.done);
+    } else {
+        ZG_HIP(hipMalloc(&take.p, need));
+        take.bytes = need;
+        take.device = dev;
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        g_scratch_live[take.p] = {take.bytes, take.device};
+    }
+    *out = take.p;
     return ZG_OK;
-}
-
-// Small hipMemcpy / hipMemcpyAsync calls from PAGEABLE host memory were seen, on some hosts, to be invisible to a kernel
-// launched right after the copy had been synchronised: the kernel read zeros where the 52 bytes of a PNG's scan data or the
-// 256 bytes of a JPEG block had just been "copied" (zg_png_decode_host / zg_jpeg_decode_host in a bare C++ process, up to
-// 29 runs in 30 on an affected host, never on others). Copies whose source is pinned memory are DMA reads issued by the GPU
-// and ordered in the stream like any other command, so uploads that feed kernels go through a pinned staging buffer.
-namespace {
-struct PinnedStage {
-    void *p = nullptr;
-    size_t bytes = 0;
-    ~PinnedStage() { if (p) (void)hipHostFree(p); }
-};
-} // namespace
-static const size_t kStageBytes = (size_t)8 << 20, kStageLimit = (size_t)4 << 20;
-static int stage_buffer(void **out) {
-    static thread_local PinnedStage stage;
-    if (!stage.p) {
-        ZG_HIP(hipHostMalloc(&stage.p, kStageBytes, hipHostMallocDefault));
-        stage.bytes = kStageBytes;
-    }
-    *out = stage.p;
-    return ZG_OK;
-}
-int upload_pageable_rows(void *dst_dev, const void *src_host, size_t spitch, size_t width, size_t rows, hipStream_t s) {
-    if (width == 0 || rows == 0) return ZG_OK;
-    // large transfers keep the runtime's own pipelined pageable path (tens of GB/s); the staging buffer is for the small ones,
-    // where the copy is a CPU write into device memory rather than a DMA (ZG_NO_PINNED_UPLOAD: diagnostic switch, never stage)
-    if (width * rows > kStageLimit || getenv("ZG_NO_PINNED_UPLOAD")) {
-        ZG_HIP(hipMemcpy2DAsync(dst_dev, width, src_host, spitch, width, rows, hipMemcpyHostToDevice, s));
-        ZG_HIP(hipStreamSynchronize(s));
-        return ZG_OK;
-    }
-    void *stage = nullptr;
-    int rc;
-    if ((rc = stage_buffer(&stage))) return rc;
-    if (width > kStageBytes) { // absurdly wide rows: piecewise
-        for (size_t r = 0; r < rows; ++r)
-            for (size_t at = 0; at < width; at += kStageBytes) {
-                const size_t n = width - at < kStageBytes ? width - at : kStageBytes;
-                memcpy(stage, (const char *)src_host + r * spitch + at, n);
-                ZG_HIP(hipMemcpyAsync((char *)dst_dev + r * width + at, stage, n, hipMemcpyHostToDevice, s));
-                ZG_HIP(hipStreamSynchronize(s));
-            }
-        return ZG_OK;
-    }
-    const size_t per = kStageBytes / width;
-    for (size_t r0 = 0; r0 < rows; r0 += per) {
-        const size_t n = rows - r0 < per ? rows - r0 : per;
-        if (spitch == width) memcpy(stage, (const char *)src_host + r0 * spitch, n * width);
-        else for (size_t r = 0; r < n; ++r) memcpy((char *)stage + r * width, (const char *)src_host + (r0 + r) * spitch, width);
-        ZG_HIP(hipMemcpyAsync((char *)dst_dev + r0 * width, stage, n * width, hipMemcpyHostToDevice, s));
-        ZG_HIP(hipStreamSynchronize(s)); // the staging buffer is reused by the next chunk / call
-    }
-    return ZG_OK;
-}
-int upload_pageable(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s) {
-    if (bytes > kStageLimit) {
-        ZG_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s));
-        ZG_HIP(hipStreamSynchronize(s));
-        return ZG_OK;
-    }
-    const size_t row = (size_t)1 << 20; // as rows of 1 MiB plus a tail
-    int rc = upload_pageable_rows(dst_dev, src_host, row, row, bytes / row, s);
-    if (rc == ZG_OK && bytes % row) rc = upload_pageable_rows((char *)dst_dev + bytes / row * row, (const char *)src_host + bytes / row * row, bytes % row, bytes % row, 1, s);
-    return rc;
-}
-int download_pageable_rows(void *dst_host, size_t dpitch, const void *src_dev, size_t width, size_t rows, hipStream_t s) {
-    if (width == 0 || rows == 0) return ZG_OK;
-    if (width * rows > kStageLimit || getenv("ZG_NO_PINNED_UPLOAD")) {
-        ZG_HIP(hipMemcpy2DAsync(dst_host, dpitch, src_dev, width, width, rows, hipMemcpyDeviceToHost, s));
-        ZG_HIP(hipStreamSynchronize(s));
-        return ZG_OK;
-    }
-    void *stage = nullptr;
-    int rc;
-    if ((rc = stage_buffer(&stage))) return rc;
-    if (width > kStageBytes) {
-        for (size_t r = 0; r < rows; ++r)
-            for (size_t at = 0; at < width; at += kStageBytes) {
-                const size_t n = width - at < kStageBytes ? width - at : kStageBytes;
-                ZG_HIP(hipMemcpyAsync(stage, (const char *)src_dev + r * width + at, n, hipMemcpyDeviceToHost, s));
-                ZG_HIP(hipStreamSynchronize(s));
-                memcpy((char *)dst_host + r * dpitch + at, stage, n);
-            }
-        return ZG_OK;
-    }
-    const size_t per = kStageBytes / width;
-    for (size_t r0 = 0; r0 < rows; r0 += per) {
-        const size_t n = rows - r0 < per ? rows - r0 : per;
-        ZG_HIP(hipMemcpyAsync(stage, (const char *)src_dev + r0 * width, n * width, hipMemcpyDeviceToHost, s));
-        ZG_HIP(hipStreamSynchronize(s));
-        if (dpitch == width) memcpy((char *)dst_host + r0 * dpitch, stage, n * width);
-        else for (size_t r = 0; r < n; ++r) memcpy((char *)dst_host + (r0 + r) * dpitch, (const char *)stage + r * width, width);
-    }
-    return ZG_OK;
-}
-int download_pageable(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s) {
-    if (bytes > kStageLimit) {
-        ZG_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
-        ZG_HIP(hipStreamSynchronize(s));
-        return ZG_OK;
-    }
-    const size_t row = (size_t)1 << 20;
-    int rc = download_pageable_rows(dst_host, row, src_dev, row, bytes / row, s);
-    if (rc == ZG_OK && bytes % row) rc = download_pageable_rows((char *)dst_host + bytes / row * row, bytes % row, (const char *)src_dev + bytes / row * row, bytes % row, 1, s);
-    return rc;
 }
 
 void scratch_free(void *p, hipStream_t s) {
-    if (p) (void)hipFreeAsync(p, s);
+    if (!p) return;
+    CachedBlock b{p, 0, 0, s, nullptr};
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        auto it = g_scratch_live.find(p);
+        if (it == g_scratch_live.end()) { // a graph-owned (captured) allocation
+            (void)hipFreeAsync(p, s);
+            return;
+        }
+        b.bytes = it->second.first;
+        b.device = it->second.second;
+        g_scratch_live.erase(it);
+    }
+    if (hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess || hipEventRecord(b.done, s) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(p);
+        return;
+    }
+    CachedBlock evict{};
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        g_scratch_free.push_back(b);
+        if (g_scratch_free.size() > 64) {
+            evict = g_scratch_free.front();
+            g_scratch_free.erase(g_scratch_free.begin());
+        }
+    }
+    if (evict.p) {
+        (void)hipEventSynchronize(evict.done);
+        (void)hipEventDestroy(evict.done);
+        (void)hipFree(evict.p);
+    }
+}
+
+// Pageable host memory <-> device memory, synchronised before returning (the callers' host buffers are short-lived).
+int upload_pageable_rows(void *dst_dev, const void *src_host, size_t spitch, size_t width, size_t rows, hipStream_t s) {
+    if (width == 0 || rows == 0) return ZG_OK;
+    ZG_HIP(hipMemcpy2DAsync(dst_dev, width, src_host, spitch, width, rows, hipMemcpyHostToDevice, s));
+    ZG_HIP(hipStreamSynchronize(s));
+    return ZG_OK;
+}
+int upload_pageable(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return ZG_OK;
+    ZG_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s));
+    ZG_HIP(hipStreamSynchronize(s));
+    return ZG_OK;
+}
+int download_pageable_rows(void *dst_host, size_t dpitch, const void *src_dev, size_t width, size_t rows, hipStream_t s) {
+    if (width == 0 || rows == 0) return ZG_OK;
+    ZG_HIP(hipMemcpy2DAsync(dst_host, dpitch, src_dev, width, width, rows, hipMemcpyDeviceToHost, s));
+    ZG_HIP(hipStreamSynchronize(s));
+    return ZG_OK;
+}
+int download_pageable(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return ZG_OK;
+    ZG_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
+    ZG_HIP(hipStreamSynchronize(s));
+    return ZG_OK;
 }
 
 HostStage::~HostStage() {
@@ -205,11 +190,6 @@ int HostStage::upload(const zg_image *h, bool copy_in, bool write_back) {
     ZG_HIP(hipMalloc(&dev.data, bytes));
     if (copy_in) {
         if ((rc = upload_pageable_rows(dev.data, h->data, h->stride * ps, (size_t)h->cols * ps, h->rows, nullptr))) return rc;
-    } else {
-        // A destination-only twin is still touched once through the runtime before any kernel writes it: on a fresh
-        // hipMalloc block a small kernel's stores were observed to be overwritten by the allocation's own (deferred) clear
-        // — the first zg_png_decode_host of a process came back all zero in ~1 of 4 runs — and never after a memset.
-        ZG_HIP(hipMemset(dev.data, 0, bytes));
     }
     return ZG_OK;
 }
