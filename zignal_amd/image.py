@@ -93,6 +93,8 @@ class Image:
             itemsize = data.element_size()
             strides = tuple(s * itemsize for s in data.stride())
         else:
+            if data is None:
+                raise TypeError("expected an array, got None")  # numpy_interop.zig: TypeError for None / a wrong dtype
             data = np.asarray(data)
             dtype = data.dtype.name
             itemsize = data.itemsize
@@ -102,7 +104,9 @@ class Image:
         ch = 1 if data.ndim == 2 else int(data.shape[2])
         key = (dtype, ch)
         if key not in _PIXEL_BY_LAYOUT:
-            raise TypeError(f"unsupported pixel layout {dtype} x {ch}")
+            if dtype not in ("uint8", "float32"):
+                raise TypeError(f"unsupported dtype {dtype} (uint8 or float32)")
+            raise ValueError(f"unsupported channel count {ch} (1, 3 or 4)")  # a wrong shape is a ValueError, as in the reference
         self.data = data
         self.pixel = _PIXEL_BY_LAYOUT[key]
         self.rows, self.cols = int(data.shape[0]), int(data.shape[1])
@@ -164,6 +168,10 @@ class Image:
 
     @staticmethod
     def from_numpy(a) -> "Image":
+        """Image.from_numpy (bindings/python/src/image/numpy_interop.zig:114-210): zero-copy; rows may be strided, pixels of a
+        row must be contiguous; TypeError for None / a wrong dtype, ValueError for a wrong shape or incompatible strides."""
+        if a is None:
+            raise TypeError("expected an array, got None")
         return Image(np.asarray(a))
 
     def to_device(self, device="cuda") -> "Image":
