@@ -857,6 +857,33 @@ done:
 }
 ZO_API void zo_jpeg_free(void *p) { free(p); }
 
+/* decode (+ performBlockScan for a baseline file): FNV-1a over the coefficient blocks, component by component, block by block
+ * — the state toNativeImage starts from. Lets the entropy decoders be compared without rendering anything. */
+ZO_API int zo_jpeg_coefficient_hash(const uint8_t *data, size_t len, const zo_jpeg_limits *lim_in, uint64_t *hash_out) {
+    zo_jpeg_limits lim;
+    if (lim_in) lim = *lim_in; else zo_jpeg_default_limits(&lim);
+    jstate *s = calloc(1, sizeof *s);
+    if (!s) return J_OutOfMemory;
+    s->header.precision = 8;
+    int rc = decode_stream(s, data, len, &lim);
+    if (!rc && !s->header.progressive) rc = baseline_scan(s);
+    if (!rc && !s->blocks) rc = J_BlockStorageNotAllocated;
+    if (!rc) {
+        uint64_t h = 1469598103934665603ull;
+        for (int c = 0; c < s->header.num_components; ++c)
+            for (size_t b = 0; b < s->nblocks; ++b)
+                for (int i = 0; i < 64; ++i) {
+                    uint32_t v = (uint32_t)s->blocks[b][c][i];
+                    for (int k = 0; k < 4; ++k) { h ^= (v >> (8 * k)) & 0xff; h *= 1099511628211ull; }
+                }
+        *hash_out = h;
+    }
+    free(s->blocks);
+    free(s->rgb);
+    free(s);
+    return rc;
+}
+
 /* ==== encoder (jpeg.zig:293-1043): baseline SOF0, the reference's own tables, LLM forward DCT, reciprocal quantisation ============
  * The output is a deterministic function of the pixels and options (fixed Huffman tables), so files are compared byte for byte. */
 static const uint8_t Q_LUMA[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,

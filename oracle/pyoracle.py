@@ -662,6 +662,15 @@ def jpeg_decode_native(data: bytes, limits: ZoJpegLimits | None = None):
     return arr.reshape((h.height, h.width) if ch == 1 else (h.height, h.width, 3)), h, bool(lim_hit.value)
 
 
+def jpeg_coefficient_hash(data: bytes, limits: ZoJpegLimits | None = None) -> int:
+    """FNV-1a of the entropy-decoded coefficient blocks (decode + performBlockScan), before dequantisation."""
+    h = C.c_uint64(0)
+    fn = lib().zo_jpeg_coefficient_hash
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    _jpeg_check(fn(_png_buf(data), len(data), C.byref(limits) if limits else None, C.byref(h)))
+    return h.value
+
+
 def jpeg_load(data: bytes, kind: str, limits: ZoJpegLimits | None = None) -> np.ndarray:
     """jpeg.loadFromBytes(T) (jpeg.zig:2825-2851)."""
     native, _, _ = jpeg_decode_native(data, limits)

@@ -124,6 +124,46 @@ def test_host_decoder_under_random_corruption(oracle):
     assert n_err > 100 and n_ok > 100
 
 
+def test_entropy_decoders_match_oracle_on_the_cpu(oracle):
+    """zg_jpeg_coefficient_hash: decode + performBlockScan on the host, hashed. Baseline and progressive files from libjpeg, our
+    own coefficient-level files (4:1:1, odd ids, restart intervals, 16-bit DQT, large values), cuts and flipped bytes: the same
+    hash or the same error name as the oracle — the whole entropy layer compared without a GPU."""
+    rng = np.random.default_rng(77)
+    files = []
+    for (h, w) in ((8, 8), (33, 47), (100, 37), (130, 258)):
+        for smooth in (True, False):
+            img = J.test_image(h, w, seed=h, smooth=smooth)
+            for kw in (dict(subsampling=0), dict(subsampling=1), dict(subsampling=2), dict(subsampling=2, progressive=True), dict(subsampling=0, progressive=True, quality=40),
+                       dict(subsampling=2, optimize=True, quality=97), dict(subsampling=1, restart_marker_blocks=2), dict(subsampling=2, progressive=True, restart_marker_rows=1)):
+                files.append(J.pil_jpeg(img, **{"quality": 88, **kw}))
+            files.append(J.pil_jpeg(img[..., 0], quality=75))
+    for (lh, lv) in ((1, 1), (2, 1), (2, 2), (4, 1)):
+        for ids in ((1, 2, 3), (0, 1, 2), (9, 1, 7)):
+            comps = J.layout(lh, lv, ids)
+            for ri in (0, 1, 3):
+                files.append(J.write_baseline(50, 35, comps, J.FLAT_Q, J.random_coefficients(rng, comps, 50, 35), restart_interval=ri, dqt16=(ri == 3)))
+    big = J.random_coefficients(rng, J.YCC, 48, 32, density=0.7, dc_range=1023, ac_range=1023)
+    files.append(J.write_baseline(48, 32, J.YCC, {0: [255] * 64, 1: [65535] * 64}, big, dqt16=True))
+    seen = set()
+    n = 0
+    for data in files:
+        variants = [data]
+        sos = data.index(b"\xFF\xDA")
+        for _ in range(6):
+            if rng.random() < 0.5:
+                variants.append(data[:int(rng.integers(sos, len(data)))])
+            else:
+                bad = bytearray(data)
+                bad[int(rng.integers(sos + 10, len(data) - 1))] = int(rng.integers(0, 256))
+                variants.append(bytes(bad))
+        for v in variants:
+            want, got = outcome(oracle.jpeg_coefficient_hash, v), outcome(zg.jpeg.coefficient_hash, v)
+            assert want == got, (len(v), want, got)
+            seen.add(want[1] if want[0] == "err" else "ok")
+            n += 1
+    assert n > 700 and "ok" in seen and len(seen) >= 3, seen
+
+
 # ---- GPU ---------------------------------------------------------------------------------------------------------------------
 
 def decode_both(oracle, data, kind=None, limits=None):

@@ -191,6 +191,7 @@ _SIGNATURES = {
     "zg_jpeg_default_limits": [C.POINTER(ZgJpegLimits)],
     "zg_jpeg_info": [C.c_void_p, C.c_size_t, C.POINTER(ZgJpegLimits), C.POINTER(ZgJpegHeader)],
     "zg_jpeg_probe": [C.c_void_p, C.c_size_t, C.POINTER(ZgJpegLimits), C.POINTER(ZgJpegHeader), C.POINTER(C.c_int)],
+    "zg_jpeg_coefficient_hash": [C.c_void_p, C.c_size_t, C.POINTER(ZgJpegLimits), C.POINTER(C.c_uint64)],
     "zg_jpeg_decode": [C.c_void_p, C.c_size_t, C.POINTER(ZgJpegLimits), _IMG, C.c_int, C.POINTER(C.c_int), C.c_void_p],
     "zg_jpeg_decode_host": [C.c_void_p, C.c_size_t, C.POINTER(ZgJpegLimits), _IMG, C.c_int, C.POINTER(C.c_int)],
     "zg_jpeg_default_encode_options": [C.POINTER(ZgJpegEncodeOptions)],

@@ -1216,6 +1216,28 @@ int zg_jpeg_probe(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits,
     if (scan_limit_reached_out) *scan_limit_reached_out = holder[0].scan_limit_reached ? 1 : 0;
     return ZG_OK;
 }
+int zg_jpeg_coefficient_hash(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, uint64_t *hash_out) {
+    ZG_REQUIRE(jpeg && hash_out, ZG_ERR_INVALID_ARGUMENT, "jpeg coefficient hash: null argument");
+    zg_jpeg_limits lim;
+    if (limits) lim = *limits; else zg_jpeg_default_limits(&lim);
+    std::vector<Decoder> holder(1);
+    Decoder &d = holder[0];
+    d.header.precision = 8;
+    int rc = d.read_stream(jpeg, len, lim);
+    if (rc == ZG_OK && !d.header.progressive) rc = d.run_baseline_scan();
+    if (rc) return rc;
+    if (!d.allocated) JPEG_FAIL("BlockStorageNotAllocated");
+    uint64_t h = 1469598103934665603ull; // FNV-1a, little-endian bytes of every coefficient, component by component
+    for (int c = 0; c < d.header.num_components; ++c) {
+        const int32_t *p = d.coef[c].data();
+        for (size_t i = 0; i < d.nblocks * 64; ++i) {
+            const uint32_t v = (uint32_t)p[i];
+            for (int k = 0; k < 4; ++k) { h ^= (v >> (8 * k)) & 0xff; h *= 1099511628211ull; }
+        }
+    }
+    *hash_out = h;
+    return ZG_OK;
+}
 int zg_jpeg_decode(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, const zg_image *dst, int dst_space, int *scan_limit_reached_out, zg_stream stream) {
     return decode_impl(jpeg, len, limits, dst, dst_space, scan_limit_reached_out, as_stream(stream));
 }

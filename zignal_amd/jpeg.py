@@ -52,6 +52,14 @@ def decode(data: bytes, limits: Optional[L.ZgJpegLimits] = None):
     return h, bool(hit.value)
 
 
+def coefficient_hash(data: bytes, limits: Optional[L.ZgJpegLimits] = None) -> int:
+    """FNV-1a of the entropy-decoded coefficients (jpeg.decode + performBlockScan): the host half of a decode, no device."""
+    buf, n = _buf(data)
+    h = C.c_uint64(0)
+    L.check(L.lib().zg_jpeg_coefficient_hash(buf, n, C.byref(limits) if limits is not None else None, C.byref(h)))
+    return h.value
+
+
 def load_from_bytes(data: bytes, kind: Optional[str] = None, limits: Optional[L.ZgJpegLimits] = None, device: Optional[str] = "cuda",
                     return_scan_limit_reached: bool = False):
     """jpeg.loadFromBytes(T) (jpeg.zig:2825-2851). kind = "u8" | "rgb_u8" | "rgba_u8" names T; None keeps the file's native
