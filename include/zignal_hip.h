@@ -433,7 +433,7 @@ ZG_API int zg_jpeg_info(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *l
  * header and JpegState.scan_limit_reached. */
 ZG_API int zg_jpeg_probe(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, zg_jpeg_header *header_out, int *scan_limit_reached_out);
 /* The host half of a decode on its own: jpeg.decode, plus performBlockScan (jpeg.zig:2397-2479) for a baseline file, then
- * FNV-1a over the coefficient blocks (i32, little-endian, component by component) — the state jpeg.toNativeImage starts
+ * FNV-1a over the coefficient blocks (one i32 per step, component by component) — the state jpeg.toNativeImage starts
  * from. No device is touched: this is how the entropy decoders are compared with the reference's without a GPU. */
 ZG_API int zg_jpeg_coefficient_hash(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, uint64_t *hash_out);
 /* jpeg.loadFromBytes(T) (jpeg.zig:2825-2851): dst is rows x cols == height x width of the frame header

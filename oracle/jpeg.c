@@ -857,7 +857,7 @@ done:
 }
 ZO_API void zo_jpeg_free(void *p) { free(p); }
 
-/* decode (+ performBlockScan for a baseline file): FNV-1a over the coefficient blocks, component by component, block by block
+/* decode (+ performBlockScan for a baseline file): FNV-1a (one 32-bit coefficient per step) over the coefficient blocks, component by component, block by block
  * — the state toNativeImage starts from. Lets the entropy decoders be compared without rendering anything. */
 ZO_API int zo_jpeg_coefficient_hash(const uint8_t *data, size_t len, const zo_jpeg_limits *lim_in, uint64_t *hash_out) {
     zo_jpeg_limits lim;
@@ -873,8 +873,8 @@ ZO_API int zo_jpeg_coefficient_hash(const uint8_t *data, size_t len, const zo_jp
         for (int c = 0; c < s->header.num_components; ++c)
             for (size_t b = 0; b < s->nblocks; ++b)
                 for (int i = 0; i < 64; ++i) {
-                    uint32_t v = (uint32_t)s->blocks[b][c][i];
-                    for (int k = 0; k < 4; ++k) { h ^= (v >> (8 * k)) & 0xff; h *= 1099511628211ull; }
+                    h ^= (uint32_t)s->blocks[b][c][i];
+                    h *= 1099511628211ull;
                 }
         *hash_out = h;
     }

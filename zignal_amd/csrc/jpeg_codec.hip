@@ -1227,12 +1227,12 @@ int zg_jpeg_coefficient_hash(const uint8_t *jpeg, size_t len, const zg_jpeg_limi
     if (rc == ZG_OK && !d.header.progressive) rc = d.run_baseline_scan();
     if (rc) return rc;
     if (!d.allocated) JPEG_FAIL("BlockStorageNotAllocated");
-    uint64_t h = 1469598103934665603ull; // FNV-1a, little-endian bytes of every coefficient, component by component
+    uint64_t h = 1469598103934665603ull; // FNV-1a, one 32-bit coefficient per step, component by component
     for (int c = 0; c < d.header.num_components; ++c) {
         const int32_t *p = d.coef[c].data();
         for (size_t i = 0; i < d.nblocks * 64; ++i) {
-            const uint32_t v = (uint32_t)p[i];
-            for (int k = 0; k < 4; ++k) { h ^= (v >> (8 * k)) & 0xff; h *= 1099511628211ull; }
+            h ^= (uint32_t)p[i];
+            h *= 1099511628211ull;
         }
     }
     *hash_out = h;
