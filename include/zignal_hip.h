@@ -384,6 +384,10 @@ ZG_API int zg_png_info(const uint8_t *png, size_t len, const zg_png_limits *limi
  * is cut short (missing IEND). Nothing is inflated. */
 ZG_API int zg_png_probe(const uint8_t *png, size_t len, const zg_png_limits *limits, zg_png_header *header_out, int *native_pixel_out,
                         int *truncated_out);
+/* The host half of a decode on its own (png.decode + the inflate / recovery / de-filter part of png.toNativeImage, png.zig:
+ * 801-852, :1721-1803, and the palette-index check of :1080 / :1119): FNV-1a over the de-filtered scan data, filter bytes
+ * included. No device is touched: this is how the host layers are compared with the reference's without a GPU. */
+ZG_API int zg_png_scan_hash(const uint8_t *png, size_t len, const zg_png_limits *limits, uint64_t *hash_out, int *truncated_out);
 /* png.loadFromBytes(T) (png.zig:1151-1186): decode into `dst` (rows x cols must equal the header's height x width, else
  * ZG_ERR_DIMENSION_MISMATCH). dst's pixel type and dst_space name T exactly as in zg_convert: when T is not the native
  * type the native image is converted with Image.convert. Cut pixel data decodes partially (whole rows kept, the rest

@@ -705,6 +705,48 @@ done:
 }
 ZO_API void zo_png_free(void *p) { free(p); }
 
+/* The host half of a decode on its own: chunk layer, inflate with the recovery rules, de-filtering, and the palette-index check
+ * of the non-interlaced path; FNV-1a over the de-filtered scan data (filter bytes included). */
+ZO_API int zo_png_scan_hash(const uint8_t *png, size_t len, const zo_png_limits *lim_in, uint64_t *hash_out, int *truncated_out) {
+    zo_png_limits lim;
+    if (lim_in) lim = *lim_in; else zo_png_default_limits(&lim);
+    png_state st;
+    int rc = decode_chunks(png, len, &lim, &st);
+    uint8_t *scan = NULL;
+    if (rc) goto done;
+    const zo_png_header *h = &st.header;
+    const size_t want = st.scan_data_bytes;
+    scan = (uint8_t *)calloc(want + 1, 1);
+    if (!scan) { rc = E_OutOfMemory; goto done; }
+    size_t produced = 0;
+    const int zrc = zlib_inflate(st.idat, st.idat_len, scan, want, &produced);
+    if (zrc == 2) { rc = E_ReadFailed; goto done; }
+    if (produced > want) { rc = E_ImageTooLarge; goto done; }
+    if (produced < want) {
+        st.truncated = 1;
+        memset(scan + complete_scan_prefix(produced, h), 0, want - complete_scan_prefix(produced, h));
+    }
+    if ((rc = defilter_scanlines(scan, h))) goto done;
+    if (h->color_type == 3 && h->interlace_method != 1) {
+        const size_t rb = scanline_bytes(h);
+        for (uint32_t y = 0; y < h->height && !rc; ++y)
+            for (uint32_t x = 0; x < h->width; ++x) {
+                uint8_t px[4];
+                int ok;
+                if (!extract_palette(scan + (size_t)y * (rb + 1) + 1, rb, x, h, &st, px, &ok)) { rc = E_InvalidPaletteIndex; break; }
+            }
+        if (rc) goto done;
+    }
+    uint64_t hash = 1469598103934665603ull;
+    for (size_t i = 0; i < want; ++i) { hash ^= scan[i]; hash *= 1099511628211ull; }
+    *hash_out = hash;
+    if (truncated_out) *truncated_out = st.truncated;
+done:
+    free(st.idat);
+    free(scan);
+    return rc;
+}
+
 /* decode() alone: header + the chunk layer's truncated flag (what png.decode returns before any inflate) */
 ZO_API int zo_png_decode_chunks(const uint8_t *png, size_t len, const zo_png_limits *lim_in, zo_png_header *header_out, int *truncated_out,
                                 int *palette_len, int *trns_len) {

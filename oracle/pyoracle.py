@@ -556,6 +556,15 @@ def png_decode_native(data: bytes, limits: ZoPngLimits | None = None):
     return arr.reshape((h.height, h.width) if ch == 1 else (h.height, h.width, ch)), bool(t.value), h
 
 
+def png_scan_hash(data: bytes, limits: ZoPngLimits | None = None):
+    """(FNV-1a of the inflated, de-filtered scan data, truncated): the host half of a PNG decode."""
+    h, t = C.c_uint64(0), C.c_int(0)
+    fn = lib().zo_png_scan_hash
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    _png_check(fn(_png_buf(data), len(data), C.byref(limits) if limits else None, C.byref(h), C.byref(t)))
+    return h.value, bool(t.value)
+
+
 def png_load(data: bytes, kind: str, limits: ZoPngLimits | None = None) -> np.ndarray:
     """png.loadFromBytes(T): the native image, converted with Image.convert when T differs (png.zig:1151-1186)."""
     native, _, _ = png_decode_native(data, limits)

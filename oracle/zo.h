@@ -140,6 +140,7 @@ ZO_API int zo_png_decode_chunks(const uint8_t *png, size_t len, const zo_png_lim
 ZO_API int zo_png_decode_native(const uint8_t *png, size_t len, const zo_png_limits *limits, zo_png_header *header_out, int *native_out,
                                 uint8_t **pixels_out, int *truncated_out);
 ZO_API void zo_png_free(void *p);
+ZO_API int zo_png_scan_hash(const uint8_t *png, size_t len, const zo_png_limits *limits, uint64_t *hash_out, int *truncated_out);
 ZO_API int zo_png_filter(const uint8_t *raw, uint32_t rows, size_t row_bytes, int bpp, int mode, uint8_t *filtered);
 ZO_API int zo_png_encode_stored(const zo_image *img, int mode, uint8_t **out, size_t *out_len);
 

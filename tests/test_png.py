@@ -163,6 +163,41 @@ def test_chunk_layer_under_random_corruption(oracle):
     assert n_err > 100 and n_ok > 100
 
 
+def test_host_layers_match_oracle_on_the_cpu(oracle):
+    """zg_png_scan_hash: chunk layer + inflate (zlib) with the recovery rules + de-filtering + the palette check, hashed, against
+    the oracle's own inflater and de-filter: every format, Adam7, all five filters, split IDATs, cuts and flipped bytes."""
+    rng = np.random.default_rng(17)
+    n, seen = 0, set()
+    for color_type, bit_depth in FORMATS:
+        for interlace in (0, 1):
+            for (h, w) in ((1, 1), (9, 17), (40, 33)):
+                plen = min(1 << bit_depth, 200) if color_type == P.PALETTE else None
+                palette = rng.integers(0, 256, (plen, 3)).tolist() if plen else None
+                s = P.random_samples(rng, h, w, bit_depth, color_type, plen)
+                data = P.make_png(s, bit_depth, color_type, interlace, filters=lambda y: int(rng.integers(0, 5)), palette=palette,
+                                  idat_split=int(rng.integers(0, 2)) * 101, level=int(rng.integers(0, 10)))
+                variants = [data, data[:-12], data[:-8]]
+                idat = data.index(b"IDAT")
+                for _ in range(4):
+                    if rng.random() < 0.5:
+                        variants.append(data[:int(rng.integers(idat, len(data)))])
+                    else:
+                        bad = bytearray(data)
+                        bad[int(rng.integers(idat + 4, len(data) - 12))] = int(rng.integers(0, 256))
+                        variants.append(bytes(bad))
+                for v in variants:
+                    want, got = outcome(oracle.png_scan_hash, v), outcome(zg.png.scan_hash, v)
+                    assert want == got, (color_type, bit_depth, interlace, h, w, len(v), want, got)
+                    seen.add(want[1] if want[0] == "err" else ("truncated" if want[1][1] else "complete"))
+                    n += 1
+    s = np.array([[[0], [2]]], np.uint32)  # a palette index past PLTE: an error, but not when interlaced
+    for inter in (0, 1):
+        v = P.make_png(s, 8, P.PALETTE, palette=[[1, 2, 3], [4, 5, 6]], interlace=inter)
+        want, got = outcome(oracle.png_scan_hash, v), outcome(zg.png.scan_hash, v)
+        assert want == got and (want == ("err", "InvalidPaletteIndex")) == (inter == 0)
+    assert n > 600 and {"complete", "truncated", "InvalidCrc"} <= seen, seen
+
+
 # ---- GPU ---------------------------------------------------------------------------------------------------------------------
 
 def decode_both(oracle, data, kind=None, limits=None):

@@ -182,6 +182,7 @@ _SIGNATURES = {
     "zg_png_default_encode_options": [C.POINTER(ZgPngEncodeOptions)],
     "zg_png_info": [C.c_void_p, C.c_size_t, C.POINTER(ZgPngLimits), C.POINTER(ZgPngHeader)],
     "zg_png_probe": [C.c_void_p, C.c_size_t, C.POINTER(ZgPngLimits), C.POINTER(ZgPngHeader), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "zg_png_scan_hash": [C.c_void_p, C.c_size_t, C.POINTER(ZgPngLimits), C.POINTER(C.c_uint64), C.POINTER(C.c_int)],
     "zg_png_decode": [C.c_void_p, C.c_size_t, C.POINTER(ZgPngLimits), _IMG, C.c_int, C.POINTER(C.c_int), C.c_void_p],
     "zg_png_decode_host": [C.c_void_p, C.c_size_t, C.POINTER(ZgPngLimits), _IMG, C.c_int, C.POINTER(C.c_int)],
     "zg_png_filter": [_IMG, C.c_int, C.c_void_p, C.c_void_p],

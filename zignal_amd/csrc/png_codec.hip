@@ -840,6 +840,25 @@ int zg_png_probe(const uint8_t *png, size_t len, const zg_png_limits *limits, zg
     return ZG_OK;
 }
 
+int zg_png_scan_hash(const uint8_t *png, size_t len, const zg_png_limits *limits, uint64_t *hash_out, int *truncated_out) {
+    ZG_REQUIRE(png && hash_out, ZG_ERR_INVALID_ARGUMENT, "png scan hash: null argument");
+    zg_png_limits lim;
+    if (limits) lim = *limits; else zg_png_default_limits(&lim);
+    PngFile f;
+    int rc;
+    if ((rc = read_chunks(png, len, lim, &f))) return rc;
+    const ScanLayout L = scan_layout(f.header);
+    std::vector<uint8_t> scan;
+    bool truncated = f.truncated;
+    if ((rc = inflate_scan(f, L, &scan, &truncated))) return rc;
+    if ((rc = defilter_scan(&scan, f.header, L))) return rc;
+    if (f.header.color_type == 3 && f.header.interlace_method != 1 && (rc = check_palette_indices(scan, f, L))) return rc;
+    uint64_t h = 1469598103934665603ull; // FNV-1a over the de-filtered scan data, filter bytes included
+    for (size_t i = 0; i < L.total; ++i) { h ^= scan[i]; h *= 1099511628211ull; }
+    *hash_out = h;
+    if (truncated_out) *truncated_out = truncated ? 1 : 0;
+    return ZG_OK;
+}
 int zg_png_decode(const uint8_t *png, size_t len, const zg_png_limits *limits, const zg_image *dst, int dst_space, int *truncated_out, zg_stream stream) {
     return decode_impl(png, len, limits, dst, dst_space, truncated_out, as_stream(stream));
 }

@@ -71,6 +71,14 @@ def decode(data: bytes, limits: Optional[L.ZgPngLimits] = None):
     return h, _KIND_OF_PIXEL[native.value], bool(trunc.value)
 
 
+def scan_hash(data: bytes, limits: Optional[L.ZgPngLimits] = None):
+    """(FNV-1a of the inflated, de-filtered scan data, truncated): the host half of a decode, no device involved."""
+    buf, n = _buf(data)
+    h, t = C.c_uint64(0), C.c_int(0)
+    L.check(L.lib().zg_png_scan_hash(buf, n, _lim(limits), C.byref(h), C.byref(t)))
+    return h.value, bool(t.value)
+
+
 def load_from_bytes(data: bytes, kind: Optional[str] = None, limits: Optional[L.ZgPngLimits] = None, device: Optional[str] = "cuda",
                     return_truncated: bool = False):
     """png.loadFromBytes(T) (png.zig:1151-1186). kind = "u8" | "rgb_u8" | "rgba_u8" names T; None keeps the file's native
