@@ -212,6 +212,10 @@ class Image:
     def has_same_shape(self, other: "Image") -> bool:
         return self.rows == other.rows and self.cols == other.cols
 
+    def get_rectangle(self) -> Tuple[int, int, int, int]:
+        """Image.getRectangle (image.zig:304-312): (l, t, r, b) = (0, 0, cols, rows)."""
+        return (0, 0, self.cols, self.rows)
+
     def is_contiguous(self) -> bool:
         return self.cols == self.stride
 
