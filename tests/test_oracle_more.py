@@ -153,3 +153,26 @@ def test_copy_with_views_and_in_place():
     assert np.array_equal(small.data, np.arange(9, dtype=np.uint8).reshape(3, 3))
     with pytest.raises(zg.DimensionMismatch):
         view.copy(zg.Image(np.zeros((4, 4), np.uint8)))
+
+
+# ---- src/color.zig in-file tests not cited elsewhere (:1813-1865) ------------------------------------------------------------------
+
+def test_color_known_answers_luma_invert_union_clamping(oracle):
+    # "Luma calculation" (:1813-1833): the grey of a float Rgb is its luma
+    def luma(r, g, b):
+        return float(oracle.convert(np.array([[[r, g, b]]], np.float32), oracle.CS_RGB, oracle.CS_GRAY, np.float32, 1)[0, 0])
+    assert abs(luma(1, 1, 1) - 1.0) < 1e-3 and abs(luma(0, 0, 0)) < 1e-3
+    assert abs(luma(1, 0, 0) - 0.2126) < 1e-3 and abs(luma(0, 1, 0) - 0.7152) < 1e-3 and abs(luma(0, 0, 1) - 0.0722) < 1e-3
+    rgba = np.array([[[1, 0, 0, 0.5]]], np.float32)  # Rgba ignores alpha
+    assert abs(float(oracle.convert(rgba, oracle.CS_RGBA, oracle.CS_GRAY, np.float32, 1)[0, 0]) - 0.2126) < 1e-3
+    # "Rgba invert" (:1835-1841): colour channels flip, alpha stays
+    px = np.array([[[255, 255, 255, 0], [100, 150, 200, 255]]], np.uint8)
+    assert oracle.invert(px.copy()).tolist() == [[[0, 0, 0, 0], [155, 105, 55, 255]]]
+    # "Color union float" (:1843-1852): red is hsv (0, 100, 100)
+    h, s, v = oracle.color_to([1.0, 0.0, 0.0], oracle.CS_RGB, oracle.CS_HSV, np.float32)
+    assert abs(h) < 1e-3 and abs(s - 100) < 1e-3 and abs(v - 100) < 1e-3
+    # "clamping out-of-range inputs" (:1854-1865): convertColor(u8, f32) and Rgb(f32).as(u8) clamp, 0.5 rounds to 128
+    g = oracle.convert(np.array([[-0.5, 1.5]], np.float32), oracle.CS_GRAY, oracle.CS_GRAY, np.uint8, 1)
+    assert g.tolist() == [[0, 255]]
+    rgb = oracle.convert(np.array([[[1.2, -0.2, 0.5]]], np.float32), oracle.CS_RGB, oracle.CS_RGB, np.uint8, 3)
+    assert rgb.tolist() == [[[255, 0, 128]]]
