@@ -857,6 +857,15 @@ done:
 }
 ZO_API void zo_jpeg_free(void *p) { free(p); }
 
+/* BitReader.getBits (:1660-1736) on its own: reads counts[i] bits n times; returns how many reads succeeded */
+ZO_API int zo_jpeg_get_bits(const uint8_t *data, size_t len, const int *counts, int n, uint32_t *out) {
+    bit_reader b = {data, len, 0, 0, 0};
+    int i = 0;
+    for (; i < n; ++i)
+        if (br_get(&b, counts[i], &out[i])) break;
+    return i;
+}
+
 /* decode (+ performBlockScan for a baseline file): FNV-1a (one 32-bit coefficient per step) over the coefficient blocks, component by component, block by block
  * — the state toNativeImage starts from. Lets the entropy decoders be compared without rendering anything. */
 ZO_API int zo_jpeg_coefficient_hash(const uint8_t *data, size_t len, const zo_jpeg_limits *lim_in, uint64_t *hash_out) {

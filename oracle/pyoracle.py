@@ -671,6 +671,16 @@ def jpeg_decode_native(data: bytes, limits: ZoJpegLimits | None = None):
     return arr.reshape((h.height, h.width) if ch == 1 else (h.height, h.width, 3)), h, bool(lim_hit.value)
 
 
+def jpeg_get_bits(data: bytes, counts) -> list:
+    """BitReader.getBits for each count in turn; stops at the first failure (UnexpectedEndOfData)."""
+    n = len(counts)
+    arr, out = (C.c_int * n)(*counts), (C.c_uint32 * n)()
+    fn = lib().zo_jpeg_get_bits
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
+    got = fn(_png_buf(data), len(data), arr, n, out)
+    return list(out)[:got]
+
+
 def jpeg_coefficient_hash(data: bytes, limits: ZoJpegLimits | None = None) -> int:
     """FNV-1a of the entropy-decoded coefficient blocks (decode + performBlockScan), before dequantisation."""
     h = C.c_uint64(0)

@@ -164,6 +164,7 @@ ZO_API void zo_jpeg_idct8x8(int32_t block[64]);
 ZO_API int zo_jpeg_decode_native(const uint8_t *data, size_t len, const zo_jpeg_limits *limits, zo_jpeg_header *header_out, int *native_out,
                                  uint8_t **pixels_out, int *scan_limit_reached_out);
 ZO_API void zo_jpeg_free(void *p);
+ZO_API int zo_jpeg_get_bits(const uint8_t *data, size_t len, const int *counts, int n, uint32_t *out);
 ZO_API int zo_jpeg_coefficient_hash(const uint8_t *data, size_t len, const zo_jpeg_limits *limits, uint64_t *hash_out);
 ZO_API void zo_jpeg_fdct8x8(const int32_t src[64], int32_t dst[64]);
 /* jpeg.encode for Image(u8) / Image(Rgb(u8)): 0 ok, 1 InvalidImageDimensions, 2 ImageTooLarge, 3 other; *out from malloc (zo_jpeg_free) */

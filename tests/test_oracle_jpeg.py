@@ -236,3 +236,16 @@ def test_load_conversions(oracle):  # loadFromBytes(T) (:2825-2851)
     gdata = J.pil_jpeg(J.test_image(20, 28)[..., 0])
     g = oracle.jpeg_decode_native(gdata)[0]
     assert np.array_equal(oracle.jpeg_load(gdata, "rgb_u8"), np.stack([g, g, g], -1))
+
+
+def test_bit_reader_and_ycbcr_known_answers(oracle):  # jpeg.zig:3132-3149, :3151-3174; markers :3119-3130
+    assert oracle.jpeg_get_bits(bytes([0b10110011, 0b01010101]), [4, 4, 8]) == [0b1011, 0b0011, 0b01010101]
+    assert oracle.jpeg_get_bits(bytes([0xFF, 0x00, 0x0F]), [8, 8]) == [0xFF, 0x0F]          # a stuffed 0xFF is one data byte
+    assert oracle.jpeg_get_bits(bytes([0xAB, 0xFF, 0xD3, 0xCD]), [8, 8]) == [0xAB, 0xCD]    # an RSTn marker is swallowed
+    assert oracle.jpeg_get_bits(bytes([0xAB, 0xFF, 0xD9]), [8, 8]) == [0xAB]                # any other marker ends the data
+    assert oracle.jpeg_get_bits(bytes([0xAB]), [4, 8]) == [0xA]                             # end of data
+    for ycc, rgb in (((128, 128, 128), (128, 128, 128)), ((255, 128, 128), (255, 255, 255)), ((0, 128, 128), (0, 0, 0))):
+        got = oracle.convert(np.array([[ycc]], np.uint8), oracle.CS_YCBCR, oracle.CS_RGB, np.uint8, 3)
+        assert tuple(got[0, 0]) == rgb
+    # Marker.fromBytes: SOI and SOF0 are markers the decoder knows (a stream of just those two is "no scan data", not "invalid marker")
+    expect_error(oracle, "NoScanData", oracle.jpeg_decode_state, SIG + bytes([0xFF, 0xC0, 0x00, 0x0B, 8, 0, 8, 0, 8, 1, 1, 0x11, 0]) + EOI)
