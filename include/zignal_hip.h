@@ -235,6 +235,8 @@ ZG_API int zg_insert_host(const zg_image *self, const zg_image *source, const fl
 ZG_API int zg_copy(const zg_image *src, const zg_image *dst, zg_stream stream);
 ZG_API int zg_fill(const zg_image *img, const void *pixel_value, zg_stream stream);
 ZG_API int zg_set_border(const zg_image *img, const uint32_t rect[4], const void *pixel_value, zg_stream stream);
+ZG_API int zg_fill_host(const zg_image *img, const void *pixel_value);
+ZG_API int zg_set_border_host(const zg_image *img, const uint32_t rect[4], const void *pixel_value);
 
 /* ---- colour -------------------------------------------------------------------------- */
 

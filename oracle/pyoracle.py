@@ -337,6 +337,24 @@ def integral(src):
     return planes
 
 
+def fill(img, value):
+    s = as_image(img)
+    v = np.atleast_1d(np.asarray(value, img.dtype))
+    lib().zo_fill.argtypes = [C.c_void_p, C.c_void_p]
+    _check(lib().zo_fill(C.byref(s), v.ctypes.data), "fill")
+    return img
+
+
+def set_border(img, rect, value=None):
+    """Image.setBorder (image.zig:200-230), in place; rect = (l, t, r, b)."""
+    s = as_image(img)
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    v = np.zeros(ch, img.dtype) if value is None else np.atleast_1d(np.asarray(value, img.dtype))
+    lib().zo_set_border.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    _check(lib().zo_set_border(C.byref(s), (C.c_uint32 * 4)(*[int(x) for x in rect]), v.ctypes.data), "set_border")
+    return img
+
+
 def invert(img):
     s = as_image(img)
     _check(lib().zo_invert(C.byref(s)), "invert")

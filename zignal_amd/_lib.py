@@ -143,6 +143,8 @@ _SIGNATURES = {
     "zg_copy": [_IMG, _IMG, C.c_void_p],
     "zg_fill": [_IMG, C.c_void_p, C.c_void_p],
     "zg_set_border": [_IMG, _U32P, C.c_void_p, C.c_void_p],
+    "zg_fill_host": [_IMG, C.c_void_p],
+    "zg_set_border_host": [_IMG, _U32P, C.c_void_p],
     "zg_convert": [_IMG, C.c_int, _IMG, C.c_int, _F32P, C.c_void_p],
     "zg_convert_host": [_IMG, C.c_int, _IMG, C.c_int, _F32P],
     "zg_sharpen": [_IMG, _IMG, C.c_uint32, C.c_void_p],

@@ -151,6 +151,24 @@ int zg_set_border(const zg_image *img, const uint32_t rect[4], const void *pixel
     return set_border_impl(img, rect, pixel_value, as_stream(stream));
 }
 
+int zg_fill_host(const zg_image *img, const void *pixel_value) {
+    HostStage a;
+    int rc;
+    if ((rc = a.upload(img, false, true))) return rc;
+    if ((rc = fill_outside_impl(&a.dev, pixel_value, 0, 0, 0, 0, nullptr))) return rc;
+    ZG_HIP(hipStreamSynchronize(nullptr));
+    return a.finish();
+}
+int zg_set_border_host(const zg_image *img, const uint32_t rect[4], const void *pixel_value) {
+    HostStage a;
+    int rc;
+    ZG_REQUIRE(rect, ZG_ERR_INVALID_ARGUMENT, "setBorder: null rect");
+    if ((rc = a.upload(img, true, true))) return rc; // the inside of rect keeps its pixels
+    if ((rc = set_border_impl(&a.dev, rect, pixel_value, nullptr))) return rc;
+    ZG_HIP(hipStreamSynchronize(nullptr));
+    return a.finish();
+}
+
 int zg_invert(const zg_image *img, zg_stream stream) { return invert_impl(img, as_stream(stream)); }
 int zg_invert_host(const zg_image *img) {
     HostStage a;

@@ -227,6 +227,34 @@ class Image:
             return Image(self.data[0:0, 0:0])
         return Image(self.data[t:b, l:r])
 
+    def _pixel_value(self, value):
+        """One pixel of this image's type as bytes: a scalar for one channel, a sequence otherwise; None is all zeros."""
+        ch = 1 if self.data.ndim == 2 else int(self.data.shape[2])
+        np_dtype = np.float32 if "float" in str(self.data.dtype) else np.uint8
+        if value is None:
+            v = np.zeros(ch, np_dtype)
+        else:
+            v = np.atleast_1d(np.asarray(value, np_dtype))
+            if v.shape != (ch,):
+                raise ValueError(f"expected {ch} channel value(s), got {v.shape}")
+        return (C.c_uint8 * v.nbytes).from_buffer_copy(v.tobytes())
+
+    def fill(self, value) -> "Image":
+        """Image.fill (image.zig:191-198): every pixel of the image (or view) becomes `value`."""
+        d, v = self._desc(), self._pixel_value(value)
+        self._call("fill", C.byref(d), v)
+        return self
+
+    def set_border(self, rect: Sequence[int], value=None) -> "Image":
+        """Image.setBorder (image.zig:200-230): every pixel outside rect = (l, t, r, b) becomes `value` (zero by default); a rect
+        that misses the image fills all of it. The reference binding raises TypeError for a missing rect."""
+        if rect is None:
+            raise TypeError("set_border requires a rectangle (l, t, r, b)")
+        l, t, r, b = (max(int(x), 0) for x in rect)
+        d, v = self._desc(), self._pixel_value(value)
+        self._call("set_border", C.byref(d), (C.c_uint32 * 4)(l, t, r, b), v)
+        return self
+
     def copy(self, dst: Optional["Image"] = None) -> "Image":
         dst = self._like() if dst is None else self._wrap(dst)
         self._same_side(dst)
