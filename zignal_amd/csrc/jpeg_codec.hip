@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <new>
 #include <vector>
 
 namespace zg {
@@ -1116,6 +1117,16 @@ int encode_impl(const zg_image *src, int src_space, const zg_jpeg_encode_options
 
 using namespace zg;
 
+// std::vector growth inside the host layers can throw; nothing may unwind through the C ABI
+template <typename F> static int no_throw(F &&body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        set_error("out of host memory");
+        return ZG_ERR_OUT_OF_MEMORY;
+    }
+}
+
 extern "C" {
 
 void zg_jpeg_default_limits(zg_jpeg_limits *l) { // jpeg.zig:19-33
@@ -1194,13 +1205,13 @@ void zg_jpeg_default_encode_options(zg_jpeg_encode_options *o) { // EncodeOption
     o->comment_len = 0;
 }
 int zg_jpeg_encode(const zg_image *src, int src_space, const zg_jpeg_encode_options *options, uint8_t **out, size_t *out_len, zg_stream stream) {
-    return encode_impl(src, src_space, options, out, out_len, as_stream(stream));
+    return no_throw([&] { return encode_impl(src, src_space, options, out, out_len, as_stream(stream)); });
 }
 int zg_jpeg_encode_host(const zg_image *src, int src_space, const zg_jpeg_encode_options *options, uint8_t **out, size_t *out_len) {
     HostStage a;
     int rc;
     if ((rc = a.upload(src, true, false))) return rc;
-    return encode_impl(&a.dev, src_space, options, out, out_len, nullptr);
+    return no_throw([&] { return encode_impl(&a.dev, src_space, options, out, out_len, nullptr); });
 }
 void zg_jpeg_free(void *p) { free(p); }
 
@@ -1208,44 +1219,48 @@ int zg_jpeg_probe(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits,
     ZG_REQUIRE(jpeg != nullptr, ZG_ERR_INVALID_ARGUMENT, "jpeg probe: null data");
     zg_jpeg_limits lim;
     if (limits) lim = *limits; else zg_jpeg_default_limits(&lim);
-    std::vector<Decoder> holder(1);
-    holder[0].header.precision = 8;
-    const int rc = holder[0].read_stream(jpeg, len, lim);
-    if (rc) return rc;
-    if (header_out) { *header_out = holder[0].header; header_out->subsampling = -1; }
-    if (scan_limit_reached_out) *scan_limit_reached_out = holder[0].scan_limit_reached ? 1 : 0;
-    return ZG_OK;
+    return no_throw([&]() -> int {
+        std::vector<Decoder> holder(1);
+        holder[0].header.precision = 8;
+        const int rc = holder[0].read_stream(jpeg, len, lim);
+        if (rc) return rc;
+        if (header_out) { *header_out = holder[0].header; header_out->subsampling = -1; }
+        if (scan_limit_reached_out) *scan_limit_reached_out = holder[0].scan_limit_reached ? 1 : 0;
+        return ZG_OK;
+    });
 }
 int zg_jpeg_coefficient_hash(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, uint64_t *hash_out) {
     ZG_REQUIRE(jpeg && hash_out, ZG_ERR_INVALID_ARGUMENT, "jpeg coefficient hash: null argument");
     zg_jpeg_limits lim;
     if (limits) lim = *limits; else zg_jpeg_default_limits(&lim);
-    std::vector<Decoder> holder(1);
-    Decoder &d = holder[0];
-    d.header.precision = 8;
-    int rc = d.read_stream(jpeg, len, lim);
-    if (rc == ZG_OK && !d.header.progressive) rc = d.run_baseline_scan();
-    if (rc) return rc;
-    if (!d.allocated) JPEG_FAIL("BlockStorageNotAllocated");
-    uint64_t h = 1469598103934665603ull; // FNV-1a, one 32-bit coefficient per step, component by component
-    for (int c = 0; c < d.header.num_components; ++c) {
-        const int32_t *p = d.coef[c].data();
-        for (size_t i = 0; i < d.nblocks * 64; ++i) {
-            h ^= (uint32_t)p[i];
-            h *= 1099511628211ull;
+    return no_throw([&]() -> int {
+        std::vector<Decoder> holder(1);
+        Decoder &d = holder[0];
+        d.header.precision = 8;
+        int rc = d.read_stream(jpeg, len, lim);
+        if (rc == ZG_OK && !d.header.progressive) rc = d.run_baseline_scan();
+        if (rc) return rc;
+        if (!d.allocated) JPEG_FAIL("BlockStorageNotAllocated");
+        uint64_t h = 1469598103934665603ull; // FNV-1a, one 32-bit coefficient per step, component by component
+        for (int c = 0; c < d.header.num_components; ++c) {
+            const int32_t *p = d.coef[c].data();
+            for (size_t i = 0; i < d.nblocks * 64; ++i) {
+                h ^= (uint32_t)p[i];
+                h *= 1099511628211ull;
+            }
         }
-    }
-    *hash_out = h;
-    return ZG_OK;
+        *hash_out = h;
+        return ZG_OK;
+    });
 }
 int zg_jpeg_decode(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, const zg_image *dst, int dst_space, int *scan_limit_reached_out, zg_stream stream) {
-    return decode_impl(jpeg, len, limits, dst, dst_space, scan_limit_reached_out, as_stream(stream));
+    return no_throw([&] { return decode_impl(jpeg, len, limits, dst, dst_space, scan_limit_reached_out, as_stream(stream)); });
 }
 int zg_jpeg_decode_host(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, const zg_image *dst, int dst_space, int *scan_limit_reached_out) {
     HostStage d;
     int rc;
     if ((rc = d.upload(dst, false, true))) return rc;
-    if ((rc = decode_impl(jpeg, len, limits, &d.dev, dst_space, scan_limit_reached_out, nullptr))) return rc;
+    if ((rc = no_throw([&] { return decode_impl(jpeg, len, limits, &d.dev, dst_space, scan_limit_reached_out, nullptr); }))) return rc;
     ZG_HIP(hipStreamSynchronize(nullptr));
     return d.finish();
 }

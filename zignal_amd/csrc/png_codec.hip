@@ -11,6 +11,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <new>
 #include <vector>
 #include <zlib.h>
 
@@ -748,6 +749,16 @@ int encode_impl(const zg_image *src, int src_space, const zg_png_encode_options 
 
 using namespace zg;
 
+// std::vector growth inside the host layers can throw; nothing may unwind through the C ABI
+template <typename F> static int no_throw(F &&body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        set_error("out of host memory");
+        return ZG_ERR_OUT_OF_MEMORY;
+    }
+}
+
 extern "C" {
 
 void zg_png_default_limits(zg_png_limits *l) { // png.zig:16-41
@@ -831,54 +842,58 @@ int zg_png_probe(const uint8_t *png, size_t len, const zg_png_limits *limits, zg
     ZG_REQUIRE(png != nullptr, ZG_ERR_INVALID_ARGUMENT, "png probe: null data");
     zg_png_limits lim;
     if (limits) lim = *limits; else zg_png_default_limits(&lim);
-    PngFile f;
-    const int rc = read_chunks(png, len, lim, &f);
-    if (rc) return rc;
-    if (header_out) *header_out = f.header;
-    if (native_pixel_out) *native_pixel_out = native_pixel(f);
-    if (truncated_out) *truncated_out = f.truncated ? 1 : 0;
-    return ZG_OK;
+    return no_throw([&]() -> int {
+        PngFile f;
+        const int rc = read_chunks(png, len, lim, &f);
+        if (rc) return rc;
+        if (header_out) *header_out = f.header;
+        if (native_pixel_out) *native_pixel_out = native_pixel(f);
+        if (truncated_out) *truncated_out = f.truncated ? 1 : 0;
+        return ZG_OK;
+    });
 }
 
 int zg_png_scan_hash(const uint8_t *png, size_t len, const zg_png_limits *limits, uint64_t *hash_out, int *truncated_out) {
     ZG_REQUIRE(png && hash_out, ZG_ERR_INVALID_ARGUMENT, "png scan hash: null argument");
     zg_png_limits lim;
     if (limits) lim = *limits; else zg_png_default_limits(&lim);
-    PngFile f;
-    int rc;
-    if ((rc = read_chunks(png, len, lim, &f))) return rc;
-    const ScanLayout L = scan_layout(f.header);
-    std::vector<uint8_t> scan;
-    bool truncated = f.truncated;
-    if ((rc = inflate_scan(f, L, &scan, &truncated))) return rc;
-    if ((rc = defilter_scan(&scan, f.header, L))) return rc;
-    if (f.header.color_type == 3 && f.header.interlace_method != 1 && (rc = check_palette_indices(scan, f, L))) return rc;
-    uint64_t h = 1469598103934665603ull; // FNV-1a over the de-filtered scan data, filter bytes included
-    for (size_t i = 0; i < L.total; ++i) { h ^= scan[i]; h *= 1099511628211ull; }
-    *hash_out = h;
-    if (truncated_out) *truncated_out = truncated ? 1 : 0;
-    return ZG_OK;
+    return no_throw([&]() -> int {
+        PngFile f;
+        int rc;
+        if ((rc = read_chunks(png, len, lim, &f))) return rc;
+        const ScanLayout L = scan_layout(f.header);
+        std::vector<uint8_t> scan;
+        bool truncated = f.truncated;
+        if ((rc = inflate_scan(f, L, &scan, &truncated))) return rc;
+        if ((rc = defilter_scan(&scan, f.header, L))) return rc;
+        if (f.header.color_type == 3 && f.header.interlace_method != 1 && (rc = check_palette_indices(scan, f, L))) return rc;
+        uint64_t h = 1469598103934665603ull; // FNV-1a over the de-filtered scan data, filter bytes included
+        for (size_t i = 0; i < L.total; ++i) { h ^= scan[i]; h *= 1099511628211ull; }
+        *hash_out = h;
+        if (truncated_out) *truncated_out = truncated ? 1 : 0;
+        return ZG_OK;
+    });
 }
 int zg_png_decode(const uint8_t *png, size_t len, const zg_png_limits *limits, const zg_image *dst, int dst_space, int *truncated_out, zg_stream stream) {
-    return decode_impl(png, len, limits, dst, dst_space, truncated_out, as_stream(stream));
+    return no_throw([&] { return decode_impl(png, len, limits, dst, dst_space, truncated_out, as_stream(stream)); });
 }
 int zg_png_decode_host(const uint8_t *png, size_t len, const zg_png_limits *limits, const zg_image *dst, int dst_space, int *truncated_out) {
     HostStage d;
     int rc;
     if ((rc = d.upload(dst, false, true))) return rc;
-    if ((rc = decode_impl(png, len, limits, &d.dev, dst_space, truncated_out, nullptr))) return rc;
+    if ((rc = no_throw([&] { return decode_impl(png, len, limits, &d.dev, dst_space, truncated_out, nullptr); }))) return rc;
     ZG_HIP(hipStreamSynchronize(nullptr));
     return d.finish();
 }
 int zg_png_filter(const zg_image *src, int filter, uint8_t *filtered, zg_stream stream) { return filter_impl(src, filter, filtered, as_stream(stream)); }
 int zg_png_encode(const zg_image *src, int src_space, const zg_png_encode_options *options, uint8_t **out, size_t *out_len, zg_stream stream) {
-    return encode_impl(src, src_space, options, out, out_len, as_stream(stream));
+    return no_throw([&] { return encode_impl(src, src_space, options, out, out_len, as_stream(stream)); });
 }
 int zg_png_encode_host(const zg_image *src, int src_space, const zg_png_encode_options *options, uint8_t **out, size_t *out_len) {
     HostStage a;
     int rc;
     if ((rc = a.upload(src, true, false))) return rc;
-    return encode_impl(&a.dev, src_space, options, out, out_len, nullptr);
+    return no_throw([&] { return encode_impl(&a.dev, src_space, options, out, out_len, nullptr); });
 }
 void zg_png_free(void *p) { free(p); }
 
