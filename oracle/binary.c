@@ -50,7 +50,8 @@ ZO_API int zo_threshold_adaptive_mean(const zo_image *src, const zo_image *dst, 
     if (radius == 0) return 3;
     const size_t rows = src->rows, cols = src->cols, n = rows * cols;
     if (n == 0) return 0;
-    float *plane = (float *)malloc(n * 4), *sat = (float *)malloc(n * 4);
+    float *plane = (float *)calloc(n, 4), *sat = (float *)calloc(n, 4);
+    if (!plane || !sat) { free(plane); free(sat); return 4; }
     for (size_t r = 0; r < rows; ++r)
         for (size_t c = 0; c < cols; ++c) plane[r * cols + c] = (float)((const uint8_t *)src->data)[r * src->stride + c];
     zo_integral_plane_f32(plane, cols, sat, (uint32_t)rows, (uint32_t)cols);
