@@ -216,6 +216,9 @@ static int read_code(jstate *s, const huff_table *t, int *sym) {
         code = (code << 1 | bit) & 0xffff;
         length += 1;
         if ((int32_t)code <= t->max_code[length]) {
+            /* reachable below min_code only through a table that holds symbol 255, which the fast table reads as
+             * "empty"; the reference asserts here (:1238) and its index would be out of range: an error, not a read */
+            if (code < t->min_code[length]) return J_InvalidHuffmanCode;
             *sym = t->huffval[(size_t)t->val_ptr[length] + code - t->min_code[length]];
             return J_OK;
         }
@@ -286,6 +289,9 @@ static int parse_sof(jstate *s, const uint8_t *d, size_t n, int progressive, con
         pos += 3;
     }
     if (max_h > 4 || max_v > 4) return J_UnsupportedSamplingFactor;
+    /* a one-component frame whose sampling byte has a zero nibble: the reference goes on to divide by the MCU size (:1401-1404,
+     * a panic); the restatement has to answer something, and answers with the error the three-component check gives */
+    if (max_h == 0 || max_v == 0) return J_UnsupportedSamplingFactor;
     s->header.subsampling = -1;
     if (nc == 3) {
         const component *c = s->comp;

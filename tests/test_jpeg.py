@@ -164,6 +164,31 @@ def test_entropy_decoders_match_oracle_on_the_cpu(oracle):
     assert n > 700 and "ok" in seen and len(seen) >= 3, seen
 
 
+def test_damaged_tables_found_by_the_host_layer_fuzz(oracle):
+    """Two inputs tools/fuzz_host_layers.py turned up where the reference itself has no defined result (it asserts / divides by
+    zero); both sides now return the same error. A Huffman table holding symbol 255 — the fast table's own "empty" mark — sends
+    short codes down the slow path below min_code (jpeg.zig:1211, :1238); a zero sampling nibble makes the MCU size zero."""
+    img = J.test_image(40, 56, seed=3, smooth=False)
+    data = bytearray(J.pil_jpeg(img, quality=90, subsampling=2))
+    at, hits = 2, 0
+    while data[at + 1] != 0xDA:
+        n = (data[at + 2] << 8) | data[at + 3]
+        if data[at + 1] == 0xC4 and data[at + 4] == 0x10:  # AC table 0: give its second-shortest code the symbol 255
+            data[at + 4 + 17 + 1] = 255
+            hits += 1
+        at += 2 + n
+    assert hits == 1
+    want, got = outcome(oracle.jpeg_coefficient_hash, bytes(data)), outcome(zg.jpeg.coefficient_hash, bytes(data))
+    assert want == got == ("err", "InvalidHuffmanCode"), (want, got)
+
+    gray = bytearray(J.pil_jpeg(img[..., 0], quality=75))
+    sof = gray.index(b"\xFF\xC0")
+    for nibbles in (0x01, 0x10, 0x00):
+        gray[sof + 11] = nibbles
+        want, got = outcome(oracle.jpeg_coefficient_hash, bytes(gray)), outcome(zg.jpeg.coefficient_hash, bytes(gray))
+        assert want == got == ("err", "UnsupportedSamplingFactor"), (nibbles, want, got)
+
+
 # ---- GPU ---------------------------------------------------------------------------------------------------------------------
 
 def decode_both(oracle, data, kind=None, limits=None):

@@ -151,6 +151,9 @@ struct Decoder {
             code = ((code << 1) | bit) & 0xffff;
             ++length;
             if ((int32_t)code <= t.max_code[length]) {
+                // Only a table holding the symbol 255 (the fast table's own "empty" mark) gets here below min_code;
+                // the reference asserts (:1238) and would index out of range, so this is an error rather than a read.
+                if (code < t.min_code[length]) JPEG_FAIL("InvalidHuffmanCode");
                 *symbol = t.values[(size_t)t.first_value[length] + code - t.min_code[length]];
                 return 0;
             }
@@ -409,6 +412,9 @@ struct Decoder {
             if (comp[i].v > mv) mv = comp[i].v;
         }
         if (mh > 4 || mv > 4) JPEG_FAIL("UnsupportedSamplingFactor");
+        // a one-component frame with a zero sampling nibble: the reference divides by the MCU size next (:1401-1404, a panic);
+        // here it is the error the three-component layouts get
+        if (mh == 0 || mv == 0) JPEG_FAIL("UnsupportedSamplingFactor");
         if (nc == 3) {
             if (comp[1].h != comp[2].h || comp[1].v != comp[2].v) JPEG_FAIL("InvalidComponentCount");
             const bool chroma_unit = comp[1].h == 1 && comp[1].v == 1;

@@ -259,8 +259,11 @@ int inflate_scan(const PngFile &f, const ScanLayout &L, std::vector<uint8_t> *sc
     }
     const size_t produced = (size_t)(zs.next_out - scan->data());
     inflateEnd(&zs);
-    if (zr == Z_DATA_ERROR || zr == Z_NEED_DICT || zr == Z_MEM_ERROR || zr == Z_STREAM_ERROR) PNG_FAIL("ReadFailed"); // corruption, not truncation
+    // The reference reads exactly the expected size and then asks for one more byte (:829-842): a byte arriving is
+    // ImageTooLarge whatever comes after it, so that test goes first; zlib, given all the input at once, may already have run
+    // into a later error (a checksum that no longer matches, say) in the same call.
     if (produced > L.total) PNG_FAIL("ImageTooLarge");
+    if (zr == Z_DATA_ERROR || zr == Z_NEED_DICT || zr == Z_MEM_ERROR || zr == Z_STREAM_ERROR) PNG_FAIL("ReadFailed"); // corruption, not truncation
     if (produced < L.total) { // a short or cut stream: keep whole rows, the rest decodes as zero pixels (:846-851)
         *truncated = true;
         const size_t keep = complete_prefix(produced, L);
