@@ -95,10 +95,26 @@ int scratch_alloc(void **out, size_t bytes, hipStream_t s) {
         }
     }
     if (take.p) {
-        if (take.last != s) ZG_HIP(hipStreamWaitEvent(s, take.done, 0));
+        const hipError_t e = take.last != s ? hipStreamWaitEvent(s, take.done, 0) : hipSuccess;
+        if (e != hipSuccess) (void)hipEventSynchronize(take.done); // still ordered, just not asynchronously
         (void)hipEventDestroy(take.done);
     } else {
-        ZG_HIP(hipMalloc(&take.p, need));
+        hipError_t e = hipMalloc(&take.p, need);
+        if (e == hipErrorOutOfMemory) { // give the cache back to the driver and try once more
+            (void)hipGetLastError();
+            std::vector<CachedBlock> drop;
+            {
+                std::lock_guard<std::mutex> lock(g_scratch_mu);
+                drop.swap(g_scratch_free);
+            }
+            for (const CachedBlock &b : drop) {
+                (void)hipEventSynchronize(b.done);
+                (void)hipEventDestroy(b.done);
+                (void)hipFree(b.p);
+            }
+            e = hipMalloc(&take.p, need);
+        }
+        ZG_HIP(e);
         take.bytes = need;
         take.device = dev;
     }
