@@ -404,6 +404,12 @@ ZG_API int zg_png_decode_host(const uint8_t *png, size_t len, const zg_png_limit
  * Adaptive: per-row costs of all five filters in one pass, the reference's sampling state machine on the device, then
  * the chosen filter per row. Asynchronous on `stream`. */
 ZG_API int zg_png_filter(const zg_image *src, int filter, uint8_t *filtered, zg_stream stream);
+/* The IDAT payload of encodeRaw (png.zig:1297-1306, :1372-1391): the zlib stream of `len` bytes of filtered scanlines in
+ * host memory (what zg_png_filter wrote, copied back), at EncodeOptions.compression_level (negative: the default, zlib
+ * level 5 "filtered"). Host only, no device call: with zg_png_filter it is zg_png_encode taken apart, for callers that
+ * filter many frames on the device and deflate elsewhere. Inputs of 4 MiB and more are deflated on up to 16 host threads
+ * (ZIGNAL_HIP_HOST_THREADS overrides) as one stream any inflater reads. *out is malloc'd: zg_png_free. */
+ZG_API int zg_png_compress(const uint8_t *scanlines, size_t len, int compression_level, uint8_t **out, size_t *out_len);
 /* png.encode(T) (png.zig:1400-1425): Image(u8) -> greyscale, Rgb -> RGB, Rgba -> RGBA, anything else (src_space as in
  * zg_convert) is converted to Rgb first. *out is malloc'd host memory holding the file, release it with zg_png_free.
  * options may be NULL (EncodeOptions.default). The device filters, the host deflates: the call synchronises `stream`. */

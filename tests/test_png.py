@@ -204,6 +204,34 @@ def test_host_layers_match_oracle_on_the_cpu(oracle):
     assert n > 600 and {"complete", "truncated", "InvalidCrc"} <= seen, seen
 
 
+def test_compress_scanlines_is_one_zlib_stream(oracle, monkeypatch):
+    """zg_png_compress: the IDAT stream, cut into 1 MiB pieces and deflated on several threads for inputs of 4 MiB and more.
+    Whatever the piece / thread count, zlib reads it back as one stream, and so does the oracle's own inflater when the
+    stream sits in a PNG file (png.zig:829-842 would reject a wrong Adler-32 or a stream that ends early or late)."""
+    rng = np.random.default_rng(5)
+
+    def scanlines(h, w):  # filter byte 0 + smooth-ish bytes: compressible, with matches that reach across the cuts
+        img = ((np.arange(h)[:, None] * 3 + np.arange(w * 4)[None, :] // 5) % 251 + rng.integers(0, 3, (h, w * 4))).astype(np.uint8)
+        return img, np.concatenate([np.zeros((h, 1), np.uint8), img], 1).tobytes()
+
+    for threads in ("1", "3", "16"):
+        monkeypatch.setenv("ZIGNAL_HIP_HOST_THREADS", threads)
+        for n in (0, 1, (1 << 20) + 1, (4 << 20) - 1, 4 << 20, (5 << 20) + 12345):
+            for level in (-1, 0, 9):
+                raw = rng.integers(0, 256, n, dtype=np.uint8).tobytes() if level == 0 else bytes(rng.integers(0, 4, n, dtype=np.uint8))
+                assert zlib.decompress(zg.png.compress_scanlines(raw, level)) == raw, (threads, n, level)
+        img, raw = scanlines(1100, 1200)  # 5.3 MB of scanlines: six pieces
+        z = zg.png.compress_scanlines(raw)
+        assert zlib.decompress(z) == raw and len(z) < len(raw)
+        file = P.SIGNATURE + P.ihdr(1200, 1100, 8, P.RGBA) + P.chunk(b"IDAT", z) + P.chunk(b"IEND")
+        out = oracle.png_decode_native(file)
+        assert np.array_equal(out[0].reshape(1100, 4800), img) and not out[1]
+        want, got = outcome(oracle.png_scan_hash, file), outcome(zg.png.scan_hash, file)
+        assert want == got and want[0] == "ok"
+    with pytest.raises(zg.ZignalError):
+        zg._lib.check(zg._lib.lib().zg_png_compress(None, 5, -1, None, None))
+
+
 # ---- GPU ---------------------------------------------------------------------------------------------------------------------
 
 def decode_both(oracle, data, kind=None, limits=None):

@@ -61,6 +61,7 @@ pub const c = struct {
     pub extern fn zg_png_filter(src: *const ZgImage, filter: c_int, filtered: [*]u8, stream: ?*anyopaque) c_int;
     pub extern fn zg_png_encode(src: *const ZgImage, src_space: c_int, options: ?*const ZgPngEncodeOptions, out: *?[*]u8, out_len: *usize, stream: ?*anyopaque) c_int;
     pub extern fn zg_png_encode_host(src: *const ZgImage, src_space: c_int, options: ?*const ZgPngEncodeOptions, out: *?[*]u8, out_len: *usize) c_int;
+    pub extern fn zg_png_compress(scanlines: [*]const u8, len: usize, compression_level: c_int, out: *?[*]u8, out_len: *usize) c_int;
     pub extern fn zg_png_free(p: ?*anyopaque) void;
     pub const ZgJpegHeader = extern struct { width: u32, height: u32, precision: u8, num_components: u8, progressive: u8, subsampling: i8 };
     pub const ZgJpegLimits = extern struct { max_jpeg_bytes: usize, max_marker_bytes: usize, max_width: u32, max_height: u32, max_pixels: u64, max_blocks: usize, max_scans: usize };

@@ -190,6 +190,7 @@ _SIGNATURES = {
     "zg_png_filter": [_IMG, C.c_int, C.c_void_p, C.c_void_p],
     "zg_png_encode": [_IMG, C.c_int, C.POINTER(ZgPngEncodeOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p],
     "zg_png_encode_host": [_IMG, C.c_int, C.POINTER(ZgPngEncodeOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
+    "zg_png_compress": [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
     "zg_png_free": [C.c_void_p],
     "zg_jpeg_default_limits": [C.POINTER(ZgJpegLimits)],
     "zg_jpeg_info": [C.c_void_p, C.c_size_t, C.POINTER(ZgJpegLimits), C.POINTER(ZgJpegHeader)],

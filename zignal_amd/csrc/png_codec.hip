@@ -11,7 +11,11 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 #include <zlib.h>
 
@@ -657,6 +661,105 @@ int filter_impl(const zg_image *src, int filter, uint8_t *filtered, hipStream_t 
     return rc;
 }
 
+// ---- the IDAT stream (png.zig:1297-1306 + std.compress.flate) -----------------------------------------------------------
+// Level 5 / Z_FILTERED is zlib's own "filtered" configuration (good 8, lazy 16, nice 32), the one the reference's preset
+// names. Compressed bytes differ between deflaters; what they decode to does not — which is also what lets a large image be
+// deflated on several cores: the scanlines are cut into 1 MiB pieces, every piece is a raw deflate stream primed with the
+// 32 KiB before it (so matches still reach back across the cut) and flushed to a byte boundary, and the pieces are
+// concatenated under one zlib header with the Adler-32 of the whole. Any inflater reads it as one stream.
+int host_threads() {
+    if (const char *e = getenv("ZIGNAL_HIP_HOST_THREADS")) {
+        const long n = strtol(e, nullptr, 10);
+        if (n >= 1) return n > 256 ? 256 : (int)n;
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return hw == 0 ? 1 : (hw > 16 ? 16 : (int)hw);
+}
+int deflate_piece(const uint8_t *in, size_t n, const uint8_t *dict, size_t dict_len, int level, int window_bits, bool last, std::vector<uint8_t> *out) {
+    z_stream zs{};
+    if (deflateInit2(&zs, level, Z_DEFLATED, window_bits, 8, Z_FILTERED) != Z_OK) { set_error("deflateInit2 failed"); return ZG_ERR_OUT_OF_MEMORY; }
+    if (dict_len && deflateSetDictionary(&zs, dict, (uInt)dict_len) != Z_OK) { deflateEnd(&zs); set_error("deflateSetDictionary failed"); return ZG_ERR_HIP; }
+    out->resize(n + n / 1000 + 1024);
+    size_t in_at = 0, out_at = 0;
+    for (;;) {
+        if (zs.avail_in == 0 && in_at < n) {
+            const size_t take = n - in_at < (1u << 30) ? n - in_at : (1u << 30);
+            zs.next_in = const_cast<uint8_t *>(in) + in_at;
+            zs.avail_in = (uInt)take;
+            in_at += take;
+        }
+        if (out_at + (1u << 16) > out->size()) out->resize(out->size() * 2);
+        const size_t room = out->size() - out_at < (1u << 30) ? out->size() - out_at : (1u << 30);
+        zs.next_out = out->data() + out_at;
+        zs.avail_out = (uInt)room;
+        const int zr = deflate(&zs, in_at < n ? Z_NO_FLUSH : (last ? Z_FINISH : Z_SYNC_FLUSH));
+        out_at += room - zs.avail_out;
+        if (zr == Z_STREAM_END) break;
+        if (zr != Z_OK && zr != Z_BUF_ERROR) { deflateEnd(&zs); set_error("deflate failed (%d)", zr); return ZG_ERR_HIP; }
+        if (!last && in_at >= n && zs.avail_in == 0 && zs.avail_out != 0) break; // the sync flush is complete
+    }
+    deflateEnd(&zs);
+    out->resize(out_at);
+    return ZG_OK;
+}
+int deflate_scanlines(const uint8_t *scan, size_t scan_bytes, int compression_level, std::vector<uint8_t> *z) {
+    const int level = compression_level < 0 ? 5 : (compression_level > 9 ? 9 : compression_level);
+    const size_t piece = (size_t)1 << 20, pieces = (scan_bytes + piece - 1) / piece;
+    const int threads = (int)std::min<size_t>((size_t)host_threads(), pieces);
+    if (threads <= 1 || pieces < 4) return deflate_piece(scan, scan_bytes, nullptr, 0, level, 15, true, z);
+
+    std::vector<std::vector<uint8_t>> part(pieces);
+    std::vector<uLong> sum(pieces);
+    std::atomic<size_t> next{0};
+    std::atomic<int> status{ZG_OK};
+    char message[512] = "";
+    std::mutex message_mu;
+    auto work = [&]() {
+        for (size_t i = next.fetch_add(1); i < pieces && status.load() == ZG_OK; i = next.fetch_add(1)) {
+            const size_t at = i * piece, n = std::min(piece, scan_bytes - at), back = std::min<size_t>(at, 32768);
+            int rc;
+            try {
+                rc = deflate_piece(scan + at, n, scan + at - back, back, level, -15, i + 1 == pieces, &part[i]);
+            } catch (const std::bad_alloc &) {
+                set_error("out of host memory");
+                rc = ZG_ERR_OUT_OF_MEMORY;
+            }
+            sum[i] = adler32(adler32(0L, Z_NULL, 0), scan + at, (uInt)n);
+            if (rc != ZG_OK) { // the error text is per thread: carry it to the caller's
+                std::lock_guard<std::mutex> lock(message_mu);
+                if (status.exchange(rc) == ZG_OK) snprintf(message, sizeof message, "%s", zg_last_error());
+            }
+        }
+    };
+    {
+        std::vector<std::thread> crew;
+        crew.reserve((size_t)threads - 1);
+        for (int t = 1; t < threads; ++t) crew.emplace_back(work);
+        work();
+        for (std::thread &t : crew) t.join();
+    }
+    if (status.load() != ZG_OK) { set_error("%s", message); return status.load(); }
+
+    size_t total = 2 + 4;
+    for (const auto &v : part) total += v.size();
+    z->clear();
+    z->reserve(total);
+    const unsigned cmf = 0x78, flevel = level < 2 ? 0 : (level < 6 ? 1 : (level == 6 ? 2 : 3));
+    unsigned flg = flevel << 6;
+    flg += 31 - (cmf * 256 + flg) % 31;
+    z->push_back((uint8_t)cmf);
+    z->push_back((uint8_t)flg);
+    uLong adler = adler32(0L, Z_NULL, 0);
+    for (size_t i = 0; i < pieces; ++i) {
+        z->insert(z->end(), part[i].begin(), part[i].end());
+        adler = adler32_combine(adler, sum[i], (z_off_t)std::min(piece, scan_bytes - i * piece));
+    }
+    uint8_t tail[4];
+    store_be32(tail, (uint32_t)adler);
+    z->insert(z->end(), tail, tail + 4);
+    return ZG_OK;
+}
+
 // ---- the container writer (encodeRaw, png.zig:1335-1398) ------------------------------------------------------------------
 void append_chunk(std::vector<uint8_t> *out, const char *type, const uint8_t *data, size_t n) {
     const size_t at = out->size();
@@ -697,30 +800,9 @@ int encode_impl(const zg_image *src, int src_space, const zg_png_encode_options 
     scratch_free(dev, s);
     if (rc) return rc;
 
-    // zlib stream for IDAT: level 5 / Z_FILTERED is zlib's own "filtered" configuration (good 8, lazy 16, nice 32), the one
-    // the reference's preset names (png.zig:1297-1306). Compressed bytes differ between deflaters; what they decode to does not.
-    z_stream zs{};
-    const int level = opt.compression_level < 0 ? 5 : (opt.compression_level > 9 ? 9 : opt.compression_level);
-    if (deflateInit2(&zs, level, Z_DEFLATED, 15, 8, Z_FILTERED) != Z_OK) { set_error("deflateInit2 failed"); return ZG_ERR_OUT_OF_MEMORY; }
-    std::vector<uint8_t> z(scan_bytes + scan_bytes / 1000 + 1024);
-    size_t in_at = 0, out_at = 0;
-    int zr = Z_OK;
-    while (zr != Z_STREAM_END) {
-        if (zs.avail_in == 0 && in_at < scan_bytes) {
-            const size_t take = scan_bytes - in_at < (1u << 30) ? scan_bytes - in_at : (1u << 30);
-            zs.next_in = scan.data() + in_at;
-            zs.avail_in = (uInt)take;
-            in_at += take;
-        }
-        if (out_at + (1u << 16) > z.size()) z.resize(z.size() * 2);
-        const size_t room = z.size() - out_at < (1u << 30) ? z.size() - out_at : (1u << 30);
-        zs.next_out = z.data() + out_at;
-        zs.avail_out = (uInt)room;
-        zr = deflate(&zs, in_at >= scan_bytes ? Z_FINISH : Z_NO_FLUSH);
-        out_at += room - zs.avail_out;
-        if (zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR) { deflateEnd(&zs); set_error("deflate failed (%d)", zr); return ZG_ERR_HIP; }
-    }
-    deflateEnd(&zs);
+    std::vector<uint8_t> z;
+    if ((rc = deflate_scanlines(scan.data(), scan_bytes, opt.compression_level, &z))) return rc;
+    const size_t out_at = z.size();
 
     std::vector<uint8_t> file(kSignature, kSignature + 8);
     uint8_t ihdr[13] = {0};
@@ -897,6 +979,24 @@ int zg_png_encode_host(const zg_image *src, int src_space, const zg_png_encode_o
     int rc;
     if ((rc = a.upload(src, true, false))) return rc;
     return no_throw([&] { return encode_impl(&a.dev, src_space, options, out, out_len, nullptr); });
+}
+int zg_png_compress(const uint8_t *scanlines, size_t len, int compression_level, uint8_t **out, size_t *out_len) {
+    ZG_REQUIRE(out && out_len, ZG_ERR_INVALID_ARGUMENT, "png compress: null output");
+    *out = nullptr;
+    *out_len = 0;
+    ZG_REQUIRE(scanlines != nullptr || len == 0, ZG_ERR_INVALID_ARGUMENT, "png compress: null input");
+    return no_throw([&]() -> int {
+        std::vector<uint8_t> z;
+        const uint8_t none = 0;
+        const int rc = deflate_scanlines(len ? scanlines : &none, len, compression_level, &z);
+        if (rc) return rc;
+        uint8_t *mem = (uint8_t *)malloc(z.size());
+        if (!mem) { set_error("png compress: out of host memory"); return ZG_ERR_OUT_OF_MEMORY; }
+        memcpy(mem, z.data(), z.size());
+        *out = mem;
+        *out_len = z.size();
+        return ZG_OK;
+    });
 }
 void zg_png_free(void *p) { free(p); }
 

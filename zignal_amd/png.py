@@ -145,3 +145,16 @@ def filter_scanlines(image, filter: int = FILTER_ADAPTIVE):
     d = image._desc()
     L.check(L.lib().zg_png_filter(C.byref(d), int(filter), C.c_void_p(out.data_ptr()), image._stream()))
     return out
+
+
+def compress_scanlines(scanlines, compression_level: int = -1) -> bytes:
+    """The IDAT payload of encodeRaw (png.zig:1297-1306, :1372-1391): the zlib stream of filtered scanlines (bytes, or a
+    uint8 array such as filter_scanlines(...).cpu().numpy()). Host only; large inputs are deflated on several threads."""
+    raw = scanlines if isinstance(scanlines, (bytes, bytearray)) else np.ascontiguousarray(scanlines, dtype=np.uint8).tobytes()
+    raw = bytes(raw)
+    mem, n = C.c_void_p(), C.c_size_t()
+    L.check(L.lib().zg_png_compress(raw, len(raw), int(compression_level), C.byref(mem), C.byref(n)))
+    try:
+        return C.string_at(mem.value, n.value)
+    finally:
+        L.lib().zg_png_free(mem)
