@@ -189,6 +189,38 @@ def test_damaged_tables_found_by_the_host_layer_fuzz(oracle):
         assert want == got == ("err", "UnsupportedSamplingFactor"), (nibbles, want, got)
 
 
+def test_storage_shortcuts_keep_the_reference_result(oracle):
+    """The decoder stores subsampled chroma on its own grid and skips the clears and zero stores the reference repeats on
+    memory that is already zero. The cases where that would show: a scan that names one component twice (its blocks are
+    decoded twice: the second pass must start from a cleared block), a chroma component whose id is 1 (a scan of it alone
+    walks the full grid), padded MCUs at the right / bottom edge, and files cut inside a block."""
+    rng = np.random.default_rng(91)
+    files = []
+    for (h, w) in ((8, 8), (17, 50), (70, 33)):
+        img = J.test_image(h, w, seed=w, smooth=False)
+        for sub in (0, 1, 2):
+            data = bytearray(J.pil_jpeg(img, quality=93, subsampling=sub))
+            sos = data.index(b"\xFF\xDA")
+            assert data[sos + 4] == 3
+            for a, b in ((1, 0), (2, 0), (2, 1)):  # component b's id copied over component a's
+                twice = bytearray(data)
+                twice[sos + 5 + 2 * a] = twice[sos + 5 + 2 * b]
+                files.append(bytes(twice))
+            files.append(bytes(data))
+    for (lh, lv) in ((2, 2), (2, 1), (4, 1), (1, 1)):
+        for ids in ((9, 1, 7), (5, 6, 1), (1, 1, 1), (2, 2, 3)):
+            comps = J.layout(lh, lv, ids)
+            files.append(J.write_baseline(45, 52, comps, J.FLAT_Q, J.random_coefficients(rng, comps, 45, 52, density=0.5)))
+    n = 0
+    for data in files:
+        sos = data.index(b"\xFF\xDA")
+        for v in [data] + [data[:int(c)] for c in rng.integers(sos + 12, len(data), 5)]:
+            want, got = outcome(oracle.jpeg_coefficient_hash, v), outcome(zg.jpeg.coefficient_hash, v)
+            assert want == got, (len(v), want, got)
+            n += want[0] == "ok"
+    assert n > 150
+
+
 # ---- GPU ---------------------------------------------------------------------------------------------------------------------
 
 def decode_both(oracle, data, kind=None, limits=None):

@@ -120,11 +120,24 @@ struct Decoder {
     unsigned bw = 0, bh = 0, bwa = 0, bha = 0; // block_width / height, and the MCU-padded grid
     size_t nblocks = 0;
     bool allocated = false;
-    ZeroedWords coef[3]; // per component, nblocks x 64 on the luma grid (the reference's block_storage[block][component])
+    // The reference's block_storage[block][component] (:1157), one array per component. Luma-grid positions a component can
+    // never be written at are not stored: the chroma of a subsampled frame only ever lands on MCU origins (its sampling
+    // factors are 1 x 1, :1383-1395), so it is kept as the (bha / mv) x (bwa / mh) grid of those — a quarter of the pages
+    // for 4:2:0, and already the layout the device wants. A component whose id is 1 keeps the full grid: a scan of that
+    // component alone walks every position (the reference's "non-interleaved" rule, :1745, :2402).
+    ZeroedWords coef[3];
+    bool compact[3] = {false, false, false};
+    unsigned fmh = 1, fmv = 1, cgw = 0, cgh = 0; // frame sampling maxima; the compact grid
     int32_t dc_pred[4] = {0, 0, 0, 0};
     bool scan_limit_reached = false;
 
-    int32_t *block(size_t id, size_t c) { return coef[c].data() + id * 64; }
+    int32_t *block(size_t ay, size_t ax, size_t c) {
+        return coef[c].data() + (compact[c] ? (ay / fmv) * cgw + ax / fmh : ay * bwa + ax) * 64;
+    }
+    const int32_t *block_or_zero(size_t ay, size_t ax, size_t c) { // any position of the luma grid, stored or not
+        static const int32_t zeros[64] = {0};
+        return compact[c] && (ay % fmv != 0 || ax % fmh != 0) ? zeros : block(ay, ax, c);
+    }
 
     // readCode (:1196-1236): 0 ok, kEndOfData, or a ZG status with the error set
     int read_symbol(const Huffman &t, int *symbol) {
@@ -170,21 +183,20 @@ struct Decoder {
         *out = v;
         return 0;
     }
-    int read_ac_run(const Huffman &t, int32_t *blk) { // decodeAC (:1255-1310)
+    // decodeAC (:1255-1310). The reference stores a zero for every skipped position; its only caller has just cleared the
+    // block (:1939) and positions are visited once, in order, so skipping them leaves the same 64 words.
+    int read_ac_run(const Huffman &t, int32_t *blk) {
         int k = 1, rc, symbol;
         while (k < 64) {
             if ((rc = read_symbol(t, &symbol))) return rc;
-            if (symbol == 0) {
-                while (k < 64) blk[kZigzag[k++]] = 0;
-                return 0;
-            }
+            if (symbol == 0) return 0; // end of block
             const int run = symbol >> 4, size = symbol & 15;
             if (size == 0) {
                 if (run != 15) JPEG_FAIL("InvalidACCoefficient");
-                for (int i = 0; i < 16 && k < 64; ++i) blk[kZigzag[k++]] = 0;
+                k += 16;
                 continue;
             }
-            for (int i = 0; i < run && k < 64; ++i) blk[kZigzag[k++]] = 0;
+            k += run;
             if (k >= 64) break;
             int32_t value;
             if ((rc = read_extended(size, &value))) return rc;
@@ -193,8 +205,10 @@ struct Decoder {
         return 0;
     }
 
-    int decode_baseline_block(const ScanComponent &sc, int32_t *blk, int32_t *pred) { // decodeBlockBaseline (:1933-1952)
-        memset(blk, 0, 64 * sizeof(int32_t));
+    // decodeBlockBaseline (:1933-1952). `clear` is the reference's @memset: not needed for a block of the zeroed storage that
+    // this, the only block scan of a baseline file, reaches for the first time.
+    int decode_baseline_block(const ScanComponent &sc, int32_t *blk, int32_t *pred, bool clear) {
+        if (clear) memset(blk, 0, 64 * sizeof(int32_t));
         if (sc.dc > 3 || !dc[sc.dc].present) JPEG_FAIL("MissingHuffmanTable");
         int rc, symbol;
         if ((rc = read_symbol(dc[sc.dc], &symbol))) return rc;
@@ -343,7 +357,7 @@ struct Decoder {
                             const size_t id = (size_t)(y + v) * bwa + (x + h);
                             if (id >= nblocks) continue;
                             (void)bits.fill(24);
-                            const int rc = decode_progressive_block(s, s.comp[i], block(id, ci), &dc_pred[ci], &eob_run);
+                            const int rc = decode_progressive_block(s, s.comp[i], block(y + v, x + h, ci), &dc_pred[ci], &eob_run);
                             if (rc == kEndOfData) return ZG_OK; // a cut scan keeps what it decoded (:1799-1803)
                             if (rc) return rc;
                         }
@@ -360,6 +374,9 @@ struct Decoder {
         const unsigned ystep = single ? 1 : (unsigned)mv, xstep = single ? 1 : (unsigned)mh;
         int32_t pred[4] = {0, 0, 0, 0}, spare[64];
         uint32_t since_restart = 0;
+        bool revisits = false; // a scan that names a component twice decodes into the same blocks twice
+        for (int i = 0; i < s.n; ++i)
+            for (int j = 0; j < i; ++j) revisits = revisits || s.comp[i].id == s.comp[j].id;
         for (unsigned y = 0; y < bh; y += ystep)
             for (unsigned x = 0; x < bw; x += xstep) {
                 if (restart_interval != 0 && since_restart == restart_interval) {
@@ -374,9 +391,9 @@ struct Decoder {
                     for (unsigned v = 0; v < vcount; ++v)
                         for (unsigned h = 0; h < hcount; ++h) {
                             const unsigned ax = x + h, ay = y + v;
-                            int32_t *blk = (ay < bh && ax < bw) ? block((size_t)ay * bwa + ax, ci) : spare; // padding blocks are decoded and dropped
+                            int32_t *blk = (ay < bh && ax < bw) ? block(ay, ax, ci) : spare; // padding blocks are decoded and dropped
                             (void)bits.fill(24);
-                            const int rc = decode_baseline_block(s.comp[i], blk, &pred[ci]);
+                            const int rc = decode_baseline_block(s.comp[i], blk, &pred[ci], revisits || blk == spare);
                             if (rc == kEndOfData) return ZG_OK;
                             if (rc) return rc;
                         }
@@ -432,8 +449,14 @@ struct Decoder {
         if (over(lim.max_pixels, padded)) JPEG_FAIL("ImageTooLarge");
         if (over(lim.max_blocks, padded / 64)) JPEG_FAIL("BlockMemoryLimitExceeded");
         nblocks = (size_t)(padded / 64);
-        for (int i = 0; i < nc; ++i)
-            if (!coef[i].reset(nblocks * 64)) { set_error("jpeg: out of host memory for %zu blocks", nblocks); return ZG_ERR_OUT_OF_MEMORY; }
+        fmh = (unsigned)mh;
+        fmv = (unsigned)mv;
+        cgw = bwa / fmh;
+        cgh = bha / fmv;
+        for (int i = 0; i < nc; ++i) {
+            compact[i] = nc == 3 && i > 0 && comp[i].id != 1 && (mh > 1 || mv > 1);
+            if (!coef[i].reset(compact[i] ? (size_t)cgw * cgh * 64 : nblocks * 64)) { set_error("jpeg: out of host memory for %zu blocks", nblocks); return ZG_ERR_OUT_OF_MEMORY; }
+        }
         allocated = true;
         return ZG_OK;
     }
@@ -780,13 +803,16 @@ int decode_impl(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, c
     const bool subsampled = nc == 3 && !(mh == 1 && mv == 1);
     const unsigned cbx = subsampled ? d.bwa / mh : d.bwa, cby = subsampled ? d.bha / mv : d.bha;
     std::vector<int32_t> packed[2];
-    if (subsampled) {
-        for (int c = 0; c < 2; ++c) {
-            packed[c].resize((size_t)cbx * cby * 64);
-            for (unsigned y = 0; y < cby; ++y)
-                for (unsigned x = 0; x < cbx; ++x)
-                    memcpy(packed[c].data() + ((size_t)y * cbx + x) * 64, d.block((size_t)y * mv * d.bwa + (size_t)x * mh, (size_t)c + 1), 64 * sizeof(int32_t));
-        }
+    const int32_t *chroma[2] = {nullptr, nullptr};
+    for (int c = 0; c < 2 && nc == 3; ++c) {
+        chroma[c] = d.coef[c + 1].data(); // the whole grid of a 4:4:4 frame, or the compact grid: MCU origins, row-major
+        const bool as_stored = !subsampled || (d.compact[c + 1] && d.cgw == cbx && d.cgh == cby && (unsigned)mh == d.fmh && (unsigned)mv == d.fmv);
+        if (as_stored) continue;
+        packed[c].resize((size_t)cbx * cby * 64); // a chroma component with id 1 has the full grid: gather the origins
+        for (unsigned y = 0; y < cby; ++y)
+            for (unsigned x = 0; x < cbx; ++x)
+                memcpy(packed[c].data() + ((size_t)y * cbx + x) * 64, d.block_or_zero((size_t)y * mv, (size_t)x * mh, (size_t)c + 1), 64 * sizeof(int32_t));
+        chroma[c] = packed[c].data();
     }
     const size_t luma_coefs = d.nblocks * 64, chroma_coefs = nc == 3 ? (size_t)cbx * cby * 64 : 0;
     const size_t coef_words = luma_coefs + 2 * chroma_coefs;
@@ -798,7 +824,7 @@ int decode_impl(const uint8_t *jpeg, size_t len, const zg_jpeg_limits *limits, c
     if ((rc = scratch_alloc((void **)&dev, coef_words * 2 * sizeof(int32_t) + native_bytes + 256, s))) return rc;
     rc = upload_pageable(dev, d.coef[0].data(), luma_coefs * sizeof(int32_t), s); // the host buffers die with this call
     for (int c = 0; c < 2 && nc == 3 && rc == ZG_OK; ++c)
-        rc = upload_pageable(dev + luma_coefs + (size_t)c * chroma_coefs, subsampled ? packed[c].data() : d.coef[c + 1].data(), chroma_coefs * sizeof(int32_t), s);
+        rc = upload_pageable(dev + luma_coefs + (size_t)c * chroma_coefs, chroma[c], chroma_coefs * sizeof(int32_t), s);
     if (rc) { scratch_free(dev, s); return rc; }
 
     int32_t *planes = dev + coef_words;
@@ -1248,13 +1274,15 @@ int zg_jpeg_coefficient_hash(const uint8_t *jpeg, size_t len, const zg_jpeg_limi
         if (rc) return rc;
         if (!d.allocated) JPEG_FAIL("BlockStorageNotAllocated");
         uint64_t h = 1469598103934665603ull; // FNV-1a, one 32-bit coefficient per step, component by component
-        for (int c = 0; c < d.header.num_components; ++c) {
-            const int32_t *p = d.coef[c].data();
-            for (size_t i = 0; i < d.nblocks * 64; ++i) {
-                h ^= (uint32_t)p[i];
-                h *= 1099511628211ull;
-            }
-        }
+        for (int c = 0; c < d.header.num_components; ++c)
+            for (size_t ay = 0; ay < d.bha; ++ay)
+                for (size_t ax = 0; ax < d.bwa; ++ax) { // every position of the luma grid, zeros where nothing is stored
+                    const int32_t *p = d.block_or_zero(ay, ax, (size_t)c);
+                    for (int i = 0; i < 64; ++i) {
+                        h ^= (uint32_t)p[i];
+                        h *= 1099511628211ull;
+                    }
+                }
         *hash_out = h;
         return ZG_OK;
     });
