@@ -532,7 +532,7 @@ def extras(zg, torch, np):
         return {"decode_ms": round(best * 1e3, 1), "decode_Mpixels/s": round(ROWS * COLS / best / 1e6, 1),
                 "decode_16_threads_Mpixels/s": round(32 * ROWS * COLS / par / 1e6, 1), "file_MiB": round(len(data) / 2**20, 1),
                 "encode_ms": round(enc * 1e3, 1), "encode_Mpixels/s": round(ROWS * COLS / enc / 1e6, 1), "encoded_MiB": round(len(ours) / 2**20, 1),
-                "note": "host-bound: Huffman decoding / coding is one serial chain; device share ~0.12 ms (IDCT 3 planes + render) / ~0.2 ms (forward DCT)"}
+                "note": "host-bound: Huffman decoding is one serial chain, coding runs in bands of MCU rows on up to 16 host threads; device share ~0.12 ms (IDCT 3 planes + render) / ~0.2 ms (forward DCT)"}
 
     leg("next_sobel_rgba_u8_4096", sobel)
     leg("next_pyramid_build_default_u8_4096", pyramid_build)

@@ -472,6 +472,16 @@ typedef struct zg_jpeg_encode_options { /* jpeg.EncodeOptions (jpeg.zig:284-290)
 ZG_API void zg_jpeg_default_encode_options(zg_jpeg_encode_options *options);
 ZG_API int zg_jpeg_encode(const zg_image *src, int src_space, const zg_jpeg_encode_options *options, uint8_t **out, size_t *out_len, zg_stream stream);
 ZG_API int zg_jpeg_encode_host(const zg_image *src, int src_space, const zg_jpeg_encode_options *options, uint8_t **out, size_t *out_len);
+/* The host half of zg_jpeg_encode on its own: the container and the entropy-coded scan (encodeRgb :929-975,
+ * encodeGrayscale :977-1043, encodeBlock :771-817) around quantised coefficient blocks in host memory, laid out as the
+ * device half writes them: 64 int16 per block in natural order; luma blocks row-major on the
+ * (mcus_y * v) x (mcus_x * h) grid, then (gray == 0) all Cb blocks, then all Cr blocks on the mcus_y x mcus_x grid, where
+ * h x v is 1 x 1 / 2 x 1 / 2 x 2 for yuv444 / yuv422 / yuv420 and mcus = ceil(size / (8 h, 8 v)). Quantisation tables in
+ * the file come from options->quality. Host only, no device call. Large frames are coded in bands of MCU rows on up to
+ * 16 host threads (ZIGNAL_HIP_HOST_THREADS overrides) and spliced bit-exactly: the bytes do not depend on the thread
+ * count. *out is malloc'd: zg_jpeg_free. */
+ZG_API int zg_jpeg_encode_blocks(const int16_t *blocks, uint32_t rows, uint32_t cols, int gray, const zg_jpeg_encode_options *options, uint8_t **out,
+                                 size_t *out_len);
 ZG_API void zg_jpeg_free(void *p);
 
 #ifdef __cplusplus

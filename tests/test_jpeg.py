@@ -221,6 +221,68 @@ def test_storage_shortcuts_keep_the_reference_result(oracle):
     assert n > 150
 
 
+def random_blocks(rng, rows, cols, gray, subsampling, density):
+    hm = 1 if gray or subsampling == 0 else 2
+    vm = 2 if not gray and subsampling == 2 else 1
+    n = -(-cols // (8 * hm)) * -(-rows // (8 * vm)) * (hm * vm + (0 if gray else 2))
+    b = np.zeros((n, 64), np.int16)
+    mask = rng.random((n, 64)) < density
+    b[mask] = rng.integers(-1023, 1024, int(mask.sum()))
+    b[:, 0] = rng.integers(-1024, 1024, n)
+    b[rng.random(n) < 0.1, 1:] = 0  # DC-only blocks; runs past sixteen zeros come with the low densities
+    return b
+
+
+def test_encode_blocks_does_not_depend_on_the_thread_count(oracle, monkeypatch):
+    """zg_jpeg_encode_blocks, the host half of encode: frames of 16 384 blocks and more are entropy-coded in bands of MCU rows
+    on several threads and spliced at bit granularity. One thread is the plain serial coder (the one the GPU tests compare
+    with the oracle's files byte for byte); every other thread count must give the same bytes, and files both decoders read."""
+    rng = np.random.default_rng(12)
+    n_banded = 0
+    for (rows, cols) in ((1, 1), (8, 8), (640, 480), (1000, 1500), (777, 2049), (1536, 1536)):
+        for gray in (False, True):
+            for sub in ((0,) if gray else (0, 1, 2)):
+                for density in (0.02, 0.4, 1.0):
+                    blocks = random_blocks(rng, rows, cols, gray, sub, density)
+                    opt = zg.jpeg.EncodeOptions(quality=80, subsampling=sub)
+                    monkeypatch.setenv("ZIGNAL_HIP_HOST_THREADS", "1")
+                    want = zg.jpeg.encode_blocks(blocks, rows, cols, gray, opt)
+                    for threads in ("2", "5", "16", "64"):
+                        monkeypatch.setenv("ZIGNAL_HIP_HOST_THREADS", threads)
+                        assert zg.jpeg.encode_blocks(blocks, rows, cols, gray, opt) == want, (rows, cols, gray, sub, density, threads)
+                    assert outcome(oracle.jpeg_coefficient_hash, want) == outcome(zg.jpeg.coefficient_hash, want)
+                    n_banded += len(blocks) >= 16384
+    assert n_banded >= 20
+    with pytest.raises(ValueError):
+        zg.jpeg.encode_blocks(np.zeros((3, 64), np.int16), 8, 8, True)
+    with pytest.raises(zg.CodecError):
+        zg.jpeg.encode_blocks(np.zeros((0, 64), np.int16), 0, 8, True)
+
+
+def test_encode_blocks_writes_the_oracle_file(oracle, monkeypatch):
+    """The same entry point against the oracle's encoder, byte for byte, on grey frames: the blocks are made here from the
+    oracle's forward DCT (jpeg.zig:631-746), the quantiser restated in numpy (quantizeWithRecip :763-770) and the table the
+    oracle's own file carries. 1024 x 1024 is 16 384 blocks: two bands on two threads; the small frame goes the serial way."""
+    for (rows, cols, threads) in ((61, 83, "4"), (1024, 1024, "2"), (1024, 1030, "16")):
+        img = J.test_image(rows, cols, seed=rows, smooth=False)[..., 0]
+        for quality in (35, 90):
+            want = oracle.jpeg_encode(img, quality=quality)
+            dqt = want.index(b"\xFF\xDB")
+            q = np.zeros(64, np.int64)
+            q[J.ZIGZAG] = np.frombuffer(want[dqt + 5:dqt + 69], np.uint8)
+            recip = np.round(16777216.0 / (q * 8.0)).astype(np.int64)
+            by, bx = -(-rows // 8), -(-cols // 8)
+            padded = np.pad(img.astype(np.int32), ((0, by * 8 - rows), (0, bx * 8 - cols)), mode="edge") - 128
+            blocks = np.zeros((by * bx, 64), np.int16)
+            for y in range(by):
+                for x in range(bx):
+                    d = oracle.jpeg_fdct8x8(padded[y * 8:y * 8 + 8, x * 8:x * 8 + 8]).reshape(64).astype(np.int64)
+                    blocks[y * bx + x] = np.sign(d) * ((np.abs(d) * recip + (1 << 23)) >> 24)
+            monkeypatch.setenv("ZIGNAL_HIP_HOST_THREADS", threads)
+            got = zg.jpeg.encode_blocks(blocks, rows, cols, True, zg.jpeg.EncodeOptions(quality=quality))
+            assert got == want, (rows, cols, quality, len(got), len(want))
+
+
 # ---- GPU ---------------------------------------------------------------------------------------------------------------------
 
 def decode_both(oracle, data, kind=None, limits=None):

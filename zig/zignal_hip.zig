@@ -74,6 +74,7 @@ pub const c = struct {
     pub extern fn zg_jpeg_default_encode_options(options: *ZgJpegEncodeOptions) void;
     pub extern fn zg_jpeg_encode(src: *const ZgImage, src_space: c_int, options: ?*const ZgJpegEncodeOptions, out: *?[*]u8, out_len: *usize, stream: ?*anyopaque) c_int;
     pub extern fn zg_jpeg_encode_host(src: *const ZgImage, src_space: c_int, options: ?*const ZgJpegEncodeOptions, out: *?[*]u8, out_len: *usize) c_int;
+    pub extern fn zg_jpeg_encode_blocks(blocks: [*]const i16, rows: u32, cols: u32, gray: c_int, options: ?*const ZgJpegEncodeOptions, out: *?[*]u8, out_len: *usize) c_int;
     pub extern fn zg_jpeg_free(p: ?*anyopaque) void;
     pub extern fn zg_shen_castan_host(src: *const ZgImage, dst: *const ZgImage, smooth: f32, window_size: u32, high_ratio: f32, low_rel: f32, hysteresis: c_int, use_nms: c_int) c_int;
     pub extern fn zg_canny_host(src: *const ZgImage, dst: *const ZgImage, sigma: f32, low_threshold: f32, high_threshold: f32) c_int;

@@ -201,6 +201,7 @@ _SIGNATURES = {
     "zg_jpeg_default_encode_options": [C.POINTER(ZgJpegEncodeOptions)],
     "zg_jpeg_encode": [_IMG, C.c_int, C.POINTER(ZgJpegEncodeOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p],
     "zg_jpeg_encode_host": [_IMG, C.c_int, C.POINTER(ZgJpegEncodeOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
+    "zg_jpeg_encode_blocks": [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(ZgJpegEncodeOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
     "zg_jpeg_free": [C.c_void_p],
 }
 _RESTYPES = {"zg_last_error": C.c_char_p, "zg_shutdown": None, "zg_pixel_size": C.c_size_t, "zg_pyramid_scale": C.c_float,

@@ -13,7 +13,11 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <atomic>
 #include <new>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 namespace zg {
@@ -984,7 +988,7 @@ struct HuffmanCodes { // buildHuffmanEncoder (:399-415)
         }
     }
 };
-class EntropyWriter { // :417-447
+template <bool STUFF> class EntropyWriter { // :417-447; STUFF = false leaves the 0xFF bytes alone (a piece that is spliced later)
   public:
     std::vector<uint8_t> bytes;
     uint32_t window = 0;
@@ -996,7 +1000,7 @@ class EntropyWriter { // :417-447
         while (held >= 8) {
             const uint8_t b = (uint8_t)(window >> (held - 8));
             bytes.push_back(b);
-            if (b == 0xFF) bytes.push_back(0x00);
+            if (STUFF && b == 0xFF) bytes.push_back(0x00);
             held -= 8;
         }
     }
@@ -1006,7 +1010,7 @@ class EntropyWriter { // :417-447
 };
 inline int bit_length(int32_t v) { int n = 0; for (uint32_t a = (uint32_t)(v < 0 ? -v : v); a; a >>= 1) ++n; return n; }
 inline uint32_t extra_bits(int32_t v, int n) { return v >= 0 ? (uint32_t)v : (uint32_t)(((int32_t)1 << n) - 1 + v); }
-void write_block(const int16_t *co, EntropyWriter *w, const HuffmanCodes &dc, const HuffmanCodes &ac, int32_t *prev_dc) { // encodeBlock (:771-817), after the quantiser
+template <class Writer> void write_block(const int16_t *co, Writer *w, const HuffmanCodes &dc, const HuffmanCodes &ac, int32_t *prev_dc) { // encodeBlock (:771-817), after the quantiser
     const int32_t diff = co[0] - *prev_dc;
     *prev_dc = co[0];
     const int n = bit_length(diff);
@@ -1034,6 +1038,168 @@ void push_segment(std::vector<uint8_t> *f, int marker, const std::vector<uint8_t
     f->insert(f->end(), payload.begin(), payload.end());
 }
 
+void quant_tables(int quality_in, uint8_t *ql, uint8_t *qc, RecipTable *rl, RecipTable *rcq) {
+    const int quality = quality_in < 1 ? 1 : (quality_in > 100 ? 100 : quality_in); // scaleQuantTables (:464-476)
+    const int scale = quality < 50 ? 5000 / quality : 200 - quality * 2;
+    for (int i = 0; i < 64; ++i) {
+        const int l = (kQLuma[i] * scale + 50) / 100, c = (kQChroma[i] * scale + 50) / 100;
+        ql[i] = (uint8_t)(l < 1 ? 1 : (l > 255 ? 255 : l));
+        qc[i] = (uint8_t)(c < 1 ? 1 : (c > 255 ? 255 : c));
+        rl->r[i] = (uint32_t)round(16777216.0 / ((double)ql[i] * 8.0));   // buildQuantRecipLLM (:749-761)
+        rcq->r[i] = (uint32_t)round(16777216.0 / ((double)qc[i] * 8.0));
+    }
+}
+
+// The entropy-coded segment of the one scan (:862-925, :1020-1037): MCU by MCU, vm x hm luma blocks then Cb then Cr.
+// The code is a pure function of the coefficients — the DC predictor of a block is the DC of the block before it in scan
+// order, which is known without coding anything — so bands of MCU rows are coded on separate host threads into bit strings
+// of their own and spliced: the splice shifts every band to the bit position the one before it ended on, and the 0xFF
+// stuffing, which depends on that final byte alignment, happens there. Byte for byte the serial coder's output.
+template <class Writer>
+void code_mcu_rows(const int16_t *blocks, bool gray, int hm, int vm, unsigned mcus_x, unsigned mcus_y, unsigned row0, unsigned row1, Writer *w) {
+    static const uint8_t dc_vals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+    static const HuffmanCodes dc_codes(kBitsDc, dc_vals), ac_luma(kBitsAcLuma, kValAcLuma), ac_chroma(kBitsAcChroma, kValAcChroma);
+    const unsigned lbx = mcus_x * hm;
+    const size_t luma_blocks = (size_t)lbx * mcus_y * vm, chroma_blocks = gray ? 0 : (size_t)mcus_x * mcus_y;
+    const int16_t *cb = blocks + luma_blocks * 64, *cr = cb + chroma_blocks * 64;
+    int32_t pred[3] = {0, 0, 0};
+    if (row0 > 0) { // the last block of each component in the MCU before this band
+        pred[0] = blocks[((size_t)(row0 * vm - 1) * lbx + (lbx - 1)) * 64];
+        if (!gray) {
+            pred[1] = cb[((size_t)row0 * mcus_x - 1) * 64];
+            pred[2] = cr[((size_t)row0 * mcus_x - 1) * 64];
+        }
+    }
+    for (unsigned my = row0; my < row1; ++my)
+        for (unsigned mx = 0; mx < mcus_x; ++mx) {
+            for (int vy = 0; vy < vm; ++vy)
+                for (int hx = 0; hx < hm; ++hx)
+                    write_block(blocks + ((size_t)(my * vm + vy) * lbx + (mx * hm + hx)) * 64, w, dc_codes, ac_luma, &pred[0]);
+            if (!gray) {
+                write_block(cb + ((size_t)my * mcus_x + mx) * 64, w, dc_codes, ac_chroma, &pred[1]);
+                write_block(cr + ((size_t)my * mcus_x + mx) * 64, w, dc_codes, ac_chroma, &pred[2]);
+            }
+        }
+}
+// Appends n whole bytes to a writer that holds 0..7 pending bits: eight source bytes per step, shifted into place as one
+// big-endian word; a word with a 0xFF byte in it (one in thirty or so) goes byte by byte for the stuffing.
+void splice(const uint8_t *src, size_t n, EntropyWriter<true> *w) {
+    const int k = w->held; // pending bits, unchanged by whole bytes
+    uint64_t carry = w->window & ((1u << k) - 1);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t v;
+        memcpy(&v, src + i, 8);
+        v = __builtin_bswap64(v);
+        const uint64_t word = k ? (carry << (64 - k)) | (v >> k) : v;
+        carry = v & (((uint64_t)1 << k) - 1);
+        const uint64_t inv = ~word; // a zero byte in ~word is a 0xFF byte in word
+        if (((inv - 0x0101010101010101ull) & ~inv & 0x8080808080808080ull) == 0) {
+            const uint64_t be = __builtin_bswap64(word);
+            const size_t at = w->bytes.size();
+            w->bytes.resize(at + 8);
+            memcpy(w->bytes.data() + at, &be, 8);
+        } else {
+            for (int b = 56; b >= 0; b -= 8) {
+                const uint8_t byte = (uint8_t)(word >> b);
+                w->bytes.push_back(byte);
+                if (byte == 0xFF) w->bytes.push_back(0x00);
+            }
+        }
+    }
+    w->window = (uint32_t)carry;
+    for (; i < n; ++i) w->put(src[i], 8);
+}
+void entropy_code(const int16_t *blocks, bool gray, int hm, int vm, unsigned mcus_x, unsigned mcus_y, std::vector<uint8_t> *file) {
+    const size_t total_blocks = (size_t)mcus_x * mcus_y * ((size_t)hm * vm + (gray ? 0 : 2));
+    EntropyWriter<true> w;
+    w.bytes.reserve(total_blocks * 24);
+    const unsigned bands = (unsigned)std::min<size_t>({(size_t)host_threads(), (size_t)mcus_y, total_blocks / 8192});
+    if (bands <= 1) {
+        code_mcu_rows(blocks, gray, hm, vm, mcus_x, mcus_y, 0, mcus_y, &w);
+    } else {
+        std::vector<EntropyWriter<false>> piece(bands);
+        std::atomic<bool> out_of_memory{false};
+        std::atomic<unsigned> next{0};
+        auto work = [&]() {
+            for (unsigned b = next.fetch_add(1); b < bands; b = next.fetch_add(1)) {
+                const unsigned row0 = (unsigned)((uint64_t)mcus_y * b / bands), row1 = (unsigned)((uint64_t)mcus_y * (b + 1) / bands);
+                try {
+                    EntropyWriter<false> mine; // on this thread's stack: neighbours in `piece` would share cache lines
+                    mine.bytes.reserve((size_t)(row1 - row0) * mcus_x * ((size_t)hm * vm + (gray ? 0 : 2)) * 24);
+                    code_mcu_rows(blocks, gray, hm, vm, mcus_x, mcus_y, row0, row1, &mine);
+                    piece[b] = std::move(mine);
+                } catch (const std::bad_alloc &) { // nothing may unwind out of a thread
+                    out_of_memory = true;
+                }
+            }
+        };
+        std::vector<std::thread> crew;
+        crew.reserve(bands - 1);
+        try {
+            for (unsigned t = 1; t < bands; ++t) crew.emplace_back(work);
+        } catch (const std::system_error &) { // no more threads to be had: the ones there are share the bands
+        }
+        work();
+        for (std::thread &t : crew) t.join();
+        if (out_of_memory) throw std::bad_alloc();
+        size_t room = 16;
+        for (const EntropyWriter<false> &p : piece) room += p.bytes.size() + p.bytes.size() / 32 + 16;
+        w.bytes.reserve(room);
+        for (const EntropyWriter<false> &p : piece) {
+            splice(p.bytes.data(), p.bytes.size(), &w);
+            w.put(p.window, p.held); // the bits of its last, incomplete byte
+        }
+    }
+    w.finish();
+    file->insert(file->end(), w.bytes.begin(), w.bytes.end());
+}
+
+// The host half of encode: the container (encodeRgb :929-975, encodeGrayscale :977-1043) around the coefficient blocks the
+// device wrote (luma on its (mcus_y vm) x (mcus_x hm) grid, then Cb, then Cr on the MCU grid; natural order within a block).
+int write_file(const int16_t *blocks, uint32_t rows, uint32_t cols, bool gray, const zg_jpeg_encode_options &opt, std::vector<uint8_t> *file_out) {
+    const int hm = gray || opt.subsampling == 0 ? 1 : 2, vm = !gray && opt.subsampling == 2 ? 2 : 1;
+    const unsigned mcus_x = ceil_div(cols, 8u * hm), mcus_y = ceil_div(rows, 8u * vm);
+    uint8_t ql[64], qc[64];
+    RecipTable rl, rcq;
+    quant_tables(opt.quality, ql, qc, &rl, &rcq);
+    // the container (encodeRgb :929-975, encodeGrayscale :977-1043)
+    std::vector<uint8_t> &file = *file_out;
+    file.assign({0xFF, 0xD8});
+    const uint8_t dh = (uint8_t)(opt.density_dpi >> 8), dl = (uint8_t)opt.density_dpi;
+    push_segment(&file, 0xE0, {'J', 'F', 'I', 'F', 0, 1, 1, 1, dh, dl, dh, dl, 0, 0});
+    if (opt.comment) push_segment(&file, 0xFE, std::vector<uint8_t>(opt.comment, opt.comment + opt.comment_len));
+    std::vector<uint8_t> seg = {0x00};
+    for (int i = 0; i < 64; ++i) seg.push_back(ql[kZigzag[i]]);
+    if (!gray) {
+        seg.push_back(0x01);
+        for (int i = 0; i < 64; ++i) seg.push_back(qc[kZigzag[i]]);
+    }
+    push_segment(&file, 0xDB, seg);
+    const uint8_t hi_r = (uint8_t)(rows >> 8), lo_r = (uint8_t)rows, hi_c = (uint8_t)(cols >> 8), lo_c = (uint8_t)cols;
+    if (gray) push_segment(&file, 0xC0, {8, hi_r, lo_r, hi_c, lo_c, 1, 1, 0x11, 0});
+    else push_segment(&file, 0xC0, {8, hi_r, lo_r, hi_c, lo_c, 3, 1, (uint8_t)(hm << 4 | vm), 0, 2, 0x11, 1, 3, 0x11, 1});
+    const uint8_t dc_vals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+    seg.assign(1, 0x00);
+    seg.insert(seg.end(), kBitsDc, kBitsDc + 16); seg.insert(seg.end(), dc_vals, dc_vals + 12);
+    seg.push_back(0x10);
+    seg.insert(seg.end(), kBitsAcLuma, kBitsAcLuma + 16); seg.insert(seg.end(), kValAcLuma, kValAcLuma + 162);
+    if (!gray) {
+        seg.push_back(0x01);
+        seg.insert(seg.end(), kBitsDc, kBitsDc + 16); seg.insert(seg.end(), dc_vals, dc_vals + 12);
+        seg.push_back(0x11);
+        seg.insert(seg.end(), kBitsAcChroma, kBitsAcChroma + 16); seg.insert(seg.end(), kValAcChroma, kValAcChroma + 162);
+    }
+    push_segment(&file, 0xC4, seg);
+    if (gray) push_segment(&file, 0xDA, {1, 1, 0x00, 0, 63, 0});
+    else push_segment(&file, 0xDA, {3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0});
+
+    entropy_code(blocks, gray, hm, vm, mcus_x, mcus_y, &file);
+    file.push_back(0xFF);
+    file.push_back(0xD9);
+    return ZG_OK;
+}
+
 int encode_impl(const zg_image *src, int src_space, const zg_jpeg_encode_options *options, uint8_t **out, size_t *out_len, hipStream_t s) {
     ZG_REQUIRE(out && out_len, ZG_ERR_INVALID_ARGUMENT, "jpeg encode: null output");
     *out = nullptr;
@@ -1059,17 +1225,9 @@ int encode_impl(const zg_image *src, int src_space, const zg_jpeg_encode_options
     const zg_image *img = direct ? src : &rgb;
     int16_t *coef = (int16_t *)(dev + rgb_bytes);
 
-    int quality = opt.quality < 1 ? 1 : (opt.quality > 100 ? 100 : opt.quality); // scaleQuantTables (:464-476)
-    const int scale = quality < 50 ? 5000 / quality : 200 - quality * 2;
     uint8_t ql[64], qc[64];
     RecipTable rl, rcq;
-    for (int i = 0; i < 64; ++i) {
-        const int l = (kQLuma[i] * scale + 50) / 100, c = (kQChroma[i] * scale + 50) / 100;
-        ql[i] = (uint8_t)(l < 1 ? 1 : (l > 255 ? 255 : l));
-        qc[i] = (uint8_t)(c < 1 ? 1 : (c > 255 ? 255 : c));
-        rl.r[i] = (uint32_t)round(16777216.0 / ((double)ql[i] * 8.0));   // buildQuantRecipLLM (:749-761)
-        rcq.r[i] = (uint32_t)round(16777216.0 / ((double)qc[i] * 8.0));
-    }
+    quant_tables(opt.quality, ql, qc, &rl, &rcq);
     if (rc == ZG_OK) {
         for (int c = 0; c < (gray ? 1 : 3); ++c) {
             const ForwardArgs a{dimg(img), c, hm, vm, c == 0 ? lbx : mcus_x, (unsigned)(c == 0 ? luma_blocks : chroma_blocks)};
@@ -1087,55 +1245,8 @@ int encode_impl(const zg_image *src, int src_space, const zg_jpeg_encode_options
     scratch_free(dev, s);
     if (rc) return rc;
 
-    // the container (encodeRgb :929-975, encodeGrayscale :977-1043)
-    std::vector<uint8_t> file = {0xFF, 0xD8};
-    const uint8_t dh = (uint8_t)(opt.density_dpi >> 8), dl = (uint8_t)opt.density_dpi;
-    push_segment(&file, 0xE0, {'J', 'F', 'I', 'F', 0, 1, 1, 1, dh, dl, dh, dl, 0, 0});
-    if (opt.comment) push_segment(&file, 0xFE, std::vector<uint8_t>(opt.comment, opt.comment + opt.comment_len));
-    std::vector<uint8_t> seg = {0x00};
-    for (int i = 0; i < 64; ++i) seg.push_back(ql[kZigzag[i]]);
-    if (!gray) {
-        seg.push_back(0x01);
-        for (int i = 0; i < 64; ++i) seg.push_back(qc[kZigzag[i]]);
-    }
-    push_segment(&file, 0xDB, seg);
-    const uint8_t hi_r = (uint8_t)(src->rows >> 8), lo_r = (uint8_t)src->rows, hi_c = (uint8_t)(src->cols >> 8), lo_c = (uint8_t)src->cols;
-    if (gray) push_segment(&file, 0xC0, {8, hi_r, lo_r, hi_c, lo_c, 1, 1, 0x11, 0});
-    else push_segment(&file, 0xC0, {8, hi_r, lo_r, hi_c, lo_c, 3, 1, (uint8_t)(hm << 4 | vm), 0, 2, 0x11, 1, 3, 0x11, 1});
-    const uint8_t dc_vals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
-    seg.assign(1, 0x00);
-    seg.insert(seg.end(), kBitsDc, kBitsDc + 16); seg.insert(seg.end(), dc_vals, dc_vals + 12);
-    seg.push_back(0x10);
-    seg.insert(seg.end(), kBitsAcLuma, kBitsAcLuma + 16); seg.insert(seg.end(), kValAcLuma, kValAcLuma + 162);
-    if (!gray) {
-        seg.push_back(0x01);
-        seg.insert(seg.end(), kBitsDc, kBitsDc + 16); seg.insert(seg.end(), dc_vals, dc_vals + 12);
-        seg.push_back(0x11);
-        seg.insert(seg.end(), kBitsAcChroma, kBitsAcChroma + 16); seg.insert(seg.end(), kValAcChroma, kValAcChroma + 162);
-    }
-    push_segment(&file, 0xC4, seg);
-    if (gray) push_segment(&file, 0xDA, {1, 1, 0x00, 0, 63, 0});
-    else push_segment(&file, 0xDA, {3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0});
-
-    const HuffmanCodes dc_codes(kBitsDc, dc_vals), ac_luma(kBitsAcLuma, kValAcLuma), ac_chroma(kBitsAcChroma, kValAcChroma);
-    EntropyWriter w;
-    w.bytes.reserve(total_blocks * 24);
-    int32_t pred[3] = {0, 0, 0};
-    const int16_t *cb = host.data() + luma_blocks * 64, *cr = cb + chroma_blocks * 64;
-    for (unsigned my = 0; my < mcus_y; ++my)
-        for (unsigned mx = 0; mx < mcus_x; ++mx) { // one MCU: its vm x hm luma blocks, then Cb, then Cr (:862-925)
-            for (int vy = 0; vy < vm; ++vy)
-                for (int hx = 0; hx < hm; ++hx)
-                    write_block(host.data() + ((size_t)(my * vm + vy) * lbx + (mx * hm + hx)) * 64, &w, dc_codes, ac_luma, &pred[0]);
-            if (!gray) {
-                write_block(cb + ((size_t)my * mcus_x + mx) * 64, &w, dc_codes, ac_chroma, &pred[1]);
-                write_block(cr + ((size_t)my * mcus_x + mx) * 64, &w, dc_codes, ac_chroma, &pred[2]);
-            }
-        }
-    w.finish();
-    file.insert(file.end(), w.bytes.begin(), w.bytes.end());
-    file.push_back(0xFF);
-    file.push_back(0xD9);
+    std::vector<uint8_t> file;
+    if ((rc = write_file(host.data(), src->rows, src->cols, gray, opt, &file))) return rc;
     uint8_t *mem = (uint8_t *)malloc(file.size());
     if (!mem) { set_error("jpeg encode: out of host memory"); return ZG_ERR_OUT_OF_MEMORY; }
     memcpy(mem, file.data(), file.size());
@@ -1244,6 +1355,28 @@ int zg_jpeg_encode_host(const zg_image *src, int src_space, const zg_jpeg_encode
     int rc;
     if ((rc = a.upload(src, true, false))) return rc;
     return no_throw([&] { return encode_impl(&a.dev, src_space, options, out, out_len, nullptr); });
+}
+int zg_jpeg_encode_blocks(const int16_t *blocks, uint32_t rows, uint32_t cols, int gray, const zg_jpeg_encode_options *options, uint8_t **out, size_t *out_len) {
+    ZG_REQUIRE(out && out_len, ZG_ERR_INVALID_ARGUMENT, "jpeg encode blocks: null output");
+    *out = nullptr;
+    *out_len = 0;
+    ZG_REQUIRE(blocks != nullptr, ZG_ERR_INVALID_ARGUMENT, "jpeg encode blocks: null input");
+    zg_jpeg_encode_options opt;
+    if (options) opt = *options; else zg_jpeg_default_encode_options(&opt);
+    if (rows == 0 || cols == 0) JPEG_FAIL("InvalidImageDimensions");
+    if (rows > 65535 || cols > 65535) JPEG_FAIL("ImageTooLarge");
+    ZG_REQUIRE(opt.subsampling >= 0 && opt.subsampling <= 2, ZG_ERR_INVALID_ARGUMENT, "jpeg encode: subsampling %d (0 yuv444, 1 yuv422, 2 yuv420)", opt.subsampling);
+    return no_throw([&]() -> int {
+        std::vector<uint8_t> file;
+        const int rc = write_file(blocks, rows, cols, gray != 0, opt, &file);
+        if (rc) return rc;
+        uint8_t *mem = (uint8_t *)malloc(file.size());
+        if (!mem) { set_error("jpeg encode: out of host memory"); return ZG_ERR_OUT_OF_MEMORY; }
+        memcpy(mem, file.data(), file.size());
+        *out = mem;
+        *out_len = file.size();
+        return ZG_OK;
+    });
 }
 void zg_jpeg_free(void *p) { free(p); }
 

@@ -15,6 +15,7 @@
 #include <atomic>
 #include <mutex>
 #include <new>
+#include <system_error>
 #include <thread>
 #include <vector>
 #include <zlib.h>
@@ -667,14 +668,6 @@ int filter_impl(const zg_image *src, int filter, uint8_t *filtered, hipStream_t 
 // deflated on several cores: the scanlines are cut into 1 MiB pieces, every piece is a raw deflate stream primed with the
 // 32 KiB before it (so matches still reach back across the cut) and flushed to a byte boundary, and the pieces are
 // concatenated under one zlib header with the Adler-32 of the whole. Any inflater reads it as one stream.
-int host_threads() {
-    if (const char *e = getenv("ZIGNAL_HIP_HOST_THREADS")) {
-        const long n = strtol(e, nullptr, 10);
-        if (n >= 1) return n > 256 ? 256 : (int)n;
-    }
-    const unsigned hw = std::thread::hardware_concurrency();
-    return hw == 0 ? 1 : (hw > 16 ? 16 : (int)hw);
-}
 int deflate_piece(const uint8_t *in, size_t n, const uint8_t *dict, size_t dict_len, int level, int window_bits, bool last, std::vector<uint8_t> *out) {
     z_stream zs{};
     if (deflateInit2(&zs, level, Z_DEFLATED, window_bits, 8, Z_FILTERED) != Z_OK) { set_error("deflateInit2 failed"); return ZG_ERR_OUT_OF_MEMORY; }
@@ -734,7 +727,10 @@ int deflate_scanlines(const uint8_t *scan, size_t scan_bytes, int compression_le
     {
         std::vector<std::thread> crew;
         crew.reserve((size_t)threads - 1);
-        for (int t = 1; t < threads; ++t) crew.emplace_back(work);
+        try {
+            for (int t = 1; t < threads; ++t) crew.emplace_back(work);
+        } catch (const std::system_error &) { // no more threads to be had: the ones there are share the pieces
+        }
         work();
         for (std::thread &t : crew) t.join();
     }

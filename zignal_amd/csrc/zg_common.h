@@ -183,6 +183,7 @@ int download_pageable_rows(void *dst_host, size_t dpitch, const void *src_dev, s
 
 // scratch blocks from the library's caching allocator, ordered on stream s (zg_runtime.cpp)
 int scratch_alloc(void **out, size_t bytes, hipStream_t s);
+int host_threads(); // ZIGNAL_HIP_HOST_THREADS, else min(16, hardware threads)
 void scratch_free(void *p, hipStream_t s);
 
 } // namespace zg

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include <cstdarg>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 
@@ -160,6 +161,16 @@ void scratch_free(void *p, hipStream_t s) {
         (void)hipEventDestroy(evict.done);
         (void)hipFree(evict.p);
     }
+}
+
+// How many host threads the codecs' host halves may use for one call (deflate pieces, entropy-coding bands).
+int host_threads() {
+    if (const char *e = getenv("ZIGNAL_HIP_HOST_THREADS")) {
+        const long n = strtol(e, nullptr, 10);
+        if (n >= 1) return n > 256 ? 256 : (int)n;
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return hw == 0 ? 1 : (hw > 16 ? 16 : (int)hw);
 }
 
 // Pageable host memory <-> device memory, synchronised before returning (the callers' host buffers are short-lived).

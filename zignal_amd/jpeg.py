@@ -126,3 +126,21 @@ def save(image, path: str, options: Optional[EncodeOptions] = None) -> None:
     """jpeg.save (jpeg.zig:293-303): EncodeOptions{ .subsampling = .yuv420 } unless told otherwise."""
     with open(path, "wb") as f:
         f.write(encode(image, options))
+
+
+def encode_blocks(blocks, rows: int, cols: int, gray: bool = False, options: Optional[EncodeOptions] = None) -> bytes:
+    """The host half of encode (jpeg.zig:771-817, :929-1043) around quantised coefficient blocks: an int16 array of
+    (n_blocks, 64) in the device half's order (luma row-major on its padded block grid, then all Cb, then all Cr)."""
+    blocks = np.ascontiguousarray(blocks, dtype=np.int16)
+    opt = (options or EncodeOptions())._c()
+    hm = 1 if gray or opt.subsampling == 0 else 2
+    vm = 2 if not gray and opt.subsampling == 2 else 1
+    mcus = -(-int(cols) // (8 * hm)) * -(-int(rows) // (8 * vm)) if rows > 0 and cols > 0 else 0
+    if rows > 0 and cols > 0 and blocks.size != mcus * (hm * vm + (0 if gray else 2)) * 64:
+        raise ValueError(f"encode_blocks: {blocks.size // 64} blocks given, the layout has {mcus * (hm * vm + (0 if gray else 2))}")
+    out, n = C.c_void_p(), C.c_size_t(0)
+    L.check(L.lib().zg_jpeg_encode_blocks(C.c_void_p(blocks.ctypes.data), int(rows), int(cols), int(bool(gray)), C.byref(opt), C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out.value, n.value)
+    finally:
+        L.lib().zg_jpeg_free(out)
