@@ -281,6 +281,15 @@ def test_encode_blocks_writes_the_oracle_file(oracle, monkeypatch):
             monkeypatch.setenv("ZIGNAL_HIP_HOST_THREADS", threads)
             got = zg.jpeg.encode_blocks(blocks, rows, cols, True, zg.jpeg.EncodeOptions(quality=quality))
             assert got == want, (rows, cols, quality, len(got), len(want))
+    # colour: everything up to the first entropy-coded byte is a function of the options alone
+    rng = np.random.default_rng(2)
+    rgb = J.test_image(37, 50, seed=5)
+    for sub in (0, 1, 2):
+        for kw in (dict(quality=77), dict(quality=12, density_dpi=300, comment=b"made by the test")):
+            want = oracle.jpeg_encode(rgb, subsampling=sub, **kw)
+            got = zg.jpeg.encode_blocks(random_blocks(rng, 37, 50, False, sub, 0.2), 37, 50, False, zg.jpeg.EncodeOptions(subsampling=sub, **kw))
+            head = want.index(b"\xFF\xDA") + 14
+            assert got[:head] == want[:head] and got[-2:] == b"\xFF\xD9", (sub, kw)
 
 
 # ---- GPU ---------------------------------------------------------------------------------------------------------------------
