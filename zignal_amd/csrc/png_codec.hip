@@ -13,6 +13,7 @@
 #include <string.h>
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <system_error>
@@ -21,6 +22,16 @@
 #include <zlib.h>
 
 namespace zg {
+// A byte buffer whose resize() does not clear: the inflater (or the download) overwrites all of it, and 64 MiB of zeros
+// first is a tenth of a large file's decode time.
+template <class T> struct NoInit : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInit<U>; };
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+using ScanBytes = std::vector<uint8_t, NoInit<uint8_t>>;
+
 namespace {
 
 int png_fail(const char *zig_error, const char *where) {
@@ -234,8 +245,8 @@ int native_pixel(const PngFile &f) {
 }
 
 // ---- inflate + de-filter (png.toNativeImage :801-852; :1442-1533, :1721-1803) ----------------------------------------------
-int inflate_scan(const PngFile &f, const ScanLayout &L, std::vector<uint8_t> *scan, bool *truncated) {
-    scan->assign(L.total + 1, 0); // one spare byte: output past the expected size is error.ImageTooLarge (:829-833)
+int inflate_scan(const PngFile &f, const ScanLayout &L, ScanBytes *scan, bool *truncated) {
+    scan->resize(L.total + 1); // not cleared; one spare byte: output past the expected size is error.ImageTooLarge (:829-833)
     z_stream zs{};
     if (inflateInit(&zs) != Z_OK) { set_error("inflateInit failed"); return ZG_ERR_OUT_OF_MEMORY; }
     // zlib counts in 32-bit quantities: both sides are fed in slices. All the input and all the room are on offer, so the
@@ -317,7 +328,7 @@ template <int BPP> void defilter_rows(uint8_t *block, size_t row_bytes, uint32_t
         up = cur;
     }
 }
-int defilter_scan(std::vector<uint8_t> *scan, const zg_png_header &h, const ScanLayout &L) {
+int defilter_scan(ScanBytes *scan, const zg_png_header &h, const ScanLayout &L) {
     const int bpp = (png_channels(h.color_type) * h.bit_depth + 7) / 8;
     bool bad = false;
     for (int p = 0; p < L.npass && !bad; ++p) {
@@ -338,7 +349,7 @@ int defilter_scan(std::vector<uint8_t> *scan, const zg_png_header &h, const Scan
 }
 // A palette index past PLTE is error.InvalidPaletteIndex on the non-interlaced path (:1080, :1119); the Adam7 path falls
 // back to black instead (:2038-2045) and never looks. Only the `width` real pixels of a row count, not the padding bits.
-int check_palette_indices(const std::vector<uint8_t> &scan, const PngFile &f, const ScanLayout &L) {
+int check_palette_indices(const ScanBytes &scan, const PngFile &f, const ScanLayout &L) {
     const PassGeom &g = L.pass[0];
     const int depth = f.header.bit_depth, per = 8 / depth, mask = (1 << depth) - 1;
     if ((1 << depth) <= f.palette_len) return ZG_OK;
@@ -452,7 +463,7 @@ int decode_impl(const uint8_t *png, size_t len, const zg_png_limits *limits, con
     ZG_REQUIRE(dst->rows == f.header.height && dst->cols == f.header.width, ZG_ERR_DIMENSION_MISMATCH, "png: the file is %ux%u, dst is %ux%u",
                f.header.height, f.header.width, dst->rows, dst->cols);
     const ScanLayout L = scan_layout(f.header);
-    std::vector<uint8_t> scan;
+    ScanBytes scan;
     bool truncated = f.truncated;
     if ((rc = inflate_scan(f, L, &scan, &truncated))) return rc;
     if ((rc = defilter_scan(&scan, f.header, L))) return rc;
@@ -788,7 +799,7 @@ int encode_impl(const zg_image *src, int src_space, const zg_png_encode_options 
     zg_image rgb{dev, src->cols, src->rows, src->cols, ZG_PIXEL_RGB_U8};
     if (!direct) rc = zg_convert(src, src_space, &rgb, ZG_CS_RGB, nullptr, (zg_stream)s);
     if (rc == ZG_OK) rc = filter_impl(direct ? src : &rgb, opt.filter, dev + rgb_bytes, s);
-    std::vector<uint8_t> scan;
+    ScanBytes scan;
     if (rc == ZG_OK) {
         scan.resize(scan_bytes);
         rc = download_pageable(scan.data(), dev + rgb_bytes, scan_bytes, s);
@@ -943,7 +954,7 @@ int zg_png_scan_hash(const uint8_t *png, size_t len, const zg_png_limits *limits
         int rc;
         if ((rc = read_chunks(png, len, lim, &f))) return rc;
         const ScanLayout L = scan_layout(f.header);
-        std::vector<uint8_t> scan;
+        ScanBytes scan;
         bool truncated = f.truncated;
         if ((rc = inflate_scan(f, L, &scan, &truncated))) return rc;
         if ((rc = defilter_scan(&scan, f.header, L))) return rc;
