@@ -221,6 +221,25 @@ def test_storage_shortcuts_keep_the_reference_result(oracle):
     assert n > 150
 
 
+def test_host_decoder_from_many_threads(oracle):
+    """The coefficient arrays of the last decode stay with the calling thread and are cleared, not reallocated, for the next
+    one: frames of different sizes and layouts, decoded in a different order by each of eight threads, must hash as they do alone."""
+    from concurrent.futures import ThreadPoolExecutor
+    files = []
+    for i, (h, w) in enumerate(((16, 16), (200, 300), (90, 41), (301, 199), (64, 512))):
+        img = J.test_image(h, w, seed=i, smooth=bool(i % 2))
+        files += [J.pil_jpeg(img, quality=90, subsampling=i % 3), J.pil_jpeg(img, quality=60, subsampling=2, progressive=True), J.pil_jpeg(img[..., 0], quality=80)]
+        files.append(files[-3][:len(files[-3]) * 2 // 3])  # a cut file: the tail of a reused array must read as zero
+    want = [outcome(oracle.jpeg_coefficient_hash, f) for f in files]
+    assert sum(w[0] == "ok" for w in want) >= 18
+
+    def worker(seed):
+        order = np.random.default_rng(seed).permutation(len(files) * 3) % len(files)
+        return all(outcome(zg.jpeg.coefficient_hash, files[i]) == want[i] for i in order)
+    with ThreadPoolExecutor(8) as pool:
+        assert all(pool.map(worker, range(8)))
+
+
 def random_blocks(rng, rows, cols, gray, subsampling, density):
     hm = 1 if gray or subsampling == 0 else 2
     vm = 2 if not gray and subsampling == 2 else 1

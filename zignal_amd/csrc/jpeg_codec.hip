@@ -97,12 +97,54 @@ class BitReader { // :1660-1736
 };
 
 // Coefficient storage: calloc'd so that pages nothing writes to (most of a subsampled chroma plane) are never materialised.
+// The last decode's three arrays stay with the thread that made them: a frame-sized calloc is an mmap, a page fault per 4 KiB
+// written and an munmap (a TLB shoot-down across every thread of the process) per call, where clearing a kept array is
+// one memset. Arrays above 256 MiB are not kept, and one that is more than twice what is asked for is not reused.
+struct CoefficientCache {
+    struct Slot { int32_t *p = nullptr; size_t words = 0; } slot[3];
+    ~CoefficientCache() { for (Slot &s : slot) free(s.p); }
+    int32_t *take(size_t n, size_t *words) {
+        Slot *best = nullptr;
+        for (Slot &s : slot)
+            if (s.p && s.words >= n && s.words / 2 <= n && (!best || s.words < best->words)) best = &s;
+        if (!best) return nullptr;
+        int32_t *p = best->p;
+        *words = best->words;
+        *best = Slot{};
+        return p;
+    }
+    void give(int32_t *p, size_t words) {
+        Slot *into = nullptr;
+        if (words * sizeof(int32_t) <= ((size_t)256 << 20))
+            for (Slot &s : slot)
+                if (!into || s.words < into->words) into = &s; // an empty slot, else the smallest kept array
+        if (!into || (into->p && into->words >= words)) { free(p); return; }
+        free(into->p);
+        *into = Slot{p, words};
+    }
+};
+inline CoefficientCache &coefficient_cache() {
+    static thread_local CoefficientCache cache;
+    return cache;
+}
 struct ZeroedWords {
     int32_t *p = nullptr;
-    ~ZeroedWords() { free(p); }
+    size_t words = 0;
+    ~ZeroedWords() { release(); }
+    void release() {
+        if (p) coefficient_cache().give(p, words);
+        p = nullptr;
+        words = 0;
+    }
     bool reset(size_t n) {
-        free(p);
-        p = (int32_t *)calloc(n ? n : 1, sizeof(int32_t));
+        release();
+        if (n == 0) n = 1;
+        if ((p = coefficient_cache().take(n, &words))) {
+            memset(p, 0, n * sizeof(int32_t));
+            return true;
+        }
+        p = (int32_t *)calloc(n, sizeof(int32_t));
+        words = n;
         return p != nullptr;
     }
     int32_t *data() { return p; }
