@@ -31,6 +31,19 @@ template <class T> struct NoInit : std::allocator<T> {
     }
 };
 using ScanBytes = std::vector<uint8_t, NoInit<uint8_t>>;
+// The scanline buffer of the last call stays with the calling thread (up to 256 MiB): the next frame of a similar size
+// finds its pages already mapped instead of faulting 4 KiB at a time under the inflater.
+struct ScanLease {
+    ScanBytes bytes;
+    static ScanBytes &kept() {
+        static thread_local ScanBytes buffer;
+        return buffer;
+    }
+    ScanLease() { bytes.swap(kept()); }
+    ~ScanLease() {
+        if (bytes.capacity() <= ((size_t)256 << 20) && bytes.capacity() > kept().capacity()) bytes.swap(kept());
+    }
+};
 
 namespace {
 
@@ -463,7 +476,8 @@ int decode_impl(const uint8_t *png, size_t len, const zg_png_limits *limits, con
     ZG_REQUIRE(dst->rows == f.header.height && dst->cols == f.header.width, ZG_ERR_DIMENSION_MISMATCH, "png: the file is %ux%u, dst is %ux%u",
                f.header.height, f.header.width, dst->rows, dst->cols);
     const ScanLayout L = scan_layout(f.header);
-    ScanBytes scan;
+    ScanLease lease;
+    ScanBytes &scan = lease.bytes;
     bool truncated = f.truncated;
     if ((rc = inflate_scan(f, L, &scan, &truncated))) return rc;
     if ((rc = defilter_scan(&scan, f.header, L))) return rc;
@@ -799,7 +813,8 @@ int encode_impl(const zg_image *src, int src_space, const zg_png_encode_options 
     zg_image rgb{dev, src->cols, src->rows, src->cols, ZG_PIXEL_RGB_U8};
     if (!direct) rc = zg_convert(src, src_space, &rgb, ZG_CS_RGB, nullptr, (zg_stream)s);
     if (rc == ZG_OK) rc = filter_impl(direct ? src : &rgb, opt.filter, dev + rgb_bytes, s);
-    ScanBytes scan;
+    ScanLease lease;
+    ScanBytes &scan = lease.bytes;
     if (rc == ZG_OK) {
         scan.resize(scan_bytes);
         rc = download_pageable(scan.data(), dev + rgb_bytes, scan_bytes, s);
@@ -954,7 +969,8 @@ int zg_png_scan_hash(const uint8_t *png, size_t len, const zg_png_limits *limits
         int rc;
         if ((rc = read_chunks(png, len, lim, &f))) return rc;
         const ScanLayout L = scan_layout(f.header);
-        ScanBytes scan;
+        ScanLease lease;
+        ScanBytes &scan = lease.bytes;
         bool truncated = f.truncated;
         if ((rc = inflate_scan(f, L, &scan, &truncated))) return rc;
         if ((rc = defilter_scan(&scan, f.header, L))) return rc;
