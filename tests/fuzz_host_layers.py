@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """CPU-only fuzz of the codecs' host layers: zg_png_scan_hash / zg_jpeg_coefficient_hash / the probes against the oracle on random
-files, cuts, byte flips, duplicated and dropped segments. usage: python tools/fuzz_host_layers.py [seconds] [seed]"""
+files, cuts, byte flips, duplicated and dropped segments. usage: python tests/fuzz_host_layers.py [seconds] [seed]"""
 import struct
 import sys
 import time

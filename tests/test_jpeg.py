@@ -165,7 +165,7 @@ def test_entropy_decoders_match_oracle_on_the_cpu(oracle):
 
 
 def test_damaged_tables_found_by_the_host_layer_fuzz(oracle):
-    """Two inputs tools/fuzz_host_layers.py turned up where the reference itself has no defined result (it asserts / divides by
+    """Two inputs tests/fuzz_host_layers.py turned up where the reference itself has no defined result (it asserts / divides by
     zero); both sides now return the same error. A Huffman table holding symbol 255 — the fast table's own "empty" mark — sends
     short codes down the slow path below min_code (jpeg.zig:1211, :1238); a zero sampling nibble makes the MCU size zero."""
     img = J.test_image(40, 56, seed=3, smooth=False)

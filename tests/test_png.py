@@ -195,7 +195,7 @@ def test_host_layers_match_oracle_on_the_cpu(oracle):
         v = P.make_png(s, 8, P.PALETTE, palette=[[1, 2, 3], [4, 5, 6]], interlace=inter)
         want, got = outcome(oracle.png_scan_hash, v), outcome(zg.png.scan_hash, v)
         assert want == got and (want == ("err", "InvalidPaletteIndex")) == (inter == 0)
-    # more data than the header allows wins over a wrong Adler-32 (png.zig:829-842; found by tools/fuzz_host_layers.py)
+    # more data than the header allows wins over a wrong Adler-32 (png.zig:829-842; found by tests/fuzz_host_layers.py)
     z = bytearray(zlib.compress(bytes(5)))
     z[-1] ^= 1
     v = P.SIGNATURE + P.ihdr(1, 1, 8, P.RGB) + P.chunk(b"IDAT", bytes(z)) + P.chunk(b"IEND")
