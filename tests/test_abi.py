@@ -34,6 +34,13 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(L.EXPORTED_SYMBOLS) == declared
 
 
+def test_zig_shim_declares_the_whole_header():
+    """zig/zignal_hip.zig cannot be compiled here (no Zig toolchain): at least keep its extern block in step with the header."""
+    shim = open(os.path.join(ROOT, "zig", "zignal_hip.zig")).read()
+    externs = set(re.findall(r"pub extern fn (zg_\w+)\(", shim))
+    assert externs == set(_header_symbols()), sorted(externs ^ set(_header_symbols()))
+
+
 def test_enum_ordinals_follow_reference_declaration_order():
     # border.zig:10-18, interpolation.zig:53-68
     assert (zg.BorderMode.zero, zg.BorderMode.replicate, zg.BorderMode.mirror, zg.BorderMode.wrap) == (0, 1, 2, 3)

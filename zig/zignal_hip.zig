@@ -33,6 +33,63 @@ pub const c = struct {
     pub extern fn zg_rotate_into_host(src: *const ZgImage, dst: *const ZgImage, angle: f32, cos_a: f32, sin_a: f32, method: *const ZgMethod, border: c_int) c_int;
     pub extern fn zg_extract_host(src: *const ZgImage, dst: *const ZgImage, rect: *const [4]f32, angle: f32, cos_a: f32, sin_a: f32, method: *const ZgMethod, border: c_int) c_int;
     pub extern fn zg_insert_host(self: *const ZgImage, source: *const ZgImage, rect: *const [4]f32, angle: f32, cos_a: f32, sin_a: f32, method: *const ZgMethod, blend_mode: c_int) c_int;
+    pub extern fn zg_fill_host(img: *const ZgImage, pixel_value: *const anyopaque) c_int;
+    pub extern fn zg_set_border_host(img: *const ZgImage, rect: *const [4]u32, pixel_value: *const anyopaque) c_int;
+    pub extern fn zg_crop_host(src: *const ZgImage, dst: *const ZgImage, rect: *const [4]f32) c_int;
+    pub extern fn zg_crop_dims(rect: *const [4]f32, out_rows: *u32, out_cols: *u32) c_int;
+    pub extern fn zg_gaussian_blur_host(src: *const ZgImage, dst: *const ZgImage, sigma: f32) c_int;
+    pub extern fn zg_gaussian_kernel(sigma: f32, taps: [*]f32, capacity: u32) c_int;
+    pub extern fn zg_rotate_bounds(rows: u32, cols: u32, angle: f32, cos_a: f32, sin_a: f32, out_rows: *u32, out_cols: *u32) c_int;
+    pub extern fn zg_pyramid_scale(scale_factor: f32, level: u32) f32;
+    pub extern fn zg_pyramid_level(rows: u32, cols: u32, scale: f32, blur_sigma: f32, out_rows: *u32, out_cols: *u32, out_sigma: *f32) c_int;
+    pub extern fn zg_png_scan_hash(png: [*]const u8, len: usize, limits: ?*const ZgPngLimits, hash_out: *u64, truncated_out: ?*c_int) c_int;
+    pub extern fn zg_jpeg_coefficient_hash(jpeg: [*]const u8, len: usize, limits: ?*const ZgJpegLimits, hash_out: *u64) c_int;
+    // Device-resident frames (pointers from zg_malloc, work ordered on a zg_stream): what a pipeline that keeps its images in
+    // HBM between calls uses instead of the *_host entry points. Every *_host function above has the same-named twin
+    // without the suffix and with a trailing `stream` argument (include/zignal_hip.h); these are the ones around them.
+    pub extern fn zg_version() c_int;
+    pub extern fn zg_device_count() c_int;
+    pub extern fn zg_shutdown() void;
+    pub extern fn zg_pixel_size(pixel: c_int) usize;
+    pub extern fn zg_malloc(dev_ptr: *?*anyopaque, bytes: usize) c_int;
+    pub extern fn zg_free(dev_ptr: ?*anyopaque) c_int;
+    pub extern fn zg_memcpy_h2d(dst_dev: *anyopaque, src_host: *const anyopaque, bytes: usize, stream: ?*anyopaque) c_int;
+    pub extern fn zg_memcpy_d2h(dst_host: *anyopaque, src_dev: *const anyopaque, bytes: usize, stream: ?*anyopaque) c_int;
+    pub extern fn zg_stream_create(out: *?*anyopaque) c_int;
+    pub extern fn zg_stream_destroy(stream: ?*anyopaque) c_int;
+    pub extern fn zg_stream_synchronize(stream: ?*anyopaque) c_int;
+    pub extern fn zg_copy(src: *const ZgImage, dst: *const ZgImage, stream: ?*anyopaque) c_int;
+    pub extern fn zg_fill(img: *const ZgImage, pixel_value: *const anyopaque, stream: ?*anyopaque) c_int;
+    pub extern fn zg_set_border(img: *const ZgImage, rect: *const [4]u32, pixel_value: *const anyopaque, stream: ?*anyopaque) c_int;
+    pub extern fn zg_crop(src: *const ZgImage, dst: *const ZgImage, rect: *const [4]f32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_gaussian_blur(src: *const ZgImage, dst: *const ZgImage, sigma: f32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_autocontrast(img: *const ZgImage, cutoff: f32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_box_blur(src: *const ZgImage, dst: *const ZgImage, radius: u32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_canny(src: *const ZgImage, dst: *const ZgImage, sigma: f32, low_threshold: f32, high_threshold: f32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_conv_separable(src: *const ZgImage, dst: *const ZgImage, kx: [*]const f32, nkx: u32, ky: [*]const f32, nky: u32, border: c_int, stream: ?*anyopaque) c_int;
+    pub extern fn zg_convert(src: *const ZgImage, src_space: c_int, dst: *const ZgImage, dst_space: c_int, srgb_lut: ?[*]const f32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_convolve(src: *const ZgImage, dst: *const ZgImage, kernel: [*]const f32, kh: u32, kw: u32, border: c_int, stream: ?*anyopaque) c_int;
+    pub extern fn zg_equalize(img: *const ZgImage, stream: ?*anyopaque) c_int;
+    pub extern fn zg_extract(src: *const ZgImage, dst: *const ZgImage, rect: *const [4]f32, angle: f32, cos_a: f32, sin_a: f32, method: *const ZgMethod, border: c_int, stream: ?*anyopaque) c_int;
+    pub extern fn zg_flip_left_right(img: *const ZgImage, stream: ?*anyopaque) c_int;
+    pub extern fn zg_flip_top_bottom(img: *const ZgImage, stream: ?*anyopaque) c_int;
+    pub extern fn zg_insert(self: *const ZgImage, source: *const ZgImage, rect: *const [4]f32, angle: f32, cos_a: f32, sin_a: f32, method: *const ZgMethod, blend_mode: c_int, stream: ?*anyopaque) c_int;
+    pub extern fn zg_integral(src: *const ZgImage, planes: [*]f32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_invert(img: *const ZgImage, stream: ?*anyopaque) c_int;
+    pub extern fn zg_letterbox(src: *const ZgImage, dst: *const ZgImage, method: *const ZgMethod, rect_out: *[4]u32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_morph(src: *const ZgImage, dst: *const ZgImage, kernel: [*]const u8, kernel_rows: u32, kernel_cols: u32, iterations: u32, op: c_int, stream: ?*anyopaque) c_int;
+    pub extern fn zg_motion_blur_linear(src: *const ZgImage, dst: *const ZgImage, angle: f32, cos_a: f32, sin_a: f32, distance: u32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_motion_blur_radial(src: *const ZgImage, dst: *const ZgImage, center_x: f32, center_y: f32, strength: f32, spin: c_int, stream: ?*anyopaque) c_int;
+    pub extern fn zg_order_statistic_blur(src: *const ZgImage, dst: *const ZgImage, radius: u32, op: c_int, param: f64, border: c_int, stream: ?*anyopaque) c_int;
+    pub extern fn zg_resize(src: *const ZgImage, dst: *const ZgImage, method: *const ZgMethod, stream: ?*anyopaque) c_int;
+    pub extern fn zg_rotate_into(src: *const ZgImage, dst: *const ZgImage, angle: f32, cos_a: f32, sin_a: f32, method: *const ZgMethod, border: c_int, stream: ?*anyopaque) c_int;
+    pub extern fn zg_sharpen(src: *const ZgImage, dst: *const ZgImage, radius: u32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_shen_castan(src: *const ZgImage, dst: *const ZgImage, smooth: f32, window_size: u32, high_ratio: f32, low_rel: f32, hysteresis: c_int, use_nms: c_int, stream: ?*anyopaque) c_int;
+    pub extern fn zg_sobel(src: *const ZgImage, dst: *const ZgImage, stream: ?*anyopaque) c_int;
+    pub extern fn zg_threshold_adaptive_mean(src: *const ZgImage, dst: *const ZgImage, radius: u32, c: f32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_threshold_otsu(src: *const ZgImage, dst: *const ZgImage, threshold_out: ?*u8, stream: ?*anyopaque) c_int;
+    pub extern fn zg_warp(src: *const ZgImage, dst: *const ZgImage, kind: c_int, m: [*]const f32, method: *const ZgMethod, stream: ?*anyopaque) c_int;
+    pub extern fn zg_batch_blur_resize(src_frames: *const anyopaque, n_frames: u32, rows: u32, cols: u32, pixel: c_int, sigma: f32, dst_frames: *anyopaque, out_rows: u32, out_cols: u32, method: *const ZgMethod, stream: ?*anyopaque) c_int;
     pub extern fn zg_flip_left_right_host(img: *const ZgImage) c_int;
     pub extern fn zg_flip_top_bottom_host(img: *const ZgImage) c_int;
     /// ImagePyramid.build's loop body (src/image/pyramid.zig:76-92) for device-resident images: blur when sigma > 0.5, then bilinear resize
@@ -362,6 +419,16 @@ pub fn Image(comptime T: type) type {
         pub fn insert(self: *Self, source: anytype, rect: Rectangle(f32), angle: f32, method: Interpolation, blend_mode: zignal.Blending) void {
             const r = [4]f32{ rect.l, rect.t, rect.r, rect.b };
             check(c.zg_insert_host(&desc(self.base), &desc(source.base), &r, angle, @cos(angle), @sin(angle), &methodOf(method, null), @intFromEnum(blend_mode))) catch unreachable;
+        }
+
+        /// reference src/image.zig:187-196
+        pub fn fill(self: Self, value: T) void {
+            check(c.zg_fill_host(&desc(self.base), &value)) catch unreachable;
+        }
+        /// reference src/image.zig:200-227 (rect is clipped to the image; no overlap fills everything)
+        pub fn setBorder(self: Self, rect: Rectangle(u32), value: T) void {
+            const r = [4]u32{ rect.l, rect.t, rect.r, rect.b };
+            check(c.zg_set_border_host(&desc(self.base), &r, &value)) catch unreachable;
         }
 
         /// reference src/image/transforms.zig:28-44
