@@ -64,6 +64,17 @@ int main() {
         auto lab = rgb.convert<Oklab<float>>();
         EXPECT(std::fabs(lab.at(0, 1).l - 0.628f) < 4e-3f);
     }
+    { // image.zig:187-227: fill, then setBorder outside a rectangle (and with no overlap: everything)
+        auto img = Image<uint8_t>::init(5, 6);
+        img.fill(7);
+        img.setBorder({1, 1, 4, 3}, 9);
+        bool ok = true;
+        for (uint32_t r = 0; r < 5; ++r)
+            for (uint32_t c = 0; c < 6; ++c) ok = ok && img.at(r, c) == ((r >= 1 && r < 3 && c >= 1 && c < 4) ? 7 : 9);
+        EXPECT(ok);
+        img.setBorder({10, 10, 12, 12}, 3);
+        EXPECT(img.at(0, 0) == 3 && img.at(2, 2) == 3 && img.at(4, 5) == 3);
+    }
     { // image/tests/resize.zig:258-298 "scale image"
         auto img = Image<uint8_t>::init(100, 100);
         EXPECT(img.scale(0.5f, Interpolation::bilinear()).rows == 50);

@@ -204,6 +204,12 @@ template <typename T> class Image {
         check(zg_crop_host(&s, &d, r));
         return out;
     }
+    void fill(const T &value) const { const zg_image s = desc(); check(zg_fill_host(&s, &value)); } // image.zig:187
+    void setBorder(Rectangle<uint32_t> rect, const T &value) const {                      // image.zig:200
+        const zg_image s = desc();
+        const uint32_t r[4] = {rect.l, rect.t, rect.r, rect.b};
+        check(zg_set_border_host(&s, r, &value));
+    }
     void flipLeftRight() const { const zg_image s = desc(); check(zg_flip_left_right_host(&s)); }   // transforms.zig:28
     void flipTopBottom() const { const zg_image s = desc(); check(zg_flip_top_bottom_host(&s)); }   // transforms.zig:36
     // ---- colour ----
