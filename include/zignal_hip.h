@@ -118,9 +118,19 @@ typedef struct zg_method {
 } zg_method;
 
 typedef void *zg_stream; /* hipStream_t; NULL = default stream */
+typedef void *zg_event;  /* hipEvent_t */
+typedef void *zg_graph;  /* hipGraphExec_t: an instantiated, launchable graph */
 
 /* ---- runtime ------------------------------------------------------------------------- */
-ZG_API int zg_init(int device);               /* hipSetDevice + warm the per-device tables */
+/* The reference has no device: `Image(T)` owns host memory from a std.mem.Allocator (src/image.zig:124-134, deinit :173).
+ * A device-resident image (zig/zignal_hip.zig DeviceImage(T), zignal_amd/cpp/zignal_hip.hpp DeviceImage<T>) gets its pixels
+ * from zg_malloc, crosses PCIe once with zg_image_upload / zg_image_download, and calls the stream-taking entry points
+ * below in between, so that a chain like pipeline.zig:153-179's [blur, resize] never leaves HBM. */
+ZG_API int zg_init(int device);               /* hipSetDevice + the gfx950 check; == zg_set_device */
+/* The current device belongs to the calling THREAD. A host driving several GPUs runs one thread per GPU, each calling
+ * zg_set_device(i) once; that thread's allocations, scratch, cached tables and launches then live on GPU i. */
+ZG_API int zg_set_device(int device);
+ZG_API int zg_get_device(int *device);
 ZG_API void zg_shutdown(void);
 ZG_API const char *zg_last_error(void);       /* thread-local message of the last non-OK status */
 ZG_API int zg_version(void);
@@ -128,11 +138,35 @@ ZG_API int zg_device_count(void);
 
 ZG_API int zg_malloc(void **dev_ptr, size_t bytes);
 ZG_API int zg_free(void *dev_ptr);
+ZG_API int zg_malloc_host(void **host_ptr, size_t bytes); /* pinned host memory: copies to and from it are asynchronous */
+ZG_API int zg_free_host(void *host_ptr);
+/* Host pointer <-> device pointer; the call returns when the copy is complete (any host memory). */
 ZG_API int zg_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, zg_stream stream);
 ZG_API int zg_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, zg_stream stream);
+/* The same, only enqueued on `stream` (meant for zg_malloc_host memory, which must stay valid until the stream gets there). */
+ZG_API int zg_memcpy_h2d_async(void *dst_dev, const void *src_host, size_t bytes, zg_stream stream);
+ZG_API int zg_memcpy_d2h_async(void *dst_host, const void *src_dev, size_t bytes, zg_stream stream);
+/* A whole image or view across PCIe, strides honoured on both sides (same rows, cols and pixel type, else
+ * ZG_ERR_DIMENSION_MISMATCH / ZG_ERR_INVALID_ARGUMENT); complete on return. */
+ZG_API int zg_image_upload(const zg_image *dst_dev, const zg_image *src_host, zg_stream stream);
+ZG_API int zg_image_download(const zg_image *dst_host, const zg_image *src_dev, zg_stream stream);
 ZG_API int zg_stream_create(zg_stream *out);
 ZG_API int zg_stream_destroy(zg_stream s);
 ZG_API int zg_stream_synchronize(zg_stream s);
+ZG_API int zg_stream_wait_event(zg_stream s, zg_event e);
+ZG_API int zg_event_create(zg_event *out);
+ZG_API int zg_event_destroy(zg_event e);
+ZG_API int zg_event_record(zg_event e, zg_stream s);
+ZG_API int zg_event_synchronize(zg_event e);
+ZG_API int zg_event_elapsed_ms(zg_event start, zg_event stop, float *ms); /* device time between two recorded events */
+/* Everything the library enqueues on `stream` (not the default stream) between begin and end becomes one launchable
+ * graph; host-side work of the captured calls (taps, tables, checks) is done at capture time. Scratch that captured calls
+ * take stays reserved for the graph until zg_release_graph_scratch(), to be called once the graphs are destroyed. */
+ZG_API int zg_graph_begin_capture(zg_stream stream);
+ZG_API int zg_graph_end_capture(zg_stream stream, zg_graph *out);
+ZG_API int zg_graph_launch(zg_graph graph, zg_stream stream);
+ZG_API int zg_graph_destroy(zg_graph graph);
+ZG_API int zg_release_graph_scratch(void);
 ZG_API size_t zg_pixel_size(int pixel);
 
 /* ---- filters ------------------------------------------------------------------------- */

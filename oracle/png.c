@@ -87,19 +87,28 @@ static int bytes_per_pixel(const zo_png_header *h) { return (channels_of(h->colo
 
 static const uint32_t A7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}}; /* x0 y0 dx dy */
 static void a7_dims(int pass, uint32_t w, uint32_t h, uint32_t *pw, uint32_t *ph) {
-    *pw = w > A7[pass][0] ? (w - A7[pass][0] + A7[pass][2] - 1) / A7[pass][2] : 0;
-    *ph = h > A7[pass][1] ? (h - A7[pass][1] + A7[pass][3] - 1) / A7[pass][3] : 0;
+    *pw = w > A7[pass][0] ? (uint32_t)(((uint64_t)w - A7[pass][0] + A7[pass][2] - 1) / A7[pass][2]) : 0;
+    *ph = h > A7[pass][1] ? (uint32_t)(((uint64_t)h - A7[pass][1] + A7[pass][3] - 1) / A7[pass][3]) : 0;
 }
 static size_t a7_scanline_bytes(uint32_t pw, const zo_png_header *h) { return ((size_t)pw * channels_of(h->color_type) * h->bit_depth + 7) / 8; }
-static size_t scan_data_length(const zo_png_header *h) {
-    if (h->interlace_method != 1) return (scanline_bytes(h) + 1) * (size_t)h->height;
-    size_t total = 0;
+/* scanDataLength / adam7TotalSize (:219-245): std.math.add / std.math.mul, error.ImageTooLarge when a usize overflows. */
+static int scan_data_length(const zo_png_header *h, size_t *out) {
+    size_t stride, total = 0;
+    if (h->interlace_method != 1) {
+        if (__builtin_add_overflow(scanline_bytes(h), (size_t)1, &stride) || __builtin_mul_overflow(stride, (size_t)h->height, &total)) return E_ImageTooLarge;
+        *out = total;
+        return E_OK;
+    }
     for (int p = 0; p < 7; ++p) {
         uint32_t pw, ph;
+        size_t pass_total;
         a7_dims(p, h->width, h->height, &pw, &ph);
-        if (pw && ph) total += (a7_scanline_bytes(pw, h) + 1) * (size_t)ph;
+        if (!pw || !ph) continue;
+        if (__builtin_add_overflow(a7_scanline_bytes(pw, h), (size_t)1, &stride) || __builtin_mul_overflow(stride, (size_t)ph, &pass_total) ||
+            __builtin_add_overflow(total, pass_total, &total)) return E_ImageTooLarge;
     }
-    return total;
+    *out = total;
+    return E_OK;
 }
 static size_t complete_scan_prefix(size_t len, const zo_png_header *h) { /* :254-272 */
     if (h->interlace_method != 1) {
@@ -328,7 +337,7 @@ static int decode_chunks(const uint8_t *png, size_t len, const zo_png_limits *li
     if (!header_found) return E_MissingHeader;
     if (st->idat_len == 0) return E_MissingImageData;
     if (!seen_iend) st->truncated = 1;
-    st->scan_data_bytes = scan_data_length(&st->header);
+    if (scan_data_length(&st->header, &st->scan_data_bytes) != E_OK) return E_ImageTooLarge;
     if (exceeds(lim->max_decompressed_bytes, st->scan_data_bytes)) return E_ImageTooLarge;
     return E_OK;
 }

@@ -1,0 +1,174 @@
+// Device-resident Image(T) in a bare process (the configuration a Zig or C++ host has: the image's system ROCm runtime,
+// no PyTorch anywhere): BASELINE config 5's `pipeline [blur, resize]` (reference src/cli/pipeline.zig:153-179) on
+// DeviceImage<T> without leaving HBM between the two, checked bit for bit against the CPU oracle (oracle/liboracle.so is
+// linked here as the checker — this file is test infrastructure), timed with device events; the host-pointer layer's banded
+// pipeline against the whole-frame trip; and graph capture of multi-kernel ops that take scratch.
+// Needs a GPU: built by tests/test_cpp_mirror.py, run there. Prints `key=value` lines the Python side reads.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+extern "C" {
+#include "../../oracle/zo.h"
+}
+#include "../../zignal_amd/cpp/zignal_hip.hpp"
+
+using namespace zignal;
+
+static int failures = 0;
+#define EXPECT(cond) do { if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } } while (0)
+
+static uint32_t lcg(uint32_t &s) { s = s * 1664525u + 1013904223u; return s >> 8; }
+template <typename T> static zo_image zo_of(const Image<T> &im) { return zo_image{(void *)im.data, im.stride, im.rows, im.cols, PixelTraits<T>::pixel}; }
+template <typename T> static bool same_bits(const Image<T> &a, const Image<T> &b) {
+    if (a.rows != b.rows || a.cols != b.cols) return false;
+    for (uint32_t r = 0; r < a.rows; ++r)
+        if (std::memcmp(&a.at(r, 0), &b.at(r, 0), (size_t)a.cols * sizeof(T)) != 0) return false;
+    return true;
+}
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Events {
+    zg_event a = nullptr, b = nullptr;
+    Events() { check(zg_event_create(&a)); check(zg_event_create(&b)); }
+    ~Events() { (void)zg_event_destroy(a); (void)zg_event_destroy(b); }
+    float ms() const { float t = 0; check(zg_event_synchronize(b)); check(zg_event_elapsed_ms(a, b, &t)); return t; }
+};
+
+int main(int argc, char **argv) {
+    const bool quick = argc > 1 && std::strcmp(argv[1], "quick") == 0;
+    if (zg_init(0) != ZG_OK) { std::printf("no gfx950 device: %s\n", zg_last_error()); return 77; }
+    const float sigma = 0.6f; // gaussianBlur(0.6): the 5 x 5 kernel BASELINE.json names
+    Stream stream = Stream::create();
+    uint32_t seed = 12345;
+
+    { // config 5, one frame at a time as pipeline.zig runs it: blur -> resize on a device image, one upload, one download
+        const uint32_t rows = 1080, cols = 1920, n_frames = quick ? 2 : 6;
+        auto blurred = DeviceImage<Rgba<uint8_t>>::init(rows, cols, stream.handle());
+        auto small = DeviceImage<Rgba<uint8_t>>::init(rows / 2, cols / 2, stream.handle());
+        auto frame = DeviceImage<Rgba<uint8_t>>::init(rows, cols, stream.handle());
+        for (uint32_t f = 0; f < n_frames; ++f) {
+            auto host = Image<Rgba<uint8_t>>::init(rows, cols);
+            for (size_t i = 0; i < (size_t)rows * cols; ++i) { const uint32_t v = lcg(seed); host.data[i] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 5)}; }
+            frame.upload(host);
+            frame.gaussianBlur(blurred, sigma);
+            blurred.resize(small, Interpolation::bilinear());
+            const Image<Rgba<uint8_t>> got = small.toHost();
+            auto want_blur = Image<Rgba<uint8_t>>::init(rows, cols), want = Image<Rgba<uint8_t>>::init(rows / 2, cols / 2);
+            const zo_image zs = zo_of(host), zb = zo_of(want_blur), zw = zo_of(want);
+            const zo_method bil = {ZO_BILINEAR, 0, 0, nullptr};
+            EXPECT(zo_gaussian_blur(&zs, &zb, sigma) == 0 && zo_resize(&zb, &zw, &bil) == 0);
+            EXPECT(same_bits(got, want));
+        }
+        // device time of the resident chain (what bench.py's per-frame leg measures from Python)
+        const int reps = 200;
+        for (int i = 0; i < 20; ++i) { frame.gaussianBlur(blurred, sigma); blurred.resize(small, Interpolation::bilinear()); }
+        Events ev;
+        check(zg_event_record(ev.a, stream.handle()));
+        for (int i = 0; i < reps; ++i) { frame.gaussianBlur(blurred, sigma); blurred.resize(small, Interpolation::bilinear()); }
+        check(zg_event_record(ev.b, stream.handle()));
+        std::printf("chain_1080p_rgba8_blur_resize_us=%.2f\n", ev.ms() * 1000.0 / reps);
+    }
+
+    { // BASELINE config 2 through the compiled-language mirror: 4096^2 Rgba(f32), resident, and the same through host pointers
+        const uint32_t n = quick ? 1024 : 4096;
+        auto host = Image<Rgba<float>>::init(n, n), want = Image<Rgba<float>>::init(n, n), out = Image<Rgba<float>>::init(n, n);
+        for (size_t i = 0; i < (size_t)n * n; ++i) {
+            const uint32_t v = lcg(seed), w = lcg(seed);
+            host.data[i] = {(float)(v & 0xffff) / 65535.0f, (float)(v >> 16 & 0xff) / 255.0f, (float)(w & 0xffff) / 4096.0f - 3.0f, (float)(w >> 12 & 0xfff) / 4095.0f};
+        }
+        const zo_image zs = zo_of(host), zw = zo_of(want);
+        EXPECT(zo_gaussian_blur(&zs, &zw, sigma) == 0);
+        auto dsrc = DeviceImage<Rgba<float>>::fromHost(host, stream.handle());
+        auto ddst = DeviceImage<Rgba<float>>::init(n, n, stream.handle());
+        dsrc.gaussianBlur(ddst, sigma);
+        ddst.download(out);
+        EXPECT(same_bits(out, want));
+        const int reps = 100;
+        for (int i = 0; i < 30; ++i) dsrc.gaussianBlur(ddst, sigma);
+        Events ev;
+        check(zg_event_record(ev.a, stream.handle()));
+        for (int i = 0; i < reps; ++i) dsrc.gaussianBlur(ddst, sigma);
+        check(zg_event_record(ev.b, stream.handle()));
+        std::printf("resident_blur_rgba_f32_%u_us=%.2f\n", n, ev.ms() * 1000.0 / reps);
+
+        // host pointers: the banded full-duplex pipeline, then the plain upload -> kernel -> download trip
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) setenv("ZIGNAL_HIP_NO_BANDS", "1", 1);
+            std::memset((void *)out.data, 0, (size_t)n * n * sizeof(Rgba<float>));
+            host.gaussianBlur(out, sigma); // first call of a size pays the device allocations
+            EXPECT(same_bits(out, want));
+            double best = 1e30;
+            for (int i = 0; i < 5; ++i) {
+                const double t0 = now_ms();
+                host.gaussianBlur(out, sigma);
+                const double t = now_ms() - t0;
+                if (t < best) best = t;
+            }
+            EXPECT(same_bits(out, want));
+            std::printf(pass == 0 ? "host_blur_rgba_f32_%u_banded_ms=%.3f\n" : "host_blur_rgba_f32_%u_whole_ms=%.3f\n", n, best);
+        }
+        unsetenv("ZIGNAL_HIP_NO_BANDS");
+        // views on both sides (strides differ from cols) through the banded path, and a convert (halo 0) with a type change
+        auto big = Image<Rgba<float>>::init(n, n + 8);
+        auto hv = big.view({3, 0, n + 3, n});
+        for (uint32_t r = 0; r < n; ++r) std::memcpy(&hv.at(r, 0), &host.at(r, 0), (size_t)n * sizeof(Rgba<float>));
+        auto obig = Image<Rgba<float>>::init(n, n + 5);
+        auto ov = obig.view({5, 0, n + 5, n});
+        hv.gaussianBlur(ov, sigma);
+        EXPECT(same_bits(ov, want));
+        auto lab = Image<Oklab<float>>::init(n, n), lab_want = Image<Oklab<float>>::init(n, n);
+        host.convertInto<Oklab<float>>(lab);
+        const zo_image zl = zo_of(lab_want);
+        EXPECT(zo_convert(&zs, ZO_CS_RGBA, &zl, ZO_CS_OKLAB, nullptr) == 0);
+        EXPECT(same_bits(lab, lab_want));
+    }
+
+    { // graph capture under the system runtime: multi-kernel ops that take scratch (17-tap two-pass blur, canny), replayed
+      // while eager calls of the same sizes run in between; every replay must equal the eager result
+        const uint32_t rows = 600, cols = 800;
+        auto host = Image<Rgba<uint8_t>>::init(rows, cols);
+        for (size_t i = 0; i < (size_t)rows * cols; ++i) { const uint32_t v = lcg(seed); host.data[i] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), 255}; }
+        auto src = DeviceImage<Rgba<uint8_t>>::fromHost(host, stream.handle());
+        auto eager_blur = DeviceImage<Rgba<uint8_t>>::init(rows, cols, stream.handle()), graph_blur = DeviceImage<Rgba<uint8_t>>::init(rows, cols, stream.handle());
+        auto eager_edges = DeviceImage<uint8_t>::init(rows, cols, stream.handle()), graph_edges = DeviceImage<uint8_t>::init(rows, cols, stream.handle());
+        const float big_sigma = 2.6f; // ceil(7.8) = 8 -> 17 taps: the packed two-pass path with a temp plane
+        src.gaussianBlur(eager_blur, big_sigma);
+        src.canny(eager_edges, 1.4f, 50.0f, 100.0f);
+        const Image<Rgba<uint8_t>> want_blur = eager_blur.toHost();
+        const Image<uint8_t> want_edges = eager_edges.toHost();
+        { // the eager results themselves against the oracle
+            auto ob = Image<Rgba<uint8_t>>::init(rows, cols);
+            const zo_image zs = zo_of(host), zb = zo_of(ob);
+            EXPECT(zo_gaussian_blur(&zs, &zb, big_sigma) == 0);
+            EXPECT(same_bits(want_blur, ob));
+        }
+        check(zg_graph_begin_capture(stream.handle()));
+        src.gaussianBlur(graph_blur, big_sigma);
+        src.canny(graph_edges, 1.4f, 50.0f, 100.0f);
+        zg_graph graph = nullptr;
+        check(zg_graph_end_capture(stream.handle(), &graph));
+        for (int replay = 0; replay < 4; ++replay) {
+            const Rgba<uint8_t> junk = {1, 2, 3, 4};
+            graph_blur.fill(junk);
+            graph_edges.fill((uint8_t)7);
+            check(zg_graph_launch(graph, stream.handle()));
+            // eager calls of the same sizes between replays: they must not be handed the graph's scratch
+            src.gaussianBlur(eager_blur, big_sigma);
+            src.canny(eager_edges, 1.4f, 50.0f, 100.0f);
+            EXPECT(same_bits(graph_blur.toHost(), want_blur));
+            EXPECT(same_bits(graph_edges.toHost(), want_edges));
+            EXPECT(same_bits(eager_blur.toHost(), want_blur));
+            EXPECT(same_bits(eager_edges.toHost(), want_edges));
+        }
+        check(zg_graph_destroy(graph));
+        check(zg_release_graph_scratch());
+        src.gaussianBlur(eager_blur, big_sigma); // and the library is still in working order afterwards
+        EXPECT(same_bits(eager_blur.toHost(), want_blur));
+    }
+
+    std::printf(failures ? "%d FAILED\n" : "device image ok\n", failures);
+    return failures ? 1 : 0;
+}

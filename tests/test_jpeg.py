@@ -517,3 +517,22 @@ def test_encode_files_byte_for_byte(oracle):
     with pytest.raises(zg.CodecError) as e:
         zg.jpeg.encode(zg.Image(torch.zeros((0, 5, 3), dtype=torch.uint8, device="cuda")))
     assert e.value.name == "InvalidImageDimensions"
+
+
+def test_header_beyond_the_limits_sizes_no_allocation():
+    """A 20-byte header declaring 65535 x 65535 x 3 used to force a 12.9 GB zero-filled image before the decode refused it
+    (jpeg.zig's limits run on the header, :19-33): the mirror now looks at the effective limits before it allocates."""
+    import struct
+    import tracemalloc
+
+    data = bytearray(J.pil_jpeg(J.test_image(16, 16)))
+    at = data.index(b"\xff\xc0")
+    data[at + 5:at + 9] = struct.pack(">HH", 65535, 65535)
+    tracemalloc.start()
+    try:
+        with pytest.raises(Exception):
+            zg.jpeg.load_from_bytes(bytes(data), device=None)  # ImageTooLarge on a GPU box; no device at all here
+        peak = tracemalloc.get_traced_memory()[1]
+    finally:
+        tracemalloc.stop()
+    assert peak < 64 << 20, peak

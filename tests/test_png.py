@@ -449,3 +449,32 @@ def test_encode_files(oracle):
     g = rng.random((9, 14), dtype=np.float32)
     png = zg.png.encode(zg.Image(torch.from_numpy(g).cuda()))
     assert np.array_equal(oracle.png_decode_native(png)[0], oracle.convert(g, oracle.CS_GRAY, oracle.CS_RGB, np.uint8, 3))
+
+
+def test_scan_size_arithmetic_is_checked_like_the_reference(oracle):
+    """png.zig:229-245: scanDataLength / adam7TotalSize use std.math.add / std.math.mul and return error.ImageTooLarge. With every
+    limit disabled a crafted IHDR (gray16, 2147516415 x 4294901762) used to wrap the byte count to 196606: a buffer of that size
+    and a de-filter walk of 4e9 bytes per row past it. It must be refused before anything is sized."""
+    import struct
+    import zlib
+
+    def png_with_ihdr(w, h, depth, ctype, interlace):
+        ihdr = P.chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace))
+        return b"\x89PNG\r\n\x1a\n" + ihdr + P.chunk(b"IDAT", zlib.compress(b"\0" * 64)) + P.chunk(b"IEND")
+
+    off = zg.png.decode_limits(max_png_bytes=0, max_chunk_bytes=0, max_idat_bytes=0, max_chunks=0, max_width=0, max_height=0, max_pixels=0,
+                               max_decompressed_bytes=0)
+    cases = [(2147516415, 4294901762, 16, 0, 0),   # the advisor's reproducer: (2 w + 1) h wraps to 196606
+             (0xFFFFFFFF, 0xFFFFFFFF, 16, 6, 0),   # 8 bytes per pixel: row bytes * rows leaves 64 bits
+             (0xFFFFFFFF, 0xFFFFFFFF, 16, 6, 1)]   # and the Adam7 sum of passes
+    for w, h, depth, ctype, inter in cases:
+        data = png_with_ihdr(w, h, depth, ctype, inter)
+        assert outcome(zg.png.scan_hash, data, off) == ("err", "ImageTooLarge"), (w, h, inter)
+        assert outcome(zg.png.decode, data, off) == ("err", "ImageTooLarge")
+        olim = oracle.png_limits(**{k: 0 for k in ("max_png_bytes", "max_chunk_bytes", "max_idat_bytes", "max_chunks", "max_width", "max_height",
+                                                    "max_pixels", "max_decompressed_bytes")}) if hasattr(oracle, "png_limits") else None
+        if olim is not None:
+            assert outcome(oracle.png_scan_hash, data, olim) == ("err", "ImageTooLarge")
+    # a large but representable size is still only refused by its limit, not by the arithmetic
+    ok = png_with_ihdr(70000, 70000, 8, 0, 0)
+    assert outcome(zg.png.scan_hash, ok, zg.png.decode_limits(max_width=0, max_height=0, max_pixels=0, max_decompressed_bytes=1 << 20)) == ("err", "ImageTooLarge")

@@ -55,6 +55,25 @@ pub const c = struct {
     pub extern fn zg_free(dev_ptr: ?*anyopaque) c_int;
     pub extern fn zg_memcpy_h2d(dst_dev: *anyopaque, src_host: *const anyopaque, bytes: usize, stream: ?*anyopaque) c_int;
     pub extern fn zg_memcpy_d2h(dst_host: *anyopaque, src_dev: *const anyopaque, bytes: usize, stream: ?*anyopaque) c_int;
+    pub extern fn zg_set_device(device: c_int) c_int;
+    pub extern fn zg_get_device(device: *c_int) c_int;
+    pub extern fn zg_malloc_host(host_ptr: *?*anyopaque, bytes: usize) c_int;
+    pub extern fn zg_free_host(host_ptr: ?*anyopaque) c_int;
+    pub extern fn zg_memcpy_h2d_async(dst_dev: *anyopaque, src_host: *const anyopaque, bytes: usize, stream: ?*anyopaque) c_int;
+    pub extern fn zg_memcpy_d2h_async(dst_host: *anyopaque, src_dev: *const anyopaque, bytes: usize, stream: ?*anyopaque) c_int;
+    pub extern fn zg_image_upload(dst_dev: *const ZgImage, src_host: *const ZgImage, stream: ?*anyopaque) c_int;
+    pub extern fn zg_image_download(dst_host: *const ZgImage, src_dev: *const ZgImage, stream: ?*anyopaque) c_int;
+    pub extern fn zg_stream_wait_event(stream: ?*anyopaque, event: ?*anyopaque) c_int;
+    pub extern fn zg_event_create(out: *?*anyopaque) c_int;
+    pub extern fn zg_event_destroy(event: ?*anyopaque) c_int;
+    pub extern fn zg_event_record(event: ?*anyopaque, stream: ?*anyopaque) c_int;
+    pub extern fn zg_event_synchronize(event: ?*anyopaque) c_int;
+    pub extern fn zg_event_elapsed_ms(start: ?*anyopaque, stop: ?*anyopaque, ms: *f32) c_int;
+    pub extern fn zg_graph_begin_capture(stream: ?*anyopaque) c_int;
+    pub extern fn zg_graph_end_capture(stream: ?*anyopaque, out: *?*anyopaque) c_int;
+    pub extern fn zg_graph_launch(graph: ?*anyopaque, stream: ?*anyopaque) c_int;
+    pub extern fn zg_graph_destroy(graph: ?*anyopaque) c_int;
+    pub extern fn zg_release_graph_scratch() c_int;
     pub extern fn zg_stream_create(out: *?*anyopaque) c_int;
     pub extern fn zg_stream_destroy(stream: ?*anyopaque) c_int;
     pub extern fn zg_stream_synchronize(stream: ?*anyopaque) c_int;
@@ -458,6 +477,222 @@ pub fn Image(comptime T: type) type {
         }
     };
 }
+
+/// `Image(T)` whose pixels live in HBM: the device-resident face of the drop-in. The reference's `Image(T)` owns host memory
+/// from a std.mem.Allocator (src/image.zig:124-134, deinit :173); this one owns a zg_malloc block and a stream to order its
+/// work on. Methods have the reference's names and argument meaning but call the stream-taking entry points (zg_<op>, no
+/// `_host`): they return as soon as the work is enqueued, and a chain such as the CLI's `pipeline [blur, resize]`
+/// (src/cli/pipeline.zig:153-179) keeps every intermediate image on the GPU — PCIe is crossed once on the way in
+/// (`upload` / `fromHost`) and once on the way out (`download` / `toHost`). Zig's own maths still makes every number
+/// that depends on it (Gaussian taps with @exp, @cos / @sin of rotation angles, the sRGB table with std.math.pow).
+/// Allocator parameters are kept where the reference has them so call sites do not change; they allocate host scratch only
+/// (tap arrays), never pixels.
+pub fn DeviceImage(comptime T: type) type {
+    return struct {
+        const Self = @This();
+        rows: u32 = 0,
+        cols: u32 = 0,
+        stride: usize = 0,
+        data: ?*anyopaque = null, // device pointer: never dereferenced on the host
+        stream: ?*anyopaque = null, // zg_stream; null = the default stream
+        owned: bool = false,
+
+        fn desc(self: Self) c.ZgImage {
+            return .{ .data = self.data, .stride = self.stride, .rows = self.rows, .cols = self.cols, .pixel = @intFromEnum(pixelOf(T)) };
+        }
+        fn hostDesc(img: zignal.Image(T)) c.ZgImage {
+            return .{ .data = @ptrCast(img.data.ptr), .stride = img.stride, .rows = img.rows, .cols = img.cols, .pixel = @intFromEnum(pixelOf(T)) };
+        }
+
+        /// reference src/image.zig:124-134, in HBM
+        pub fn init(rows: u32, cols: u32, stream: ?*anyopaque) !Self {
+            var p: ?*anyopaque = null;
+            try check(c.zg_malloc(&p, @as(usize, rows) * cols * @sizeOf(T)));
+            return .{ .rows = rows, .cols = cols, .stride = cols, .data = p, .stream = stream, .owned = true };
+        }
+        /// reference src/image.zig:173
+        pub fn deinit(self: *Self) void {
+            if (self.owned) _ = c.zg_free(self.data); // waits for work that still uses the block
+            self.* = .{};
+        }
+        pub fn fromHost(host: zignal.Image(T), stream: ?*anyopaque) !Self {
+            var img = try init(host.rows, host.cols, stream);
+            errdefer img.deinit();
+            try img.upload(host);
+            return img;
+        }
+        /// one trip across PCIe, strides honoured on both sides; complete on return
+        pub fn upload(self: Self, host: zignal.Image(T)) !void {
+            try check(c.zg_image_upload(&self.desc(), &hostDesc(host), self.stream));
+        }
+        /// waits for the stream's work on this image, then one trip back
+        pub fn download(self: Self, host: zignal.Image(T)) !void {
+            try check(c.zg_image_download(&hostDesc(host), &self.desc(), self.stream));
+        }
+        pub fn toHost(self: Self, allocator: std.mem.Allocator) !zignal.Image(T) {
+            const host: zignal.Image(T) = try .init(allocator, self.rows, self.cols);
+            errdefer host.deinit(allocator);
+            try self.download(host);
+            return host;
+        }
+        pub fn synchronize(self: Self) !void {
+            try check(c.zg_stream_synchronize(self.stream));
+        }
+        /// reference src/image.zig:332-352 (non-owning)
+        pub fn view(self: Self, rect: Rectangle(u32)) Self {
+            const l = rect.l;
+            const t = rect.t;
+            const r = @min(rect.r, self.cols);
+            const b = @min(rect.b, self.rows);
+            if (l >= r or t >= b) return .{ .stream = self.stream };
+            const offset = (@as(usize, t) * self.stride + l) * @sizeOf(T);
+            return .{ .rows = b - t, .cols = r - l, .stride = self.stride, .data = @ptrFromInt(@intFromPtr(self.data.?) + offset), .stream = self.stream, .owned = false };
+        }
+        pub fn hasSameShape(self: Self, other: anytype) bool {
+            return self.rows == other.rows and self.cols == other.cols;
+        }
+
+        /// reference src/image.zig:935-951
+        pub fn convolveSeparable(self: Self, out: Self, allocator: std.mem.Allocator, kernel_x: []const f32, kernel_y: []const f32, border: BorderMode) !void {
+            _ = allocator;
+            if (!self.hasSameShape(out)) return error.DimensionMismatch;
+            try check(c.zg_conv_separable(&self.desc(), &out.desc(), kernel_x.ptr, @intCast(kernel_x.len), kernel_y.ptr, @intCast(kernel_y.len), @intFromEnum(border), self.stream));
+        }
+        /// reference src/image.zig:954-994 — taps built here with Zig's @exp (the library copies them before returning)
+        pub fn gaussianBlur(self: Self, out: Self, allocator: std.mem.Allocator, sigma: f32) !void {
+            if (!self.hasSameShape(out)) return error.DimensionMismatch;
+            if (sigma == 0) return check(c.zg_copy(&self.desc(), &out.desc(), self.stream));
+            if (sigma < 0) return error.InvalidSigma;
+            const radius: usize = @ceil(3.0 * sigma);
+            const kernel = try allocator.alloc(f32, 2 * radius + 1);
+            defer allocator.free(kernel);
+            var sum: f32 = 0;
+            for (kernel, 0..) |*k, i| {
+                const x = @as(f32, @floatFromInt(i)) - @as(f32, @floatFromInt(radius));
+                k.* = @exp(-(x * x) / (2.0 * sigma * sigma));
+                sum += k.*;
+            }
+            for (kernel) |*k| k.* /= sum;
+            try self.convolveSeparable(out, allocator, kernel, kernel, .mirror);
+        }
+        /// reference src/image.zig:917-932
+        pub fn convolve(self: Self, out: Self, allocator: std.mem.Allocator, kernel: anytype, border: BorderMode) !void {
+            _ = allocator;
+            if (!self.hasSameShape(out)) return error.DimensionMismatch;
+            const kh = kernel.len;
+            const kw = kernel[0].len;
+            var flat: [kh * kw]f32 = undefined;
+            inline for (0..kh) |r| inline for (0..kw) |cc| {
+                flat[r * kw + cc] = zignal.meta.as(f32, kernel[r][cc]);
+            };
+            try check(c.zg_convolve(&self.desc(), &out.desc(), &flat, kh, kw, @intFromEnum(border), self.stream));
+        }
+        /// reference src/image.zig:635-648
+        pub fn boxBlur(self: Self, out: Self, allocator: std.mem.Allocator, radius: u32) !void {
+            _ = allocator;
+            if (!self.hasSameShape(out)) return error.DimensionMismatch;
+            try check(c.zg_box_blur(&self.desc(), &out.desc(), radius, self.stream));
+        }
+        /// reference src/image.zig:1001-1010
+        pub fn sobel(self: Self, out: DeviceImage(u8), allocator: std.mem.Allocator) !void {
+            _ = allocator;
+            if (!self.hasSameShape(out)) return error.DimensionMismatch;
+            try check(c.zg_sobel(&self.desc(), &out.desc(), self.stream));
+        }
+        /// reference src/image.zig:1047-1063
+        pub fn canny(self: Self, out: DeviceImage(u8), allocator: std.mem.Allocator, sigma: f32, low_threshold: f32, high_threshold: f32) !void {
+            _ = allocator;
+            if (!self.hasSameShape(out)) return error.DimensionMismatch;
+            if (!std.math.isFinite(sigma) or !std.math.isFinite(low_threshold) or !std.math.isFinite(high_threshold)) return error.InvalidParameter;
+            if (sigma < 0) return error.InvalidSigma;
+            if (low_threshold < 0 or high_threshold < 0 or low_threshold >= high_threshold) return error.InvalidThreshold;
+            try check(c.zg_canny(&self.desc(), &out.desc(), sigma, low_threshold, high_threshold, self.stream));
+        }
+        /// reference src/image.zig:523-525
+        pub fn resize(self: Self, out: Self, allocator: std.mem.Allocator, method: Interpolation) void {
+            _ = allocator;
+            check(c.zg_resize(&self.desc(), &out.desc(), &methodOf(method, null), self.stream)) catch unreachable;
+        }
+        /// reference src/image.zig:530-541
+        pub fn scale(self: Self, allocator: std.mem.Allocator, factor: f32, method: Interpolation) !Self {
+            if (factor <= 0) return error.InvalidScaleFactor;
+            const new_rows: u32 = @round(@as(f32, @floatFromInt(self.rows)) * factor);
+            const new_cols: u32 = @round(@as(f32, @floatFromInt(self.cols)) * factor);
+            if (new_rows == 0 or new_cols == 0) return error.InvalidDimensions;
+            const scaled = try init(new_rows, new_cols, self.stream);
+            self.resize(scaled, allocator, method);
+            return scaled;
+        }
+        /// reference src/image.zig:546-548
+        pub fn letterbox(self: Self, out: Self, allocator: std.mem.Allocator, method: Interpolation) Rectangle(u32) {
+            _ = allocator;
+            var r: [4]u32 = undefined;
+            check(c.zg_letterbox(&self.desc(), &out.desc(), &methodOf(method, null), &r, self.stream)) catch unreachable;
+            return .init(r[0], r[1], r[2], r[3]);
+        }
+        /// reference src/image.zig:621-623
+        pub fn warp(self: Self, out: Self, transform: anytype, method: Interpolation) void {
+            const Tr = @TypeOf(transform);
+            if (@hasField(Tr, "bias")) {
+                const m = [6]f32{ transform.matrix.items[0][0], transform.matrix.items[0][1], transform.matrix.items[1][0], transform.matrix.items[1][1], transform.bias.items[0][0], transform.bias.items[1][0] };
+                check(c.zg_warp(&self.desc(), &out.desc(), 1, &m, &methodOf(method, null), self.stream)) catch unreachable;
+            } else {
+                var m: [9]f32 = undefined;
+                inline for (0..3) |r| inline for (0..3) |cc| {
+                    m[r * 3 + cc] = transform.matrix.items[r][cc];
+                };
+                check(c.zg_warp(&self.desc(), &out.desc(), 2, &m, &methodOf(method, null), self.stream)) catch unreachable;
+            }
+        }
+        /// reference src/image.zig:566-568 — @cos / @sin evaluated in Zig
+        pub fn rotateInto(self: Self, out: Self, angle: f32, method: Interpolation, border: BorderMode) void {
+            check(c.zg_rotate_into(&self.desc(), &out.desc(), angle, @cos(angle), @sin(angle), &methodOf(method, null), @intFromEnum(border), self.stream)) catch unreachable;
+        }
+        /// reference src/image.zig:593-595
+        pub fn extract(self: Self, out: Self, rect: Rectangle(f32), angle: f32, method: Interpolation, border: BorderMode) void {
+            const r = [4]f32{ rect.l, rect.t, rect.r, rect.b };
+            check(c.zg_extract(&self.desc(), &out.desc(), &r, angle, @cos(angle), @sin(angle), &methodOf(method, null), @intFromEnum(border), self.stream)) catch unreachable;
+        }
+        /// reference src/image.zig:582-584
+        pub fn crop(self: Self, allocator: std.mem.Allocator, rectangle: Rectangle(f32)) !Self {
+            _ = allocator;
+            const chip_rows: u32 = @round(rectangle.height());
+            const chip_cols: u32 = @round(rectangle.width());
+            const chip = try init(chip_rows, chip_cols, self.stream);
+            self.extract(chip, rectangle, 0, .nearest, .zero);
+            return chip;
+        }
+        /// reference src/image.zig:187-196
+        pub fn fill(self: Self, value: T) void {
+            check(c.zg_fill(&self.desc(), &value, self.stream)) catch unreachable;
+        }
+        /// reference src/image/transforms.zig:28-44
+        pub fn flipLeftRight(self: Self) void {
+            check(c.zg_flip_left_right(&self.desc(), self.stream)) catch unreachable;
+        }
+        pub fn flipTopBottom(self: Self) void {
+            check(c.zg_flip_top_bottom(&self.desc(), self.stream)) catch unreachable;
+        }
+        /// reference src/image.zig:396-407
+        pub fn convertInto(self: Self, comptime Target: type, out: DeviceImage(Target)) void {
+            const lut = srgbLut();
+            const src_space: c_int = switch (pixelOf(T)) { .u8, .f32 => 0, .rgb_u8, .rgb_f32 => 1, .rgba_u8, .rgba_f32 => 2 };
+            const dst_space: c_int = comptime if (Target == u8 or Target == f32) 0 else switch (Target.space) {
+                .gray => 0, .rgb => 1, .rgba => 2, .oklab => 3, .xyz => 4, .ycbcr => 5,
+                else => @compileError("colour space not on the GPU hot path"),
+            };
+            check(c.zg_convert(&self.desc(), src_space, &out.desc(), dst_space, &lut, self.stream)) catch unreachable;
+        }
+        /// reference src/image.zig:418-422
+        pub fn convert(self: Self, allocator: std.mem.Allocator, comptime Target: type) !DeviceImage(Target) {
+            _ = allocator;
+            const result = try DeviceImage(Target).init(self.rows, self.cols, self.stream);
+            self.convertInto(Target, result);
+            return result;
+        }
+    };
+}
+
 
 /// PNG through the library (reference src/codecs/png.zig): the chunk layer, inflate / deflate and de-filtering run on the
 /// host inside libzignal_hip.so, unpacking / conversion / row filtering on the MI355X. The library reports the reference's

@@ -107,6 +107,25 @@ _SIGNATURES = {
     "zg_free": [C.c_void_p],
     "zg_memcpy_h2d": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
     "zg_memcpy_d2h": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+    "zg_set_device": [C.c_int],
+    "zg_get_device": [C.POINTER(C.c_int)],
+    "zg_malloc_host": [C.POINTER(C.c_void_p), C.c_size_t],
+    "zg_free_host": [C.c_void_p],
+    "zg_memcpy_h2d_async": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+    "zg_memcpy_d2h_async": [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+    "zg_image_upload": [_IMG, _IMG, C.c_void_p],
+    "zg_image_download": [_IMG, _IMG, C.c_void_p],
+    "zg_stream_wait_event": [C.c_void_p, C.c_void_p],
+    "zg_event_create": [C.POINTER(C.c_void_p)],
+    "zg_event_destroy": [C.c_void_p],
+    "zg_event_record": [C.c_void_p, C.c_void_p],
+    "zg_event_synchronize": [C.c_void_p],
+    "zg_event_elapsed_ms": [C.c_void_p, C.c_void_p, _F32P],
+    "zg_graph_begin_capture": [C.c_void_p],
+    "zg_graph_end_capture": [C.c_void_p, C.POINTER(C.c_void_p)],
+    "zg_graph_launch": [C.c_void_p, C.c_void_p],
+    "zg_graph_destroy": [C.c_void_p],
+    "zg_release_graph_scratch": [],
     "zg_stream_create": [C.POINTER(C.c_void_p)],
     "zg_stream_destroy": [C.c_void_p],
     "zg_stream_synchronize": [C.c_void_p],

@@ -5,9 +5,19 @@
 // src/image.zig (line numbers per method). Zig error unions become exceptions:
 //   error.DimensionMismatch -> zignal::DimensionMismatch, error.InvalidSigma / InvalidScaleFactor /
 //   InvalidDimensions -> zignal::InvalidArgument, error.OutOfMemory -> std::bad_alloc.
-// Header only; link with -lzignal_hip. Host pixels (std::vector-backed or borrowed), synchronous calls through
-// the zg_<op>_host entry points, exactly like the reference's synchronous CPU methods.
+// Header only; link with -lzignal_hip.
+//
+// Two image classes share one set of methods (detail::Ops, written once):
+//   Image<T>        pixels in host memory (std::vector-backed or borrowed). Every call is synchronous and crosses
+//                   PCIe twice (zg_<op>_host), exactly like calling the reference's CPU method — the drop-in for code
+//                   that touches pixels between calls.
+//   DeviceImage<T>  pixels in HBM (zg_malloc), a stream to order work on. Calls go to the stream-taking entry points
+//                   (zg_<op>) and return as soon as the work is enqueued; a chain such as the CLI's
+//                   `pipeline [blur, resize]` (reference src/cli/pipeline.zig:153-179) keeps its intermediate images
+//                   on the GPU and crosses PCIe once on the way in (upload / fromHost) and once on the way out
+//                   (download / toHost). This is the one that runs at the measured kernel rates.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -15,6 +25,7 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/zignal_hip.h"
@@ -68,20 +79,227 @@ struct Interpolation {                                                          
 template <typename T> struct Rectangle { T l, t, r, b; T width() const { return l >= r ? T(0) : r - l; } T height() const { return t >= b ? T(0) : b - t; } };
 struct ProjectiveTransform { float m[9]; };                                              // geometry/transforms.zig:197
 
-// Image(T): rows, cols, stride (pixels), data — owning (init) or borrowed (initFromSlice / view).
-template <typename T> class Image {
+// A HIP stream owned by the caller; DeviceImage work is ordered on one. The default-constructed handle is the default stream.
+class Stream {
+  public:
+    Stream() = default;
+    static Stream create() { Stream s; check(zg_stream_create(&s.s_)); s.owned_ = true; return s; }
+    Stream(Stream &&o) noexcept : s_(o.s_), owned_(o.owned_) { o.s_ = nullptr; o.owned_ = false; }
+    Stream &operator=(Stream &&o) noexcept { if (this != &o) { release(); s_ = o.s_; owned_ = o.owned_; o.s_ = nullptr; o.owned_ = false; } return *this; }
+    Stream(const Stream &) = delete;
+    Stream &operator=(const Stream &) = delete;
+    ~Stream() { release(); }
+    zg_stream handle() const { return s_; }
+    void synchronize() const { check(zg_stream_synchronize(s_)); }
+  private:
+    void release() { if (owned_ && s_) (void)zg_stream_destroy(s_); s_ = nullptr; owned_ = false; }
+    zg_stream s_ = nullptr;
+    bool owned_ = false;
+};
+
+template <typename T> class Image;
+template <typename T> class DeviceImage;
+
+namespace detail {
+
+// Every hot-path method of Image(T), written once. `run(dev_fn, host_fn, args...)` calls zg_<op>(args..., stream) for a
+// DeviceImage and zg_<op>_host(args...) for an Image; `Of<U>` is the same kind of image with pixel type U.
+template <template <typename> class Img, typename T> class Ops {
+    using Derived = Img<T>;
+    template <typename U> using Of = Img<U>;
+    const Derived &self() const { return static_cast<const Derived &>(*this); }
+    template <class DevFn, class HostFn, class... A> void run(DevFn dev, HostFn host, A... a) const {
+        if constexpr (Derived::on_device) check(dev(a..., self().stream()));
+        else check(host(a...));
+    }
+
   public:
     uint32_t rows = 0, cols = 0;
     size_t stride = 0;
-    T *data = nullptr;
+    T *data = nullptr; // host pointer (Image) or device pointer (DeviceImage): never dereference the latter on the host
+
+    template <class O> bool hasSameShape(const O &o) const { return rows == o.rows && cols == o.cols; }
+    bool isContiguous() const { return cols == stride; }
+    zg_image desc() const { return zg_image{(void *)data, stride, rows, cols, PixelTraits<T>::pixel}; }
+
+    // ---- filters ----
+    void convolveSeparable(const Derived &out, const std::vector<float> &kx, const std::vector<float> &ky, BorderMode border) const { // image.zig:935
+        if (!hasSameShape(out)) throw DimensionMismatch(1, "convolveSeparable");
+        const zg_image s = desc(), d = out.desc();
+        run(zg_conv_separable, zg_conv_separable_host, &s, &d, kx.data(), (uint32_t)kx.size(), ky.data(), (uint32_t)ky.size(), (int)border);
+    }
+    void gaussianBlur(const Derived &out, float sigma) const {                           // image.zig:954
+        if (!hasSameShape(out)) throw DimensionMismatch(1, "gaussianBlur");
+        const zg_image s = desc(), d = out.desc();
+        run(zg_gaussian_blur, zg_gaussian_blur_host, &s, &d, sigma);
+    }
+    template <size_t KH, size_t KW> void convolve(const Derived &out, const float (&kernel)[KH][KW], BorderMode border) const { // image.zig:917
+        if (!hasSameShape(out)) throw DimensionMismatch(1, "convolve");
+        const zg_image s = desc(), d = out.desc();
+        run(zg_convolve, zg_convolve_host, &s, &d, &kernel[0][0], (uint32_t)KH, (uint32_t)KW, (int)border);
+    }
+    void boxBlur(const Derived &out, uint32_t radius) const {                            // image.zig:635
+        if (!hasSameShape(out)) throw DimensionMismatch(1, "boxBlur");
+        const zg_image s = desc(), d = out.desc();
+        run(zg_box_blur, zg_box_blur_host, &s, &d, radius);
+    }
+    void medianBlur(const Derived &out, uint32_t radius) const {                          // image.zig:653
+        if (!hasSameShape(out)) throw DimensionMismatch(1, "medianBlur");
+        const zg_image s = desc(), d = out.desc();
+        run(zg_order_statistic_blur, zg_order_statistic_blur_host, &s, &d, radius, 0, 0.5, (int)ZG_BORDER_MIRROR);
+    }
+    void equalize() const { const zg_image s = desc(); run(zg_equalize, zg_equalize_host, &s); } // image.zig:824 (in place)
+    void sharpen(const Derived &out, uint32_t radius) const {                             // image.zig:785
+        if (!hasSameShape(out)) throw DimensionMismatch(1, "sharpen");
+        const zg_image s = desc(), d = out.desc();
+        run(zg_sharpen, zg_sharpen_host, &s, &d, radius);
+    }
+    void invert() const { const zg_image s = desc(); run(zg_invert, zg_invert_host, &s); }  // image.zig:494 (in place)
+    Of<uint8_t> sobel() const {                                                          // image.zig:1001 (out allocated here)
+        auto out = Of<uint8_t>::like(self(), rows, cols);
+        const zg_image s = desc(), d = out.desc();
+        run(zg_sobel, zg_sobel_host, &s, &d);
+        return out;
+    }
+    void canny(const Of<uint8_t> &out, float sigma, float low_threshold, float high_threshold) const {      // image.zig:1047
+        if (rows != out.rows || cols != out.cols) throw DimensionMismatch(1, "canny");
+        const zg_image s = desc(), d = out.desc();
+        run(zg_canny, zg_canny_host, &s, &d, sigma, low_threshold, high_threshold);
+    }
+    struct ShenCastan { float smooth = 0.9f; uint32_t window_size = 7; float high_ratio = 0.99f, low_rel = 0.5f; bool hysteresis = true, use_nms = false; }; // ShenCastan.zig:9-32
+    void shenCastan(const Of<uint8_t> &out, const ShenCastan &o = {}) const {            // image.zig:1015
+        if (rows != out.rows || cols != out.cols) throw DimensionMismatch(1, "shenCastan");
+        const zg_image s = desc(), d = out.desc();
+        run(zg_shen_castan, zg_shen_castan_host, &s, &d, o.smooth, o.window_size, o.high_ratio, o.low_rel, o.hysteresis ? 1 : 0, o.use_nms ? 1 : 0);
+    }
+    void motionBlurLinear(const Derived &out, float angle, uint32_t distance) const {    // image.zig:1077 (.linear)
+        if (!hasSameShape(out)) throw DimensionMismatch(1, "motionBlur");
+        const zg_image s = desc(), d = out.desc();
+        run(zg_motion_blur_linear, zg_motion_blur_linear_host, &s, &d, angle, std::cos(angle), std::sin(angle), distance);
+    }
+    void motionBlurRadial(const Derived &out, float center_x, float center_y, float strength, bool spin) const {  // (.radial_zoom / .radial_spin)
+        if (!hasSameShape(out)) throw DimensionMismatch(1, "motionBlur");
+        const zg_image s = desc(), d = out.desc();
+        run(zg_motion_blur_radial, zg_motion_blur_radial_host, &s, &d, center_x, center_y, strength, spin ? 1 : 0);
+    }
+    // ---- resampling ----
+    void resize(const Derived &out, Interpolation method) const {                        // image.zig:523
+        const zg_image s = desc(), d = out.desc(); const zg_method m = method.c_method();
+        run(zg_resize, zg_resize_host, &s, &d, &m);
+    }
+    Derived scale(float factor, Interpolation method) const {                            // image.zig:530
+        if (factor <= 0) throw InvalidArgument(2, "InvalidScaleFactor");
+        const uint32_t nr = (uint32_t)std::round((float)rows * factor), nc = (uint32_t)std::round((float)cols * factor);
+        if (nr == 0 || nc == 0) throw InvalidArgument(2, "InvalidDimensions");
+        Derived out = Derived::like(self(), nr, nc);
+        resize(out, method);
+        return out;
+    }
+    Rectangle<uint32_t> letterbox(const Derived &out, Interpolation method) const {      // image.zig:546
+        const zg_image s = desc(), d = out.desc(); const zg_method m = method.c_method();
+        uint32_t r[4];
+        run(zg_letterbox, zg_letterbox_host, &s, &d, &m, r);
+        return {r[0], r[1], r[2], r[3]};
+    }
+    void warp(const Derived &out, const ProjectiveTransform &t, Interpolation method) const { // image.zig:621
+        const zg_image s = desc(), d = out.desc(); const zg_method m = method.c_method();
+        run(zg_warp, zg_warp_host, &s, &d, (int)ZG_TRANSFORM_PROJECTIVE, t.m, &m);
+    }
+    void rotateInto(const Derived &out, float angle, Interpolation method, BorderMode border) const { // image.zig:566
+        const zg_image s = desc(), d = out.desc(); const zg_method m = method.c_method();
+        run(zg_rotate_into, zg_rotate_into_host, &s, &d, angle, std::cos(angle), std::sin(angle), &m, (int)border);
+    }
+    Derived rotate(float angle, Interpolation method, BorderMode border) const {         // image.zig:558
+        uint32_t r, c;
+        check(zg_rotate_bounds(rows, cols, angle, std::cos(angle), std::sin(angle), &r, &c));
+        Derived out = Derived::like(self(), r, c);
+        rotateInto(out, angle, method, border);
+        return out;
+    }
+    void extract(const Derived &out, Rectangle<float> rect, float angle, Interpolation method, BorderMode border) const { // image.zig:593
+        const zg_image s = desc(), d = out.desc(); const zg_method m = method.c_method();
+        const float r[4] = {rect.l, rect.t, rect.r, rect.b};
+        run(zg_extract, zg_extract_host, &s, &d, r, angle, std::cos(angle), std::sin(angle), &m, (int)border);
+    }
+    Derived crop(Rectangle<float> rect) const {                                          // image.zig:582
+        const float r[4] = {rect.l, rect.t, rect.r, rect.b};
+        uint32_t nr, nc;
+        check(zg_crop_dims(r, &nr, &nc));
+        Derived out = Derived::like(self(), nr, nc);
+        const zg_image s = desc(), d = out.desc();
+        run(zg_crop, zg_crop_host, &s, &d, r);
+        return out;
+    }
+    void fill(const T &value) const { const zg_image s = desc(); run(zg_fill, zg_fill_host, &s, (const void *)&value); } // image.zig:187
+    void setBorder(Rectangle<uint32_t> rect, const T &value) const {                      // image.zig:200
+        const zg_image s = desc();
+        const uint32_t r[4] = {rect.l, rect.t, rect.r, rect.b};
+        run(zg_set_border, zg_set_border_host, &s, r, (const void *)&value);
+    }
+    void flipLeftRight() const { const zg_image s = desc(); run(zg_flip_left_right, zg_flip_left_right_host, &s); }   // transforms.zig:28
+    void flipTopBottom() const { const zg_image s = desc(); run(zg_flip_top_bottom, zg_flip_top_bottom_host, &s); }   // transforms.zig:36
+    // ---- colour ----
+    template <typename Target> void convertInto(const Of<Target> &out) const {          // image.zig:396
+        const zg_image s = desc(), d = out.desc();
+        run(zg_convert, zg_convert_host, &s, (int)PixelTraits<T>::space, &d, (int)PixelTraits<Target>::space, (const float *)nullptr);
+    }
+    template <typename Target> Of<Target> convert() const {                              // image.zig:418
+        Of<Target> out = Of<Target>::like(self(), rows, cols);
+        convertInto<Target>(out);
+        return out;
+    }
+    // ---- file output (src/codecs/jpeg.zig:307, src/codecs/png.zig:1400); the file lands in host memory either way ----
+    std::vector<uint8_t> encodeJpeg(const zg_jpeg_encode_options *options = nullptr) const {
+        uint8_t *mem = nullptr;
+        size_t n = 0;
+        const zg_image s = desc();
+        run(zg_jpeg_encode, zg_jpeg_encode_host, &s, (int)PixelTraits<T>::space, options, &mem, &n);
+        std::vector<uint8_t> out(mem, mem + n);
+        zg_jpeg_free(mem);
+        return out;
+    }
+    std::vector<uint8_t> encodePng(const zg_png_encode_options *options = nullptr) const {
+        uint8_t *mem = nullptr;
+        size_t n = 0;
+        const zg_image s = desc();
+        run(zg_png_encode, zg_png_encode_host, &s, (int)PixelTraits<T>::space, options, &mem, &n);
+        std::vector<uint8_t> out(mem, mem + n);
+        zg_png_free(mem);
+        return out;
+    }
+};
+
+} // namespace detail
+
+// Image(T): rows, cols, stride (pixels), data — owning (init) or borrowed (initFromSlice / view), in host memory.
+template <typename T> class Image : public detail::Ops<Image, T> {
+    using Base = detail::Ops<Image, T>;
+
+  public:
+    static constexpr bool on_device = false;
+    using Base::rows; using Base::cols; using Base::stride; using Base::data;
 
     Image() = default;
+    Image(Image &&o) noexcept { *this = std::move(o); }
+    Image &operator=(Image &&o) noexcept {
+        rows = o.rows; cols = o.cols; stride = o.stride; data = o.data; owned_ = std::move(o.owned_); // a moved vector keeps its buffer
+        o.rows = o.cols = 0; o.stride = 0; o.data = nullptr;
+        return *this;
+    }
+    Image(const Image &o) { *this = o; }
+    Image &operator=(const Image &o) { // an owning image is copied with its pixels, a borrowed one stays a borrow
+        if (this == &o) return *this;
+        rows = o.rows; cols = o.cols; stride = o.stride; owned_ = o.owned_;
+        data = o.owned_.empty() ? o.data : owned_.data() + (o.data - o.owned_.data());
+        return *this;
+    }
     static Image init(uint32_t rows, uint32_t cols) {                                    // image.zig:124-134
         Image im;
         im.owned_.resize((size_t)rows * cols);
         im.rows = rows; im.cols = cols; im.stride = cols; im.data = im.owned_.data();
         return im;
     }
+    template <class Proto> static Image like(const Proto &, uint32_t rows, uint32_t cols) { return init(rows, cols); }
     static Image initFromSlice(uint32_t rows, uint32_t cols, T *data) {                  // image.zig:161-170
         Image im; im.rows = rows; im.cols = cols; im.stride = cols; im.data = data; return im;
     }
@@ -92,138 +310,10 @@ template <typename T> class Image {
         v.rows = b - t; v.cols = r - l; v.stride = stride; v.data = data + (size_t)t * stride + l;
         return v;
     }
-    bool hasSameShape(const Image &o) const { return rows == o.rows && cols == o.cols; }
-    bool isContiguous() const { return cols == stride; }
     T &at(size_t r, size_t c) const { return data[r * stride + c]; }                     // image.zig:426-430
+    zg_stream stream() const { return nullptr; }
 
-    // ---- filters ----
-    void convolveSeparable(const Image &out, const std::vector<float> &kx, const std::vector<float> &ky, BorderMode border) const { // image.zig:935
-        if (!hasSameShape(out)) throw DimensionMismatch(1, "convolveSeparable");
-        const zg_image s = desc(), d = out.desc();
-        check(zg_conv_separable_host(&s, &d, kx.data(), (uint32_t)kx.size(), ky.data(), (uint32_t)ky.size(), (int)border));
-    }
-    void gaussianBlur(const Image &out, float sigma) const {                             // image.zig:954
-        if (!hasSameShape(out)) throw DimensionMismatch(1, "gaussianBlur");
-        const zg_image s = desc(), d = out.desc();
-        check(zg_gaussian_blur_host(&s, &d, sigma));
-    }
-    template <size_t KH, size_t KW> void convolve(const Image &out, const float (&kernel)[KH][KW], BorderMode border) const { // image.zig:917
-        if (!hasSameShape(out)) throw DimensionMismatch(1, "convolve");
-        const zg_image s = desc(), d = out.desc();
-        check(zg_convolve_host(&s, &d, &kernel[0][0], (uint32_t)KH, (uint32_t)KW, (int)border));
-    }
-    void boxBlur(const Image &out, uint32_t radius) const {                              // image.zig:635
-        if (!hasSameShape(out)) throw DimensionMismatch(1, "boxBlur");
-        const zg_image s = desc(), d = out.desc();
-        check(zg_box_blur_host(&s, &d, radius));
-    }
-    void medianBlur(const Image &out, uint32_t radius) const {                            // image.zig:653
-        if (!hasSameShape(out)) throw DimensionMismatch(1, "medianBlur");
-        const zg_image s = desc(), d = out.desc();
-        check(zg_order_statistic_blur_host(&s, &d, radius, 0, 0.5, ZG_BORDER_MIRROR));
-    }
-    void equalize() const { const zg_image s = desc(); check(zg_equalize_host(&s)); }     // image.zig:824 (in place)
-    void sharpen(const Image &out, uint32_t radius) const {                               // image.zig:785
-        if (!hasSameShape(out)) throw DimensionMismatch(1, "sharpen");
-        const zg_image s = desc(), d = out.desc();
-        check(zg_sharpen_host(&s, &d, radius));
-    }
-    void invert() const { const zg_image s = desc(); check(zg_invert_host(&s)); }        // image.zig:494 (in place)
-    Image<uint8_t> sobel() const {                                                       // image.zig:1001 (out allocated here)
-        auto out = Image<uint8_t>::init(rows, cols);
-        const zg_image s = desc(), d = out.desc();
-        check(zg_sobel_host(&s, &d));
-        return out;
-    }
-    void canny(const Image<uint8_t> &out, float sigma, float low_threshold, float high_threshold) const {   // image.zig:1047
-        if (rows != out.rows || cols != out.cols) throw DimensionMismatch(1, "canny");
-        const zg_image s = desc(), d = out.desc();
-        check(zg_canny_host(&s, &d, sigma, low_threshold, high_threshold));
-    }
-    struct ShenCastan { float smooth = 0.9f; uint32_t window_size = 7; float high_ratio = 0.99f, low_rel = 0.5f; bool hysteresis = true, use_nms = false; }; // ShenCastan.zig:9-32
-    void shenCastan(const Image<uint8_t> &out, const ShenCastan &o = {}) const {         // image.zig:1015
-        if (rows != out.rows || cols != out.cols) throw DimensionMismatch(1, "shenCastan");
-        const zg_image s = desc(), d = out.desc();
-        check(zg_shen_castan_host(&s, &d, o.smooth, o.window_size, o.high_ratio, o.low_rel, o.hysteresis ? 1 : 0, o.use_nms ? 1 : 0));
-    }
-    void motionBlurLinear(const Image &out, float angle, uint32_t distance) const {     // image.zig:1077 (.linear)
-        if (!hasSameShape(out)) throw DimensionMismatch(1, "motionBlur");
-        const zg_image s = desc(), d = out.desc();
-        check(zg_motion_blur_linear_host(&s, &d, angle, std::cos(angle), std::sin(angle), distance));
-    }
-    void motionBlurRadial(const Image &out, float center_x, float center_y, float strength, bool spin) const {   // (.radial_zoom / .radial_spin)
-        if (!hasSameShape(out)) throw DimensionMismatch(1, "motionBlur");
-        const zg_image s = desc(), d = out.desc();
-        check(zg_motion_blur_radial_host(&s, &d, center_x, center_y, strength, spin ? 1 : 0));
-    }
-    // ---- resampling ----
-    void resize(const Image &out, Interpolation method) const {                          // image.zig:523
-        const zg_image s = desc(), d = out.desc(); const zg_method m = method.c_method();
-        check(zg_resize_host(&s, &d, &m));
-    }
-    Image scale(float factor, Interpolation method) const {                              // image.zig:530
-        if (factor <= 0) throw InvalidArgument(2, "InvalidScaleFactor");
-        const uint32_t nr = (uint32_t)std::round((float)rows * factor), nc = (uint32_t)std::round((float)cols * factor);
-        if (nr == 0 || nc == 0) throw InvalidArgument(2, "InvalidDimensions");
-        Image out = init(nr, nc);
-        resize(out, method);
-        return out;
-    }
-    Rectangle<uint32_t> letterbox(const Image &out, Interpolation method) const {        // image.zig:546
-        const zg_image s = desc(), d = out.desc(); const zg_method m = method.c_method();
-        uint32_t r[4];
-        check(zg_letterbox_host(&s, &d, &m, r));
-        return {r[0], r[1], r[2], r[3]};
-    }
-    void warp(const Image &out, const ProjectiveTransform &t, Interpolation method) const { // image.zig:621
-        const zg_image s = desc(), d = out.desc(); const zg_method m = method.c_method();
-        check(zg_warp_host(&s, &d, ZG_TRANSFORM_PROJECTIVE, t.m, &m));
-    }
-    void rotateInto(const Image &out, float angle, Interpolation method, BorderMode border) const { // image.zig:566
-        const zg_image s = desc(), d = out.desc(); const zg_method m = method.c_method();
-        check(zg_rotate_into_host(&s, &d, angle, std::cos(angle), std::sin(angle), &m, (int)border));
-    }
-    Image rotate(float angle, Interpolation method, BorderMode border) const {           // image.zig:558
-        uint32_t r, c;
-        check(zg_rotate_bounds(rows, cols, angle, std::cos(angle), std::sin(angle), &r, &c));
-        Image out = init(r, c);
-        rotateInto(out, angle, method, border);
-        return out;
-    }
-    void extract(const Image &out, Rectangle<float> rect, float angle, Interpolation method, BorderMode border) const { // image.zig:593
-        const zg_image s = desc(), d = out.desc(); const zg_method m = method.c_method();
-        const float r[4] = {rect.l, rect.t, rect.r, rect.b};
-        check(zg_extract_host(&s, &d, r, angle, std::cos(angle), std::sin(angle), &m, (int)border));
-    }
-    Image crop(Rectangle<float> rect) const {                                            // image.zig:582
-        const float r[4] = {rect.l, rect.t, rect.r, rect.b};
-        uint32_t nr, nc;
-        check(zg_crop_dims(r, &nr, &nc));
-        Image out = init(nr, nc);
-        const zg_image s = desc(), d = out.desc();
-        check(zg_crop_host(&s, &d, r));
-        return out;
-    }
-    void fill(const T &value) const { const zg_image s = desc(); check(zg_fill_host(&s, &value)); } // image.zig:187
-    void setBorder(Rectangle<uint32_t> rect, const T &value) const {                      // image.zig:200
-        const zg_image s = desc();
-        const uint32_t r[4] = {rect.l, rect.t, rect.r, rect.b};
-        check(zg_set_border_host(&s, r, &value));
-    }
-    void flipLeftRight() const { const zg_image s = desc(); check(zg_flip_left_right_host(&s)); }   // transforms.zig:28
-    void flipTopBottom() const { const zg_image s = desc(); check(zg_flip_top_bottom_host(&s)); }   // transforms.zig:36
-    // ---- colour ----
-    template <typename Target> void convertInto(const Image<Target> &out) const {       // image.zig:396
-        const zg_image s = desc(), d = out.desc();
-        check(zg_convert_host(&s, PixelTraits<T>::space, &d, PixelTraits<Target>::space, nullptr));
-    }
-    template <typename Target> Image<Target> convert() const {                           // image.zig:418
-        Image<Target> out = Image<Target>::init(rows, cols);
-        convertInto(out);
-        return out;
-    }
-
-    // ---- file I/O (image.zig:239-287: the format comes from the signature; src/codecs/png.zig, src/codecs/jpeg.zig) ----
+    // ---- file input (image.zig:239-287: the format comes from the signature; src/codecs/png.zig, src/codecs/jpeg.zig) ----
     static Image loadFromBytes(const uint8_t *bytes, size_t len) {                                          // image.zig:265
         if (len >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) {                                             // jpeg.zig:2825
             zg_jpeg_header h;
@@ -240,29 +330,96 @@ template <typename T> class Image {
         check(zg_png_decode_host(bytes, len, nullptr, &d, PixelTraits<T>::space, nullptr));
         return out;
     }
-    std::vector<uint8_t> encodeJpeg(const zg_jpeg_encode_options *options = nullptr) const {                // jpeg.zig:307
-        uint8_t *mem = nullptr;
-        size_t n = 0;
-        const zg_image s = desc();
-        check(zg_jpeg_encode_host(&s, PixelTraits<T>::space, options, &mem, &n));
-        std::vector<uint8_t> out(mem, mem + n);
-        zg_jpeg_free(mem);
-        return out;
-    }
-    std::vector<uint8_t> encodePng(const zg_png_encode_options *options = nullptr) const {                  // png.zig:1400
-        uint8_t *mem = nullptr;
-        size_t n = 0;
-        const zg_image s = desc();
-        check(zg_png_encode_host(&s, PixelTraits<T>::space, options, &mem, &n));
-        std::vector<uint8_t> out(mem, mem + n);
-        zg_png_free(mem);
-        return out;
-    }
-
-    zg_image desc() const { return zg_image{(void *)data, stride, rows, cols, PixelTraits<T>::pixel}; }
 
   private:
     std::vector<T> owned_;
+};
+
+// Image(T) whose pixels live in HBM. Owning (init / fromHost / results of scale, crop, convert ...) or a non-owning view.
+// Move-only. All methods of detail::Ops enqueue on stream() and return; call synchronize() (or download, which does)
+// before looking at results from the host.
+template <typename T> class DeviceImage : public detail::Ops<DeviceImage, T> {
+    using Base = detail::Ops<DeviceImage, T>;
+
+  public:
+    static constexpr bool on_device = true;
+    using Base::rows; using Base::cols; using Base::stride; using Base::data;
+
+    DeviceImage() = default;
+    DeviceImage(DeviceImage &&o) noexcept { *this = std::move(o); }
+    DeviceImage &operator=(DeviceImage &&o) noexcept {
+        if (this == &o) return *this;
+        deinit();
+        rows = o.rows; cols = o.cols; stride = o.stride; data = o.data; stream_ = o.stream_; owned_ = o.owned_;
+        o.rows = o.cols = 0; o.stride = 0; o.data = nullptr; o.owned_ = nullptr;
+        return *this;
+    }
+    DeviceImage(const DeviceImage &) = delete;
+    DeviceImage &operator=(const DeviceImage &) = delete;
+    ~DeviceImage() { deinit(); }
+
+    static DeviceImage init(uint32_t rows, uint32_t cols, zg_stream stream = nullptr) {  // image.zig:124-134, in HBM
+        DeviceImage im;
+        check(zg_malloc(&im.owned_, (size_t)rows * cols * sizeof(T)));
+        im.rows = rows; im.cols = cols; im.stride = cols; im.data = (T *)im.owned_; im.stream_ = stream;
+        return im;
+    }
+    template <class Proto> static DeviceImage like(const Proto &proto, uint32_t rows, uint32_t cols) { return init(rows, cols, proto.stream()); }
+    void deinit() {                                                                       // image.zig:173
+        if (owned_) (void)zg_free(owned_); // hipFree waits for work that still uses the block
+        owned_ = nullptr; data = nullptr; rows = cols = 0; stride = 0;
+    }
+    static DeviceImage fromHost(const Image<T> &host, zg_stream stream = nullptr) {
+        DeviceImage im = init(host.rows, host.cols, stream);
+        im.upload(host);
+        return im;
+    }
+    void upload(const Image<T> &host) const {   // one trip across PCIe, strides honoured; complete on return
+        const zg_image d = this->desc(), s = host.desc();
+        check(zg_image_upload(&d, &s, stream_));
+    }
+    void download(const Image<T> &host) const { // waits for the stream's work on this image, then one trip back
+        const zg_image d = host.desc(), s = this->desc();
+        check(zg_image_download(&d, &s, stream_));
+    }
+    Image<T> toHost() const {
+        Image<T> out = Image<T>::init(rows, cols);
+        download(out);
+        return out;
+    }
+    DeviceImage view(Rectangle<uint32_t> rect) const {                                   // image.zig:332-352 (non-owning)
+        const uint32_t l = rect.l, t = rect.t, r = std::min(rect.r, cols), b = std::min(rect.b, rows);
+        DeviceImage v;
+        v.stream_ = stream_;
+        if (l >= r || t >= b) return v;
+        v.rows = b - t; v.cols = r - l; v.stride = stride; v.data = data + (size_t)t * stride + l;
+        return v;
+    }
+    zg_stream stream() const { return stream_; }
+    void setStream(zg_stream s) { stream_ = s; }
+    void synchronize() const { check(zg_stream_synchronize(stream_)); }
+
+    // decode a PNG / JPEG file straight into HBM (host: entropy layers; device: everything per pixel)
+    static DeviceImage loadFromBytes(const uint8_t *bytes, size_t len, zg_stream stream = nullptr) {        // image.zig:265
+        if (len >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) {
+            zg_jpeg_header h;
+            check(zg_jpeg_probe(bytes, len, nullptr, &h, nullptr));
+            DeviceImage out = init(h.height, h.width, stream);
+            const zg_image d = out.desc();
+            check(zg_jpeg_decode(bytes, len, nullptr, &d, PixelTraits<T>::space, nullptr, stream));
+            return out;
+        }
+        zg_png_header h;
+        check(zg_png_probe(bytes, len, nullptr, &h, nullptr, nullptr));
+        DeviceImage out = init(h.height, h.width, stream);
+        const zg_image d = out.desc();
+        check(zg_png_decode(bytes, len, nullptr, &d, PixelTraits<T>::space, nullptr, stream));
+        return out;
+    }
+
+  private:
+    void *owned_ = nullptr;
+    zg_stream stream_ = nullptr;
 };
 
 } // namespace zignal

@@ -186,6 +186,10 @@ int zg_convolve(const zg_image *src, const zg_image *dst, const float *kernel, u
 }
 
 int zg_convolve_host(const zg_image *src, const zg_image *dst, const float *kernel, uint32_t kh, uint32_t kw, int border) {
+    if (border != ZG_BORDER_WRAP && kh >= 1) {
+        const int brc = host_banded(src, dst, kh / 2, [&](const zg_image *sv, const zg_image *dv, hipStream_t s) { return convolve_impl(sv, dv, kernel, kh, kw, border, s); });
+        if (brc >= 0) return brc;
+    }
     HostStage a, b;
     int rc;
     if ((rc = a.upload(src, true, false))) return rc;

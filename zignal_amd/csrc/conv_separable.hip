@@ -609,6 +609,12 @@ int zg_conv_separable(const zg_image *src, const zg_image *dst, const float *kx,
 
 int zg_conv_separable_host(const zg_image *src, const zg_image *dst, const float *kx, uint32_t nkx,
                            const float *ky, uint32_t nky, int border) {
+    if (border != ZG_BORDER_WRAP && nky >= 1) { // row-local with a halo of nky / 2 rows: upload, kernel and download overlap band by band
+        const int brc = host_banded(src, dst, nky / 2, [&](const zg_image *sv, const zg_image *dv, hipStream_t s) {
+            return conv_separable_impl(sv, dv, kx, nkx, ky, nky, border, s);
+        });
+        if (brc >= 0) return brc;
+    }
     HostStage a, b;
     int rc;
     if ((rc = a.upload(src, true, false))) return rc;
@@ -654,6 +660,13 @@ int zg_gaussian_blur(const zg_image *src, const zg_image *dst, float sigma, zg_s
 }
 
 int zg_gaussian_blur_host(const zg_image *src, const zg_image *dst, float sigma) {
+    if (sigma > 0) { // gaussianBlur is convolveSeparable(.mirror) with ceil(3 sigma) rows of halo (image.zig:973-994)
+        const int n = zg_gaussian_kernel(sigma, nullptr, 0);
+        if (n > 0) {
+            const int brc = host_banded(src, dst, (uint32_t)n / 2, [&](const zg_image *sv, const zg_image *dv, hipStream_t s) { return gaussian_impl(sv, dv, sigma, s); });
+            if (brc >= 0) return brc;
+        }
+    }
     HostStage a, b;
     int rc;
     if ((rc = a.upload(src, true, false))) return rc;

@@ -233,6 +233,10 @@ int zg_convert(const zg_image *src, int src_space, const zg_image *dst, int dst_
 }
 
 int zg_convert_host(const zg_image *src, int src_space, const zg_image *dst, int dst_space, const float *srgb_lut) {
+    { // per-pixel: no halo at all
+        const int brc = host_banded(src, dst, 0, [&](const zg_image *sv, const zg_image *dv, hipStream_t s) { return convert_impl(sv, src_space, dv, dst_space, srgb_lut, s); });
+        if (brc >= 0) return brc;
+    }
     HostStage a, b;
     int rc;
     if ((rc = a.upload(src, true, false))) return rc;

@@ -1253,6 +1253,8 @@ int encode_impl(const zg_image *src, int src_space, const zg_jpeg_encode_options
     if (src->rows == 0 || src->cols == 0) JPEG_FAIL("InvalidImageDimensions");
     if (src->rows > 65535 || src->cols > 65535) JPEG_FAIL("ImageTooLarge");
     ZG_REQUIRE(opt.subsampling >= 0 && opt.subsampling <= 2, ZG_ERR_INVALID_ARGUMENT, "jpeg encode: subsampling %d (0 yuv444, 1 yuv422, 2 yuv420)", opt.subsampling);
+    // writeSegment's length is a u16 of payload + 2 (:457-462; the reference traps in @intCast beyond it): refuse, never wrap
+    ZG_REQUIRE(!opt.comment || opt.comment_len <= 65533, ZG_ERR_INVALID_ARGUMENT, "jpeg encode: comment of %zu bytes does not fit a COM segment (65533 at most)", opt.comment_len);
     const bool gray = src->pixel == ZG_PIXEL_U8;                         // T == u8 (:321)
     const bool direct = gray || (src->pixel == ZG_PIXEL_RGB_U8 && src_space == ZG_CS_RGB);
     const int hm = gray || opt.subsampling == 0 ? 1 : 2, vm = !gray && opt.subsampling == 2 ? 2 : 1;
@@ -1408,6 +1410,18 @@ int zg_jpeg_encode_blocks(const int16_t *blocks, uint32_t rows, uint32_t cols, i
     if (rows == 0 || cols == 0) JPEG_FAIL("InvalidImageDimensions");
     if (rows > 65535 || cols > 65535) JPEG_FAIL("ImageTooLarge");
     ZG_REQUIRE(opt.subsampling >= 0 && opt.subsampling <= 2, ZG_ERR_INVALID_ARGUMENT, "jpeg encode: subsampling %d (0 yuv444, 1 yuv422, 2 yuv420)", opt.subsampling);
+    ZG_REQUIRE(!opt.comment || opt.comment_len <= 65533, ZG_ERR_INVALID_ARGUMENT, "jpeg encode: comment of %zu bytes does not fit a COM segment (65533 at most)", opt.comment_len);
+    { // caller-made blocks must stay inside what the baseline Huffman tables can code: AC magnitudes of 10 bits, DC
+      // differences of 11 (tables of 11 / 12 size categories; a larger value would index past them)
+        const int hm = gray || opt.subsampling == 0 ? 1 : 2, vm = !gray && opt.subsampling == 2 ? 2 : 1;
+        const size_t mx = ceil_div(cols, 8u * hm), my = ceil_div(rows, 8u * vm), n_blocks = mx * hm * my * vm + (gray ? 0 : 2 * mx * my);
+        for (size_t b = 0; b < n_blocks; ++b) {
+            const int16_t *co = blocks + b * 64;
+            bool ok = co[0] >= -1024 && co[0] <= 1023;
+            for (int i = 1; i < 64; ++i) ok = ok && co[i] >= -1023 && co[i] <= 1023;
+            ZG_REQUIRE(ok, ZG_ERR_INVALID_ARGUMENT, "jpeg encode blocks: block %zu holds a coefficient outside the baseline range (DC -1024..1023, AC -1023..1023)", b);
+        }
+    }
     return no_throw([&]() -> int {
         std::vector<uint8_t> file;
         const int rc = write_file(blocks, rows, cols, gray != 0, opt, &file);

@@ -71,24 +71,41 @@ struct ScanLayout {
     PassGeom pass[7];
     int npass;
     size_t total;
+    bool overflow; // the byte count left usize: error.ImageTooLarge (png.zig:229-245)
 };
 const uint32_t kAdam7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
 
+// scanDataLength / adam7TotalSize (png.zig:219-245): every product and sum is checked (std.math.mul / std.math.add in the
+// reference); a header whose scan data does not fit a usize sets `overflow`, which the chunk layer reports as
+// error.ImageTooLarge before anything is sized from `total`.
 ScanLayout scan_layout(const zg_png_header &h) {
     ScanLayout L{};
-    const size_t bits = (size_t)png_channels(h.color_type) * h.bit_depth;
+    const size_t bits = (size_t)png_channels(h.color_type) * h.bit_depth; // <= 64
+    auto pass_bytes = [&](size_t row_bytes, uint32_t rows, size_t *out) { // (row_bytes + 1) * rows, checked
+        size_t stride;
+        return !__builtin_add_overflow(row_bytes, (size_t)1, &stride) && !__builtin_mul_overflow(stride, (size_t)rows, out);
+    };
     if (h.interlace_method != 1) {
         L.pass[0] = PassGeom{0, 0, 1, 1, h.width, h.height, ((size_t)h.width * bits + 7) / 8, 0};
         L.npass = 1;
-        L.total = (L.pass[0].row_bytes + 1) * h.height;
+        if (!pass_bytes(L.pass[0].row_bytes, h.height, &L.total)) L.overflow = true, L.total = 0;
         return L;
     }
     for (int p = 0; p < 7; ++p) {
         const uint32_t x0 = kAdam7[p][0], y0 = kAdam7[p][1], dx = kAdam7[p][2], dy = kAdam7[p][3];
-        const uint32_t w = h.width > x0 ? (h.width - x0 + dx - 1) / dx : 0, ht = h.height > y0 ? (h.height - y0 + dy - 1) / dy : 0;
+        const uint32_t w = h.width > x0 ? (uint32_t)(((uint64_t)h.width - x0 + dx - 1) / dx) : 0,
+                       ht = h.height > y0 ? (uint32_t)(((uint64_t)h.height - y0 + dy - 1) / dy) : 0;
         PassGeom g{x0, y0, dx, dy, w, ht, ((size_t)w * bits + 7) / 8, L.total};
         if (w == 0 || ht == 0) g.w = g.h = 0; // an empty pass has no bytes at all
-        else L.total += (g.row_bytes + 1) * ht;
+        else {
+            size_t pass_total;
+            if (!pass_bytes(g.row_bytes, ht, &pass_total) || __builtin_add_overflow(L.total, pass_total, &L.total)) {
+                L.overflow = true;
+                L.total = 0;
+                L.npass = 7;
+                return L;
+            }
+        }
         L.pass[p] = g;
     }
     L.npass = 7;
@@ -241,7 +258,9 @@ int read_chunks(const uint8_t *png, size_t len, const zg_png_limits &lim, PngFil
     if (!have_header) PNG_FAIL("MissingHeader");
     if (f->idat.empty()) PNG_FAIL("MissingImageData");
     if (!iend) f->truncated = true;
-    if (over(lim.max_decompressed_bytes, scan_layout(f->header).total)) PNG_FAIL("ImageTooLarge");
+    const ScanLayout L = scan_layout(f->header); // scanDataLength (:787): checked arithmetic, then the limit
+    if (L.overflow) PNG_FAIL("ImageTooLarge");
+    if (over(lim.max_decompressed_bytes, L.total)) PNG_FAIL("ImageTooLarge");
     return ZG_OK;
 }
 

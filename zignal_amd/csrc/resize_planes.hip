@@ -20,6 +20,7 @@
 #include <cstring>
 #include <list>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <tuple>
 #include <vector>
@@ -242,36 +243,53 @@ static void build_axis(int kind, uint32_t src_n, uint32_t dst_n, int taps, std::
 
 // Device-resident tables, cached per (device, kind, src_n, dst_n): repeated resizes of the same geometry
 // (video frames, batches) upload nothing and are graph-capturable after the first call.
-struct AxisBuf { int32_t *dev = nullptr; size_t n = 0; };
+// Lifetime: the cache and every caller that has fetched a table share ownership (shared_ptr). The cache is LRU (a hit
+// moves the entry to the back), eviction only drops the cache's reference, and a caller keeps its reference until its
+// kernel has been launched — so a table that a launch still points at is never freed under it, whatever other host
+// threads insert meanwhile. The last owner's release is a hipFree, which waits for the device: a kernel already in
+// flight finishes before the memory goes away.
+struct AxisBuf {
+    int32_t *dev = nullptr;
+    size_t n = 0;
+    ~AxisBuf() { if (dev) (void)hipFree(dev); }
+};
+typedef std::tuple<int, int, uint32_t, uint32_t> AxisKey;
 static std::mutex g_cache_mu;
-static std::map<std::tuple<int, int, uint32_t, uint32_t>, AxisBuf> g_cache;
-static std::list<std::tuple<int, int, uint32_t, uint32_t>> g_cache_order;
+static std::map<AxisKey, std::pair<std::shared_ptr<AxisBuf>, std::list<AxisKey>::iterator>> g_cache;
+static std::list<AxisKey> g_cache_order; // least recently used first
 
-static int axis_table(int kind, uint32_t src_n, uint32_t dst_n, int taps, AxisTable &out) {
+static int axis_table(int kind, uint32_t src_n, uint32_t dst_n, int taps, AxisTable &out, std::shared_ptr<AxisBuf> &hold) {
     int dev = 0;
     ZG_HIP(hipGetDevice(&dev));
-    const auto key = std::make_tuple(dev, kind, src_n, dst_n);
-    std::lock_guard<std::mutex> lock(g_cache_mu);
-    auto it = g_cache.find(key);
-    if (it == g_cache.end()) {
-        std::vector<int32_t> idx, w;
-        build_axis(kind, src_n, dst_n, taps, idx, w);
-        AxisBuf buf;
-        buf.n = idx.size();
-        ZG_HIP(hipMalloc((void **)&buf.dev, 2 * buf.n * sizeof(int32_t)));
-        if (int rc = upload_pageable(buf.dev, idx.data(), buf.n * sizeof(int32_t), nullptr)) return rc;
-        if (int rc = upload_pageable(buf.dev + buf.n, w.data(), buf.n * sizeof(int32_t), nullptr)) return rc;
-        if (g_cache.size() >= 64) { // bounded: drop the oldest geometry
-            const auto old = g_cache_order.front();
-            g_cache_order.pop_front();
-            (void)hipFree(g_cache[old].dev);
-            g_cache.erase(old);
+    const AxisKey key = std::make_tuple(dev, kind, src_n, dst_n);
+    std::shared_ptr<AxisBuf> evicted; // released after the lock is dropped (hipFree may block)
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mu);
+        auto it = g_cache.find(key);
+        if (it != g_cache.end()) {
+            g_cache_order.splice(g_cache_order.end(), g_cache_order, it->second.second); // most recently used
+            hold = it->second.first;
+        } else {
+            std::vector<int32_t> idx, w;
+            build_axis(kind, src_n, dst_n, taps, idx, w);
+            auto buf = std::make_shared<AxisBuf>(); // frees its device block on every error path below
+            buf->n = idx.size();
+            ZG_HIP(hipMalloc((void **)&buf->dev, 2 * buf->n * sizeof(int32_t)));
+            if (int rc = upload_pageable(buf->dev, idx.data(), buf->n * sizeof(int32_t), nullptr)) return rc;
+            if (int rc = upload_pageable(buf->dev + buf->n, w.data(), buf->n * sizeof(int32_t), nullptr)) return rc;
+            if (g_cache.size() >= 64) { // bounded: the least recently used geometry leaves the cache
+                auto old = g_cache.find(g_cache_order.front());
+                evicted = std::move(old->second.first);
+                g_cache.erase(old);
+                g_cache_order.pop_front();
+            }
+            g_cache_order.push_back(key);
+            g_cache.emplace(key, std::make_pair(buf, std::prev(g_cache_order.end())));
+            hold = buf;
         }
-        it = g_cache.emplace(key, buf).first;
-        g_cache_order.push_back(key);
     }
-    out.idx = it->second.dev;
-    out.w = it->second.dev + it->second.n;
+    out.idx = hold->dev;
+    out.w = hold->dev + hold->n;
     return ZG_OK;
 }
 
@@ -379,10 +397,11 @@ int resize_planes_impl(const zg_image *src, const zg_image *dst, const zg_method
     const int kind = method->kind;
     const int taps = kind == ZG_INTERP_NEAREST ? 1 : (kind == ZG_INTERP_BILINEAR ? 2 : (kind == ZG_INTERP_LANCZOS ? 6 : 4));
     AxisTable tx{}, ty{};
+    std::shared_ptr<AxisBuf> hold_x, hold_y; // keep both tables alive until the kernel below has been launched
     int rc;
     if (kind == ZG_INTERP_LANCZOS) { // the only kernel whose weights need a transcendental: tables from the host
-        if ((rc = axis_table(kind, src->cols, dst->cols, taps, tx))) return rc;
-        if ((rc = axis_table(kind, src->rows, dst->rows, taps, ty))) return rc;
+        if ((rc = axis_table(kind, src->cols, dst->cols, taps, tx, hold_x))) return rc;
+        if ((rc = axis_table(kind, src->rows, dst->rows, taps, ty, hold_y))) return rc;
     }
     if (src->pixel == ZG_PIXEL_RGB_U8) return resize_planes_pix<ZG_PIXEL_RGB_U8>(src, dst, kind, tx, ty, s);
     return resize_planes_pix<ZG_PIXEL_RGBA_U8>(src, dst, kind, tx, ty, s);

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <functional>
 #include <string>
 #include <type_traits>
 
@@ -172,6 +173,12 @@ struct HostStage {
 };
 
 int check_image(const zg_image *im, const char *name, bool device_pointer = true);
+
+// Host images through a row-local device op as a banded, full-duplex pipeline (zg_runtime.cpp): `op` is called once per
+// band with device views (source rows include up to `halo` real neighbour rows on each side) and the stream to launch on.
+// Returns -1 when the call does not qualify (small, overlapping, too few rows): the caller then takes the whole-frame path.
+typedef std::function<int(const zg_image *src_view, const zg_image *dst_view, hipStream_t s)> BandOp;
+int host_banded(const zg_image *src, const zg_image *dst, uint32_t halo, const BandOp &op);
 
 // Pageable host memory -> device memory on stream s, synchronised before returning (zg_runtime.cpp).
 int upload_pageable(void *dst_dev, const void *src_host, size_t bytes, hipStream_t s);

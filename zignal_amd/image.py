@@ -134,7 +134,8 @@ class Image:
         return L.ZgImage(ptr, self.stride, self.rows, self.cols, self.pixel)
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        # the stream of the device that OWNS the pixels, not of whatever device happens to be current
+        return C.c_void_p(torch.cuda.current_stream(self.data.device).cuda_stream)
 
     def _like(self, rows: Optional[int] = None, cols: Optional[int] = None, dtype=None, channels=None) -> "Image":
         rows = self.rows if rows is None else rows
@@ -151,13 +152,17 @@ class Image:
         """Run zg_<name> (device) or zg_<name>_host (host) with the stream appended as needed."""
         lib = L.lib()
         if self.on_device:
-            L.check(getattr(lib, f"zg_{name}")(*args, self._stream()))
+            # scratch, per-device tables and the launch itself follow hipGetDevice(): make the owner current for the call
+            with torch.cuda.device(self.data.device):
+                L.check(getattr(lib, f"zg_{name}")(*args, self._stream()))
         else:
             L.check(getattr(lib, f"zg_{name}_host")(*args))
 
     def _same_side(self, other: "Image"):
         if self.on_device != other.on_device:
             raise ValueError("source and destination must both be host or both be device images")
+        if self.on_device and self.data.device != other.data.device:
+            raise ValueError(f"source is on {self.data.device}, destination on {other.data.device}: one call runs on one device")
 
     @staticmethod
     def _wrap(x) -> "Image":

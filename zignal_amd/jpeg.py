@@ -67,6 +67,13 @@ def load_from_bytes(data: bytes, kind: Optional[str] = None, limits: Optional[L.
     try:  # dimensions only (to allocate the image): every check and limit is the decode's own, below
         header = get_info(data, decode_limits(max_jpeg_bytes=2**62))
         rows, cols, comps = header.height, header.width, header.num_components
+        # a few header bytes must not size a multi-gigabyte allocation the decode is going to refuse anyway: a frame
+        # beyond the effective limits (the caller's, else DecodeLimits{}) gets a 1 x 1 stand-in and the decode below
+        # reports error.ImageTooLarge in its own words, before it ever looks at the destination
+        eff = limits if limits is not None else decode_limits()
+        if ((eff.max_width and cols > eff.max_width) or (eff.max_height and rows > eff.max_height)
+                or (eff.max_pixels and rows * cols > eff.max_pixels)):
+            rows, cols = 1, 1
     except L.CodecError:
         rows, cols, comps = 1, 1, 3  # no readable frame header: let the decode report what is wrong, in its own words
     native = "u8" if comps == 1 else "rgb_u8"

@@ -31,11 +31,13 @@ def shard_sizes(n_frames: int, world: int) -> List[int]:
 
 
 def scatter_frames(batch: Optional[torch.Tensor], n_frames: int, frame_shape: Tuple[int, ...], dtype: torch.dtype,
-                   device: torch.device, root: int = 0) -> torch.Tensor:
+                   device: torch.device, root: int = 0, loopback: bool = False) -> torch.Tensor:
     """Root holds `batch` (n_frames, *frame_shape); every rank returns its own shard (k, *frame_shape).
 
     Implemented as grouped point-to-point sends (ncclSend/ncclRecv == the scatter pattern): each peer link
-    carries one shard, the per-link bound of xGMI, no ring."""
+    carries one shard, the per-link bound of xGMI, no ring. `loopback` sends the root's own shard through the
+    communicator too (a send to and a receive from itself in one group) instead of a device copy: that is how a
+    one-GPU box executes the RCCL path for real."""
     rank, world = dist.get_rank(), dist.get_world_size()
     begin, end = shard_range(n_frames, rank, world)
     mine = torch.empty((end - begin,) + tuple(frame_shape), dtype=dtype, device=device)
@@ -44,7 +46,10 @@ def scatter_frames(batch: Optional[torch.Tensor], n_frames: int, frame_shape: Tu
         ops = []
         for r in range(world):
             b, e = shard_range(n_frames, r, world)
-            if r == root:
+            if r == root and loopback and e > b:
+                ops.append(dist.P2POp(dist.isend, batch[b:e].contiguous(), root))
+                ops.append(dist.P2POp(dist.irecv, mine, root))
+            elif r == root:
                 mine.copy_(batch[b:e])
             elif e > b:
                 ops.append(dist.P2POp(dist.isend, batch[b:e].contiguous(), r))
@@ -57,7 +62,7 @@ def scatter_frames(batch: Optional[torch.Tensor], n_frames: int, frame_shape: Tu
     return mine
 
 
-def gather_frames(shard: torch.Tensor, n_frames: int, root: int = 0) -> Optional[torch.Tensor]:
+def gather_frames(shard: torch.Tensor, n_frames: int, root: int = 0, loopback: bool = False) -> Optional[torch.Tensor]:
     """Inverse of scatter_frames: root returns (n_frames, *frame_shape), the others None."""
     rank, world = dist.get_rank(), dist.get_world_size()
     if rank == root:
@@ -65,7 +70,10 @@ def gather_frames(shard: torch.Tensor, n_frames: int, root: int = 0) -> Optional
         ops = []
         for r in range(world):
             b, e = shard_range(n_frames, r, world)
-            if r == root:
+            if r == root and loopback and e > b:
+                ops.append(dist.P2POp(dist.isend, shard.contiguous(), root))
+                ops.append(dist.P2POp(dist.irecv, out[b:e], root))
+            elif r == root:
                 out[b:e].copy_(shard)
             elif e > b:
                 ops.append(dist.P2POp(dist.irecv, out[b:e], r))
