@@ -57,9 +57,8 @@ int check_image(const zg_image *im, const char *name, bool device_pointer) {
 // 0 in 20 with the pool under PyTorch's bundled runtime. The pool is therefore not used at all, graph capture included.
 //
 // Under stream capture a scratch block has to outlive the call — the captured kernels run at every replay — and nobody
-// else may touch it between replays. Such blocks are "graph-owned": taken from the cache (only blocks whose last use has
-// already completed, so that no event wait needs capturing) or from hipMalloc (with the thread's capture mode switched to
-// relaxed for the duration, as any caching allocator under a global-mode capture has to), and never handed to anybody
+// else may touch it between replays. Such blocks are "graph-owned": taken from hipMalloc (with the thread's capture mode
+// switched to relaxed for the duration, as any caching allocator under a capture has to) and never handed to anybody
 // outside the capture that took them. scratch_free inside the capture makes the block reusable by later calls of the SAME
 // capture on the SAME stream (graph order separates the two uses); after the capture ends the blocks stay reserved until
 // zg_release_graph_scratch(), which the owner of the graphs calls once they are destroyed.
@@ -101,8 +100,6 @@ size_t scratch_round(size_t bytes) {
 }
 
 int scratch_alloc_captured(void **out, size_t need, int dev, unsigned long long id, hipStream_t s) {
-    RelaxedCapture relaxed;
-    CachedBlock take{};
     {
         std::lock_guard<std::mutex> lock(g_scratch_mu);
         for (GraphBlock &g : g_graph_blocks) // a block this capture has already finished with, on this stream
@@ -111,25 +108,18 @@ int scratch_alloc_captured(void **out, size_t need, int dev, unsigned long long 
                 *out = g.p;
                 return ZG_OK;
             }
-        for (size_t i = 0; i < g_scratch_free.size(); ++i) { // a cached block that is idle right now
-            const CachedBlock &b = g_scratch_free[i];
-            if (b.device == dev && b.bytes >= need && b.bytes <= 2 * need && hipEventQuery(b.done) == hipSuccess) {
-                take = b;
-                g_scratch_free.erase(g_scratch_free.begin() + (long)i);
-                break;
-            }
-        }
-        (void)hipGetLastError(); // hipErrorNotReady from hipEventQuery is an answer, not a failure
     }
-    if (take.p) {
-        (void)hipEventDestroy(take.done);
-    } else {
-        ZG_HIP(hipMalloc(&take.p, need));
-        take.bytes = need;
+    // Nothing from the general cache: whether a cached block is idle can only be learnt from its event, and querying an
+    // event invalidates a capture in progress. A capture happens once; a fresh allocation per scratch request is cheap
+    // against that.
+    void *p = nullptr;
+    {
+        RelaxedCapture relaxed;
+        ZG_HIP(hipMalloc(&p, need));
     }
     std::lock_guard<std::mutex> lock(g_scratch_mu);
-    g_graph_blocks.push_back(GraphBlock{take.p, take.bytes, dev, id, s, true});
-    *out = take.p;
+    g_graph_blocks.push_back(GraphBlock{p, need, dev, id, s, true});
+    *out = p;
     return ZG_OK;
 }
 } // namespace
