@@ -14,9 +14,12 @@ if op == "blur_u8":
 elif op == "blur_f32":
     s = zg.Image(torch.rand((R, R, 4), dtype=torch.float32, device="cuda")); d = zg.Image(torch.empty_like(s.data))
     f = lambda: s.gaussian_blur(0.6, out=d)
-elif op == "resize":
-    s = zg.Image(torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")); d = zg.Image(torch.empty((1024, 1024, 4), dtype=torch.uint8, device="cuda"))
-    f = lambda: s.resize(d, I.bilinear)
+elif op == "resize":  # eight distinct sources (512 MiB): past the 256 MiB Infinity Cache
+    ss = [zg.Image(torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")) for _ in range(8)]; d = zg.Image(torch.empty((1024, 1024, 4), dtype=torch.uint8, device="cuda"))
+    it = [0]
+    def f():
+        it[0] += 1
+        ss[it[0] % 8].resize(d, I.bilinear)
 elif op in ("warp_u8", "warp_f32"):
     tr = zg.ProjectiveTransform.from_points([(0, 0), (4095, 0), (0, 4095), (4095, 4095)], [(200, 120), (3900, 60), (90, 3980), (4000, 4050)])
     t = torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda") if op == "warp_u8" else torch.rand((R, R, 4), dtype=torch.float32, device="cuda")

@@ -330,9 +330,11 @@ int host_banded(const zg_image *src, const zg_image *dst, uint32_t halo, const B
         if (s0 < d1 && d0 < s1) return -1;
     }
     const uint32_t rows = src->rows, min_band = halo > 0 ? 2 * halo : 1;
-    size_t want = (bytes_s > bytes_d ? bytes_s : bytes_d) / ((size_t)16 << 20); // ~16 MiB of the larger side per band
+    size_t band_mib = 16; // ~16 MiB of the larger side per band
+    if (const char *e = getenv("ZIGNAL_HIP_BAND_MIB")) { const long v = strtol(e, nullptr, 10); if (v >= 1 && v <= 1024) band_mib = (size_t)v; }
+    size_t want = (bytes_s > bytes_d ? bytes_s : bytes_d) / (band_mib << 20);
     if (want < 4) want = 4;
-    if (want > 48) want = 48;
+    if (want > 96) want = 96;
     uint32_t band = (uint32_t)((rows + want - 1) / want);
     if (band < min_band) band = min_band;
     uint32_t nb = (rows + band - 1) / band;
