@@ -271,3 +271,24 @@ float zo_cosf(float x) {
     default: return k_sindf(y);
     }
 }
+
+/* Element-wise application over arrays (the checker's side of tests/test_math_pin.py). fn as in zg_devmath_apply:
+ * 0 cbrt, 1 pow(x, 2.4), 2 exp, 3 log, 4 sin, 5 cos, 6 atan2(x, y), 7 pow(x, y), 8 gammaToLinear (color.zig:1252-1258). */
+ZO_API int zo_math_apply(int fn, const float *x, const float *y, float *out, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        const float a = x[i];
+        switch (fn) {
+        case 0: out[i] = zo_cbrtf(a); break;
+        case 1: out[i] = zo_powf(a, 2.4f); break;
+        case 2: out[i] = zo_expf(a); break;
+        case 3: out[i] = zo_logf(a); break;
+        case 4: out[i] = zo_sinf(a); break;
+        case 5: out[i] = zo_cosf(a); break;
+        case 6: out[i] = zo_atan2f(a, y[i]); break;
+        case 7: out[i] = zo_powf(a, y[i]); break;
+        case 8: out[i] = a > 0.04045f ? zo_powf((a + 0.055f) / 1.055f, 2.4f) : a / 12.92f; break;
+        default: return -1;
+        }
+    }
+    return 0;
+}

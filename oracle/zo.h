@@ -62,6 +62,7 @@ ZO_API float zo_cosf(float x);
 ZO_API float zo_atanf(float x);
 ZO_API float zo_atan2f(float y, float x);
 ZO_API double zo_pow64(double x, double y);
+ZO_API int zo_math_apply(int fn, const float *x, const float *y, float *out, size_t n); /* element-wise, fn as in zg_devmath_apply */
 
 /* colorspaces.c — <Space>(T).to(target) for every float colour space (src/color.zig), fields in declaration order */
 ZO_API void zo_color_to_f32(int from, const float in[4], int to, float out[4]);

@@ -74,6 +74,7 @@ pub const c = struct {
     pub extern fn zg_graph_launch(graph: ?*anyopaque, stream: ?*anyopaque) c_int;
     pub extern fn zg_graph_destroy(graph: ?*anyopaque) c_int;
     pub extern fn zg_release_graph_scratch() c_int;
+    pub extern fn zg_devmath_apply(func: c_int, x_dev: [*]const f32, y_dev: ?[*]const f32, out_dev: [*]f32, n: usize, stream: ?*anyopaque) c_int;
     pub extern fn zg_stream_create(out: *?*anyopaque) c_int;
     pub extern fn zg_stream_destroy(stream: ?*anyopaque) c_int;
     pub extern fn zg_stream_synchronize(stream: ?*anyopaque) c_int;

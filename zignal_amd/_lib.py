@@ -126,6 +126,7 @@ _SIGNATURES = {
     "zg_graph_launch": [C.c_void_p, C.c_void_p],
     "zg_graph_destroy": [C.c_void_p],
     "zg_release_graph_scratch": [],
+    "zg_devmath_apply": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
     "zg_stream_create": [C.POINTER(C.c_void_p)],
     "zg_stream_destroy": [C.c_void_p],
     "zg_stream_synchronize": [C.c_void_p],

@@ -14,6 +14,7 @@
 // For float-typed RGB sources gammaToLinear needs pow on the device: restated below (exp/log based, as Zig's
 // port of Go's Pow); like the oracle's it is parity-unpinned against real Zig at the last ulp.
 #include "zg_common.h"
+#include <algorithm>
 #include "zg_hostmath.h"
 #include "zg_devmath.h"
 
@@ -222,6 +223,26 @@ static int convert_impl(const zg_image *src, int src_space, const zg_image *dst,
     return rc;
 }
 
+
+__global__ __launch_bounds__(256) void k_devmath_apply(int fn, const float *x, const float *y, float *out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float a = x[i];
+        float r;
+        switch (fn) { // wave-uniform
+        case 0: r = dev_cbrtf(a); break;
+        case 1: r = dev_pow_2p4(a); break;
+        case 2: r = dev_expf(a); break;
+        case 3: r = dev_logf(a); break;
+        case 4: r = dev_sinf(a); break;
+        case 5: r = dev_cosf(a); break;
+        case 6: r = dev_atan2f(a, y[i]); break;
+        case 7: r = dev_powf(a, y[i]); break;
+        default: r = dev_gamma_to_linear(a); break;
+        }
+        out[i] = r;
+    }
+}
+
 } // namespace zg
 
 using namespace zg;
@@ -244,6 +265,21 @@ int zg_convert_host(const zg_image *src, int src_space, const zg_image *dst, int
     if ((rc = convert_impl(&a.dev, src_space, &b.dev, dst_space, srgb_lut, nullptr))) return rc;
     ZG_HIP(hipStreamSynchronize(nullptr));
     return b.finish();
+}
+
+
+// Diagnostics: the device's own maths functions (zg_devmath.h) applied element-wise to device arrays, so that the
+// transcendental boundary of DESIGN.md section 4 can be swept densely against the oracle's restatement (tests/test_math_pin.py).
+// fn: 0 cbrt, 1 pow(x, 2.4), 2 exp, 3 log, 4 sin, 5 cos, 6 atan2(x, y), 7 pow(x, y), 8 gammaToLinear. y may be NULL for unary fn.
+int zg_devmath_apply(int fn, const float *x_dev, const float *y_dev, float *out_dev, size_t n, zg_stream stream) {
+    ZG_REQUIRE(fn >= 0 && fn <= 8, ZG_ERR_INVALID_ARGUMENT, "zg_devmath_apply: unknown function %d", fn);
+    ZG_REQUIRE((x_dev && out_dev) || n == 0, ZG_ERR_INVALID_ARGUMENT, "zg_devmath_apply: null array");
+    ZG_REQUIRE((fn != 6 && fn != 7) || y_dev || n == 0, ZG_ERR_INVALID_ARGUMENT, "zg_devmath_apply: function %d needs y", fn);
+    if (n == 0) return ZG_OK;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_devmath_apply, dim3(blocks), dim3(256), 0, as_stream(stream), fn, x_dev, y_dev, out_dev, n);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
 }
 
 } // extern "C"
