@@ -210,6 +210,16 @@ ZG_API int zg_box_blur_host(const zg_image *src, const zg_image *dst, uint32_t r
 ZG_API int zg_resize(const zg_image *src, const zg_image *dst, const zg_method *method, zg_stream stream);
 ZG_API int zg_resize_host(const zg_image *src, const zg_image *dst, const zg_method *method);
 
+/* Image(Rgb(u8) / Rgba(u8)).resize(.lanczos) = resizePlaneLanczosU8 (src/image/channel_ops.zig:438-493) with the plane weights
+ * made by the CALLER: the reference evaluates lanczosKernel with @sin for every destination column and row (:446-466), so a Zig
+ * host computes wx[d * 6 + k] = lanczosKernel((k - 2) - frac((d + 0.5) * src_cols / dst_cols - 0.5)) for d < dst.cols, k < 6 (and wy
+ * likewise over rows) with Zig's own @sin and hands them over; the library supplies only the integer tap indices and the f32
+ * accumulation. Host pointers in both layers; NULL takes the library's own weights for that axis (zg_lanczos_plane_weights, which is
+ * also what zg_resize uses). Pixel types other than RGB_U8 / RGBA_U8: ZG_ERR_UNSUPPORTED (they go through zg_method.lanczos_lut). */
+ZG_API int zg_lanczos_plane_weights(uint32_t src_n, uint32_t dst_n, float *weights /* dst_n * 6 */);
+ZG_API int zg_resize_lanczos_weights(const zg_image *src, const zg_image *dst, const float *wx, const float *wy, zg_stream stream);
+ZG_API int zg_resize_lanczos_weights_host(const zg_image *src, const zg_image *dst, const float *wx, const float *wy);
+
 /* Image(T).letterbox (src/image.zig:546 -> src/image/transforms.zig:49-108). Writes the content
  * rectangle {l,t,r,b} to rect_out (may be NULL). */
 ZG_API int zg_letterbox(const zg_image *src, const zg_image *dst, const zg_method *method,

@@ -51,6 +51,46 @@ def test_resize_parity(oracle, kind, mname):
     assert not base.any()
 
 
+@pytest.mark.parametrize("kind", ("rgb_u8", "rgba_u8"))
+def test_resize_lanczos_with_caller_made_plane_weights(oracle, kind):
+    """resizePlaneLanczosU8's weights come from @sin (channel_ops.zig:446-454): a caller may supply its own (R6). The library's own
+    weights reproduce the default path and the oracle; perturbed weights are followed exactly (checked against a plain f32
+    restatement of the 6 x 6 accumulation, channel_ops.zig:468-489), on both layers."""
+    f32 = np.float32
+    for (sr, sc), (dr, dc) in (((37, 53), (19, 71)), ((64, 64), (16, 16)), ((9, 14), (30, 5))):
+        src = synth(oracle, kind, 33, sr, sc)
+        wx, wy = zg.lanczos_plane_weights(sc, dc), zg.lanczos_plane_weights(sr, dr)
+        want = oracle.resize(src, (dr, dc), om(oracle, I.lanczos))
+        assert_bits_equal(sync(dev(src).resize((dr, dc), I.lanczos, lanczos_weights=(wx, wy))), want, f"{kind} library weights {sr}x{sc}")
+        assert_bits_equal(zg.Image(src).resize((dr, dc), I.lanczos, lanczos_weights=(wx, wy)).data, want, f"{kind} library weights, host layer")
+    # a caller whose sin differs: weights rounded to 12 bits of significand
+    sr, sc, dr, dc = 11, 13, 6, 9
+    src = synth(oracle, kind, 34, sr, sc)
+    q = lambda w: (np.round(w.astype(np.float64) * 4096) / 4096).astype(f32)
+    wx, wy = q(zg.lanczos_plane_weights(sc, dc)), q(zg.lanczos_plane_weights(sr, dr))
+    got = sync(dev(src).resize((dr, dc), I.lanczos, lanczos_weights=(wx, wy)))
+    mirror = lambda i, n: int(oracle.resolve_index(i, n, oracle.MIRROR))
+    rx, ry = f32(sc) / f32(dc), f32(sr) / f32(dr)
+    want = np.zeros_like(got)
+    for r in range(dr):
+        y0 = int(np.floor(f32(f32(f32(r) + f32(0.5)) * ry) - f32(0.5)))
+        for c in range(dc):
+            x0 = int(np.floor(f32(f32(f32(c) + f32(0.5)) * rx) - f32(0.5)))
+            for ch in range(src.shape[2]):
+                acc, wsum = f32(0), f32(0)
+                for ky in range(6):
+                    py = mirror(y0 + ky - 2, sr)
+                    for kx in range(6):
+                        w = f32(wx[c, kx] * wy[r, ky])
+                        acc = f32(acc + f32(f32(src[py, mirror(x0 + kx - 2, sc), ch]) * w))
+                        wsum = f32(wsum + w)
+                val = f32(acc / wsum) if wsum != 0 else f32(0)
+                want[r, c, ch] = int(oracle.lib().zo_clamp_u8_f32(float(val)))
+    assert_bits_equal(got, want, f"{kind} caller-made weights")
+    with pytest.raises(zg.ZignalError):  # the plane kernels are the Rgb(u8) / Rgba(u8) path only
+        dev(synth(oracle, "u8", 1, 8, 8)).resize((4, 4), I.lanczos, lanczos_weights=(zg.lanczos_plane_weights(8, 4), zg.lanczos_plane_weights(8, 4)))
+
+
 def test_resize_known_answers(oracle):
     # channel_ops.zig:144-190 at ratio 4: floor of the mean of the 2x2 block at (4d+1, 4d+2)
     src = oracle.synth_u8(3, (64, 64, 4))

@@ -1,6 +1,8 @@
 """The reference unit tests that the other oracle test files had not yet transcribed (found by listing every `test "..."` of
 src/image/tests/*.zig against the file:line citations in tests/): boxBlur and sharpen properties, the integral-image helpers,
 letterbox with every interpolation, the Shen-Castan property tests, and the container operations of Image(T). CPU only."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -176,3 +178,31 @@ def test_color_known_answers_luma_invert_union_clamping(oracle):
     assert g.tolist() == [[0, 255]]
     rgb = oracle.convert(np.array([[[1.2, -0.2, 0.5]]], np.float32), oracle.CS_RGB, oracle.CS_RGB, np.uint8, 3)
     assert rgb.tolist() == [[[255, 0, 128]]]
+
+
+def test_lanczos_plane_weights_follow_channel_ops(oracle):
+    """zg_lanczos_plane_weights (what zg_resize uses, and what a Zig host replaces with its own @sin): lanczosKernel of
+    channel_ops.zig:446-454 at (k - 2) - frac((d + 0.5) ratio - 0.5), every step in f32, sin from the oracle's restatement."""
+    import zignal_amd as zg
+
+    l = oracle.lib()
+    l.zo_sinf.restype = ctypes.c_float
+    l.zo_sinf.argtypes = [ctypes.c_float]
+    f32 = np.float32
+
+    def kernel(x):
+        if x == 0:
+            return f32(1.0)
+        if abs(x) >= 3:
+            return f32(0.0)
+        pi_x = f32(np.pi) * x
+        return f32(f32(f32(f32(3.0) * f32(l.zo_sinf(float(pi_x)))) * f32(l.zo_sinf(float(f32(pi_x / f32(3.0)))))) / f32(pi_x * pi_x))
+
+    for src_n, dst_n in ((16, 5), (7, 23), (4096, 1024), (100, 100)):
+        got = zg.lanczos_plane_weights(src_n, dst_n)
+        ratio = f32(src_n) / f32(dst_n)
+        for d in list(range(min(dst_n, 40))) + [dst_n - 1]:
+            s = f32(f32(f32(d) + f32(0.5)) * ratio) - f32(0.5)
+            f = f32(s - np.floor(s))
+            want = [kernel(f32(f32(k - 2) - f)) for k in range(6)]
+            assert [w.tobytes() for w in want] == [w.tobytes() for w in got[d]], (src_n, dst_n, d, want, got[d])

@@ -75,6 +75,9 @@ pub const c = struct {
     pub extern fn zg_graph_destroy(graph: ?*anyopaque) c_int;
     pub extern fn zg_release_graph_scratch() c_int;
     pub extern fn zg_devmath_apply(func: c_int, x_dev: [*]const f32, y_dev: ?[*]const f32, out_dev: [*]f32, n: usize, stream: ?*anyopaque) c_int;
+    pub extern fn zg_lanczos_plane_weights(src_n: u32, dst_n: u32, weights: [*]f32) c_int;
+    pub extern fn zg_resize_lanczos_weights(src: *const ZgImage, dst: *const ZgImage, wx: ?[*]const f32, wy: ?[*]const f32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_resize_lanczos_weights_host(src: *const ZgImage, dst: *const ZgImage, wx: ?[*]const f32, wy: ?[*]const f32) c_int;
     pub extern fn zg_stream_create(out: *?*anyopaque) c_int;
     pub extern fn zg_stream_destroy(stream: ?*anyopaque) c_int;
     pub extern fn zg_stream_synchronize(stream: ?*anyopaque) c_int;
@@ -200,6 +203,29 @@ fn srgbLut() [256]f32 {
         v.* = if (cc > 0.04045) std.math.pow(f32, (cc + 0.055) / 1.055, 2.4) else cc / 12.92;
     }
     return lut;
+}
+
+/// lanczosKernel of resizePlaneLanczosU8 (reference src/image/channel_ops.zig:446-454), evaluated with Zig's own @sin.
+fn lanczosPlaneKernel(x: f32) f32 {
+    if (x == 0) return 1.0;
+    const a = 3.0;
+    if (@abs(x) >= a) return 0.0;
+    const pi_x = std.math.pi * x;
+    return (a * @sin(pi_x) * @sin(pi_x / a)) / (pi_x * pi_x);
+}
+/// The six plane weights of every destination index of one axis (channel_ops.zig:456-466), for zg_resize_lanczos_weights.
+fn lanczosPlaneWeights(allocator: std.mem.Allocator, src_n: u32, dst_n: u32) ![]f32 {
+    const w = try allocator.alloc(f32, @as(usize, dst_n) * 6);
+    const ratio = @as(f32, @floatFromInt(src_n)) / @as(f32, @floatFromInt(dst_n));
+    for (0..dst_n) |d| {
+        const s = (@as(f32, @floatFromInt(d)) + 0.5) * ratio - 0.5;
+        const f = s - @floor(s);
+        for (0..6) |k| w[d * 6 + k] = lanczosPlaneKernel(@as(f32, @floatFromInt(@as(isize, @intCast(k)) - 2)) - f);
+    }
+    return w;
+}
+fn isRgbU8(comptime T: type) bool {
+    return T == zignal.Rgb(u8) or T == zignal.Rgba(u8);
 }
 
 /// Drop-in for zignal.Image(T) on the hot path. Fields and non-hot-path methods are zignal's own.
@@ -369,7 +395,19 @@ pub fn Image(comptime T: type) type {
 
         /// reference src/image.zig:523-525 (void: never fails; a HIP failure is a programming error here)
         pub fn resize(self: Self, out: Self, allocator: std.mem.Allocator, method: Interpolation) void {
-            _ = allocator;
+            if (comptime isRgbU8(T)) {
+                if (method == .lanczos and (self.base.rows != out.base.rows or self.base.cols != out.base.cols) and self.base.rows > 0 and self.base.cols > 0 and out.base.rows > 0 and out.base.cols > 0) {
+                    // the plane kernel's weights come from @sin (channel_ops.zig:446-454): made here, in Zig
+                    if (lanczosPlaneWeights(allocator, self.base.cols, out.base.cols)) |wx| {
+                        defer allocator.free(wx);
+                        if (lanczosPlaneWeights(allocator, self.base.rows, out.base.rows)) |wy| {
+                            defer allocator.free(wy);
+                            check(c.zg_resize_lanczos_weights_host(&desc(self.base), &desc(out.base), wx.ptr, wy.ptr)) catch unreachable;
+                            return;
+                        } else |_| {}
+                    } else |_| {}
+                }
+            }
             check(c.zg_resize_host(&desc(self.base), &desc(out.base), &methodOf(method, null))) catch unreachable;
         }
 
@@ -611,7 +649,18 @@ pub fn DeviceImage(comptime T: type) type {
         }
         /// reference src/image.zig:523-525
         pub fn resize(self: Self, out: Self, allocator: std.mem.Allocator, method: Interpolation) void {
-            _ = allocator;
+            if (comptime isRgbU8(T)) {
+                if (method == .lanczos and (self.rows != out.rows or self.cols != out.cols) and self.rows > 0 and self.cols > 0 and out.rows > 0 and out.cols > 0) {
+                    if (lanczosPlaneWeights(allocator, self.cols, out.cols)) |wx| {
+                        defer allocator.free(wx);
+                        if (lanczosPlaneWeights(allocator, self.rows, out.rows)) |wy| {
+                            defer allocator.free(wy);
+                            check(c.zg_resize_lanczos_weights(&self.desc(), &out.desc(), wx.ptr, wy.ptr, self.stream)) catch unreachable;
+                            return;
+                        } else |_| {}
+                    } else |_| {}
+                }
+            }
             check(c.zg_resize(&self.desc(), &out.desc(), &methodOf(method, null), self.stream)) catch unreachable;
         }
         /// reference src/image.zig:530-541

@@ -33,6 +33,8 @@ int copy_impl(const zg_image *src, const zg_image *dst, hipStream_t s);
 int fill_outside_impl(const zg_image *img, const void *pixel_value, int l, int t, int r, int b, hipStream_t s);
 int set_border_impl(const zg_image *img, const uint32_t rect[4], const void *pixel_value, hipStream_t s);
 int resize_planes_impl(const zg_image *src, const zg_image *dst, const zg_method *method, hipStream_t s);
+int resize_lanczos_weights_impl(const zg_image *src, const zg_image *dst, const float *wx, const float *wy, hipStream_t s);
+void lanczos_plane_weights(uint32_t src_n, uint32_t dst_n, float *w);
 
 enum : int { GEOM_RESIZE = 0, GEOM_PROJECTIVE = 1, GEOM_AFFINE = 2, GEOM_ROTATE = 3, GEOM_EXTRACT = 4 };
 
@@ -202,6 +204,21 @@ int resize_impl(const zg_image *src, const zg_image *dst, const zg_method *metho
     g.p[0] = (float)src->cols / (float)dst->cols;
     g.p[1] = (float)src->rows / (float)dst->rows;
     return launch_geom(src, dst, g, method, ZG_BORDER_MIRROR, s);
+}
+
+// Image(Rgb(u8) / Rgba(u8)).resize(.lanczos) with the caller's plane weights (channel_ops.zig:438-493)
+static int resize_lanczos_weights_checked(const zg_image *src, const zg_image *dst, const float *wx, const float *wy, hipStream_t s) {
+    int rc;
+    if ((rc = check_pair(src, dst, "resize"))) return rc;
+    ZG_REQUIRE(src->pixel == ZG_PIXEL_RGB_U8 || src->pixel == ZG_PIXEL_RGBA_U8, ZG_ERR_UNSUPPORTED,
+               "resize with Lanczos plane weights is the Rgb(u8) / Rgba(u8) path; other pixel types interpolate through zg_method.lanczos_lut");
+    if (dst->rows == 0 || dst->cols == 0) return ZG_OK;
+    if (src->rows == dst->rows && src->cols == dst->cols) return copy_impl(src, dst, s); // interpolation.zig:91-108
+    if (src->rows == 0 || src->cols == 0) { // no source pixel to resolve an index to: what resize_impl does
+        const zg_method m{ZG_INTERP_LANCZOS, 0, 0, nullptr};
+        return resize_impl(src, dst, &m, s);
+    }
+    return resize_lanczos_weights_impl(src, dst, wx, wy, s);
 }
 
 // ---- letterbox (transforms.zig:49-108) -------------------------------------------------------------
@@ -641,6 +658,18 @@ int zg_resize(const zg_image *src, const zg_image *dst, const zg_method *method,
 }
 int zg_resize_host(const zg_image *src, const zg_image *dst, const zg_method *method) {
     ZG_HOST2(resize_impl(&a.dev, &b.dev, method, nullptr))
+}
+
+int zg_lanczos_plane_weights(uint32_t src_n, uint32_t dst_n, float *weights) {
+    ZG_REQUIRE(weights != nullptr && src_n > 0 && dst_n > 0, ZG_ERR_INVALID_ARGUMENT, "zg_lanczos_plane_weights: null output or empty axis");
+    lanczos_plane_weights(src_n, dst_n, weights);
+    return ZG_OK;
+}
+int zg_resize_lanczos_weights(const zg_image *src, const zg_image *dst, const float *wx, const float *wy, zg_stream stream) {
+    return resize_lanczos_weights_checked(src, dst, wx, wy, as_stream(stream));
+}
+int zg_resize_lanczos_weights_host(const zg_image *src, const zg_image *dst, const float *wx, const float *wy) {
+    ZG_HOST2(resize_lanczos_weights_checked(&a.dev, &b.dev, wx, wy, nullptr))
 }
 
 int zg_letterbox(const zg_image *src, const zg_image *dst, const zg_method *method, uint32_t rect_out[4], zg_stream stream) {

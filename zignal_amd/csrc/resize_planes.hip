@@ -407,4 +407,37 @@ int resize_planes_impl(const zg_image *src, const zg_image *dst, const zg_method
     return resize_planes_pix<ZG_PIXEL_RGBA_U8>(src, dst, kind, tx, ty, s);
 }
 
+
+// The Lanczos3 plane weights of one axis (channel_ops.zig:446-466): for destination index d, weight k is
+// lanczosKernel((k - 2) - f) with f = frac((d + 0.5) * ratio - 0.5). dst_n * 6 floats.
+void lanczos_plane_weights(uint32_t src_n, uint32_t dst_n, float *w) {
+    std::vector<int32_t> idx, bits;
+    build_axis(ZG_INTERP_LANCZOS, src_n, dst_n, 6, idx, bits);
+    std::memcpy(w, bits.data(), bits.size() * sizeof(float));
+}
+
+// resizePlaneLanczosU8 with caller-made weights: the taps' source indices are the library's (integer arithmetic), the
+// weights are whatever the caller's @sin produced. Tables go up per call (KBs), outside the geometry cache.
+int resize_lanczos_weights_impl(const zg_image *src, const zg_image *dst, const float *wx, const float *wy, hipStream_t s) {
+    const size_t nx = (size_t)dst->cols * 6, ny = (size_t)dst->rows * 6;
+    std::vector<int32_t> ix, iy, own;
+    build_axis(ZG_INTERP_LANCZOS, src->cols, dst->cols, 6, ix, own);
+    std::vector<int32_t> host(2 * nx + 2 * ny);
+    std::memcpy(host.data(), ix.data(), nx * 4);
+    std::memcpy(host.data() + nx, wx ? (const void *)wx : (const void *)own.data(), nx * 4);
+    build_axis(ZG_INTERP_LANCZOS, src->rows, dst->rows, 6, iy, own);
+    std::memcpy(host.data() + 2 * nx, iy.data(), ny * 4);
+    std::memcpy(host.data() + 2 * nx + ny, wy ? (const void *)wy : (const void *)own.data(), ny * 4);
+    int32_t *dev = nullptr;
+    int rc;
+    if ((rc = scratch_alloc((void **)&dev, host.size() * 4, s))) return rc;
+    if ((rc = upload_pageable(dev, host.data(), host.size() * 4, s)) == ZG_OK) {
+        const AxisTable tx{dev, dev + nx}, ty{dev + 2 * nx, dev + 2 * nx + ny};
+        rc = src->pixel == ZG_PIXEL_RGB_U8 ? resize_planes_pix<ZG_PIXEL_RGB_U8>(src, dst, ZG_INTERP_LANCZOS, tx, ty, s)
+                                           : resize_planes_pix<ZG_PIXEL_RGBA_U8>(src, dst, ZG_INTERP_LANCZOS, tx, ty, s);
+    }
+    scratch_free(dev, s);
+    return rc;
+}
+
 } // namespace zg

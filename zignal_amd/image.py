@@ -338,11 +338,22 @@ class Image:
         return self
 
     # ---- resampling -------------------------------------------------------------------------
-    def resize(self, size_or_out, method: Interpolation = Interpolation.bilinear) -> "Image":
-        """Image.resize (image.zig:523): `size_or_out` is (rows, cols) or a pre-allocated Image."""
+    def resize(self, size_or_out, method: Interpolation = Interpolation.bilinear, lanczos_weights=None) -> "Image":
+        """Image.resize (image.zig:523): `size_or_out` is (rows, cols) or a pre-allocated Image.
+        `lanczos_weights` = (wx, wy): for Rgb(u8) / Rgba(u8) with `.lanczos`, the plane kernel's weights made by the caller
+        (channel_ops.zig:446-466; arrays of out.cols x 6 and out.rows x 6 f32) — how a host with its own `sin` keeps its bits."""
         out = size_or_out if isinstance(size_or_out, Image) else self._like(int(size_or_out[0]), int(size_or_out[1]))
         self._same_side(out)
         s, d, m = self._desc(), out._desc(), method._c()
+        if lanczos_weights is not None:
+            if method.kind != L.INTERP_LANCZOS:
+                raise ValueError("lanczos_weights only apply to Interpolation.lanczos")
+            wx = np.ascontiguousarray(lanczos_weights[0], np.float32).reshape(-1)
+            wy = np.ascontiguousarray(lanczos_weights[1], np.float32).reshape(-1)
+            if wx.size != out.cols * 6 or wy.size != out.rows * 6:
+                raise ValueError(f"lanczos_weights: expected {out.cols} x 6 and {out.rows} x 6 values")
+            self._call("resize_lanczos_weights", C.byref(s), C.byref(d), wx.ctypes.data_as(L._F32P), wy.ctypes.data_as(L._F32P))
+            return out
         self._call("resize", C.byref(s), C.byref(d), C.byref(m))
         return out
 
@@ -630,6 +641,13 @@ def gaussian_kernel(sigma: float) -> np.ndarray:
         L.check(-n)
     out = np.empty(n, np.float32)
     lib.zg_gaussian_kernel(C.c_float(sigma), out.ctypes.data_as(C.POINTER(C.c_float)), n)
+    return out
+
+
+def lanczos_plane_weights(src_n: int, dst_n: int) -> np.ndarray:
+    """The library's own Lanczos3 plane weights of one axis (channel_ops.zig:446-466): dst_n x 6 f32."""
+    out = np.empty((int(dst_n), 6), np.float32)
+    L.check(L.lib().zg_lanczos_plane_weights(int(src_n), int(dst_n), out.ctypes.data_as(L._F32P)))
     return out
 
 
