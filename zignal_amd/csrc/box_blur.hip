@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256) void k_box_mean(const float *sat, DImg src, DI
     using P = Px<PIX>;
     using Vec = typename P::Vec;
     constexpr int C = P::C;
-    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
-    if (c >= dst.cols) return;
+    const int c = blockIdx.x * 256 + threadIdx.x, r = grid_row();
+    if (c >= dst.cols || r >= dst.rows) return;
     const int rows = dst.rows, cols = dst.cols;
     const int r1 = max(r - radius, 0), r2 = (int)min((long long)r + radius, (long long)rows - 1);
     const int c1 = max(c - radius, 0), c2 = (int)min((long long)c + radius, (long long)cols - 1);
@@ -221,8 +221,8 @@ static int box_blur_impl(const zg_image *src, const zg_image *dst, uint32_t radi
     if ((rc = sat_planes_impl(src, sat, s, false)) == ZG_OK)
         rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
             constexpr int PIX = decltype(tag)::value;
-            if (sharpen) hipLaunchKernelGGL((k_box_mean<PIX, true>), dim3(ceil_div(dst->cols, 256), dst->rows), dim3(256), 0, s, (const float *)sat, dimg(src), dimg(dst), (int)radius);
-            else hipLaunchKernelGGL((k_box_mean<PIX, false>), dim3(ceil_div(dst->cols, 256), dst->rows), dim3(256), 0, s, (const float *)sat, dimg(src), dimg(dst), (int)radius);
+            if (sharpen) hipLaunchKernelGGL((k_box_mean<PIX, true>), row_grid(ceil_div(dst->cols, 256), dst->rows), dim3(256), 0, s, (const float *)sat, dimg(src), dimg(dst), (int)radius);
+            else hipLaunchKernelGGL((k_box_mean<PIX, false>), row_grid(ceil_div(dst->cols, 256), dst->rows), dim3(256), 0, s, (const float *)sat, dimg(src), dimg(dst), (int)radius);
             ZG_HIP(hipGetLastError());
             return ZG_OK;
         });

@@ -351,8 +351,8 @@ __global__ __launch_bounds__(256) void k_convert_spaces(DImg src, DImg dst, int 
     constexpr bool SF = std::is_same<typename SP::Elem, float>::value;
     constexpr bool DF = std::is_same<typename DP::Elem, float>::value;
     constexpr int SC = SP::C, DC = DP::C;
-    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
-    if (c >= src.cols) return;
+    const int c = blockIdx.x * 256 + threadIdx.x, r = grid_row();
+    if (c >= src.cols || r >= src.rows) return;
     const typename SP::Vec sv = SP::load(src.data, (size_t)r * src.stride + (size_t)c);
     typename DP::Vec dv = DP::zero();
     float f[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -421,7 +421,7 @@ int convert_spaces_impl(const zg_image *src, int src_space, const zg_image *dst,
     const bool sf = pixel_is_float(src->pixel), df = pixel_is_float(dst->pixel);
     ZG_REQUIRE(sf || space_has_u8(src_space), ZG_ERR_UNSUPPORTED, "convert: colour space %d has no u8 form (float-only type)", src_space);
     ZG_REQUIRE(df || space_has_u8(dst_space), ZG_ERR_UNSUPPORTED, "convert: colour space %d has no u8 form (float-only type)", dst_space);
-    const dim3 grid(ceil_div(src->cols, 256), src->rows);
+    const dim3 grid = row_grid(ceil_div(src->cols, 256), src->rows);
     return dispatch_pixel(src->pixel, [&](auto stag) -> int {
         constexpr int SPIX = decltype(stag)::value;
         return dispatch_pixel(dst->pixel, [&](auto dtag) -> int {

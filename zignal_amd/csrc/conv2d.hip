@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <vector>
 
 #pragma clang fp contract(off)
 
@@ -125,6 +126,51 @@ __global__ __launch_bounds__(256) void k_conv2d(DImg src, DImg dst, Kernel2D k, 
     }
 }
 
+// Kernels larger than 15 x 15 (the reference takes any comptime size, convolution.zig:76): one lane per output pixel, taps
+// from device memory, every source pixel fetched through the border rule. No tile, no size limit; the accumulation order
+// is the same (ky-major, kx ascending).
+template <int PIX, int MODE>
+__global__ __launch_bounds__(256) void k_conv2d_big(DImg src, DImg dst, const void *taps, int kh, int kw, int border) {
+    using P = Px<PIX>;
+    using Vec = typename P::Vec;
+    constexpr int C = P::C;
+    const int c = blockIdx.x * 256 + threadIdx.x, r = grid_row();
+    if (c >= dst.cols || r >= dst.rows) return;
+    using Acc = typename std::conditional<MODE == 0, float, int64_t>::type;
+    Acc acc[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) acc[ch] = 0;
+    const int hh = kh / 2, hw = kw / 2;
+    for (int ky = 0; ky < kh; ++ky) {
+        const int gr = resolve_index(r + ky - hh, src.rows, border);
+        for (int kx = 0; kx < kw; ++kx) {
+            const int gc = gr < 0 ? -1 : resolve_index(c + kx - hw, src.cols, border);
+            Vec v = P::load(src.data, (size_t)max(gr, 0) * src.stride + (size_t)max(gc, 0)); // clamped address, unpredicated
+            if (gc < 0) v = P::zero();
+            if constexpr (MODE == 0) {
+                const float w = ((const float *)taps)[ky * kw + kx];
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) { const float p = v[ch] * w; acc[ch] = acc[ch] + p; }
+            } else {
+                const int32_t w = ((const int32_t *)taps)[ky * kw + kx];
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) acc[ch] += (Acc)v[ch] * (Acc)w;
+            }
+        }
+    }
+    Vec out;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+        if constexpr (MODE == 0) out[ch] = acc[ch];
+        else {
+            const Acc a = acc[ch];
+            if (a < 0) out[ch] = 0;
+            else { const Acc q = (a + 128) >> 8; out[ch] = (uint8_t)(q > 255 ? 255 : q); }
+        }
+    }
+    P::store(dst.data, (size_t)r * dst.stride + (size_t)c, out);
+}
+
 template <int PIX, int MODE>
 static int launch_conv2d(const zg_image *src, const zg_image *dst, const Kernel2D &k, int border, hipStream_t s) {
     const int tiles_x = (int)ceil_div(dst->cols, C2_TW), tiles_y = (int)ceil_div(dst->rows, C2_TH);
@@ -145,34 +191,51 @@ static int convolve_impl(const zg_image *src, const zg_image *dst, const float *
     ZG_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, ZG_ERR_DIMENSION_MISMATCH, "convolve: %ux%u vs %ux%u",
                src->rows, src->cols, dst->rows, dst->cols);
     ZG_REQUIRE(src->pixel == dst->pixel, ZG_ERR_INVALID_ARGUMENT, "convolve: pixel types differ");
-    ZG_REQUIRE(kernel && kh >= 1 && kw >= 1 && kh * kw <= (uint32_t)MAX_K2D, ZG_ERR_INVALID_ARGUMENT,
-               "convolve: kernel %ux%u (at most %d taps)", kh, kw, MAX_K2D);
+    ZG_REQUIRE(kernel && kh >= 1 && kw >= 1 && kh <= 4096 && kw <= 4096, ZG_ERR_INVALID_ARGUMENT, "convolve: kernel %ux%u (sides of 1..4096)", kh, kw);
     ZG_REQUIRE(border >= ZG_BORDER_ZERO && border <= ZG_BORDER_WRAP, ZG_ERR_INVALID_ARGUMENT, "invalid border %d", border);
     if (src->rows == 0 || src->cols == 0) return ZG_OK;
-    Kernel2D k;
-    k.kh = (int)kh;
-    k.kw = (int)kw;
+    const size_t nk = (size_t)kh * kw;
     const bool is_float = pixel_is_float(src->pixel);
+    std::vector<int32_t> ik;
     int mode = 0;
-    if (is_float) {
-        for (uint32_t i = 0; i < kh * kw; ++i) k.f[i] = kernel[i];
-    } else {
-        int64_t sum_abs = 0, max_abs = 0;
-        for (uint32_t i = 0; i < kh * kw; ++i) {
+    if (!is_float) {
+        ik.resize(nk);
+        int64_t sum_abs = 0;
+        for (size_t i = 0; i < nk; ++i) {
             const float r = std::round(kernel[i] * 256.0f); // ConvolutionKernel.flatten (convolution.zig:95-113)
-            ZG_REQUIRE(std::fabs(r) < 2147483648.0f, ZG_ERR_INVALID_ARGUMENT, "kernel[%u] does not fit i32 after scaling", i);
-            k.i[i] = (int32_t)r;
-            sum_abs += std::llabs((long long)k.i[i]);
-            max_abs = std::max<int64_t>(max_abs, std::llabs((long long)k.i[i]));
+            ZG_REQUIRE(std::fabs(r) < 2147483648.0f, ZG_ERR_INVALID_ARGUMENT, "kernel[%zu] does not fit i32 after scaling", i);
+            ik[i] = (int32_t)r;
+            sum_abs += std::llabs((long long)ik[i]);
         }
         mode = (255 * sum_abs < (int64_t)INT32_MAX - 256) ? 1 : 2;
     }
-    ZG_REQUIRE(kh <= 15 && kw <= 15, ZG_ERR_INVALID_ARGUMENT, "convolve: kernel %ux%u (each side at most 15)", kh, kw);
-    return dispatch_pixel(src->pixel, [&](auto tag) -> int {
-        constexpr int PIX = decltype(tag)::value;
-        if constexpr (std::is_same<typename Px<PIX>::Elem, float>::value) return launch_conv2d<PIX, 0>(src, dst, k, border, s);
-        else return mode == 1 ? launch_conv2d<PIX, 1>(src, dst, k, border, s) : launch_conv2d<PIX, 2>(src, dst, k, border, s);
-    });
+    if (kh <= 15 && kw <= 15) { // tiled kernels, taps as a kernel argument
+        Kernel2D k;
+        k.kh = (int)kh;
+        k.kw = (int)kw;
+        for (size_t i = 0; i < nk; ++i) { if (is_float) k.f[i] = kernel[i]; else k.i[i] = ik[i]; }
+        return dispatch_pixel(src->pixel, [&](auto tag) -> int {
+            constexpr int PIX = decltype(tag)::value;
+            if constexpr (std::is_same<typename Px<PIX>::Elem, float>::value) return launch_conv2d<PIX, 0>(src, dst, k, border, s);
+            else return mode == 1 ? launch_conv2d<PIX, 1>(src, dst, k, border, s) : launch_conv2d<PIX, 2>(src, dst, k, border, s);
+        });
+    }
+    void *taps = nullptr; // larger: taps from device memory (uploaded synchronously: not capturable)
+    if ((rc = scratch_alloc(&taps, nk * 4, s))) return rc;
+    rc = upload_pageable(taps, is_float ? (const void *)kernel : (const void *)ik.data(), nk * 4, s);
+    if (rc == ZG_OK)
+        rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
+            constexpr int PIX = decltype(tag)::value;
+            const dim3 grid = row_grid(ceil_div(dst->cols, 256), dst->rows);
+            if constexpr (std::is_same<typename Px<PIX>::Elem, float>::value)
+                hipLaunchKernelGGL((k_conv2d_big<PIX, 0>), grid, dim3(256), 0, s, dimg(src), dimg(dst), (const void *)taps, (int)kh, (int)kw, border);
+            else
+                hipLaunchKernelGGL((k_conv2d_big<PIX, 2>), grid, dim3(256), 0, s, dimg(src), dimg(dst), (const void *)taps, (int)kh, (int)kw, border);
+            ZG_HIP(hipGetLastError());
+            return ZG_OK;
+        });
+    scratch_free(taps, s);
+    return rc;
 }
 
 } // namespace zg

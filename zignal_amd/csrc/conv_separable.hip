@@ -40,7 +40,8 @@
 
 namespace zg {
 
-constexpr int MAX_TAPS = 255;
+constexpr int MAX_TAPS = 255;          // as a kernel argument
+constexpr int MAX_TAPS_MEM = 1 << 22;  // from device memory (radius up to two million: far past any image)
 
 enum : int { MODE_F32 = 0, MODE_I24 = 1, MODE_I64 = 2 };
 
@@ -331,21 +332,22 @@ __global__ __launch_bounds__(256) void k_sep_fused(DImg src, DImg dst, TapsArg<N
 template <typename T, int C> struct TempVec { typedef T type __attribute__((ext_vector_type(C == 3 ? 4 : C))); };
 template <int C> constexpr int temp_lanes() { return C == 3 ? 4 : C; }
 
-// Up to MAX_TAPS taps travel as a kernel argument (1 KB): no table upload, no synchronisation, graph-capturable.
+// Up to MAX_TAPS taps travel as a kernel argument (1 KB): no table upload, no synchronisation, graph-capturable. Longer
+// kernels (the reference's gaussianBlur has radius ceil(3 sigma), unbounded: image.zig:973) come from device memory.
 struct TapsBig {
     union { float f[MAX_TAPS]; int32_t i[MAX_TAPS]; };
 };
 
 template <int PIX, int MODE>
-__global__ __launch_bounds__(256) void k_sep_h(DImg src, typename Arith<MODE>::Temp *temp, TapsBig taps,
+__global__ __launch_bounds__(256) void k_sep_h(DImg src, typename Arith<MODE>::Temp *temp, TapsBig taps, const void *taps_mem,
                                                int nk, int border) {
     using P = Px<PIX>;
     using Vec = typename P::Vec;
     using A = Arith<MODE>;
     constexpr int C = P::C;
     const int c = blockIdx.x * 256 + threadIdx.x;
-    const int r = blockIdx.y;
-    if (c >= src.cols) return;
+    const int r = grid_row();
+    if (c >= src.cols || r >= src.rows) return;
     const int h = nk / 2;
     const bool interior = (src.cols > 2 * h) && c >= h && c < src.cols - h;
     typename A::Acc acc[C];
@@ -353,14 +355,14 @@ __global__ __launch_bounds__(256) void k_sep_h(DImg src, typename Arith<MODE>::T
     const size_t row = (size_t)r * src.stride;
     for (int i = 0; i < nk; ++i) {
         if constexpr (MODE == MODE_F32) {
-            const float k = taps.f[i];
+            const float k = taps_mem ? ((const float *)taps_mem)[i] : taps.f[i]; // wave-uniform either way
             if (interior && fabsf(k) < 1e-10f) continue;
             const int gc = resolve_index(c + i - h, src.cols, border);
             Vec v = P::zero();
             if (gc >= 0) v = P::load(src.data, row + gc);
             for (int ch = 0; ch < C; ++ch) acc[ch] = A::mac(acc[ch], v[ch], k);
         } else {
-            const int32_t k = taps.i[i];
+            const int32_t k = taps_mem ? ((const int32_t *)taps_mem)[i] : taps.i[i];
             const int gc = resolve_index(c + i - h, src.cols, border);
             Vec v = P::zero();
             if (gc >= 0) v = P::load(src.data, row + gc);
@@ -375,15 +377,15 @@ __global__ __launch_bounds__(256) void k_sep_h(DImg src, typename Arith<MODE>::T
 }
 
 template <int PIX, int MODE>
-__global__ __launch_bounds__(256) void k_sep_v(const typename Arith<MODE>::Temp *temp, DImg dst, TapsBig taps,
+__global__ __launch_bounds__(256) void k_sep_v(const typename Arith<MODE>::Temp *temp, DImg dst, TapsBig taps, const void *taps_mem,
                                                int nk, int border) {
     using P = Px<PIX>;
     using Vec = typename P::Vec;
     using A = Arith<MODE>;
     constexpr int C = P::C;
     const int c = blockIdx.x * 256 + threadIdx.x;
-    const int r = blockIdx.y;
-    if (c >= dst.cols) return;
+    const int r = grid_row();
+    if (c >= dst.cols || r >= dst.rows) return;
     const int h = nk / 2;
     const bool interior = (dst.rows > 2 * h) && r >= h && r < dst.rows - h;
     typename A::Acc acc[C];
@@ -396,12 +398,12 @@ __global__ __launch_bounds__(256) void k_sep_v(const typename Arith<MODE>::Temp 
         for (int ch = 0; ch < temp_lanes<C>(); ++ch) tv[ch] = (typename A::Temp)0;
         if (gr >= 0) tv = ((const TV *)temp)[(size_t)gr * dst.cols + c];
         if constexpr (MODE == MODE_F32) {
-            const float k = taps.f[i];
+            const float k = taps_mem ? ((const float *)taps_mem)[i] : taps.f[i]; // wave-uniform either way
             if (interior && fabsf(k) < 1e-10f) continue;
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) acc[ch] = A::mac(acc[ch], tv[ch], k);
         } else {
-            const int32_t k = taps.i[i];
+            const int32_t k = taps_mem ? ((const int32_t *)taps_mem)[i] : taps.i[i];
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) acc[ch] = A::mac(acc[ch], tv[ch], k);
         }
@@ -493,12 +495,29 @@ static int launch_two_pass(const zg_image *src, const zg_image *dst, const SepPl
     const size_t temp_bytes = (size_t)src->rows * src->cols * temp_lanes<C>() * sizeof(Temp);
     Temp *temp = nullptr;
     if (int rc = scratch_alloc((void **)&temp, temp_bytes, s)) return rc;
-    TapsBig tx, ty;
-    for (int i = 0; i < p.nkx; ++i) { if constexpr (MODE == MODE_F32) tx.f[i] = p.fx[i]; else tx.i[i] = p.ix[i]; }
-    for (int i = 0; i < p.nky; ++i) { if constexpr (MODE == MODE_F32) ty.f[i] = p.fy[i]; else ty.i[i] = p.iy[i]; }
-    const dim3 grid(ceil_div(src->cols, 256), src->rows);
-    hipLaunchKernelGGL((k_sep_h<PIX, MODE>), grid, dim3(256), 0, s, dimg(src), temp, tx, p.nkx, border);
-    hipLaunchKernelGGL((k_sep_v<PIX, MODE>), grid, dim3(256), 0, s, temp, dimg(dst), ty, p.nky, border);
+    TapsBig tx{}, ty{};
+    void *taps_dev = nullptr; // kernels longer than MAX_TAPS: [kx | ky] in device memory (uploaded synchronously: not capturable)
+    const void *mx = nullptr, *my = nullptr;
+    if (p.nkx > MAX_TAPS || p.nky > MAX_TAPS) {
+        const size_t n = (size_t)p.nkx + (size_t)p.nky;
+        std::vector<uint32_t> host(n);
+        if constexpr (MODE == MODE_F32) { std::memcpy(host.data(), p.fx.data(), (size_t)p.nkx * 4); std::memcpy(host.data() + p.nkx, p.fy.data(), (size_t)p.nky * 4); }
+        else { std::memcpy(host.data(), p.ix.data(), (size_t)p.nkx * 4); std::memcpy(host.data() + p.nkx, p.iy.data(), (size_t)p.nky * 4); }
+        int rc = scratch_alloc(&taps_dev, n * 4, s);
+        if (rc == ZG_OK) rc = upload_pageable(taps_dev, host.data(), n * 4, s);
+        if (rc) { scratch_free(taps_dev, s); scratch_free(temp, s); return rc; }
+        mx = taps_dev;
+        my = (const uint32_t *)taps_dev + p.nkx;
+    } else {
+        for (int i = 0; i < p.nkx; ++i) { if constexpr (MODE == MODE_F32) tx.f[i] = p.fx[i]; else tx.i[i] = p.ix[i]; }
+        for (int i = 0; i < p.nky; ++i) { if constexpr (MODE == MODE_F32) ty.f[i] = p.fy[i]; else ty.i[i] = p.iy[i]; }
+    }
+    const dim3 grid = row_grid(ceil_div(src->cols, 256), src->rows);
+    hipLaunchKernelGGL((k_sep_h<PIX, MODE>), grid, dim3(256), 0, s, dimg(src), temp, tx, mx, p.nkx, border);
+    hipLaunchKernelGGL((k_sep_v<PIX, MODE>), grid, dim3(256), 0, s, temp, dimg(dst), ty, my, p.nky, border);
+    const hipError_t launch_error = hipGetLastError();
+    scratch_free(taps_dev, s);
+    if (launch_error != hipSuccess) { scratch_free(temp, s); ZG_HIP(launch_error); }
     ZG_HIP(hipGetLastError());
     scratch_free(temp, s);
     return ZG_OK;
@@ -527,8 +546,8 @@ static int conv_separable_impl(const zg_image *src, const zg_image *dst, const f
     ZG_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, ZG_ERR_DIMENSION_MISMATCH,
                "convolveSeparable: %ux%u vs %ux%u", src->rows, src->cols, dst->rows, dst->cols);
     ZG_REQUIRE(src->pixel == dst->pixel, ZG_ERR_INVALID_ARGUMENT, "convolveSeparable: pixel types differ");
-    ZG_REQUIRE(kx && ky && nkx >= 1 && nky >= 1 && nkx <= MAX_TAPS && nky <= MAX_TAPS, ZG_ERR_INVALID_ARGUMENT,
-               "convolveSeparable: kernel lengths %u, %u (1..%d supported)", nkx, nky, MAX_TAPS);
+    ZG_REQUIRE(kx && ky && nkx >= 1 && nky >= 1 && nkx <= MAX_TAPS_MEM && nky <= MAX_TAPS_MEM, ZG_ERR_INVALID_ARGUMENT,
+               "convolveSeparable: kernel lengths %u, %u (1..%d supported)", nkx, nky, MAX_TAPS_MEM);
     ZG_REQUIRE(border >= ZG_BORDER_ZERO && border <= ZG_BORDER_WRAP, ZG_ERR_INVALID_ARGUMENT, "invalid border %d", border);
     if (src->rows == 0 || src->cols == 0) return ZG_OK;
 
@@ -628,7 +647,7 @@ int zg_conv_separable_host(const zg_image *src, const zg_image *dst, const float
 int zg_gaussian_kernel(float sigma, float *taps, uint32_t capacity) {
     if (!(sigma > 0)) { set_error("gaussian kernel: sigma must be > 0"); return -ZG_ERR_INVALID_ARGUMENT; }
     const float rf = std::ceil(3.0f * sigma);
-    if (!(rf < (float)(MAX_TAPS / 2 + 1))) { set_error("gaussian kernel: sigma %g too large", sigma); return -ZG_ERR_INVALID_ARGUMENT; }
+    if (!(rf < (float)(MAX_TAPS_MEM / 2))) { set_error("gaussian kernel: sigma %g too large", sigma); return -ZG_ERR_INVALID_ARGUMENT; }
     const uint32_t radius = (uint32_t)rf, size = 2 * radius + 1;
     if (!taps) return (int)size;
     if (capacity < size) { set_error("gaussian kernel: capacity %u < %u", capacity, size); return -ZG_ERR_INVALID_ARGUMENT; }
@@ -649,10 +668,11 @@ static int gaussian_impl(const zg_image *src, const zg_image *dst, float sigma, 
                "gaussianBlur: %ux%u vs %ux%u", src->rows, src->cols, dst->rows, dst->cols);
     if (sigma == 0) return copy_impl(src, dst, s);                       // image.zig:966
     ZG_REQUIRE(sigma > 0, ZG_ERR_INVALID_ARGUMENT, "gaussianBlur: InvalidSigma (%g)", sigma); // image.zig:970
-    float taps[MAX_TAPS];
-    const int n = zg_gaussian_kernel(sigma, taps, MAX_TAPS);
+    const int n = zg_gaussian_kernel(sigma, nullptr, 0);
     if (n < 0) return -n;
-    return conv_separable_impl(src, dst, taps, (uint32_t)n, taps, (uint32_t)n, ZG_BORDER_MIRROR, s);
+    std::vector<float> taps((size_t)n);
+    if (zg_gaussian_kernel(sigma, taps.data(), (uint32_t)n) != n) return ZG_ERR_INVALID_ARGUMENT;
+    return conv_separable_impl(src, dst, taps.data(), (uint32_t)n, taps.data(), (uint32_t)n, ZG_BORDER_MIRROR, s);
 }
 
 int zg_gaussian_blur(const zg_image *src, const zg_image *dst, float sigma, zg_stream stream) {

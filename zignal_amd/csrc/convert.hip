@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void k_convert(DImg src, DImg dst, ConvertArgs
     constexpr bool SF = std::is_same<typename SP::Elem, float>::value;
     constexpr bool DF = std::is_same<typename DP::Elem, float>::value;
     constexpr int SC = SP::C, DC = DP::C;
-    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
-    if (c >= src.cols) return;
+    const int c = blockIdx.x * 256 + threadIdx.x, r = grid_row();
+    if (c >= src.cols || r >= src.rows) return;
     const typename SP::Vec sv = SP::load(src.data, (size_t)r * src.stride + (size_t)c);
     typename DP::Vec dv = DP::zero();
 
@@ -209,7 +209,7 @@ static int convert_impl(const zg_image *src, int src_space, const zg_image *dst,
     if (!sf && (dst_space == ZG_CS_XYZ || dst_space == ZG_CS_OKLAB)) {
         if ((rc = device_srgb_lut(srgb_lut, s, &a.srgb_lut, &owned))) return rc;
     }
-    const dim3 grid(ceil_div(src->cols, 256), src->rows);
+    const dim3 grid = row_grid(ceil_div(src->cols, 256), src->rows);
     rc = dispatch_pixel(src->pixel, [&](auto stag) -> int {
         constexpr int SPIX = decltype(stag)::value;
         return dispatch_pixel(dst->pixel, [&](auto dtag) -> int {

@@ -106,8 +106,8 @@ template <int PIX> __device__ inline float canny_gray(typename Px<PIX>::Vec v) {
 template <int PIX>
 __global__ __launch_bounds__(256) void k_canny_gray(DImg src, float *gray) {
     using P = Px<PIX>;
-    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
-    if (c >= src.cols) return;
+    const int c = blockIdx.x * 256 + threadIdx.x, r = grid_row();
+    if (c >= src.cols || r >= src.rows) return;
     gray[(size_t)r * src.cols + c] = canny_gray<PIX>(P::load(src.data, (size_t)r * src.stride + (size_t)c));
 }
 
@@ -264,8 +264,8 @@ static size_t hysteresis_work_bytes(uint32_t rows, uint32_t cols) {
 // ran (label != nullptr) and its component's root is flagged. Four pixels per lane; VEC moves them as one dword.
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_canny_emit(const uint8_t *state, int *label, const uint8_t *flag, DImg dst) {
-    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4, r = blockIdx.y;
-    if (c0 >= dst.cols) return;
+    const int c0 = (blockIdx.x * 256 + threadIdx.x) * 4, r = grid_row();
+    if (c0 >= dst.cols || r >= dst.rows) return;
     const size_t i0 = (size_t)r * dst.cols + c0;
     uint8_t *out = (uint8_t *)dst.data + (size_t)r * dst.stride + c0;
     uint8_t st[4];
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_canny_emit(const uint8_t *state, int *l
     }
 }
 static int launch_emit(const uint8_t *state, int *label, const uint8_t *flag, const zg_image *dst, hipStream_t s) {
-    const dim3 grid(ceil_div(dst->cols, 1024), dst->rows);
+    const dim3 grid = row_grid(ceil_div(dst->cols, 1024), dst->rows);
     const bool vec = dst->cols % 4 == 0 && dst->stride % 4 == 0 && (uintptr_t)dst->data % 4 == 0;
     if (vec) hipLaunchKernelGGL(k_canny_emit<true>, grid, dim3(256), 0, s, state, label, flag, dimg(dst));
     else hipLaunchKernelGGL(k_canny_emit<false>, grid, dim3(256), 0, s, state, label, flag, dimg(dst));
@@ -319,7 +319,7 @@ static int canny_impl(const zg_image *src, const zg_image *dst, float sigma, flo
 
     rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
-        hipLaunchKernelGGL((k_canny_gray<PIX>), dim3(ceil_div(cols, 256), rows), dim3(256), 0, s, dimg(src), gray);
+        hipLaunchKernelGGL((k_canny_gray<PIX>), row_grid(ceil_div(cols, 256), rows), dim3(256), 0, s, dimg(src), gray);
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     });
@@ -616,7 +616,7 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
 
     rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
-        hipLaunchKernelGGL((k_canny_gray<PIX>), dim3(ceil_div(cols, 256), rows), dim3(256), 0, s, dimg(src), gray);
+        hipLaunchKernelGGL((k_canny_gray<PIX>), row_grid(ceil_div(cols, 256), rows), dim3(256), 0, s, dimg(src), gray);
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     });

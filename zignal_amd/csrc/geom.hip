@@ -296,8 +296,8 @@ static int orthogonal_case(float angle) {
 template <int PS>
 __global__ __launch_bounds__(256) void k_rotate_orthogonal(DImg src, DImg out, int which, int off_r, int off_c) {
     struct B { uint8_t b[PS]; };
-    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
-    if (c >= src.cols) return;
+    const int c = blockIdx.x * 256 + threadIdx.x, r = grid_row();
+    if (c >= src.cols || r >= src.rows) return;
     int nr, nc;
     switch (which) {
     case 0: nr = r; nc = c; break;
@@ -320,7 +320,7 @@ static int rotate_into_impl(const zg_image *src, const zg_image *dst, float angl
         const uint32_t rr = (oc & 1) ? src->cols : src->rows, rcols = (oc & 1) ? src->rows : src->cols;
         const uint32_t off_r = (dst->rows > rr ? dst->rows - rr : 0) / 2, off_c = (dst->cols > rcols ? dst->cols - rcols : 0) / 2;
         if (src->rows && src->cols) {
-            const dim3 grid(ceil_div(src->cols, 256), src->rows);
+            const dim3 grid = row_grid(ceil_div(src->cols, 256), src->rows);
 #define ZG_ROT(PS) case PS: hipLaunchKernelGGL(k_rotate_orthogonal<PS>, grid, dim3(256), 0, s, dimg(src), dimg(dst), oc, (int)off_r, (int)off_c); break;
             switch ((int)pixel_size(src->pixel)) { ZG_ROT(1) ZG_ROT(3) ZG_ROT(4) ZG_ROT(12) ZG_ROT(16) }
 #undef ZG_ROT
@@ -349,8 +349,8 @@ static float rect_h(const float r[4]) { return r[1] >= r[3] ? 0.0f : r[3] - r[1]
 template <int PS>
 __global__ __launch_bounds__(256) void k_copy_rect(DImg src, DImg out, int rect_top, int rect_left, int border) {
     struct B { uint8_t b[PS]; };
-    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
-    if (c >= out.cols) return;
+    const int c = blockIdx.x * 256 + threadIdx.x, r = grid_row();
+    if (c >= out.cols || r >= out.rows) return;
     const int rr = resolve_index(r + rect_top, src.rows, border);
     const int cc = rr < 0 ? -1 : resolve_index(c + rect_left, src.cols, border);
     B v = {};
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void k_copy_rect(DImg src, DImg out, int rect_
 
 static int copy_rect_impl(const zg_image *src, int rect_top, int rect_left, const zg_image *out, int border, hipStream_t s) {
     if (out->rows == 0 || out->cols == 0) return ZG_OK;
-    const dim3 grid(ceil_div(out->cols, 256), out->rows);
+    const dim3 grid = row_grid(ceil_div(out->cols, 256), out->rows);
 #define ZG_CR(PS) case PS: hipLaunchKernelGGL(k_copy_rect<PS>, grid, dim3(256), 0, s, dimg(src), dimg(out), rect_top, rect_left, border); break;
     switch ((int)pixel_size(src->pixel)) { ZG_CR(1) ZG_CR(3) ZG_CR(4) ZG_CR(12) ZG_CR(16) }
 #undef ZG_CR

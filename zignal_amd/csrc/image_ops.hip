@@ -27,8 +27,8 @@ struct PixelValue { uint8_t b[16]; };
 // One thread per pixel; writes `value` where the pixel lies outside [l,r) x [t,b).
 __global__ __launch_bounds__(256) void k_fill_outside(DImg img, int ps, PixelValue value, int l, int t, int r, int b) {
     const int c = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;
-    if (c >= img.cols) return;
+    const int y = grid_row();
+    if (c >= img.cols || y >= img.rows) return;
     if (y >= t && y < b && c >= l && c < r) return;
     uint8_t *p = (uint8_t *)img.data + ((size_t)y * img.stride + c) * ps;
     for (int i = 0; i < ps; ++i) p[i] = value.b[i];
@@ -41,7 +41,7 @@ int fill_outside_impl(const zg_image *img, const void *pixel_value, int l, int t
     PixelValue v{};
     const int ps = (int)pixel_size(img->pixel);
     if (pixel_value) std::memcpy(v.b, pixel_value, (size_t)ps);
-    hipLaunchKernelGGL(k_fill_outside, dim3(ceil_div(img->cols, 256), img->rows), dim3(256), 0, s, dimg(img), ps, v, l, t, r, b);
+    hipLaunchKernelGGL(k_fill_outside, row_grid(ceil_div(img->cols, 256), img->rows), dim3(256), 0, s, dimg(img), ps, v, l, t, r, b);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -59,8 +59,8 @@ template <int PS>
 __global__ __launch_bounds__(256) void k_flip_lr(DImg img) {
     struct B { uint8_t b[PS]; };
     const int c = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;
-    if (c >= img.cols / 2) return;
+    const int y = grid_row();
+    if (c >= img.cols / 2 || y >= img.rows) return;
     B *row = (B *)img.data + (size_t)y * img.stride;
     const B a = row[c], z = row[img.cols - 1 - c];
     row[c] = z;
@@ -71,8 +71,8 @@ template <int PS>
 __global__ __launch_bounds__(256) void k_flip_tb(DImg img) {
     struct B { uint8_t b[PS]; };
     const int c = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y; // < rows / 2
-    if (c >= img.cols) return;
+    const int y = grid_row(); // < rows / 2
+    if (c >= img.cols || y >= img.rows / 2) return;
     B *top = (B *)img.data + (size_t)y * img.stride;
     B *bot = (B *)img.data + (size_t)(img.rows - 1 - y) * img.stride;
     const B a = top[c], z = bot[c];
@@ -86,8 +86,8 @@ static int flip_impl(const zg_image *img, bool lr, hipStream_t s) {
     if ((rc = check_image(img, "img"))) return rc;
     if (img->rows == 0 || img->cols == 0) return ZG_OK;
     const int ps = (int)pixel_size(img->pixel);
-    const dim3 grid_lr(ceil_div(img->cols / 2 ? img->cols / 2 : 1, 256), img->rows);
-    const dim3 grid_tb(ceil_div(img->cols, 256), img->rows / 2);
+    const dim3 grid_lr = row_grid(ceil_div(img->cols / 2 ? img->cols / 2 : 1, 256), img->rows);
+    const dim3 grid_tb = row_grid(ceil_div(img->cols, 256), img->rows / 2);
 #define ZG_FLIP(PS)                                                                              \
     case PS:                                                                                     \
         if (lr) hipLaunchKernelGGL(k_flip_lr<PS>, grid_lr, dim3(256), 0, s, dimg(img));          \
@@ -106,8 +106,8 @@ static int flip_impl(const zg_image *img, bool lr, hipStream_t s) {
 template <int PIX>
 __global__ __launch_bounds__(256) void k_invert(DImg img) {
     using P = Px<PIX>;
-    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
-    if (c >= img.cols) return;
+    const int c = blockIdx.x * 256 + threadIdx.x, r = grid_row();
+    if (c >= img.cols || r >= img.rows) return;
     const size_t i = (size_t)r * img.stride + (size_t)c;
     typename P::Vec v = P::load(img.data, i);
     constexpr int N = P::C == 4 ? 3 : P::C;
@@ -126,7 +126,7 @@ static int invert_impl(const zg_image *img, hipStream_t s) {
     if (img->rows == 0 || img->cols == 0) return ZG_OK;
     return dispatch_pixel(img->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
-        hipLaunchKernelGGL((k_invert<PIX>), dim3(ceil_div(img->cols, 256), img->rows), dim3(256), 0, s, dimg(img));
+        hipLaunchKernelGGL((k_invert<PIX>), row_grid(ceil_div(img->cols, 256), img->rows), dim3(256), 0, s, dimg(img));
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     });

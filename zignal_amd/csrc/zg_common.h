@@ -161,6 +161,12 @@ __device__ inline uint8_t clamp_u8_i32(int v) { return (uint8_t)(v < 0 ? 0 : (v 
 
 // ---- launch helpers ------------------------------------------------------------------------
 inline unsigned ceil_div(unsigned a, unsigned b) { return (a + b - 1) / b; }
+// One workgroup row per image row: HIP caps gridDim.y at 65535, so rows past that continue in gridDim.z. Kernels read their
+// row with grid_row() and return when it is past the image (the last z slice is usually partial). The reference has no
+// such limit (rows: u32, src/image.zig:97-103).
+constexpr unsigned GRID_Y_MAX = 65535u;
+inline dim3 row_grid(unsigned gx, unsigned rows) { return rows <= GRID_Y_MAX ? dim3(gx, rows, 1) : dim3(gx, GRID_Y_MAX, ceil_div(rows, GRID_Y_MAX)); }
+__device__ inline int grid_row() { return (int)(blockIdx.z * GRID_Y_MAX + blockIdx.y); }
 
 // Host-layer scaffolding (zg_runtime.cpp): stage host images to the device, run, copy back.
 struct HostStage {
