@@ -47,7 +47,8 @@ def parse_args():
     ap.add_argument("--ring", type=int, default=4, help="distinct (src, dst) frame pairs to rotate through")
     ap.add_argument("--eager", action="store_true", help="launch every step from Python instead of replaying a HIP graph")
     ap.add_argument("--scatter-gather", action="store_true",
-                    help="N>1 only: also time BASELINE configs[4] end to end (RCCL scatter -> blur+resize -> gather)")
+                    help="also time BASELINE configs[4] end to end (RCCL scatter -> blur+resize -> gather), 128 frames per GPU; "
+                         "with one GPU the shard loops back through a one-rank RCCL communicator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     return ap.parse_args()
@@ -97,9 +98,16 @@ def main():
     shared_gpu = os.environ.get("ZG_BENCH_SHARED_GPU") == "1"
     if shared_gpu:
         local_rank = 0
-    if world > 1:
+    if world > 1 or args.scatter_gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:  # a one-GPU box can still execute the RCCL path: a one-rank communicator, shards looped back through it
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         if shared_gpu:
             dist.init_process_group("gloo")
@@ -215,14 +223,23 @@ def main():
                               "kernel": "k_sep_fused<RGBA_F32,5>", "kernel_ms_mean": round(mean_ms, 5),
                               "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 5),
                               "algorithmic_bytes_per_launch": alg_bytes}
+        # The metric names two ops: the bilinear resize of BASELINE configs[2] stands beside the blur, same arithmetic.
+        try:
+            result["resize"] = resize_headline(zg, torch)
+        except Exception as e:  # never take the headline down
+            result["resize"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_extras:
             result["extras"] = extras(zg, torch, np)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
+            try:
+                result["cpu_baseline_config5_all_cores"] = cpu_config5_all_cores()
+            except Exception as e:
+                result["cpu_baseline_config5_all_cores"] = {"error": f"{type(e).__name__}: {e}"}
             if not args.no_extras:
                 cpu_extras(result["extras"])
 
-    if world > 1 and args.scatter_gather:
+    if args.scatter_gather:
         # Not the headline: BASELINE configs[4] end to end — rank 0 holds the batch, shards fan out over RCCL/xGMI
         # (grouped send/recv), every rank runs blur+resize on its shard, results are gathered back.
         try:
@@ -234,11 +251,67 @@ def main():
                 result["scatter_gather_config5"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if world > 1 or args.scatter_gather:
         dist.destroy_process_group()
 
 
-def scatter_gather_leg(zg, torch, sharding, rank, world, local_rank, frames_per_gpu=16):
+def resize_headline(zg, torch):
+    """Image(Rgba(u8)).resize(.bilinear) 4096^2 -> 1024^2 (BASELINE configs[2], channel_ops.zig:144-190), sources rotating through
+    1 GiB of distinct frames. Strict algorithmic bytes (20 B per output pixel) and, beside them, what DRAM has to move for this
+    geometry: the taps are bytes 4..11 of every 16 in rows 1, 2 mod 4 — every 64-byte line of half the rows (counter-checked:
+    profiles/r02_pmc_traffic.txt), which caps the strict fraction at 0.556 of the bandwidth reached."""
+    ring = 16
+    srcs = [torch.randint(0, 256, (ROWS, COLS, 4), dtype=torch.uint8, device="cuda") for _ in range(ring)]
+    im = [(zg.Image(s), zg.Image(torch.empty((1024, 1024, 4), dtype=torch.uint8, device="cuda"))) for s in srcs]
+    ms = _time_kernel(torch, lambda i: im[i % ring][0].resize(im[i % ring][1], zg.Interpolation.bilinear), n=64, warm=8)
+    alg = 20 * 1024 * 1024
+    traffic = None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("k_resize_bilinear_rgba8_4096_to_1024_bytes_per_launch")
+    except Exception:
+        pass
+    dram = ROWS * COLS * 4 // 2 + 4 * 1024 * 1024
+    achieved = alg / (ms * 1e-3) / 1e9
+    return {"workload": "resize(.bilinear) 4096x4096 -> 1024x1024 Rgba(u8), BASELINE.json configs[2]; one frame per launch, graph-replayed",
+            "ms_per_step": round(ms, 5), "Mpixels/s_source": round(ROWS * COLS / ms / 1e3, 1), "Mpixels/s_output": round(1024 * 1024 / ms / 1e3, 1),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "kernel": "k_resize_bilinear_rgba8<1>", "algorithmic_bytes_per_launch": alg,
+                         "dram_granular_bytes_per_launch": dram, "frac_on_dram_granular_bytes": round(dram / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "strict_frac_ceiling_of_this_geometry": round(alg / dram, 3)}}
+
+
+def cpu_config5_all_cores(budget_s: float = 20.0):
+    """config 5 as an N-way frame-parallel CPU run (the reference has no threading of its own: N
+    independent callers, one 1080p frame each at a time). Oracle port, N = the host's logical cores (capped at 64)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import pyoracle as oracle  # baseline leg only
+
+    try:
+        oracle.lib(native=True)
+        native = True
+    except Exception:
+        native = False
+    n = max(1, min(os.cpu_count() or 1, 64))
+    bil = oracle.method(oracle.BILINEAR)
+    frames = [oracle.synth_u8(5 + i, (1080, 1920, 4)) for i in range(min(n, 8))]
+
+    def one(i):  # ctypes releases the GIL for the duration of the C calls
+        return oracle.resize(oracle.gaussian_blur(frames[i % len(frames)], SIGMA, native=native), (540, 960), bil)
+
+    t0 = time.perf_counter(); one(0); single = time.perf_counter() - t0
+    per_thread = max(1, min(8, int(budget_s / 2 / max(single, 1e-3))))
+    with ThreadPoolExecutor(n) as ex:
+        list(ex.map(one, range(n)))  # warm-up: page faults, thread start
+        t0 = time.perf_counter()
+        list(ex.map(one, range(n * per_thread)))
+        wall = time.perf_counter() - t0
+    return {"value": round(n * per_thread * 1080 * 1920 / wall / 1e6, 1), "unit": "Mpixels/s", "cores": n, "kind": "port",
+            "one_caller_Mpixels/s": round(1080 * 1920 / single / 1e6, 1),
+            "sample": f"{n * per_thread} x [gaussianBlur(0.6), resize(.bilinear, 540x960)] on 1080p Rgba(u8) frames, {n} concurrent callers"}
+
+
+def scatter_gather_leg(zg, torch, sharding, rank, world, local_rank, frames_per_gpu=128):
     import ctypes as C
     import torch.distributed as dist
     dev = torch.device("cuda", local_rank)
@@ -247,13 +320,15 @@ def scatter_gather_leg(zg, torch, sharding, rank, world, local_rank, frames_per_
     lib = zg.lib()
     m = zg.Interpolation.bilinear._c()
 
+    loop = world == 1  # one rank: its own shard goes through ncclSend / ncclRecv to itself instead of a device copy
+
     def once():
-        mine = sharding.scatter_frames(batch, n, (rows, cols, 4), torch.uint8, dev)
+        mine = sharding.scatter_frames(batch, n, (rows, cols, 4), torch.uint8, dev, loopback=loop)
         out = torch.empty((mine.shape[0], 540, 960, 4), dtype=torch.uint8, device=dev)
         rc = lib.zg_batch_blur_resize(C.c_void_p(mine.data_ptr()), int(mine.shape[0]), rows, cols, 3, C.c_float(SIGMA),
                                       C.c_void_p(out.data_ptr()), 540, 960, C.byref(m), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0, lib.zg_last_error()
-        return sharding.gather_frames(out, n)
+        return sharding.gather_frames(out, n, loopback=loop)
 
     once()
     torch.cuda.synchronize()
@@ -266,7 +341,10 @@ def scatter_gather_leg(zg, torch, sharding, rank, world, local_rank, frames_per_
     dist.barrier()
     sec = sharding.max_over_ranks((time.perf_counter() - t0) / reps, dev)
     return {"frames": n, "seconds": round(sec, 6), "Mpixels/s_end_to_end": round(n * rows * cols / sec / 1e6, 1),
-            "note": "includes the xGMI scatter of 8.3 MB/frame and gather of 2.1 MB/frame; kernel-only rate is `value`"}
+            "frames_per_gpu": frames_per_gpu, "backend": "nccl (RCCL)" if not os.environ.get("ZG_BENCH_SHARED_GPU") else "gloo",
+            "note": ("one rank: the shard loops back through the communicator (ncclSend / ncclRecv to itself), so this times RCCL's "
+                     "device-local copy path, not xGMI" if world == 1 else
+                     "includes the xGMI scatter of 8.3 MB/frame and gather of 2.1 MB/frame; kernel-only rate is `value`")}
 
 
 def cpu_extras(extras_out):
@@ -375,7 +453,7 @@ def extras(zg, torch, np):
         return rate(ms, ROWS * COLS, 8 * ROWS * COLS)  # 4 B read + 4 B written per pixel
 
     def resize_u8():
-        ring = 8
+        ring = 16  # 1 GiB of sources
         im = [(zg.Image(s), zg.Image(torch.empty((1024, 1024, 4), dtype=torch.uint8, device="cuda"))) for s in u8_frames(ring, (ROWS, COLS, 4))]
         ms = _time_kernel(torch, lambda i: im[i % ring][0].resize(im[i % ring][1], I.bilinear))
         r = rate(ms, ROWS * COLS, 20 * 1024 * 1024)  # 4 taps x 4 B + 4 B per OUTPUT pixel (strict)
