@@ -98,3 +98,31 @@ def test_device_maths_equals_the_oracle_bit_for_bit(fn, oracle):
     same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
     bad = np.flatnonzero(~same)
     assert bad.size == 0, (fn, bad.size, x[bad[:4]], None if y is None else y[bad[:4]], got[bad[:4]], want[bad[:4]])
+
+
+@pytest.mark.gpu
+def test_fast_device_cbrt_equals_the_musl_steps_on_every_f32():
+    """dev_cbrtf (f32 first step, reciprocal-based f64 second step, musl fallback next to rounding midpoints) against musl's
+    cbrtf restated step for step, over all 2^32 bit patterns."""
+    import torch
+
+    import zignal_amd as zg
+
+    lib = zg.lib()
+    n = 1 << 27
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fast, ref = torch.empty(n, dtype=torch.float32, device="cuda"), torch.empty(n, dtype=torch.float32, device="cuda")
+    base = torch.arange(n, dtype=torch.int64, device="cuda")
+    bad = 0
+    for chunk in range(32):
+        bits = (base + chunk * n).to(torch.int32) if chunk < 16 else (base + chunk * n - (1 << 32)).to(torch.int32)
+        x = bits.view(torch.float32)
+        assert lib.zg_devmath_apply(0, C.c_void_p(x.data_ptr()), None, C.c_void_p(fast.data_ptr()), n, stream) == 0
+        assert lib.zg_devmath_apply(9, C.c_void_p(x.data_ptr()), None, C.c_void_p(ref.data_ptr()), n, stream) == 0
+        diff = (fast.view(torch.int32) != ref.view(torch.int32)) & ~(torch.isnan(fast) & torch.isnan(ref))
+        k = int(diff.sum().item())
+        if k:
+            idx = torch.nonzero(diff)[:4, 0]
+            print(f"chunk {chunk}: {k} differ, e.g. x bits {[hex(int(v) & 0xffffffff) for v in bits[idx].tolist()]}")
+        bad += k
+    assert bad == 0, f"{bad} of 2^32 inputs differ"

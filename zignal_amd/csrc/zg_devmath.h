@@ -9,7 +9,7 @@
 
 namespace zg {
 
-__device__ inline float dev_cbrtf(float x) { // Zig std.math.cbrt cbrt32 == musl cbrtf
+__device__ inline float dev_cbrtf_musl(float x) { // Zig std.math.cbrt cbrt32 == musl cbrtf, step for step
     const uint32_t B1 = 709958130u, B2 = 642849266u;
     uint32_t u = __float_as_uint(x);
     uint32_t hx = u & 0x7fffffffu;
@@ -32,6 +32,33 @@ __device__ inline float dev_cbrtf(float x) { // Zig std.math.cbrt cbrt32 == musl
     return (float)t;
 }
 
+// The same function, three times cheaper. musl's two Halley steps run in f64 with two IEEE divisions (~25 f64 instructions
+// each on this part, and xyzToOklab takes three cube roots per pixel). Its result is the f32 nearest to a double that is
+// accurate to ~2^-50, so any double within 2^-44 of the true cube root rounds to the same f32 unless it sits within that
+// distance of a rounding midpoint. Here: the first Halley step in f32 with v_rcp_f32 (it only has to deliver 15 bits), the
+// second in f64 with the quotient formed from a Newton-refined v_rcp_f64 instead of an IEEE division (error ~2^-45); when
+// the double lands within 2^-14 f32 ulp of a midpoint (one lane in 8 192) the lane takes musl's path instead. Subnormal and
+// near-overflow arguments, which would lose bits or overflow in the f32 step, take it as well.
+// tests/test_math_pin.py compares the two over ALL 2^32 bit patterns: identical.
+__device__ inline float dev_cbrtf(float x) {
+    const uint32_t u0 = __float_as_uint(x), hx = u0 & 0x7fffffffu;
+    if (hx < 0x00800000u || hx >= 0x7d800000u) return dev_cbrtf_musl(x); // zero, subnormal, >= 2^124 (3x and its reciprocal must stay normal), inf, nan
+    const float t0 = __uint_as_float((u0 & 0x80000000u) | (hx / 3 + 709958130u));
+    const float r0 = t0 * t0 * t0;
+    const float t1 = t0 * (((x + x) + r0) * __builtin_amdgcn_rcpf((x + r0) + r0)); // the ratio is ~1: nothing under- or overflows
+    const double xd = (double)x, t = (double)t1;
+    const double r = t * t * t;
+    const double num = t * ((xd + xd) + r), den = (xd + r) + r;
+    double rc = __builtin_amdgcn_rcp(den);
+    rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+    rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+    double q = num * rc;
+    q = __builtin_fma(__builtin_fma(-den, q, num), rc, q);
+    const uint32_t low = (uint32_t)__double_as_longlong(q) & 0x1fffffffu; // the 29 significand bits below f32's last
+    const uint32_t off = low > 0x10000000u ? low - 0x10000000u : 0x10000000u - low;
+    if (off < (1u << 15)) return dev_cbrtf_musl(x); // too close to a rounding midpoint to call: the reference's own steps decide
+    return (float)q;
+}
 __device__ inline float dev_scalbnf(float x, int n) {
     float y = x;
     if (n > 127) {
