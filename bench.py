@@ -475,6 +475,15 @@ def extras(zg, torch, np):
         ms = _time_kernel(torch, lambda i: im[i % ring][0].convert(zg.CS_OKLAB, np.float32, out=im[i % ring][1]))
         return rate(ms, ROWS * COLS, 16 * ROWS * COLS)  # 4 B read + 12 B written
 
+    def resize_oklab_fused():
+        # BASELINE configs[2] as ONE call: bilinear 4096^2 -> 1024^2 Rgba(u8) and Rgb -> Oklab(f32) fused (zg_resize_convert)
+        ring = 16
+        im = [(zg.Image(s), zg.Image(torch.empty((1024, 1024, 3), dtype=torch.float32, device="cuda"))) for s in u8_frames(ring, (ROWS, COLS, 4))]
+        ms = _time_kernel(torch, lambda i: im[i % ring][0].resize_convert(im[i % ring][1], zg.CS_OKLAB))
+        r = rate(ms, ROWS * COLS, 28 * 1024 * 1024)  # 4 taps x 4 B read + 12 B written per OUTPUT pixel
+        r["GB/s_sector_basis"] = round((ROWS * COLS * 4 // 2 + 12 * 1024 * 1024) / ms / 1e6, 1)
+        return r
+
     def warp(kind):
         tr = zg.ProjectiveTransform.from_points([(0, 0), (4095, 0), (0, 4095), (4095, 4095)], [(200, 120), (3900, 60), (90, 3980), (4000, 4050)])
         ring = 4
@@ -634,6 +643,7 @@ def extras(zg, torch, np):
     leg("resize_bilinear_rgba_u8_8192_to_4096", lambda: resize_dense(8192, 4096))
     leg("resize_bilinear_rgba_u8_2048_to_4096", lambda: resize_dense(2048, 4096))
     leg("config3_convert_rgba_u8_to_oklab_f32_4096", oklab)
+    leg("config3_fused_resize_bilinear_to_oklab_4096_to_1024", resize_oklab_fused)
     leg("config4_warp_projective_bicubic_rgba_u8_4096", lambda: warp("u8"))
     leg("config4_warp_projective_bicubic_rgba_f32_4096", lambda: warp("f32"))
     leg("config5_batch_blur_resize_64x1080p_rgba_u8", batch)

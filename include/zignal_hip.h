@@ -297,6 +297,16 @@ ZG_API int zg_convert(const zg_image *src, int src_space, const zg_image *dst, i
 ZG_API int zg_convert_host(const zg_image *src, int src_space, const zg_image *dst, int dst_space,
                            const float *srgb_lut);
 
+/* The pipeline steps [resize, convert] (reference src/cli/pipeline.zig:153-179; BASELINE configs[2]: Image(Rgba(u8)).resize(.bilinear)
+ * then .convert(Oklab(f32))) in ONE call and, where a fused kernel exists (Rgba(u8) source, bilinear, Oklab / Xyz f32 destination),
+ * one pass: the resized pixel never goes to memory. dst has the resized shape and the converted type. The result equals
+ * zg_resize into a temporary followed by zg_convert, bit for bit, for every combination (the others run as those two steps
+ * through scratch). */
+ZG_API int zg_resize_convert(const zg_image *src, int src_space, const zg_image *dst, int dst_space, const zg_method *method,
+                             const float *srgb_lut, zg_stream stream);
+ZG_API int zg_resize_convert_host(const zg_image *src, int src_space, const zg_image *dst, int dst_space, const zg_method *method,
+                                  const float *srgb_lut);
+
 /* Diagnostics, not part of Image(T): the library's device-side maths (the restatements of Zig's std.math.cbrt / pow / exp / log /
  * sin / cos / atan2 that convertColor and motionBlur reach on the device, zignal_amd/csrc/zg_devmath.h) applied element-wise to
  * device arrays of n floats. fn: 0 cbrt, 1 pow(x, 2.4), 2 exp, 3 log, 4 sin, 5 cos, 6 atan2(x, y), 7 pow(x, y), 8 gammaToLinear

@@ -423,6 +423,34 @@ def test_config3_resize_then_oklab(oracle):
     assert np.array_equal(got_small, ((s[1::4, 1::4] + s[1::4, 2::4] + s[2::4, 1::4] + s[2::4, 2::4]) // 4).astype(np.uint8))
 
 
+def test_resize_convert_equals_the_two_steps(oracle):
+    """zg_resize_convert: [resize, convert] in one call — fused for Rgba(u8) bilinear -> Oklab / Xyz, composed otherwise — equals the
+    oracle's resize followed by its convert, bit for bit, on both layers; BASELINE configs[2] at full size below."""
+    bil = oracle.method(oracle.BILINEAR)
+    for (sr, sc), (dr, dc) in (((64, 64), (16, 16)), ((37, 53), (19, 71)), ((5, 2), (9, 30)), ((300, 200), (77, 130))):
+        src = oracle.synth_u8(40, (sr, sc, 4))
+        small = oracle.resize(src, (dr, dc), bil)
+        for space, ospace in ((zg.CS_OKLAB, oracle.CS_OKLAB), (zg.CS_XYZ, oracle.CS_XYZ)):
+            want = oracle.convert(small, oracle.CS_RGBA, ospace, np.float32, 3)
+            assert_bits_equal(sync(dev(src).resize_convert((dr, dc), space)), want, f"fused {sr}x{sc}->{dr}x{dc} space {space}")
+            assert_bits_equal(zg.Image(src).resize_convert((dr, dc), space).data, want, "fused, host layer")
+        # a caller-made sRGB table is honoured by the fused kernel too
+        lut = (np.arange(256, dtype=np.float32) / 255) ** 2
+        want = oracle.convert(small, oracle.CS_RGBA, oracle.CS_OKLAB, np.float32, 3, srgb_lut=lut)
+        assert_bits_equal(sync(dev(src).resize_convert((dr, dc), zg.CS_OKLAB, srgb_lut=lut)), want, "fused, caller lut")
+    # combinations without a fused kernel run as the two steps
+    src = oracle.synth_u8(41, (40, 60, 3))
+    want = oracle.convert(oracle.resize(src, (25, 33), oracle.method(oracle.BICUBIC)), oracle.CS_RGB, oracle.CS_OKLAB, np.float32, 3)
+    assert_bits_equal(sync(dev(src).resize_convert((25, 33), zg.CS_OKLAB, method=I.bicubic)), want, "composed rgb bicubic")
+    srcf = oracle.synth_f32(42, (40, 60, 4))
+    want = oracle.convert(oracle.resize(srcf, (20, 30), bil), oracle.CS_RGBA, oracle.CS_GRAY, np.uint8, 1)
+    assert_bits_equal(sync(dev(srcf).resize_convert((20, 30), zg.CS_GRAY, dtype=np.uint8)), want, "composed f32 -> gray u8")
+    # configs[2] at full size
+    src = oracle.synth_u8(3, (4096, 4096, 4))
+    want = oracle.convert(oracle.resize(src, (1024, 1024), bil), oracle.CS_RGBA, oracle.CS_OKLAB, np.float32, 3)
+    assert_bits_equal(sync(dev(src).resize_convert((1024, 1024), zg.CS_OKLAB)), want, "configs[2] fused at full size")
+
+
 @pytest.mark.parametrize("kind", ("rgba_u8", "rgba_f32"))
 def test_config4_projective_bicubic(oracle, kind):
     src_pts = [(0, 0), (4095, 0), (0, 4095), (4095, 4095)]

@@ -78,6 +78,8 @@ pub const c = struct {
     pub extern fn zg_lanczos_plane_weights(src_n: u32, dst_n: u32, weights: [*]f32) c_int;
     pub extern fn zg_resize_lanczos_weights(src: *const ZgImage, dst: *const ZgImage, wx: ?[*]const f32, wy: ?[*]const f32, stream: ?*anyopaque) c_int;
     pub extern fn zg_resize_lanczos_weights_host(src: *const ZgImage, dst: *const ZgImage, wx: ?[*]const f32, wy: ?[*]const f32) c_int;
+    pub extern fn zg_resize_convert(src: *const ZgImage, src_space: c_int, dst: *const ZgImage, dst_space: c_int, method: *const ZgMethod, srgb_lut: ?[*]const f32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_resize_convert_host(src: *const ZgImage, src_space: c_int, dst: *const ZgImage, dst_space: c_int, method: *const ZgMethod, srgb_lut: ?[*]const f32) c_int;
     pub extern fn zg_stream_create(out: *?*anyopaque) c_int;
     pub extern fn zg_stream_destroy(stream: ?*anyopaque) c_int;
     pub extern fn zg_stream_synchronize(stream: ?*anyopaque) c_int;
@@ -732,6 +734,17 @@ pub fn DeviceImage(comptime T: type) type {
                 else => @compileError("colour space not on the GPU hot path"),
             };
             check(c.zg_convert(&self.desc(), src_space, &out.desc(), dst_space, &lut, self.stream)) catch unreachable;
+        }
+        /// resize(out-sized, method) followed by convertInto(Target) as one call (zg_resize_convert): the pipeline steps
+        /// [resize, convert] of src/cli/pipeline.zig:153-179 without the intermediate image.
+        pub fn resizeConvertInto(self: Self, comptime Target: type, out: DeviceImage(Target), method: Interpolation) void {
+            const lut = srgbLut();
+            const src_space: c_int = switch (pixelOf(T)) { .u8, .f32 => 0, .rgb_u8, .rgb_f32 => 1, .rgba_u8, .rgba_f32 => 2 };
+            const dst_space: c_int = comptime if (Target == u8 or Target == f32) 0 else switch (Target.space) {
+                .gray => 0, .rgb => 1, .rgba => 2, .oklab => 3, .xyz => 4, .ycbcr => 5,
+                else => @compileError("colour space not on the GPU hot path"),
+            };
+            check(c.zg_resize_convert(&self.desc(), src_space, &out.desc(), dst_space, &methodOf(method, null), &lut, self.stream)) catch unreachable;
         }
         /// reference src/image.zig:418-422
         pub fn convert(self: Self, allocator: std.mem.Allocator, comptime Target: type) !DeviceImage(Target) {

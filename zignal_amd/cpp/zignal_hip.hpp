@@ -248,6 +248,11 @@ template <template <typename> class Img, typename T> class Ops {
         convertInto<Target>(out);
         return out;
     }
+    // resize then convert in one call (zg_resize_convert): the pipeline steps [resize, convert] without the intermediate image
+    template <typename Target> void resizeConvertInto(const Of<Target> &out, Interpolation method) const {
+        const zg_image s = desc(), d = out.desc(); const zg_method m = method.c_method();
+        run(zg_resize_convert, zg_resize_convert_host, &s, (int)PixelTraits<T>::space, &d, (int)PixelTraits<Target>::space, &m, (const float *)nullptr);
+    }
     // ---- file output (src/codecs/jpeg.zig:307, src/codecs/png.zig:1400); the file lands in host memory either way ----
     std::vector<uint8_t> encodeJpeg(const zg_jpeg_encode_options *options = nullptr) const {
         uint8_t *mem = nullptr;

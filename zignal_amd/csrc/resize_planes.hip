@@ -15,6 +15,7 @@
 // Per output pixel the kernel reads T x T source pixels and writes one: that is the algorithmic traffic.
 #include "zg_common.h"
 #include "zg_hostmath.h"
+#include "zg_bilinear_u8.h"
 
 #include <cmath>
 #include <cstring>
@@ -301,27 +302,6 @@ static int axis_table(int kind, uint32_t src_n, uint32_t dst_n, int taps, AxisTa
 //     four destination pixels per lane, the row taps computed once, one 16-byte store.
 //     For strong downscales NPX = 4 is slower (12.2 us against 8.8 us for 4096^2 -> 1024^2: the lanes of one gather
 //     instruction then sit 256 bytes apart instead of 16), so those keep one pixel per lane.
-__device__ inline void bilinear_taps(int d, float ratio, int n, int &i0, int &i1, int &f) {
-    const float sf = ((float)d + 0.5f) * ratio - 0.5f;
-    const float fl = floorf(sf);
-    const int base = (int)fl;
-    f = (int)truncf((sf - fl) * 256.0f);
-    i0 = base;
-    i1 = base + 1;
-    if (base < 0 || base + 1 >= n) { i0 = resolve_index(base, n, ZG_BORDER_MIRROR); i1 = resolve_index(base + 1, n, ZG_BORDER_MIRROR); }
-}
-__device__ inline uint32_t bilinear_rgba8(uint32_t tl, uint32_t tr, uint32_t bl, uint32_t br, int fx, int fy) {
-    uint32_t px = 0;
-#pragma unroll
-    for (int ch = 0; ch < 4; ++ch) {
-        const int a = (int)((tl >> (8 * ch)) & 0xffu), b = (int)((tr >> (8 * ch)) & 0xffu);
-        const int c = (int)((bl >> (8 * ch)) & 0xffu), d = (int)((br >> (8 * ch)) & 0xffu);
-        const int top = a * (256 - fx) + b * fx;
-        const int bottom = c * (256 - fx) + d * fx;
-        px |= (uint32_t)((top * (256 - fy) + bottom * fy) >> 16) << (8 * ch); // @divTrunc(.., 65536), operand >= 0, <= 255
-    }
-    return px;
-}
 template <int NPX>
 __global__ __launch_bounds__(256) void k_resize_bilinear_rgba8(DImg src, DImg dst, float ratio_x, float ratio_y, int tiles_x) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));

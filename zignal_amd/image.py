@@ -621,6 +621,29 @@ class Image:
         return out
 
 
+    def resize_convert(self, size_or_out, dst_space: int, dtype=np.float32, method: Interpolation = Interpolation.bilinear,
+                       src_space: Optional[int] = None, srgb_lut=None) -> "Image":
+        """The pipeline steps [resize, convert] as one call (zg_resize_convert): `resize(size).convert(dst_space)` without the
+        intermediate image wherever a fused kernel exists (Rgba(u8), bilinear -> Oklab / Xyz f32), bit-identical to the two calls."""
+        if src_space is None:
+            src_space = {1: L.CS_GRAY, 3: L.CS_RGB, 4: L.CS_RGBA}[1 if self.data.ndim == 2 else self.data.shape[2]]
+        ch = 1 if dst_space == L.CS_GRAY else (4 if dst_space == L.CS_RGBA else 3)
+        if isinstance(size_or_out, Image):
+            out = size_or_out
+        elif self.on_device:
+            tdtype = {np.uint8: torch.uint8, np.float32: torch.float32}[np.dtype(dtype).type]
+            out = self._like(int(size_or_out[0]), int(size_or_out[1]), dtype=tdtype, channels=ch)
+        else:
+            out = self._like(int(size_or_out[0]), int(size_or_out[1]), dtype=np.dtype(dtype), channels=ch)
+        self._same_side(out)
+        lut = None
+        if srgb_lut is not None:
+            _keep, lut = _f32_array(srgb_lut)
+        s, d, m = self._desc(), out._desc(), method._c()
+        self._call("resize_convert", C.byref(s), int(src_space), C.byref(d), int(dst_space), C.byref(m), lut)
+        return out
+
+
 def _round_half_away(v) -> float:
     v = float(v)
     return math.floor(abs(v) + 0.5) * (1.0 if v >= 0 else -1.0)
