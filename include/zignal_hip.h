@@ -411,6 +411,28 @@ ZG_API int zg_batch_blur_resize(const void *src_frames, uint32_t n_frames,
                                 void *dst_frames, uint32_t out_rows, uint32_t out_cols,
                                 const zg_method *method, zg_stream stream);
 
+/* ---- the node's GPUs from one host process (BASELINE configs[4]) --------------------------------------------------------------- */
+
+/* Two routes to several GPUs:
+ *   (1) one host thread per GPU, each calling zg_set_device(i) once and then the ordinary entry points — no library state is
+ *       shared between devices (scratch, tables and streams are per device);
+ *   (2) a zg_multi context: ONE thread drives every GPU of the context. The root (first) device holds the batch; the shards go
+ *       to their owners and the results come back over RCCL (grouped ncclSend / ncclRecv: one shard per xGMI peer link, no
+ *       ring), each device runs zg_batch_blur_resize on its shard on its own stream; frames are independent, so there is no
+ *       halo and no collective on the data path. librccl is loaded at first use (dlopen).
+ * devices == NULL means 0 .. n_devices - 1; n_devices <= 0 means every visible device. */
+typedef void *zg_multi;
+ZG_API int zg_multi_create(const int *devices, int n_devices, zg_multi *out);
+ZG_API int zg_multi_destroy(zg_multi m);
+ZG_API int zg_multi_device_count(zg_multi m);
+/* zg_batch_blur_resize over the context's devices. src_frames_root / dst_frames_root are device pointers ON THE ROOT DEVICE holding
+ * all n_frames input frames / receiving all output frames. Device i owns a contiguous block of frames (sizes differ by at
+ * most one). Synchronous: results are complete on return. times_ms (may be NULL) receives wall milliseconds of {scatter, compute,
+ * gather}; asking for them adds a synchronisation between the phases. */
+ZG_API int zg_multi_batch_blur_resize(zg_multi m, const void *src_frames_root, uint32_t n_frames, uint32_t rows, uint32_t cols, int pixel,
+                                      float sigma, void *dst_frames_root, uint32_t out_rows, uint32_t out_cols, const zg_method *method,
+                                      float times_ms[3]);
+
 /* ---- the host I/O edge: PNG (src/codecs/png.zig) -------------------------- */
 
 /* Where frames come from and go to. The entropy-coded layers stay on the host (the chunk layer with the reference's

@@ -169,6 +169,48 @@ int main(int argc, char **argv) {
         EXPECT(same_bits(eager_blur.toHost(), want_blur));
     }
 
+    { // the node's GPUs from this one thread (zg_multi): on a one-GPU box the context has one device; with ZIGNAL_HIP_MULTI_LOOPBACK the
+      // root's shard makes its round trip through an RCCL communicator (ncclCommInitAll, grouped ncclSend / ncclRecv) all the same
+        const uint32_t n = quick ? 3 : 7, rows = 270, cols = 480;
+        std::vector<uint8_t> frames((size_t)n * rows * cols * 4);
+        for (auto &b : frames) b = (uint8_t)lcg(seed);
+        void *dsrc = nullptr, *dref = nullptr, *dout = nullptr;
+        const size_t in_bytes = frames.size(), out_bytes = (size_t)n * (rows / 2) * (cols / 2) * 4;
+        check(zg_malloc(&dsrc, in_bytes)); check(zg_malloc(&dref, out_bytes)); check(zg_malloc(&dout, out_bytes));
+        check(zg_memcpy_h2d(dsrc, frames.data(), in_bytes, nullptr));
+        const zg_method bil = {ZG_INTERP_BILINEAR, 0, 0, nullptr};
+        check(zg_batch_blur_resize(dsrc, n, rows, cols, ZG_PIXEL_RGBA_U8, sigma, dref, rows / 2, cols / 2, &bil, nullptr));
+        std::vector<uint8_t> want(out_bytes), got(out_bytes);
+        check(zg_memcpy_d2h(want.data(), dref, out_bytes, nullptr));
+        { // one frame of the batch against the oracle, so `want` is not merely self-consistent
+            Image<Rgba<uint8_t>> f0 = Image<Rgba<uint8_t>>::initFromSlice(rows, cols, (Rgba<uint8_t> *)frames.data());
+            auto b0 = Image<Rgba<uint8_t>>::init(rows, cols), s0 = Image<Rgba<uint8_t>>::init(rows / 2, cols / 2);
+            const zo_image zs = zo_of(f0), zb = zo_of(b0), zw = zo_of(s0);
+            const zo_method zbil = {ZO_BILINEAR, 0, 0, nullptr};
+            EXPECT(zo_gaussian_blur(&zs, &zb, sigma) == 0 && zo_resize(&zb, &zw, &zbil) == 0);
+            EXPECT(std::memcmp(want.data(), s0.data, (size_t)(rows / 2) * (cols / 2) * 4) == 0);
+        }
+        for (int loop = 0; loop < (quick ? 1 : 2); ++loop) { // the RCCL round trip (2.5 s of communicator set-up) only in the full run
+            if (loop) setenv("ZIGNAL_HIP_MULTI_LOOPBACK", "1", 1); else unsetenv("ZIGNAL_HIP_MULTI_LOOPBACK");
+            zg_multi ctx = nullptr;
+            check(zg_multi_create(nullptr, 1, &ctx));
+            EXPECT(zg_multi_device_count(ctx) == 1);
+            const uint8_t junk = 0xA5;
+            std::vector<uint8_t> fill(out_bytes, junk);
+            check(zg_memcpy_h2d(dout, fill.data(), out_bytes, nullptr));
+            float t[3] = {0, 0, 0};
+            check(zg_multi_batch_blur_resize(ctx, dsrc, n, rows, cols, ZG_PIXEL_RGBA_U8, sigma, dout, rows / 2, cols / 2, &bil, t));
+            check(zg_memcpy_d2h(got.data(), dout, out_bytes, nullptr));
+            EXPECT(got == want);
+            std::printf(loop ? "multi_1gpu_rccl_loopback_ms=%.3f %.3f %.3f\n" : "multi_1gpu_ms=%.3f %.3f %.3f\n", t[0], t[1], t[2]);
+            check(zg_multi_destroy(ctx));
+        }
+        unsetenv("ZIGNAL_HIP_MULTI_LOOPBACK");
+        zg_multi bad = nullptr;
+        EXPECT(zg_multi_create(nullptr, 99, &bad) == ZG_ERR_INVALID_ARGUMENT && bad == nullptr); // more devices than the box has
+        check(zg_free(dsrc)); check(zg_free(dref)); check(zg_free(dout));
+    }
+
     std::printf(failures ? "%d FAILED\n" : "device image ok\n", failures);
     return failures ? 1 : 0;
 }

@@ -61,7 +61,7 @@ def test_device_image_chain_banded_host_layer_and_graph_capture():
     _ensure_built()
     rc, log = _run([BIN_DEV], 600)
     assert rc == 0 and "device image ok" in log, log
-    vals = {k: float(v) for k, v in re.findall(r"^(\w+)=([0-9.]+)$", log, re.M)}
+    vals = {k: float(v) for k, v in re.findall(r"^(\w+)=([0-9.]+)(?: [0-9. ]+)?$", log, re.M)}
     print(log)
 
     # the same resident chain driven from Python (what bench.py's legs time), with device events on the same stream

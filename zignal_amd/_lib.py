@@ -132,6 +132,10 @@ _SIGNATURES = {
     "zg_resize_lanczos_weights_host": [_IMG, _IMG, _F32P, _F32P],
     "zg_resize_convert": [_IMG, C.c_int, _IMG, C.c_int, _METHOD, _F32P, C.c_void_p],
     "zg_resize_convert_host": [_IMG, C.c_int, _IMG, C.c_int, _METHOD, _F32P],
+    "zg_multi_create": [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)],
+    "zg_multi_destroy": [C.c_void_p],
+    "zg_multi_device_count": [C.c_void_p],
+    "zg_multi_batch_blur_resize": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_float, C.c_void_p, C.c_uint32, C.c_uint32, _METHOD, _F32P],
     "zg_stream_create": [C.POINTER(C.c_void_p)],
     "zg_stream_destroy": [C.c_void_p],
     "zg_stream_synchronize": [C.c_void_p],

@@ -42,12 +42,14 @@ int zg_batch_blur_resize(const void *src_frames, uint32_t n_frames, uint32_t row
     std::vector<int32_t> taps;
     if (sigma > 0 && pixel == ZG_PIXEL_RGBA_U8) {
         float f[255];
-        const int n = zg_gaussian_kernel(sigma, f, 255);
+        int n = zg_gaussian_kernel(sigma, nullptr, 0);
         if (n < 0) return -n;
-        taps.resize((size_t)n);
-        for (int i = 0; i < n; ++i) taps[(size_t)i] = (int32_t)std::round(f[i] * 256.0f);
+        if (n <= 255) n = zg_gaussian_kernel(sigma, f, 255); // longer kernels take the general per-frame path below
+        if (n < 0) return -n;
+        if (n <= 255) taps.resize((size_t)n);
+        for (size_t i = 0; i < taps.size(); ++i) taps[i] = (int32_t)std::round(f[i] * 256.0f);
         const bool half = method->kind == ZG_INTERP_BILINEAR && rows == 2 * out_rows && cols == 2 * out_cols;
-        if (half) {
+        if (half && !taps.empty()) {
             const Rgba8Batch b{src_frames, dst_frames, n_frames, rows, cols, cols, out_cols, in_px, out_px, true};
             const int rc = try_sep_rgba8_batch(b, taps.data(), taps.data(), n, ZG_BORDER_MIRROR, s);
             if (rc >= 0) return rc;
