@@ -263,6 +263,17 @@ def test_config2_full_size(oracle, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ("rgba_f32", "rgba_u8", "f32"))
+def test_config2_binomial_zero_border_full_size(oracle, kind):
+    """SURVEY 8(d)'s second input for config 2: the binomial [1, 4, 6, 4, 1] / 16 with BorderMode.zero through convolveSeparable, 4096^2."""
+    k = np.array([1, 4, 6, 4, 1], np.float32) / 16
+    img = synth(oracle, kind, 22, 4096, 4096)
+    out = dev(img).convolve_separable(k, k, zg.BorderMode.zero)
+    torch.cuda.synchronize()
+    assert_bits_equal(out.to_numpy(), oracle.conv_separable(img, k, k, oracle.ZERO), f"4096^2 {kind} binomial .zero")
+
+
+@pytest.mark.gpu
 def test_c_abi_without_torch_objects(oracle):
     """The runtime entry points on their own: device memory from zg_malloc, a stream from zg_stream_create, copies through
     zg_memcpy_h2d / d2h — the way a Zig or C caller drives the library, no torch tensor anywhere near the pixels."""

@@ -451,13 +451,24 @@ def test_resize_convert_equals_the_two_steps(oracle):
     assert_bits_equal(sync(dev(src).resize_convert((1024, 1024), zg.CS_OKLAB)), want, "configs[2] fused at full size")
 
 
+def test_config3_rgba_f32_variant_at_full_size(oracle):
+    """SURVEY 8(d) lists config 3 also for Image(Rgba(f32)): the generic resizer (interpolation.zig:194-214, lerpFloat) 4096^2 ->
+    1024^2, then Rgba(f32) -> Oklab(f32) through the device's own gammaToLinear (pow) and cbrt."""
+    src = oracle.synth_f32(3, (4096, 4096, 4))
+    small = oracle.resize(src, (1024, 1024), oracle.method(oracle.BILINEAR))
+    got = dev(src).resize((1024, 1024), I.bilinear)
+    assert_bits_equal(sync(got), small, "configs[2] Rgba(f32) resize")
+    assert_bits_equal(sync(got.convert(zg.CS_OKLAB, np.float32)), oracle.convert(small, oracle.CS_RGBA, oracle.CS_OKLAB, np.float32, 3), "configs[2] Rgba(f32) -> Oklab")
+    assert_bits_equal(sync(dev(src).resize_convert((1024, 1024), zg.CS_OKLAB)), oracle.convert(small, oracle.CS_RGBA, oracle.CS_OKLAB, np.float32, 3), "configs[2] Rgba(f32), one call")
+
+
 @pytest.mark.parametrize("kind", ("rgba_u8", "rgba_f32"))
 def test_config4_projective_bicubic(oracle, kind):
     src_pts = [(0, 0), (4095, 0), (0, 4095), (4095, 4095)]
     dst_pts = [(200, 120), (3900, 60), (90, 3980), (4000, 4050)]
     # backward map (output -> source), solved in f64 then cast to f32 as qrcode/detector.zig:667-677 does
     hmat = oracle.homography_from_4pts(src_pts, dst_pts)
-    rows = 4096 if kind == "rgba_u8" else 2048  # keep the oracle's share of the run to seconds
+    rows = 4096  # all of BASELINE configs[3] for both pixel types (the oracle needs a few seconds for the f32 one)
     src = synth(oracle, kind, 4, 4096, 4096)
     got = sync(dev(src).warp(zg.ProjectiveTransform(hmat), (rows, 4096), I.bicubic))
     want = oracle.warp(src, (rows, 4096), oracle.PROJECTIVE, hmat, om(oracle, I.bicubic))
@@ -479,6 +490,29 @@ def test_config5_batch_pipeline(oracle):
     for i in range(n):
         want = oracle.resize(oracle.gaussian_blur(frames[i], 0.6), (540, 960), om(oracle, I.bilinear))
         assert_bits_equal(got[i], want, f"config5 frame {i}")
+
+
+def test_config5_at_the_per_gpu_shard_size(oracle):
+    """BASELINE configs[4]: 1024 frames over 8 GPUs = 128 frames of 1080p per GPU in ONE zg_batch_blur_resize call (1.06 GB in,
+    265 MB out); every 16th frame and the last one against the oracle, and no frame may equal its neighbour's result (each slot
+    of the batch was really written from its own source)."""
+    import ctypes as C
+    n, rows, cols = 128, 1080, 1920
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(55)
+    t_in = torch.randint(0, 256, (n, rows, cols, 4), dtype=torch.uint8, device="cuda", generator=gen)
+    t_out = torch.zeros((n, 540, 960, 4), dtype=torch.uint8, device="cuda")
+    m = I.bilinear._c()
+    rc = zg.lib().zg_batch_blur_resize(C.c_void_p(t_in.data_ptr()), n, rows, cols, 3, C.c_float(0.6), C.c_void_p(t_out.data_ptr()),
+                                       540, 960, C.byref(m), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, zg.lib().zg_last_error()
+    torch.cuda.synchronize()
+    for i in list(range(0, n, 16)) + [n - 1]:
+        frame = t_in[i].cpu().numpy()
+        want = oracle.resize(oracle.gaussian_blur(frame, 0.6), (540, 960), om(oracle, I.bilinear))
+        assert_bits_equal(t_out[i].cpu().numpy(), want, f"config5 128-frame batch, frame {i}")
+    sums = t_out.view(n, -1).to(torch.int64).sum(dim=1)
+    assert int((sums > 0).sum()) == n and len(set(sums.tolist())) == n
 
 
 @pytest.mark.parametrize("case", ["half_sigma1", "third_bicubic", "odd_cols", "f32"])
