@@ -15,6 +15,8 @@
 //   k_box_mean   one thread per pixel: four SAT taps, divide by the clipped area, clamp.
 #include "zg_common.h"
 
+#include <cstdlib>
+
 #pragma clang fp contract(off)
 
 namespace zg {
@@ -189,6 +191,165 @@ __global__ __launch_bounds__(256) void k_sat_rows_exact(DImg src, float *sat) { 
     }
 }
 
+// ---- exact-row sources: strip carries, then prefix + chain + store in one pass ------------------------------------------------
+// The three-kernel form writes the row prefixes (4 B per element), reads them back for the column chain and writes the SAT:
+// 12 B of traffic per element for 4 B of result, and the chain kernel has only columns x channels / 64 waves to pull it with.
+// For sources whose row sums are exact (see k_sat_rows_exact) the row prefix of any element is "the sum of everything left of
+// its 16-column strip" (an exact integer, the strip's CARRY) plus a prefix inside the strip, so the column chain can rebuild
+// it on the fly: k_strip_carries writes one value per row, strip and channel (1/16 of a plane), k_sat_chain reads the source
+// once and writes the SAT once.
+
+// carry[(r * nstrips + s) * C + ch] = sum of row r, channel ch, over columns < 16 s, as an exact f32. One workgroup per row,
+// every channel at once (the source is read once): 4 pixels per thread and step, integer block scan.
+template <int PIX>
+__global__ __launch_bounds__(256) void k_strip_carries(DImg src, float *carries, int nstrips) {
+    using P = Px<PIX>;
+    constexpr int C = P::C;
+    __shared__ uint32_t wsum[4][C];
+    const int r = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    uint32_t carry[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) carry[ch] = 0;
+    for (int c0 = 0; c0 < src.cols; c0 += 1024) {
+        const int c = c0 + 4 * t;
+        uint32_t p[4][C];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const typename P::Vec v = P::load(src.data, (size_t)r * src.stride + (size_t)min(c + k, src.cols - 1)); // clamped, unpredicated
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) p[k][ch] = c + k < src.cols ? (uint32_t)v[ch] : 0u; // integer-valued elements (u8, or f32 holding 0..255)
+        }
+        uint32_t x[C];
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            p[1][ch] += p[0][ch]; p[2][ch] += p[1][ch]; p[3][ch] += p[2][ch];
+            x[ch] = p[3][ch];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = (uint32_t)__shfl_up((int)x[ch], d);
+                if (lane >= d) x[ch] += y;
+            }
+            if (lane == 63) wsum[w][ch] = x[ch];
+        }
+        __syncthreads();
+        const int next = c + 4; // the prefix through column c + 3 is the carry of the strip that starts at column c + 4
+        const bool boundary = (next & 15) == 0 && next < src.cols;
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            uint32_t base = carry[ch] + x[ch];
+            if (w > 0) base += wsum[0][ch];
+            if (w > 1) base += wsum[1][ch];
+            if (w > 2) base += wsum[2][ch];
+            if (boundary) carries[((size_t)r * nstrips + (next >> 4)) * C + ch] = (float)base; // < 2^24: exact
+            carry[ch] += wsum[0][ch] + wsum[1][ch] + wsum[2][ch] + wsum[3][ch];
+        }
+        if (c0 == 0 && t < C) carries[(size_t)r * nstrips * C + t] = 0.0f; // strip 0
+        __syncthreads();
+    }
+}
+
+// A workgroup owns four adjacent 16-column strips of ONE channel for the whole height (64 columns: 256 contiguous bytes of SAT
+// per row; strips of all channels in one workgroup were tried first and wrote 64-byte pieces into four planes: 0.8 TB/s).
+// Lane = slot * 16 + column, slot = strip within the workgroup. The row prefix of an element is its strip's carry plus an inclusive
+// scan over the 16 lanes of its slot (DPP row_shr 1, 2, 4, 8), exact; the SAT is the reference's column recurrence
+// sat[r][c] = sat[r-1][c] + rowprefix[r][c] (integral.zig:60-77): one f32 addition per row, top to bottom.
+// Only that one addition per row is sequential, and a wave that loads, scans, chains and stores by itself spends its life
+// waiting for memory (measured: 65 ns per row whatever it does — two microseconds of latency over the ~32 rows one wave can
+// keep in flight). So the roles are split: waves 1..8 are LOADERS, each taking 8 rows of every 64-row block, six blocks
+// ahead (9 loads per block and loader: 54 of the 63 operations a wave can track), turning them into row prefixes in an LDS
+// ring; wave 0 is the CHAIN: per row one LDS read, one addition, one store, and nothing in its memory queue but stores.
+template <int PIX>
+__global__ __launch_bounds__(576) void k_sat_chain(DImg src, const float *carries, float *sat, int nstrips) {
+    using P = Px<PIX>;
+    using Elem = typename P::Elem;
+    constexpr int C = P::C;
+    constexpr int SB = 64, NL = 8, RL = SB / NL, D = 6; // rows per block, loader waves, rows per loader and block, blocks in flight
+    __shared__ float ring[2][SB][64];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, slot = lane >> 4, col16 = lane & 15;
+    const int strip0 = blockIdx.x * 4, ch = blockIdx.y; // four adjacent strips of one channel: 64 columns, 256 B of SAT per row
+    const int strip = strip0 + slot;
+    const int c = strip * 16 + col16;
+    const bool live = strip < nstrips && c < src.cols; // past the last strip, past the last column
+    const int rows = src.rows;
+    const int nblocks = (rows + SB - 1) / SB;
+
+    if (wave == 0) { // ---- the chain --------------------------------------------------------------------------------------
+        float *out = sat + (size_t)ch * rows * src.cols + min(c, src.cols - 1);
+        const size_t out_step = (size_t)src.cols;
+        const bool all_live = strip0 * 16 + 64 <= src.cols; // workgroup-uniform
+        float run = 0.0f;
+        for (int blk = 0; blk < nblocks; ++blk) {
+            __syncthreads(); // block blk is in ring[blk & 1]
+            const int r0 = blk * SB;
+            float p[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) p[i] = ring[blk & 1][i][lane];
+            if (r0 + SB <= rows && all_live) { // the common case: no predicate anywhere, 64 stores back to back
+#pragma unroll
+                for (int i = 0; i < SB; ++i) {
+                    run = run + p[i];
+                    out[(size_t)(r0 + i) * out_step] = run;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < SB; ++i) {
+                    run = run + p[i];
+                    if (live && r0 + i < rows) out[(size_t)(r0 + i) * out_step] = run;
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- a loader: rows sub * RL .. + RL of every block ---------------------------------------------------------------------
+    const int sub = wave - 1;
+    const uint32_t live_mask = live ? 0xffffffffu : 0u;
+    const Elem *base = (const Elem *)src.data + (size_t)min(c, src.cols - 1) * C + ch;
+    const size_t src_step = (size_t)src.stride * C, carry_step = (size_t)nstrips * C;
+    // carry fetch: lane L holds the carry of (row L / 4 of this loader's eight, slot L % 4); lanes 32.. repeat lanes 0..31
+    const int cslot = lane & 3, crow = (lane >> 2) & (RL - 1);
+    const size_t cidx = (size_t)min(strip0 + cslot, nstrips - 1) * C + ch;
+    const int bperm0 = slot * 4; // byte address of lane `slot`; row i adds 16 i
+
+    struct Regs { uint32_t v[RL]; float k; };
+    auto fetch = [&](int blk, Regs &g) { // clamped, unpredicated; blocks past the end re-read the last row and are never used
+        const int r0 = blk * SB + sub * RL;
+#pragma unroll
+        for (int i = 0; i < RL; ++i) g.v[i] = (uint32_t)base[(size_t)min(r0 + i, rows - 1) * src_step];
+        g.k = carries[(size_t)min(r0 + crow, rows - 1) * carry_step + cidx];
+    };
+    auto publish = [&](int blk, const Regs &g) {
+        const int kbits = __builtin_bit_cast(int, g.k);
+#pragma unroll
+        for (int i = 0; i < RL; ++i) {
+            uint32_t x = g.v[i] & live_mask;
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
+            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
+            const float carry = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bperm0 + 16 * i, kbits));
+            ring[blk & 1][sub * RL + i][lane] = carry + (float)x; // integers below 2^24: exact
+        }
+    };
+    Regs g[D];
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) fetch(d, g[d]);
+    // step blk: fetch block blk + D - 1, publish block blk, meet the chain (which then consumes blk while we go on).
+    // ring[blk & 1] was last read by the chain for block blk - 2, which it finished before the barrier of step blk - 1.
+    for (int blk0 = 0; blk0 < nblocks; blk0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) { // static register rotation
+            const int blk = blk0 + d;
+            if (blk < nblocks) { // workgroup-uniform
+                fetch(blk + D - 1, g[(d + D - 1) % D]);
+                publish(blk, g[d]);
+                __syncthreads();
+            }
+        }
+    }
+}
+
 // Integral image(s) of `src` (Image(T).Integral.compute, integral.zig:95-140): one f32 plane of rows x cols per channel,
 // planar, in the reference's association order. Also used by the Shen-Castan detector (edges.hip).
 // `integer_valued`: the caller knows every element is an integer in [0, 255] (always true for u8 pixels), which makes the
@@ -196,6 +357,23 @@ __global__ __launch_bounds__(256) void k_sat_rows_exact(DImg src, float *sat) { 
 int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer_valued) {
     const int C = pixel_channels(src->pixel);
     const bool exact_rows = (integer_valued || !pixel_is_float(src->pixel)) && src->cols <= 65536; // 65536 * 255 < 2^24
+    // exact rows: carries of the 16-column strips (a small table), then prefix + chain + store in one pass over the source
+    static const bool fused_off = getenv("ZIGNAL_HIP_SAT_UNFUSED") != nullptr;
+    if (exact_rows && !fused_off) {
+        const int nstrips = (int)ceil_div(src->cols, 16u);
+        float *carries = nullptr;
+        if (int rc = scratch_alloc((void **)&carries, (size_t)src->rows * nstrips * C * sizeof(float), s)) return rc;
+        const int rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
+            constexpr int PIX = decltype(tag)::value;
+            constexpr int PC = Px<PIX>::C;
+            hipLaunchKernelGGL((k_strip_carries<PIX>), dim3(src->rows), dim3(256), 0, s, dimg(src), carries, nstrips);
+            hipLaunchKernelGGL((k_sat_chain<PIX>), dim3(ceil_div((unsigned)nstrips, 4u), (unsigned)PC), dim3(576), 0, s, dimg(src), (const float *)carries, sat, nstrips);
+            ZG_HIP(hipGetLastError());
+            return ZG_OK;
+        });
+        scratch_free(carries, s);
+        return rc;
+    }
     return dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
         if (exact_rows) hipLaunchKernelGGL((k_sat_rows_exact<PIX>), dim3(src->rows, (unsigned)C), dim3(256), 0, s, dimg(src), sat);
