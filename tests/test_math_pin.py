@@ -101,9 +101,12 @@ def test_device_maths_equals_the_oracle_bit_for_bit(fn, oracle):
 
 
 @pytest.mark.gpu
-def test_fast_device_cbrt_equals_the_musl_steps_on_every_f32():
+@pytest.mark.parametrize("fast,ref,what", [(0, 9, "cbrt"), (11, 10, "x / 100")])
+def test_fast_device_forms_equal_the_plain_ones_on_every_f32(fast, ref, what):
     """dev_cbrtf (f32 first step, reciprocal-based f64 second step, musl fallback next to rounding midpoints) against musl's
-    cbrtf restated step for step, over all 2^32 bit patterns."""
+    cbrtf restated step for step, and dev_div100 (reciprocal, exact remainder, one correction) against the IEEE division,
+    over all 2^32 bit patterns."""
+    fn_fast, fn_ref = fast, ref
     import torch
 
     import zignal_amd as zg
@@ -117,12 +120,12 @@ def test_fast_device_cbrt_equals_the_musl_steps_on_every_f32():
     for chunk in range(32):
         bits = (base + chunk * n).to(torch.int32) if chunk < 16 else (base + chunk * n - (1 << 32)).to(torch.int32)
         x = bits.view(torch.float32)
-        assert lib.zg_devmath_apply(0, C.c_void_p(x.data_ptr()), None, C.c_void_p(fast.data_ptr()), n, stream) == 0
-        assert lib.zg_devmath_apply(9, C.c_void_p(x.data_ptr()), None, C.c_void_p(ref.data_ptr()), n, stream) == 0
+        assert lib.zg_devmath_apply(fn_fast, C.c_void_p(x.data_ptr()), None, C.c_void_p(fast.data_ptr()), n, stream) == 0
+        assert lib.zg_devmath_apply(fn_ref, C.c_void_p(x.data_ptr()), None, C.c_void_p(ref.data_ptr()), n, stream) == 0
         diff = (fast.view(torch.int32) != ref.view(torch.int32)) & ~(torch.isnan(fast) & torch.isnan(ref))
         k = int(diff.sum().item())
         if k:
             idx = torch.nonzero(diff)[:4, 0]
             print(f"chunk {chunk}: {k} differ, e.g. x bits {[hex(int(v) & 0xffffffff) for v in bits[idx].tolist()]}")
         bad += k
-    assert bad == 0, f"{bad} of 2^32 inputs differ"
+    assert bad == 0, f"{what}: {bad} of 2^32 inputs differ"

@@ -307,7 +307,9 @@ __global__ __launch_bounds__(256) void k_devmath_apply(int fn, const float *x, c
         case 6: r = dev_atan2f(a, y[i]); break;
         case 7: r = dev_powf(a, y[i]); break;
         case 8: r = dev_gamma_to_linear(a); break;
-        default: r = dev_cbrtf_musl(a); break;
+        case 9: r = dev_cbrtf_musl(a); break;
+        case 10: r = a / 100.0f; break;
+        default: r = dev_div100(a); break;
         }
         out[i] = r;
     }
@@ -343,7 +345,7 @@ int zg_convert_host(const zg_image *src, int src_space, const zg_image *dst, int
 // fn: 0 cbrt, 1 pow(x, 2.4), 2 exp, 3 log, 4 sin, 5 cos, 6 atan2(x, y), 7 pow(x, y), 8 gammaToLinear, 9 cbrt by musl's own steps (what 0 is
 // checked against over all 2^32 inputs). y may be NULL for unary fn.
 int zg_devmath_apply(int fn, const float *x_dev, const float *y_dev, float *out_dev, size_t n, zg_stream stream) {
-    ZG_REQUIRE(fn >= 0 && fn <= 9, ZG_ERR_INVALID_ARGUMENT, "zg_devmath_apply: unknown function %d", fn);
+    ZG_REQUIRE(fn >= 0 && fn <= 11, ZG_ERR_INVALID_ARGUMENT, "zg_devmath_apply: unknown function %d", fn);
     ZG_REQUIRE((x_dev && out_dev) || n == 0, ZG_ERR_INVALID_ARGUMENT, "zg_devmath_apply: null array");
     ZG_REQUIRE((fn != 6 && fn != 7) || y_dev || n == 0, ZG_ERR_INVALID_ARGUMENT, "zg_devmath_apply: function %d needs y", fn);
     if (n == 0) return ZG_OK;

@@ -17,7 +17,7 @@ __device__ inline void linear_rgb_to_xyz(const float lin[3], float &X, float &Y,
 
 // Xyz -> Oklab (color.zig:1381-1400)
 __device__ inline void xyz_to_oklab(float X, float Y, float Z, float &L, float &A, float &B) {
-    const float x = X / 100.0f, y = Y / 100.0f, z = Z / 100.0f;
+    const float x = dev_div100(X), y = dev_div100(Y), z = dev_div100(Z); // == X / 100.0f, bit for bit
     const float l_linear = 0.8189330101f * x + 0.3618667424f * y - 0.1288597137f * z;
     const float m_linear = 0.0329845436f * x + 0.9293118715f * y + 0.0361456387f * z;
     const float s_linear = 0.0482003018f * x + 0.2643662691f * y + 0.6338517070f * z;

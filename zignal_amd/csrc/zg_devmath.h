@@ -32,33 +32,46 @@ __device__ inline float dev_cbrtf_musl(float x) { // Zig std.math.cbrt cbrt32 ==
     return (float)t;
 }
 
-// The same function, three times cheaper. musl's two Halley steps run in f64 with two IEEE divisions (~25 f64 instructions
+// The same function at a third of the cost. musl's two Halley steps run in f64 with two IEEE divisions (~25 f64 instructions
 // each on this part, and xyzToOklab takes three cube roots per pixel). Its result is the f32 nearest to a double that is
-// accurate to ~2^-50, so any double within 2^-44 of the true cube root rounds to the same f32 unless it sits within that
-// distance of a rounding midpoint. Here: the first Halley step in f32 with v_rcp_f32 (it only has to deliver 15 bits), the
-// second in f64 with the quotient formed from a Newton-refined v_rcp_f64 instead of an IEEE division (error ~2^-45); when
-// the double lands within 2^-14 f32 ulp of a midpoint (one lane in 8 192) the lane takes musl's path instead. Subnormal and
-// near-overflow arguments, which would lose bits or overflow in the f32 step, take it as well.
+// accurate to ~2^-50, so any double within 2^-40 of the true cube root rounds to the same f32 unless it sits within that
+// distance of a rounding midpoint. Here: two Halley steps in f32 with v_rcp_f32 (t is then good to f32 precision), and ONE
+// correction t + t (x - t^3) / (x + 2 t^3) — Halley again, written so that only the residual x - t^3 needs f64 (two
+// multiplications and a subtraction); the quotient is a 2^-22 correction and f32 is plenty for it. When the resulting
+// double lands within 2^-14 f32-ulp of a midpoint (one lane in 8 192) the lane takes musl's own steps instead; so do
+// arguments below 2^-100 or near overflow, which would lose bits or overflow in the f32 steps.
 // tests/test_math_pin.py compares the two over ALL 2^32 bit patterns: identical.
 __device__ inline float dev_cbrtf(float x) {
     const uint32_t u0 = __float_as_uint(x), hx = u0 & 0x7fffffffu;
-    if (hx < 0x00800000u || hx >= 0x7d800000u) return dev_cbrtf_musl(x); // zero, subnormal, >= 2^124 (3x and its reciprocal must stay normal), inf, nan
-    const float t0 = __uint_as_float((u0 & 0x80000000u) | (hx / 3 + 709958130u));
-    const float r0 = t0 * t0 * t0;
-    const float t1 = t0 * (((x + x) + r0) * __builtin_amdgcn_rcpf((x + r0) + r0)); // the ratio is ~1: nothing under- or overflows
-    const double xd = (double)x, t = (double)t1;
-    const double r = t * t * t;
-    const double num = t * ((xd + xd) + r), den = (xd + r) + r;
-    double rc = __builtin_amdgcn_rcp(den);
-    rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
-    rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
-    double q = num * rc;
-    q = __builtin_fma(__builtin_fma(-den, q, num), rc, q);
+    if (hx < 0x0d800000u || hx >= 0x7d800000u) return dev_cbrtf_musl(x); // zero, < 2^-100 (the residual must stay a normal f32), >= 2^124 (so must 3x and its reciprocal), inf, nan
+    float t = __uint_as_float((u0 & 0x80000000u) | (hx / 3 + 709958130u));
+    float r = t * t * t;
+    t = t * (((x + x) + r) * __builtin_amdgcn_rcpf((x + r) + r)); // the ratio is ~1: nothing under- or overflows
+    r = t * t * t;
+    const float rc = __builtin_amdgcn_rcpf((x + r) + r);
+    t = t * (((x + x) + r) * rc);
+    const double td = (double)t;
+    const float resid = (float)((double)x - td * td * td); // exact to ~2^-52 x: the part f32 could not see
+    const double q = td + (double)(t * (resid * rc));       // rc still fits: t moved by 2^-15 at most since it was formed
     const uint32_t low = (uint32_t)__double_as_longlong(q) & 0x1fffffffu; // the 29 significand bits below f32's last
     const uint32_t off = low > 0x10000000u ? low - 0x10000000u : 0x10000000u - low;
     if (off < (1u << 15)) return dev_cbrtf_musl(x); // too close to a rounding midpoint to call: the reference's own steps decide
     return (float)q;
 }
+
+// x / 100.0f (xyzToOklab, color.zig:1381-1384) without the IEEE-division expansion (~12 instructions, three per pixel): the
+// quotient by the correctly rounded reciprocal, the exact remainder with one FMA, one correction. For a constant divisor this
+// is correctly rounded wherever neither the quotient nor the remainder leaves the normal range; outside (|x| < 2^-100,
+// |x| >= 2^120, inf, nan) the division itself runs. tests/test_math_pin.py compares it with x / 100.0f over ALL 2^32 inputs.
+__device__ inline float dev_div100(float x) {
+    const uint32_t ax = __float_as_uint(x) & 0x7fffffffu;
+    if (ax < 0x0d800000u || ax >= 0x7b800000u) return x / 100.0f;
+    const float r = 0.01f;
+    const float q = x * r;
+    const float e = __builtin_fmaf(-q, 100.0f, x);
+    return __builtin_fmaf(e, r, q);
+}
+
 __device__ inline float dev_scalbnf(float x, int n) {
     float y = x;
     if (n > 127) {
