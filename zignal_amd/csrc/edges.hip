@@ -361,110 +361,118 @@ static int canny_impl(const zg_image *src, const zg_image *dst, float sigma, flo
 
 int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer_valued); // box_blur.hip
 
-// Forward recursion along rows: temp[0] = b x[0]; temp[i] = b x[i] + a temp[i-1]. One wave per 64 rows, 64-column chunks
-// transposed through LDS (lanes = columns for the coalesced global side, lanes = rows for the chain).
-__global__ __launch_bounds__(64) void k_isef_rows_fwd(const float *in, float *temp, int rows, int cols, float b) {
+// The recursions along ROWS run as the column kernel on the transposed plane: a row chain needs lanes = rows, i.e. a transpose
+// through LDS per 64-column chunk inside a kernel with one wave per 64 rows (354 + 464 us per 4096^2 plane that way); two plain
+// transposes at memory speed around the role-split column kernel do the same arithmetic, element for element, in a third of it.
+__global__ __launch_bounds__(256) void k_transpose_f32(const float *in, float *out, int rows, int cols) { // out[c][r] = in[r][c]
     __shared__ float tile[64][65];
-    const int lane = threadIdx.x, r0 = blockIdx.x * 64;
-    const int nrows = min(64, rows - r0);
-    const float a = 1.0f - b;
-    float run = 0.0f;
-    for (int c0 = 0; c0 < cols; c0 += 64) {
-        const int c = min(c0 + lane, cols - 1); // clamped, unpredicated loads (see box_blur.hip)
-#pragma unroll 16
-        for (int i = 0; i < 64; ++i) tile[i][lane] = in[(size_t)(r0 + min(i, nrows - 1)) * cols + c];
-        __syncthreads();
-        const int ncols = min(64, cols - c0);
-        for (int j = 0; j < ncols; ++j) {
-            const float x = tile[lane][j];
-            const float bx = b * x;
-            if (c0 + j == 0) run = bx;
-            else { const float ar = a * run; run = bx + ar; }
-            tile[lane][j] = run;
-        }
-        __syncthreads();
-        if (c0 + lane < cols)
-#pragma unroll 16
-            for (int i = 0; i < 64; ++i)
-                if (i < nrows) temp[(size_t)(r0 + i) * cols + c0 + lane] = tile[i][lane];
-        __syncthreads();
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int r = r0 + ly + 4 * k, c = c0 + lx;
+        tile[ly + 4 * k][lx] = in[(size_t)min(r, rows - 1) * cols + min(c, cols - 1)]; // clamped, unpredicated
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int c = c0 + ly + 4 * k, r = r0 + lx;
+        if (c < cols && r < rows) out[(size_t)c * rows + r] = tile[lx][ly + 4 * k];
     }
 }
-// Backward recursion along rows: out[n-1] = temp[n-1]; out[i] = b temp[i] + a out[i+1].
-__global__ __launch_bounds__(64) void k_isef_rows_bwd(const float *temp, float *out, int rows, int cols, float b) {
-    __shared__ float tile[64][65];
-    const int lane = threadIdx.x, r0 = blockIdx.x * 64;
-    const int nrows = min(64, rows - r0);
+// The same two recursions down / up the columns, in place on `data` with `temp` between them. One chain per column and two
+// dependent operations per row (a * run, then + b * x): a wave that also does its own loads and stores is latency-bound (one
+// wave per 64 columns: 379 us per 4096^2 plane). Roles are split as in box_blur.hip's k_sat_chain: a workgroup owns 64 columns;
+// waves 1..8 are LOADERS that keep six 64-row blocks in flight and hand rows over through an LDS ring, wave 0 is the CHAIN:
+// per row one LDS read, the recurrence, one store, nothing in its memory queue but stores. The up pass reads what the down
+// pass wrote (same workgroup, other waves): the chain wave publishes with a device-scope fence before the barrier that
+// separates the passes.
+__global__ __launch_bounds__(576) void k_isef_cols(float *data, float *temp, int rows, int cols, float b) {
+    constexpr int SB = 64, NL = 8, RL = SB / NL, D = 6;
+    __shared__ float ring[2][SB][64];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 64 + lane;
+    const bool live = c < cols;
+    const int cc = min(c, cols - 1);
+    const int nblocks = (rows + SB - 1) / SB;
     const float a = 1.0f - b;
-    float run = 0.0f;
-    for (int c0 = (cols - 1) / 64 * 64; c0 >= 0; c0 -= 64) {
-        const int c = min(c0 + lane, cols - 1);
-#pragma unroll 16
-        for (int i = 0; i < 64; ++i) tile[i][lane] = temp[(size_t)(r0 + min(i, nrows - 1)) * cols + c];
-        __syncthreads();
-        const int ncols = min(64, cols - c0);
-        for (int j = ncols - 1; j >= 0; --j) {
-            const float t = tile[lane][j];
-            if (c0 + j == cols - 1) run = t;
-            else { const float bt = b * t, ar = a * run; run = bt + ar; }
-            tile[lane][j] = run;
-        }
-        __syncthreads();
-        if (c0 + lane < cols)
-#pragma unroll 16
-            for (int i = 0; i < 64; ++i)
-                if (i < nrows) out[(size_t)(r0 + i) * cols + c0 + lane] = tile[i][lane];
-        __syncthreads();
-    }
-}
-// The same two recursions down / up the columns, in place on `data` with `temp` between them: one lane per column,
-// coalesced across lanes, sixteen rows loaded ahead of the chain.
-__global__ __launch_bounds__(64) void k_isef_cols(float *data, float *temp, int rows, int cols, float b) {
-    constexpr int G = 64; // rows per step, the next step's rows already in flight (bandwidth here = bytes in flight / latency)
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= cols) return;
-    const float a = 1.0f - b;
-    float run = 0.0f;
-    float v[G], w[G];
-    auto fetch = [&](const float *p, int r0, float (&x)[G]) {
+    const bool all_live = blockIdx.x * 64 + 64 <= (unsigned)cols; // workgroup-uniform
+
+    for (int pass = 0; pass < 2; ++pass) { // 0: down, data -> temp; 1: up, temp -> data. Block k of the up pass is block nblocks - 1 - k.
+        const float *in = pass == 0 ? data : temp;
+        float *out = pass == 0 ? temp : data;
+        if (wave == 0) {
+            float run = 0.0f;
+            for (int k = 0; k < nblocks; ++k) {
+                __syncthreads(); // block k of this pass is in ring[k & 1]
+                const int blk = pass == 0 ? k : nblocks - 1 - k, r0 = blk * SB;
+                float p[SB];
 #pragma unroll
-        for (int i = 0; i < G; ++i) x[i] = p[(size_t)min(max(r0 + i, 0), rows - 1) * cols + c]; // clamped, unpredicated
-    };
-    auto down = [&](int r0, float (&x)[G]) {
+                for (int i = 0; i < SB; ++i) p[i] = ring[k & 1][i][lane];
+                float *o = out + (size_t)r0 * cols + cc;
+                const bool plain = all_live && r0 + SB <= rows; // every row of the block exists, every lane stores: no predicate
+                if (pass == 0 && plain && r0 > 0) {
 #pragma unroll
-        for (int i = 0; i < G; ++i) {
-            if (r0 + i < rows) {
-                const float bx = b * x[i];
-                if (r0 + i == 0) run = bx;
-                else { const float ar = a * run; run = bx + ar; }
-                temp[(size_t)(r0 + i) * cols + c] = run;
+                    for (int i = 0; i < SB; ++i) {
+                        const float bx = b * p[i], ar = a * run;
+                        run = bx + ar;
+                        o[(size_t)i * cols] = run;
+                    }
+                } else if (pass == 1 && plain && r0 + SB < rows) {
+#pragma unroll
+                    for (int i = SB - 1; i >= 0; --i) {
+                        const float bt = b * p[i], ar = a * run;
+                        run = bt + ar;
+                        o[(size_t)i * cols] = run;
+                    }
+                } else if (pass == 0) {
+#pragma unroll
+                    for (int i = 0; i < SB; ++i) {
+                        const float bx = b * p[i];
+                        if (r0 + i == 0) run = bx;
+                        else { const float ar = a * run; run = bx + ar; }
+                        if (live && r0 + i < rows) o[(size_t)i * cols] = run;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = SB - 1; i >= 0; --i) {
+                        if (r0 + i < rows) { // rows past the end do not exist: the chain starts at rows - 1
+                            if (r0 + i == rows - 1) run = p[i];
+                            else { const float bt = b * p[i], ar = a * run; run = bt + ar; }
+                            if (live) o[(size_t)i * cols] = run;
+                        }
+                    }
+                }
+            }
+            if (pass == 0) __threadfence(); // temp is complete and visible before any loader of this workgroup reads it back
+        } else {
+            const int sub = wave - 1;
+            struct Regs { float v[RL]; };
+            auto fetch = [&](int k, Regs &g) { // clamped, unpredicated; steps past the last block re-read a valid row and are never used
+                const int blk = pass == 0 ? k : nblocks - 1 - k;
+                const int r0 = min(max(blk, 0), nblocks - 1) * SB + sub * RL;
+#pragma unroll
+                for (int i = 0; i < RL; ++i) g.v[i] = in[(size_t)min(r0 + i, rows - 1) * cols + cc];
+            };
+            auto publish = [&](int k, const Regs &g) {
+#pragma unroll
+                for (int i = 0; i < RL; ++i) ring[k & 1][sub * RL + i][lane] = g.v[i];
+            };
+            Regs g[D];
+#pragma unroll
+            for (int d = 0; d < D - 1; ++d) fetch(d, g[d]);
+            for (int k0 = 0; k0 < nblocks; k0 += D) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int k = k0 + d;
+                    if (k < nblocks) {
+                        fetch(k + D - 1, g[(d + D - 1) % D]);
+                        publish(k, g[d]);
+                        __syncthreads();
+                    }
+                }
             }
         }
-    };
-    fetch(data, 0, v);
-    for (int r0 = 0; r0 < rows; r0 += 2 * G) {
-        fetch(data, r0 + G, w);
-        down(r0, v);
-        fetch(data, r0 + 2 * G, v);
-        down(r0 + G, w);
-    }
-    auto up = [&](int r0, float (&x)[G]) {
-#pragma unroll
-        for (int i = G - 1; i >= 0; --i) {
-            if (r0 + i < rows && r0 + i >= 0) {
-                if (r0 + i == rows - 1) run = x[i];
-                else { const float bt = b * x[i], ar = a * run; run = bt + ar; }
-                data[(size_t)(r0 + i) * cols + c] = run;
-            }
-        }
-    };
-    const int top = (rows - 1) / G * G; // first row of the last step
-    fetch(temp, top, v);
-    for (int r0 = top; r0 >= 0; r0 -= 2 * G) {
-        fetch(temp, r0 - G, w);
-        up(r0, v);
-        fetch(temp, r0 - 2 * G, v);
-        up(r0 - G, w);
+        __syncthreads(); // the pass is over for every wave (and the ring is free again)
     }
 }
 
@@ -622,9 +630,12 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
     });
     const dim3 g64(ceil_div(cols, 64), ceil_div(rows, 4));
     if (rc == ZG_OK) {
-        hipLaunchKernelGGL(k_isef_rows_fwd, dim3(ceil_div(rows, 64)), dim3(64), 0, s, (const float *)gray, temp, (int)rows, (int)cols, smooth);
-        hipLaunchKernelGGL(k_isef_rows_bwd, dim3(ceil_div(rows, 64)), dim3(64), 0, s, (const float *)temp, sm, (int)rows, (int)cols, smooth);
-        hipLaunchKernelGGL(k_isef_cols, dim3(ceil_div(cols, 64)), dim3(64), 0, s, sm, temp, (int)rows, (int)cols, smooth);
+        // rows: transpose, column recursions on the cols x rows plane (in place on `grad`, `sat_g` between the passes: both are
+        // free until the gradient stage), transpose back into `sm`; then the columns proper
+        hipLaunchKernelGGL(k_transpose_f32, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, s, (const float *)gray, grad, (int)rows, (int)cols);
+        hipLaunchKernelGGL(k_isef_cols, dim3(ceil_div(rows, 64)), dim3(576), 0, s, grad, sat_g, (int)cols, (int)rows, smooth);
+        hipLaunchKernelGGL(k_transpose_f32, dim3(ceil_div(rows, 64), ceil_div(cols, 64)), dim3(256), 0, s, (const float *)grad, sm, (int)cols, (int)rows);
+        hipLaunchKernelGGL(k_isef_cols, dim3(ceil_div(cols, 64)), dim3(576), 0, s, sm, temp, (int)rows, (int)cols, smooth);
         hipLaunchKernelGGL(k_sc_bli, g64, dim3(256), 0, s, (const float *)gray, (const float *)sm, bli, temp /* grey * BLI */, cand, (int)rows, (int)cols, use_nms ? 0 : 1);
         if (hipGetLastError() != hipSuccess) rc = ZG_ERR_HIP;
     }
