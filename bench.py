@@ -177,10 +177,14 @@ def main():
         torch.cuda.synchronize()
     run(max(chunk, args.warmup - args.warmup % chunk) if graph is not None else args.warmup)
     barrier()
+    ev_begin, ev_end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev_begin.record()  # HIP events on the stream the launches (or graph replays) go to, around exactly the timed region
     run(args.steps)
+    ev_end.record()
     barrier()
     elapsed = time.perf_counter() - t0
+    region_ms_per_launch = ev_begin.elapsed_time(ev_end) / args.steps
     from zignal_amd import sharding
     elapsed = sharding.max_over_ranks(elapsed, torch.device("cpu") if shared_gpu else torch.device("cuda", local_rank))  # the slowest rank is the clock
 
@@ -198,8 +202,9 @@ def main():
     }
 
     if rank == 0 and world == 1:
-        # per-launch kernel time: HIP events on the launch stream (torch's current stream is the stream handed
-        # to zg_gaussian_blur), one pair per launch
+        # Kernel time per launch = HIP events around the timed region (above) / launches in it: device time on the launch stream,
+        # inter-launch gaps included, so it can only overstate the kernel. Cross-check: event pairs around 200 single eager
+        # launches (each pair also brackets its launch overhead), and the rocprofv3 mean under profiles/.
         n = min(args.steps, 200)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
         for i, (a, b) in enumerate(evs):
@@ -208,7 +213,8 @@ def main():
             b.record()
         torch.cuda.synchronize()
         kernel_ms = sorted(a.elapsed_time(b) for a, b in evs)
-        mean_ms = sum(kernel_ms) / len(kernel_ms)
+        eager_mean_ms = sum(kernel_ms) / len(kernel_ms)
+        mean_ms = region_ms_per_launch
         alg_bytes = 32 * pixels  # 16 B read + 16 B written per pixel
         achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
         traffic = None
@@ -221,7 +227,9 @@ def main():
         result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                               "kernel": "k_sep_fused<RGBA_F32,5>", "kernel_ms_mean": round(mean_ms, 5),
-                              "kernel_ms_median": round(kernel_ms[len(kernel_ms) // 2], 5),
+                              "kernel_ms_source": "HIP events around the timed region / launches in it",
+                              "kernel_ms_eager_event_pairs_mean": round(eager_mean_ms, 5),
+                              "kernel_ms_eager_event_pairs_median": round(kernel_ms[len(kernel_ms) // 2], 5),
                               "algorithmic_bytes_per_launch": alg_bytes}
         # The metric names two ops: the bilinear resize of BASELINE configs[2] stands beside the blur, same arithmetic.
         try:
