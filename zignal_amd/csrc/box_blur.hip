@@ -202,10 +202,9 @@ __global__ __launch_bounds__(256) void k_sat_rows_exact(DImg src, float *sat) { 
 // carry[(r * nstrips + s) * C + ch] = sum of row r, channel ch, over columns < 16 s, as an exact f32. One workgroup per row,
 // every channel at once (the source is read once): 4 pixels per thread and step, integer block scan.
 template <int PIX>
-__global__ __launch_bounds__(256) void k_strip_carries(DImg src, float *carries, int nstrips) {
+__device__ __forceinline__ void strip_carries_body(const DImg &src, float *carries, int nstrips, uint32_t (*wsum)[Px<PIX>::C]) {
     using P = Px<PIX>;
     constexpr int C = P::C;
-    __shared__ uint32_t wsum[4][C];
     const int r = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     uint32_t carry[C];
 #pragma unroll
@@ -247,6 +246,11 @@ __global__ __launch_bounds__(256) void k_strip_carries(DImg src, float *carries,
         __syncthreads();
     }
 }
+template <int PIX>
+__global__ __launch_bounds__(256) void k_strip_carries(DImg src, float *carries, int nstrips) {
+    __shared__ uint32_t wsum[4][Px<PIX>::C];
+    strip_carries_body<PIX>(src, carries, nstrips, wsum);
+}
 
 // A workgroup owns four adjacent 16-column strips of ONE channel for the whole height (64 columns: 256 contiguous bytes of SAT
 // per row; strips of all channels in one workgroup were tried first and wrote 64-byte pieces into four planes: 0.8 TB/s).
@@ -258,16 +262,16 @@ __global__ __launch_bounds__(256) void k_strip_carries(DImg src, float *carries,
 // keep in flight). So the roles are split: waves 1..8 are LOADERS, each taking 8 rows of every 64-row block, six blocks
 // ahead (9 loads per block and loader: 54 of the 63 operations a wave can track), turning them into row prefixes in an LDS
 // ring; wave 0 is the CHAIN: per row one LDS read, one addition, one store, and nothing in its memory queue but stores.
+constexpr int SAT_SB = 64; // rows per block of k_sat_chain
 template <int PIX>
-__global__ __launch_bounds__(576) void k_sat_chain(DImg src, const float *carries, float *sat, int nstrips) {
+__device__ __forceinline__ void sat_chain_body(const DImg &src, const float *carries, float *sat, int nstrips, int ch, float (*ring)[SAT_SB][64]) {
     using P = Px<PIX>;
     using Elem = typename P::Elem;
     constexpr int C = P::C;
-    constexpr int SB = 64, NL = 8, RL = SB / NL, D = 6; // rows per block, loader waves, rows per loader and block, blocks in flight
-    __shared__ float ring[2][SB][64];
+    constexpr int SB = SAT_SB, NL = 8, RL = SB / NL, D = 6; // rows per block, loader waves, rows per loader and block, blocks in flight
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, slot = lane >> 4, col16 = lane & 15;
-    const int strip0 = blockIdx.x * 4, ch = blockIdx.y; // four adjacent strips of one channel: 64 columns, 256 B of SAT per row
+    const int strip0 = blockIdx.x * 4; // four adjacent strips of one channel: 64 columns, 256 B of SAT per row
     const int strip = strip0 + slot;
     const int c = strip * 16 + col16;
     const bool live = strip < nstrips && c < src.cols; // past the last strip, past the last column
@@ -349,6 +353,33 @@ __global__ __launch_bounds__(576) void k_sat_chain(DImg src, const float *carrie
         }
     }
 }
+template <int PIX>
+__global__ __launch_bounds__(576) void k_sat_chain(DImg src, const float *carries, float *sat, int nstrips) {
+    __shared__ float ring[2][SAT_SB][64];
+    sat_chain_body<PIX>(src, carries, sat, nstrips, (int)blockIdx.y, ring);
+}
+
+// Several single-channel planes of one size in one launch (blockIdx.y picks the plane): a lone plane gives the chain kernel only
+// cols / 64 workgroups, and it is latency-bound, so the planes of the Shen-Castan detector cost the time of one.
+struct SatPlanes {
+    DImg src[3];
+    float *sat[3];
+    int f32[3]; // element type of the plane: f32 (holding integers 0..255) or u8
+};
+__global__ __launch_bounds__(256) void k_strip_carries_planes(SatPlanes pl, float *carries, int nstrips) {
+    __shared__ uint32_t wsum[4][1];
+    const int p = blockIdx.y;
+    float *table = carries + (size_t)p * pl.src[0].rows * nstrips;
+    if (pl.f32[p]) strip_carries_body<ZG_PIXEL_F32>(pl.src[p], table, nstrips, wsum);
+    else strip_carries_body<ZG_PIXEL_U8>(pl.src[p], table, nstrips, wsum);
+}
+__global__ __launch_bounds__(576) void k_sat_chain_planes(SatPlanes pl, const float *carries, int nstrips) {
+    __shared__ float ring[2][SAT_SB][64];
+    const int p = blockIdx.y;
+    const float *table = carries + (size_t)p * pl.src[0].rows * nstrips;
+    if (pl.f32[p]) sat_chain_body<ZG_PIXEL_F32>(pl.src[p], table, pl.sat[p], nstrips, 0, ring);
+    else sat_chain_body<ZG_PIXEL_U8>(pl.src[p], table, pl.sat[p], nstrips, 0, ring);
+}
 
 // Integral image(s) of `src` (Image(T).Integral.compute, integral.zig:95-140): one f32 plane of rows x cols per channel,
 // planar, in the reference's association order. Also used by the Shen-Castan detector (edges.hip).
@@ -382,6 +413,34 @@ int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     });
+}
+
+// Integral images of up to three single-channel planes (u8 or integer-valued f32) of one size, one launch pair for all of them.
+int sat_planes_multi(const zg_image *const *srcs, float *const *sats, int count, hipStream_t s) {
+    const zg_image *a = srcs[0];
+    bool ok = count >= 1 && count <= 3 && a->cols <= 65536 && getenv("ZIGNAL_HIP_SAT_UNFUSED") == nullptr;
+    for (int i = 0; i < count && ok; ++i)
+        ok = srcs[i]->rows == a->rows && srcs[i]->cols == a->cols && (srcs[i]->pixel == ZG_PIXEL_U8 || srcs[i]->pixel == ZG_PIXEL_F32);
+    if (!ok) { // one at a time
+        for (int i = 0; i < count; ++i)
+            if (int rc = sat_planes_impl(srcs[i], sats[i], s, true)) return rc;
+        return ZG_OK;
+    }
+    const int nstrips = (int)ceil_div(a->cols, 16u);
+    float *carries = nullptr;
+    if (int rc = scratch_alloc((void **)&carries, (size_t)count * a->rows * nstrips * sizeof(float), s)) return rc;
+    SatPlanes pl{};
+    for (int i = 0; i < count; ++i) {
+        pl.src[i] = dimg(srcs[i]);
+        pl.sat[i] = sats[i];
+        pl.f32[i] = srcs[i]->pixel == ZG_PIXEL_F32;
+    }
+    hipLaunchKernelGGL(k_strip_carries_planes, dim3(a->rows, (unsigned)count), dim3(256), 0, s, pl, carries, nstrips);
+    hipLaunchKernelGGL(k_sat_chain_planes, dim3(ceil_div((unsigned)nstrips, 4u), (unsigned)count), dim3(576), 0, s, pl, (const float *)carries, nstrips);
+    const hipError_t e = hipGetLastError();
+    scratch_free(carries, s);
+    if (e != hipSuccess) { set_error("integral image: launch failed: %s", hipGetErrorString(e)); return ZG_ERR_HIP; }
+    return ZG_OK;
 }
 
 static int box_blur_impl(const zg_image *src, const zg_image *dst, uint32_t radius, bool sharpen, hipStream_t s) {
