@@ -254,109 +254,223 @@ __global__ __launch_bounds__(256) void k_strip_carries(DImg src, float *carries,
 
 // A workgroup owns four adjacent 16-column strips of ONE channel for the whole height (64 columns: 256 contiguous bytes of SAT
 // per row; strips of all channels in one workgroup were tried first and wrote 64-byte pieces into four planes: 0.8 TB/s).
-// Lane = slot * 16 + column, slot = strip within the workgroup. The row prefix of an element is its strip's carry plus an inclusive
-// scan over the 16 lanes of its slot (DPP row_shr 1, 2, 4, 8), exact; the SAT is the reference's column recurrence
-// sat[r][c] = sat[r-1][c] + rowprefix[r][c] (integral.zig:60-77): one f32 addition per row, top to bottom.
-// Only that one addition per row is sequential, and a wave that loads, scans, chains and stores by itself spends its life
-// waiting for memory (measured: 65 ns per row whatever it does — two microseconds of latency over the ~32 rows one wave can
-// keep in flight). So the roles are split: waves 1..8 are LOADERS, each taking 8 rows of every 64-row block, six blocks
-// ahead (9 loads per block and loader: 54 of the 63 operations a wave can track), turning them into row prefixes in an LDS
-// ring; wave 0 is the CHAIN: per row one LDS read, one addition, one store, and nothing in its memory queue but stores.
-constexpr int SAT_SB = 64; // rows per block of k_sat_chain
-template <int PIX>
-__device__ __forceinline__ void sat_chain_body(const DImg &src, const float *carries, float *sat, int nstrips, int ch, float (*ring)[SAT_SB][64]) {
+// The row prefix of an element is its strip's carry plus a prefix inside the strip, exact; the SAT is the reference's column
+// recurrence sat[r][c] = sat[r-1][c] + rowprefix[r][c] (integral.zig:60-77): one f32 addition per row, top to bottom.
+// Only that addition is sequential, but every workgroup walks the whole height, and a lone wave issues one instruction per
+// ~5 ns whatever it is (measured by switching roles and instructions off one at a time, profiles/r02_experiments.txt): the wave
+// that chains must do nothing else. So the work is dealt out by role and by SIMD (wave w runs on SIMD w % 4):
+//   wave 0         the CHAIN, alone on its SIMD (waves 4, 8, 12 leave at once): per row half an LDS read, one addition, half an
+//                  LDS write: 41 us for 4096 rows, the floor of this kernel for a single plane
+//   8 LOADERS      lane = (row of four, four adjacent columns): one load brings four elements of a row, their prefix costs three
+//                  additions, the four lanes of a strip are scanned with two quad permutes, and a row-major float4 goes into the
+//                  ring: about seven instructions per 64-column row where a lane per column needed sixteen; six blocks ahead
+//   4 STORERS      float4 out of the chain's ring, four rows (4 x 256 contiguous bytes) per store instruction
+// With four channels there are 256 workgroups and the kernel sits on HBM's write rate instead (268 MB of SAT: 86 us).
+constexpr int SAT_SB = 64;         // rows per block of k_sat_chain
+constexpr int SAT_THREADS = 1024;  // sixteen waves: the chain, three that leave, eight loaders, four storers
+
+template <int PIX, bool VEC>
+__device__ __forceinline__ void sat_loader(const DImg &src, const float *carries, int nstrips, int ch, float (*ring)[SAT_SB][64], int L, int lane,
+                                           int nblocks) {
     using P = Px<PIX>;
     using Elem = typename P::Elem;
-    constexpr int C = P::C;
-    constexpr int SB = SAT_SB, NL = 8, RL = SB / NL, D = 6; // rows per block, loader waves, rows per loader and block, blocks in flight
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63, slot = lane >> 4, col16 = lane & 15;
-    const int strip0 = blockIdx.x * 4; // four adjacent strips of one channel: 64 columns, 256 B of SAT per row
-    const int strip = strip0 + slot;
-    const int c = strip * 16 + col16;
-    const bool live = strip < nstrips && c < src.cols; // past the last strip, past the last column
-    const int rows = src.rows;
-    const int nblocks = (rows + SB - 1) / SB;
+    constexpr int C = P::C, SB = SAT_SB, D = 6; // D blocks in flight: 2 x (1 or 4) + 2 loads per block
+    constexpr bool IS_F32 = sizeof(Elem) == 4;
+    const int row4 = lane >> 4, q = lane & 15;
+    const int rows = src.rows, cols = src.cols;
+    const int x0 = blockIdx.x * 64, col0 = x0 + 4 * q;
+    const bool all_live = x0 + 64 <= cols; // workgroup-uniform
+    const Elem *elems = (const Elem *)src.data;
+    const size_t row_elems = (size_t)src.stride * C, carry_step = (size_t)nstrips * C;
+    size_t coff[4];
+    uint32_t cmask[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        coff[j] = (size_t)min(col0 + j, cols - 1) * C + ch;
+        cmask[j] = col0 + j < cols ? 0xffffffffu : 0u;
+    }
+    const size_t cidx = (size_t)min((int)blockIdx.x * 4 + (q >> 2), nstrips - 1) * C + ch;
+    const uint32_t m1 = (lane & 3) >= 1 ? 0xffffffffu : 0u, m2 = (lane & 3) >= 2 ? 0xffffffffu : 0u;
 
-    if (wave == 0) { // ---- the chain --------------------------------------------------------------------------------------
-        float *out = sat + (size_t)ch * rows * src.cols + min(c, src.cols - 1);
-        const size_t out_step = (size_t)src.cols;
-        const bool all_live = strip0 * 16 + 64 <= src.cols; // workgroup-uniform
-        float run = 0.0f;
-        for (int blk = 0; blk < nblocks; ++blk) {
-            __syncthreads(); // block blk is in ring[blk & 1]
-            const int r0 = blk * SB;
-            float p[SB];
+    struct Regs { uint32_t w[2][VEC && PIX == ZG_PIXEL_U8 ? 1 : 4]; float k[2]; };
+    auto load_row = [&](const Elem *rowp, const float *kp, Regs &g, int u) {
+        if constexpr (VEC && PIX == ZG_PIXEL_U8) {
+            g.w[u][0] = *(const uint32_t *)(rowp + col0);
+        } else if constexpr (VEC) { // Rgba(u8): four pixels; f32: four elements
+            const uint4 v = *(const uint4 *)(rowp + (size_t)col0 * C);
+            g.w[u][0] = v.x; g.w[u][1] = v.y; g.w[u][2] = v.z; g.w[u][3] = v.w;
+        } else {
 #pragma unroll
-            for (int i = 0; i < SB; ++i) p[i] = ring[blk & 1][i][lane];
-            if (r0 + SB <= rows && all_live) { // the common case: no predicate anywhere, 64 stores back to back
-#pragma unroll
-                for (int i = 0; i < SB; ++i) {
-                    run = run + p[i];
-                    out[(size_t)(r0 + i) * out_step] = run;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < SB; ++i) {
-                    run = run + p[i];
-                    if (live && r0 + i < rows) out[(size_t)(r0 + i) * out_step] = run;
-                }
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (IS_F32) g.w[u][j] = __builtin_bit_cast(uint32_t, rowp[coff[j]]);
+                else g.w[u][j] = (uint32_t)rowp[coff[j]];
             }
         }
-        return;
-    }
-
-    // ---- a loader: rows sub * RL .. + RL of every block ---------------------------------------------------------------------
-    const int sub = wave - 1;
-    const uint32_t live_mask = live ? 0xffffffffu : 0u;
-    const Elem *base = (const Elem *)src.data + (size_t)min(c, src.cols - 1) * C + ch;
-    const size_t src_step = (size_t)src.stride * C, carry_step = (size_t)nstrips * C;
-    // carry fetch: lane L holds the carry of (row L / 4 of this loader's eight, slot L % 4); lanes 32.. repeat lanes 0..31
-    const int cslot = lane & 3, crow = (lane >> 2) & (RL - 1);
-    const size_t cidx = (size_t)min(strip0 + cslot, nstrips - 1) * C + ch;
-    const int bperm0 = slot * 4; // byte address of lane `slot`; row i adds 16 i
-
-    struct Regs { uint32_t v[RL]; float k; };
+        g.k[u] = kp[cidx];
+    };
     auto fetch = [&](int blk, Regs &g) { // clamped, unpredicated; blocks past the end re-read the last row and are never used
-        const int r0 = blk * SB + sub * RL;
 #pragma unroll
-        for (int i = 0; i < RL; ++i) g.v[i] = (uint32_t)base[(size_t)min(r0 + i, rows - 1) * src_step];
-        g.k = carries[(size_t)min(r0 + crow, rows - 1) * carry_step + cidx];
+        for (int u = 0; u < 2; ++u) {
+            const int r = min(blk * SB + (2 * L + u) * 4 + row4, rows - 1);
+            load_row(elems + (size_t)r * row_elems, carries + (size_t)r * carry_step, g, u);
+        }
+    };
+    // whole blocks: the row pointers just move on by 64 rows (the multiplications of the clamped form are quarter-rate
+    // instructions, and with them the three loaders of a SIMD took longer over a step than the chain)
+    const Elem *rowp[2];
+    const float *kp[2];
+    auto fetch_next = [&](Regs &g) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            load_row(rowp[u], kp[u], g, u);
+            rowp[u] += (size_t)SB * row_elems;
+            kp[u] += (size_t)SB * carry_step;
+        }
     };
     auto publish = [&](int blk, const Regs &g) {
-        const int kbits = __builtin_bit_cast(int, g.k);
 #pragma unroll
-        for (int i = 0; i < RL; ++i) {
-            uint32_t x = g.v[i] & live_mask;
-            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
-            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
-            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
-            x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
-            const float carry = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(bperm0 + 16 * i, kbits));
-            ring[blk & 1][sub * RL + i][lane] = carry + (float)x; // integers below 2^24: exact
+        for (int u = 0; u < 2; ++u) {
+            uint32_t e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (VEC && PIX == ZG_PIXEL_U8) e[j] = (g.w[u][0] >> (8 * j)) & 0xffu;
+                else if constexpr (VEC && PIX == ZG_PIXEL_RGBA_U8) e[j] = (g.w[u][j] >> (8 * ch)) & 0xffu;
+                else if constexpr (IS_F32) e[j] = (uint32_t)__builtin_bit_cast(float, g.w[u][j]); // integer-valued by contract
+                else e[j] = g.w[u][j];
+            }
+            if (!all_live) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] &= cmask[j];
+            }
+            const uint32_t p1 = e[0] + e[1], p2 = p1 + e[2], p3 = p2 + e[3];
+            // inclusive scan of the lane totals over the four lanes of the strip: quad_perm [0,0,1,2] then [0,1,0,1]
+            const uint32_t y = p3 + ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)p3, 0x90, 0xf, 0xf, false) & m1);
+            const uint32_t z = y + ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0x44, 0xf, 0xf, false) & m2);
+            const uint32_t base = (uint32_t)g.k[u] + (z - p3); // carry of the strip + the lanes to my left: integers below 2^24
+            *(float4 *)&ring[blk & 1][(2 * L + u) * 4 + row4][4 * q] = make_float4((float)(base + e[0]), (float)(base + p1), (float)(base + p2), (float)(base + p3));
         }
     };
     Regs g[D];
 #pragma unroll
     for (int d = 0; d < D - 1; ++d) fetch(d, g[d]);
-    // step blk: fetch block blk + D - 1, publish block blk, meet the chain (which then consumes blk while we go on).
-    // ring[blk & 1] was last read by the chain for block blk - 2, which it finished before the barrier of step blk - 1.
-    for (int blk0 = 0; blk0 < nblocks; blk0 += D) {
+    // whole groups of D steps run without a condition in sight: with one, the compiler can no longer count the loads in flight
+    // at the loop head and waits for all but the newest, emptying the pipe once per group
+    int blk0 = 0;
+    const int nfull = rows / SB;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int r = min((D - 1) * SB + (2 * L + u) * 4 + row4, rows - 1);
+        rowp[u] = elems + (size_t)r * row_elems;
+        kp[u] = carries + (size_t)r * carry_step;
+    }
+    for (; blk0 + 2 * D - 1 <= nfull; blk0 += D) { // every block fetched here is whole
 #pragma unroll
         for (int d = 0; d < D; ++d) { // static register rotation
-            const int blk = blk0 + d;
-            if (blk < nblocks) { // workgroup-uniform
-                fetch(blk + D - 1, g[(d + D - 1) % D]);
-                publish(blk, g[d]);
-                __syncthreads();
-            }
+            fetch_next(g[(d + D - 1) % D]);
+            publish(blk0 + d, g[d]);
+            __syncthreads(); // barrier blk0 + d
         }
     }
+    for (; blk0 + D <= nblocks; blk0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) { // static register rotation
+            fetch(blk0 + d + D - 1, g[(d + D - 1) % D]);
+            publish(blk0 + d, g[d]);
+            __syncthreads(); // barrier blk0 + d
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        if (blk0 + d < nblocks) { // workgroup-uniform; the loads are all in flight already
+            publish(blk0 + d, g[d]);
+            __syncthreads();
+        }
+    }
+    __syncthreads(); // the two draining steps
+    __syncthreads();
+}
+
+template <int PIX>
+__device__ __forceinline__ void sat_chain_body(const DImg &src, const float *carries, float *sat, int nstrips, int ch, float (*ring)[SAT_SB][64],
+                                               float (*oring)[SAT_SB][64]) {
+    using P = Px<PIX>;
+    using Elem = typename P::Elem;
+    constexpr int C = P::C, SB = SAT_SB, NS = 4, RS = SB / NS; // storer waves, rows per storer and block
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, simd = wave & 3;
+    if (simd == 0 && wave != 0) return; // the chain keeps its SIMD to itself
+    const int rows = src.rows, cols = src.cols;
+    const int nblocks = (rows + SB - 1) / SB;
+    const int x0 = blockIdx.x * 64;
+    const bool all_live = x0 + 64 <= cols; // workgroup-uniform
+
+    // Step k (between barrier k and barrier k + 1): the loaders publish block k + 1 into ring[(k + 1) & 1], the chain turns
+    // ring[k & 1] into oring[k & 1], the storers write block k - 1 out of oring[(k - 1) & 1]. Every slot is rewritten one
+    // step after its last reader finished. Two extra steps drain the pipe.
+    if (wave == 0) { // ---- the chain ------------------------------------------------------------------------------------------
+        float run = 0.0f;
+        for (int blk = 0; blk < nblocks + 2; ++blk) {
+            __syncthreads(); // block blk is in ring[blk & 1]
+            if (blk < nblocks) {
+                float p[SB];
+#pragma unroll
+                for (int i = 0; i < SB; ++i) p[i] = ring[blk & 1][i][lane];
+#pragma unroll
+                for (int i = 0; i < SB; ++i) {
+                    run = run + p[i];
+                    oring[blk & 1][i][lane] = run;
+                }
+            }
+        }
+        return;
+    }
+    const int role = (wave >> 2) * 3 + simd - 1; // 0..11
+    float *plane = sat + (size_t)ch * rows * cols;
+    if (role >= 8) { // ---- a storer: rows sub * RS .. + RS of every block, out of the chain's ring -----------------------------------
+        const int sub = role - 8, row4 = lane >> 4, q = lane & 15;
+        const bool vec = all_live && (cols & 3) == 0 && ((uintptr_t)plane & 15) == 0; // 16-byte stores: four rows per instruction
+        float *o = plane + (size_t)(sub * RS + row4) * cols + x0 + 4 * q; // row sub * RS + row4 of block 0; the four pieces are 4 rows apart
+        const size_t piece = (size_t)4 * cols, block_step = (size_t)SB * cols;
+        for (int blk = 0; blk < nblocks + 2; ++blk) {
+            if (blk >= 2) {
+                const int ob = blk - 2, r0 = ob * SB + sub * RS;
+                float4 v[RS / 4];
+#pragma unroll
+                for (int h = 0; h < RS / 4; ++h) v[h] = *(const float4 *)&oring[ob & 1][sub * RS + h * 4 + row4][4 * q];
+                if (vec && r0 + RS <= rows) { // the common case: no predicate, no multiplication
+#pragma unroll
+                    for (int h = 0; h < RS / 4; ++h) *(float4 *)(o + h * piece) = v[h];
+                } else {
+#pragma unroll
+                    for (int h = 0; h < RS / 4; ++h) {
+                        if (r0 + h * 4 + row4 < rows) {
+                            const float e[4] = {v[h].x, v[h].y, v[h].z, v[h].w};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (x0 + 4 * q + j < cols) o[h * piece + j] = e[j];
+                        }
+                    }
+                }
+                o += block_step;
+            }
+            __syncthreads(); // barrier blk
+        }
+        return;
+    }
+    // ---- a loader -------------------------------------------------------------------------------------------------------------
+    // one wide load per lane and row when the four elements are contiguous and aligned (always, for images this library allocated)
+    bool vec = false;
+    if constexpr (PIX == ZG_PIXEL_U8) vec = all_live && (src.stride & 3) == 0 && ((uintptr_t)src.data & 3) == 0;
+    if constexpr (PIX == ZG_PIXEL_RGBA_U8 || PIX == ZG_PIXEL_F32) vec = all_live && (src.stride * sizeof(Elem) * C) % 16 == 0 && ((uintptr_t)src.data & 15) == 0;
+    if constexpr (PIX == ZG_PIXEL_U8 || PIX == ZG_PIXEL_RGBA_U8 || PIX == ZG_PIXEL_F32) {
+        if (vec) { sat_loader<PIX, true>(src, carries, nstrips, ch, ring, role, lane, nblocks); return; }
+    }
+    sat_loader<PIX, false>(src, carries, nstrips, ch, ring, role, lane, nblocks);
 }
 template <int PIX>
-__global__ __launch_bounds__(576) void k_sat_chain(DImg src, const float *carries, float *sat, int nstrips) {
-    __shared__ float ring[2][SAT_SB][64];
-    sat_chain_body<PIX>(src, carries, sat, nstrips, (int)blockIdx.y, ring);
+__global__ __launch_bounds__(SAT_THREADS) void k_sat_chain(DImg src, const float *carries, float *sat, int nstrips) {
+    __shared__ float ring[2][SAT_SB][64], oring[2][SAT_SB][64];
+    sat_chain_body<PIX>(src, carries, sat, nstrips, (int)blockIdx.y, ring, oring);
 }
 
 // Several single-channel planes of one size in one launch (blockIdx.y picks the plane): a lone plane gives the chain kernel only
@@ -373,12 +487,12 @@ __global__ __launch_bounds__(256) void k_strip_carries_planes(SatPlanes pl, floa
     if (pl.f32[p]) strip_carries_body<ZG_PIXEL_F32>(pl.src[p], table, nstrips, wsum);
     else strip_carries_body<ZG_PIXEL_U8>(pl.src[p], table, nstrips, wsum);
 }
-__global__ __launch_bounds__(576) void k_sat_chain_planes(SatPlanes pl, const float *carries, int nstrips) {
-    __shared__ float ring[2][SAT_SB][64];
+__global__ __launch_bounds__(SAT_THREADS) void k_sat_chain_planes(SatPlanes pl, const float *carries, int nstrips) {
+    __shared__ float ring[2][SAT_SB][64], oring[2][SAT_SB][64];
     const int p = blockIdx.y;
     const float *table = carries + (size_t)p * pl.src[0].rows * nstrips;
-    if (pl.f32[p]) sat_chain_body<ZG_PIXEL_F32>(pl.src[p], table, pl.sat[p], nstrips, 0, ring);
-    else sat_chain_body<ZG_PIXEL_U8>(pl.src[p], table, pl.sat[p], nstrips, 0, ring);
+    if (pl.f32[p]) sat_chain_body<ZG_PIXEL_F32>(pl.src[p], table, pl.sat[p], nstrips, 0, ring, oring);
+    else sat_chain_body<ZG_PIXEL_U8>(pl.src[p], table, pl.sat[p], nstrips, 0, ring, oring);
 }
 
 // Integral image(s) of `src` (Image(T).Integral.compute, integral.zig:95-140): one f32 plane of rows x cols per channel,
@@ -398,7 +512,7 @@ int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer
             constexpr int PIX = decltype(tag)::value;
             constexpr int PC = Px<PIX>::C;
             hipLaunchKernelGGL((k_strip_carries<PIX>), dim3(src->rows), dim3(256), 0, s, dimg(src), carries, nstrips);
-            hipLaunchKernelGGL((k_sat_chain<PIX>), dim3(ceil_div((unsigned)nstrips, 4u), (unsigned)PC), dim3(576), 0, s, dimg(src), (const float *)carries, sat, nstrips);
+            hipLaunchKernelGGL((k_sat_chain<PIX>), dim3(ceil_div((unsigned)nstrips, 4u), (unsigned)PC), dim3(SAT_THREADS), 0, s, dimg(src), (const float *)carries, sat, nstrips);
             ZG_HIP(hipGetLastError());
             return ZG_OK;
         });
@@ -436,7 +550,7 @@ int sat_planes_multi(const zg_image *const *srcs, float *const *sats, int count,
         pl.f32[i] = srcs[i]->pixel == ZG_PIXEL_F32;
     }
     hipLaunchKernelGGL(k_strip_carries_planes, dim3(a->rows, (unsigned)count), dim3(256), 0, s, pl, carries, nstrips);
-    hipLaunchKernelGGL(k_sat_chain_planes, dim3(ceil_div((unsigned)nstrips, 4u), (unsigned)count), dim3(576), 0, s, pl, (const float *)carries, nstrips);
+    hipLaunchKernelGGL(k_sat_chain_planes, dim3(ceil_div((unsigned)nstrips, 4u), (unsigned)count), dim3(SAT_THREADS), 0, s, pl, (const float *)carries, nstrips);
     const hipError_t e = hipGetLastError();
     scratch_free(carries, s);
     if (e != hipSuccess) { set_error("integral image: launch failed: %s", hipGetErrorString(e)); return ZG_ERR_HIP; }
