@@ -651,14 +651,10 @@ __global__ __launch_bounds__(256) void k_sc_bli4(const float *gray, const float 
     }
 }
 
-__device__ inline float sc_sat_sum(const float *sat, int cols, int r1, int c1, int r2, int c2) { // integral.zig:85-90, in that order
-    const float a = sat[(size_t)r2 * cols + c2];
-    const float b = c1 > 0 ? sat[(size_t)r2 * cols + (c1 - 1)] : 0.0f;
-    const float c = r1 > 0 ? sat[(size_t)(r1 - 1) * cols + c2] : 0.0f;
-    const float d = (r1 > 0 && c1 > 0) ? sat[(size_t)(r1 - 1) * cols + (c1 - 1)] : 0.0f;
-    return ((a - b) - c) + d;
-}
 // adaptive gradient at the candidates (edges.zig:462-496) + the histogram of its rounded values (:139-150)
+// BUF: the planes are below 4 GiB, so a corner read is a buffer load (scalar row offset + per-lane column offset: no vector
+// address arithmetic at all; with 64-bit pointers a third of the kernel's instructions computed addresses).
+template <bool BUF>
 __global__ __launch_bounds__(256) void k_sc_gradient(const uint8_t *cand, const float *sat_g, const float *sat_m, const float *sat_gm, float *grad,
                                                      unsigned int *hist, int rows, int cols, int hw) {
     // sixteen copies of the block histogram: neighbouring pixels have similar gradients, and 64 lanes hitting one LDS counter
@@ -668,29 +664,96 @@ __global__ __launch_bounds__(256) void k_sc_gradient(const uint8_t *cand, const 
     for (int k = 0; k < 16; ++k) lh[k][threadIdx.x] = 0;
     __syncthreads();
     // a workgroup covers 64 columns x 64 rows (sixteen steps of four rows), so the 256 global histogram updates it ends
-    // with are amortised over 4096 pixels (one update per 4-row block serialised 16.7 M atomics on 256 counters: 1.09 ms)
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    for (int step = 0; step < 16; ++step) {
-        const int r = blockIdx.y * 64 + step * 4 + (int)(threadIdx.x >> 6);
-        if (c >= cols || r >= rows) continue;
-        const size_t idx = (size_t)r * cols + c;
-        float g = 0.0f;
-        if (cand[idx] != 0) {
-            const int r1 = r > hw ? r - hw : 0, r2 = min(r + hw, rows - 1), c1 = c > hw ? c - hw : 0, c2 = min(c + hw, cols - 1);
-            const float area = (float)((size_t)(r2 - r1 + 1) * (size_t)(c2 - c1 + 1));
-            const float count1 = sc_sat_sum(sat_m, cols, r1, c1, r2, c2), count0 = area - count1;
-            if (count0 > 0 && count1 > 0) {
-                const float sum1 = sc_sat_sum(sat_gm, cols, r1, c1, r2, c2), sum_total = sc_sat_sum(sat_g, cols, r1, c1, r2, c2);
-                const float sum0 = sum_total - sum1;
-                const float mean0 = sum0 / count0, mean1 = sum1 / count1;
-                g = fabsf(mean1 - mean0);
+    // with are amortised over 4096 pixels (one update per 4-row block serialised 16.7 M atomics on 256 counters: 1.09 ms).
+    // The kernel is latency-bound (one step at a time, the corner reads behind two branches: 150 us per 4096^2 frame), so the
+    // sixteen candidate bytes of a thread are read first and the steps go four at a time, the 48 corner reads of a group
+    // issued before anything is computed. The loads of a wave row are whole cache lines whichever lanes want them, so they are not
+    // predicated on the candidate bit, only skipped when no lane of the wave has a candidate in the group.
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), cc = min(c, cols - 1);
+    const int wrow = blockIdx.y * 64 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // a wave is one row: row arithmetic is scalar
+    const int c1 = cc > hw ? cc - hw : 0, c2 = min(cc + hw, cols - 1);
+    const int cl = c1 > 0 ? c1 - 1 : 0; // column of the two left-hand corners (read anyway, dropped when c1 == 0)
+    const float *const planes[3] = {sat_m, sat_gm, sat_g};
+    const uint32_t oc2 = (uint32_t)c2 * 4u, ocl = (uint32_t)cl * 4u;
+    const uint32_t plane_bytes = BUF ? (uint32_t)((size_t)rows * cols * 4) : 0u;
+    uint8_t cb[16];
+#pragma unroll
+    for (int st = 0; st < 16; ++st) cb[st] = cand[(size_t)min(wrow + st * 4, rows - 1) * cols + cc];
+    // out-of-range buffer offsets read as zero: the corners that do not exist (c1 == 0, r1 == 0) need no select afterwards
+    constexpr uint32_t OOR = 0xfffffff0u;
+    const uint32_t ocl_z = c1 > 0 ? ocl : OOR;
+    constexpr int U = 2, NG = 16 / U;
+    struct Group { float v[U][12]; };
+    auto issue = [&](int grp, Group &g) { // the 24 corner reads of steps grp * U .. + U
+        bool some = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) some = some || (c < cols && wrow + (grp * U + u) * 4 < rows && cb[grp * U + u] != 0);
+        if (__ballot(some) != 0) { // wave-uniform
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = min(wrow + (grp * U + u) * 4, rows - 1);
+                const int r1 = r > hw ? r - hw : 0, r2 = min(r + hw, rows - 1);
+                const size_t bot = (size_t)r2 * cols, top = (size_t)(r1 > 0 ? r1 - 1 : 0) * cols;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    if constexpr (BUF) {
+                        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)planes[p], (short)0, (int)plane_bytes, 0x00020000);
+                        const int sb = (int)(uint32_t)(bot * 4), stp = (int)(uint32_t)(top * 4);
+                        const uint32_t t2 = r1 > 0 ? oc2 : OOR, tl = r1 > 0 ? ocl_z : OOR;
+                        g.v[u][p * 4 + 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)oc2, sb, 0));
+                        g.v[u][p * 4 + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)ocl_z, sb, 0));
+                        g.v[u][p * 4 + 2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)t2, stp, 0));
+                        g.v[u][p * 4 + 3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)tl, stp, 0));
+                    } else {
+                        g.v[u][p * 4 + 0] = planes[p][bot + c2];
+                        g.v[u][p * 4 + 1] = c1 > 0 ? planes[p][bot + cl] : 0.0f;
+                        g.v[u][p * 4 + 2] = r1 > 0 ? planes[p][top + c2] : 0.0f;
+                        g.v[u][p * 4 + 3] = (r1 > 0 && c1 > 0) ? planes[p][top + cl] : 0.0f;
+                    }
+                }
             }
-            float hgv = g;
-            if (hgv < 0) hgv = 0;
-            if (hgv > 255) hgv = 255;
-            atomicAdd(&lh[threadIdx.x & 15][(int)roundf(hgv)], 1u);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < 12; ++k) g.v[u][k] = 0.0f;
         }
-        grad[idx] = g;
+    };
+    auto finish = [&](int grp, const Group &g) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = wrow + (grp * U + u) * 4;
+            if (c >= cols || r >= rows) continue;
+            float gr = 0.0f;
+            if (cb[grp * U + u] != 0) {
+                const int r1 = r > hw ? r - hw : 0, r2 = min(r + hw, rows - 1);
+                const float area = (float)((size_t)(r2 - r1 + 1) * (size_t)(c2 - c1 + 1));
+                float sum[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) sum[p] = ((g.v[u][p * 4 + 0] - g.v[u][p * 4 + 1]) - g.v[u][p * 4 + 2]) + g.v[u][p * 4 + 3]; // integral.zig:85-90, in that order
+                const float count1 = sum[0], count0 = area - count1;
+                if (count0 > 0 && count1 > 0) {
+                    const float sum1 = sum[1], sum_total = sum[2];
+                    const float sum0 = sum_total - sum1;
+                    const float mean0 = sum0 / count0, mean1 = sum1 / count1;
+                    gr = fabsf(mean1 - mean0);
+                }
+                float hgv = gr;
+                if (hgv < 0) hgv = 0;
+                if (hgv > 255) hgv = 255;
+                atomicAdd(&lh[threadIdx.x & 15][(int)roundf(hgv)], 1u);
+            }
+            grad[(size_t)r * cols + c] = gr;
+        }
+    };
+    Group ga, gb; // two groups in flight: the reads of the next one are out before this one is computed
+    issue(0, ga);
+#pragma unroll
+    for (int grp = 0; grp < NG; grp += 2) {
+        issue(grp + 1, gb);
+        finish(grp, ga);
+        if (grp + 2 < NG) issue(grp + 2, ga);
+        finish(grp + 1, gb);
     }
     __syncthreads();
     unsigned int total = 0;
@@ -819,8 +882,12 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
     }
     if (rc == ZG_OK) {
         if (hipMemsetAsync(hist, 0, 256 * sizeof(unsigned int), s) != hipSuccess) rc = ZG_ERR_HIP;
-        hipLaunchKernelGGL(k_sc_gradient, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, s, (const uint8_t *)cand, (const float *)sat_g, (const float *)sat_m, (const float *)sat_gm, grad, hist,
-                           (int)rows, (int)cols, (int)(window_size / 2));
+        if (n < (1u << 30))
+            hipLaunchKernelGGL(k_sc_gradient<true>, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, s, (const uint8_t *)cand, (const float *)sat_g, (const float *)sat_m, (const float *)sat_gm, grad, hist,
+                               (int)rows, (int)cols, (int)(window_size / 2));
+        else
+            hipLaunchKernelGGL(k_sc_gradient<false>, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, s, (const uint8_t *)cand, (const float *)sat_g, (const float *)sat_m, (const float *)sat_gm, grad, hist,
+                               (int)rows, (int)cols, (int)(window_size / 2));
         hipLaunchKernelGGL(k_sc_thresholds, dim3(1), dim3(64), 0, s, (const unsigned int *)hist, thr, high_ratio, low_rel);
         const uint8_t *final_cand = cand;
         if (use_nms) {
