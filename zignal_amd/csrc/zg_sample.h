@@ -105,6 +105,20 @@ template <int KIND> __device__ inline float cubic_tap_weight(int i, float t) {
     }
 }
 
+// The x and y weights of a tap come from the same polynomial: evaluated as a pair (v_pk_mul_f32 / v_pk_add_f32), each half with
+// the scalar expression's operations in the scalar expression's order.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int KIND> __device__ inline f32x2 cubic_tap_weight2(int i, f32x2 t) {
+    const f32x2 at = {fabsf(t.x), fabsf(t.y)};
+    if constexpr (KIND == ZG_INTERP_BICUBIC) {
+        if (i == 1 || i == 2) return (1.0f - (2.0f * at) * at) + (at * at) * at;
+        return ((4.0f - 8.0f * at) + (5.0f * at) * at) - (at * at) * at;
+    } else {
+        if (i == 1 || i == 2) return (((1.5f * at) * at) * at - (2.5f * at) * at) + 1.0f;
+        return ((((-0.5f * at) * at) * at + (2.5f * at) * at) - 4.0f * at) + 2.0f;
+    }
+}
+
 template <int KIND> __device__ inline float eval_kernel(const MethodArg &m, float t) {
     if constexpr (KIND == ZG_INTERP_BICUBIC) return bicubic_kernel(t);
     else if constexpr (KIND == ZG_INTERP_CATMULL_ROM) return catmull_rom_kernel(t);
@@ -179,8 +193,10 @@ __device__ inline bool interpolate(const DImg &img, float x, float y, const Meth
 #pragma unroll
         for (int i = 0; i < W; ++i) {
             if constexpr (KIND == ZG_INTERP_BICUBIC || KIND == ZG_INTERP_CATMULL_ROM) {
-                xw[i] = cubic_tap_weight<KIND>(i, (float)(i - (R - 1)) - fx);
-                yw[i] = cubic_tap_weight<KIND>(i, (float)(i - (R - 1)) - fy);
+                const f32x2 f = {fx, fy};
+                const f32x2 w = cubic_tap_weight2<KIND>(i, (float)(i - (R - 1)) - f);
+                xw[i] = w.x;
+                yw[i] = w.y;
             } else {
                 xw[i] = eval_kernel<KIND>(m, (float)(i - (R - 1)) - fx);
                 yw[i] = eval_kernel<KIND>(m, (float)(i - (R - 1)) - fy);
@@ -191,14 +207,34 @@ __device__ inline bool interpolate(const DImg &img, float x, float y, const Meth
         for (int ch = 0; ch < C; ++ch) sums[ch] = 0;
         float weight_sum = 0;
         const int bx = ix.narrow - (R - 1), by = iy.narrow - (R - 1);
-        if (ix.is_narrow && iy.is_narrow && bx >= 0 && bx + W <= img.cols && by >= 0 && by + W <= img.rows) {
+        // pixels of 4 or 16 bytes in images below 4 GiB are gathered with buffer loads; larger images take the general path
+        constexpr int PB = P::BYTES;
+        constexpr bool BUF = PB == 4 || PB == 16;
+        const size_t img_bytes = (size_t)img.rows * img.stride * PB;
+        if (ix.is_narrow && iy.is_narrow && bx >= 0 && bx + W <= img.cols && by >= 0 && by + W <= img.rows && (!BUF || img_bytes < (1ull << 32))) {
             // the whole W x W window is inside the image (every pixel but a thin rim): straight-line code, all
             // W*W gathers independent and in flight together, same accumulation order as the general path
             Vec px[W][W];
+            if constexpr (BUF) {
+                // buffer loads: one 32-bit offset per lane, the row of a tap in the scalar offset, its column in the immediate:
+                // sixteen gathers without a single address instruction
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)img.data, (short)0, (int)(uint32_t)img_bytes, 0x00020000);
+                const int voff = (by * img.stride + bx) * PB;
 #pragma unroll
-            for (int j = 0; j < W; ++j)
+                for (int j = 0; j < W; ++j) {
+                    const int soff = j * img.stride * PB;
 #pragma unroll
-                for (int i = 0; i < W; ++i) px[j][i] = P::load(img.data, (size_t)(by + j) * img.stride + (size_t)(bx + i));
+                    for (int i = 0; i < W; ++i) {
+                        if constexpr (PB == 4) px[j][i] = __builtin_bit_cast(Vec, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + i * PB, soff, 0));
+                        else px[j][i] = __builtin_bit_cast(Vec, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + i * PB, soff, 0));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < W; ++j)
+#pragma unroll
+                    for (int i = 0; i < W; ++i) px[j][i] = P::load(img.data, (size_t)(by + j) * img.stride + (size_t)(bx + i));
+            }
 #pragma unroll
             for (int j = 0; j < W; ++j) {
 #pragma unroll
@@ -210,6 +246,24 @@ __device__ inline bool interpolate(const DImg &img, float x, float y, const Meth
                         sums[ch] = sums[ch] + prod;
                     }
                     weight_sum = weight_sum + weight;
+                }
+            }
+            if constexpr (!IS_F) {
+                // The C quotients share their divisor: the refined reciprocal of the IEEE division sequence (v_rcp + one Newton
+                // step) is computed once and each quotient is the sequence's remaining five operations, bit for bit what `/`
+                // expands to when v_div_scale has nothing to scale (sums of 8-bit samples over a weight sum near 1).
+                if (weight_sum > 0.5f && weight_sum < 2.0f) {
+                    const float nd = -weight_sum, r0 = __builtin_amdgcn_rcpf(weight_sum);
+                    const float r1 = __builtin_fmaf(__builtin_fmaf(nd, r0, 1.0f), r0, r0);
+#pragma unroll
+                    for (int ch = 0; ch < C; ++ch) {
+                        const float q0 = sums[ch] * r1;
+                        const float q1 = __builtin_fmaf(__builtin_fmaf(nd, q0, sums[ch]), r1, q0);
+                        const float val = __builtin_fmaf(__builtin_fmaf(nd, q1, sums[ch]), r1, q1); // finite: no NaN case to map
+                        const float u = fminf(fmaxf(val, 0.0f), 255.0f), t = truncf(u);
+                        out[ch] = (uint8_t)((int)t + ((u - t) >= 0.5f ? 1 : 0));
+                    }
+                    return true;
                 }
             }
         } else {
