@@ -12,7 +12,7 @@
 namespace zg {
 
 int copy_impl(const zg_image *src, const zg_image *dst, hipStream_t s);
-int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer_valued); // box_blur.hip
+int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer_valued, size_t plane_stride = 0); // box_blur.hip (0: planes contiguous)
 
 __global__ __launch_bounds__(256) void k_hist_u8(DImg src, unsigned int *hist) {
     __shared__ unsigned int lh[16][256];

@@ -116,37 +116,88 @@ __global__ __launch_bounds__(64) void k_sat_cols(float *sat, int rows, int cols)
 }
 
 // SHARPEN: Integral.sharpen (integral.zig:273-323, 325-426): 2 * original - blurred instead of the mean itself.
-template <int PIX, bool SHARPEN>
-__global__ __launch_bounds__(256) void k_box_mean(const float *sat, DImg src, DImg dst, int radius) {
+// BUF: the planes are below 4 GiB together, so the four corners of a channel are buffer loads (the row and the plane in the
+// scalar offset, the column per lane, corners that do not exist pointed out of range where a buffer load reads zero): no address
+// arithmetic and no selects. For integer pixels the C quotients share their divisor: the refined reciprocal of the IEEE division
+// sequence (v_rcp + one Newton step) is computed once, each quotient is the sequence's remaining five operations, bit for bit what
+// `/` expands to when v_div_scale has nothing to scale (a finite sum of 8-bit samples over an area >= 1).
+// (One thread per pixel with 64-bit addresses and four full divisions was VALU-bound: 81 us per 4096^2 Rgba(u8) frame.)
+template <int PIX, bool SHARPEN, bool BUF>
+__global__ __launch_bounds__(256) void k_box_mean(const float *sat, size_t plane, DImg src, DImg dst, int radius) { // plane: elements from one channel's SAT to the next
     using P = Px<PIX>;
     using Vec = typename P::Vec;
     constexpr int C = P::C;
-    const int c = blockIdx.x * 256 + threadIdx.x, r = grid_row();
-    if (c >= dst.cols || r >= dst.rows) return;
+    constexpr bool IS_F = std::is_same<typename P::Elem, float>::value;
+    // One plane: a workgroup is 64 columns x 16 rows (a wave per row, four steps). The two SAT rows an output row needs are needed
+    // again 2 * radius + 1 rows further down, and the tile keeps them in the CU's L1 in between (34 -> 25 us per 4096^2 plane).
+    // Several planes: 256 columns of one row; their tiles no longer fit (64 x 16: 108 us, 64 x 4: 96 us, 256 x 1: 77 us for Rgba(u8)).
+    constexpr int STEPS = C == 1 ? 4 : 1;
+    const int c = C == 1 ? blockIdx.x * 64 + (int)(threadIdx.x & 63) : blockIdx.x * 256 + (int)threadIdx.x;
+    const int wrow = C == 1 ? grid_row() * 16 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : grid_row();
+    if (c >= dst.cols) return;
     const int rows = dst.rows, cols = dst.cols;
-    const int r1 = max(r - radius, 0), r2 = (int)min((long long)r + radius, (long long)rows - 1);
     const int c1 = max(c - radius, 0), c2 = (int)min((long long)c + radius, (long long)cols - 1);
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+    const int r = wrow + step * 4;
+    if (r >= rows) return; // wave-uniform
+    const int r1 = max(r - radius, 0), r2 = (int)min((long long)r + radius, (long long)rows - 1);
     const float area = (float)((long long)(r2 - r1 + 1) * (long long)(c2 - c1 + 1));
     Vec o, orig = P::zero();
     if constexpr (SHARPEN) orig = P::load(src.data, (size_t)r * src.stride + (size_t)c);
+    float sum[C];
+    if constexpr (BUF) {
+        constexpr uint32_t OOR = 0xfffffff0u;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sat, (short)0, (int)(uint32_t)(plane * C * 4), 0x00020000);
+        const uint32_t oa = (uint32_t)c2 * 4u, ob = c1 > 0 ? (uint32_t)(c1 - 1) * 4u : OOR;
+        const uint32_t od = r1 > 0 ? oa : OOR, oe = r1 > 0 ? ob : OOR;
+        const uint32_t bot = (uint32_t)((size_t)r2 * cols * 4), top = (uint32_t)((size_t)(r1 > 0 ? r1 - 1 : 0) * cols * 4);
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            const uint32_t pl = (uint32_t)(plane * ch * 4);
+            const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)oa, (int)(pl + bot), 0));
+            const float b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)ob, (int)(pl + bot), 0));
+            const float d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)od, (int)(pl + top), 0));
+            const float e = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)oe, (int)(pl + top), 0));
+            sum[ch] = a - b - d + e; // ((a - b) - d) + e, integral.zig:87-90
+        }
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) {
+            const float *s = sat + (size_t)ch * plane;
+            const float a = s[(size_t)r2 * cols + c2];
+            const float b = c1 > 0 ? s[(size_t)r2 * cols + (c1 - 1)] : 0.0f;
+            const float d = r1 > 0 ? s[(size_t)(r1 - 1) * cols + c2] : 0.0f;
+            const float e = (r1 > 0 && c1 > 0) ? s[(size_t)(r1 - 1) * cols + (c1 - 1)] : 0.0f;
+            sum[ch] = a - b - d + e;
+        }
+    }
+    const float nd = -area, r0 = __builtin_amdgcn_rcpf(area);
+    const float r1f = __builtin_fmaf(__builtin_fmaf(nd, r0, 1.0f), r0, r0);
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) {
-        const float *s = sat + (size_t)ch * rows * cols;
-        const float a = s[(size_t)r2 * cols + c2];
-        const float b = c1 > 0 ? s[(size_t)r2 * cols + (c1 - 1)] : 0.0f;
-        const float d = r1 > 0 ? s[(size_t)(r1 - 1) * cols + c2] : 0.0f;
-        const float e = (r1 > 0 && c1 > 0) ? s[(size_t)(r1 - 1) * cols + (c1 - 1)] : 0.0f;
-        const float sum = a - b - d + e; // ((a - b) - d) + e, integral.zig:87-90
-        float val = sum / area;
+        float val;
+        if constexpr (IS_F) {
+            val = sum[ch] / area;
+        } else {
+            const float q0 = sum[ch] * r1f;
+            const float q1 = __builtin_fmaf(__builtin_fmaf(nd, q0, sum[ch]), r1f, q0);
+            val = __builtin_fmaf(__builtin_fmaf(nd, q1, sum[ch]), r1f, q1);
+        }
         if constexpr (SHARPEN) {
             const float original = (float)orig[ch];
             const float twice = 2 * original;
             val = twice - val;
         }
-        if constexpr (std::is_same<typename P::Elem, float>::value) o[ch] = val;
-        else o[ch] = clamp_u8_f32(val);
+        if constexpr (IS_F) {
+            o[ch] = val;
+        } else { // finite: no NaN case to map
+            const float u = fminf(fmaxf(val, 0.0f), 255.0f), t = truncf(u);
+            o[ch] = (uint8_t)((int)t + ((u - t) >= 0.5f ? 1 : 0));
+        }
     }
     P::store(dst.data, (size_t)r * dst.stride + (size_t)c, o);
+    }
 }
 
 // Row pass for sources whose row sums are exact in f32 — integer-valued elements with cols * max < 2^24 (every u8 pixel type,
@@ -391,8 +442,8 @@ __device__ __forceinline__ void sat_loader(const DImg &src, const float *carries
 }
 
 template <int PIX>
-__device__ __forceinline__ void sat_chain_body(const DImg &src, const float *carries, float *sat, int nstrips, int ch, float (*ring)[SAT_SB][64],
-                                               float (*oring)[SAT_SB][64]) {
+__device__ __forceinline__ void sat_chain_body(const DImg &src, const float *carries, float *sat, size_t pstride, int nstrips, int ch,
+                                               float (*ring)[SAT_SB][64], float (*oring)[SAT_SB][64]) {
     using P = Px<PIX>;
     using Elem = typename P::Elem;
     constexpr int C = P::C, SB = SAT_SB, NS = 4, RS = SB / NS; // storer waves, rows per storer and block
@@ -425,7 +476,7 @@ __device__ __forceinline__ void sat_chain_body(const DImg &src, const float *car
         return;
     }
     const int role = (wave >> 2) * 3 + simd - 1; // 0..11
-    float *plane = sat + (size_t)ch * rows * cols;
+    float *plane = sat + (size_t)ch * pstride;
     if (role >= 8) { // ---- a storer: rows sub * RS .. + RS of every block, out of the chain's ring -----------------------------------
         const int sub = role - 8, row4 = lane >> 4, q = lane & 15;
         const bool vec = all_live && (cols & 3) == 0 && ((uintptr_t)plane & 15) == 0; // 16-byte stores: four rows per instruction
@@ -468,9 +519,9 @@ __device__ __forceinline__ void sat_chain_body(const DImg &src, const float *car
     sat_loader<PIX, false>(src, carries, nstrips, ch, ring, role, lane, nblocks);
 }
 template <int PIX>
-__global__ __launch_bounds__(SAT_THREADS) void k_sat_chain(DImg src, const float *carries, float *sat, int nstrips) {
+__global__ __launch_bounds__(SAT_THREADS) void k_sat_chain(DImg src, const float *carries, float *sat, size_t pstride, int nstrips) {
     __shared__ float ring[2][SAT_SB][64], oring[2][SAT_SB][64];
-    sat_chain_body<PIX>(src, carries, sat, nstrips, (int)blockIdx.y, ring, oring);
+    sat_chain_body<PIX>(src, carries, sat, pstride, nstrips, (int)blockIdx.y, ring, oring);
 }
 
 // Several single-channel planes of one size in one launch (blockIdx.y picks the plane): a lone plane gives the chain kernel only
@@ -491,20 +542,30 @@ __global__ __launch_bounds__(SAT_THREADS) void k_sat_chain_planes(SatPlanes pl, 
     __shared__ float ring[2][SAT_SB][64], oring[2][SAT_SB][64];
     const int p = blockIdx.y;
     const float *table = carries + (size_t)p * pl.src[0].rows * nstrips;
-    if (pl.f32[p]) sat_chain_body<ZG_PIXEL_F32>(pl.src[p], table, pl.sat[p], nstrips, 0, ring, oring);
-    else sat_chain_body<ZG_PIXEL_U8>(pl.src[p], table, pl.sat[p], nstrips, 0, ring, oring);
+    if (pl.f32[p]) sat_chain_body<ZG_PIXEL_F32>(pl.src[p], table, pl.sat[p], 0, nstrips, 0, ring, oring);
+    else sat_chain_body<ZG_PIXEL_U8>(pl.src[p], table, pl.sat[p], 0, nstrips, 0, ring, oring);
 }
 
 // Integral image(s) of `src` (Image(T).Integral.compute, integral.zig:95-140): one f32 plane of rows x cols per channel,
 // planar, in the reference's association order. Also used by the Shen-Castan detector (edges.hip).
 // `integer_valued`: the caller knows every element is an integer in [0, 255] (always true for u8 pixels), which makes the
 // row sums exact and lets the row pass run as a parallel scan.
-int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer_valued) {
+// Exact-row sources take the fused pair of kernels, which can leave a gap between the planes (see sat_plane_stride).
+static bool sat_fused_applies(const zg_image *src, bool integer_valued) {
+    static const bool fused_off = getenv("ZIGNAL_HIP_SAT_UNFUSED") != nullptr;
+    return (integer_valued || !pixel_is_float(src->pixel)) && src->cols <= 65536 && !fused_off; // 65536 * 255 < 2^24
+}
+// Planes exactly rows * cols apart are a power of two apart for the usual frame sizes: the same element of the C planes then sits in
+// the same L2 channel and the same cache set, and the kernels that walk the planes together (k_sat_chain's channel workgroups,
+// k_box_mean's corner reads) queue up there. Scratch planes are spread by 4352 bytes per channel instead.
+static size_t sat_plane_stride(const zg_image *src, bool padded) { return (size_t)src->rows * src->cols + (padded ? 1088 : 0); }
+
+int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer_valued, size_t pstride) {
     const int C = pixel_channels(src->pixel);
+    if (pstride == 0) pstride = (size_t)src->rows * src->cols;
     const bool exact_rows = (integer_valued || !pixel_is_float(src->pixel)) && src->cols <= 65536; // 65536 * 255 < 2^24
     // exact rows: carries of the 16-column strips (a small table), then prefix + chain + store in one pass over the source
-    static const bool fused_off = getenv("ZIGNAL_HIP_SAT_UNFUSED") != nullptr;
-    if (exact_rows && !fused_off) {
+    if (sat_fused_applies(src, integer_valued)) {
         const int nstrips = (int)ceil_div(src->cols, 16u);
         float *carries = nullptr;
         if (int rc = scratch_alloc((void **)&carries, (size_t)src->rows * nstrips * C * sizeof(float), s)) return rc;
@@ -512,7 +573,7 @@ int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer
             constexpr int PIX = decltype(tag)::value;
             constexpr int PC = Px<PIX>::C;
             hipLaunchKernelGGL((k_strip_carries<PIX>), dim3(src->rows), dim3(256), 0, s, dimg(src), carries, nstrips);
-            hipLaunchKernelGGL((k_sat_chain<PIX>), dim3(ceil_div((unsigned)nstrips, 4u), (unsigned)PC), dim3(SAT_THREADS), 0, s, dimg(src), (const float *)carries, sat, nstrips);
+            hipLaunchKernelGGL((k_sat_chain<PIX>), dim3(ceil_div((unsigned)nstrips, 4u), (unsigned)PC), dim3(SAT_THREADS), 0, s, dimg(src), (const float *)carries, sat, pstride, nstrips);
             ZG_HIP(hipGetLastError());
             return ZG_OK;
         });
@@ -537,7 +598,7 @@ int sat_planes_multi(const zg_image *const *srcs, float *const *sats, int count,
         ok = srcs[i]->rows == a->rows && srcs[i]->cols == a->cols && (srcs[i]->pixel == ZG_PIXEL_U8 || srcs[i]->pixel == ZG_PIXEL_F32);
     if (!ok) { // one at a time
         for (int i = 0; i < count; ++i)
-            if (int rc = sat_planes_impl(srcs[i], sats[i], s, true)) return rc;
+            if (int rc = sat_planes_impl(srcs[i], sats[i], s, true, 0)) return rc;
         return ZG_OK;
     }
     const int nstrips = (int)ceil_div(a->cols, 16u);
@@ -568,12 +629,17 @@ static int box_blur_impl(const zg_image *src, const zg_image *dst, uint32_t radi
     ZG_REQUIRE(radius < (1u << 30), ZG_ERR_INVALID_ARGUMENT, "boxBlur: radius too large");
     const int C = pixel_channels(src->pixel);
     float *sat = nullptr;
-    if ((rc = scratch_alloc((void **)&sat, (size_t)C * src->rows * src->cols * sizeof(float), s))) return rc;
-    if ((rc = sat_planes_impl(src, sat, s, false)) == ZG_OK)
+    const size_t plane = sat_plane_stride(src, sat_fused_applies(src, false));
+    if ((rc = scratch_alloc((void **)&sat, (size_t)C * plane * sizeof(float), s))) return rc;
+    if ((rc = sat_planes_impl(src, sat, s, false, plane)) == ZG_OK)
         rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
             constexpr int PIX = decltype(tag)::value;
-            if (sharpen) hipLaunchKernelGGL((k_box_mean<PIX, true>), row_grid(ceil_div(dst->cols, 256), dst->rows), dim3(256), 0, s, (const float *)sat, dimg(src), dimg(dst), (int)radius);
-            else hipLaunchKernelGGL((k_box_mean<PIX, false>), row_grid(ceil_div(dst->cols, 256), dst->rows), dim3(256), 0, s, (const float *)sat, dimg(src), dimg(dst), (int)radius);
+            const dim3 grid = C == 1 ? row_grid(ceil_div(dst->cols, 64), ceil_div(dst->rows, 16)) : row_grid(ceil_div(dst->cols, 256), dst->rows);
+            const bool buf = (size_t)C * plane * sizeof(float) < (1ull << 32);
+            if (buf && sharpen) hipLaunchKernelGGL((k_box_mean<PIX, true, true>), grid, dim3(256), 0, s, (const float *)sat, plane, dimg(src), dimg(dst), (int)radius);
+            else if (buf) hipLaunchKernelGGL((k_box_mean<PIX, false, true>), grid, dim3(256), 0, s, (const float *)sat, plane, dimg(src), dimg(dst), (int)radius);
+            else if (sharpen) hipLaunchKernelGGL((k_box_mean<PIX, true, false>), grid, dim3(256), 0, s, (const float *)sat, plane, dimg(src), dimg(dst), (int)radius);
+            else hipLaunchKernelGGL((k_box_mean<PIX, false, false>), grid, dim3(256), 0, s, (const float *)sat, plane, dimg(src), dimg(dst), (int)radius);
             ZG_HIP(hipGetLastError());
             return ZG_OK;
         });
@@ -621,7 +687,7 @@ int zg_integral(const zg_image *src, float *planes, zg_stream stream) {
     if ((rc = check_image(src, "src"))) return rc;
     ZG_REQUIRE(planes != nullptr || src->rows == 0 || src->cols == 0, ZG_ERR_INVALID_ARGUMENT, "integral: null output");
     if (src->rows == 0 || src->cols == 0) return ZG_OK;
-    return sat_planes_impl(src, planes, as_stream(stream), false);
+    return sat_planes_impl(src, planes, as_stream(stream), false, 0);
 }
 
 int zg_integral_host(const zg_image *src, float *planes) {
@@ -633,7 +699,7 @@ int zg_integral_host(const zg_image *src, float *planes) {
     ZG_REQUIRE(planes != nullptr, ZG_ERR_INVALID_ARGUMENT, "integral: null output");
     float *dev = nullptr;
     ZG_HIP(hipMalloc((void **)&dev, bytes));
-    rc = sat_planes_impl(&a.dev, dev, nullptr, false);
+    rc = sat_planes_impl(&a.dev, dev, nullptr, false, 0);
     if (rc == ZG_OK) rc = download_pageable(planes, dev, bytes, nullptr);
     (void)hipFree(dev);
     return rc;

@@ -425,7 +425,7 @@ static int canny_impl(const zg_image *src, const zg_image *dst, float sigma, flo
 // latency-bound like boxBlur's SAT. The histogram, its percentile and the thresholds stay on the device (integer atomics
 // and a one-workgroup kernel), so nothing but the hysteresis fixed-point test synchronises the stream.
 
-int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer_valued); // box_blur.hip
+int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer_valued, size_t plane_stride = 0); // box_blur.hip (0: planes contiguous)
 int sat_planes_multi(const zg_image *const *srcs, float *const *sats, int count, hipStream_t s); // box_blur.hip
 
 // The recursions along ROWS run as the column kernel on the transposed plane: a row chain needs lanes = rows, i.e. a transpose
