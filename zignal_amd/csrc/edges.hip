@@ -111,67 +111,100 @@ __global__ __launch_bounds__(256) void k_canny_gray(DImg src, float *gray) {
     gray[(size_t)r * src.cols + c] = canny_gray<PIX>(P::load(src.data, (size_t)r * src.stride + (size_t)c));
 }
 
-// blurred plane -> state plane. Tile 64 x 4 outputs; magnitudes are needed one pixel around it, blurred values two.
+// blurred plane -> state plane. Tile 64 x 16 outputs; magnitudes are needed one pixel around it, blurred values two.
+// A thread owns four consecutive rows of one column: their 3 x 3 windows share six rows of three blurred values, and the Sobel sums
+// skip the zero weights and fold the +-1 / +-2 weights into additions (exact products, so the reference's nine-term sums in the
+// reference's order, edges.zig:255-262, up to the sign of a zero); only the magnitude goes back to LDS, plus the ring of magnitudes
+// around the tile (164 positions, one each for the first threads). The round-1 form (64 x 4 tile, every gradient through a clamped
+// nine-tap loop and three LDS planes) took 111 us per 4096^2 frame.
+__device__ inline void sobel_3x3(const float (&p)[3][3], float &gx, float &gy) {
+    gx = ((((-p[0][0] + p[0][2]) - 2.0f * p[1][0]) + 2.0f * p[1][2]) - p[2][0]) + p[2][2];
+    gy = ((((-p[0][0] - 2.0f * p[0][1]) - p[0][2]) + p[2][0]) + 2.0f * p[2][1]) + p[2][2];
+}
 __global__ __launch_bounds__(256) void k_canny_nms(const float *blur, uint8_t *state, int rows, int cols, float low, float high, int tiles_x) {
-    __shared__ float b[8][68];
-    __shared__ float gxs[6][66], gys[6][66], mag[6][66];
+    constexpr int TH = 16;
+    __shared__ float b[TH + 4][68];   // blurred: tile row r, column c at [r + 2][c + 2]
+    __shared__ float mag[TH + 2][68]; // magnitude: at [r + 1][c + 1]
+    __shared__ uint8_t st[TH][64];
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
     if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
     const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
-    const int x0 = tx * 64, y0 = ty * 4;
-    for (int i = threadIdx.x; i < 8 * 68; i += 256) {
-        const int r = i / 68, c = i - r * 68;
-        int gr = y0 - 2 + r, gc = x0 - 2 + c; // .replicate of the 3x3 convolutions (and harmless clamping beyond it)
-        gr = gr < 0 ? 0 : (gr > rows - 1 ? rows - 1 : gr);
-        gc = gc < 0 ? 0 : (gc > cols - 1 ? cols - 1 : gc);
-        b[r][c] = blur[(size_t)gr * cols + gc];
+    const int x0 = tx * 64, y0 = ty * TH;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    { // .replicate of the 3 x 3 convolutions: clamped coordinates; a wave per row, the four columns beyond 64 by its first lanes
+        const int gc = min(max(x0 - 2 + lane, 0), cols - 1), gc2 = min(max(x0 + 62 + lane, 0), cols - 1);
+        for (int rr = w; rr < TH + 4; rr += 4) {
+            const size_t row = (size_t)min(max(y0 - 2 + rr, 0), rows - 1) * cols;
+            b[rr][lane] = blur[row + gc];
+            if (lane < 4) b[rr][64 + lane] = blur[row + gc2];
+        }
     }
     __syncthreads();
-    const float kx[9] = {-1, 0, 1, -2, 0, 2, -1, 0, 1}, ky[9] = {-1, -2, -1, 0, 0, 0, 1, 2, 1};
-    for (int i = threadIdx.x; i < 6 * 66; i += 256) { // gradients of pixel (y0 - 1 + r, x0 - 1 + c)
-        const int r = i / 66, c = i - r * 66;
-        // a pixel outside the image never contributes (NMS skips the border ring), but its window must still be the
-        // clamped one so that in-image neighbours read what the reference computed: recentre on the clamped position
-        int pr = y0 - 1 + r, pc = x0 - 1 + c;
-        pr = pr < 0 ? 0 : (pr > rows - 1 ? rows - 1 : pr);
-        pc = pc < 0 ? 0 : (pc > cols - 1 ? cols - 1 : pc);
-        float ax = 0.0f, ay = 0.0f;
+    float gx[4], gy[4], m[4];
+    {
+        float p[6][3];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) p[j][i] = b[4 * w + 1 + j][lane + 1 + i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float win[3][3] = {{p[k][0], p[k][1], p[k][2]}, {p[k + 1][0], p[k + 1][1], p[k + 1][2]}, {p[k + 2][0], p[k + 2][1], p[k + 2][2]}};
+            sobel_3x3(win, gx[k], gy[k]);
+            const float sx = gx[k] * gx[k], sy = gy[k] * gy[k];
+            m[k] = sqrtf(sx + sy);
+            mag[4 * w + k + 1][lane + 1] = m[k];
+        }
+    }
+    if (threadIdx.x < 2 * 66 + 2 * TH) { // the ring: row -1, row TH (columns -1 .. 64), column -1, column 64 (rows 0 .. TH - 1)
+        const int t = threadIdx.x;
+        int hr, hc;
+        if (t < 66) { hr = -1; hc = t - 1; }
+        else if (t < 132) { hr = TH; hc = t - 67; }
+        else if (t < 132 + TH) { hr = t - 132; hc = -1; }
+        else { hr = t - 132 - TH; hc = 64; }
+        float win[3][3];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                int wr = pr - 1 + j, wc = pc - 1 + k; // window position, replicate-clamped, then into tile coordinates
-                wr = wr < 0 ? 0 : (wr > rows - 1 ? rows - 1 : wr);
-                wc = wc < 0 ? 0 : (wc > cols - 1 ? cols - 1 : wc);
-                const float p = b[wr - (y0 - 2)][wc - (x0 - 2)];
-                const float px = p * kx[j * 3 + k], py = p * ky[j * 3 + k];
-                ax = ax + px;
-                ay = ay + py;
-            }
-        gxs[r][c] = ax;
-        gys[r][c] = ay;
-        const float sx = ax * ax, sy = ay * ay;
-        mag[r][c] = sqrtf(sx + sy);
+            for (int i = 0; i < 3; ++i) win[j][i] = b[hr + 1 + j][hc + 1 + i];
+        float hx, hy;
+        sobel_3x3(win, hx, hy);
+        const float sx = hx * hx, sy = hy * hy;
+        mag[hr + 1][hc + 1] = sqrtf(sx + sy);
     }
     __syncthreads();
-    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-    const int c = x0 + lx, r = y0 + ly;
-    if (c >= cols || r >= rows) return;
-    uint8_t st = 0;
-    if (rows >= 3 && cols >= 3 && r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1) { // edges.zig:710-715
-        const float K = 0.414213562f; // tan(22.5 deg)
-        const float gx = gxs[ly + 1][lx + 1], gy = gys[ly + 1][lx + 1];
-        const float ax = fabsf(gx), ay = fabsf(gy);
-        int dr1, dc1, dr2, dc2;
-        if (ay <= K * ax) { dr1 = 0; dc1 = -1; dr2 = 0; dc2 = 1; }
-        else if (ax <= K * ay) { dr1 = -1; dc1 = 0; dr2 = 1; dc2 = 0; }
-        else if (gx * gy > 0) { dr1 = -1; dc1 = 1; dr2 = 1; dc2 = -1; }
-        else { dr1 = -1; dc1 = -1; dr2 = 1; dc2 = 1; }
-        const float m = mag[ly + 1][lx + 1], n1 = mag[ly + 1 + dr1][lx + 1 + dc1], n2 = mag[ly + 1 + dr2][lx + 1 + dc2];
-        if (m >= n1 && m >= n2) st = m >= high ? 2 : (m >= low ? 1 : 0); // edges.zig:541, :566
+    const int c = x0 + lane;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int lr = 4 * w + k, r = y0 + lr;
+        uint8_t s = 0;
+        if (rows >= 3 && cols >= 3 && r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1) { // edges.zig:710-715
+            const float K = 0.414213562f; // tan(22.5 deg)
+            const float ax = fabsf(gx[k]), ay = fabsf(gy[k]);
+            int dr1, dc1, dr2, dc2;
+            if (ay <= K * ax) { dr1 = 0; dc1 = -1; dr2 = 0; dc2 = 1; }
+            else if (ax <= K * ay) { dr1 = -1; dc1 = 0; dr2 = 1; dc2 = 0; }
+            else if (gx[k] * gy[k] > 0) { dr1 = -1; dc1 = 1; dr2 = 1; dc2 = -1; }
+            else { dr1 = -1; dc1 = -1; dr2 = 1; dc2 = 1; }
+            const float n1 = mag[lr + 1 + dr1][lane + 1 + dc1], n2 = mag[lr + 1 + dr2][lane + 1 + dc2];
+            if (m[k] >= n1 && m[k] >= n2) s = m[k] >= high ? 2 : (m[k] >= low ? 1 : 0); // edges.zig:541, :566
+        }
+        st[lr][lane] = s;
     }
-    state[(size_t)r * cols + c] = st;
+    __syncthreads();
+    { // the tile's state bytes, four columns per thread
+        const int lr = threadIdx.x >> 4, q = (threadIdx.x & 15) * 4, r = y0 + lr;
+        if (r < rows && x0 + q < cols) {
+            uint8_t *o = state + (size_t)r * cols + x0 + q;
+            if ((cols & 3) == 0 && ((uintptr_t)state & 3) == 0) {
+                *(uint32_t *)o = *(const uint32_t *)&st[lr][q];
+            } else {
+                for (int j = 0; j < 4 && x0 + q + j < cols; ++j) o[j] = st[lr][q + j];
+            }
+        }
+    }
 }
 
 // Hysteresis (edges.zig:499-576): a weak candidate becomes an edge iff it is 8-connected, through candidates, to a strong
@@ -406,7 +439,7 @@ static int canny_impl(const zg_image *src, const zg_image *dst, float sigma, flo
         blurred = blur;
     }
     if (rc == ZG_OK) {
-        const int tiles_x = (int)ceil_div(cols, 64), tiles_y = (int)ceil_div(rows, 4);
+        const int tiles_x = (int)ceil_div(cols, 64), tiles_y = (int)ceil_div(rows, 16);
         hipLaunchKernelGGL(k_canny_nms, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, blurred, state, (int)rows, (int)cols, low, high, tiles_x);
         rc = run_hysteresis(state, rows, cols, work, s, "canny");
         if (rc == ZG_OK) rc = launch_emit(state, (int *)work, (const uint8_t *)((int *)work + n), dst, s);
