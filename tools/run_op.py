@@ -40,10 +40,10 @@ elif op in ("blur17_g8", "blur35_g8", "blur11_g8"):
     t = torch.randint(0, 256, (R, R), dtype=torch.uint8, device="cuda")
     s = zg.Image(t); d = zg.Image(torch.empty_like(t))
     f = lambda: s.gaussian_blur({"17": 2.5, "35": 5.5, "11": 1.5}[op[4:6]], out=d)
-elif op in ("shen", "canny"):
+elif op in ("shen", "canny", "sobel"):
     t = torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")
     s = zg.Image(t); d = zg.Image(torch.empty((R, R), dtype=torch.uint8, device="cuda"))
-    f = (lambda: s.shen_castan(out=d)) if op == "shen" else (lambda: s.canny(1.4, 50, 150, out=d))
+    f = {"shen": lambda: s.shen_castan(out=d), "canny": lambda: s.canny(1.4, 50, 150, out=d), "sobel": lambda: s.sobel(out=d)}[op]
 elif op in ("conv3_u8", "conv3_f32"):
     t = torch.rand((R, R, 4), dtype=torch.float32, device="cuda") if op.endswith("f32") else torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")
     s = zg.Image(t); d = zg.Image(torch.empty_like(t)); k3 = np.full((3, 3), 1 / 9, np.float32)

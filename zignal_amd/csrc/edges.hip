@@ -32,42 +32,63 @@ template <int PIX> __device__ inline float sobel_gray(typename Px<PIX>::Vec v) {
     }
 }
 
+// Sobel sums of a 3 x 3 window in the reference's term order (edges.zig:255-262 / image.zig sobel): the zero weights are skipped
+// and the +-1 / +-2 weights folded into additions; the products are exact, so only the sign of a zero can differ.
+__device__ inline void sobel_3x3(const float (&p)[3][3], float &gx, float &gy) {
+    gx = ((((-p[0][0] + p[0][2]) - 2.0f * p[1][0]) + 2.0f * p[1][2]) - p[2][0]) + p[2][2];
+    gy = ((((-p[0][0] - 2.0f * p[0][1]) - p[0][2]) + p[2][0]) + 2.0f * p[2][1]) + p[2][2];
+}
+
+// Tile 64 x 16 outputs, grey values one pixel around it in LDS (a wave per row, .replicate by clamped coordinates); a thread owns
+// four consecutive rows of one column, whose windows share six rows of three values; output bytes leave as dwords through LDS.
+// (Round 1: 64 x 4 tile, nine clamped taps per pixel, byte stores: 67 us per 4096^2 Rgba(u8) frame.)
 template <int PIX>
 __global__ __launch_bounds__(256) void k_sobel(DImg src, DImg dst, int tiles_x) {
     using P = Px<PIX>;
-    __shared__ float g[6][66];
+    constexpr int TH = 16;
+    __shared__ float g[TH + 2][68];
+    __shared__ uint8_t ob[TH][64];
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
     if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
     const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
-    const int x0 = tx * 64, y0 = ty * 4;
-    for (int i = threadIdx.x; i < 6 * 66; i += 256) {
-        const int r = i / 66, c = i - r * 66;
-        int gr = y0 - 1 + r, gc = x0 - 1 + c; // .replicate: clamp
-        gr = gr < 0 ? 0 : (gr > src.rows - 1 ? src.rows - 1 : gr);
-        gc = gc < 0 ? 0 : (gc > src.cols - 1 ? src.cols - 1 : gc);
-        g[r][c] = sobel_gray<PIX>(P::load(src.data, (size_t)gr * src.stride + (size_t)gc));
+    const int x0 = tx * 64, y0 = ty * TH;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {
+        const int gc = min(max(x0 - 1 + lane, 0), src.cols - 1), gc2 = min(max(x0 + 63 + lane, 0), src.cols - 1);
+        for (int rr = w; rr < TH + 2; rr += 4) {
+            const size_t row = (size_t)min(max(y0 - 1 + rr, 0), src.rows - 1) * src.stride;
+            g[rr][lane] = sobel_gray<PIX>(P::load(src.data, row + (size_t)gc));
+            if (lane < 2) g[rr][64 + lane] = sobel_gray<PIX>(P::load(src.data, row + (size_t)gc2));
+        }
     }
     __syncthreads();
-    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-    const int c = x0 + lx, r = y0 + ly;
-    if (c >= dst.cols || r >= dst.rows) return;
-    const float kx[9] = {-1, 0, 1, -2, 0, 2, -1, 0, 1}, ky[9] = {-1, -2, -1, 0, 0, 0, 1, 2, 1};
-    float ax = 0.0f, ay = 0.0f;
+    float p[6][3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < 6; ++j)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float p = g[ly + j][lx + i];
-            const float px = p * kx[j * 3 + i], py = p * ky[j * 3 + i];
-            ax = ax + px;
-            ay = ay + py;
+        for (int i = 0; i < 3; ++i) p[j][i] = g[4 * w + j][lane + i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float win[3][3] = {{p[k][0], p[k][1], p[k][2]}, {p[k + 1][0], p[k + 1][1], p[k + 1][2]}, {p[k + 2][0], p[k + 2][1], p[k + 2][2]}};
+        float ax, ay;
+        sobel_3x3(win, ax, ay);
+        const float sx = ax * ax, sy = ay * ay;
+        const float magnitude = sqrtf(sx + sy);
+        const float scaled = magnitude / 4.0f;
+        const float clamped = fmaxf(0.0f, fminf(255.0f, scaled));
+        ob[4 * w + k][lane] = (uint8_t)(int)truncf(clamped);
+    }
+    __syncthreads();
+    const int lr = threadIdx.x >> 4, q = (threadIdx.x & 15) * 4, r = y0 + lr;
+    if (r < dst.rows && x0 + q < dst.cols) {
+        uint8_t *o = (uint8_t *)dst.data + (size_t)r * dst.stride + x0 + q;
+        if (x0 + q + 4 <= dst.cols && (dst.stride & 3) == 0 && ((uintptr_t)dst.data & 3) == 0) {
+            *(uint32_t *)o = *(const uint32_t *)&ob[lr][q];
+        } else {
+            for (int j = 0; j < 4 && x0 + q + j < dst.cols; ++j) o[j] = ob[lr][q + j];
         }
-    const float sx = ax * ax, sy = ay * ay;
-    const float magnitude = sqrtf(sx + sy);
-    const float scaled = magnitude / 4.0f;
-    const float clamped = fmaxf(0.0f, fminf(255.0f, scaled));
-    ((uint8_t *)dst.data)[(size_t)r * dst.stride + (size_t)c] = (uint8_t)(int)truncf(clamped);
+    }
 }
 
 static int sobel_impl(const zg_image *src, const zg_image *dst, hipStream_t s) {
@@ -77,7 +98,7 @@ static int sobel_impl(const zg_image *src, const zg_image *dst, hipStream_t s) {
                src->rows, src->cols, dst->rows, dst->cols);
     ZG_REQUIRE(dst->pixel == ZG_PIXEL_U8, ZG_ERR_INVALID_ARGUMENT, "sobel: the output is Image(u8)");
     if (src->rows == 0 || src->cols == 0) return ZG_OK;
-    const int tiles_x = (int)ceil_div(src->cols, 64), tiles_y = (int)ceil_div(src->rows, 4);
+    const int tiles_x = (int)ceil_div(src->cols, 64), tiles_y = (int)ceil_div(src->rows, 16);
     return dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
         hipLaunchKernelGGL((k_sobel<PIX>), dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, dimg(src), dimg(dst), tiles_x);
@@ -117,10 +138,6 @@ __global__ __launch_bounds__(256) void k_canny_gray(DImg src, float *gray) {
 // reference's order, edges.zig:255-262, up to the sign of a zero); only the magnitude goes back to LDS, plus the ring of magnitudes
 // around the tile (164 positions, one each for the first threads). The round-1 form (64 x 4 tile, every gradient through a clamped
 // nine-tap loop and three LDS planes) took 111 us per 4096^2 frame.
-__device__ inline void sobel_3x3(const float (&p)[3][3], float &gx, float &gy) {
-    gx = ((((-p[0][0] + p[0][2]) - 2.0f * p[1][0]) + 2.0f * p[1][2]) - p[2][0]) + p[2][2];
-    gy = ((((-p[0][0] - 2.0f * p[0][1]) - p[0][2]) + p[2][0]) + 2.0f * p[2][1]) + p[2][2];
-}
 __global__ __launch_bounds__(256) void k_canny_nms(const float *blur, uint8_t *state, int rows, int cols, float low, float high, int tiles_x) {
     constexpr int TH = 16;
     __shared__ float b[TH + 4][68];   // blurred: tile row r, column c at [r + 2][c + 2]
