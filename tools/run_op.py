@@ -40,6 +40,19 @@ elif op in ("blur17_g8", "blur35_g8", "blur11_g8"):
     t = torch.randint(0, 256, (R, R), dtype=torch.uint8, device="cuda")
     s = zg.Image(t); d = zg.Image(torch.empty_like(t))
     f = lambda: s.gaussian_blur({"17": 2.5, "35": 5.5, "11": 1.5}[op[4:6]], out=d)
+elif op in ("shen_photo", "canny_photo"):  # photo-like frame: smooth colour fields, a few hundred hard-edged shapes, a little sensor noise
+    g = torch.Generator(device="cuda").manual_seed(7)
+    yy, xx = torch.meshgrid(torch.arange(R, device="cuda"), torch.arange(R, device="cuda"), indexing="ij")
+    pic = torch.stack([128 + 90 * torch.sin(xx / 310.0) * torch.cos(yy / 270.0), 128 + 80 * torch.cos(xx / 190.0 + yy / 400.0), 128 + 100 * torch.sin((xx + yy) / 520.0)], -1)
+    for _ in range(300):
+        cx, cy, rad = [int(v) for v in torch.randint(0, R, (3,), generator=g, device="cuda").tolist()]
+        rad = 20 + rad % 180
+        m = ((xx - cx) ** 2 + (yy - cy) ** 2) < rad * rad
+        pic[m] = pic[m] * 0.5 + torch.randint(0, 256, (3,), generator=g, device="cuda").float() * 0.5
+    pic = (pic + 2.0 * torch.randn(pic.shape, generator=g, device="cuda")).clamp(0, 255)
+    t = torch.cat([pic, torch.full((R, R, 1), 255.0, device="cuda")], -1).to(torch.uint8).contiguous()
+    s = zg.Image(t); d = zg.Image(torch.empty((R, R), dtype=torch.uint8, device="cuda"))
+    f = (lambda: s.shen_castan(out=d)) if op == "shen_photo" else (lambda: s.canny(1.4, 50, 150, out=d))
 elif op in ("shen", "canny", "sobel"):
     t = torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")
     s = zg.Image(t); d = zg.Image(torch.empty((R, R), dtype=torch.uint8, device="cuda"))

@@ -228,13 +228,18 @@ __global__ __launch_bounds__(256) void k_canny_nms(const float *blur, uint8_t *s
 // one. The reference grows the set with a BFS queue; the set itself is "the connected components of the candidate mask
 // that contain a strong pixel", which a lock-free union-find labels in a fixed number of kernels (no convergence loop, no
 // host synchronisation, so the detectors stay asynchronous and graph-capturable):
-//   k_cc_tile    a workgroup labels one 64 x 64 tile entirely in LDS (runs from a ballot, unions with LDS atomics, then every
-//                candidate is pointed straight at its tile root) and writes the labels once, as global pixel indices
+//   k_cc_tile    a workgroup labels one 64 x 64 tile entirely in LDS (runs from a ballot, unions with LDS atomics). A component that
+//                does not reach the tile's edge is finished there and then: its pixels are written to the output (strong, or weak with
+//                a strong pixel in the component) and leave the state plane. Only the components on a tile edge stay PENDING: their
+//                pixels keep their state and get a label (the global index of the tile root), their roots a cleared flag.
 //   k_cc_border  the pixels on tile edges are united with their neighbours in the next tile through global memory: 1/32 of
 //                the pixels; roots only ever move to smaller indices (atomicMin), so the structure stays a forest whatever
 //                the interleaving
-//   k_cc_flag    every strong pixel marks its root; the emit kernel turns the weak pixels of marked roots into edges
-// (round 1 united every pixel pair through global memory: 177 - 296 us of the detectors' time on 4096^2 noise.)
+//   k_cc_flag    every pending strong pixel marks its root
+//   k_cc_emit    every pending weak pixel of a marked root becomes an edge
+// The label plane is only touched where components cross tiles, and the two last passes read a byte per pixel.
+// (Round 1 united every pixel pair through global memory: 177 - 296 us of the detectors' time on 4096^2 noise; labelling tiles but
+// still writing a label per pixel and resolving every weak pixel in a separate pass took 149 us on canny's frame.)
 __device__ inline int cc_find(int *label, int x) {
     int p = label[x];
     while (p != x) { // path halving (plain stores: another lane can only have written a smaller ancestor)
@@ -260,9 +265,10 @@ __device__ inline void cc_unite(int *label, int a, int b) {
 // structure already implies are skipped: with S a candidate, SW and SE hang off S's run, and S itself is implied when W and
 // SW are both candidates (the pixel to the left makes the same link); without S, SW is implied by W and SE by E.
 constexpr int CC_T = 64; // tile edge
-__global__ __launch_bounds__(256) void k_cc_tile(const uint8_t *state, int *label, int rows, int cols) {
+__global__ __launch_bounds__(256) void k_cc_tile(uint8_t *state, int *label, uint8_t *flag, DImg dst, int rows, int cols) {
     __shared__ int lab[CC_T * CC_T];
     __shared__ uint8_t st[CC_T + 1][CC_T]; // one spare row of zeros below
+    __shared__ uint8_t out[CC_T][CC_T];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int x0 = blockIdx.x * CC_T, y0 = blockIdx.y * CC_T;
     const bool whole = x0 + CC_T <= cols && y0 + CC_T <= rows && (((uintptr_t)state | (uintptr_t)cols) & 3) == 0;
@@ -307,22 +313,73 @@ __global__ __launch_bounds__(256) void k_cc_tile(const uint8_t *state, int *labe
         }
     }
     __syncthreads();
+    // every candidate straight under its root ...
+    int root[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) root[k] = ((mine >> k) & 1) ? cc_find(lab, (w * 16 + k) * CC_T + lane) : 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if ((mine >> k) & 1) lab[(w * 16 + k) * CC_T + lane] = root[k];
+    __syncthreads();
+    // ... then what the component holds goes into the top bits of the root's entry (entries are < 4096): STRONG, EDGE (of the tile)
+    constexpr int STRONG = 1 << 16, EDGE = 1 << 17;
+    if (mine) {
+        for (int k = 0; k < 16; ++k) {
+            if (!((mine >> k) & 1)) continue;
+            const int r = w * 16 + k;
+            int a = st[r][lane] == 2 ? STRONG : 0;
+            if (r == 0 || r == CC_T - 1 || lane == 0 || lane == CC_T - 1) a |= EDGE;
+            if (a) atomicOr(&lab[root[k]], a);
+        }
+    }
+    __syncthreads();
     const bool col_ok = x0 + lane < cols;
 #pragma unroll 4
     for (int k = 0; k < 16; ++k) {
         const int r = w * 16 + k;
-        if (y0 + r >= rows) break; // wave-uniform
-        int v = -1;
+        uint8_t o = 0, ns = 0;
         if ((mine >> k) & 1) {
-            const int root = cc_find(lab, r * CC_T + lane);
-            v = (y0 + (root >> 6)) * cols + x0 + (root & 63);
+            const int a = lab[root[k]];
+            const uint8_t s = st[r][lane];
+            if (a & EDGE) { // pending: keeps its state, gets a label; a strong pixel is an edge whatever happens
+                ns = s;
+                o = s == 2 ? 255 : 0;
+                if (col_ok && y0 + r < rows) {
+                    const size_t gi = (size_t)(y0 + r) * cols + x0 + lane;
+                    const int groot = (y0 + (root[k] >> 6)) * cols + x0 + (root[k] & 63);
+                    label[gi] = groot;
+                    if ((int)gi == groot) flag[gi] = 0;
+                }
+            } else {
+                o = (s == 2 || (a & STRONG)) ? 255 : 0;
+            }
         }
-        if (col_ok) label[(size_t)(y0 + r) * cols + x0 + lane] = v;
+        st[r][lane] = ns; // my own pixel: nobody else reads it any more
+        out[r][lane] = o;
+    }
+    __syncthreads();
+    const bool vec = whole && (dst.stride & 3) == 0 && ((uintptr_t)dst.data & 3) == 0;
+    if (vec) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = k * 16 + (t >> 4), c = (t & 15) * 4;
+            *(uint32_t *)(state + (size_t)(y0 + r) * cols + x0 + c) = *(const uint32_t *)&st[r][c];
+            *(uint32_t *)((uint8_t *)dst.data + (size_t)(y0 + r) * dst.stride + x0 + c) = *(const uint32_t *)&out[r][c];
+        }
+    } else {
+        for (int i = t; i < CC_T * CC_T; i += 256) {
+            const int r = i >> 6, c = i & 63;
+            if (y0 + r < rows && x0 + c < cols) {
+                state[(size_t)(y0 + r) * cols + x0 + c] = st[r][c];
+                ((uint8_t *)dst.data)[(size_t)(y0 + r) * dst.stride + x0 + c] = out[r][c];
+            }
+        }
     }
 }
 // blockIdx.y < nvb: the right-hand column of a tile column (pixel with E / NE / SE in the next tile); otherwise the bottom row
 // of a tile row (SW / S / SE below). The skip rules above hold across tiles for the same reasons: the link they rely on is
-// either inside a tile or another border link.
+// either inside a tile or another border link. A candidate on a tile edge is pending by construction, so `state` still has it.
 __global__ __launch_bounds__(256) void k_cc_border(const uint8_t *state, int *label, int rows, int cols, int nvb) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     int b = blockIdx.y;
@@ -350,24 +407,43 @@ __global__ __launch_bounds__(256) void k_cc_border(const uint8_t *state, int *la
         }
     }
 }
-__global__ __launch_bounds__(256) void k_cc_flag(const uint8_t *state, int *label, uint8_t *flag, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n && state[i] == 2) flag[cc_find(label, (int)i)] = 1;
+// The pending pixels of four adjacent bytes of the state plane: strong ones mark their root (EMIT false), weak ones of a marked
+// root become edges (EMIT true). Most dwords are zero.
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_cc_pending(const uint8_t *state, int *label, uint8_t *flag, DImg dst, size_t n, int cols) {
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    uint32_t s4 = 0;
+    if (i0 + 4 <= n && ((uintptr_t)state & 3) == 0) s4 = *(const uint32_t *)(state + i0);
+    else for (size_t k = i0; k < n; ++k) s4 |= (uint32_t)state[k] << (8 * (k - i0));
+    if (s4 == 0) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t s = (s4 >> (8 * j)) & 0xffu;
+        if (s != (EMIT ? 1u : 2u)) continue;
+        const size_t i = i0 + j;
+        const int root = cc_find(label, (int)i);
+        if (!EMIT) flag[root] = 1;
+        else if (flag[root]) {
+            const size_t r = i / (size_t)cols, c = i - r * (size_t)cols;
+            ((uint8_t *)dst.data)[r * dst.stride + c] = 255;
+        }
+    }
 }
-// Labels the candidates of `state` and marks the roots of the components that hold a strong pixel; k_canny_emit then
-// resolves each weak pixel through its root. `work` holds an int label and a flag byte per pixel.
-static int run_hysteresis(uint8_t *state, uint32_t rows, uint32_t cols, char *work, hipStream_t s, const char *who) {
+// Writes the edge map of `state` (0 none / 1 weak / 2 strong) into dst; `state` is consumed. `work` holds an int label and a
+// flag byte per pixel (touched only where components cross tiles).
+static int run_hysteresis(uint8_t *state, uint32_t rows, uint32_t cols, char *work, const zg_image *dst, hipStream_t s, const char *who) {
     const size_t n = (size_t)rows * cols;
     if (n > 0x7fffffffu) { set_error("%s: hysteresis labels are 32-bit (rows * cols must stay below 2^31)", who); return ZG_ERR_UNSUPPORTED; }
     int *label = (int *)work;
     uint8_t *flag = (uint8_t *)(label + n);
-    const unsigned nb = (unsigned)((n + 255) / 256);
+    const unsigned nb = (unsigned)((n + 1023) / 1024);
     const unsigned nvb = (cols - 1) / CC_T, nhb = (rows - 1) / CC_T;
-    if (hipMemsetAsync(flag, 0, n, s) != hipSuccess) { set_error("%s: hysteresis memset failed", who); return ZG_ERR_HIP; }
-    hipLaunchKernelGGL(k_cc_tile, dim3(ceil_div(cols, (unsigned)CC_T), ceil_div(rows, (unsigned)CC_T)), dim3(256), 0, s, (const uint8_t *)state, label, (int)rows, (int)cols);
+    hipLaunchKernelGGL(k_cc_tile, dim3(ceil_div(cols, (unsigned)CC_T), ceil_div(rows, (unsigned)CC_T)), dim3(256), 0, s, state, label, flag, dimg(dst), (int)rows, (int)cols);
     if (nvb + nhb)
         hipLaunchKernelGGL(k_cc_border, dim3(ceil_div(rows > cols ? rows : cols, 256u), nvb + nhb), dim3(256), 0, s, (const uint8_t *)state, label, (int)rows, (int)cols, (int)nvb);
-    hipLaunchKernelGGL(k_cc_flag, dim3(nb), dim3(256), 0, s, (const uint8_t *)state, label, flag, n);
+    hipLaunchKernelGGL(k_cc_pending<false>, dim3(nb), dim3(256), 0, s, (const uint8_t *)state, label, flag, dimg(dst), n, (int)cols);
+    hipLaunchKernelGGL(k_cc_pending<true>, dim3(nb), dim3(256), 0, s, (const uint8_t *)state, label, flag, dimg(dst), n, (int)cols);
     if (hipGetLastError() != hipSuccess) { set_error("%s: hysteresis launch failed", who); return ZG_ERR_HIP; }
     return ZG_OK;
 }
@@ -458,8 +534,7 @@ static int canny_impl(const zg_image *src, const zg_image *dst, float sigma, flo
     if (rc == ZG_OK) {
         const int tiles_x = (int)ceil_div(cols, 64), tiles_y = (int)ceil_div(rows, 16);
         hipLaunchKernelGGL(k_canny_nms, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, blurred, state, (int)rows, (int)cols, low, high, tiles_x);
-        rc = run_hysteresis(state, rows, cols, work, s, "canny");
-        if (rc == ZG_OK) rc = launch_emit(state, (int *)work, (const uint8_t *)((int *)work + n), dst, s);
+        rc = run_hysteresis(state, rows, cols, work, dst, s, "canny");
     }
     scratch_free(scratch, s);
     return rc;
@@ -947,8 +1022,7 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
         hipLaunchKernelGGL(k_sc_classify4, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, final_cand, (const float *)grad, (const float *)thr, state, n, hysteresis ? 1 : 0);
         if (hipGetLastError() != hipSuccess) rc = ZG_ERR_HIP;
     }
-    if (rc == ZG_OK && hysteresis) rc = run_hysteresis(state, rows, cols, work, s, "shenCastan");
-    if (rc == ZG_OK) rc = launch_emit(state, hysteresis ? (int *)work : nullptr, (const uint8_t *)((int *)work + n), dst, s);
+    if (rc == ZG_OK) rc = hysteresis ? run_hysteresis(state, rows, cols, work, dst, s, "shenCastan") : launch_emit(state, nullptr, nullptr, dst, s);
     scratch_free(scratch, s);
     return rc;
 }
