@@ -253,53 +253,76 @@ __global__ __launch_bounds__(256) void k_sat_rows_exact(DImg src, float *sat) { 
 // carry[(r * nstrips + s) * C + ch] = sum of row r, channel ch, over columns < 16 s, as an exact f32. One workgroup per row,
 // every channel at once (the source is read once): 4 pixels per thread and step, integer block scan.
 template <int PIX>
-__device__ __forceinline__ void strip_carries_body(const DImg &src, float *carries, int nstrips, uint32_t (*wsum)[Px<PIX>::C]) {
+__device__ __forceinline__ void strip_carries_body(const DImg &src, float *carries, int nstrips, uint32_t (*wsum)[4][Px<PIX>::C]) {
     using P = Px<PIX>;
+    using Elem = typename P::Elem;
     constexpr int C = P::C;
-    const int r = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int r = blockIdx.x, t = threadIdx.x, w = t >> 6;
+    // four adjacent pixels in one load when they are contiguous and aligned (always, for images this library allocated)
+    bool vec = false;
+    if constexpr (PIX == ZG_PIXEL_U8) vec = (src.stride & 3) == 0 && ((uintptr_t)src.data & 3) == 0;
+    if constexpr (PIX == ZG_PIXEL_RGBA_U8 || PIX == ZG_PIXEL_F32) vec = ((size_t)src.stride * sizeof(Elem) * C) % 16 == 0 && ((uintptr_t)src.data & 15) == 0;
+    const Elem *row = (const Elem *)src.data + (size_t)r * src.stride * C;
     uint32_t carry[C];
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) carry[ch] = 0;
-    for (int c0 = 0; c0 < src.cols; c0 += 1024) {
+    for (int c0 = 0, it = 0; c0 < src.cols; c0 += 1024, ++it) {
         const int c = c0 + 4 * t;
-        uint32_t p[4][C];
+        uint32_t x[C]; // the sum of my four pixels, then its inclusive scan over the wave
+        if (vec && c0 + 1024 <= src.cols) { // workgroup-uniform
+            if constexpr (PIX == ZG_PIXEL_U8) {
+                const uint32_t v = *(const uint32_t *)(row + c);
+                x[0] = (v & 0xffu) + ((v >> 8) & 0xffu) + ((v >> 16) & 0xffu) + (v >> 24);
+            } else if constexpr (PIX == ZG_PIXEL_RGBA_U8) {
+                const uint4 v = *(const uint4 *)(row + (size_t)c * 4);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const typename P::Vec v = P::load(src.data, (size_t)r * src.stride + (size_t)min(c + k, src.cols - 1)); // clamped, unpredicated
-#pragma unroll
-            for (int ch = 0; ch < C; ++ch) p[k][ch] = c + k < src.cols ? (uint32_t)v[ch] : 0u; // integer-valued elements (u8, or f32 holding 0..255)
-        }
-        uint32_t x[C];
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-            p[1][ch] += p[0][ch]; p[2][ch] += p[1][ch]; p[3][ch] += p[2][ch];
-            x[ch] = p[3][ch];
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = (uint32_t)__shfl_up((int)x[ch], d);
-                if (lane >= d) x[ch] += y;
+                for (int ch = 0; ch < C; ++ch)
+                    x[ch] = ((v.x >> (8 * ch)) & 0xffu) + ((v.y >> (8 * ch)) & 0xffu) + ((v.z >> (8 * ch)) & 0xffu) + ((v.w >> (8 * ch)) & 0xffu);
+            } else if constexpr (PIX == ZG_PIXEL_F32) {
+                const float4 v = *(const float4 *)(row + c);
+                x[0] = (uint32_t)v.x + (uint32_t)v.y + (uint32_t)v.z + (uint32_t)v.w; // integer-valued by contract
             }
-            if (lane == 63) wsum[w][ch] = x[ch];
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) x[ch] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const typename P::Vec v = P::load(src.data, (size_t)r * src.stride + (size_t)min(c + k, src.cols - 1)); // clamped, unpredicated
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) x[ch] += c + k < src.cols ? (uint32_t)v[ch] : 0u; // integer-valued elements (u8, or f32 holding 0..255)
+            }
         }
-        __syncthreads();
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) { // inclusive scan over 64 lanes: four steps inside the 16-lane rows, then the row totals broadcast
+            uint32_t y = x[ch];
+            y += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0x111, 0xf, 0xf, true);  // row_shr:1
+            y += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0x112, 0xf, 0xf, true);  // row_shr:2
+            y += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0x114, 0xf, 0xf, true);  // row_shr:4
+            y += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0x118, 0xf, 0xf, true);  // row_shr:8
+            y += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1, 3
+            y += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2, 3
+            x[ch] = y;
+            if ((t & 63) == 63) wsum[it & 1][w][ch] = y;
+        }
+        __syncthreads(); // one barrier per step: the totals alternate between two buffers
         const int next = c + 4; // the prefix through column c + 3 is the carry of the strip that starts at column c + 4
         const bool boundary = (next & 15) == 0 && next < src.cols;
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) {
+            const uint32_t w0 = wsum[it & 1][0][ch], w1 = wsum[it & 1][1][ch], w2 = wsum[it & 1][2][ch], w3 = wsum[it & 1][3][ch];
             uint32_t base = carry[ch] + x[ch];
-            if (w > 0) base += wsum[0][ch];
-            if (w > 1) base += wsum[1][ch];
-            if (w > 2) base += wsum[2][ch];
+            if (w > 0) base += w0;
+            if (w > 1) base += w1;
+            if (w > 2) base += w2;
             if (boundary) carries[((size_t)r * nstrips + (next >> 4)) * C + ch] = (float)base; // < 2^24: exact
-            carry[ch] += wsum[0][ch] + wsum[1][ch] + wsum[2][ch] + wsum[3][ch];
+            carry[ch] += w0 + w1 + w2 + w3;
         }
         if (c0 == 0 && t < C) carries[(size_t)r * nstrips * C + t] = 0.0f; // strip 0
-        __syncthreads();
     }
 }
 template <int PIX>
 __global__ __launch_bounds__(256) void k_strip_carries(DImg src, float *carries, int nstrips) {
-    __shared__ uint32_t wsum[4][Px<PIX>::C];
+    __shared__ uint32_t wsum[2][4][Px<PIX>::C];
     strip_carries_body<PIX>(src, carries, nstrips, wsum);
 }
 
@@ -532,7 +555,7 @@ struct SatPlanes {
     int f32[3]; // element type of the plane: f32 (holding integers 0..255) or u8
 };
 __global__ __launch_bounds__(256) void k_strip_carries_planes(SatPlanes pl, float *carries, int nstrips) {
-    __shared__ uint32_t wsum[4][1];
+    __shared__ uint32_t wsum[2][4][1];
     const int p = blockIdx.y;
     float *table = carries + (size_t)p * pl.src[0].rows * nstrips;
     if (pl.f32[p]) strip_carries_body<ZG_PIXEL_F32>(pl.src[p], table, nstrips, wsum);
