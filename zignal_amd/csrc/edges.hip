@@ -886,18 +886,36 @@ __global__ __launch_bounds__(256) void k_sc_gradient(const uint8_t *cand, const 
     for (int k = 0; k < 16; ++k) total += lh[k][threadIdx.x];
     if (total) atomicAdd(&hist[threadIdx.x], total);
 }
-// thr[0] = t_high, thr[1] = t_low (edges.zig:160-166); one workgroup
-__global__ void k_sc_thresholds(const unsigned int *hist, float *thr, float high_ratio, float low_rel) {
-    if (threadIdx.x != 0) return;
-    unsigned long long total = 0;
-    for (int i = 0; i < 256; ++i) total += hist[i];
+// thr[0] = t_high, thr[1] = t_low (edges.zig:160-166): the reference walks the histogram until the running count reaches
+// floor(total * high_ratio); the number of steps it takes is the number of bins whose EXCLUSIVE prefix is below that target.
+// One workgroup of 256 threads, a bin each (a single thread walking 256 global loads took 12 us).
+__global__ __launch_bounds__(256) void k_sc_thresholds(const unsigned int *hist, float *thr, float high_ratio, float low_rel) {
+    __shared__ unsigned int wtot[4], below[4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const unsigned int h = hist[t];
+    unsigned int y = h; // inclusive scan over the wave (counts sum to the pixel count, below 2^31)
+    y += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)y, 0x111, 0xf, 0xf, true);
+    y += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)y, 0x112, 0xf, 0xf, true);
+    y += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)y, 0x114, 0xf, 0xf, true);
+    y += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)y, 0x118, 0xf, 0xf, true);
+    y += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)y, 0x142, 0xa, 0xf, false);
+    y += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)y, 0x143, 0xc, 0xf, false);
+    if (lane == 63) wtot[w] = y;
+    __syncthreads();
+    unsigned int before = 0;
+    for (int k = 0; k < w; ++k) before += wtot[k];
+    const unsigned long long total = (unsigned long long)wtot[0] + wtot[1] + wtot[2] + wtot[3];
     const unsigned long long target = (unsigned long long)floorf((float)total * high_ratio);
-    unsigned long long cum = 0;
-    int idx = 0;
-    while (idx < 256 && cum < target) { cum += hist[idx]; idx += 1; }
-    const float t_high = (float)min(idx, 255);
-    thr[0] = t_high;
-    thr[1] = low_rel * t_high;
+    const unsigned long long excl = (unsigned long long)before + (y - h);
+    const unsigned long long m = __ballot(excl < target);
+    if (lane == 0) below[w] = (unsigned int)__popcll(m);
+    __syncthreads();
+    if (t == 0) {
+        const int idx = (int)(below[0] + below[1] + below[2] + below[3]);
+        const float t_high = (float)min(idx, 255);
+        thr[0] = t_high;
+        thr[1] = low_rel * t_high;
+    }
 }
 // NMS on central differences of the smoothed plane (edges.zig:582-661)
 __global__ __launch_bounds__(256) void k_sc_nms(const float *sm, const float *grad, const uint8_t *cand, uint8_t *out, int rows, int cols) {
@@ -1013,7 +1031,7 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
         else
             hipLaunchKernelGGL(k_sc_gradient<false>, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, s, (const uint8_t *)cand, (const float *)sat_g, (const float *)sat_m, (const float *)sat_gm, grad, hist,
                                (int)rows, (int)cols, (int)(window_size / 2));
-        hipLaunchKernelGGL(k_sc_thresholds, dim3(1), dim3(64), 0, s, (const unsigned int *)hist, thr, high_ratio, low_rel);
+        hipLaunchKernelGGL(k_sc_thresholds, dim3(1), dim3(256), 0, s, (const unsigned int *)hist, thr, high_ratio, low_rel);
         const uint8_t *final_cand = cand;
         if (use_nms) {
             hipLaunchKernelGGL(k_sc_nms, g64, dim3(256), 0, s, (const float *)sm, (const float *)grad, (const uint8_t *)cand, nms, (int)rows, (int)cols);
