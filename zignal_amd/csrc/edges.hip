@@ -132,6 +132,38 @@ __global__ __launch_bounds__(256) void k_canny_gray(DImg src, float *gray) {
     gray[(size_t)r * src.cols + c] = canny_gray<PIX>(P::load(src.data, (size_t)r * src.stride + (size_t)c));
 }
 
+// four pixels per lane: one 16-byte load of Rgba(u8) (when the rows are 16-byte aligned), one float4 store
+template <int PIX>
+__global__ __launch_bounds__(256) void k_canny_gray4(DImg src, float *gray, int wide) { // cols % 4 == 0, gray 16-byte aligned
+    using P = Px<PIX>;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4, r = grid_row();
+    if (c >= src.cols || r >= src.rows) return;
+    typename P::Vec v[4];
+    if constexpr (PIX == ZG_PIXEL_RGBA_U8) {
+        if (wide) {
+            const uint4 q = *(const uint4 *)((const uint8_t *)src.data + ((size_t)r * src.stride + (size_t)c) * 4);
+            v[0] = __builtin_bit_cast(typename P::Vec, q.x); v[1] = __builtin_bit_cast(typename P::Vec, q.y);
+            v[2] = __builtin_bit_cast(typename P::Vec, q.z); v[3] = __builtin_bit_cast(typename P::Vec, q.w);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = P::load(src.data, (size_t)r * src.stride + (size_t)(c + k));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = P::load(src.data, (size_t)r * src.stride + (size_t)(c + k));
+    }
+    *(float4 *)(gray + (size_t)r * src.cols + c) = make_float4(canny_gray<PIX>(v[0]), canny_gray<PIX>(v[1]), canny_gray<PIX>(v[2]), canny_gray<PIX>(v[3]));
+}
+template <int PIX>
+static void launch_canny_gray(const zg_image *src, float *gray, hipStream_t s) {
+    if (src->cols % 4 == 0 && ((uintptr_t)gray & 15) == 0) {
+        const int wide = ((size_t)src->stride * 4) % 16 == 0 && ((uintptr_t)src->data & 15) == 0;
+        hipLaunchKernelGGL((k_canny_gray4<PIX>), row_grid(ceil_div(src->cols, 1024), src->rows), dim3(256), 0, s, dimg(src), gray, wide);
+    } else {
+        hipLaunchKernelGGL((k_canny_gray<PIX>), row_grid(ceil_div(src->cols, 256), src->rows), dim3(256), 0, s, dimg(src), gray);
+    }
+}
+
 // blurred plane -> state plane. Tile 64 x 16 outputs; magnitudes are needed one pixel around it, blurred values two.
 // A thread owns four consecutive rows of one column: their 3 x 3 windows share six rows of three blurred values, and the Sobel sums
 // skip the zero weights and fold the +-1 / +-2 weights into additions (exact products, so the reference's nine-term sums in the
@@ -511,7 +543,7 @@ static int canny_impl(const zg_image *src, const zg_image *dst, float sigma, flo
 
     rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
-        hipLaunchKernelGGL((k_canny_gray<PIX>), row_grid(ceil_div(cols, 256), rows), dim3(256), 0, s, dimg(src), gray);
+        launch_canny_gray<PIX>(src, gray, s);
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     });
@@ -994,7 +1026,7 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
 
     rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
-        hipLaunchKernelGGL((k_canny_gray<PIX>), row_grid(ceil_div(cols, 256), rows), dim3(256), 0, s, dimg(src), gray);
+        launch_canny_gray<PIX>(src, gray, s);
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     });
