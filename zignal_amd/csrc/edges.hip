@@ -808,6 +808,7 @@ __global__ __launch_bounds__(256) void k_sc_bli4(const float *gray, const float 
     }
 }
 
+constexpr int SC_HIST_COPIES = 64;
 // adaptive gradient at the candidates (edges.zig:462-496) + the histogram of its rounded values (:139-150)
 // BUF: the planes are below 4 GiB, so a corner read is a buffer load (scalar row offset + per-lane column offset: no vector
 // address arithmetic at all; with 64-bit pointers a third of the kernel's instructions computed addresses).
@@ -855,7 +856,8 @@ __global__ __launch_bounds__(256) void k_sc_gradient(const uint8_t *cand, const 
                 for (int p = 0; p < 3; ++p) {
                     if constexpr (BUF) {
                         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)planes[p], (short)0, (int)plane_bytes, 0x00020000);
-                        const int sb = (int)(uint32_t)(bot * 4), stp = (int)(uint32_t)(top * 4);
+                        // readfirstlane: the row offsets are wave-uniform, and saying so spares a waterfall loop around every load
+                        const int sb = __builtin_amdgcn_readfirstlane((int)(uint32_t)(bot * 4)), stp = __builtin_amdgcn_readfirstlane((int)(uint32_t)(top * 4));
                         const uint32_t t2 = r1 > 0 ? oc2 : OOR, tl = r1 > 0 ? ocl_z : OOR;
                         g.v[u][p * 4 + 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)oc2, sb, 0));
                         g.v[u][p * 4 + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)ocl_z, sb, 0));
@@ -916,7 +918,9 @@ __global__ __launch_bounds__(256) void k_sc_gradient(const uint8_t *cand, const 
     unsigned int total = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) total += lh[k][threadIdx.x];
-    if (total) atomicAdd(&hist[threadIdx.x], total);
+    // SC_HIST_COPIES copies of the frame histogram, picked by workgroup: 4096 workgroups adding into one set of 256 counters queued
+    // up at the L2 atomic units (about half of this kernel's time on a 4096^2 frame); k_sc_thresholds sums the copies
+    if (total) atomicAdd(&hist[((blockIdx.y * gridDim.x + blockIdx.x) % SC_HIST_COPIES) * 256 + threadIdx.x], total);
 }
 // thr[0] = t_high, thr[1] = t_low (edges.zig:160-166): the reference walks the histogram until the running count reaches
 // floor(total * high_ratio); the number of steps it takes is the number of bins whose EXCLUSIVE prefix is below that target.
@@ -924,7 +928,9 @@ __global__ __launch_bounds__(256) void k_sc_gradient(const uint8_t *cand, const 
 __global__ __launch_bounds__(256) void k_sc_thresholds(const unsigned int *hist, float *thr, float high_ratio, float low_rel) {
     __shared__ unsigned int wtot[4], below[4];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const unsigned int h = hist[t];
+    unsigned int h = 0;
+#pragma unroll 8
+    for (int k = 0; k < SC_HIST_COPIES; ++k) h += hist[k * 256 + t];
     unsigned int y = h; // inclusive scan over the wave (counts sum to the pixel count, below 2^31)
     y += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)y, 0x111, 0xf, 0xf, true);
     y += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)y, 0x112, 0xf, 0xf, true);
@@ -1017,12 +1023,13 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
     // histogram (256) | thresholds (2) | hysteresis work
     char *scratch = nullptr;
     const size_t f32_bytes = 7 * nf * sizeof(float), u8_off = f32_bytes, small_off = (u8_off + 4 * nf + 255) / 256 * 256;
-    if ((rc = scratch_alloc((void **)&scratch, small_off + 2048 + hysteresis_work_bytes(rows, cols), s))) return rc;
+    constexpr size_t small_bytes = SC_HIST_COPIES * 256 * sizeof(unsigned int) + 256; // histogram copies | thresholds
+    if ((rc = scratch_alloc((void **)&scratch, small_off + small_bytes + hysteresis_work_bytes(rows, cols), s))) return rc;
     float *gray = (float *)scratch, *sm = gray + nf, *temp = sm + nf, *grad = temp + nf, *sat_g = grad + nf, *sat_m = sat_g + nf, *sat_gm = sat_m + nf;
     uint8_t *bli = (uint8_t *)(scratch + u8_off), *cand = bli + nf, *nms = cand + nf, *state = nms + nf;
     unsigned int *hist = (unsigned int *)(scratch + small_off);
-    float *thr = (float *)(hist + 256);
-    char *work = scratch + small_off + 2048;
+    float *thr = (float *)(hist + SC_HIST_COPIES * 256);
+    char *work = scratch + small_off + small_bytes;
 
     rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
@@ -1056,7 +1063,7 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
         rc = sat_planes_multi(srcs, sats, 3, s);
     }
     if (rc == ZG_OK) {
-        if (hipMemsetAsync(hist, 0, 256 * sizeof(unsigned int), s) != hipSuccess) rc = ZG_ERR_HIP;
+        if (hipMemsetAsync(hist, 0, SC_HIST_COPIES * 256 * sizeof(unsigned int), s) != hipSuccess) rc = ZG_ERR_HIP;
         if (n < (1u << 30))
             hipLaunchKernelGGL(k_sc_gradient<true>, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, s, (const uint8_t *)cand, (const float *)sat_g, (const float *)sat_m, (const float *)sat_gm, grad, hist,
                                (int)rows, (int)cols, (int)(window_size / 2));
