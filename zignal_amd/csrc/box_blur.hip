@@ -6,13 +6,19 @@
 // for bit; the window and its area are clipped at the borders and the mean goes through meta.clamp for u8.
 // All SAT planes are complete before any output is written, so src may alias dst as in the reference.
 //
+// f32 sources (the general case):
 //   k_sat_rows   one wave per (64 rows, channel): 64x64 tiles staged through LDS (coalesced, loads batched), each lane
 //                scans its row of the tile sequentially and carries the running sum to the next tile.
 //   k_sat_cols   one thread per (column, channel): sequential accumulation down the rows, coalesced across lanes,
-//                16 rows prefetched ahead of the chain.
+//                128 rows prefetched ahead of the chain.
 // The two scans are sequential f32 chains by contract (the reference's rounding order), so their parallelism is capped
 // at rows x channels and columns x channels chains; they are latency-bound, not bandwidth-bound.
-//   k_box_mean   one thread per pixel: four SAT taps, divide by the clipped area, clamp.
+// Integer-valued sources (every u8 pixel type; the detectors' planes) have exact row sums in any order:
+//   k_strip_carries  the sum left of every 16-column strip of every row (a block scan per row), 1/16 of a plane
+//   k_sat_chain      reads the source once, rebuilds the row prefixes from the carries, runs the column chain and writes the SAT
+//                    once: a chain wave alone on its SIMD, eight loader waves, four storer waves per 64 columns of one channel
+// then, for both:
+//   k_box_mean   one thread per pixel: four SAT taps (buffer loads), divide by the clipped area, clamp.
 #include "zg_common.h"
 
 #include <cstdlib>
