@@ -53,6 +53,9 @@ elif op in ("shen_photo", "canny_photo"):  # photo-like frame: smooth colour fie
     t = torch.cat([pic, torch.full((R, R, 1), 255.0, device="cuda")], -1).to(torch.uint8).contiguous()
     s = zg.Image(t); d = zg.Image(torch.empty((R, R), dtype=torch.uint8, device="cuda"))
     f = (lambda: s.shen_castan(out=d)) if op == "shen_photo" else (lambda: s.canny(1.4, 50, 150, out=d))
+elif op == "pyramid":  # ImagePyramid.build(source, 8, 1.2, 1.6) on a grey frame (ORB's default)
+    src = zg.Image(torch.randint(0, 256, (R, R), dtype=torch.uint8, device="cuda"))
+    f = lambda: zg.ImagePyramid.build_default(src)
 elif op in ("shen", "canny", "sobel"):
     t = torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")
     s = zg.Image(t); d = zg.Image(torch.empty((R, R), dtype=torch.uint8, device="cuda"))

@@ -78,36 +78,47 @@ template <int SP, int NK, int RPT> struct StageB {
     }
 };
 
-// The u16 pair (byte S, byte S + 1) of a 48-byte window held as 12 dwords; S is a compile-time constant after unrolling.
-template <int S> __device__ __forceinline__ u16x2 byte_pair(const uint32_t (&q)[12]) {
+// Arithmetic on ROW PAIRS: the u16 pair (byte S of tile row r, byte S of tile row r + 1) of two 48-byte windows held as 12 dwords
+// each (S is a compile-time constant after unrolling). A position is unpacked once (one v_perm) and every tap that reaches it reuses the
+// register — tap i of output byte b reads position b + SP * (i - H), whatever SP is — so the row pass is one v_pk_mad_u16 per tap and
+// byte for two rows; and the temps come out as (row 2q, row 2q + 1) pairs, which is what v_dot2_u32_u16 wants in the column pass: two
+// taps per instruction. (Pairs of adjacent bytes of one row needed a v_perm per tap, and the column pass one v_mad_u32_u16 per tap:
+// ten instructions per byte against six and a half.)
+template <int S> __device__ __forceinline__ u16x2 row_pair(const uint32_t (&q0)[12], const uint32_t (&q1)[12]) {
     constexpr int d = S >> 2, o = S & 3;
-    if constexpr (o == 0) return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, q[d], 0x0c010c00u));
-    else if constexpr (o == 1) return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, q[d], 0x0c020c01u));
-    else if constexpr (o == 2) return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, q[d], 0x0c030c02u));
-    else return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(q[d + 1], q[d], 0x0c040c03u));
+    constexpr uint32_t sel = 0x0c000c00u | ((4u + o) << 16) | (uint32_t)o; // byte o of q0[d] -> low half, byte o of q1[d] -> high half
+    return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(q1[d], q0[d], sel));
 }
-
-template <int SP, int NK, int T, int I> struct RowTaps { // unrolled over taps with compile-time byte offsets
-    __device__ static __forceinline__ u16x2 run(const uint32_t (&q)[12], const TapsU8<NK> &kx, u16x2 acc) {
+template <int SP, int NK, int S0, int N, int I = 0> struct UnpackRows { // P[I] = position S0 + I, I < N
+    __device__ static __forceinline__ void run(const uint32_t (&q0)[12], const uint32_t (&q1)[12], u16x2 (&P)[N]) {
+        if constexpr (I < N) {
+            P[I] = row_pair<S0 + I>(q0, q1);
+            UnpackRows<SP, NK, S0, N, I + 1>::run(q0, q1, P);
+        }
+    }
+};
+template <int SP, int NK, int N, int T, int I> struct RowTaps2 { // unrolled over taps: register index is a compile-time constant
+    __device__ static __forceinline__ u16x2 run(const u16x2 (&P)[N], const TapsU8<NK> &kx, u16x2 acc) {
         if constexpr (I == NK) return acc;
         else {
-            constexpr int S = 16 + 2 * T + SP * (I - NK / 2);
             const uint16_t k = (uint16_t)kx.k[I];
             const u16x2 kk = {k, k};
-            acc += byte_pair<S>(q) * kk; // <= 65535 by the preconditions: exact
-            return RowTaps<SP, NK, T, I + 1>::run(q, kx, acc);
+            acc += P[T + SP * I] * kk; // P[0] is position 16 - H * SP; <= 65535 by the preconditions: exact
+            return RowTaps2<SP, NK, N, T, I + 1>::run(P, kx, acc);
         }
     }
 };
-
-template <int SP, int NK, int T> struct RowPairs { // unrolled over the lane's eight output pairs
-    __device__ static __forceinline__ void run(const uint32_t (&q)[12], const TapsU8<NK> &kx, u16x2 (&out)[8]) {
-        if constexpr (T < 8) {
-            out[T] = RowTaps<SP, NK, T, 0>::run(q, kx, u16x2{0, 0});
-            RowPairs<SP, NK, T + 1>::run(q, kx, out);
+template <int SP, int NK, int N, int T> struct RowBytes2 { // unrolled over the lane's sixteen output bytes
+    __device__ static __forceinline__ void run(const u16x2 (&P)[N], const TapsU8<NK> &kx, u16x2 (&out)[16]) {
+        if constexpr (T < 16) {
+            out[T] = RowTaps2<SP, NK, N, T, 0>::run(P, kx, u16x2{0, 0});
+            RowBytes2<SP, NK, N, T + 1>::run(P, kx, out);
         }
     }
 };
+__device__ __forceinline__ uint32_t dot2_u16(uint32_t packed, uint32_t kpair, uint32_t acc) { // acc + lo * klo + hi * khi
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, packed), __builtin_bit_cast(u16x2, kpair), acc, false);
+}
 
 template <int SP, int NK, int RPT, bool CLAMP>
 __global__ __launch_bounds__(256) void k_sep_bytes(DImg src, DImg dst, TapsU8<NK> kx, TapsU8<NK> ky, int border, int tiles_x) {
@@ -133,45 +144,58 @@ __global__ __launch_bounds__(256) void k_sep_bytes(DImg src, DImg dst, TapsU8<NK
     }
     __syncthreads();
 
-    u16x2 win[NK][8];
+    static_assert(RPT % 2 == 0, "rows are processed in pairs");
+    constexpr int NQ = H + 1;                 // row pairs the column pass of one output pair reaches
+    constexpr int NP = 16 + 2 * H * SP;       // unpacked positions: the lane's sixteen bytes and the taps' reach on both sides
+    u16x2 win[NQ][16];                        // [row pair][byte]: (temp of tile row 2q, temp of tile row 2q + 1)
 #pragma unroll
-    for (int j = 0; j < RPT + 2 * H; ++j) {
-        const int lr = wave * RPT + j;
-        const u32x4 a = tile[lr * R8_UNITS + lx], b = tile[lr * R8_UNITS + lx + 1], c = tile[lr * R8_UNITS + lx + 2];
-        const uint32_t q[12] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3]}; // byte 16 = this lane's first
-        RowPairs<SP, NK, 0>::run(q, kx, win[j % NK]);
-        if (j >= 2 * H) {
-            const int gy = y0 + wave * RPT + (j - 2 * H);
-            uint32_t v[16]; // one per output byte
+    for (int q = 0; q < (RPT + 2 * H) / 2; ++q) {
+        const int lr = wave * RPT + 2 * q;
+        const u32x4 a0 = tile[lr * R8_UNITS + lx], b0 = tile[lr * R8_UNITS + lx + 1], c0 = tile[lr * R8_UNITS + lx + 2];
+        const u32x4 a1 = tile[(lr + 1) * R8_UNITS + lx], b1 = tile[(lr + 1) * R8_UNITS + lx + 1], c1 = tile[(lr + 1) * R8_UNITS + lx + 2];
+        const uint32_t q0[12] = {a0[0], a0[1], a0[2], a0[3], b0[0], b0[1], b0[2], b0[3], c0[0], c0[1], c0[2], c0[3]}; // byte 16 = this lane's first
+        const uint32_t q1[12] = {a1[0], a1[1], a1[2], a1[3], b1[0], b1[1], b1[2], b1[3], c1[0], c1[1], c1[2], c1[3]};
+        u16x2 P[NP];
+        UnpackRows<SP, NK, 16 - H * SP, NP>::run(q0, q1, P);
+        RowBytes2<SP, NK, NP, 0>::run(P, kx, win[q % NQ]);
+        if (q >= H) { // output rows 2m, 2m + 1 of the strip, m = q - H: tile rows 2m .. 2m + 2H + 1 = row pairs m .. m + H
+            const int m = q - H;
+            uint32_t ve[16], vo[16]; // one per output byte, even row and odd row
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < 16; ++t) {
                 // divClampU8(65536, a) for a >= 0 is min(255, (a + 32768) >> 16): the rounding term seeds the accumulator
-                uint32_t lo = 32768u, hi = 32768u;
+                uint32_t e = 32768u, o = 32768u;
+                o = mad_hi16(__builtin_bit_cast(uint32_t, win[m % NQ][t]), ky.k[0], o);
 #pragma unroll
-                for (int i = 0; i < NK; ++i) {
-                    const uint32_t w = __builtin_bit_cast(uint32_t, win[(j + 1 + i) % NK][t]);
-                    lo = mad_lo16(w, ky.k[i], lo);
-                    hi = mad_hi16(w, ky.k[i], hi);
+                for (int h = 0; h < H; ++h) {
+                    e = dot2_u16(__builtin_bit_cast(uint32_t, win[(m + h) % NQ][t]), ky.k[2 * h] | (ky.k[2 * h + 1] << 16), e);
+                    o = dot2_u16(__builtin_bit_cast(uint32_t, win[(m + 1 + h) % NQ][t]), ky.k[2 * h + 1] | (ky.k[2 * h + 2] << 16), o);
                 }
+                e = mad_lo16(__builtin_bit_cast(uint32_t, win[(m + H) % NQ][t]), ky.k[NK - 1], e);
                 if constexpr (CLAMP) {
-                    lo >>= 16; hi >>= 16;
-                    v[2 * t] = lo > 255u ? 255u : lo;
-                    v[2 * t + 1] = hi > 255u ? 255u : hi;
+                    e >>= 16; o >>= 16;
+                    ve[t] = e > 255u ? 255u : e;
+                    vo[t] = o > 255u ? 255u : o;
                 } else { // host proved acc < 2^24: the value is byte 2, extracted below
-                    v[2 * t] = lo;
-                    v[2 * t + 1] = hi;
+                    ve[t] = e;
+                    vo[t] = o;
                 }
             }
-            u32x4 o;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                if constexpr (CLAMP) o[d] = v[4 * d] | (v[4 * d + 1] << 8) | (v[4 * d + 2] << 16) | (v[4 * d + 3] << 24);
-                else o[d] = __builtin_amdgcn_perm(v[4 * d + 1], v[4 * d], 0x0c0c0602u) | __builtin_amdgcn_perm(v[4 * d + 3], v[4 * d + 2], 0x06020c0cu);
+            for (int half = 0; half < 2; ++half) {
+                const uint32_t(&v)[16] = half == 0 ? ve : vo;
+                u32x4 o;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if constexpr (CLAMP) o[d] = v[4 * d] | (v[4 * d + 1] << 8) | (v[4 * d + 2] << 16) | (v[4 * d + 3] << 24);
+                    else o[d] = __builtin_amdgcn_perm(v[4 * d + 1], v[4 * d], 0x0c0c0602u) | __builtin_amdgcn_perm(v[4 * d + 3], v[4 * d + 2], 0x06020c0cu);
+                }
+                const int gy = y0 + wave * RPT + 2 * m + half;
+                const bool row_ok = gy < dst.rows;
+                char *row = (char *)dst.data + (row_ok ? (size_t)gy * dst.stride * SP : (size_t)0);
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)row, (short)0, row_ok ? dst.cols * SP : 0, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, xb0 + 16 * lx, 0, 2); // row bytes % 16 == 0: a unit is all in or all out
             }
-            const bool row_ok = gy < dst.rows;
-            char *row = (char *)dst.data + (row_ok ? (size_t)gy * dst.stride * SP : (size_t)0);
-            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)row, (short)0, row_ok ? dst.cols * SP : 0, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, xb0 + 16 * lx, 0, 2); // row bytes % 16 == 0: a unit is all in or all out
         }
     }
 }
