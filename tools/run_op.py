@@ -53,6 +53,16 @@ elif op in ("shen_photo", "canny_photo"):  # photo-like frame: smooth colour fie
     t = torch.cat([pic, torch.full((R, R, 1), 255.0, device="cuda")], -1).to(torch.uint8).contiguous()
     s = zg.Image(t); d = zg.Image(torch.empty((R, R), dtype=torch.uint8, device="cuda"))
     f = (lambda: s.shen_castan(out=d)) if op == "shen_photo" else (lambda: s.canny(1.4, 50, 150, out=d))
+elif op == "batch64":  # BASELINE configs[4]: 64 x 1080p Rgba(u8) frames, gaussianBlur(0.6) then resize(.bilinear) to 540 x 960
+    import ctypes as C
+    src = torch.randint(0, 256, (64, 1080, 1920, 4), dtype=torch.uint8, device="cuda")
+    dst = torch.empty((64, 540, 960, 4), dtype=torch.uint8, device="cuda")
+    m = I.bilinear._c()
+    lib = zg.lib()
+    def f():
+        rc = lib.zg_batch_blur_resize(C.c_void_p(src.data_ptr()), 64, 1080, 1920, 3, C.c_float(0.6), C.c_void_p(dst.data_ptr()), 540, 960, C.byref(m),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, lib.zg_last_error()
 elif op == "pyramid":  # ImagePyramid.build(source, 8, 1.2, 1.6) on a grey frame (ORB's default)
     src = zg.Image(torch.randint(0, 256, (R, R), dtype=torch.uint8, device="cuda"))
     f = lambda: zg.ImagePyramid.build_default(src)

@@ -79,102 +79,115 @@ template <int NK, int RPT> struct Stage8 {
 // (src/image/channel_ops.zig:144-190), so out = ((tl + tr) * 128 * 128 + (bl + br) * 128 * 128) >> 16 = (tl + tr + bl + br) >> 2
 // of the BLURRED pixels — two adjacent pixels of a lane and two consecutive rows of its strip. The blurred frame
 // never touches HBM.
+// Arithmetic on ROW PAIRS, as in conv_sep_bytes.hip: the u16 pair (byte S of tile row r, byte S of tile row r + 1) is unpacked once per
+// position (one v_perm) and reused by every tap that reaches it (taps are 4 bytes apart: whole pixels); the row pass is one
+// v_pk_mad_u16 per tap and byte for two rows, and its results are (row 2q, row 2q + 1) pairs, which v_dot2_u32_u16 consumes two taps at a
+// time in the column pass (it used to be one v_mad_u32_u16 per tap and channel). An output row pair is also exactly what DOWN2 averages.
+template <int S> __device__ __forceinline__ u16x2 row_pair8(const uint32_t (&q0)[12], const uint32_t (&q1)[12]) {
+    constexpr int d = S >> 2, o = S & 3;
+    constexpr uint32_t sel = 0x0c000c00u | ((4u + o) << 16) | (uint32_t)o; // byte o of q0[d] -> low half, byte o of q1[d] -> high half
+    return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(q1[d], q0[d], sel));
+}
+template <int S0, int N, int I = 0> struct UnpackRows8 { // P[I] = position S0 + I, I < N
+    __device__ static __forceinline__ void run(const uint32_t (&q0)[12], const uint32_t (&q1)[12], u16x2 (&P)[N]) {
+        if constexpr (I < N) {
+            P[I] = row_pair8<S0 + I>(q0, q1);
+            UnpackRows8<S0, N, I + 1>::run(q0, q1, P);
+        }
+    }
+};
+__device__ __forceinline__ uint32_t dot2_u16_8(uint32_t packed, uint32_t kpair, uint32_t acc) { // acc + lo * klo + hi * khi
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, packed), __builtin_bit_cast(u16x2, kpair), acc, false);
+}
+
 template <int NK, int RPT, bool NT, bool CLAMP, bool DOWN2>
 __device__ __forceinline__ void convolve_tile8(const u32x4 *tile, const DImg &dst, const TapsU8<NK> &kx, const TapsU8<NK> &ky,
                                                int x0, int y0, int lx, int wave) {
     constexpr int H = NK / 2;
-    const int gx = x0 + 4 * lx; // first of this lane's four pixels
-    u16x2 win[NK][4][2];        // [slot][pixel][rg | ba]
-    uint32_t prev_sum[2][2];    // DOWN2: horizontal pair sums of the previous (even) row, as packed u16 pairs (rg | ba)
+    static_assert(RPT % 2 == 0, "rows are processed in pairs");
+    constexpr int NQ = H + 1;           // row pairs the column pass of one output pair reaches
+    constexpr int NP = 16 + 8 * H;      // unpacked positions: the lane's sixteen bytes and H pixels on both sides
+    const int gx = x0 + 4 * lx;         // first of this lane's four pixels
+    u16x2 win[NQ][16];                  // [row pair][byte]: (temp of tile row 2q, temp of tile row 2q + 1)
 #pragma unroll
-    for (int j = 0; j < RPT + 2 * H; ++j) {
-        const int lr = wave * RPT + j;
-        const u32x4 a = tile[lr * R8_UNITS + lx], b = tile[lr * R8_UNITS + lx + 1], c = tile[lr * R8_UNITS + lx + 2];
-        const uint32_t q[12] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3]}; // q[4] = pixel gx
-        u16x2 lo[4 + 2 * H], hi[4 + 2 * H];
+    for (int q = 0; q < (RPT + 2 * H) / 2; ++q) {
+        const int lr = wave * RPT + 2 * q;
+        const u32x4 a0 = tile[lr * R8_UNITS + lx], b0 = tile[lr * R8_UNITS + lx + 1], c0 = tile[lr * R8_UNITS + lx + 2];
+        const u32x4 a1 = tile[(lr + 1) * R8_UNITS + lx], b1 = tile[(lr + 1) * R8_UNITS + lx + 1], c1 = tile[(lr + 1) * R8_UNITS + lx + 2];
+        const uint32_t q0[12] = {a0[0], a0[1], a0[2], a0[3], b0[0], b0[1], b0[2], b0[3], c0[0], c0[1], c0[2], c0[3]}; // q0[4] = pixel gx
+        const uint32_t q1[12] = {a1[0], a1[1], a1[2], a1[3], b1[0], b1[1], b1[2], b1[3], c1[0], c1[1], c1[2], c1[3]};
+        u16x2 P[NP];
+        UnpackRows8<16 - 4 * H, NP>::run(q0, q1, P);
 #pragma unroll
-        for (int i = 0; i < 4 + 2 * H; ++i) { lo[i] = pair_lo(q[4 - H + i]); hi[i] = pair_hi(q[4 - H + i]); }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            u16x2 tl = {0, 0}, th = {0, 0};
+        for (int t = 0; t < 16; ++t) {
+            u16x2 acc = {0, 0};
 #pragma unroll
             for (int i = 0; i < NK; ++i) {
                 const uint16_t k = (uint16_t)kx.k[i];
                 const u16x2 kk = {k, k};
-                tl += lo[p + i] * kk; // <= 65535 by the preconditions: exact
-                th += hi[p + i] * kk;
+                acc += P[t + 4 * i] * kk; // P[0] is position 16 - 4 H; <= 65535 by the preconditions: exact
             }
-            win[j % NK][p][0] = tl;
-            win[j % NK][p][1] = th;
+            win[q % NQ][t] = acc;
         }
-        if (j >= 2 * H) {
-            const int orow = j - 2 * H;             // output row within this wave's strip
-            const int gy = y0 + wave * RPT + orow;
-            uint32_t v[4][4];                       // [pixel][channel], each 0..255
+        if (q >= H) { // output rows 2m, 2m + 1 of the strip, m = q - H: tile rows 2m .. 2m + 2H + 1 = row pairs m .. m + H
+            const int m = q - H;
+            const int gy = y0 + wave * RPT + 2 * m;
+            uint32_t ve[16], vo[16]; // one per output byte, even row and odd row
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
+            for (int t = 0; t < 16; ++t) {
                 // divClampU8(65536, a) for a >= 0 is min(255, (a + 32768) >> 16): the rounding term seeds the accumulator
-                uint32_t acc[4] = {32768u, 32768u, 32768u, 32768u};
+                uint32_t e = 32768u, o = 32768u;
+                o = mad_hi16(__builtin_bit_cast(uint32_t, win[m % NQ][t]), ky.k[0], o);
 #pragma unroll
-                for (int i = 0; i < NK; ++i) {
-                    const uint32_t wl = __builtin_bit_cast(uint32_t, win[(j + 1 + i) % NK][p][0]);
-                    const uint32_t wh = __builtin_bit_cast(uint32_t, win[(j + 1 + i) % NK][p][1]);
-                    const uint32_t k = ky.k[i]; // wave-uniform (kernel argument): an SGPR operand
-                    acc[0] = mad_lo16(wl, k, acc[0]);
-                    acc[1] = mad_hi16(wl, k, acc[1]);
-                    acc[2] = mad_lo16(wh, k, acc[2]);
-                    acc[3] = mad_hi16(wh, k, acc[3]);
+                for (int h = 0; h < H; ++h) {
+                    e = dot2_u16_8(__builtin_bit_cast(uint32_t, win[(m + h) % NQ][t]), ky.k[2 * h] | (ky.k[2 * h + 1] << 16), e);
+                    o = dot2_u16_8(__builtin_bit_cast(uint32_t, win[(m + 1 + h) % NQ][t]), ky.k[2 * h + 1] | (ky.k[2 * h + 2] << 16), o);
                 }
-#pragma unroll
-                for (int ch = 0; ch < 4; ++ch) {
-                    if constexpr (CLAMP) { const uint32_t t = acc[ch] >> 16; v[p][ch] = t > 255u ? 255u : t; }
-                    else v[p][ch] = acc[ch]; // host proved acc < 2^24: the value is byte 2, extracted below
+                e = mad_lo16(__builtin_bit_cast(uint32_t, win[(m + H) % NQ][t]), ky.k[NK - 1], e);
+                if constexpr (CLAMP) {
+                    e >>= 16; o >>= 16;
+                    ve[t] = e > 255u ? 255u : e;
+                    vo[t] = o > 255u ? 255u : o;
+                } else if constexpr (DOWN2) { // host proved acc < 2^24: the value is byte 2
+                    ve[t] = e >> 16;
+                    vo[t] = o >> 16;
+                } else { // ... extracted by the packing below
+                    ve[t] = e;
+                    vo[t] = o;
                 }
             }
             if constexpr (!DOWN2) {
-                u32x4 o;
 #pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    if constexpr (CLAMP) o[p] = v[p][0] | (v[p][1] << 8) | (v[p][2] << 16) | (v[p][3] << 24);
-                    else o[p] = __builtin_amdgcn_perm(v[p][1], v[p][0], 0x0c0c0602u) | __builtin_amdgcn_perm(v[p][3], v[p][2], 0x06020c0cu);
+                for (int half = 0; half < 2; ++half) {
+                    const uint32_t(&v)[16] = half == 0 ? ve : vo;
+                    u32x4 o;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        if constexpr (CLAMP) o[d] = v[4 * d] | (v[4 * d + 1] << 8) | (v[4 * d + 2] << 16) | (v[4 * d + 3] << 24);
+                        else o[d] = __builtin_amdgcn_perm(v[4 * d + 1], v[4 * d], 0x0c0c0602u) | __builtin_amdgcn_perm(v[4 * d + 3], v[4 * d + 2], 0x06020c0cu);
+                    }
+                    const bool row_ok = gy + half < dst.rows;
+                    char *row = (char *)dst.data + (row_ok ? (size_t)(gy + half) * dst.stride * 4 : (size_t)0);
+                    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)row, (short)0, row_ok ? dst.cols * 4 : 0, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, gx * 4, 0, NT ? 2 : 0); // cols % 4 == 0: a unit is all in or all out
                 }
-                const bool row_ok = gy < dst.rows;
-                char *row = (char *)dst.data + (row_ok ? (size_t)gy * dst.stride * 4 : (size_t)0);
-                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)row, (short)0, row_ok ? dst.cols * 4 : 0, 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b128(o, rsrc, gx * 4, 0, NT ? 2 : 0); // cols % 4 == 0: a unit is all in or all out
             } else {
-                // horizontal pair sums of this blurred row: pixels (0,1) -> output 0, (2,3) -> output 1; u16 lanes (c0 | c1 << 16)
-                uint32_t hs[2][2];
+                // 2 x 2 means of the blurred pixels: pixels (0, 1) -> output 0, (2, 3) -> output 1, rows 2m and 2m + 1 (y0 and RPT are even)
+                uint32_t opx[2];
 #pragma unroll
                 for (int o2 = 0; o2 < 2; ++o2) {
                     uint32_t c[4];
 #pragma unroll
-                    for (int ch = 0; ch < 4; ++ch) {
-                        const uint32_t a0 = CLAMP ? v[2 * o2][ch] : ((v[2 * o2][ch] >> 16) & 0xffu);
-                        const uint32_t a1 = CLAMP ? v[2 * o2 + 1][ch] : ((v[2 * o2 + 1][ch] >> 16) & 0xffu);
-                        c[ch] = a0 + a1;
-                    }
-                    hs[o2][0] = c[0] | (c[1] << 16);
-                    hs[o2][1] = c[2] | (c[3] << 16);
+                    for (int ch = 0; ch < 4; ++ch) c[ch] = (ve[8 * o2 + ch] + ve[8 * o2 + 4 + ch] + vo[8 * o2 + ch] + vo[8 * o2 + 4 + ch]) >> 2;
+                    opx[o2] = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
                 }
-                if ((orow & 1) == 0) { // even row: keep (rows pair up inside the strip because RPT and y0 are even)
-                    prev_sum[0][0] = hs[0][0]; prev_sum[0][1] = hs[0][1]; prev_sum[1][0] = hs[1][0]; prev_sum[1][1] = hs[1][1];
-                } else {
-                    uint32_t opx[2];
-#pragma unroll
-                    for (int o2 = 0; o2 < 2; ++o2) {
-                        const uint32_t rg = ((prev_sum[o2][0] + hs[o2][0]) >> 2) & 0x00ff00ffu; // per-lane sums <= 1020: no carry across lanes
-                        const uint32_t ba = ((prev_sum[o2][1] + hs[o2][1]) >> 2) & 0x00ff00ffu;
-                        opx[o2] = (rg & 0xffu) | ((rg >> 8) & 0xff00u) | ((ba & 0xffu) << 16) | ((ba >> 16) << 24);
-                    }
-                    const int oy = gy >> 1;
-                    const bool row_ok = oy < dst.rows;
-                    char *row = (char *)dst.data + (row_ok ? (size_t)oy * dst.stride * 4 : (size_t)0);
-                    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)row, (short)0, row_ok ? dst.cols * 4 : 0, 0x00020000);
-                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                    const u32x2 o = {opx[0], opx[1]};
-                    __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, (gx >> 1) * 4, 0, NT ? 2 : 0); // dst.cols even: a pair is all in or all out
-                }
+                const int oy = gy >> 1;
+                const bool row_ok = oy < dst.rows;
+                char *row = (char *)dst.data + (row_ok ? (size_t)oy * dst.stride * 4 : (size_t)0);
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)row, (short)0, row_ok ? dst.cols * 4 : 0, 0x00020000);
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 o = {opx[0], opx[1]};
+                __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, (gx >> 1) * 4, 0, NT ? 2 : 0); // dst.cols even: a pair is all in or all out
             }
         }
     }
@@ -253,7 +266,7 @@ int try_sep_rgba8_batch(const Rgba8Batch &b, const int32_t *ix, const int32_t *i
     const bool clamp = sx * sy * 255 + 32768 >= 256 * 65536; // only then can (acc >> 16) exceed 255
     // RPT 4 (21 KB of LDS, 7 workgroups / CU) measured best on MI355X: profiles/r01_sep_variant_sweep.txt
 #define ZG_R8(NK) case NK: \
-        if (b.down2) return clamp ? launch_rgba8<NK, 4, true, true>(b, ix, iy, border, s) : launch_rgba8<NK, 4, false, true>(b, ix, iy, border, s); \
+        if (b.down2) return clamp ? launch_rgba8<NK, (NK < 9 ? 8 : 4), true, true>(b, ix, iy, border, s) : launch_rgba8<NK, (NK < 9 ? 8 : 4), false, true>(b, ix, iy, border, s); \
         return clamp ? launch_rgba8<NK, 4, true, false>(b, ix, iy, border, s) : launch_rgba8<NK, 4, false, false>(b, ix, iy, border, s);
     switch (nk) { ZG_R8(3) ZG_R8(5) ZG_R8(7) ZG_R8(9) }
 #undef ZG_R8
