@@ -116,3 +116,18 @@ def test_bicubic_family_interior_fast_path(oracle, kind):
         om = oracle.method(m.kind, m.b, m.c)
         want = oracle.resize(src, (77, 150), om)
         assert_bits_equal(sync(dev(src).resize((77, 150), m)), want, f"resize {kind} kind={m.kind}")
+
+
+@pytest.mark.parametrize("kind", ("f32", "rgb_f32", "rgba_f32", "u8", "rgb_u8", "rgba_u8"))
+def test_separable_equal_odd_taps_on_narrow_images(oracle, kind):
+    """Equal odd tap counts up to 13 on images narrower than a tile: the fused kernels' widest instantiations (a fuzz run found the
+    13-tap Rgba(f32) one returning a wrong third channel: register spills miscompiled; it now takes the two-pass kernels)."""
+    rng = np.random.default_rng(17)
+    for nk in (9, 11, 13):
+        for cols in (1, 2, 5, 16, 40, 63):
+            img = synth(oracle, kind, 90 + nk + cols, 37, cols)
+            kx = rng.random(nk).astype(np.float32) - np.float32(0.3)
+            ky = rng.random(nk).astype(np.float32) - np.float32(0.3)
+            for border in (0, 1, 2, 3):
+                assert_bits_equal(sync(dev(img).convolve_separable(kx, ky, border)), oracle.conv_separable(img, kx, ky, border),
+                                  f"sep {kind} 37x{cols} n={nk} b={border}")
