@@ -354,7 +354,8 @@ __device__ __forceinline__ void sat_loader(const DImg &src, const float *carries
                                            int nblocks) {
     using P = Px<PIX>;
     using Elem = typename P::Elem;
-    constexpr int C = P::C, SB = SAT_SB, D = 6; // D blocks in flight: 2 x (1 or 4) + 2 loads per block
+    constexpr int C = P::C, SB = SAT_SB;
+    constexpr int D = (VEC && PIX == ZG_PIXEL_U8) ? 6 : 5; // blocks in flight: 2 x (1 or 4) + 2 loads per block; five keep the wider forms out of scratch
     constexpr bool IS_F32 = sizeof(Elem) == 4;
     const int row4 = lane >> 4, q = lane & 15;
     const int rows = src.rows, cols = src.cols;
