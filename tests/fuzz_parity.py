@@ -65,6 +65,8 @@ def case(rng):
         return f"blur {kind} {rows}x{cols} sigma={sigma}", D(img).gaussian_blur(sigma), o.gaussian_blur(img, sigma)
     if op == "sep":
         nx, ny = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        if rng.random() < 0.35:  # equal odd tap counts: the fused single-launch kernels (one instantiation per count and pixel type)
+            nx = ny = int(rng.choice([1, 3, 5, 7, 9, 11, 13]))
         if rng.random() < 0.5:  # non-negative, normalised (the packed u8 paths)
             kx = rng.random(nx).astype(np.float32); kx /= kx.sum()
             ky = rng.random(ny).astype(np.float32); ky /= ky.sum()
