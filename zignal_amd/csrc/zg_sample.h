@@ -94,17 +94,6 @@ __device__ inline float lanczos3_kernel_lut(const float *lut, float x) {
 // i = 1, 2, so for the two kernels whose branches are closed intervals (`<= 1`, `<= 2`) the branch taken is known per
 // tap — except i = 0 at f == 0 (|t| == 1 takes the inner branch in the reference), where both polynomials evaluate to
 // exactly +0. Evaluating only the polynomial that applies halves the weight arithmetic; the result is bit-identical.
-template <int KIND> __device__ inline float cubic_tap_weight(int i, float t) {
-    const float at = fabsf(t);
-    if constexpr (KIND == ZG_INTERP_BICUBIC) {
-        if (i == 1 || i == 2) return 1 - 2 * at * at + at * at * at;
-        return 4 - 8 * at + 5 * at * at - at * at * at;
-    } else {
-        if (i == 1 || i == 2) return 1.5f * at * at * at - 2.5f * at * at + 1;
-        return -0.5f * at * at * at + 2.5f * at * at - 4 * at + 2;
-    }
-}
-
 // The x and y weights of a tap come from the same polynomial: evaluated as a pair (v_pk_mul_f32 / v_pk_add_f32), each half with
 // the scalar expression's operations in the scalar expression's order.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
