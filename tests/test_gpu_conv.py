@@ -263,6 +263,33 @@ def test_config2_full_size(oracle, kind):
 
 
 @pytest.mark.gpu
+def test_stream_kernel_is_deterministic_at_full_size(oracle):
+    """Twelve runs of the 4096^2 Rgba(u8) Gaussian, each equal to the oracle. A chip full of waves is what it takes to hit the store-data
+    hazard described in conv_sep_stream.hip (an even row stored with part of the odd row): small frames never showed it, and the wrong
+    pixels (0.05 %) differed from run to run. Also a frame whose rows end inside a strip (1920 pixels: 7.5 strips) and the 3- / 7-tap forms."""
+    img = synth(oracle, "rgba_u8", 31, 4096, 4096)
+    want = oracle.gaussian_blur(img, 0.6)
+    d = dev(img)
+    for run in range(12):
+        out = d.gaussian_blur(0.6)
+        torch.cuda.synchronize()
+        assert_bits_equal(out.to_numpy(), want, f"4096^2 rgba_u8, run {run}")
+    img = synth(oracle, "rgba_u8", 32, 1080, 1920)
+    for sigma in (0.3, 0.6, 1.0):
+        want = oracle.gaussian_blur(img, sigma)
+        for run in range(3):
+            out = dev(img).gaussian_blur(sigma)
+            torch.cuda.synchronize()
+            assert_bits_equal(out.to_numpy(), want, f"1080p rgba_u8 sigma={sigma}, run {run}")
+    for kind, border in (("rgb_u8", zg.BorderMode.replicate), ("rgba_u8", zg.BorderMode.wrap), ("rgba_u8", zg.BorderMode.zero), ("rgb_u8", zg.BorderMode.mirror)):
+        img = synth(oracle, kind, 33, 600, 1360)  # 4080 / 5440 bytes per row: the last strip is partial
+        k = np.array([1, 4, 6, 4, 1], np.float32) / 16
+        out = dev(img).convolve_separable(k, k, border)
+        torch.cuda.synchronize()
+        assert_bits_equal(out.to_numpy(), oracle.conv_separable(img, k, k, int(border)), f"{kind} 600x1360 border={border}")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind", ("rgba_f32", "rgba_u8", "f32"))
 def test_config2_binomial_zero_border_full_size(oracle, kind):
     """SURVEY 8(d)'s second input for config 2: the binomial [1, 4, 6, 4, 1] / 16 with BorderMode.zero through convolveSeparable, 4096^2."""

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzignal_hip.so")
+LIB_PATH = os.environ.get("ZIGNAL_HIP_LIBRARY") or os.path.join(_HERE, "libzignal_hip.so")  # the override is for A/B runs of two builds
 
 # enums (ordinals as in include/zignal_hip.h == the reference's declaration order)
 PIXEL_U8, PIXEL_F32, PIXEL_RGB_U8, PIXEL_RGBA_U8, PIXEL_RGB_F32, PIXEL_RGBA_F32 = range(6)

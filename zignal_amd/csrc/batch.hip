@@ -50,6 +50,9 @@ int zg_batch_blur_resize(const void *src_frames, uint32_t n_frames, uint32_t row
         for (size_t i = 0; i < taps.size(); ++i) taps[i] = (int32_t)std::round(f[i] * 256.0f);
         const bool half = method->kind == ZG_INTERP_BILINEAR && rows == 2 * out_rows && cols == 2 * out_cols;
         if (half && !taps.empty()) {
+            const StreamJob job{src_frames, dst_frames, n_frames, rows, cols, 4, (size_t)cols * 4, (size_t)out_cols * 4, in_px * 4, out_px * 4, true};
+            const int rcs = try_sep_stream(job, taps.data(), taps.data(), n, ZG_BORDER_MIRROR, s);
+            if (rcs >= 0) return rcs;
             const Rgba8Batch b{src_frames, dst_frames, n_frames, rows, cols, cols, out_cols, in_px, out_px, true};
             const int rc = try_sep_rgba8_batch(b, taps.data(), taps.data(), n, ZG_BORDER_MIRROR, s);
             if (rc >= 0) return rc;
@@ -60,8 +63,12 @@ int zg_batch_blur_resize(const void *src_frames, uint32_t n_frames, uint32_t row
     int rc = ZG_OK;
     if (!taps.empty()) { // batched blur of every frame in one launch, then the reference's resize per frame
         if ((rc = scratch_alloc(&scratch, (size_t)n_frames * in_px * ps, s))) return rc;
-        const Rgba8Batch b{src_frames, scratch, n_frames, rows, cols, cols, cols, in_px, in_px, false};
-        rc = try_sep_rgba8_batch(b, taps.data(), taps.data(), (int)taps.size(), ZG_BORDER_MIRROR, s);
+        const StreamJob job{src_frames, scratch, n_frames, rows, cols, 4, (size_t)cols * 4, (size_t)cols * 4, in_px * 4, in_px * 4, false};
+        rc = try_sep_stream(job, taps.data(), taps.data(), (int)taps.size(), ZG_BORDER_MIRROR, s);
+        if (rc < 0) {
+            const Rgba8Batch b{src_frames, scratch, n_frames, rows, cols, cols, cols, in_px, in_px, false};
+            rc = try_sep_rgba8_batch(b, taps.data(), taps.data(), (int)taps.size(), ZG_BORDER_MIRROR, s);
+        }
         if (rc >= 0) {
             for (uint32_t i = 0; i < n_frames && rc == ZG_OK; ++i) {
                 zg_image tmp{(char *)scratch + (size_t)i * in_px * ps, cols, rows, cols, pixel};

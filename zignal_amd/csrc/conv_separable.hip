@@ -481,9 +481,9 @@ static int launch_fused_nk(const zg_image *src, const zg_image *dst, const SepPl
     case 3: return launch_fused_skip<PIX, 3, MODE>(src, dst, p, border, s);
     case 5: return launch_fused_skip<PIX, 5, MODE>(src, dst, p, border, s);
     case 7: return launch_fused_skip<PIX, 7, MODE>(src, dst, p, border, s);
-    case 9: return launch_fused_skip<PIX, 9, MODE>(src, dst, p, border, s);
-    case 11: return launch_fused_skip<PIX, 11, MODE>(src, dst, p, border, s);
-    case 13: return launch_fused_skip<PIX, 13, MODE>(src, dst, p, border, s);
+    case 9: if constexpr (MODE != MODE_I64) return launch_fused_skip<PIX, 9, MODE>(src, dst, p, border, s); else break;
+    case 11: if constexpr (MODE != MODE_I64 && Px<PIX>::BYTES < 12) return launch_fused_skip<PIX, 11, MODE>(src, dst, p, border, s); else break;
+    case 13: if constexpr (MODE != MODE_I64 && Px<PIX>::BYTES < 12) return launch_fused_skip<PIX, 13, MODE>(src, dst, p, border, s); else break;
     }
     return -1;
 }
@@ -525,10 +525,14 @@ static int launch_two_pass(const zg_image *src, const zg_image *dst, const SepPl
 
 template <int PIX, int MODE>
 static int run_sep(const zg_image *src, const zg_image *dst, const SepPlan &p, int border, hipStream_t s) {
-    // (the 13-tap kernel of 16-byte pixels needs 512 registers and 676 bytes of scratch, and hipcc 7.2 miscompiles it: the third
-    // channel comes out wrong (tests/test_gpu_aligned_shapes.py pins the case); such images are narrower than 64 columns anyway —
-    // wider ones take the two coalesced passes of conv_sep_f32long.hip — so the general two-pass kernels serve them)
-    const bool fused_ok = !(Px<PIX>::BYTES == 16 && p.nkx == 13);
+    // The fused kernel keeps NK rows of temps per lane in registers; where that window does not fit the register file hipcc spills,
+    // and the one spilling instantiation ever exercised (13 taps, 16-byte pixels: 512 registers + 676 bytes of scratch) came back with
+    // a wrong third channel under hipcc 7.2 (tests/test_gpu_aligned_shapes.py pins the case). So no spilling instantiation exists:
+    // 12- and 16-byte pixels stop at 9 taps, the i64 path at 7; longer kernels take the two-pass kernels (images of 64 columns and
+    // more have gone to conv_sep_f32long.hip / conv_sep_bytes2.hip before they get here anyway). The build checks it
+    // (tools/isa_report.py --check).
+    constexpr int NK_MAX = MODE == MODE_I64 ? 7 : (Px<PIX>::BYTES >= 12 ? 9 : 13);
+    const bool fused_ok = p.nkx <= NK_MAX;
     if (p.nkx == p.nky && p.nkx <= 13 && (p.nkx & 1) && fused_ok) {
         const int rc = launch_fused_nk<PIX, MODE>(src, dst, p, border, s);
         if (rc >= 0) return rc;
@@ -598,6 +602,10 @@ static int conv_separable_impl(const zg_image *src, const zg_image *dst, const f
                           max_temp * say < (int64_t)INT32_MAX - 65536;
         p.mode = fits ? MODE_I24 : MODE_I64;
         if (p.nkx == p.nky) { // small non-negative taps: packed-u16 arithmetic on the row as a byte stream, 16 bytes / lane
+            const size_t sp = pixel_size(src->pixel);
+            const StreamJob job{src->data, dst->data, 1, src->rows, src->cols, (int)sp, src->stride * sp, dst->stride * sp, 0, 0, false};
+            const int rcs = try_sep_stream(job, p.ix.data(), p.iy.data(), p.nkx, border, s); // one wave per column strip, no LDS
+            if (rcs >= 0) return rcs;
             const int rcb = try_sep_bytes(src, dst, p.ix.data(), p.iy.data(), p.nkx, border, s);
             if (rcb >= 0) return rcb;
         }

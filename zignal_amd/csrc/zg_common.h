@@ -194,6 +194,18 @@ int upload_pageable_rows(void *dst_dev, const void *src_host, size_t spitch, siz
 int download_pageable(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s);
 int download_pageable_rows(void *dst_host, size_t dpitch, const void *src_dev, size_t width, size_t rows, hipStream_t s);
 
+// u8 separable convolution of a batch of equally sized frames laid out back to back, one wave per column strip
+// (conv_sep_stream.hip). Returns -1 when its preconditions do not hold: the caller falls back to the tiled kernels.
+struct StreamJob {
+    const void *src; void *dst;
+    uint32_t n_frames, rows, cols;
+    int sp;                                // bytes per pixel: 1, 3, 4
+    size_t src_pitch, dst_pitch;           // bytes between rows
+    size_t src_frame, dst_frame;           // bytes between frames
+    bool down2;                            // dst is (rows / 2) x (cols / 2): blur then 2:1 bilinear (sp == 4)
+};
+int try_sep_stream(const StreamJob &j, const int32_t *ix, const int32_t *iy, int nk, int border, hipStream_t s);
+
 // scratch blocks from the library's caching allocator, ordered on stream s (zg_runtime.cpp)
 int scratch_alloc(void **out, size_t bytes, hipStream_t s);
 int host_threads(); // ZIGNAL_HIP_HOST_THREADS, else min(16, hardware threads)
