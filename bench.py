@@ -11,6 +11,10 @@ A step = one frame through the hot path (one kernel launch). N GPUs: one process
 across ranks with no data-path collective (independent frames) -> weak scaling; value is the
 whole-job Mpixels/s = N * frame pixels * steps / max-over-ranks time.
 
+`python bench.py --gpus N` with N > 1 and no launcher around it starts its own ranks (one process per GPU through
+torch.distributed.run on 127.0.0.1); under a launcher (RANK / WORLD_SIZE in the environment) it is one of them. The JSON says how
+many ranks the RCCL process group really spanned (`ranks.rccl_ranks`: an all-reduce of 1) and every rank's own ms_per_step.
+
 Extra legs (rank 0, N = 1 only):
     roofline      algorithmic bytes (32 B/px: 16 read + 16 written) / mean kernel time from HIP events
                   recorded around each launch on the launch stream, against the 8.0 TB/s HBM3E peak.
@@ -83,8 +87,30 @@ def cpu_baseline(budget_s: float = 12.0):
                       f"host has {os.cpu_count()} logical cores"}
 
 
+def launch_ranks(args) -> int:
+    """--gpus N without a launcher: become the launcher. One process per GPU, rendezvous on 127.0.0.1 (the container's host name
+    may not resolve), same arguments; rank 0's JSON line is the only thing the children print on stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL's peer-to-peer set-up needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    # stdout carries exactly one line, the JSON: everything libraries print on the way (RCCL's version banner, for one) goes to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import numpy as np
     import torch
 
@@ -113,7 +139,10 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE)")
+    if not shared_gpu and torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} wants cuda:{local_rank} but {torch.cuda.device_count()} GPUs are visible")
     torch.cuda.set_device(local_rank)
     lib = zg.lib()
     rc = lib.zg_init(local_rank)
@@ -186,14 +215,24 @@ def main():
     elapsed = time.perf_counter() - t0
     region_ms_per_launch = ev_begin.elapsed_time(ev_end) / args.steps
     from zignal_amd import sharding
-    elapsed = sharding.max_over_ranks(elapsed, torch.device("cpu") if shared_gpu else torch.device("cuda", local_rank))  # the slowest rank is the clock
+    ctl = torch.device("cpu") if shared_gpu else torch.device("cuda", local_rank)  # where the control-plane collectives run
+    own_ms = elapsed / args.steps * 1e3
+    elapsed = sharding.max_over_ranks(elapsed, ctl)  # the slowest rank is the clock
+    ranks = {"backend": "none (one process)", "rccl_ranks": None, "ms_per_step_per_rank": [round(own_ms, 5)], "devices": [torch.cuda.get_device_name(local_rank)]}
+    if world > 1 or args.scatter_gather:
+        seen = sharding.count_ranks(ctl)  # an all-reduce(SUM) of 1 over the process group: what the group spans, not what was asked for
+        names = [None] * world
+        dist.all_gather_object(names, f"cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}")
+        ranks = {"backend": "gloo (ZG_BENCH_SHARED_GPU test hook: every rank on cuda:0)" if shared_gpu else "nccl (RCCL)",
+                 "rccl_ranks": None if shared_gpu else seen, "ranks_seen": seen,
+                 "ms_per_step_per_rank": [round(v, 5) for v in sharding.per_rank(own_ms, ctl)], "devices": names}
 
     pixels = ROWS * COLS
     value = world * pixels * args.steps / elapsed / 1e6
     result = {
         "metric": METRIC, "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "ranks": ranks,
         "config": {"workload": "gaussianBlur(sigma=0.6): 5x5 separable Gaussian, mirror border, 4096x4096 RGBA f32 "
                                "(BASELINE.json configs[1]); one frame per step per GPU, frames resident in HBM",
                    "frame": [ROWS, COLS, 4], "ring_bytes": ring_bytes, "frames_per_step_per_gpu": 1, "untimed_clock_ramp_s": PREWARM_S,
@@ -257,10 +296,11 @@ def main():
         except Exception as e:
             if rank == 0:
                 result["scatter_gather_config5"] = {"error": f"{type(e).__name__}: {e}"}
-    if rank == 0:
-        print(json.dumps(result), flush=True)
     if world > 1 or args.scatter_gather:
         dist.destroy_process_group()
+    if rank == 0:
+        json_out.write(json.dumps(result) + "\n")
+        json_out.flush()
 
 
 def resize_headline(zg, torch):
@@ -319,40 +359,90 @@ def cpu_config5_all_cores(budget_s: float = 20.0):
             "sample": f"{n * per_thread} x [gaussianBlur(0.6), resize(.bilinear, 540x960)] on 1080p Rgba(u8) frames, {n} concurrent callers"}
 
 
-def scatter_gather_leg(zg, torch, sharding, rank, world, local_rank, frames_per_gpu=128):
+def scatter_gather_leg(zg, torch, sharding, rank, world, local_rank, frames_per_gpu=128, chunks=4):
+    """BASELINE configs[4] three ways, 128 frames of 1080p Rgba(u8) per GPU through [gaussianBlur(0.6), resize 0.5 bilinear]:
+    (i)   kernel only: every rank's shard already resident, one batched launch per rank;
+    (ii)  end to end over xGMI: rank 0 holds the whole batch, shards go out and results come back over RCCL point-to-point, cut into
+          `chunks` pieces so that transfer, compute and the return trip overlap (sharding.scatter_compute_gather);
+    (iii) host-staged: every rank feeds its own GPU from pinned host memory over its own PCIe link and takes the results back, chunked.
+    Rates are whole-job: all ranks' source pixels / the slowest rank's time."""
     import ctypes as C
     import torch.distributed as dist
     dev = torch.device("cuda", local_rank)
+    shared = os.environ.get("ZG_BENCH_SHARED_GPU") == "1"
+    ctl = torch.device("cpu") if shared else dev
     n, rows, cols = frames_per_gpu * world, 1080, 1920
-    batch = torch.randint(0, 256, (n, rows, cols, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
     lib = zg.lib()
     m = zg.Interpolation.bilinear._c()
+    px_all = n * rows * cols
 
-    loop = world == 1  # one rank: its own shard goes through ncclSend / ncclRecv to itself instead of a device copy
-
-    def once():
-        mine = sharding.scatter_frames(batch, n, (rows, cols, 4), torch.uint8, dev, loopback=loop)
-        out = torch.empty((mine.shape[0], 540, 960, 4), dtype=torch.uint8, device=dev)
-        rc = lib.zg_batch_blur_resize(C.c_void_p(mine.data_ptr()), int(mine.shape[0]), rows, cols, 3, C.c_float(SIGMA),
-                                      C.c_void_p(out.data_ptr()), 540, 960, C.byref(m), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    def blur_resize(src, dst):  # on the current stream
+        rc = lib.zg_batch_blur_resize(C.c_void_p(src.data_ptr()), int(src.shape[0]), rows, cols, 3, C.c_float(SIGMA), C.c_void_p(dst.data_ptr()),
+                                      540, 960, C.byref(m), C.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0, lib.zg_last_error()
-        return sharding.gather_frames(out, n, loopback=loop)
 
-    once()
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    reps = 3
-    for _ in range(reps):
-        once()
-    torch.cuda.synchronize()
-    dist.barrier()
-    sec = sharding.max_over_ranks((time.perf_counter() - t0) / reps, dev)
-    return {"frames": n, "seconds": round(sec, 6), "Mpixels/s_end_to_end": round(n * rows * cols / sec / 1e6, 1),
-            "frames_per_gpu": frames_per_gpu, "backend": "nccl (RCCL)" if not os.environ.get("ZG_BENCH_SHARED_GPU") else "gloo",
-            "note": ("one rank: the shard loops back through the communicator (ncclSend / ncclRecv to itself), so this times RCCL's "
-                     "device-local copy path, not xGMI" if world == 1 else
-                     "includes the xGMI scatter of 8.3 MB/frame and gather of 2.1 MB/frame; kernel-only rate is `value`")}
+    def clock(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        return sharding.max_over_ranks((time.perf_counter() - t0) / reps, ctl)
+
+    out = {"frames": n, "frames_per_gpu": frames_per_gpu, "chunks": chunks, "backend": "gloo (test hook)" if shared else "nccl (RCCL)"}
+    # (i) resident shards
+    shard = torch.randint(0, 256, (frames_per_gpu, rows, cols, 4), dtype=torch.uint8, device=dev)
+    res = torch.empty((frames_per_gpu, 540, 960, 4), dtype=torch.uint8, device=dev)
+    sec = clock(lambda: blur_resize(shard, res), reps=5)
+    out["kernel_only"] = {"seconds": round(sec, 6), "Mpixels/s": round(px_all / sec / 1e6, 1)}
+
+    # (iii) host-staged, chunked: copy-in stream -> compute stream -> copy-out stream
+    host_in = torch.empty((frames_per_gpu, rows, cols, 4), dtype=torch.uint8).pin_memory()
+    host_in.copy_(shard.cpu())
+    host_out = torch.empty((frames_per_gpu, 540, 960, 4), dtype=torch.uint8).pin_memory()
+    s_in, s_k, s_out = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    pieces = sharding.chunk_ranges(frames_per_gpu, 2 * chunks)
+
+    def host_staged():
+        evs = []
+        for c0, c1 in pieces:
+            with torch.cuda.stream(s_in):
+                shard[c0:c1].copy_(host_in[c0:c1], non_blocking=True)
+                e_in = torch.cuda.Event(); e_in.record()
+            with torch.cuda.stream(s_k):
+                s_k.wait_event(e_in)
+                blur_resize(shard[c0:c1], res[c0:c1])
+                e_k = torch.cuda.Event(); e_k.record()
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(e_k)
+                host_out[c0:c1].copy_(res[c0:c1], non_blocking=True)
+            evs.append((e_in, e_k))
+        s_out.synchronize()
+    sec = clock(host_staged)
+    out["host_staged_pcie"] = {"seconds": round(sec, 6), "Mpixels/s": round(px_all / sec / 1e6, 1),
+                               "GB/s_per_gpu_in": round(frames_per_gpu * rows * cols * 4 / sec / 1e9, 1), "pieces": len(pieces)}
+    del host_in, host_out
+
+    # (ii) over the fabric: RCCL point-to-point, pipelined
+    if shared:
+        out["end_to_end_xgmi"] = {"skipped": "every rank shares cuda:0 under the test hook; RCCL needs one GPU per rank"}
+    else:
+        loop = world == 1  # one rank: its shard goes through ncclSend / ncclRecv to itself instead of staying in place
+        second = dist.new_group(backend="nccl")  # results return on a communicator (and stream) of their own
+        batch = torch.randint(0, 256, (n, rows, cols, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+        gathered = torch.empty((n, 540, 960, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+        for label, k in (("end_to_end_xgmi", chunks), ("end_to_end_xgmi_unchunked", 1)):
+            sec = clock(lambda: sharding.scatter_compute_gather(batch, n, (rows, cols, 4), (540, 960, 4), torch.uint8, dev, blur_resize, chunks=k,
+                                                                loopback=loop, gather_group=second, out=gathered))
+            out[label] = {"seconds": round(sec, 6), "Mpixels/s": round(px_all / sec / 1e6, 1),
+                          "GB/s_scattered": round((n - (0 if loop else frames_per_gpu)) * rows * cols * 4 / sec / 1e9, 1)}
+        out["note"] = ("one rank: the shard loops back through the communicator (ncclSend / ncclRecv to itself), so this times RCCL's "
+                       "device-local copy path, not xGMI" if world == 1 else
+                       "rank 0 sends 8.3 MB per frame to the frame's owner and receives 2.1 MB back, each peer over its own xGMI link")
+    return out
 
 
 def cpu_extras(extras_out):

@@ -190,20 +190,56 @@ int main(int argc, char **argv) {
             EXPECT(zo_gaussian_blur(&zs, &zb, sigma) == 0 && zo_resize(&zb, &zw, &zbil) == 0);
             EXPECT(std::memcmp(want.data(), s0.data, (size_t)(rows / 2) * (cols / 2) * 4) == 0);
         }
-        for (int loop = 0; loop < (quick ? 1 : 2); ++loop) { // the RCCL round trip (2.5 s of communicator set-up) only in the full run
-            if (loop) setenv("ZIGNAL_HIP_MULTI_LOOPBACK", "1", 1); else unsetenv("ZIGNAL_HIP_MULTI_LOOPBACK");
+        // one device, then the same with the shard looped through both RCCL communicators in 1, 3 and 8 pieces (communicator set-up
+        // costs seconds, so the loop-back runs only in the full mode)
+        struct Mode { int loop; const char *chunks; };
+        const Mode modes[] = {{0, "4"}, {1, "1"}, {1, "3"}, {1, "8"}};
+        for (const Mode &mode : modes) {
+            if (mode.loop && quick) continue;
+            if (mode.loop) setenv("ZIGNAL_HIP_MULTI_LOOPBACK", "1", 1); else unsetenv("ZIGNAL_HIP_MULTI_LOOPBACK");
+            setenv("ZIGNAL_HIP_MULTI_CHUNKS", mode.chunks, 1);
             zg_multi ctx = nullptr;
             check(zg_multi_create(nullptr, 1, &ctx));
             EXPECT(zg_multi_device_count(ctx) == 1);
             const uint8_t junk = 0xA5;
             std::vector<uint8_t> fill(out_bytes, junk);
-            check(zg_memcpy_h2d(dout, fill.data(), out_bytes, nullptr));
-            float t[3] = {0, 0, 0};
-            check(zg_multi_batch_blur_resize(ctx, dsrc, n, rows, cols, ZG_PIXEL_RGBA_U8, sigma, dout, rows / 2, cols / 2, &bil, t));
-            check(zg_memcpy_d2h(got.data(), dout, out_bytes, nullptr));
-            EXPECT(got == want);
-            std::printf(loop ? "multi_1gpu_rccl_loopback_ms=%.3f %.3f %.3f\n" : "multi_1gpu_ms=%.3f %.3f %.3f\n", t[0], t[1], t[2]);
+            for (int call = 0; call < 2; ++call) { // a context is reusable
+                check(zg_memcpy_h2d(dout, fill.data(), out_bytes, nullptr));
+                check(zg_multi_wait_stream(ctx, nullptr));
+                float t[3] = {0, 0, 0};
+                check(zg_multi_batch_blur_resize(ctx, dsrc, n, rows, cols, ZG_PIXEL_RGBA_U8, sigma, dout, rows / 2, cols / 2, &bil, call ? nullptr : t));
+                check(zg_memcpy_d2h(got.data(), dout, out_bytes, nullptr));
+                EXPECT(got == want);
+                if (!call) std::printf(mode.loop ? "multi_1gpu_rccl_loopback_%s_pieces_ms=%.3f %.3f %.3f\n" : "multi_1gpu_%s_ms=%.3f %.3f %.3f\n", mode.chunks, t[0], t[1], t[2]);
+            }
+            // argument errors leave the context usable
+            EXPECT(zg_multi_batch_blur_resize(ctx, dsrc, n, rows, cols, 99, sigma, dout, rows / 2, cols / 2, &bil, nullptr) == ZG_ERR_INVALID_ARGUMENT);
+            check(zg_multi_batch_blur_resize(ctx, dsrc, 1, rows, cols, ZG_PIXEL_RGBA_U8, sigma, dout, rows / 2, cols / 2, &bil, nullptr));
             check(zg_multi_destroy(ctx));
+        }
+        unsetenv("ZIGNAL_HIP_MULTI_CHUNKS");
+        // every visible device (the world > 1 branches: shard ownership, staging, both communicators): needs a box with >= 2 GPUs
+        if (zg_device_count() >= 2 && !quick) {
+            for (const char *chunks : {"1", "4"}) {
+                setenv("ZIGNAL_HIP_MULTI_CHUNKS", chunks, 1);
+                unsetenv("ZIGNAL_HIP_MULTI_LOOPBACK");
+                zg_multi ctx = nullptr;
+                check(zg_multi_create(nullptr, 0, &ctx));
+                const int world = zg_multi_device_count(ctx);
+                EXPECT(world == zg_device_count());
+                std::vector<uint8_t> fill(out_bytes, 0x5A);
+                check(zg_set_device(0));
+                check(zg_memcpy_h2d(dout, fill.data(), out_bytes, nullptr));
+                float t[3] = {0, 0, 0};
+                check(zg_multi_batch_blur_resize(ctx, dsrc, n, rows, cols, ZG_PIXEL_RGBA_U8, sigma, dout, rows / 2, cols / 2, &bil, t));
+                check(zg_memcpy_d2h(got.data(), dout, out_bytes, nullptr));
+                EXPECT(got == want);
+                std::printf("multi_%dgpu_%s_pieces_ms=%.3f %.3f %.3f\n", world, chunks, t[0], t[1], t[2]);
+                check(zg_multi_destroy(ctx));
+            }
+            unsetenv("ZIGNAL_HIP_MULTI_CHUNKS");
+        } else {
+            std::printf("multi_world_gt_1=skipped (%d device%s visible)\n", zg_device_count(), zg_device_count() == 1 ? "" : "s");
         }
         unsetenv("ZIGNAL_HIP_MULTI_LOOPBACK");
         zg_multi bad = nullptr;

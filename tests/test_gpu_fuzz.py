@@ -17,17 +17,38 @@ def test_fuzz_parity_short():
 
 
 def test_bench_two_rank_path_on_one_gpu():
-    """bench.py's N > 1 control flow (rendezvous, barriers, max-over-ranks clock, one JSON line from rank 0) with both ranks
-    on cuda:0 and gloo for the control-plane collectives (ZG_BENCH_SHARED_GPU=1, a test hook the driver never sets)."""
+    """`python bench.py --gpus 2` with NO launcher around it — the shape of the driver's own command — starts its two ranks itself
+    (rendezvous on 127.0.0.1, barriers, max-over-ranks clock, one JSON line from rank 0). Both ranks share cuda:0 here and gloo carries
+    the control-plane collectives (ZG_BENCH_SHARED_GPU=1, a test hook the driver never sets)."""
     import json
     pytest.importorskip("torch")
-    env = dict(os.environ, ZG_BENCH_SHARED_GPU="1")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "100", "--warmup", "100"],
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ZG_BENCH_SHARED_GPU"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "100", "--warmup", "100"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 100 and res["scaling"] == "weak" and res["value"] > 0
+    assert res["ranks"]["ranks_seen"] == 2 and len(res["ranks"]["ms_per_step_per_rank"]) == 2 and len(res["ranks"]["devices"]) == 2
+    assert abs(max(res["ranks"]["ms_per_step_per_rank"]) - res["ms_per_step"]) < 1e-3  # the slowest rank is the clock
     assert "roofline" not in res  # N = 1 legs only
+
+
+def test_bench_counts_its_rccl_ranks_and_times_the_three_distribution_routes():
+    """One GPU, `--scatter-gather`: the process group is RCCL (world 1) and the JSON says so; BASELINE configs[4] comes out three ways
+    (kernel only, end to end through the communicator — the shard looped back —, host-staged over PCIe)."""
+    import json
+    pytest.importorskip("torch")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "100", "--warmup", "100", "--scatter-gather", "--no-extras", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert res["ranks"]["backend"].startswith("nccl") and res["ranks"]["rccl_ranks"] == 1
+    sg = res["scatter_gather_config5"]
+    assert "error" not in sg, sg
+    for leg in ("kernel_only", "end_to_end_xgmi", "end_to_end_xgmi_unchunked", "host_staged_pcie"):
+        assert sg[leg]["Mpixels/s"] > 0, (leg, sg)
+    assert sg["kernel_only"]["Mpixels/s"] > sg["end_to_end_xgmi"]["Mpixels/s"]

@@ -47,6 +47,19 @@ for f in range(n):
     want = oracle.resize(oracle.gaussian_blur(host[f], 0.6), (rows // 2, cols // 2), bil)
     assert np.array_equal(got[f], want), f"frame {f} differs from the oracle after the RCCL round trip"
 assert sharding.max_over_ranks(1.25, dev) == 1.25
+assert sharding.count_ranks(dev) == 1 and sharding.per_rank(2.5, dev) == [2.5]
+
+# the chunked form of the same exchange (what bench.py --scatter-gather times): three pieces, results back on a second communicator
+second = dist.new_group(backend="nccl")
+def blur_resize(src, dst):
+    rc = lib.zg_batch_blur_resize(C.c_void_p(src.data_ptr()), int(src.shape[0]), rows, cols, 3, C.c_float(0.6), C.c_void_p(dst.data_ptr()),
+                                  rows // 2, cols // 2, C.byref(m), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, lib.zg_last_error()
+for chunks in (3, 1, 8):
+    piped = sharding.scatter_compute_gather(batch, n, (rows, cols, 4), (rows // 2, cols // 2, 4), torch.uint8, dev, blur_resize, chunks=chunks,
+                                            loopback=True, gather_group=second)
+    torch.cuda.synchronize()
+    assert np.array_equal(piped.cpu().numpy(), got), f"pipelined exchange with {chunks} pieces differs"
 dist.destroy_process_group()
 print("rccl world1 ok")
 '''

@@ -18,6 +18,7 @@ ALLOW = {
     # kernels known to spill or to need more than 256 VGPRs, with the reason they are tolerated; anything else fails the build
     "k_sat_chain": "role-split SAT chain, launch_bounds(1024) caps it at 128 VGPRs: 40-272 B of spill in the loader role; parity-tested on "
                    "every shape class (tests/test_gpu_conv.py, test_gpu_aligned_shapes.py: fused vs ZIGNAL_HIP_SAT_UNFUSED)",
+    "k_sat_cols": "262 VGPRs (256 + 6 AGPRs used as spill space), no scratch: 64 column accumulators per lane by design (f32 sources only)",
     "k_convert_spaces": "16 B: one spilled SGPR pair of the hop loop; lattice-tested for every space pair (tests/test_gpu_color.py)",
     "k_sep_fused<4, 9,": "328 VGPRs, no scratch: nine f32x3 temps per lane by design (launch_bounds(256) allows 512)",
     "k_sep_fused<5, 9,": "329 VGPRs, no scratch: nine f32x4 temps per lane by design",

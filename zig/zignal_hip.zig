@@ -83,6 +83,7 @@ pub const c = struct {
     pub extern fn zg_multi_create(devices: ?[*]const c_int, n_devices: c_int, out: *?*anyopaque) c_int;
     pub extern fn zg_multi_destroy(m: ?*anyopaque) c_int;
     pub extern fn zg_multi_device_count(m: ?*anyopaque) c_int;
+    pub extern fn zg_multi_wait_stream(m: ?*anyopaque, producer: ?*anyopaque) c_int;
     pub extern fn zg_multi_batch_blur_resize(m: ?*anyopaque, src_frames_root: *const anyopaque, n_frames: u32, rows: u32, cols: u32, pixel: c_int, sigma: f32, dst_frames_root: *anyopaque, out_rows: u32, out_cols: u32, method: *const ZgMethod, times_ms: ?*[3]f32) c_int;
     pub extern fn zg_stream_create(out: *?*anyopaque) c_int;
     pub extern fn zg_stream_destroy(stream: ?*anyopaque) c_int;

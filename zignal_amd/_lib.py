@@ -135,6 +135,7 @@ _SIGNATURES = {
     "zg_multi_create": [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)],
     "zg_multi_destroy": [C.c_void_p],
     "zg_multi_device_count": [C.c_void_p],
+    "zg_multi_wait_stream": [C.c_void_p, C.c_void_p],
     "zg_multi_batch_blur_resize": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_float, C.c_void_p, C.c_uint32, C.c_uint32, _METHOD, _F32P],
     "zg_stream_create": [C.POINTER(C.c_void_p)],
     "zg_stream_destroy": [C.c_void_p],

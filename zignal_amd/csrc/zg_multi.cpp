@@ -5,10 +5,12 @@
 // Frames are independent units (reference src/cli/pipeline.zig:153-179 runs one image at a time): device i of the context
 // owns a contiguous block of frames, there is no halo and no collective on the data path. The only exchange is
 // distribution: the root device holds the batch, the shards travel to their owners and the results travel back. That is a
-// scatter and a gather of point-to-point transfers — over RCCL (ncclSend / ncclRecv grouped into one launch per direction: each
-// xGMI peer link carries exactly one shard, nothing rings through third devices) — issued from this one thread against a
-// communicator per device (ncclCommInitAll). Each device then runs the same zg_batch_blur_resize on its shard on its own
-// stream; the root works on its slice of the caller's buffers in place.
+// scatter and a gather of point-to-point transfers over RCCL (grouped ncclSend / ncclRecv: each xGMI peer link carries its own
+// peer's frames, nothing rings through third devices), issued from this one thread against two communicators per device
+// (ncclCommInitAll twice: shards out on one, results back on the other, so both directions of a link are busy at once). A shard
+// travels in pieces: a device convolves piece c (zg_batch_blur_resize on its compute stream) while piece c + 1 is arriving and
+// piece c - 1 is on its way back; the root works on its slice of the caller's buffers in place. Nothing blocks the host until
+// the final wait; a failure half-way closes any open RCCL group, drains every stream and marks the context unusable.
 //
 // librccl is bound at first use with dlopen, not linked: a Python process already carries PyTorch's own copy (same SONAME,
 // found first), a bare process gets the system's, and a host that never asks for more than one GPU never loads it.
@@ -16,7 +18,9 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -74,23 +78,47 @@ int load_rccl() {
         }                                                                                               \
     } while (0)
 
+constexpr int MAX_CHUNKS = 8;
+
 struct DeviceSlot {
     int device = -1;
-    hipStream_t stream = nullptr;
-    nccl_comm comm = nullptr;
+    // three streams so that a shard's pieces can arrive, be convolved and travel back at the same time
+    hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
+    nccl_comm comm_in = nullptr, comm_out = nullptr; // scatter and gather on communicators of their own: the two directions of a link overlap
+    hipEvent_t arrived[MAX_CHUNKS] = {}, done[MAX_CHUNKS] = {};
+    hipEvent_t t0 = nullptr, t_in = nullptr, t_run0 = nullptr, t_run1 = nullptr; // timing (root: scatter; every device: its kernels)
     void *in = nullptr, *out = nullptr; // shard staging on a non-root device (grow-only)
     size_t in_bytes = 0, out_bytes = 0;
 };
 
 struct Multi {
     std::vector<DeviceSlot> dev; // dev[0] is the root
+    hipEvent_t ready = nullptr;  // root: whatever produced the caller's frames
     bool loopback = false;       // one device: still pass the root's shard through ncclSend / ncclRecv (diagnostics)
+    bool poisoned = false;       // a call failed half-way: streams and communicators are in an unknown state
+    int chunks = 4;
 };
 
 struct DeviceScope { // the calling thread's current device, restored on exit
     int saved = 0;
     DeviceScope() { (void)hipGetDevice(&saved); }
     ~DeviceScope() { (void)hipSetDevice(saved); }
+};
+
+struct GroupScope { // an RCCL group that is closed on every path out of the scope
+    bool open = false;
+    int begin() {
+        const int r = g_rccl.GroupStart();
+        open = r == 0;
+        return r;
+    }
+    int end() {
+        open = false;
+        return g_rccl.GroupEnd();
+    }
+    ~GroupScope() {
+        if (open) (void)g_rccl.GroupEnd();
+    }
 };
 
 void shard_range(uint32_t n, int i, int world, uint32_t *begin, uint32_t *end) { // as zignal_amd/sharding.py: blocks differ by at most one frame
@@ -135,23 +163,39 @@ int zg_multi_create(const int *devices, int n_devices, zg_multi *out) {
     Multi *m = new Multi();
     m->dev.resize((size_t)n_devices);
     m->loopback = getenv("ZIGNAL_HIP_MULTI_LOOPBACK") != nullptr;
+    if (const char *e = getenv("ZIGNAL_HIP_MULTI_CHUNKS")) m->chunks = std::max(1, std::min(MAX_CHUNKS, atoi(e)));
     int rc = ZG_OK;
+    auto hip = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == ZG_OK) rc = hip_fail(e, what, __FILE__, __LINE__);
+    };
     for (int i = 0; i < n_devices && rc == ZG_OK; ++i) {
-        m->dev[(size_t)i].device = list[(size_t)i];
-        rc = zg_init(list[(size_t)i]); // gfx950 check + current device
-        if (rc == ZG_OK && hipStreamCreateWithFlags(&m->dev[(size_t)i].stream, hipStreamNonBlocking) != hipSuccess)
-            rc = hip_fail(hipGetLastError(), "hipStreamCreateWithFlags", __FILE__, __LINE__);
+        DeviceSlot &d = m->dev[(size_t)i];
+        d.device = list[(size_t)i];
+        rc = zg_init(d.device); // gfx950 check + current device
+        if (rc != ZG_OK) break;
+        hip(hipStreamCreateWithFlags(&d.s_in, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+        hip(hipStreamCreateWithFlags(&d.s_run, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+        hip(hipStreamCreateWithFlags(&d.s_out, hipStreamNonBlocking), "hipStreamCreateWithFlags");
+        for (int c = 0; c < MAX_CHUNKS; ++c) {
+            hip(hipEventCreateWithFlags(&d.arrived[c], hipEventDisableTiming), "hipEventCreateWithFlags");
+            hip(hipEventCreateWithFlags(&d.done[c], hipEventDisableTiming), "hipEventCreateWithFlags");
+        }
+        hip(hipEventCreate(&d.t0), "hipEventCreate");
+        hip(hipEventCreate(&d.t_in), "hipEventCreate");
+        hip(hipEventCreate(&d.t_run0), "hipEventCreate");
+        hip(hipEventCreate(&d.t_run1), "hipEventCreate");
+        if (i == 0) hip(hipEventCreateWithFlags(&m->ready, hipEventDisableTiming), "hipEventCreateWithFlags");
     }
     if (rc == ZG_OK && (n_devices > 1 || m->loopback)) {
         rc = load_rccl();
-        if (rc == ZG_OK) {
+        for (int pass = 0; pass < 2 && rc == ZG_OK; ++pass) {
             std::vector<nccl_comm> comms((size_t)n_devices, nullptr);
             const int r = g_rccl.CommInitAll(comms.data(), n_devices, list.data());
             if (r != 0) {
                 set_error("RCCL error %d (%s) in ncclCommInitAll over %d devices", r, g_rccl.GetErrorString(r), n_devices);
                 rc = ZG_ERR_HIP;
             } else {
-                for (int i = 0; i < n_devices; ++i) m->dev[(size_t)i].comm = comms[(size_t)i];
+                for (int i = 0; i < n_devices; ++i) (pass == 0 ? m->dev[(size_t)i].comm_in : m->dev[(size_t)i].comm_out) = comms[(size_t)i];
             }
         }
     }
@@ -170,17 +214,167 @@ int zg_multi_destroy(zg_multi handle) {
     for (DeviceSlot &d : m->dev) {
         if (d.device < 0) continue;
         (void)hipSetDevice(d.device);
-        if (d.stream) (void)hipStreamSynchronize(d.stream);
-        if (d.comm) (void)g_rccl.CommDestroy(d.comm);
+        for (hipStream_t s : {d.s_in, d.s_run, d.s_out})
+            if (s) (void)hipStreamSynchronize(s);
+        if (d.comm_in) (void)g_rccl.CommDestroy(d.comm_in);
+        if (d.comm_out) (void)g_rccl.CommDestroy(d.comm_out);
         if (d.in) (void)hipFree(d.in);
         if (d.out) (void)hipFree(d.out);
-        if (d.stream) (void)hipStreamDestroy(d.stream);
+        for (int c = 0; c < MAX_CHUNKS; ++c) {
+            if (d.arrived[c]) (void)hipEventDestroy(d.arrived[c]);
+            if (d.done[c]) (void)hipEventDestroy(d.done[c]);
+        }
+        for (hipEvent_t e : {d.t0, d.t_in, d.t_run0, d.t_run1})
+            if (e) (void)hipEventDestroy(e);
+        for (hipStream_t s : {d.s_in, d.s_run, d.s_out})
+            if (s) (void)hipStreamDestroy(s);
+    }
+    if (m->ready) {
+        (void)hipSetDevice(m->dev[0].device);
+        (void)hipEventDestroy(m->ready);
     }
     delete m;
     return ZG_OK;
 }
 
 int zg_multi_device_count(zg_multi handle) { return handle ? (int)((Multi *)handle)->dev.size() : 0; }
+
+int zg_multi_wait_stream(zg_multi handle, zg_stream producer) {
+    ZG_REQUIRE(handle != nullptr, ZG_ERR_INVALID_ARGUMENT, "zg_multi_wait_stream: null context");
+    Multi *m = (Multi *)handle;
+    DeviceScope scope;
+    DeviceSlot &root = m->dev[0];
+    ZG_HIP(hipSetDevice(root.device));
+    ZG_HIP(hipEventRecord(m->ready, as_stream(producer)));
+    for (hipStream_t s : {root.s_in, root.s_run, root.s_out}) ZG_HIP(hipStreamWaitEvent(s, m->ready, 0));
+    return ZG_OK;
+}
+
+namespace {
+
+// The whole exchange, asynchronous: nothing here blocks the host. Piece c of device i's shard: root -> i on the scatter communicator
+// (streams s_in), the kernel on i's s_run once the piece has arrived, the result i -> root on the gather communicator (streams s_out)
+// once the kernel is done. One grouped launch per piece index and direction, so every xGMI link carries its own peer's pieces back to
+// back and no transfer rings through a third device. Issue order = piece order on every device, which is what RCCL needs from a single
+// thread driving several communicators.
+int run_batch(Multi *m, const void *src_root, uint32_t n_frames, uint32_t rows, uint32_t cols, int pixel, float sigma, void *dst_root,
+              uint32_t out_rows, uint32_t out_cols, const zg_method *method, bool timed) {
+    const int world = (int)m->dev.size();
+    const size_t ps = pixel_size(pixel), in_frame = (size_t)rows * cols * ps, out_frame = (size_t)out_rows * out_cols * ps;
+    DeviceSlot &root = m->dev[0];
+    const bool loop = world == 1 && m->loopback;
+    const int first_peer = loop ? 0 : 1;
+    auto piece = [&](int i, int c, uint32_t *b, uint32_t *e) { // frames [b, e) of the batch: piece c of device i's shard
+        uint32_t sb, se, cb, ce;
+        shard_range(n_frames, i, world, &sb, &se);
+        const uint32_t k = se - sb;
+        const int pieces = (int)std::min<uint32_t>((uint32_t)m->chunks, std::max<uint32_t>(k, 1));
+        if (c >= pieces || k == 0) { *b = *e = sb; return; }
+        shard_range(k, c, pieces, &cb, &ce);
+        *b = sb + cb;
+        *e = sb + ce;
+    };
+    auto staged = [&](int i, uint32_t frame, bool input) -> char * { // where device i keeps `frame` of its shard
+        uint32_t sb, se;
+        shard_range(n_frames, i, world, &sb, &se);
+        DeviceSlot &d = m->dev[(size_t)i];
+        return (char *)(input ? d.in : d.out) + (size_t)(frame - sb) * (input ? in_frame : out_frame);
+    };
+
+    if (timed) {
+        ZG_HIP(hipSetDevice(root.device));
+        ZG_HIP(hipEventRecord(root.t0, root.s_in));
+    }
+    // the root's own frames need no transfer: one launch on its compute stream, in place
+    if (!loop) {
+        uint32_t b, e;
+        shard_range(n_frames, 0, world, &b, &e);
+        ZG_HIP(hipSetDevice(root.device));
+        if (timed) ZG_HIP(hipEventRecord(root.t_run0, root.s_run));
+        if (e > b) {
+            const int rc = zg_batch_blur_resize((const char *)src_root + (size_t)b * in_frame, e - b, rows, cols, pixel, sigma,
+                                                (char *)dst_root + (size_t)b * out_frame, out_rows, out_cols, method, (zg_stream)root.s_run);
+            if (rc) return rc;
+        }
+        if (timed) ZG_HIP(hipEventRecord(root.t_run1, root.s_run));
+    }
+    for (int c = 0; c < m->chunks; ++c) {
+        // ---- scatter piece c ----
+        {
+            GroupScope g;
+            bool any = false;
+            for (int i = first_peer; i < world; ++i) {
+                uint32_t b, e;
+                piece(i, c, &b, &e);
+                if (e == b) continue;
+                if (!any) { ZG_NCCL(g.begin()); any = true; }
+                DeviceSlot &d = m->dev[(size_t)i];
+                const size_t bytes = (size_t)(e - b) * in_frame;
+                ZG_NCCL(g_rccl.Send((const char *)src_root + (size_t)b * in_frame, bytes, NCCL_UINT8, i, root.comm_in, root.s_in));
+                ZG_NCCL(g_rccl.Recv(staged(i, b, true), bytes, NCCL_UINT8, 0, d.comm_in, d.s_in));
+            }
+            if (any) ZG_NCCL(g.end());
+        }
+        // ---- compute piece c where it landed ----
+        for (int i = first_peer; i < world; ++i) {
+            uint32_t b, e;
+            piece(i, c, &b, &e);
+            if (e == b) continue;
+            DeviceSlot &d = m->dev[(size_t)i];
+            ZG_HIP(hipSetDevice(d.device));
+            ZG_HIP(hipEventRecord(d.arrived[c], d.s_in));
+            ZG_HIP(hipStreamWaitEvent(d.s_run, d.arrived[c], 0));
+            if (timed && c == 0) ZG_HIP(hipEventRecord(d.t_run0, d.s_run));
+            const int rc = zg_batch_blur_resize(staged(i, b, true), e - b, rows, cols, pixel, sigma, staged(i, b, false), out_rows, out_cols, method,
+                                                (zg_stream)d.s_run);
+            if (rc) return rc;
+            ZG_HIP(hipEventRecord(d.done[c], d.s_run));
+            ZG_HIP(hipStreamWaitEvent(d.s_out, d.done[c], 0));
+        }
+        // ---- gather piece c ----
+        {
+            GroupScope g;
+            bool any = false;
+            for (int i = first_peer; i < world; ++i) {
+                uint32_t b, e;
+                piece(i, c, &b, &e);
+                if (e == b) continue;
+                if (!any) { ZG_NCCL(g.begin()); any = true; }
+                DeviceSlot &d = m->dev[(size_t)i];
+                const size_t bytes = (size_t)(e - b) * out_frame;
+                ZG_NCCL(g_rccl.Send(staged(i, b, false), bytes, NCCL_UINT8, 0, d.comm_out, d.s_out));
+                ZG_NCCL(g_rccl.Recv((char *)dst_root + (size_t)b * out_frame, bytes, NCCL_UINT8, i, root.comm_out, root.s_out));
+            }
+            if (any) ZG_NCCL(g.end());
+        }
+    }
+    if (timed) {
+        ZG_HIP(hipSetDevice(root.device));
+        ZG_HIP(hipEventRecord(root.t_in, root.s_in));
+        for (int i = first_peer; i < world; ++i) {
+            uint32_t b, e;
+            shard_range(n_frames, i, world, &b, &e);
+            if (e == b || (i == 0 && !loop)) continue;
+            ZG_HIP(hipSetDevice(m->dev[(size_t)i].device));
+            ZG_HIP(hipEventRecord(m->dev[(size_t)i].t_run1, m->dev[(size_t)i].s_run));
+        }
+    }
+    return ZG_OK;
+}
+
+int sync_all(Multi *m) {
+    int rc = ZG_OK;
+    for (DeviceSlot &d : m->dev) {
+        if (hipSetDevice(d.device) != hipSuccess) { rc = ZG_ERR_HIP; continue; }
+        for (hipStream_t s : {d.s_in, d.s_run, d.s_out}) {
+            const hipError_t e = hipStreamSynchronize(s);
+            if (e != hipSuccess && rc == ZG_OK) rc = hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+        }
+    }
+    return rc;
+}
+
+} // namespace
 
 int zg_multi_batch_blur_resize(zg_multi handle, const void *src_frames_root, uint32_t n_frames, uint32_t rows, uint32_t cols, int pixel, float sigma,
                                void *dst_frames_root, uint32_t out_rows, uint32_t out_cols, const zg_method *method, float times_ms[3]) {
@@ -191,14 +385,14 @@ int zg_multi_batch_blur_resize(zg_multi handle, const void *src_frames_root, uin
     if (n_frames == 0 || rows == 0 || cols == 0 || out_rows == 0 || out_cols == 0) return ZG_OK;
     ZG_REQUIRE(src_frames_root && dst_frames_root, ZG_ERR_INVALID_ARGUMENT, "batch: null frame pointer");
     Multi *m = (Multi *)handle;
+    ZG_REQUIRE(!m->poisoned, ZG_ERR_INVALID_ARGUMENT, "zg_multi: an earlier call on this context failed half-way; destroy it and create a new one");
     const int world = (int)m->dev.size();
     const size_t ps = pixel_size(pixel), in_frame = (size_t)rows * cols * ps, out_frame = (size_t)out_rows * out_cols * ps;
     DeviceScope scope;
     DeviceSlot &root = m->dev[0];
-    ZG_HIP(hipSetDevice(root.device));
-    ZG_HIP(hipDeviceSynchronize()); // whatever produced the caller's frames on the root, on any of its streams, is complete
+    const double wall0 = now_ms();
 
-    // shard staging on the owners
+    // shard staging on the owners (before anything is enqueued: a failure here leaves the context usable)
     for (int i = 1; i < world; ++i) {
         uint32_t b, e;
         shard_range(n_frames, i, world, &b, &e);
@@ -207,75 +401,38 @@ int zg_multi_batch_blur_resize(zg_multi handle, const void *src_frames_root, uin
         if ((rc = ensure(&m->dev[(size_t)i].in, &m->dev[(size_t)i].in_bytes, (size_t)(e - b) * in_frame))) return rc;
         if ((rc = ensure(&m->dev[(size_t)i].out, &m->dev[(size_t)i].out_bytes, (size_t)(e - b) * out_frame))) return rc;
     }
-    void *loop_in = nullptr; // one-device diagnostics: the root's shard makes a round trip through the communicator first
-    if (world == 1 && m->loopback) {
+    if (world == 1 && m->loopback) { // one-device diagnostics: the root's shard makes the round trip through both communicators
         ZG_HIP(hipSetDevice(root.device));
         int rc;
         if ((rc = ensure(&root.in, &root.in_bytes, (size_t)n_frames * in_frame))) return rc;
-        loop_in = root.in;
+        if ((rc = ensure(&root.out, &root.out_bytes, (size_t)n_frames * out_frame))) return rc;
     }
-
-    auto sync_all = [&]() -> int {
-        for (DeviceSlot &d : m->dev) {
-            ZG_HIP(hipSetDevice(d.device));
-            ZG_HIP(hipStreamSynchronize(d.stream));
-        }
-        return ZG_OK;
-    };
-
-    // ---- scatter: one grouped launch, root sends shard i to device i, device i receives it --------------------------------
-    int rc;
-    double t0 = now_ms();
-    if (world > 1 || loop_in) {
-        ZG_NCCL(g_rccl.GroupStart());
-        for (int i = (loop_in ? 0 : 1); i < world; ++i) {
-            uint32_t b, e;
-            shard_range(n_frames, i, world, &b, &e);
-            if (e == b) continue;
-            const size_t bytes = (size_t)(e - b) * in_frame;
-            ZG_NCCL(g_rccl.Send((const char *)src_frames_root + (size_t)b * in_frame, bytes, NCCL_UINT8, i, root.comm, root.stream));
-            ZG_NCCL(g_rccl.Recv(i == 0 ? loop_in : m->dev[(size_t)i].in, bytes, NCCL_UINT8, 0, m->dev[(size_t)i].comm, m->dev[(size_t)i].stream));
-        }
-        ZG_NCCL(g_rccl.GroupEnd());
-        if (times_ms) {
-            if ((rc = sync_all())) return rc;
-            times_ms[0] = (float)(now_ms() - t0);
-        }
+    // Whatever produced the caller's frames: an event on the root's legacy default stream, which is ordered behind every blocking stream
+    // of the device, holds the three root streams back — no host synchronisation. Producers on non-blocking streams (PyTorch's side
+    // streams) are named with zg_multi_wait_stream, or synchronised by the caller.
+    {
+        const int rc = zg_multi_wait_stream(handle, nullptr);
+        if (rc) return rc;
     }
-
-    // ---- compute: every device runs the batch kernel on its shard, on its own stream -----------------------------------
-    t0 = now_ms();
-    for (int i = 0; i < world; ++i) {
-        uint32_t b, e;
-        shard_range(n_frames, i, world, &b, &e);
-        if (e == b) continue;
-        DeviceSlot &d = m->dev[(size_t)i];
-        ZG_HIP(hipSetDevice(d.device));
-        const void *in = i == 0 ? (loop_in ? loop_in : (const void *)((const char *)src_frames_root + (size_t)b * in_frame)) : d.in;
-        void *outp = i == 0 ? (void *)((char *)dst_frames_root + (size_t)b * out_frame) : d.out;
-        if ((rc = zg_batch_blur_resize(in, e - b, rows, cols, pixel, sigma, outp, out_rows, out_cols, method, (zg_stream)d.stream))) return rc;
+    int rc = run_batch(m, src_frames_root, n_frames, rows, cols, pixel, sigma, dst_frames_root, out_rows, out_cols, method, times_ms != nullptr);
+    const int src = sync_all(m); // results are complete on return; after a failure this also drains what was already enqueued
+    if (rc != ZG_OK || src != ZG_OK) {
+        m->poisoned = true; // shards may be half-way: no later call may trust the streams or the communicators
+        return rc != ZG_OK ? rc : src;
     }
     if (times_ms) {
-        if ((rc = sync_all())) return rc;
-        times_ms[1] = (float)(now_ms() - t0);
-    }
-
-    // ---- gather: the results travel back the same way (stream order on each device puts them behind its kernel) ----------
-    t0 = now_ms();
-    if (world > 1) {
-        ZG_NCCL(g_rccl.GroupStart());
-        for (int i = 1; i < world; ++i) {
+        float ms = 0;
+        (void)hipSetDevice(root.device);
+        if (hipEventElapsedTime(&ms, root.t0, root.t_in) == hipSuccess) times_ms[0] = ms; // the scatter stream, first send to last send
+        for (int i = 0; i < world; ++i) {
             uint32_t b, e;
             shard_range(n_frames, i, world, &b, &e);
             if (e == b) continue;
-            const size_t bytes = (size_t)(e - b) * out_frame;
-            ZG_NCCL(g_rccl.Send(m->dev[(size_t)i].out, bytes, NCCL_UINT8, 0, m->dev[(size_t)i].comm, m->dev[(size_t)i].stream));
-            ZG_NCCL(g_rccl.Recv((char *)dst_frames_root + (size_t)b * out_frame, bytes, NCCL_UINT8, i, root.comm, root.stream));
+            (void)hipSetDevice(m->dev[(size_t)i].device);
+            if (hipEventElapsedTime(&ms, m->dev[(size_t)i].t_run0, m->dev[(size_t)i].t_run1) == hipSuccess) times_ms[1] = std::max(times_ms[1], ms);
         }
-        ZG_NCCL(g_rccl.GroupEnd());
+        times_ms[2] = (float)(now_ms() - wall0);
     }
-    if ((rc = sync_all())) return rc;
-    if (times_ms) times_ms[2] = (float)(now_ms() - t0);
     return ZG_OK;
 }
 
