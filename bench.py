@@ -320,7 +320,17 @@ def resize_headline(zg, torch):
         pass
     dram = ROWS * COLS * 4 // 2 + 4 * 1024 * 1024
     achieved = alg / (ms * 1e-3) / 1e9
-    return {"workload": "resize(.bilinear) 4096x4096 -> 1024x1024 Rgba(u8), BASELINE.json configs[2]; one frame per launch, graph-replayed",
+    # the same resize as a step of zg_batch_pipeline over 16 frames per launch (one frame is 4 096 one-gather workgroups: launch ramp and tail)
+    nb = 16
+    del im, srcs
+    batches = [torch.randint(0, 256, (nb, ROWS, COLS, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]  # 2 GiB of sources
+    bouts = [torch.empty((nb, 1024, 1024, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    pipe = zg.Pipeline([zg.Step.resize(1024, 1024)])
+    bms = _time_kernel(torch, lambda i: pipe.run(batches[i % 2], out=bouts[i % 2]), n=8, warm=2) / nb
+    batched = {"frames_per_launch": nb, "ms_per_frame": round(bms, 5), "Mpixels/s_source": round(ROWS * COLS / bms / 1e3, 1),
+               "frac_strict": round(alg / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "frac_on_dram_granular_bytes": round(dram / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "kernel": "k_resize_bilinear_rgba8<1>, frame index in the grid (zg_batch_pipeline)"}
+    return {"workload": "resize(.bilinear) 4096x4096 -> 1024x1024 Rgba(u8), BASELINE.json configs[2]; one frame per launch, graph-replayed", "batched": batched,
             "ms_per_step": round(ms, 5), "Mpixels/s_source": round(ROWS * COLS / ms / 1e3, 1), "Mpixels/s_output": round(1024 * 1024 / ms / 1e3, 1),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "kernel": "k_resize_bilinear_rgba8<1>", "algorithmic_bytes_per_launch": alg,
@@ -724,6 +734,46 @@ def extras(zg, torch, np):
                 "encode_ms": round(enc * 1e3, 1), "encode_Mpixels/s": round(ROWS * COLS / enc / 1e6, 1), "encoded_MiB": round(len(ours) / 2**20, 1),
                 "note": "host-bound: Huffman decoding is one serial chain, coding runs in bands of MCU rows on up to 16 host threads; device share ~0.12 ms (IDCT 3 planes + render) / ~0.2 ms (forward DCT)"}
 
+    def box(kind, radius=2, sharpen=False):
+        ring = 8
+        shape = (ROWS, COLS, 4) if kind == "rgba" else (ROWS, COLS)
+        im = [(zg.Image(s), zg.Image(torch.empty_like(s))) for s in u8_frames(ring, shape)]
+        if sharpen:
+            ms = _time_kernel(torch, lambda i: im[i % ring][0].sharpen(radius, out=im[i % ring][1]), n=16, warm=3)
+        else:
+            ms = _time_kernel(torch, lambda i: im[i % ring][0].box_blur(radius, out=im[i % ring][1]), n=16, warm=3)
+        bpp = 8 if kind == "rgba" else 2
+        return rate(ms, ROWS * COLS, bpp * ROWS * COLS)
+
+    def conv3x3(kind):
+        ring = 4
+        if kind == "u8":
+            srcs, bpp = u8_frames(ring, (ROWS, COLS, 4)), 8
+        else:
+            srcs, bpp = [torch.rand((ROWS, COLS, 4), dtype=torch.float32, device="cuda") for _ in range(ring)], 32
+        im = [(zg.Image(s), zg.Image(torch.empty_like(s))) for s in srcs]
+        k = np.full((3, 3), 1.0 / 9.0, np.float32)
+        ms = _time_kernel(torch, lambda i: im[i % ring][0].convolve(k, zg.BorderMode.replicate, out=im[i % ring][1]), n=16, warm=3)
+        return rate(ms, ROWS * COLS, bpp * ROWS * COLS)
+
+    def fused_batch16():
+        nb = 16
+        srcs = [torch.randint(0, 256, (nb, ROWS, COLS, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        outs = [torch.empty((nb, 1024, 1024, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+        pipe = zg.Pipeline([zg.Step.resize(1024, 1024), zg.Step.convert(zg.CS_OKLAB)])
+        ms = _time_kernel(torch, lambda i: pipe.run(srcs[i % 2], out=outs[i % 2]), n=8, warm=2) / nb
+        r = rate(ms, ROWS * COLS, 28 * 1024 * 1024)
+        r["GB/s_sector_basis"] = round((ROWS * COLS * 4 // 2 + 12 * 1024 * 1024) / ms / 1e6, 1)
+        r["frames_per_launch"] = nb
+        return r
+
+    leg("s5_box_blur_r2_rgba_u8_4096", lambda: box("rgba"))
+    leg("s5_box_blur_r2_u8_4096", lambda: box("grey"))
+    leg("s5_box_blur_r1_u8_4096", lambda: box("grey", 1))
+    leg("s5_sharpen_r2_rgba_u8_4096", lambda: box("rgba", 2, True))
+    leg("s4_convolve_3x3_rgba_u8_4096", lambda: conv3x3("u8"))
+    leg("s4_convolve_3x3_rgba_f32_4096", lambda: conv3x3("f32"))
+    leg("config3_fused_resize_oklab_16_frames_per_launch", fused_batch16)
     leg("next_sobel_rgba_u8_4096", sobel)
     leg("next_pyramid_build_default_u8_4096", pyramid_build)
     leg("next_canny_rgba_u8_4096", canny)

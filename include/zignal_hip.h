@@ -412,6 +412,38 @@ ZG_API int zg_batch_blur_resize(const void *src_frames, uint32_t n_frames,
                                 void *dst_frames, uint32_t out_rows, uint32_t out_cols,
                                 const zg_method *method, zg_stream stream);
 
+/* The `pipeline` command in general (src/cli/pipeline.zig:153-179: `for (steps) |step| current = step.apply(current)` on every input image)
+ * over a batch of n_frames equally shaped images laid out back to back: frame f of the result is step[n-1](... step[0](frame f)).
+ * Every step runs as ONE launch over the whole batch where a batched kernel exists (the u8 Gaussians, Rgba(u8) bilinear resize,
+ * every conversion; a frame is too short a launch to fill the chip), frame by frame otherwise; consecutive steps the library has a
+ * fused kernel for ([gaussian blur, resize to half size] and [resize, convert to Oklab / Xyz] on Rgba(u8)) run as that kernel, the
+ * rest hands frames on through scratch. Results equal the per-frame calls bit for bit.
+ * Steps mirror the CLI's (blur: src/cli/blur.zig:98-128, resize: src/cli/resize.zig:77-99) plus convert and warp. */
+typedef enum zg_step_kind {
+    ZG_STEP_GAUSSIAN_BLUR = 0, /* Image.gaussianBlur(sigma) */
+    ZG_STEP_BOX_BLUR = 1,      /* Image.boxBlur(radius) */
+    ZG_STEP_RESIZE = 2,        /* Image.resize(out_rows x out_cols, method) */
+    ZG_STEP_CONVERT = 3,       /* Image.convert(dst_pixel / dst_space) */
+    ZG_STEP_WARP = 4           /* Image.warp(transform, m, method) into out_rows x out_cols */
+} zg_step_kind;
+typedef struct zg_step {
+    int kind;                    /* zg_step_kind */
+    float sigma;                 /* GAUSSIAN_BLUR */
+    uint32_t radius;             /* BOX_BLUR */
+    uint32_t out_rows, out_cols; /* RESIZE, WARP: the shape of the step's output frames */
+    zg_method method;            /* RESIZE, WARP */
+    int dst_pixel, dst_space;    /* CONVERT: zg_pixel, zg_colorspace of the step's output */
+    const float *srgb_lut;       /* CONVERT: as zg_convert (host pointer, may be NULL) */
+    int transform;               /* WARP: zg_transform */
+    float m[9];                  /* WARP: as zg_warp */
+} zg_step;
+/* Host only: shape and type of the frames after the steps (what dst_frames of zg_batch_pipeline must hold, n_frames times). */
+ZG_API int zg_batch_pipeline_shape(uint32_t rows, uint32_t cols, int pixel, int space, const zg_step *steps, uint32_t n_steps,
+                                   uint32_t *out_rows, uint32_t *out_cols, int *out_pixel, int *out_space);
+/* Device pointers; `space` is the colour space of the source frames (only CONVERT steps look at it). Asynchronous on `stream`. */
+ZG_API int zg_batch_pipeline(const void *src_frames, uint32_t n_frames, uint32_t rows, uint32_t cols, int pixel, int space,
+                             const zg_step *steps, uint32_t n_steps, void *dst_frames, zg_stream stream);
+
 /* ---- the node's GPUs from one host process (BASELINE configs[4]) --------------------------------------------------------------- */
 
 /* Two routes to several GPUs:

@@ -190,6 +190,41 @@ int main(int argc, char **argv) {
             EXPECT(zo_gaussian_blur(&zs, &zb, sigma) == 0 && zo_resize(&zb, &zw, &zbil) == 0);
             EXPECT(std::memcmp(want.data(), s0.data, (size_t)(rows / 2) * (cols / 2) * 4) == 0);
         }
+        { // the same recipe through the general batched pipeline (zg_batch_pipeline behind zignal::Pipeline), and a three-step one
+            Pipeline recipe;
+            recipe.gaussianBlur(sigma).resize(rows / 2, cols / 2);
+            uint32_t orows = 0, ocols = 0; int opix = -1;
+            recipe.outShape(rows, cols, ZG_PIXEL_RGBA_U8, ZG_CS_RGBA, orows, ocols, opix);
+            EXPECT(orows == rows / 2 && ocols == cols / 2 && opix == ZG_PIXEL_RGBA_U8);
+            std::vector<uint8_t> fill(out_bytes, 0x3C);
+            check(zg_memcpy_h2d(dout, fill.data(), out_bytes, nullptr));
+            recipe.run((const Rgba<uint8_t> *)dsrc, n, rows, cols, dout);
+            check(zg_memcpy_d2h(got.data(), dout, out_bytes, nullptr));
+            EXPECT(got == want);
+            Pipeline three;
+            three.resize(rows / 2, cols / 2).gaussianBlur(sigma).convert<Rgb<float>>();
+            three.outShape(rows, cols, ZG_PIXEL_RGBA_U8, ZG_CS_RGBA, orows, ocols, opix);
+            EXPECT(opix == ZG_PIXEL_RGB_F32);
+            void *dlab = nullptr;
+            const size_t lab_bytes = (size_t)n * orows * ocols * 12;
+            check(zg_malloc(&dlab, lab_bytes));
+            three.run((const Rgba<uint8_t> *)dsrc, n, rows, cols, dlab);
+            std::vector<float> lab(lab_bytes / 4);
+            check(zg_memcpy_d2h(lab.data(), dlab, lab_bytes, nullptr));
+            // frame 0 against the oracle: resize, blur, Rgba(u8) -> Rgb(f32) (c / 255)
+            Image<Rgba<uint8_t>> f0 = Image<Rgba<uint8_t>>::initFromSlice(rows, cols, (Rgba<uint8_t> *)frames.data());
+            auto r0 = Image<Rgba<uint8_t>>::init(rows / 2, cols / 2), b0 = Image<Rgba<uint8_t>>::init(rows / 2, cols / 2);
+            const zo_image zs = zo_of(f0), zr = zo_of(r0), zb = zo_of(b0);
+            const zo_method zbil = {ZO_BILINEAR, 0, 0, nullptr};
+            EXPECT(zo_resize(&zs, &zr, &zbil) == 0 && zo_gaussian_blur(&zr, &zb, sigma) == 0);
+            bool same = true;
+            for (size_t i = 0; i < (size_t)orows * ocols && same; ++i) {
+                const Rgba<uint8_t> px = b0.data[i];
+                same = lab[3 * i] == (float)px.r / 255.0f && lab[3 * i + 1] == (float)px.g / 255.0f && lab[3 * i + 2] == (float)px.b / 255.0f;
+            }
+            EXPECT(same);
+            check(zg_free(dlab));
+        }
         // one device, then the same with the shard looped through both RCCL communicators in 1, 3 and 8 pieces (communicator set-up
         // costs seconds, so the loop-back runs only in the full mode)
         struct Mode { int loop; const char *chunks; };

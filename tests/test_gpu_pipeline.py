@@ -1,0 +1,109 @@
+"""zg_batch_pipeline: the CLI's `pipeline` command (reference src/cli/pipeline.zig:153-179) over a batch of frames, against the
+per-frame Image methods (which the other GPU tests hold to the oracle) and, for the BASELINE recipes, against the oracle itself."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import zignal_amd as zg  # noqa: E402
+from zignal_amd import _lib as L  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+I = zg.Interpolation
+
+
+def frames_u8(oracle, seed, n, rows, cols, ch=4):
+    shape = (n, rows, cols) if ch == 1 else (n, rows, cols, ch)
+    return np.stack([oracle.synth_u8(seed + i, shape[1:]) for i in range(n)])
+
+
+def per_frame(host, fn):
+    return np.stack([fn(zg.Image(torch.from_numpy(f).cuda())).to_numpy() for f in host])
+
+
+def check(host, steps, ref, what, space=None):
+    got = zg.Pipeline(steps).run(torch.from_numpy(host).cuda(), space=space)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    want = per_frame(host, ref)
+    assert got.shape == want.shape and got.dtype == want.dtype, (what, got.shape, want.shape)
+    assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), f"{what}: batch differs from the per-frame calls"
+    return got
+
+
+def test_blur_resize_both_orders_against_the_oracle(oracle):
+    """the recipe [blur gaussian 0.6, resize 0.5 bilinear] of BASELINE configs[4] and its secondary order [resize, blur]."""
+    host = frames_u8(oracle, 5, 5, 270, 480)
+    bil = oracle.method(oracle.BILINEAR)
+    got = check(host, [zg.Step.gaussian_blur(0.6), zg.Step.resize(135, 240)], lambda im: im.gaussian_blur(0.6).resize((135, 240), I.bilinear), "[blur, resize]")
+    for f in range(host.shape[0]):
+        assert np.array_equal(got[f], oracle.resize(oracle.gaussian_blur(host[f], 0.6), (135, 240), bil))
+    got = check(host, [zg.Step.resize(135, 240), zg.Step.gaussian_blur(0.6)], lambda im: im.resize((135, 240), I.bilinear).gaussian_blur(0.6), "[resize, blur]")
+    for f in range(host.shape[0]):
+        assert np.array_equal(got[f], oracle.gaussian_blur(oracle.resize(host[f], (135, 240), bil), 0.6))
+
+
+def test_resize_convert_config3_recipe(oracle):
+    """BASELINE configs[2] as a recipe: resize(.bilinear) 4:1 then convert(Oklab f32), fused over the batch."""
+    host = frames_u8(oracle, 3, 3, 512, 768)
+    got = check(host, [zg.Step.resize(128, 192), zg.Step.convert(zg.CS_OKLAB)], lambda im: im.resize((128, 192), I.bilinear).convert(zg.CS_OKLAB, np.float32), "[resize, convert]")
+    want0 = oracle.convert(oracle.resize(host[0], (128, 192), oracle.method(oracle.BILINEAR)), oracle.CS_RGBA, oracle.CS_OKLAB, np.float32, 3)
+    assert np.array_equal(got[0].view(np.uint32), want0.view(np.uint32))
+    check(host, [zg.Step.resize(128, 192), zg.Step.convert(zg.CS_XYZ)], lambda im: im.resize((128, 192), I.bilinear).convert(zg.CS_XYZ, np.float32), "[resize, convert xyz]")
+    check(host, [zg.Step.resize(100, 333, I.bicubic), zg.Step.convert(zg.CS_LAB)], lambda im: im.resize((100, 333), I.bicubic).convert(zg.CS_LAB, np.float32), "[resize bicubic, convert lab]")
+
+
+@pytest.mark.parametrize("n", (1, 4, 9))
+def test_long_recipes_mixed_steps(oracle, n):
+    """Four and five steps, batched and per-frame kernels mixed, shapes and types changing along the way (ping-pong scratch)."""
+    host = frames_u8(oracle, 40, n, 96, 160)
+    tr = zg.AffineTransform(np.array([[0.9, 0.1], [-0.1, 0.9]], np.float32), np.array([3.0, -2.0], np.float32))
+    steps = [zg.Step.gaussian_blur(1.0), zg.Step.resize(120, 200, I.bilinear), zg.Step.box_blur(2), zg.Step.warp(tr, 64, 80, I.bicubic), zg.Step.convert(zg.CS_OKLAB)]
+    ref = lambda im: im.gaussian_blur(1.0).resize((120, 200), I.bilinear).box_blur(2).warp(tr, (64, 80), I.bicubic).convert(zg.CS_OKLAB, np.float32)  # noqa: E731
+    check(host, steps, ref, f"five steps, {n} frames")
+    check(host, steps[:4], lambda im: im.gaussian_blur(1.0).resize((120, 200), I.bilinear).box_blur(2).warp(tr, (64, 80), I.bicubic), f"four steps, {n} frames")
+    check(host, [zg.Step.convert(zg.CS_GRAY, np.uint8), zg.Step.gaussian_blur(2.5), zg.Step.resize(48, 80, I.nearest)],
+          lambda im: im.convert(zg.CS_GRAY, np.uint8).gaussian_blur(2.5).resize((48, 80), I.nearest), f"grey long blur, {n} frames")
+
+
+def test_other_pixel_types_and_single_steps(oracle):
+    f32 = np.stack([oracle.synth_f32(70 + i, (66, 130, 4)) for i in range(3)])
+    check(f32, [zg.Step.gaussian_blur(0.6), zg.Step.resize(33, 65)], lambda im: im.gaussian_blur(0.6).resize((33, 65), I.bilinear), "Rgba(f32) [blur, resize]")
+    rgb = frames_u8(oracle, 80, 4, 100, 256, 3)
+    check(rgb, [zg.Step.gaussian_blur(0.6)], lambda im: im.gaussian_blur(0.6), "Rgb(u8) blur")
+    check(rgb, [zg.Step.resize(50, 128), zg.Step.convert(zg.CS_HSV)], lambda im: im.resize((50, 128), I.bilinear).convert(zg.CS_HSV, np.float32), "Rgb(u8) [resize, convert hsv]")
+    grey = frames_u8(oracle, 90, 6, 128, 256, 1)
+    check(grey, [zg.Step.gaussian_blur(0.6), zg.Step.gaussian_blur(0.0)], lambda im: im.gaussian_blur(0.6), "grey blur + sigma 0 copy")
+    rgba = frames_u8(oracle, 95, 2, 64, 64)
+    check(rgba, [], lambda im: im, "no steps: copy")
+    check(rgba, [zg.Step.resize(64, 64)], lambda im: im, "equal-size resize: copy")
+    check(rgba, [zg.Step.resize(128, 256)], lambda im: im.resize((128, 256), I.bilinear), "upscale (four pixels per lane)")
+
+
+def test_validation_happens_before_any_work():
+    lib = zg.lib()
+    p = zg.Pipeline([zg.Step.gaussian_blur(0.6), zg.Step.gaussian_blur(-1.0)])
+    with pytest.raises(zg.InvalidArgument):
+        p.out_layout(10, 10, L.PIXEL_RGBA_U8, L.CS_RGBA)
+    bad = L.ZgStep()
+    bad.kind = 17
+    arr = (L.ZgStep * 1)(bad)
+    assert lib.zg_batch_pipeline_shape(4, 4, L.PIXEL_U8, L.CS_GRAY, arr, 1, None, None, None, None) == L.ERR_INVALID_ARGUMENT
+    t = torch.zeros((2, 8, 8, 4), dtype=torch.uint8, device="cuda")
+    with pytest.raises(zg.ZignalError):
+        zg.Pipeline([zg.Step.convert(zg.CS_OKLAB, np.uint8)]).run(t)  # float-only colour type into u8 pixels
+    with pytest.raises(ValueError):
+        zg.Pipeline([]).run(torch.zeros((2, 8, 8, 4), dtype=torch.uint8))  # host tensor
+
+
+def test_large_batch_goes_through_in_groups(oracle):
+    """Intermediates above the scratch budget: 40 frames of 1080p through three steps run as several groups, same bits."""
+    one = oracle.synth_u8(123, (1080, 1920, 4))
+    host = np.stack([np.roll(one, 7 * i, axis=1) for i in range(40)])
+    got = zg.Pipeline([zg.Step.gaussian_blur(0.6), zg.Step.resize(540, 960), zg.Step.gaussian_blur(0.6)]).run(torch.from_numpy(host).cuda())
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    for f in (0, 17, 39):
+        want = zg.Image(torch.from_numpy(host[f]).cuda()).gaussian_blur(0.6).resize((540, 960), I.bilinear).gaussian_blur(0.6).to_numpy()
+        assert np.array_equal(got[f], want), f

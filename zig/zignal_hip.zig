@@ -19,9 +19,55 @@ const Rectangle = zignal.Rectangle;
 const Point = zignal.Point;
 
 // ---- C ABI (include/zignal_hip.h) -----------------------------------------------------------------
+/// The `pipeline` command (src/cli/pipeline.zig:153-179) over a batch of equally shaped frames resident on the device: every frame
+/// goes through `steps` in order with one zg_batch_pipeline call (a launch per step over the whole batch where the library has a
+/// batched kernel, fused neighbours where it has a fused one). `src` / `dst` are device pointers (DeviceImage memory, zg_malloc).
+pub const Pipeline = struct {
+    steps: []const c.ZgStep,
+
+    pub fn gaussianBlur(sigma: f32) c.ZgStep {
+        return .{ .kind = 0, .sigma = sigma, .radius = 0, .out_rows = 0, .out_cols = 0, .method = .{ .kind = 0, .b = 0, .c = 0, .lanczos_lut = null }, .dst_pixel = 0, .dst_space = 0, .srgb_lut = null, .transform = 0, .m = [_]f32{0} ** 9 };
+    }
+    pub fn boxBlur(radius: u32) c.ZgStep {
+        var s = gaussianBlur(0);
+        s.kind = 1;
+        s.radius = radius;
+        return s;
+    }
+    pub fn resize(rows: u32, cols: u32, method: c.ZgMethod) c.ZgStep {
+        var s = gaussianBlur(0);
+        s.kind = 2;
+        s.out_rows = rows;
+        s.out_cols = cols;
+        s.method = method;
+        return s;
+    }
+    pub fn convert(dst_pixel: c_int, dst_space: c_int) c.ZgStep {
+        var s = gaussianBlur(0);
+        s.kind = 3;
+        s.dst_pixel = dst_pixel;
+        s.dst_space = dst_space;
+        return s;
+    }
+    /// rows, cols, pixel type and colour space of the frames after the steps
+    pub fn outShape(self: Pipeline, rows: u32, cols: u32, pixel: c_int, space: c_int) !struct { rows: u32, cols: u32, pixel: c_int, space: c_int } {
+        var r: u32 = 0;
+        var cc: u32 = 0;
+        var p: c_int = 0;
+        var sp: c_int = 0;
+        try check(c.zg_batch_pipeline_shape(rows, cols, pixel, space, self.steps.ptr, @intCast(self.steps.len), &r, &cc, &p, &sp));
+        return .{ .rows = r, .cols = cc, .pixel = p, .space = sp };
+    }
+    pub fn run(self: Pipeline, src: *const anyopaque, n_frames: u32, rows: u32, cols: u32, pixel: c_int, space: c_int, dst: *anyopaque, stream: ?*anyopaque) !void {
+        try check(c.zg_batch_pipeline(src, n_frames, rows, cols, pixel, space, self.steps.ptr, @intCast(self.steps.len), dst, stream));
+    }
+};
+
 pub const c = struct {
     pub const ZgImage = extern struct { data: ?*anyopaque, stride: usize, rows: u32, cols: u32, pixel: i32 };
     pub const ZgMethod = extern struct { kind: i32, b: f32, c: f32, lanczos_lut: ?[*]const f32 };
+    /// zg_step: one step of zg_batch_pipeline (kind: 0 gaussian blur, 1 box blur, 2 resize, 3 convert, 4 warp)
+    pub const ZgStep = extern struct { kind: c_int, sigma: f32, radius: u32, out_rows: u32, out_cols: u32, method: ZgMethod, dst_pixel: c_int, dst_space: c_int, srgb_lut: ?[*]const f32, transform: c_int, m: [9]f32 };
     pub extern fn zg_init(device: c_int) c_int;
     pub extern fn zg_last_error() [*:0]const u8;
     pub extern fn zg_conv_separable_host(src: *const ZgImage, dst: *const ZgImage, kx: [*]const f32, nkx: u32, ky: [*]const f32, nky: u32, border: c_int) c_int;
@@ -80,6 +126,8 @@ pub const c = struct {
     pub extern fn zg_resize_lanczos_weights_host(src: *const ZgImage, dst: *const ZgImage, wx: ?[*]const f32, wy: ?[*]const f32) c_int;
     pub extern fn zg_resize_convert(src: *const ZgImage, src_space: c_int, dst: *const ZgImage, dst_space: c_int, method: *const ZgMethod, srgb_lut: ?[*]const f32, stream: ?*anyopaque) c_int;
     pub extern fn zg_resize_convert_host(src: *const ZgImage, src_space: c_int, dst: *const ZgImage, dst_space: c_int, method: *const ZgMethod, srgb_lut: ?[*]const f32) c_int;
+    pub extern fn zg_batch_pipeline_shape(rows: u32, cols: u32, pixel: c_int, space: c_int, steps: ?[*]const ZgStep, n_steps: u32, out_rows: ?*u32, out_cols: ?*u32, out_pixel: ?*c_int, out_space: ?*c_int) c_int;
+    pub extern fn zg_batch_pipeline(src_frames: ?*const anyopaque, n_frames: u32, rows: u32, cols: u32, pixel: c_int, space: c_int, steps: ?[*]const ZgStep, n_steps: u32, dst_frames: ?*anyopaque, stream: ?*anyopaque) c_int;
     pub extern fn zg_multi_create(devices: ?[*]const c_int, n_devices: c_int, out: *?*anyopaque) c_int;
     pub extern fn zg_multi_destroy(m: ?*anyopaque) c_int;
     pub extern fn zg_multi_device_count(m: ?*anyopaque) c_int;

@@ -30,6 +30,16 @@ class ZgMethod(C.Structure):
     _fields_ = [("kind", C.c_int32), ("b", C.c_float), ("c", C.c_float), ("lanczos_lut", C.c_void_p)]
 
 
+class ZgStep(C.Structure):
+    """zg_step: one step of zg_batch_pipeline (the CLI's `pipeline` recipe steps, src/cli/pipeline.zig:20-24, plus convert and warp)."""
+    _fields_ = [("kind", C.c_int), ("sigma", C.c_float), ("radius", C.c_uint32), ("out_rows", C.c_uint32), ("out_cols", C.c_uint32),
+                ("method", ZgMethod), ("dst_pixel", C.c_int), ("dst_space", C.c_int), ("srgb_lut", C.c_void_p), ("transform", C.c_int),
+                ("m", C.c_float * 9)]
+
+
+STEP_GAUSSIAN_BLUR, STEP_BOX_BLUR, STEP_RESIZE, STEP_CONVERT, STEP_WARP = range(5)
+
+
 class ZgPngHeader(C.Structure):
     """zg_png_header == png.Header (png.zig:135-149)."""
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("bit_depth", C.c_uint8), ("color_type", C.c_uint8),
@@ -132,6 +142,8 @@ _SIGNATURES = {
     "zg_resize_lanczos_weights_host": [_IMG, _IMG, _F32P, _F32P],
     "zg_resize_convert": [_IMG, C.c_int, _IMG, C.c_int, _METHOD, _F32P, C.c_void_p],
     "zg_resize_convert_host": [_IMG, C.c_int, _IMG, C.c_int, _METHOD, _F32P],
+    "zg_batch_pipeline_shape": [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(ZgStep), C.c_uint32, _U32P, _U32P, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "zg_batch_pipeline": [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(ZgStep), C.c_uint32, C.c_void_p, C.c_void_p],
     "zg_multi_create": [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)],
     "zg_multi_destroy": [C.c_void_p],
     "zg_multi_device_count": [C.c_void_p],

@@ -427,4 +427,32 @@ template <typename T> class DeviceImage : public detail::Ops<DeviceImage, T> {
     zg_stream stream_ = nullptr;
 };
 
+// The `pipeline` command (src/cli/pipeline.zig:153-179) over a batch of equally shaped frames resident on the device: a recipe is a
+// list of steps, `run` sends every frame through them in order with one zg_batch_pipeline call (a launch per step over the whole
+// batch where the library has a batched kernel, fused neighbours where it has a fused one; equal to the per-frame methods bit for bit).
+struct Pipeline {
+    std::vector<zg_step> steps;
+    Pipeline &gaussianBlur(float sigma) { zg_step s{}; s.kind = ZG_STEP_GAUSSIAN_BLUR; s.sigma = sigma; steps.push_back(s); return *this; }              // cli/blur.zig:113-120
+    Pipeline &boxBlur(uint32_t radius) { zg_step s{}; s.kind = ZG_STEP_BOX_BLUR; s.radius = radius; steps.push_back(s); return *this; }                  // cli/blur.zig:109-112
+    Pipeline &resize(uint32_t rows, uint32_t cols, Interpolation method = Interpolation::bilinear()) {                                                // cli/resize.zig:77-99
+        zg_step s{}; s.kind = ZG_STEP_RESIZE; s.out_rows = rows; s.out_cols = cols; s.method = method.c_method(); steps.push_back(s); return *this;
+    }
+    template <typename Target> Pipeline &convert() {                                                                                                  // image.zig:418
+        zg_step s{}; s.kind = ZG_STEP_CONVERT; s.dst_pixel = PixelTraits<Target>::pixel; s.dst_space = PixelTraits<Target>::space; steps.push_back(s); return *this;
+    }
+    Pipeline &warp(int transform, const float *m, int n_coefficients, uint32_t rows, uint32_t cols, Interpolation method = Interpolation::bilinear()) {  // image.zig:621
+        zg_step s{}; s.kind = ZG_STEP_WARP; s.transform = transform; s.out_rows = rows; s.out_cols = cols; s.method = method.c_method();
+        for (int i = 0; i < n_coefficients && i < 9; ++i) s.m[i] = m[i];
+        steps.push_back(s); return *this;
+    }
+    // shape and type of the frames after the steps
+    void outShape(uint32_t rows, uint32_t cols, int pixel, int space, uint32_t &out_rows, uint32_t &out_cols, int &out_pixel) const {
+        check(zg_batch_pipeline_shape(rows, cols, pixel, space, steps.data(), (uint32_t)steps.size(), &out_rows, &out_cols, &out_pixel, nullptr));
+    }
+    // n frames of Src, rows x cols each, back to back at `src` (device memory) -> frames of Dst at `dst` (device memory, n * outShape)
+    template <typename Src> void run(const Src *src, uint32_t n_frames, uint32_t rows, uint32_t cols, void *dst, zg_stream stream = nullptr) const {
+        check(zg_batch_pipeline(src, n_frames, rows, cols, PixelTraits<Src>::pixel, PixelTraits<Src>::space, steps.data(), (uint32_t)steps.size(), dst, stream));
+    }
+};
+
 } // namespace zignal

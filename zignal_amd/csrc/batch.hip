@@ -9,7 +9,9 @@
 //   * anything else: gaussianBlur + resize per frame.
 #include "zg_common.h"
 
+#include <algorithm>
 #include <cmath>
+#include <functional>
 #include <vector>
 
 namespace zg {
@@ -23,9 +25,213 @@ struct Rgba8Batch {
 int try_sep_rgba8_batch(const Rgba8Batch &b, const int32_t *ix, const int32_t *iy, int nk, int border, hipStream_t s);
 }
 
+namespace zg {
+int convert_impl(const zg_image *src, int src_space, const zg_image *dst, int dst_space, const float *srgb_lut, hipStream_t s);
+
+namespace {
+
+struct Frames { // n equally shaped frames back to back
+    void *data;
+    uint32_t n, rows, cols;
+    int pixel, space;
+    size_t frame_bytes() const { return (size_t)rows * cols * pixel_size(pixel); }
+    zg_image frame(uint32_t i) const { return zg_image{(char *)data + (size_t)i * frame_bytes(), cols, rows, cols, pixel}; }
+};
+
+// the integer taps convolveSeparable derives from gaussianBlur's f32 taps (convolution.zig:303-309), when the kernel is short
+int gaussian_taps_u8(float sigma, std::vector<int32_t> &taps) {
+    taps.clear();
+    float f[255];
+    int n = zg_gaussian_kernel(sigma, nullptr, 0);
+    if (n < 0) return -n;
+    if (n > 255) return ZG_OK; // long kernels: the per-frame path
+    n = zg_gaussian_kernel(sigma, f, 255);
+    if (n < 0) return -n;
+    taps.resize((size_t)n);
+    for (int i = 0; i < n; ++i) taps[(size_t)i] = (int32_t)std::round(f[i] * 256.0f);
+    return ZG_OK;
+}
+
+int apply_shape(const zg_step &st, Frames &f) { // what a step does to shape and type; validates the step
+    switch (st.kind) {
+    case ZG_STEP_GAUSSIAN_BLUR:
+        ZG_REQUIRE(st.sigma >= 0, ZG_ERR_INVALID_ARGUMENT, "pipeline: InvalidSigma (%g)", st.sigma);
+        return ZG_OK;
+    case ZG_STEP_BOX_BLUR: return ZG_OK;
+    case ZG_STEP_RESIZE:
+    case ZG_STEP_WARP:
+        ZG_REQUIRE(st.method.kind >= ZG_INTERP_NEAREST && st.method.kind <= ZG_INTERP_LANCZOS, ZG_ERR_INVALID_ARGUMENT, "pipeline: invalid interpolation method %d", st.method.kind);
+        if (st.kind == ZG_STEP_WARP) ZG_REQUIRE(st.transform >= ZG_TRANSFORM_SIMILARITY && st.transform <= ZG_TRANSFORM_PROJECTIVE, ZG_ERR_INVALID_ARGUMENT, "pipeline: invalid transform %d", st.transform);
+        f.rows = st.out_rows;
+        f.cols = st.out_cols;
+        return ZG_OK;
+    case ZG_STEP_CONVERT:
+        ZG_REQUIRE(pixel_valid(st.dst_pixel), ZG_ERR_INVALID_ARGUMENT, "pipeline: invalid pixel type %d", st.dst_pixel);
+        ZG_REQUIRE(st.dst_space >= ZG_CS_GRAY && st.dst_space <= ZG_CS_XYB, ZG_ERR_INVALID_ARGUMENT, "pipeline: invalid colour space %d", st.dst_space);
+        f.pixel = st.dst_pixel;
+        f.space = st.dst_space;
+        return ZG_OK;
+    }
+    set_error("pipeline: unknown step kind %d", st.kind);
+    return ZG_ERR_INVALID_ARGUMENT;
+}
+
+int per_frame(const Frames &in, const Frames &out, const std::function<int(const zg_image *, const zg_image *)> &op) {
+    for (uint32_t i = 0; i < in.n; ++i) {
+        const zg_image a = in.frame(i), b = out.frame(i);
+        if (const int rc = op(&a, &b)) return rc;
+    }
+    return ZG_OK;
+}
+
+int run_blur(const Frames &in, const Frames &out, float sigma, hipStream_t s) {
+    if (sigma == 0) { ZG_HIP(hipMemcpyAsync(out.data, in.data, in.n * in.frame_bytes(), hipMemcpyDeviceToDevice, s)); return ZG_OK; } // image.zig:966
+    if (!pixel_is_float(in.pixel)) {
+        std::vector<int32_t> taps;
+        if (const int rc = gaussian_taps_u8(sigma, taps)) return rc;
+        if (!taps.empty()) {
+            const size_t sp = pixel_size(in.pixel);
+            const StreamJob job{in.data, out.data, in.n, in.rows, in.cols, (int)sp, in.cols * sp, in.cols * sp, in.frame_bytes(), in.frame_bytes(), false};
+            const int rc = try_sep_stream(job, taps.data(), taps.data(), (int)taps.size(), ZG_BORDER_MIRROR, s);
+            if (rc >= 0) return rc;
+        }
+    }
+    return per_frame(in, out, [&](const zg_image *a, const zg_image *b) { return zg_gaussian_blur(a, b, sigma, (zg_stream)s); });
+}
+
+int run_resize(const Frames &in, const Frames &out, const zg_method &method, hipStream_t s) {
+    if (method.kind == ZG_INTERP_BILINEAR && in.n > 0) {
+        const zg_image a = in.frame(0), b = out.frame(0);
+        const int rc = resize_bilinear_rgba8_frames(&a, &b, in.n, in.frame_bytes(), out.frame_bytes(), s);
+        if (rc >= 0) return rc;
+    }
+    return per_frame(in, out, [&](const zg_image *a, const zg_image *b) { return resize_impl(a, b, &method, s); });
+}
+
+int run_convert(const Frames &in, const Frames &out, const float *lut, hipStream_t s) {
+    // per pixel, and the frames are contiguous: the batch is one tall image
+    const uint64_t tall = (uint64_t)in.rows * in.n;
+    if (tall <= 0x7fffffffu) {
+        const zg_image a{in.data, in.cols, (uint32_t)tall, in.cols, in.pixel}, b{out.data, out.cols, (uint32_t)tall, out.cols, out.pixel};
+        return convert_impl(&a, in.space, &b, out.space, lut, s);
+    }
+    return per_frame(in, out, [&](const zg_image *a, const zg_image *b) { return convert_impl(a, in.space, b, out.space, lut, s); });
+}
+
+// steps [i, i + 2) as one fused launch over the batch, or -1
+int run_fused_pair(const zg_step &s0, const zg_step &s1, const Frames &in, const Frames &out, hipStream_t s) {
+    if (s0.kind == ZG_STEP_GAUSSIAN_BLUR && s1.kind == ZG_STEP_RESIZE && in.pixel == ZG_PIXEL_RGBA_U8 && s0.sigma > 0 && s1.method.kind == ZG_INTERP_BILINEAR &&
+        in.rows == 2 * out.rows && in.cols == 2 * out.cols) {
+        std::vector<int32_t> taps;
+        if (const int rc = gaussian_taps_u8(s0.sigma, taps)) return rc;
+        if (taps.empty()) return -1;
+        const StreamJob job{in.data, out.data, in.n, in.rows, in.cols, 4, (size_t)in.cols * 4, (size_t)out.cols * 4, in.frame_bytes(), out.frame_bytes(), true};
+        return try_sep_stream(job, taps.data(), taps.data(), (int)taps.size(), ZG_BORDER_MIRROR, s);
+    }
+    if (s0.kind == ZG_STEP_RESIZE && s1.kind == ZG_STEP_CONVERT && in.space == ZG_CS_RGBA && s0.method.kind == ZG_INTERP_BILINEAR && in.n > 0) {
+        const zg_image a = in.frame(0), b = out.frame(0);
+        return resize_convert_rgba8_frames(&a, &b, s1.dst_space, in.n, in.frame_bytes(), out.frame_bytes(), s1.srgb_lut, s);
+    }
+    return -1;
+}
+
+} // namespace
+} // namespace zg
+
 using namespace zg;
 
 extern "C" {
+
+int zg_batch_pipeline_shape(uint32_t rows, uint32_t cols, int pixel, int space, const zg_step *steps, uint32_t n_steps, uint32_t *out_rows, uint32_t *out_cols,
+                            int *out_pixel, int *out_space) {
+    ZG_REQUIRE(pixel_valid(pixel), ZG_ERR_INVALID_ARGUMENT, "pipeline: invalid pixel type %d", pixel);
+    ZG_REQUIRE(n_steps == 0 || steps != nullptr, ZG_ERR_INVALID_ARGUMENT, "pipeline: null steps");
+    Frames f{nullptr, 0, rows, cols, pixel, space};
+    for (uint32_t i = 0; i < n_steps; ++i)
+        if (const int rc = apply_shape(steps[i], f)) return rc;
+    if (out_rows) *out_rows = f.rows;
+    if (out_cols) *out_cols = f.cols;
+    if (out_pixel) *out_pixel = f.pixel;
+    if (out_space) *out_space = f.space;
+    return ZG_OK;
+}
+
+int zg_batch_pipeline(const void *src_frames, uint32_t n_frames, uint32_t rows, uint32_t cols, int pixel, int space, const zg_step *steps, uint32_t n_steps,
+                      void *dst_frames, zg_stream stream) {
+    ZG_REQUIRE(pixel_valid(pixel), ZG_ERR_INVALID_ARGUMENT, "pipeline: invalid pixel type %d", pixel);
+    ZG_REQUIRE(n_steps == 0 || steps != nullptr, ZG_ERR_INVALID_ARGUMENT, "pipeline: null steps");
+    hipStream_t s = as_stream(stream);
+    // shapes after every step (validates all steps before anything is enqueued, like the CLI validates its recipe first: pipeline.zig:108-114)
+    std::vector<Frames> shape(n_steps + 1);
+    shape[0] = Frames{nullptr, 0, rows, cols, pixel, space};
+    size_t widest = 0; // bytes per frame of the largest intermediate
+    for (uint32_t i = 0; i < n_steps; ++i) {
+        shape[i + 1] = shape[i];
+        if (const int rc = apply_shape(steps[i], shape[i + 1])) return rc;
+        if (i + 1 < n_steps) widest = std::max(widest, shape[i + 1].frame_bytes());
+    }
+    if (n_frames == 0 || rows == 0 || cols == 0) return ZG_OK;
+    ZG_REQUIRE(src_frames && dst_frames, ZG_ERR_INVALID_ARGUMENT, "pipeline: null frame pointer");
+    for (const Frames &f : shape) ZG_REQUIRE(f.rows > 0 && f.cols > 0, ZG_ERR_INVALID_ARGUMENT, "pipeline: a step produces empty frames");
+    if (n_steps == 0) {
+        ZG_HIP(hipMemcpyAsync(dst_frames, src_frames, (size_t)n_frames * shape[0].frame_bytes(), hipMemcpyDeviceToDevice, s));
+        return ZG_OK;
+    }
+    // which steps run fused with their successor
+    std::vector<char> fused_with_next(n_steps, 0);
+    // Frames go through in groups: two ping-pong scratch blocks of at most ~1 GiB each hold a group's intermediates (a 1024-frame
+    // 1080p batch has 8.5 GB of them; nothing is gained by keeping more than a chip-filling group in flight).
+    const size_t budget = (size_t)1 << 30;
+    const uint32_t group = widest ? (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, budget / widest)) : n_frames;
+    void *ping[2] = {nullptr, nullptr};
+    int rc = ZG_OK;
+    if (widest) {
+        if ((rc = scratch_alloc(&ping[0], (size_t)group * widest, s))) return rc;
+        if (n_steps > 2 && (rc = scratch_alloc(&ping[1], (size_t)group * widest, s))) { scratch_free(ping[0], s); return rc; }
+    }
+    for (uint32_t g0 = 0; g0 < n_frames && rc == ZG_OK; g0 += group) {
+        const uint32_t gn = std::min(group, n_frames - g0);
+        Frames cur = shape[0];
+        cur.n = gn;
+        cur.data = (char *)src_frames + (size_t)g0 * shape[0].frame_bytes();
+        int flip = 0;
+        for (uint32_t i = 0; i < n_steps && rc == ZG_OK;) {
+            // try the step together with its successor
+            uint32_t take = 1;
+            if (i + 1 < n_steps) {
+                Frames two = shape[i + 2];
+                two.n = gn;
+                two.data = i + 2 == n_steps ? (void *)((char *)dst_frames + (size_t)g0 * shape[n_steps].frame_bytes()) : ping[flip];
+                const int rf = run_fused_pair(steps[i], steps[i + 1], cur, two, s);
+                if (rf >= 0) {
+                    rc = rf;
+                    take = 2;
+                    cur = two;
+                    if (i + 2 != n_steps) flip ^= 1;
+                }
+            }
+            if (take == 1) {
+                Frames next = shape[i + 1];
+                next.n = gn;
+                next.data = i + 1 == n_steps ? (void *)((char *)dst_frames + (size_t)g0 * shape[n_steps].frame_bytes()) : ping[flip];
+                const zg_step &st = steps[i];
+                switch (st.kind) {
+                case ZG_STEP_GAUSSIAN_BLUR: rc = run_blur(cur, next, st.sigma, s); break;
+                case ZG_STEP_BOX_BLUR: rc = per_frame(cur, next, [&](const zg_image *a, const zg_image *b) { return zg_box_blur(a, b, st.radius, stream); }); break;
+                case ZG_STEP_RESIZE: rc = run_resize(cur, next, st.method, s); break;
+                case ZG_STEP_CONVERT: rc = run_convert(cur, next, st.srgb_lut, s); break;
+                default: rc = per_frame(cur, next, [&](const zg_image *a, const zg_image *b) { return zg_warp(a, b, st.transform, st.m, &st.method, stream); }); break;
+                }
+                cur = next;
+                if (i + 1 != n_steps) flip ^= 1;
+            }
+            i += take;
+        }
+    }
+    scratch_free(ping[0], s);
+    scratch_free(ping[1], s);
+    return rc;
+}
 
 int zg_batch_blur_resize(const void *src_frames, uint32_t n_frames, uint32_t rows, uint32_t cols, int pixel, float sigma,
                          void *dst_frames, uint32_t out_rows, uint32_t out_cols, const zg_method *method, zg_stream stream) {

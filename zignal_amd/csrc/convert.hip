@@ -174,7 +174,7 @@ static int space_channels(int space) { return space == ZG_CS_GRAY ? 1 : (space =
 int copy_impl(const zg_image *src, const zg_image *dst, hipStream_t s);
 int convert_spaces_impl(const zg_image *src, int src_space, const zg_image *dst, int dst_space, const float *srgb_lut_dev, hipStream_t s);
 
-static int convert_impl(const zg_image *src, int src_space, const zg_image *dst, int dst_space, const float *srgb_lut, hipStream_t s) {
+int convert_impl(const zg_image *src, int src_space, const zg_image *dst, int dst_space, const float *srgb_lut, hipStream_t s) {
     int rc;
     if ((rc = check_image(src, "src")) || (rc = check_image(dst, "dst"))) return rc;
     ZG_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, ZG_ERR_DIMENSION_MISMATCH, "convert: shapes differ");
@@ -227,11 +227,15 @@ static int convert_impl(const zg_image *src, int src_space, const zg_image *dst,
 int resize_impl(const zg_image *src, const zg_image *dst, const zg_method *method, hipStream_t s);
 
 template <bool OKLAB>
-__global__ __launch_bounds__(256) void k_resize_bilinear_rgba8_to_lab(DImg src, DImg dst, float ratio_x, float ratio_y, int tiles_x, const float *srgb_lut) {
+__global__ __launch_bounds__(256) void k_resize_bilinear_rgba8_to_lab(DImg src, DImg dst, float ratio_x, float ratio_y, int tiles_x, const float *srgb_lut, FrameSpan fr) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
     if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    const int frame = wg / fr.tiles_per_frame; // a batch of equally shaped frames in one launch (batch.hip)
+    wg -= frame * fr.tiles_per_frame;
+    src.data = (char *)src.data + (size_t)frame * fr.src_frame;
+    dst.data = (char *)dst.data + (size_t)frame * fr.dst_frame;
     const int tyi = wg / tiles_x, txi = wg - tyi * tiles_x;
     const int c = txi * 64 + (int)(threadIdx.x & 63);
     const int r = __builtin_amdgcn_readfirstlane(tyi * 4 + (int)(threadIdx.x >> 6));
@@ -254,6 +258,30 @@ __global__ __launch_bounds__(256) void k_resize_bilinear_rgba8_to_lab(DImg src, 
     o[0] = o0; o[1] = o1; o[2] = o2;
 }
 
+// [resize(.bilinear), convert(Oklab | Xyz f32)] of n Rgba(u8) frames in one launch; -1 when the fused kernel does not apply.
+int resize_convert_rgba8_frames(const zg_image *src, const zg_image *dst, int dst_space, uint32_t n, size_t src_frame, size_t dst_frame, const float *srgb_lut,
+                                hipStream_t s) {
+    const bool fused = src->pixel == ZG_PIXEL_RGBA_U8 && dst->pixel == ZG_PIXEL_RGB_F32 && (dst_space == ZG_CS_OKLAB || dst_space == ZG_CS_XYZ) && src->rows > 0 &&
+                       src->cols >= 2 && dst->rows > 0 && dst->cols > 0 && n > 0 && !(src->rows == dst->rows && src->cols == dst->cols);
+    if (!fused) return -1;
+    const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, 4);
+    const uint64_t grid = (uint64_t)tiles_x * tiles_y * n;
+    if (grid > 0x7fffffffu) return -1;
+    const float *lut_dev = nullptr;
+    float *owned = nullptr;
+    if (int rc = device_srgb_lut(srgb_lut, s, &lut_dev, &owned)) return rc;
+    const float ratio_x = (float)src->cols / (float)dst->cols, ratio_y = (float)src->rows / (float)dst->rows;
+    const FrameSpan fr{src_frame, dst_frame, tiles_x * tiles_y};
+    if (dst_space == ZG_CS_OKLAB)
+        hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<true>, dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr);
+    else
+        hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<false>, dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr);
+    const hipError_t e = hipGetLastError();
+    if (owned) scratch_free(owned, s);
+    ZG_HIP(e);
+    return ZG_OK;
+}
+
 static int resize_convert_impl(const zg_image *src, int src_space, const zg_image *dst, int dst_space, const zg_method *method,
                                const float *srgb_lut, hipStream_t s) {
     int rc;
@@ -261,23 +289,9 @@ static int resize_convert_impl(const zg_image *src, int src_space, const zg_imag
     ZG_REQUIRE(method != nullptr && method->kind >= ZG_INTERP_NEAREST && method->kind <= ZG_INTERP_LANCZOS, ZG_ERR_INVALID_ARGUMENT, "resize + convert: invalid interpolation method");
     ZG_REQUIRE(src_space >= ZG_CS_GRAY && src_space <= ZG_CS_XYB && dst_space >= ZG_CS_GRAY && dst_space <= ZG_CS_XYB, ZG_ERR_INVALID_ARGUMENT, "resize + convert: invalid colour space");
     if (dst->rows == 0 || dst->cols == 0) return ZG_OK;
-    const bool fused = src->pixel == ZG_PIXEL_RGBA_U8 && src_space == ZG_CS_RGBA && dst->pixel == ZG_PIXEL_RGB_F32 &&
-                       (dst_space == ZG_CS_OKLAB || dst_space == ZG_CS_XYZ) && method->kind == ZG_INTERP_BILINEAR && src->rows > 0 && src->cols >= 2 &&
-                       !(src->rows == dst->rows && src->cols == dst->cols);
-    if (fused) {
-        const float *lut_dev = nullptr;
-        float *owned = nullptr;
-        if ((rc = device_srgb_lut(srgb_lut, s, &lut_dev, &owned))) return rc;
-        const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, 4);
-        const float ratio_x = (float)src->cols / (float)dst->cols, ratio_y = (float)src->rows / (float)dst->rows;
-        if (dst_space == ZG_CS_OKLAB)
-            hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<true>, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev);
-        else
-            hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<false>, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev);
-        const hipError_t e = hipGetLastError();
-        if (owned) scratch_free(owned, s);
-        ZG_HIP(e);
-        return ZG_OK;
+    if (src_space == ZG_CS_RGBA && method->kind == ZG_INTERP_BILINEAR) {
+        const int rcf = resize_convert_rgba8_frames(src, dst, dst_space, 1, 0, 0, srgb_lut, s);
+        if (rcf >= 0) return rcf;
     }
     // every other combination: the two steps as they are, through a resized image that lives in scratch for the call
     zg_image mid = *src;

@@ -302,13 +302,20 @@ static int axis_table(int kind, uint32_t src_n, uint32_t dst_n, int taps, AxisTa
 //     four destination pixels per lane, the row taps computed once, one 16-byte store.
 //     For strong downscales NPX = 4 is slower (12.2 us against 8.8 us for 4096^2 -> 1024^2: the lanes of one gather
 //     instruction then sit 256 bytes apart instead of 16), so those keep one pixel per lane.
+// A launch covers `frames` equally shaped images laid out `src_frame` / `dst_frame` bytes apart (a batch of the pipeline, batch.hip):
+// a 4096^2 -> 1024^2 frame is 4 096 workgroups of one gather each, i.e. launch ramp and tail; sixteen of them in one grid keep the chip
+// full (profiles/r03_batched_resize.txt).
 template <int NPX>
-__global__ __launch_bounds__(256) void k_resize_bilinear_rgba8(DImg src, DImg dst, float ratio_x, float ratio_y, int tiles_x) {
+__global__ __launch_bounds__(256) void k_resize_bilinear_rgba8(DImg src, DImg dst, float ratio_x, float ratio_y, int tiles_x, FrameSpan fr) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
     if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    const int frame = wg / fr.tiles_per_frame;
+    wg -= frame * fr.tiles_per_frame;
+    src.data = (char *)src.data + (size_t)frame * fr.src_frame;
+    dst.data = (char *)dst.data + (size_t)frame * fr.dst_frame;
     const int tyi = wg / tiles_x, txi = wg - tyi * tiles_x;
     const int c0 = (txi * 64 + (int)(threadIdx.x & 63)) * NPX;
     const int r = __builtin_amdgcn_readfirstlane(tyi * 4 + (int)(threadIdx.x >> 6)); // one row per wave
@@ -337,22 +344,30 @@ __global__ __launch_bounds__(256) void k_resize_bilinear_rgba8(DImg src, DImg ds
     else o[0] = out[0];
 }
 
+// Image(Rgba(u8)).resize(.bilinear) of n frames in one launch; -1 when the fast kernel does not apply (the caller goes frame by frame).
+int resize_bilinear_rgba8_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s) {
+    if (src->pixel != ZG_PIXEL_RGBA_U8 || dst->pixel != ZG_PIXEL_RGBA_U8 || src->cols < 2 || src->rows == 0 || dst->rows == 0 || dst->cols == 0 || n == 0) return -1;
+    if (src->rows == dst->rows && src->cols == dst->cols) return -1; // equal sizes are a copy (interpolation.zig:100-108)
+    const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, 4);
+    const float ratio_x = (float)src->cols / (float)dst->cols, ratio_y = (float)src->rows / (float)dst->rows;
+    const bool x4 = ratio_x <= 1.5f && dst->cols % 4 == 0 && dst->stride % 4 == 0 && ((uintptr_t)dst->data & 15) == 0 && dst_frame % 16 == 0;
+    const int tx = x4 ? (int)ceil_div(dst->cols, 256) : tiles_x;
+    const uint64_t grid = (uint64_t)tx * tiles_y * n;
+    if (grid > 0x7fffffffu) return -1;
+    const FrameSpan fr{src_frame, dst_frame, tx * tiles_y};
+    if (x4) hipLaunchKernelGGL(k_resize_bilinear_rgba8<4>, dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr);
+    else hipLaunchKernelGGL(k_resize_bilinear_rgba8<1>, dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
 template <int PIX, int CLS, int KIND, int T>
 static int launch_planes(const zg_image *src, const zg_image *dst, const AxisTable &tx, const AxisTable &ty, hipStream_t s) {
     const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, 4);
     const float ratio_x = (float)src->cols / (float)dst->cols, ratio_y = (float)src->rows / (float)dst->rows;
     if constexpr (PIX == ZG_PIXEL_RGBA_U8 && CLS == RC_BILINEAR) {
-        if (src->cols >= 2) {
-            const bool x4 = ratio_x <= 1.5f && dst->cols % 4 == 0 && dst->stride % 4 == 0 && ((uintptr_t)dst->data & 15) == 0;
-            if (x4) {
-                const int tx4 = (int)ceil_div(dst->cols, 256);
-                hipLaunchKernelGGL(k_resize_bilinear_rgba8<4>, dim3((unsigned)(tx4 * tiles_y)), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx4);
-            } else {
-                hipLaunchKernelGGL(k_resize_bilinear_rgba8<1>, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x);
-            }
-            ZG_HIP(hipGetLastError());
-            return ZG_OK;
-        }
+        const int rcb = resize_bilinear_rgba8_frames(src, dst, 1, 0, 0, s);
+        if (rcb >= 0) return rcb;
     }
     hipLaunchKernelGGL((k_resize_planes<PIX, CLS, KIND, T>), dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, dimg(src), dimg(dst), tx, ty,
                        ratio_x, ratio_y, tiles_x);

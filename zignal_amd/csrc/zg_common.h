@@ -194,6 +194,15 @@ int upload_pageable_rows(void *dst_dev, const void *src_host, size_t spitch, siz
 int download_pageable(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s);
 int download_pageable_rows(void *dst_host, size_t dpitch, const void *src_dev, size_t width, size_t rows, hipStream_t s);
 
+// Frames of a batch inside one launch: bytes from one frame to the next on both sides, workgroups (tiles) per frame.
+struct FrameSpan {
+    size_t src_frame, dst_frame;
+    int tiles_per_frame;
+};
+int resize_bilinear_rgba8_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s);              // resize_planes.hip
+int resize_convert_rgba8_frames(const zg_image *src, const zg_image *dst, int dst_space, uint32_t n, size_t src_frame, size_t dst_frame, const float *srgb_lut,
+                                hipStream_t s);                                                                                                       // convert.hip
+
 // u8 separable convolution of a batch of equally sized frames laid out back to back, one wave per column strip
 // (conv_sep_stream.hip). Returns -1 when its preconditions do not hold: the caller falls back to the tiled kernels.
 struct StreamJob {

@@ -1,0 +1,101 @@
+"""The `pipeline` command over a batch of frames (reference src/cli/pipeline.zig:153-179: every input image goes through the recipe's
+steps in order), resident on the device: `Pipeline(steps).run(frames)` with frames a torch tensor (n, rows, cols[, channels]).
+
+One call of the C ABI (zg_batch_pipeline) per batch: each step is a single launch over all frames where the library has a batched
+kernel, fused with its neighbour where it has a fused one, and equals the per-frame `Image` methods bit for bit."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+from .image import _PIXEL_BY_LAYOUT, Interpolation
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+_LAYOUT_BY_PIXEL = {v: k for k, v in _PIXEL_BY_LAYOUT.items()}
+
+
+class Step:
+    """One recipe step; the constructors mirror the CLI's step options (blur: src/cli/blur.zig, resize: src/cli/resize.zig)."""
+
+    def __init__(self, c_step: L.ZgStep, keep=None):
+        self.c = c_step
+        self._keep = keep  # host arrays the C struct points at
+
+    @staticmethod
+    def gaussian_blur(sigma: float) -> "Step":
+        s = L.ZgStep()
+        s.kind, s.sigma = L.STEP_GAUSSIAN_BLUR, float(sigma)
+        return Step(s)
+
+    @staticmethod
+    def box_blur(radius: int) -> "Step":
+        s = L.ZgStep()
+        s.kind, s.radius = L.STEP_BOX_BLUR, int(radius)
+        return Step(s)
+
+    @staticmethod
+    def resize(rows: int, cols: int, method: Interpolation = Interpolation.bilinear) -> "Step":
+        s = L.ZgStep()
+        s.kind, s.out_rows, s.out_cols, s.method = L.STEP_RESIZE, int(rows), int(cols), method._c()
+        return Step(s)
+
+    @staticmethod
+    def convert(dst_space: int, dtype=np.float32, srgb_lut=None) -> "Step":
+        ch = 1 if dst_space == L.CS_GRAY else (4 if dst_space == L.CS_RGBA else 3)
+        s = L.ZgStep()
+        s.kind, s.dst_space, s.dst_pixel = L.STEP_CONVERT, int(dst_space), _PIXEL_BY_LAYOUT[(np.dtype(dtype).name, ch)]
+        keep = None
+        if srgb_lut is not None:
+            keep = np.ascontiguousarray(srgb_lut, np.float32)
+            s.srgb_lut = keep.ctypes.data
+        return Step(s, keep)
+
+    @staticmethod
+    def warp(transform, rows: int, cols: int, method: Interpolation = Interpolation.bilinear) -> "Step":
+        s = L.ZgStep()
+        s.kind, s.out_rows, s.out_cols, s.method, s.transform = L.STEP_WARP, int(rows), int(cols), method._c(), int(transform.kind)
+        for i, v in enumerate(transform.coefficients()):
+            s.m[i] = float(v)
+        return Step(s)
+
+
+class Pipeline:
+    def __init__(self, steps: Sequence[Step]):
+        self.steps: List[Step] = list(steps)
+        self._c = (L.ZgStep * max(1, len(self.steps)))(*[st.c for st in self.steps])
+
+    def out_layout(self, rows: int, cols: int, pixel: int, space: int):
+        r, c, p, sp = C.c_uint32(), C.c_uint32(), C.c_int(), C.c_int()
+        L.check(L.lib().zg_batch_pipeline_shape(rows, cols, pixel, space, self._c, len(self.steps), C.byref(r), C.byref(c), C.byref(p), C.byref(sp)))
+        return r.value, c.value, p.value, sp.value
+
+    def run(self, frames, space: Optional[int] = None, out=None):
+        """frames: CUDA tensor (n, rows, cols) or (n, rows, cols, channels), contiguous. Returns the (n, rows', cols'[, channels']) result."""
+        if torch is None or not isinstance(frames, torch.Tensor) or not frames.is_cuda:
+            raise ValueError("Pipeline.run takes device frames (a CUDA torch tensor); the host-pointer layer is per image")
+        if frames.ndim not in (3, 4) or not frames.is_contiguous():
+            raise ValueError("expected contiguous frames (n, rows, cols[, channels])")
+        n, rows, cols = (int(v) for v in frames.shape[:3])
+        ch = 1 if frames.ndim == 3 else int(frames.shape[3])
+        pixel = _PIXEL_BY_LAYOUT[(str(frames.dtype).replace("torch.", ""), ch)]
+        if space is None:
+            space = {1: L.CS_GRAY, 3: L.CS_RGB, 4: L.CS_RGBA}[ch]
+        orows, ocols, opixel, _ = self.out_layout(rows, cols, pixel, space)
+        odtype, och = _LAYOUT_BY_PIXEL[opixel]
+        shape = (n, orows, ocols) if och == 1 else (n, orows, ocols, och)
+        tdtype = {"uint8": torch.uint8, "float32": torch.float32}[odtype]
+        if out is None:
+            out = torch.empty(shape, dtype=tdtype, device=frames.device)
+        elif tuple(out.shape) != shape or out.dtype != tdtype or not out.is_contiguous() or out.device != frames.device:
+            raise L.DimensionMismatch(f"out must be a contiguous {tdtype} tensor of shape {shape} on {frames.device}")
+        with torch.cuda.device(frames.device):
+            L.check(L.lib().zg_batch_pipeline(C.c_void_p(frames.data_ptr()), n, rows, cols, pixel, int(space), self._c, len(self.steps),
+                                              C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(frames.device).cuda_stream)))
+        return out
