@@ -161,12 +161,18 @@ ZG_API int zg_event_synchronize(zg_event e);
 ZG_API int zg_event_elapsed_ms(zg_event start, zg_event stop, float *ms); /* device time between two recorded events */
 /* Everything the library enqueues on `stream` (not the default stream) between begin and end becomes one launchable
  * graph; host-side work of the captured calls (taps, tables, checks) is done at capture time. Scratch that captured calls
- * take stays reserved for the graph until zg_release_graph_scratch(), to be called once the graphs are destroyed. */
+ * take belongs to the graph and is freed by zg_graph_destroy. Captures ended by somebody else (torch.cuda.graph around Image
+ * calls, a caller's own hipStreamEndCapture) cannot be followed: their scratch stays reserved until zg_release_graph_scratch(),
+ * to be called once those graphs are destroyed (it skips captures still in progress). */
 ZG_API int zg_graph_begin_capture(zg_stream stream);
 ZG_API int zg_graph_end_capture(zg_stream stream, zg_graph *out);
 ZG_API int zg_graph_launch(zg_graph graph, zg_stream stream);
 ZG_API int zg_graph_destroy(zg_graph graph);
 ZG_API int zg_release_graph_scratch(void);
+/* Idle scratch blocks the library keeps for reuse (at most ZIGNAL_HIP_SCRATCH_CACHE_MB, default 2048 MiB) go back to the driver. The
+ * library does this itself when one of its own allocations (zg_malloc included) runs out of memory; another allocator in the same
+ * process calls it before giving up. */
+ZG_API int zg_trim_scratch(void);
 ZG_API size_t zg_pixel_size(int pixel);
 
 /* ---- filters ------------------------------------------------------------------------- */

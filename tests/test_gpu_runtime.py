@@ -1,0 +1,111 @@
+"""Runtime services behind the C ABI: scratch ownership under graph capture, the idle-scratch cache and its trim, and the role-split
+SAT chain against the plain two-kernel form on awkward shapes."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import zignal_amd as zg  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_bytes():
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0]
+
+
+def test_a_graph_owns_the_scratch_its_capture_took():
+    """zg_graph_end_capture hands the capture's scratch blocks to the graph and zg_graph_destroy frees them: re-capturing in a loop
+    does not grow the device's footprint, and zg_release_graph_scratch (for foreign captures) leaves living graphs alone."""
+    lib = zg.lib()
+    src = zg.Image(torch.randint(0, 256, (2048, 2048, 4), dtype=torch.uint8, device="cuda"))
+    dst = zg.Image(torch.empty_like(src.data))
+    stream = torch.cuda.Stream()
+    want = src.gaussian_blur(2.5).to_numpy()  # 17 taps: the two-pass path with a 32 MiB u16 temp plane
+    lib.zg_trim_scratch()
+    base = free_bytes()
+    graphs = []
+    for i in range(6):
+        with torch.cuda.stream(stream):
+            assert lib.zg_graph_begin_capture(C.c_void_p(stream.cuda_stream)) == 0
+            src.gaussian_blur(2.5, out=dst)
+            g = C.c_void_p()
+            assert lib.zg_graph_end_capture(C.c_void_p(stream.cuda_stream), C.byref(g)) == 0, lib.zg_last_error()
+        graphs.append(g)
+        if i == 2:  # a live graph survives somebody else's clean-up call
+            assert lib.zg_release_graph_scratch() == 0
+        with torch.cuda.stream(stream):
+            dst.data.zero_()  # on the stream the graph replays on
+        assert lib.zg_graph_launch(g, C.c_void_p(stream.cuda_stream)) == 0
+        stream.synchronize()
+        assert np.array_equal(dst.to_numpy(), want), f"replay of capture {i}"
+    held = base - free_bytes()
+    assert held >= 6 * 30 * 2**20, held  # six graphs, six temp planes
+    for g in graphs[:3]:
+        assert lib.zg_graph_destroy(g) == 0
+    assert base - free_bytes() <= held // 2 + 8 * 2**20
+    with torch.cuda.stream(stream):
+        dst.data.zero_()
+    assert lib.zg_graph_launch(graphs[4], C.c_void_p(stream.cuda_stream)) == 0  # the others still work
+    stream.synchronize()
+    assert np.array_equal(dst.to_numpy(), want)
+    for g in graphs[3:]:
+        assert lib.zg_graph_destroy(g) == 0
+    assert base - free_bytes() <= 8 * 2**20
+
+
+def test_trim_returns_the_idle_scratch_cache():
+    lib = zg.lib()
+    host = np.random.default_rng(0).integers(0, 256, (4096, 4096, 4), dtype=np.uint8)
+    zg.Image(host).box_blur(2)  # once, so that what the HIP runtime allocates on first use (code objects, staging) is in the baseline
+    lib.zg_trim_scratch()
+    base = free_bytes()
+    zg.Image(host).box_blur(2)  # host-pointer layer: the frame's device twins and the SAT come from the cache
+    assert base - free_bytes() >= 64 * 2**20
+    assert lib.zg_trim_scratch() == 0
+    assert base - free_bytes() <= 8 * 2**20
+    # a capped cache keeps nothing above its budget (the cap is read once per process: a child process)
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import zignal_amd as zg\n"
+            "h = np.zeros((4096, 4096, 4), np.uint8); zg.Image(h).box_blur(2); zg.lib().zg_trim_scratch(); torch.cuda.synchronize()\n"
+            "b = torch.cuda.mem_get_info()[0]; zg.Image(h).box_blur(2); torch.cuda.synchronize(); print(b - torch.cuda.mem_get_info()[0])" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, ZIGNAL_HIP_SCRATCH_CACHE_MB="16"))
+    assert out.returncode == 0, out.stderr[-1500:]
+    assert int(out.stdout.strip().splitlines()[-1]) <= 24 * 2**20, out.stdout  # 16 MiB budget + allocation granularity
+
+
+@pytest.mark.parametrize("shape", ((63, 97), (64, 64), (1, 300), (300, 1), (65, 4097), (130, 1023, 4), (67, 129, 3), (257, 63, 4)))
+def test_role_split_sat_chain_equals_the_unfused_kernels(shape, oracle):
+    """k_sat_chain retires some of its waves before the others reach their barriers (fine on CDNA, outside HIP's barrier contract):
+    hold it to the plain row-scan + column-scan pair (ZIGNAL_HIP_SAT_UNFUSED=1, a child process) and to the oracle on shapes with
+    rows / columns off the 64 grid, single rows and columns, and strided views."""
+    host = oracle.synth_u8(500 + shape[0], shape)
+    view = oracle.synth_u8(900 + shape[0], (shape[0] + 5, shape[1] + 9) + shape[2:])
+    here = {}
+    for name, arr in (("whole", host), ("view", view)):
+        im = zg.Image(torch.from_numpy(arr).cuda())
+        if name == "view":
+            im = im.view((3, 2, 3 + shape[1], 2 + shape[0]))
+        here[name] = [im.box_blur(r).to_numpy() for r in (1, 2, 7)] + [im.sharpen(2).to_numpy()]
+    src_whole, src_view = host, view[2:2 + shape[0], 3:3 + shape[1]]
+    for r, got in zip((1, 2, 7), here["whole"]):
+        assert np.array_equal(got, oracle.box_blur(src_whole, r)), (shape, r)
+    for r, got in zip((1, 2, 7), here["view"]):
+        assert np.array_equal(got, oracle.box_blur(np.ascontiguousarray(src_view), r)), (shape, r, "view")
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import zignal_amd as zg\n"
+            "a = np.load(sys.argv[1]); im = zg.Image(torch.from_numpy(a).cuda())\n"
+            "np.savez(sys.argv[2], *([im.box_blur(r).to_numpy() for r in (1, 2, 7)] + [im.sharpen(2).to_numpy()]))" % ROOT)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "in.npy"), host)
+        out = subprocess.run([sys.executable, "-c", code, os.path.join(d, "in.npy"), os.path.join(d, "out.npz")], capture_output=True, text=True,
+                             timeout=300, env=dict(os.environ, ZIGNAL_HIP_SAT_UNFUSED="1"))
+        assert out.returncode == 0, out.stderr[-1500:]
+        other = np.load(os.path.join(d, "out.npz"))
+        for i, got in enumerate(here["whole"]):
+            assert np.array_equal(got, other[f"arr_{i}"]), (shape, i)

@@ -120,6 +120,7 @@ pub const c = struct {
     pub extern fn zg_graph_launch(graph: ?*anyopaque, stream: ?*anyopaque) c_int;
     pub extern fn zg_graph_destroy(graph: ?*anyopaque) c_int;
     pub extern fn zg_release_graph_scratch() c_int;
+    pub extern fn zg_trim_scratch() c_int;
     pub extern fn zg_devmath_apply(func: c_int, x_dev: [*]const f32, y_dev: ?[*]const f32, out_dev: [*]f32, n: usize, stream: ?*anyopaque) c_int;
     pub extern fn zg_lanczos_plane_weights(src_n: u32, dst_n: u32, weights: [*]f32) c_int;
     pub extern fn zg_resize_lanczos_weights(src: *const ZgImage, dst: *const ZgImage, wx: ?[*]const f32, wy: ?[*]const f32, stream: ?*anyopaque) c_int;

@@ -136,6 +136,7 @@ _SIGNATURES = {
     "zg_graph_launch": [C.c_void_p, C.c_void_p],
     "zg_graph_destroy": [C.c_void_p],
     "zg_release_graph_scratch": [],
+    "zg_trim_scratch": [],
     "zg_devmath_apply": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
     "zg_lanczos_plane_weights": [C.c_uint32, C.c_uint32, _F32P],
     "zg_resize_lanczos_weights": [_IMG, _IMG, _F32P, _F32P, C.c_void_p],

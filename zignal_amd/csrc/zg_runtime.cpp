@@ -5,6 +5,7 @@
 #include <vector>
 #include <unordered_map>
 #include <mutex>
+#include <new>
 #include <condition_variable>
 #include <string.h>
 #include <stdlib.h>
@@ -80,6 +81,37 @@ struct GraphBlock {
 };
 std::mutex g_scratch_mu;
 std::vector<CachedBlock> g_scratch_free;                           // oldest first
+size_t g_scratch_cached_bytes = 0;                                 // sum over g_scratch_free
+std::unordered_map<void *, std::vector<void *>> g_graph_owned;     // zg_graph -> the scratch blocks its capture took
+
+// Idle blocks are kept up to this many bytes (ZIGNAL_HIP_SCRATCH_CACHE_MB, default 2048): enough for the temp planes of a few 4096^2
+// calls in flight, small against 288 GB, and a bound — the host-pointer layer stages whole frames through this cache, and a process
+// that shares the device with another allocator (PyTorch's) must not find gigabytes parked here. zg_trim_scratch() empties it.
+size_t scratch_cache_limit() {
+    static const size_t limit = [] {
+        const char *e = getenv("ZIGNAL_HIP_SCRATCH_CACHE_MB");
+        const long mb = e ? strtol(e, nullptr, 10) : 2048;
+        return (size_t)(mb < 0 ? 0 : mb) << 20;
+    }();
+    return limit;
+}
+void release_blocks(std::vector<CachedBlock> &drop) {
+    for (const CachedBlock &b : drop) {
+        (void)hipEventSynchronize(b.done);
+        (void)hipEventDestroy(b.done);
+        (void)hipFree(b.p);
+    }
+    drop.clear();
+}
+void drop_scratch_cache() {
+    std::vector<CachedBlock> drop;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        drop.swap(g_scratch_free);
+        g_scratch_cached_bytes = 0;
+    }
+    release_blocks(drop);
+}
 std::unordered_map<void *, std::pair<size_t, int>> g_scratch_live; // ptr -> (bytes, device)
 std::vector<GraphBlock> g_graph_blocks;
 
@@ -142,6 +174,7 @@ int scratch_alloc(void **out, size_t bytes, hipStream_t s) {
         if (best != g_scratch_free.size()) {
             take = g_scratch_free[best];
             g_scratch_free.erase(g_scratch_free.begin() + (long)best);
+            g_scratch_cached_bytes -= take.bytes;
         }
     }
     if (take.p) {
@@ -152,16 +185,7 @@ int scratch_alloc(void **out, size_t bytes, hipStream_t s) {
         hipError_t e = hipMalloc(&take.p, need);
         if (e == hipErrorOutOfMemory) { // give the cache back to the driver and try once more
             (void)hipGetLastError();
-            std::vector<CachedBlock> drop;
-            {
-                std::lock_guard<std::mutex> lock(g_scratch_mu);
-                drop.swap(g_scratch_free);
-            }
-            for (const CachedBlock &b : drop) {
-                (void)hipEventSynchronize(b.done);
-                (void)hipEventDestroy(b.done);
-                (void)hipFree(b.p);
-            }
+            drop_scratch_cache();
             e = hipMalloc(&take.p, need);
         }
         ZG_HIP(e);
@@ -197,20 +221,18 @@ void scratch_free(void *p, hipStream_t s) {
         (void)hipFree(p);
         return;
     }
-    CachedBlock evict{};
+    std::vector<CachedBlock> evict; // oldest first, until the cache is back under its byte and block limits
     {
         std::lock_guard<std::mutex> lock(g_scratch_mu);
         g_scratch_free.push_back(b);
-        if (g_scratch_free.size() > 64) {
-            evict = g_scratch_free.front();
+        g_scratch_cached_bytes += b.bytes;
+        while (!g_scratch_free.empty() && (g_scratch_free.size() > 64 || g_scratch_cached_bytes > scratch_cache_limit())) {
+            evict.push_back(g_scratch_free.front());
+            g_scratch_cached_bytes -= g_scratch_free.front().bytes;
             g_scratch_free.erase(g_scratch_free.begin());
         }
     }
-    if (evict.p) {
-        (void)hipEventSynchronize(evict.done);
-        (void)hipEventDestroy(evict.done);
-        (void)hipFree(evict.p);
-    }
+    release_blocks(evict);
 }
 
 // How many host threads the codecs' host halves may use for one call (deflate pieces, entropy-coding bands).
@@ -448,7 +470,15 @@ int host_banded(const zg_image *src, const zg_image *dst, uint32_t halo, const B
         dv.data = dband + band_bytes * (k % NB);
         dv.stride = dst->cols;
         dv.rows = v1 - v0;
-        rc = op(&sv, &dv, run);
+        try { // an exception (std::bad_alloc from a tap vector, say) must not unwind past the live downloader thread: that is std::terminate
+            rc = op(&sv, &dv, run);
+        } catch (const std::bad_alloc &) {
+            set_error("band pipeline: out of host memory");
+            rc = ZG_ERR_OUT_OF_MEMORY;
+        } catch (...) {
+            set_error("band pipeline: the operation threw");
+            rc = ZG_ERR_INVALID_ARGUMENT;
+        }
         if (rc) break;
         if (hipEventRecord(ev_run[k], run) != hipSuccess) {
             rc = hip_fail(hipGetLastError(), "band pipeline: kernel -> download hand-off", __FILE__, __LINE__);
@@ -518,7 +548,18 @@ int zg_malloc(void **dev_ptr, size_t bytes) {
     *dev_ptr = nullptr;
     if (bytes == 0) return ZG_OK;
     RelaxedCapture relaxed; // legal while another thread captures
-    ZG_HIP(hipMalloc(dev_ptr, bytes));
+    hipError_t e = hipMalloc(dev_ptr, bytes);
+    if (e == hipErrorOutOfMemory) { // the library's own idle scratch must never be the reason an allocation fails
+        (void)hipGetLastError();
+        drop_scratch_cache();
+        e = hipMalloc(dev_ptr, bytes);
+    }
+    ZG_HIP(e);
+    return ZG_OK;
+}
+
+int zg_trim_scratch(void) {
+    drop_scratch_cache();
     return ZG_OK;
 }
 
@@ -656,11 +697,29 @@ int zg_graph_begin_capture(zg_stream stream) {
 int zg_graph_end_capture(zg_stream stream, zg_graph *out) {
     ZG_REQUIRE(stream && out, ZG_ERR_INVALID_ARGUMENT, "zg_graph_end_capture: null argument");
     *out = nullptr;
+    unsigned long long capture_id = 0;
+    const bool capturing = stream_capture_id(as_stream(stream), &capture_id);
     hipGraph_t g = nullptr;
     ZG_HIP(hipStreamEndCapture(as_stream(stream), &g));
     hipGraphExec_t exec = nullptr;
     const hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
+    // the scratch this capture took now belongs to the graph (or goes back at once if there is no graph to own it)
+    std::vector<void *> mine;
+    if (capturing) {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        for (size_t i = 0; i < g_graph_blocks.size();) {
+            if (g_graph_blocks[i].capture_id == capture_id) {
+                mine.push_back(g_graph_blocks[i].p);
+                g_graph_blocks.erase(g_graph_blocks.begin() + (long)i);
+            } else {
+                ++i;
+            }
+        }
+        if (e == hipSuccess && !mine.empty()) g_graph_owned[(void *)exec] = mine;
+    }
+    if (e != hipSuccess)
+        for (void *p : mine) (void)hipFree(p);
     ZG_HIP(e);
     *out = (zg_graph)exec;
     return ZG_OK;
@@ -673,17 +732,41 @@ int zg_graph_launch(zg_graph graph, zg_stream stream) {
 }
 
 int zg_graph_destroy(zg_graph graph) {
-    if (graph) ZG_HIP(hipGraphExecDestroy((hipGraphExec_t)graph));
+    if (!graph) return ZG_OK;
+    std::vector<void *> mine;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        auto it = g_graph_owned.find((void *)graph);
+        if (it != g_graph_owned.end()) {
+            mine.swap(it->second);
+            g_graph_owned.erase(it);
+        }
+    }
+    const hipError_t e = hipGraphExecDestroy((hipGraphExec_t)graph);
+    for (void *p : mine) (void)hipFree(p); // hipFree waits for a replay that is still running
+    ZG_HIP(e);
     return ZG_OK;
 }
 
-// Every scratch block that captures have taken goes back to the driver. The caller guarantees that no graph built from
-// those captures will be launched again (hipFree waits for whatever is still running).
+// Scratch of captures the library did not end itself (torch.cuda.graph around Image calls, a caller's own hipStreamEndCapture):
+// nobody tells the library when those graphs die, so their blocks stay reserved until the caller says so here — once the graphs
+// are destroyed (hipFree waits for whatever is still running). Graphs made with zg_graph_end_capture own their scratch and are
+// not touched; neither are blocks of a capture that is still in progress or of a call that is still running.
 int zg_release_graph_scratch(void) {
     std::vector<GraphBlock> drop;
     {
         std::lock_guard<std::mutex> lock(g_scratch_mu);
-        drop.swap(g_graph_blocks);
+        for (size_t i = 0; i < g_graph_blocks.size();) {
+            const GraphBlock &g = g_graph_blocks[i];
+            unsigned long long id = 0;
+            const bool still_capturing = stream_capture_id(g.stream, &id) && id == g.capture_id;
+            if (g.in_use || still_capturing) {
+                ++i;
+                continue;
+            }
+            drop.push_back(g);
+            g_graph_blocks.erase(g_graph_blocks.begin() + (long)i);
+        }
     }
     for (const GraphBlock &g : drop) ZG_HIP(hipFree(g.p));
     return ZG_OK;
