@@ -54,6 +54,7 @@ def parse_args():
                     help="also time BASELINE configs[4] end to end (RCCL scatter -> blur+resize -> gather), 128 frames per GPU; "
                          "with one GPU the shard loops back through a one-rank RCCL communicator")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="take roofline.traffic from profiles/traffic.json instead of two rocprofv3 counter passes")
     ap.add_argument("--no-extras", action="store_true")
     return ap.parse_args()
 
@@ -256,15 +257,15 @@ def main():
         mean_ms = region_ms_per_launch
         alg_bytes = 32 * pixels  # 16 B read + 16 B written per pixel
         achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        traffic, traffic_source = (None if args.no_live_traffic else live_traffic("blur_f32", "k_sep_fused")), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, this run"
+        if traffic is None:
+            traffic_source = "profiles/traffic.json (an earlier rocprofv3 measurement of the same kernel)"
             try:
-                traffic = json.load(open(tpath)).get("k_sep_fused_rgba_f32_bytes_per_launch")
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("k_sep_fused_rgba_f32_bytes_per_launch")
             except Exception:
-                traffic = None
+                traffic, traffic_source = None, None
         result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                              "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                               "kernel": "k_sep_fused<RGBA_F32,5>", "kernel_ms_mean": round(mean_ms, 5),
                               "kernel_ms_source": "HIP events around the timed region / launches in it",
                               "kernel_ms_eager_event_pairs_mean": round(eager_mean_ms, 5),
@@ -272,7 +273,7 @@ def main():
                               "algorithmic_bytes_per_launch": alg_bytes}
         # The metric names two ops: the bilinear resize of BASELINE configs[2] stands beside the blur, same arithmetic.
         try:
-            result["resize"] = resize_headline(zg, torch)
+            result["resize"] = resize_headline(zg, torch, not args.no_live_traffic)
         except Exception as e:  # never take the headline down
             result["resize"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_extras:
@@ -303,7 +304,38 @@ def main():
         json_out.flush()
 
 
-def resize_headline(zg, torch):
+def live_traffic(op: str, kernel: str, launches: int = 5):
+    """HBM bytes per launch of `kernel` measured now, on this box: two rocprofv3 passes (--pmc FETCH_SIZE, then WRITE_SIZE, --kernel-trace
+    only, as MI355X_MICROARCH.md prescribes) over tools/run_op.py <op>; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (the counters are in
+    KiB, and gfx950's FETCH_SIZE counts 32-byte units as 64). None when rocprofv3 is not on the box or a pass fails."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    got = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(dir="/tmp") as d:
+                env = dict(os.environ, TMPDIR="/tmp")
+                p = subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "r", "--", sys.executable, os.path.join(ROOT, "tools", "run_op.py"), op, str(launches)],
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+                dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+                if p.returncode != 0 or not dbs:
+                    return None
+                vals = [v for k, name, v in sqlite3.connect(dbs[0]).execute("select kernel_name, counter_name, value from counters_collection")
+                        if kernel in k and name == ctr]
+                if not vals:
+                    return None
+                got[ctr] = sum(vals) / len(vals)
+        return int((2 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024)
+    except Exception:
+        return None
+
+
+def resize_headline(zg, torch, live=True):
     """Image(Rgba(u8)).resize(.bilinear) 4096^2 -> 1024^2 (BASELINE configs[2], channel_ops.zig:144-190), sources rotating through
     1 GiB of distinct frames. Strict algorithmic bytes (20 B per output pixel) and, beside them, what DRAM has to move for this
     geometry: the taps are bytes 4..11 of every 16 in rows 1, 2 mod 4 — every 64-byte line of half the rows (counter-checked:
@@ -313,11 +345,12 @@ def resize_headline(zg, torch):
     im = [(zg.Image(s), zg.Image(torch.empty((1024, 1024, 4), dtype=torch.uint8, device="cuda"))) for s in srcs]
     ms = _time_kernel(torch, lambda i: im[i % ring][0].resize(im[i % ring][1], zg.Interpolation.bilinear), n=64, warm=8)
     alg = 20 * 1024 * 1024
-    traffic = None
-    try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("k_resize_bilinear_rgba8_4096_to_1024_bytes_per_launch")
-    except Exception:
-        pass
+    traffic = live_traffic("resize", "k_resize_bilinear_rgba8") if live else None
+    if traffic is None:
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("k_resize_bilinear_rgba8_4096_to_1024_bytes_per_launch")
+        except Exception:
+            pass
     dram = ROWS * COLS * 4 // 2 + 4 * 1024 * 1024
     achieved = alg / (ms * 1e-3) / 1e9
     # the same resize as a step of zg_batch_pipeline over 16 frames per launch (one frame is 4 096 one-gather workgroups: launch ramp and tail)
@@ -667,10 +700,12 @@ def extras(zg, torch, np):
 
     def pyramid_build():
         # ImagePyramid.build(source, 8, 1.2, 1.6) — ORB's default — on a grey frame: seven blur + resize levels from the
-        # original (sigma up to 5.5: 35 taps), launched from Python; output pixels = sum of the level sizes
+        # original (sigma up to 5.5: 35 taps), one C call (zg_pyramid_build: the levels fork over internal streams under capture)
         src = zg.Image(torch.randint(0, 256, (ROWS, COLS), dtype=torch.uint8, device="cuda"))
-        ms = _time_kernel(torch, lambda i: zg.ImagePyramid.build_default(src), n=6, warm=2, capture=False)
-        return rate(ms, ROWS * COLS, 2 * ROWS * COLS)
+        ms = _time_kernel(torch, lambda i: zg.ImagePyramid.build_default(src), n=6, warm=2)  # one zg_pyramid_build per pyramid, graph-replayed like every leg
+        r = rate(ms, ROWS * COLS, 2 * ROWS * COLS)
+        r["eager_ms"] = round(_time_kernel(torch, lambda i: zg.ImagePyramid.build_default(src), n=6, warm=2, capture=False), 5)
+        return r
 
     def png_frame():
         # photo-like content (smooth ramps + a little noise): uniform noise would measure nothing but deflate's worst case

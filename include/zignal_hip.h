@@ -408,6 +408,11 @@ ZG_API int zg_pyramid_level(uint32_t rows, uint32_t cols, float scale, float blu
 /* One level in one call (pyramid.zig:76-92): gaussianBlur(source, sigma) when sigma > 0.5 (scratch inside), then
  * resize(.bilinear) into `level` (pre-allocated with zg_pyramid_level's dimensions). Device pointers. */
 ZG_API int zg_pyramid_build_level(const zg_image *source, const zg_image *level, float sigma, zg_stream stream);
+/* ImagePyramid.build (pyramid.zig:31-102) as ONE device operation: levels[i] / sigmas[i] are pyramid level i + 1 (level 0 is the
+ * source itself: no copy, pyramid.zig:54), n_levels of them, shapes and sigmas from zg_pyramid_level, memory from the caller. Every
+ * level is made from the original, so they are independent: the call forks them over internal streams and joins them back into
+ * `stream` with events — asynchronous, no host round trip between levels, recordable into a graph. */
+ZG_API int zg_pyramid_build(const zg_image *source, const zg_image *levels, const float *sigmas, uint32_t n_levels, zg_stream stream);
 
 /* ---- batch (config: N frames, gaussianBlur(sigma) then bilinear resize) ----------------- */
 

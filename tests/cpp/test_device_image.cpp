@@ -169,6 +169,25 @@ int main(int argc, char **argv) {
         EXPECT(same_bits(eager_blur.toHost(), want_blur));
     }
 
+    { // ImagePyramid.build as one device operation (zg_pyramid_build behind zignal::ImagePyramid), each level against the oracle
+        const uint32_t prow = quick ? 160 : 540, pcol = quick ? 200 : 960;
+        Image<uint8_t> g = Image<uint8_t>::init(prow, pcol);
+        for (size_t i = 0; i < (size_t)prow * pcol; ++i) g.data[i] = (uint8_t)lcg(seed);
+        DeviceImage<uint8_t> dg = DeviceImage<uint8_t>::fromHost(g);
+        ImagePyramid<uint8_t> pyr = ImagePyramid<uint8_t>::buildDefault(dg);
+        EXPECT(pyr.nLevels() == 8 && pyr.levels[0].data == dg.data);
+        for (size_t i = 1; i < pyr.nLevels(); ++i) {
+            uint32_t r = 0, c = 0; float sg = 0;
+            check(zg_pyramid_level(prow, pcol, pyr.getScale(i), 1.6f, &r, &c, &sg));
+            EXPECT(pyr.levels[i].rows == r && pyr.levels[i].cols == c);
+            auto blurred = Image<uint8_t>::init(prow, pcol), want_level = Image<uint8_t>::init(r, c);
+            const zo_image zs = zo_of(g), zb = zo_of(blurred), zw = zo_of(want_level);
+            const zo_method zbil = {ZO_BILINEAR, 0, 0, nullptr};
+            EXPECT(zo_gaussian_blur(&zs, &zb, sg) == 0 && zo_resize(&zb, &zw, &zbil) == 0);
+            EXPECT(same_bits(pyr.levels[i].toHost(), want_level));
+        }
+    }
+
     { // the node's GPUs from this one thread (zg_multi): on a one-GPU box the context has one device; with ZIGNAL_HIP_MULTI_LOOPBACK the
       // root's shard makes its round trip through an RCCL communicator (ncclCommInitAll, grouped ncclSend / ncclRecv) all the same
         const uint32_t n = quick ? 3 : 7, rows = 270, cols = 480;

@@ -42,7 +42,7 @@ def test_bench_counts_its_rccl_ranks_and_times_the_three_distribution_routes():
     import json
     pytest.importorskip("torch")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "100", "--warmup", "100", "--scatter-gather", "--no-extras", "--no-cpu-baseline"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "100", "--warmup", "100", "--scatter-gather", "--no-extras", "--no-cpu-baseline", "--no-live-traffic"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     res = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])

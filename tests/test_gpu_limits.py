@@ -80,3 +80,17 @@ def test_ops_on_an_image_taller_than_the_grid_limit(oracle):
     f = synth(oracle, "rgba_f32", 75, rows, 12)
     assert_bits_equal(sync(dev(f).gaussian_blur(0.6)), oracle.gaussian_blur(f, 0.6), "f32 blur")
     assert_bits_equal(sync(dev(f).gaussian_blur(3.0)), oracle.gaussian_blur(f, 3.0), "f32 blur 19 taps")
+
+
+def test_canny_and_axis_aligned_motion_blur_past_255_taps(oracle):
+    """The last two places that refused kernels longer than 255 taps: canny's own blur at sigma 45 (271 taps) and
+    motionBlur(.linear) along an axis at distance 300. The reference has neither limit (edges.zig:212-260, motion_blur.zig:65-130)."""
+    img = oracle.synth_u8(61, (96, 700, 4))
+    got = zg.Image(torch.from_numpy(img).cuda()).canny(45.0, 5, 15)
+    torch.cuda.synchronize()
+    assert np.array_equal(got.to_numpy(), oracle.canny(img, 45.0, 5, 15))
+    for angle, shape in ((0.0, (40, 900, 4)), (np.float32(np.pi / 2), (900, 40, 4))):
+        img = oracle.synth_u8(62, shape)
+        got = zg.Image(torch.from_numpy(img).cuda()).motion_blur_linear(float(angle), 300)
+        torch.cuda.synchronize()
+        assert np.array_equal(got.to_numpy(), oracle.motion_blur_linear(img, float(angle), 300)), angle

@@ -129,6 +129,7 @@ pub const c = struct {
     pub extern fn zg_resize_convert_host(src: *const ZgImage, src_space: c_int, dst: *const ZgImage, dst_space: c_int, method: *const ZgMethod, srgb_lut: ?[*]const f32) c_int;
     pub extern fn zg_batch_pipeline_shape(rows: u32, cols: u32, pixel: c_int, space: c_int, steps: ?[*]const ZgStep, n_steps: u32, out_rows: ?*u32, out_cols: ?*u32, out_pixel: ?*c_int, out_space: ?*c_int) c_int;
     pub extern fn zg_batch_pipeline(src_frames: ?*const anyopaque, n_frames: u32, rows: u32, cols: u32, pixel: c_int, space: c_int, steps: ?[*]const ZgStep, n_steps: u32, dst_frames: ?*anyopaque, stream: ?*anyopaque) c_int;
+    pub extern fn zg_pyramid_build(source: *const ZgImage, levels: ?[*]const ZgImage, sigmas: ?[*]const f32, n_levels: u32, stream: ?*anyopaque) c_int;
     pub extern fn zg_multi_create(devices: ?[*]const c_int, n_devices: c_int, out: *?*anyopaque) c_int;
     pub extern fn zg_multi_destroy(m: ?*anyopaque) c_int;
     pub extern fn zg_multi_device_count(m: ?*anyopaque) c_int;

@@ -145,6 +145,7 @@ _SIGNATURES = {
     "zg_resize_convert_host": [_IMG, C.c_int, _IMG, C.c_int, _METHOD, _F32P],
     "zg_batch_pipeline_shape": [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(ZgStep), C.c_uint32, _U32P, _U32P, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "zg_batch_pipeline": [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(ZgStep), C.c_uint32, C.c_void_p, C.c_void_p],
+    "zg_pyramid_build": [_IMG, _IMG, _F32P, C.c_uint32, C.c_void_p],
     "zg_multi_create": [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)],
     "zg_multi_destroy": [C.c_void_p],
     "zg_multi_device_count": [C.c_void_p],

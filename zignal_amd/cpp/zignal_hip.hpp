@@ -427,6 +427,38 @@ template <typename T> class DeviceImage : public detail::Ops<DeviceImage, T> {
     zg_stream stream_ = nullptr;
 };
 
+// ImagePyramid(T) (src/image/pyramid.zig:11-170) resident on the device: level 0 is the source itself (not copied, pyramid.zig:54), level i
+// the source blurred with sigma_i = blur_sigma * sqrt(scale_i^2 - 1) (only if > 0.5) and resized bilinearly to trunc(dim / scale_i),
+// scale_i = pow(scale_factor, i); a level below 8 x 8 truncates the pyramid. `build` is ONE call of the C ABI: every level is enqueued
+// without a host round trip (they fork over internal streams and join back into the source's stream).
+template <typename T> struct ImagePyramid {
+    std::vector<DeviceImage<T>> levels; // levels[0] is a view of the source
+    float scale_factor = 0, blur_sigma = 0;
+    static ImagePyramid build(const DeviceImage<T> &source, uint8_t n_levels, float scale_factor, float blur_sigma) {       // pyramid.zig:31-102
+        ImagePyramid p;
+        p.scale_factor = scale_factor;
+        p.blur_sigma = blur_sigma;
+        p.levels.push_back(source.view(Rectangle<uint32_t>{0, 0, source.cols, source.rows}));
+        std::vector<zg_image> descs;
+        std::vector<float> sigmas;
+        for (uint32_t i = 1; i < n_levels; ++i) {
+            uint32_t r = 0, c = 0;
+            float sigma = 0;
+            check(zg_pyramid_level(source.rows, source.cols, zg_pyramid_scale(scale_factor, i), blur_sigma, &r, &c, &sigma));
+            if (r < 8 || c < 8) break;                                                                                       // pyramid.zig:63-73
+            p.levels.push_back(DeviceImage<T>::init(r, c, source.stream()));
+            descs.push_back(p.levels.back().desc());
+            sigmas.push_back(sigma);
+        }
+        const zg_image s = source.desc();
+        check(zg_pyramid_build(&s, descs.data(), sigmas.data(), (uint32_t)descs.size(), source.stream()));
+        return p;
+    }
+    static ImagePyramid buildDefault(const DeviceImage<T> &source) { return build(source, 8, 1.2f, 1.6f); }                 // pyramid.zig:105-107
+    size_t nLevels() const { return levels.size(); }
+    float getScale(size_t level) const { return zg_pyramid_scale(scale_factor, (uint32_t)level); }                          // pyramid.zig:122-125
+};
+
 // The `pipeline` command (src/cli/pipeline.zig:153-179) over a batch of equally shaped frames resident on the device: a recipe is a
 // list of steps, `run` sends every frame through them in order with one zg_batch_pipeline call (a launch per step over the whole
 // batch where the library has a batched kernel, fused neighbours where it has a fused one; equal to the per-frame methods bit for bit).

@@ -128,7 +128,7 @@ static int motion_linear_impl(const zg_image *src, const zg_image *dst, float an
     if (distance == 0) return copy_impl(src, dst, s);
     if (src->rows == 0 || src->cols == 0) return ZG_OK;
     if (std::fabs(sin_a) < 0.001f || std::fabs(cos_a) < 0.001f) { // motion_blur.zig:77-118
-        ZG_REQUIRE(distance <= 255, ZG_ERR_UNSUPPORTED, "motionBlur.linear: axis-aligned distance %u needs %u taps (255 supported)", distance, distance);
+        ZG_REQUIRE(distance <= (1u << 22), ZG_ERR_INVALID_ARGUMENT, "motionBlur.linear: distance %u is out of range", distance); // any length the separable convolution takes
         std::vector<float> k(distance, 1.0f / (float)distance);
         const float identity = 1.0f;
         return std::fabs(sin_a) < 0.001f ? zg_conv_separable(src, dst, k.data(), distance, &identity, 1, ZG_BORDER_REPLICATE, stream)

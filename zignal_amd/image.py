@@ -690,7 +690,7 @@ class ImagePyramid:
     def build(source: "Image", n_levels: int, scale_factor: float, blur_sigma: float) -> "ImagePyramid":
         assert n_levels > 0 and scale_factor > 1.0 and blur_sigma > 0
         lib = L.lib()
-        levels = [source]
+        levels, sigmas = [source], []
         for i in range(1, n_levels):
             scale = lib.zg_pyramid_scale(C.c_float(scale_factor), i)
             r, c, sigma = C.c_uint32(), C.c_uint32(), C.c_float()
@@ -698,14 +698,18 @@ class ImagePyramid:
                                          C.byref(r), C.byref(c), C.byref(sigma)))
             if r.value < 8 or c.value < 8:
                 break
-            if source.on_device:  # one C call per level: blur (library scratch) + bilinear resize
-                lvl = source._like(r.value, c.value)
-                sd, ld = source._desc(), lvl._desc()
-                L.check(lib.zg_pyramid_build_level(C.byref(sd), C.byref(ld), C.c_float(sigma.value), source._stream()))
-                levels.append(lvl)
+            sigmas.append(sigma.value)
+            if source.on_device:
+                levels.append(source._like(r.value, c.value))
             else:
                 base = source.gaussian_blur(sigma.value) if sigma.value > 0.5 else source
                 levels.append(base.resize((r.value, c.value), Interpolation.bilinear))
+        if source.on_device and len(levels) > 1:  # ONE call for the whole pyramid: the levels fork over internal streams and join back
+            descs = (L.ZgImage * (len(levels) - 1))(*[l._desc() for l in levels[1:]])
+            sig = (C.c_float * len(sigmas))(*sigmas)
+            sd = source._desc()
+            with torch.cuda.device(source.data.device):
+                L.check(lib.zg_pyramid_build(C.byref(sd), descs, sig, len(sigmas), source._stream()))
         return ImagePyramid(levels, scale_factor, blur_sigma)
 
     @staticmethod
