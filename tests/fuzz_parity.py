@@ -50,7 +50,7 @@ def same(a, b):
 
 def case(rng):
     kind = str(rng.choice(KINDS))
-    op = str(rng.choice(["blur", "sep", "conv2d", "box", "resize", "warp", "rotate", "convert", "sobel", "canny", "shen", "motion", "insert_flip", "letterbox_extract", "misc8", "codec"]))
+    op = str(rng.choice(["blur", "sep", "conv2d", "box", "resize", "warp", "rotate", "convert", "sobel", "canny", "shen", "motion", "insert_flip", "letterbox_extract", "misc8", "codec", "pipeline", "pipeline"]))
     rows, cols = dim(rng, MAX_ROWS), dim(rng, MAX_COLS)
     img = synth(rng, kind, rows, cols)
     border = int(rng.integers(0, 4))
@@ -60,6 +60,8 @@ def case(rng):
     methods = [(I.nearest, o.NEAREST), (I.bilinear, o.BILINEAR), (I.bicubic, o.BICUBIC), (I.catmull_rom, o.CATMULL_ROM), (I.lanczos, o.LANCZOS)]
     if op == "codec":
         return codec_case(rng)
+    if op == "pipeline":
+        return pipeline_case(rng, kind)
     if op == "blur":
         sigma = float(rng.choice([0.3, 0.6, 1.0, 1.4, 2.25, 3.3, 5.5]))
         return f"blur {kind} {rows}x{cols} sigma={sigma}", D(img).gaussian_blur(sigma), o.gaussian_blur(img, sigma)
@@ -195,6 +197,48 @@ def case(rng):
         got = D(img).extract(rect, ang, (dr, dc), m, border, cos_sin=cs)
         return f"extract {kind} {rows}x{cols} rect={rect} a={ang}", got, want
     return None
+
+
+def pipeline_case(rng, kind):
+    """zg_batch_pipeline over a few frames against the oracle applied step by step to every frame (a recipe of 1-4 random steps)."""
+    n = int(rng.integers(1, 6))
+    rows, cols = dim(rng, min(MAX_ROWS, 200)), dim(rng, min(MAX_COLS, 600))
+    frames = np.stack([synth(rng, kind, rows, cols) for _ in range(n)])
+    I = zg.Interpolation
+    methods = [(I.nearest, o.NEAREST), (I.bilinear, o.BILINEAR), (I.bicubic, o.BICUBIC), (I.catmull_rom, o.CATMULL_ROM)]
+    steps, refs, desc = [], [], []
+    cur_kind, r, c = kind, rows, cols
+    for _ in range(int(rng.integers(1, 5))):
+        what = str(rng.choice(["blur", "blur", "resize", "resize", "box", "convert", "half"]))
+        if what == "blur":
+            sigma = float(rng.choice([0.0, 0.3, 0.6, 1.0, 1.4, 2.25]))
+            steps.append(zg.Step.gaussian_blur(sigma)); refs.append(lambda a, sigma=sigma: o.gaussian_blur(a, sigma) if sigma > 0 else a.copy()); desc.append(f"blur{sigma}")
+        elif what == "box":
+            rad = int(rng.integers(0, 4))
+            steps.append(zg.Step.box_blur(rad)); refs.append(lambda a, rad=rad: o.box_blur(a, rad)); desc.append(f"box{rad}")
+        elif what in ("resize", "half"):
+            if what == "half" and r % 2 == 0 and c % 4 == 0 and r >= 2:
+                nr, nc, (zm, om) = r // 2, c // 2, methods[1]
+            else:
+                nr, nc, (zm, om) = dim(rng, min(MAX_ROWS, 200)), dim(rng, min(MAX_COLS, 600)), methods[int(rng.integers(0, len(methods)))]
+            steps.append(zg.Step.resize(nr, nc, zm)); refs.append(lambda a, nr=nr, nc=nc, om=om: o.resize(a, (nr, nc), o.method(om))); desc.append(f"resize{nr}x{nc}:{om}")
+            r, c = nr, nc
+        elif what == "convert" and cur_kind in ("rgb_u8", "rgba_u8"):
+            space, ospace = (zg.CS_OKLAB, o.CS_OKLAB) if rng.random() < 0.5 else (zg.CS_XYZ, o.CS_XYZ)
+            src_space = o.CS_RGB if cur_kind == "rgb_u8" else o.CS_RGBA
+            steps.append(zg.Step.convert(space)); refs.append(lambda a, src_space=src_space, ospace=ospace: o.convert(a, src_space, ospace, np.float32, 3)); desc.append(f"convert{space}")
+            cur_kind = "lab_f32"
+            break  # colour types past Rgb / Rgba are not inputs of the other steps here
+    if not steps:
+        return None
+    got = zg.Pipeline(steps).run(torch.from_numpy(frames).cuda()).cpu().numpy()
+    want = []
+    for f in frames:
+        a = f
+        for ref in refs:
+            a = ref(a)
+        want.append(a)
+    return f"pipeline {kind} {n}x{rows}x{cols} " + ",".join(desc), got, np.stack(want)
 
 
 def codec_case(rng):

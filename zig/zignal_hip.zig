@@ -583,6 +583,60 @@ pub fn Image(comptime T: type) type {
 /// that depends on it (Gaussian taps with @exp, @cos / @sin of rotation angles, the sRGB table with std.math.pow).
 /// Allocator parameters are kept where the reference has them so call sites do not change; they allocate host scratch only
 /// (tap arrays), never pixels.
+/// ImagePyramid(T) (reference src/image/pyramid.zig:11-170) resident on the device. `build` has the reference's signature and rules:
+/// level 0 is the source itself (not copied, pyramid.zig:54), level i the source blurred with sigma_i = blur_sigma * sqrt(scale_i^2 - 1)
+/// (only above 0.5) and resized bilinearly to trunc(dim / scale_i); a level below 8 x 8 truncates the pyramid. scale_i is computed HERE
+/// with std.math.pow, so a Zig host keeps Zig's own bits; the whole pyramid is then one zg_pyramid_build call (no host round trip
+/// between levels; the levels fork over internal streams under capture and join back into the source's stream).
+pub fn DevicePyramid(comptime T: type) type {
+    return struct {
+        const Self = @This();
+        levels: []DeviceImage(T),
+        scale_factor: f32,
+        n_levels: u8,
+        blur_sigma: f32,
+        allocator: std.mem.Allocator,
+
+        pub fn build(allocator: std.mem.Allocator, source: DeviceImage(T), n_levels: u8, scale_factor: f32, blur_sigma: f32) !Self {
+            std.debug.assert(n_levels > 0 and scale_factor > 1.0 and blur_sigma > 0);
+            var levels = try allocator.alloc(DeviceImage(T), n_levels);
+            errdefer allocator.free(levels);
+            levels[0] = source;
+            levels[0].owned = false;
+            var descs = try allocator.alloc(c.ZgImage, n_levels);
+            defer allocator.free(descs);
+            var sigmas = try allocator.alloc(f32, n_levels);
+            defer allocator.free(sigmas);
+            var built: usize = 1;
+            errdefer for (levels[1..built]) |*l| l.deinit();
+            while (built < n_levels) : (built += 1) {
+                const scale = std.math.pow(f32, scale_factor, @as(f32, @floatFromInt(built)));
+                var r: u32 = 0;
+                var cc: u32 = 0;
+                var sigma: f32 = 0;
+                try check(c.zg_pyramid_level(source.rows, source.cols, scale, blur_sigma, &r, &cc, &sigma));
+                if (r < 8 or cc < 8) break; // pyramid.zig:63-73
+                levels[built] = try DeviceImage(T).init(r, cc, source.stream);
+                descs[built - 1] = levels[built].desc();
+                sigmas[built - 1] = sigma;
+            }
+            const s = source.desc();
+            try check(c.zg_pyramid_build(&s, descs.ptr, sigmas.ptr, @intCast(built - 1), source.stream));
+            return .{ .levels = try allocator.realloc(levels, built), .scale_factor = scale_factor, .n_levels = @intCast(built), .blur_sigma = blur_sigma, .allocator = allocator };
+        }
+        pub fn buildDefault(allocator: std.mem.Allocator, source: DeviceImage(T)) !Self { // pyramid.zig:105-107
+            return build(allocator, source, 8, 1.2, 1.6);
+        }
+        pub fn deinit(self: *Self) void { // pyramid.zig:110-118: level 0 belongs to the caller
+            for (self.levels[1..]) |*l| l.deinit();
+            self.allocator.free(self.levels);
+        }
+        pub fn getScale(self: Self, level: usize) f32 { // pyramid.zig:122-125
+            return std.math.pow(f32, self.scale_factor, @as(f32, @floatFromInt(level)));
+        }
+    };
+}
+
 pub fn DeviceImage(comptime T: type) type {
     return struct {
         const Self = @This();
