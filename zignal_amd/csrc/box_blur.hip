@@ -258,8 +258,9 @@ __global__ __launch_bounds__(256) void k_sat_rows_exact(DImg src, float *sat) { 
 
 // carry[(r * nstrips + s) * C + ch] = sum of row r, channel ch, over columns < 16 s, as an exact f32. One workgroup per row,
 // every channel at once (the source is read once): 4 pixels per thread and step, integer block scan.
-template <int PIX>
+template <int PIX, int LOG2G = 4> // strips of 2^LOG2G columns (16 for the SAT kernels, 8 for the fused box blur)
 __device__ __forceinline__ void strip_carries_body(const DImg &src, float *carries, int nstrips, uint32_t (*wsum)[4][Px<PIX>::C]) {
+    static_assert(LOG2G >= 2, "a thread covers four columns");
     using P = Px<PIX>;
     using Elem = typename P::Elem;
     constexpr int C = P::C;
@@ -312,7 +313,7 @@ __device__ __forceinline__ void strip_carries_body(const DImg &src, float *carri
         }
         __syncthreads(); // one barrier per step: the totals alternate between two buffers
         const int next = c + 4; // the prefix through column c + 3 is the carry of the strip that starts at column c + 4
-        const bool boundary = (next & 15) == 0 && next < src.cols;
+        const bool boundary = (next & ((1 << LOG2G) - 1)) == 0 && next < src.cols;
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) {
             const uint32_t w0 = wsum[it & 1][0][ch], w1 = wsum[it & 1][1][ch], w2 = wsum[it & 1][2][ch], w3 = wsum[it & 1][3][ch];
@@ -320,16 +321,16 @@ __device__ __forceinline__ void strip_carries_body(const DImg &src, float *carri
             if (w > 0) base += w0;
             if (w > 1) base += w1;
             if (w > 2) base += w2;
-            if (boundary) carries[((size_t)r * nstrips + (next >> 4)) * C + ch] = (float)base; // < 2^24: exact
+            if (boundary) carries[((size_t)r * nstrips + (next >> LOG2G)) * C + ch] = (float)base; // < 2^24: exact
             carry[ch] += w0 + w1 + w2 + w3;
         }
         if (c0 == 0 && t < C) carries[(size_t)r * nstrips * C + t] = 0.0f; // strip 0
     }
 }
-template <int PIX>
+template <int PIX, int LOG2G = 4>
 __global__ __launch_bounds__(256) void k_strip_carries(DImg src, float *carries, int nstrips) {
     __shared__ uint32_t wsum[2][4][Px<PIX>::C];
-    strip_carries_body<PIX>(src, carries, nstrips, wsum);
+    strip_carries_body<PIX, LOG2G>(src, carries, nstrips, wsum);
 }
 
 // A workgroup owns four adjacent 16-column strips of ONE channel for the whole height (64 columns: 256 contiguous bytes of SAT
@@ -647,6 +648,7 @@ int sat_planes_multi(const zg_image *const *srcs, float *const *sats, int count,
     if (e != hipSuccess) { set_error("integral image: launch failed: %s", hipGetErrorString(e)); return ZG_ERR_HIP; }
     return ZG_OK;
 }
+
 
 static int box_blur_impl(const zg_image *src, const zg_image *dst, uint32_t radius, bool sharpen, hipStream_t s) {
     int rc;
