@@ -319,7 +319,7 @@ def live_traffic(op: str, kernel: str, launches: int = 5):
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             with tempfile.TemporaryDirectory(dir="/tmp") as d:
-                env = dict(os.environ, TMPDIR="/tmp")
+                env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))  # run_op.py imports zignal_amd from the cwd otherwise
                 p = subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "r", "--", sys.executable, os.path.join(ROOT, "tools", "run_op.py"), op, str(launches)],
                                    cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
                 dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
