@@ -100,9 +100,9 @@ int run_blur(const Frames &in, const Frames &out, float sigma, hipStream_t s) {
 }
 
 int run_resize(const Frames &in, const Frames &out, const zg_method &method, hipStream_t s) {
-    if (method.kind == ZG_INTERP_BILINEAR && in.n > 0) {
+    if (in.n > 0) { // one launch over the batch wherever the path is a single kernel
         const zg_image a = in.frame(0), b = out.frame(0);
-        const int rc = resize_bilinear_rgba8_frames(&a, &b, in.n, in.frame_bytes(), out.frame_bytes(), s);
+        const int rc = resize_frames(&a, &b, &method, in.n, in.frame_bytes(), out.frame_bytes(), s);
         if (rc >= 0) return rc;
     }
     return per_frame(in, out, [&](const zg_image *a, const zg_image *b) { return resize_impl(a, b, &method, s); });
@@ -220,7 +220,11 @@ int zg_batch_pipeline(const void *src_frames, uint32_t n_frames, uint32_t rows, 
                 case ZG_STEP_BOX_BLUR: rc = per_frame(cur, next, [&](const zg_image *a, const zg_image *b) { return zg_box_blur(a, b, st.radius, stream); }); break;
                 case ZG_STEP_RESIZE: rc = run_resize(cur, next, st.method, s); break;
                 case ZG_STEP_CONVERT: rc = run_convert(cur, next, st.srgb_lut, s); break;
-                default: rc = per_frame(cur, next, [&](const zg_image *a, const zg_image *b) { return zg_warp(a, b, st.transform, st.m, &st.method, stream); }); break;
+                default: { // warp: the same map for every frame, one launch
+                    const zg_image a = cur.frame(0), b = next.frame(0);
+                    rc = warp_frames(&a, &b, st.transform, st.m, &st.method, gn, cur.frame_bytes(), next.frame_bytes(), s);
+                    break;
+                }
                 }
                 cur = next;
                 if (i + 1 != n_steps) flip ^= 1;

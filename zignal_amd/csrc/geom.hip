@@ -95,7 +95,7 @@ __device__ inline void source_coord(const GeomParams &g, int c, int r, float &sx
 }
 
 template <int PIX, int KIND>
-__global__ __launch_bounds__(256) void k_geom(DImg src, DImg dst, GeomParams g, MethodArg m, int border, int tiles_x) {
+__global__ __launch_bounds__(256) void k_geom(DImg src, DImg dst, GeomParams g, MethodArg m, int border, int tiles_x, FrameSpan fr) {
     using P = Px<PIX>;
     using Vec = typename P::Vec;
     // 64 x 4 destination tile per workgroup; workgroups numbered XCD-major so one XCD's L2 serves a
@@ -103,6 +103,10 @@ __global__ __launch_bounds__(256) void k_geom(DImg src, DImg dst, GeomParams g, 
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
     if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    const int frame = wg / fr.tiles_per_frame; // a batch of equally shaped frames, the same map for each (zg_batch_pipeline)
+    wg -= frame * fr.tiles_per_frame;
+    src.data = (char *)src.data + (size_t)frame * fr.src_frame;
+    dst.data = (char *)dst.data + (size_t)frame * fr.dst_frame;
     const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
     const int c = tx * 64 + (int)(threadIdx.x & 63);
     const int r = ty * 4 + (int)(threadIdx.x >> 6);
@@ -153,15 +157,22 @@ static int check_method(const zg_method *method) {
     return ZG_OK;
 }
 
+struct FrameBatch { // n frames src_frame / dst_frame bytes apart (defaults: the one image)
+    uint32_t n = 1;
+    size_t src_frame = 0, dst_frame = 0;
+};
 template <int PIX, int KIND>
-static int launch_geom_k(const zg_image *src, const zg_image *dst, const GeomParams &g, const MethodArg &m, int border, hipStream_t s) {
+static int launch_geom_k(const zg_image *src, const zg_image *dst, const GeomParams &g, const MethodArg &m, int border, const FrameBatch &fb, hipStream_t s) {
     const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, 4);
-    hipLaunchKernelGGL((k_geom<PIX, KIND>), dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, dimg(src), dimg(dst), g, m, border, tiles_x);
+    const uint64_t grid = (uint64_t)tiles_x * tiles_y * fb.n;
+    ZG_REQUIRE(grid <= 0x7fffffffu, ZG_ERR_INVALID_ARGUMENT, "too many tiles in one launch (%llu)", (unsigned long long)grid);
+    const FrameSpan fr{fb.src_frame, fb.dst_frame, tiles_x * tiles_y};
+    hipLaunchKernelGGL((k_geom<PIX, KIND>), dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), g, m, border, tiles_x, fr);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
 
-static int launch_geom(const zg_image *src, const zg_image *dst, const GeomParams &g, const zg_method *method, int border, hipStream_t s) {
+static int launch_geom(const zg_image *src, const zg_image *dst, const GeomParams &g, const zg_method *method, int border, hipStream_t s, const FrameBatch &fb = FrameBatch{}) {
     int rc;
     if ((rc = check_method(method))) return rc;
     ZG_REQUIRE(border >= ZG_BORDER_ZERO && border <= ZG_BORDER_WRAP, ZG_ERR_INVALID_ARGUMENT, "invalid border %d", border);
@@ -172,12 +183,12 @@ static int launch_geom(const zg_image *src, const zg_image *dst, const GeomParam
     rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
         switch (method->kind) {
-        case ZG_INTERP_NEAREST: return launch_geom_k<PIX, ZG_INTERP_NEAREST>(src, dst, g, m, border, s);
-        case ZG_INTERP_BILINEAR: return launch_geom_k<PIX, ZG_INTERP_BILINEAR>(src, dst, g, m, border, s);
-        case ZG_INTERP_BICUBIC: return launch_geom_k<PIX, ZG_INTERP_BICUBIC>(src, dst, g, m, border, s);
-        case ZG_INTERP_CATMULL_ROM: return launch_geom_k<PIX, ZG_INTERP_CATMULL_ROM>(src, dst, g, m, border, s);
-        case ZG_INTERP_MITCHELL: return launch_geom_k<PIX, ZG_INTERP_MITCHELL>(src, dst, g, m, border, s);
-        default: return launch_geom_k<PIX, ZG_INTERP_LANCZOS>(src, dst, g, m, border, s);
+        case ZG_INTERP_NEAREST: return launch_geom_k<PIX, ZG_INTERP_NEAREST>(src, dst, g, m, border, fb, s);
+        case ZG_INTERP_BILINEAR: return launch_geom_k<PIX, ZG_INTERP_BILINEAR>(src, dst, g, m, border, fb, s);
+        case ZG_INTERP_BICUBIC: return launch_geom_k<PIX, ZG_INTERP_BICUBIC>(src, dst, g, m, border, fb, s);
+        case ZG_INTERP_CATMULL_ROM: return launch_geom_k<PIX, ZG_INTERP_CATMULL_ROM>(src, dst, g, m, border, fb, s);
+        case ZG_INTERP_MITCHELL: return launch_geom_k<PIX, ZG_INTERP_MITCHELL>(src, dst, g, m, border, fb, s);
+        default: return launch_geom_k<PIX, ZG_INTERP_LANCZOS>(src, dst, g, m, border, fb, s);
         }
     });
     release_lut(lut, s);
@@ -204,6 +215,24 @@ int resize_impl(const zg_image *src, const zg_image *dst, const zg_method *metho
     g.p[0] = (float)src->cols / (float)dst->cols;
     g.p[1] = (float)src->rows / (float)dst->rows;
     return launch_geom(src, dst, g, method, ZG_BORDER_MIRROR, s);
+}
+
+// resize of n equally shaped frames in one launch where the path is a single kernel with a frame index (the generic interpolators of every
+// type that is not Rgb(u8) / Rgba(u8), and Rgba(u8) bilinear); -1 otherwise (zg_batch_pipeline then goes frame by frame).
+int resize_frames(const zg_image *src, const zg_image *dst, const zg_method *method, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s) {
+    int rc;
+    if ((rc = check_pair(src, dst, "resize")) || (rc = check_method(method))) return rc;
+    if (n == 0 || dst->rows == 0 || dst->cols == 0 || src->rows == 0 || src->cols == 0) return -1;
+    if (src->rows == dst->rows && src->cols == dst->cols) return -1; // a copy per frame
+    const bool is_rgb_u8 = src->pixel == ZG_PIXEL_RGB_U8 || src->pixel == ZG_PIXEL_RGBA_U8;
+    if (is_rgb_u8) return method->kind == ZG_INTERP_BILINEAR ? resize_bilinear_rgba8_frames(src, dst, n, src_frame, dst_frame, s) : -1;
+    GeomParams g{};
+    g.mode = GEOM_RESIZE;
+    g.p[0] = (float)src->cols / (float)dst->cols;
+    g.p[1] = (float)src->rows / (float)dst->rows;
+    FrameBatch fb;
+    fb.n = n; fb.src_frame = src_frame; fb.dst_frame = dst_frame;
+    return launch_geom(src, dst, g, method, ZG_BORDER_MIRROR, s, fb);
 }
 
 // Image(Rgb(u8) / Rgba(u8)).resize(.lanczos) with the caller's plane weights (channel_ops.zig:438-493)
@@ -260,7 +289,7 @@ static int letterbox_impl(const zg_image *src, const zg_image *dst, const zg_met
 }
 
 // ---- warp (transforms.zig:522-531) ------------------------------------------------------------------
-static int warp_impl(const zg_image *src, const zg_image *dst, int kind, const float *mat, const zg_method *method, hipStream_t s) {
+static int warp_impl(const zg_image *src, const zg_image *dst, int kind, const float *mat, const zg_method *method, hipStream_t s, const FrameBatch &fb = FrameBatch{}) {
     int rc;
     if ((rc = check_pair(src, dst, "warp"))) return rc;
     ZG_REQUIRE(mat != nullptr, ZG_ERR_INVALID_ARGUMENT, "warp: null transform coefficients");
@@ -273,7 +302,13 @@ static int warp_impl(const zg_image *src, const zg_image *dst, int kind, const f
         g.mode = GEOM_AFFINE;
         for (int i = 0; i < 6; ++i) g.p[i] = mat[i];
     }
-    return launch_geom(src, dst, g, method, ZG_BORDER_MIRROR, s);
+    return launch_geom(src, dst, g, method, ZG_BORDER_MIRROR, s, fb);
+}
+// the same warp applied to n equally shaped frames in one launch
+int warp_frames(const zg_image *src, const zg_image *dst, int kind, const float *mat, const zg_method *method, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s) {
+    FrameBatch fb;
+    fb.n = n; fb.src_frame = src_frame; fb.dst_frame = dst_frame;
+    return warp_impl(src, dst, kind, mat, method, s, fb);
 }
 
 // ---- rotate (transforms.zig:112-212, :385-462) -----------------------------------------------------
