@@ -95,3 +95,36 @@ def test_errors_and_host_layer(oracle):
     out = view.convert(zg.CS_LAB, np.float32)
     torch.cuda.synchronize()
     assert_bits_equal(out.to_numpy(), oracle.convert(np.ascontiguousarray(every_colour_frame()[8:100, 16:200]), zg.CS_RGB, zg.CS_LAB, np.float32, 3), "view")
+
+
+def test_u8_to_xyz_and_oklab_four_pixels_per_lane(oracle):
+    """k_u8_to_lab4 (convert.hip): ragged row ends (cols % 4, cols % 256), one wave's worth of full lanes and more, Rgb and Rgba
+    sources, views whose pitch keeps or breaks the 16-byte rule (the latter stay on k_convert), and linearisation tables that are
+    not 'plain' (negative, tiny, huge, zero, infinite entries: xyz_to_oklab's range tests must then run) — all equal to the oracle."""
+    rng = np.random.default_rng(77)
+    for rows, cols in ((1, 1), (3, 5), (7, 255), (5, 256), (4, 257), (2, 1023), (3, 1027), (2, 2048), (1, 4096 + 64)):
+        for ch, space in ((4, zg.CS_RGBA), (3, zg.CS_RGB)):
+            src = rng.integers(0, 256, (rows, cols, ch), dtype=np.uint8)
+            src[0, : min(cols, 9)] = 0  # black pixels: cbrt(0) takes the reference's own early return
+            for dst in (zg.CS_OKLAB, zg.CS_XYZ):
+                want = oracle.convert(src, space, dst, np.float32, 3)
+                assert_bits_equal(run(src, space, dst, np.float32), want, f"{rows}x{cols}x{ch} -> {dst}")
+    # views: a 1024-wide window of a wider frame (pitch a multiple of four pixels: the four-pixel kernel) and one shifted by a pixel
+    wide = rng.integers(0, 256, (6, 1200, 4), dtype=np.uint8)
+    whole = dev(wide)
+    for c0, c1 in ((0, 1024), (4, 1028), (1, 1025), (3, 1003)):
+        view = zg.Image(whole.data[:, c0:c1])
+        out = view.convert(zg.CS_OKLAB, np.float32)
+        torch.cuda.synchronize()
+        assert_bits_equal(out.to_numpy(), oracle.convert(np.ascontiguousarray(wide[:, c0:c1]), zg.CS_RGBA, zg.CS_OKLAB, np.float32, 3), f"view {c0}:{c1}")
+    ramp = np.stack([np.arange(256, dtype=np.uint8)] * 3, -1)[None].repeat(3, 0)
+    ramp[1] = ramp[1][::-1]
+    ramp[2, :, 1:] = 0
+    odd = np.linspace(0, 1, 256, dtype=np.float32) ** 2
+    odd[3], odd[7], odd[11], odd[200], odd[255] = -0.25, 1e-30, 1e-42, 3e38, np.inf
+    odd[13] = np.float32(-0.0)
+    with np.errstate(all="ignore"):
+        want = oracle.convert(ramp, zg.CS_RGB, zg.CS_OKLAB, np.float32, 3, srgb_lut=odd)
+    got = dev(ramp).convert(zg.CS_OKLAB, np.float32, srgb_lut=odd)
+    torch.cuda.synchronize()
+    assert_bits_equal(got.to_numpy(), want, "odd table")

@@ -20,6 +20,7 @@
 #include "zg_bilinear_u8.h"
 
 #include <cmath>
+#include <cstring>
 #include <mutex>
 
 #pragma clang fp contract(off)
@@ -146,8 +147,120 @@ __global__ __launch_bounds__(256) void k_convert(DImg src, DImg dst, ConvertArgs
     DP::store(dst.data, (size_t)r * dst.stride + (size_t)c, dv);
 }
 
-static int device_srgb_lut(const float *host_lut, hipStream_t s, const float **out, float **owned) {
+// Rgb(u8) / Rgba(u8) -> Xyz / Oklab (f32), four pixels per lane. k_convert's one pixel per lane leaves a wave with a single chain
+// load -> three table look-ups -> ~220 VALU -> store and nothing to overlap it with: at eight waves per SIMD the VALU sat idle a third
+// of the time (SQ_WAIT_INST_ANY 37 % of wave-cycles). Here a lane loads four pixels at once (one dwordx4 / dwordx3), looks its twelve
+// bytes up in an LDS copy of the sRGB table, and stores 48 contiguous bytes as three dwordx4. Same device functions as k_convert
+// (zg_colordev.h), so the bits are the same by construction. Needs 16-byte aligned rows on the f32 side and 4 * SC-byte aligned
+// rows on the u8 side (the launcher checks; anything else stays on k_convert).
+typedef uint32_t lab4_u32x4 __attribute__((ext_vector_type(4)));
+typedef float lab4_f32x4 __attribute__((ext_vector_type(4)));
+template <int SC, int MODE> // MODE 0: Xyz, 1: Oklab, 2: Oklab from a table whose entries are +0 or within [2^-60, 2^60] (xyz_to_oklab<true>)
+__global__ __launch_bounds__(256) void k_u8_to_lab4(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint64_t src_pitch, uint64_t dst_pitch,
+                                                    int rows, int cols, const float *__restrict__ lut_global) {
+    __shared__ float lut[256];
+    __shared__ __attribute__((aligned(16))) float turn[4 * 768];
+    lut[threadIdx.x] = lut_global[threadIdx.x];
+    __syncthreads();
+    const int c0 = (int)(blockIdx.x * 256 + threadIdx.x) * 4, r = grid_row();
+    if (c0 >= cols || r >= rows) return;
+    const uint8_t *sp = src + (uint64_t)r * src_pitch + (uint64_t)c0 * SC;
+    float *dp = (float *)(dst + (uint64_t)r * dst_pitch) + (uint64_t)c0 * 3;
+    const int n = cols - c0 < 4 ? cols - c0 : 4;
+    uint32_t w[SC] = {};
+    if (n == 4) {
+        if constexpr (SC == 4) {
+            const lab4_u32x4 v = *(const lab4_u32x4 *)sp;
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+            const uint32_t *q = (const uint32_t *)sp;
+            w[0] = q[0]; w[1] = q[1]; w[2] = q[2];
+        }
+    } else { // the ragged end of a row, byte by byte
+        for (int i = 0; i < n * SC; ++i) {
+            const uint32_t b = (uint32_t)sp[i] << (8 * (i & 3));
+#pragma unroll
+            for (int k = 0; k < SC; ++k) w[k] |= (i >> 2) == k ? b : 0u;
+        }
+    }
+    float out[12];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        float lin[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int byte = p * SC + i;
+            lin[i] = lut[(w[byte >> 2] >> (8 * (byte & 3))) & 255u];
+        }
+        float X, Y, Z;
+        linear_rgb_to_xyz(lin, X, Y, Z);
+        if constexpr (MODE == 0) { out[3 * p] = X; out[3 * p + 1] = Y; out[3 * p + 2] = Z; }
+        else xyz_to_oklab<MODE == 2>(X, Y, Z, out[3 * p], out[3 * p + 1], out[3 * p + 2]);
+    }
+    // a lane's 48 bytes are contiguous but the next lane's start 48 bytes on: stored as they are, every dwordx4 store of the wave touches
+    // 24 cache lines and fills a third of each. When all 64 lanes hold four pixels the wave turns its 3 KiB through LDS instead (each
+    // wave its own 3 KiB, LDS operations of one wave execute in order) and stores three times 1 KiB of consecutive addresses.
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int wave_c0 = (int)(blockIdx.x * 256 + (threadIdx.x & ~63u)) * 4;
+    if (wave_c0 + 256 <= cols) {
+        lab4_f32x4 *mine = (lab4_f32x4 *)(turn + wave * 768);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) mine[lane * 3 + k] = lab4_f32x4{out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        lab4_f32x4 *wave_dp = (lab4_f32x4 *)(dp - (size_t)lane * 12);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wave_dp[k * 64 + lane] = mine[k * 64 + lane];
+    } else if (n == 4) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ((lab4_f32x4 *)dp)[k] = lab4_f32x4{out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            if (i < 3 * n) dp[i] = out[i];
+    }
+}
+
+static bool lab4_applies(const zg_image *src, const zg_image *dst, int src_space, int dst_space) {
+    if (dst->pixel != ZG_PIXEL_RGB_F32 || (dst_space != ZG_CS_XYZ && dst_space != ZG_CS_OKLAB)) return false;
+    if (!((src->pixel == ZG_PIXEL_RGBA_U8 && src_space == ZG_CS_RGBA) || (src->pixel == ZG_PIXEL_RGB_U8 && src_space == ZG_CS_RGB))) return false;
+    const uint64_t sc = src->pixel == ZG_PIXEL_RGBA_U8 ? 4 : 3, need = sc == 4 ? 16 : 4;
+    if (((uintptr_t)src->data % need) || ((uint64_t)src->stride * sc % need)) return false;
+    if (((uintptr_t)dst->data % 16) || ((uint64_t)dst->stride * 12 % 16)) return false;
+    static const bool off = getenv("ZIGNAL_HIP_NO_LAB4") != nullptr; // tuning hook
+    return !off;
+}
+
+static int launch_lab4(const zg_image *src, const zg_image *dst, int dst_space, const float *lut, bool plain_table, hipStream_t s) {
+    const dim3 grid = row_grid(ceil_div(ceil_div((unsigned)src->cols, 4u), 256u), (unsigned)src->rows);
+    const uint8_t *sp = (const uint8_t *)src->data;
+    uint8_t *dp = (uint8_t *)dst->data;
+    const bool four = src->pixel == ZG_PIXEL_RGBA_U8, oklab = dst_space == ZG_CS_OKLAB;
+    const uint64_t spitch = (uint64_t)src->stride * (four ? 4 : 3), dpitch = (uint64_t)dst->stride * 12;
+    const int rows = (int)src->rows, cols = (int)src->cols;
+    const int mode = !oklab ? 0 : (plain_table ? 2 : 1);
+#define ZG_LAB4(SC, MODE) hipLaunchKernelGGL((k_u8_to_lab4<SC, MODE>), grid, dim3(256), 0, s, sp, dp, spitch, dpitch, rows, cols, lut)
+    if (four) { if (mode == 0) ZG_LAB4(4, 0); else if (mode == 1) ZG_LAB4(4, 1); else ZG_LAB4(4, 2); }
+    else { if (mode == 0) ZG_LAB4(3, 0); else if (mode == 1) ZG_LAB4(3, 1); else ZG_LAB4(3, 2); }
+#undef ZG_LAB4
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+// `plain` (optional) comes back true when every entry of the table is +0 or a positive number within [2^-60, 2^60]: what
+// xyz_to_oklab<true> asks for. The library's own sRGB table is (entry 1 is 3.0e-4).
+static int device_srgb_lut(const float *host_lut, hipStream_t s, const float **out, float **owned, bool *plain = nullptr) {
     *owned = nullptr;
+    if (plain) {
+        *plain = true;
+        if (host_lut)
+            for (int i = 0; i < 256; ++i) {
+                uint32_t u;
+                memcpy(&u, &host_lut[i], 4);
+                if (u != 0 && (u < 0x21800000u || u >= 0x5d800000u)) *plain = false; // -0, negatives, tiny, huge, inf, nan
+            }
+    }
     if (host_lut) {
         if (int rc = scratch_alloc((void **)owned, 256 * sizeof(float), s)) return rc;
         if (int rc = upload_pageable(*owned, host_lut, 256 * sizeof(float), s)) return rc;
@@ -201,8 +314,14 @@ int convert_impl(const zg_image *src, int src_space, const zg_image *dst, int ds
 
     ConvertArgs a{src_space, dst_space, nullptr};
     float *owned = nullptr;
+    bool plain_table = false;
     if (!sf && (dst_space == ZG_CS_XYZ || dst_space == ZG_CS_OKLAB)) {
-        if ((rc = device_srgb_lut(srgb_lut, s, &a.srgb_lut, &owned))) return rc;
+        if ((rc = device_srgb_lut(srgb_lut, s, &a.srgb_lut, &owned, &plain_table))) return rc;
+    }
+    if (lab4_applies(src, dst, src_space, dst_space)) {
+        rc = launch_lab4(src, dst, dst_space, a.srgb_lut, plain_table, s);
+        if (owned) scratch_free(owned, s);
+        return rc;
     }
     const dim3 grid = row_grid(ceil_div(src->cols, 256), src->rows);
     rc = dispatch_pixel(src->pixel, [&](auto stag) -> int {
@@ -226,7 +345,7 @@ int convert_impl(const zg_image *src, int src_space, const zg_image *dst, int ds
 // result equals the two calls bit for bit. Algorithmic bytes: 16 read + 12 written per output pixel (28 B).
 int resize_impl(const zg_image *src, const zg_image *dst, const zg_method *method, hipStream_t s);
 
-template <bool OKLAB>
+template <int MODE> // as k_u8_to_lab4's
 __global__ __launch_bounds__(256) void k_resize_bilinear_rgba8_to_lab(DImg src, DImg dst, float ratio_x, float ratio_y, int tiles_x, const float *srgb_lut, FrameSpan fr) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
@@ -252,8 +371,8 @@ __global__ __launch_bounds__(256) void k_resize_bilinear_rgba8_to_lab(DImg src, 
     const float lin[3] = {srgb_lut[px & 0xffu], srgb_lut[(px >> 8) & 0xffu], srgb_lut[(px >> 16) & 0xffu]};
     float X, Y, Z, o0, o1, o2;
     linear_rgb_to_xyz(lin, X, Y, Z);
-    if constexpr (OKLAB) xyz_to_oklab(X, Y, Z, o0, o1, o2);
-    else { o0 = X; o1 = Y; o2 = Z; }
+    if constexpr (MODE == 0) { o0 = X; o1 = Y; o2 = Z; }
+    else xyz_to_oklab<MODE == 2>(X, Y, Z, o0, o1, o2);
     float *o = (float *)dst.data + ((size_t)r * dst.stride + (size_t)c) * 3;
     o[0] = o0; o[1] = o1; o[2] = o2;
 }
@@ -269,13 +388,16 @@ int resize_convert_rgba8_frames(const zg_image *src, const zg_image *dst, int ds
     if (grid > 0x7fffffffu) return -1;
     const float *lut_dev = nullptr;
     float *owned = nullptr;
-    if (int rc = device_srgb_lut(srgb_lut, s, &lut_dev, &owned)) return rc;
+    bool plain_table = false;
+    if (int rc = device_srgb_lut(srgb_lut, s, &lut_dev, &owned, &plain_table)) return rc;
     const float ratio_x = (float)src->cols / (float)dst->cols, ratio_y = (float)src->rows / (float)dst->rows;
     const FrameSpan fr{src_frame, dst_frame, tiles_x * tiles_y};
-    if (dst_space == ZG_CS_OKLAB)
-        hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<true>, dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr);
+    if (dst_space != ZG_CS_OKLAB)
+        hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<0>, dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr);
+    else if (plain_table)
+        hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<2>, dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr);
     else
-        hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<false>, dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr);
+        hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<1>, dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr);
     const hipError_t e = hipGetLastError();
     if (owned) scratch_free(owned, s);
     ZG_HIP(e);

@@ -15,13 +15,34 @@ __device__ inline void linear_rgb_to_xyz(const float lin[3], float &X, float &Y,
     Z = (lin[0] * 0.0193f + lin[1] * 0.1192f + lin[2] * 0.9505f) * 100;
 }
 
-// Xyz -> Oklab (color.zig:1381-1400)
+// Xyz -> Oklab (color.zig:1381-1400). IN_RANGE: the caller vouches that X, Y, Z are each +0 or a normal number between 2^-100 and
+// 2^120 — true whenever they come from a linearisation table whose entries are +0 or within [2^-60, 2^60] (the sRGB table is;
+// the launchers check a caller's table on the host) — and dev_div100's range test is left out.
+template <bool IN_RANGE = false>
 __device__ inline void xyz_to_oklab(float X, float Y, float Z, float &L, float &A, float &B) {
-    const float x = dev_div100(X), y = dev_div100(Y), z = dev_div100(Z); // == X / 100.0f, bit for bit
+    float x, y, z;
+    if constexpr (IN_RANGE) {
+        bool unused;
+        x = dev_div100_fast(X, unused); y = dev_div100_fast(Y, unused); z = dev_div100_fast(Z, unused);
+    } else {
+        bool rx, ry, rz; // the rare inputs the fast forms hand back (zg_devmath.h): one branch for all three
+        x = dev_div100_fast(X, rx); y = dev_div100_fast(Y, ry); z = dev_div100_fast(Z, rz); // == X / 100.0f, bit for bit
+        if (rx | ry | rz) {
+            if (rx) x = X / 100.0f;
+            if (ry) y = Y / 100.0f;
+            if (rz) z = Z / 100.0f;
+        }
+    }
     const float l_linear = 0.8189330101f * x + 0.3618667424f * y - 0.1288597137f * z;
     const float m_linear = 0.0329845436f * x + 0.9293118715f * y + 0.0361456387f * z;
     const float s_linear = 0.0482003018f * x + 0.2643662691f * y + 0.6338517070f * z;
-    const float l_dash = dev_cbrtf(l_linear), m_dash = dev_cbrtf(m_linear), s_dash = dev_cbrtf(s_linear);
+    bool rl, rm, rs;
+    float l_dash = dev_cbrtf_fast(l_linear, rl), m_dash = dev_cbrtf_fast(m_linear, rm), s_dash = dev_cbrtf_fast(s_linear, rs);
+    if (rl | rm | rs) {
+        if (rl) l_dash = dev_cbrtf_musl(l_linear);
+        if (rm) m_dash = dev_cbrtf_musl(m_linear);
+        if (rs) s_dash = dev_cbrtf_musl(s_linear);
+    }
     L = 0.2104542553f * l_dash + 0.7936177850f * m_dash - 0.0040720468f * s_dash;
     A = 1.9779984951f * l_dash - 2.4285922050f * m_dash + 0.4505937099f * s_dash;
     B = 0.0259040371f * l_dash + 0.7827717662f * m_dash - 0.8086757660f * s_dash;

@@ -32,44 +32,60 @@ __device__ inline float dev_cbrtf_musl(float x) { // Zig std.math.cbrt cbrt32 ==
     return (float)t;
 }
 
-// The same function at a third of the cost. musl's two Halley steps run in f64 with two IEEE divisions (~25 f64 instructions
-// each on this part, and xyzToOklab takes three cube roots per pixel). Its result is the f32 nearest to a double that is
-// accurate to ~2^-50, so any double within 2^-40 of the true cube root rounds to the same f32 unless it sits within that
-// distance of a rounding midpoint. Here: two Halley steps in f32 with v_rcp_f32 (t is then good to f32 precision), and ONE
-// correction t + t (x - t^3) / (x + 2 t^3) — Halley again, written so that only the residual x - t^3 needs f64 (two
-// multiplications and a subtraction); the quotient is a 2^-22 correction and f32 is plenty for it. When the resulting
-// double lands within 2^-14 f32-ulp of a midpoint (one lane in 8 192) the lane takes musl's own steps instead; so do
-// arguments below 2^-100 or near overflow, which would lose bits or overflow in the f32 steps.
-// tests/test_math_pin.py compares the two over ALL 2^32 bit patterns: identical.
-__device__ inline float dev_cbrtf(float x) {
+// The same function at a quarter of the cost. musl's two Halley steps run in f64 with two IEEE divisions (~25 f64 instructions
+// each, and xyzToOklab takes three cube roots per pixel). Its result is the f32 nearest to a double that is accurate to ~2^-50, so
+// any value within 2^-40 of the true cube root rounds to the same f32 unless it sits within that distance of a rounding midpoint.
+// Here: t = exp2(log2 |x| / 3) from the two hardware transcendentals (good to ~2^-20 between 2^-60 and 2^60) and ONE Halley
+// correction c = t (x - t^3) / (x + 2 t^3), written so that only the residual x - t^3 needs more than f32: t^2 and t^2 t are split
+// into product + rounding error by FMA (both exact), x - fl(t^3) is exact (the two agree to 2^-19), and what remains are 2^-20-sized
+// terms for which f32 is plenty. t + c is then ONE f32 addition, i.e. the correctly rounded sum, and its own rounding error
+// (c - (s - t), exact) says how far the sum was from a rounding midpoint: within 2^-16 ulp (one lane in 32 768) the lane takes
+// musl's own steps instead; so do arguments outside [2^-60, 2^60). Contraction is off in this file: the FMAs below are the ones
+// written. v_log_f32 / v_exp_f32 / v_rcp_f32 are gfx950's: tests/test_math_pin.py compares this function with the musl form over
+// ALL 2^32 bit patterns on the part itself, which is the proof that the margins above are wide enough — identical.
+// `redo` comes back true when the value returned is not to be used and dev_cbrtf_musl must run instead; callers with several
+// cube roots (xyz_to_oklab) run all the fast parts back to back and share ONE rare branch.
+__device__ inline float dev_cbrtf_fast(float x, bool &redo) {
     const uint32_t u0 = __float_as_uint(x), hx = u0 & 0x7fffffffu;
-    if (hx < 0x0d800000u || hx >= 0x7d800000u) return dev_cbrtf_musl(x); // zero, < 2^-100 (the residual must stay a normal f32), >= 2^124 (so must 3x and its reciprocal), inf, nan
-    float t = __uint_as_float((u0 & 0x80000000u) | (hx / 3 + 709958130u));
-    float r = t * t * t;
-    t = t * (((x + x) + r) * __builtin_amdgcn_rcpf((x + r) + r)); // the ratio is ~1: nothing under- or overflows
-    r = t * t * t;
-    const float rc = __builtin_amdgcn_rcpf((x + r) + r);
-    t = t * (((x + x) + r) * rc);
-    const double td = (double)t;
-    const float resid = (float)((double)x - td * td * td); // exact to ~2^-52 x: the part f32 could not see
-    const double q = td + (double)(t * (resid * rc));       // rc still fits: t moved by 2^-15 at most since it was formed
-    const uint32_t low = (uint32_t)__double_as_longlong(q) & 0x1fffffffu; // the 29 significand bits below f32's last
-    const uint32_t off = low > 0x10000000u ? low - 0x10000000u : 0x10000000u - low;
-    if (off < (1u << 15)) return dev_cbrtf_musl(x); // too close to a rounding midpoint to call: the reference's own steps decide
-    return (float)q;
+    const float mag = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(__uint_as_float(hx)) * 0x1.555556p-2f);
+    const float t = __uint_as_float(__float_as_uint(mag) | (u0 & 0x80000000u));
+    const float t2 = t * t, e2 = __builtin_fmaf(t, t, -t2);    // t^2   = t2 + e2
+    const float t3 = t2 * t, e3 = __builtin_fmaf(t2, t, -t3);  // t2 t  = t3 + e3
+    const float resid = ((x - t3) - e3) - e2 * t;              // x - t^3 to ~2^-44 x
+    const float c = t * (resid * __builtin_amdgcn_rcpf((x + t3) + t3));
+    const float s = t + c;
+    const float lost = c - (s - t);                            // exact: |t| > |c|
+    const uint32_t se = __float_as_uint(s) & 0x7f800000u;
+    const float half_ulp = __uint_as_float(se - (24u << 23)), near = __uint_as_float(se - (39u << 23));
+    // a tie is |lost| == half_ulp. Zero is its own cube root and musl says so before doing any arithmetic: it takes that road too,
+    // with everything else outside the range, in ONE unsigned comparison.
+    redo = (hx - 0x21800000u >= 0x5d800000u - 0x21800000u) | (fabsf(fabsf(lost) - half_ulp) < near);
+    return s;
+}
+__device__ inline float dev_cbrtf(float x) {
+    bool redo;
+    const float s = dev_cbrtf_fast(x, redo);
+    if (redo) return dev_cbrtf_musl(x);
+    return s;
 }
 
 // x / 100.0f (xyzToOklab, color.zig:1381-1384) without the IEEE-division expansion (~12 instructions, three per pixel): the
 // quotient by the correctly rounded reciprocal, the exact remainder with one FMA, one correction. For a constant divisor this
 // is correctly rounded wherever neither the quotient nor the remainder leaves the normal range; outside (|x| < 2^-100,
 // |x| >= 2^120, inf, nan) the division itself runs. tests/test_math_pin.py compares it with x / 100.0f over ALL 2^32 inputs.
-__device__ inline float dev_div100(float x) {
-    const uint32_t ax = __float_as_uint(x) & 0x7fffffffu;
-    if (ax < 0x0d800000u || ax >= 0x7b800000u) return x / 100.0f;
+__device__ inline float dev_div100_fast(float x, bool &redo) { // `redo`: as in dev_cbrtf_fast. +0 stays here (the steps below give +0); -0 does not
+    const uint32_t u = __float_as_uint(x), ax = u & 0x7fffffffu;
+    redo = (ax - 0x0d800000u >= 0x7b800000u - 0x0d800000u) & (u != 0);
     const float r = 0.01f;
     const float q = x * r;
     const float e = __builtin_fmaf(-q, 100.0f, x);
     return __builtin_fmaf(e, r, q);
+}
+__device__ inline float dev_div100(float x) {
+    bool redo;
+    const float q = dev_div100_fast(x, redo);
+    if (redo) return x / 100.0f;
+    return q;
 }
 
 __device__ inline float dev_scalbnf(float x, int n) {
