@@ -23,6 +23,9 @@
 #include "zg_common.h"
 #include "zg_u8pack.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace zg {
 
 constexpr int B2_HMAX = 32;  // padded half width of the row pass (a multiple of 4)
@@ -217,6 +220,87 @@ __global__ __launch_bounds__(256) void k_cols_u16(const uint32_t *temp, uint8_t 
         cols_strip<CLAMP, false>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
 }
 
+// The column pass of every normalised kernel. When the host proved sum(kx) * sum(ky) * 255 + 32768 < 2^24 each partial sum is an
+// integer below 2^24 and f32 holds it exactly, so the multiply-adds run as (packed) f32 FMAs with the taps as f32 in SGPRs — two
+// per instruction where v_mad_u32_u16 does one at the same issue cost (tools/exp/valu_rate.hip) — and the temps are converted once
+// per streamed row. A lane owns TWO adjacent bytes (one packed temp dword) of 32 output rows: 64 accumulator registers instead of
+// 128, so four waves fit a SIMD where the integer form fits two, and a 4096-byte row gives 4 096 waves instead of 2 048.
+template <bool INSIDE>
+__device__ __forceinline__ void cols_strip_f32(const uint32_t *temp, uint8_t *dst, size_t dst_pitch, int rows, int row_bytes,
+                                               const TapsCols &taps, int nk, int half, int border, int tx, int ty) {
+    const int xd = tx * 256 + (int)threadIdx.x; // this lane's packed temp dword of the row (2 bytes of output)
+    const bool live = xd * 2 < row_bytes;
+    const int xdc = live ? xd : 0;
+    const int y0 = ty * B2_R;
+    const size_t trow = (size_t)row_bytes / 2;
+    float acc[B2_R][2];
+#pragma unroll
+    for (int o = 0; o < B2_R; ++o) acc[o][0] = acc[o][1] = 32768.0f; // divClampU8's rounding term
+    const int nrows_in = B2_R + nk - 1;
+    const uint32_t *tcol = temp + (size_t)xdc;
+    const uint32_t *next_row = tcol + (size_t)(INSIDE ? y0 - half : 0) * trow;
+    auto fetch = [&](int r) -> uint32_t { // temp row y0 - half + r; called with r = 0, 1, 2, ... in order
+        if constexpr (INSIDE) { // rows past the strip's last (prefetch overshoot) fall in the temp plane's slack rows
+            const uint32_t p = *next_row;
+            next_row += trow;
+            return p;
+        } else {
+            const int gr = resolve_index(y0 - half + min(r, nrows_in - 1), rows, border); // scalar
+            const uint32_t p = tcol[(size_t)max(gr, 0) * trow];
+            return gr < 0 ? 0u : p;
+        }
+    };
+    uint32_t cur[8], nxt[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cur[i] = fetch(i);
+    for (int r0 = 0; r0 < nrows_in; r0 += 8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) nxt[i] = fetch(r0 + 8 + i);
+        uint32_t kw[40]; // as in cols_strip: entry 32 + i - o is the tap output row o takes from temp row r0 + i
+#pragma unroll
+        for (int c = 0; c < 40; ++c) kw[c] = taps.k[r0 + c];
+#pragma unroll
+        for (int ib = 0; ib < 8; ib += 4) {
+#pragma unroll
+            for (int ob = 0; ob < B2_R; ob += 4) {
+                if (r0 + ib + 3 >= ob && r0 + ib - ob - 3 < nk) {
+#pragma unroll
+                    for (int i = ib; i < ib + 4; ++i) {
+                        const float t0 = (float)(cur[i] & 0xffffu), t1 = (float)(cur[i] >> 16);
+#pragma unroll
+                        for (int o = ob; o < ob + 4; ++o) {
+                            const float k = __uint_as_float(__builtin_amdgcn_readfirstlane(kw[32 + i - o]));
+                            acc[o][0] = __builtin_fmaf(t0, k, acc[o][0]);
+                            acc[o][1] = __builtin_fmaf(t1, k, acc[o][1]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+    }
+    if (!live) return;
+#pragma unroll
+    for (int o = 0; o < B2_R; ++o) {
+        const int y = y0 + o;
+        if (y >= rows) break;
+        // acc < 2^24: the value is byte 2 of the (exact) integer
+        const uint32_t out = __builtin_amdgcn_perm((uint32_t)acc[o][1], (uint32_t)acc[o][0], 0x0c0c0602u);
+        *(uint16_t *)(dst + (size_t)y * dst_pitch + 2 * (size_t)xd) = (uint16_t)out;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cols_f32(const uint32_t *temp, uint8_t *dst, size_t dst_pitch, int rows, int row_bytes,
+                                                  TapsCols taps, int nk, int half, int border, int tiles_x) {
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * B2_R;
+    if (y0 - half >= 0 && y0 - half + B2_R + nk - 1 <= rows) // workgroup-uniform: every streamed row is inside the image
+        cols_strip_f32<true>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
+    else
+        cols_strip_f32<false>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
+}
+
 // Returns -1 when the preconditions do not hold (caller falls back to the general kernels).
 int try_sep_bytes2(const zg_image *src, const zg_image *dst, const int32_t *ix, int nkx, const int32_t *iy, int nky, int border, hipStream_t s) {
     if (src->pixel != ZG_PIXEL_U8 && src->pixel != ZG_PIXEL_RGB_U8 && src->pixel != ZG_PIXEL_RGBA_U8) return -1;
@@ -238,7 +322,12 @@ int try_sep_bytes2(const zg_image *src, const zg_image *dst, const int32_t *ix, 
     TapsRows tr{};
     for (int j = 0; j < nkx; ++j) tr.kk[j - halfx + hpad] = (uint32_t)ix[j] | ((uint32_t)ix[j] << 16);
     TapsCols tc{};
-    for (int j = 0; j < nky; ++j) tc.k[B2_R + j] = (uint32_t)iy[j];
+    for (int j = 0; j < nky; ++j) { // k_cols_f32 (!clamp) reads its taps as floats; a zero is a zero either way
+        const float f = (float)iy[j];
+        uint32_t bits;
+        memcpy(&bits, &f, 4);
+        tc.k[B2_R + j] = clamp ? (uint32_t)iy[j] : bits;
+    }
 
     const int row_bytes = (int)(src->cols * sp);
     uint32_t *temp = nullptr;
@@ -251,8 +340,16 @@ int try_sep_bytes2(const zg_image *src, const zg_image *dst, const int32_t *ix, 
     else if (sp == 3) hipLaunchKernelGGL((k_rows_u16<3>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave);
     else hipLaunchKernelGGL((k_rows_u16<4>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave);
     const dim3 grid_cols((unsigned)(tiles_x * ceil_div(src->rows, (uint32_t)B2_R)));
+    static const bool int_cols = getenv("ZIGNAL_HIP_COLS_INT") != nullptr; // tuning hook: the integer column pass for every kernel
     if (clamp) hipLaunchKernelGGL((k_cols_u16<true>), grid_cols, dim3(256), 0, s, (const uint32_t *)temp, (uint8_t *)dst->data, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x);
-    else hipLaunchKernelGGL((k_cols_u16<false>), grid_cols, dim3(256), 0, s, (const uint32_t *)temp, (uint8_t *)dst->data, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x);
+    else if (int_cols) {
+        for (int j = 0; j < nky; ++j) tc.k[B2_R + j] = (uint32_t)iy[j];
+        hipLaunchKernelGGL((k_cols_u16<false>), grid_cols, dim3(256), 0, s, (const uint32_t *)temp, (uint8_t *)dst->data, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x);
+    } else {
+        const int tiles_x2 = (int)ceil_div((uint32_t)row_bytes, 512u);
+        const dim3 grid2((unsigned)(tiles_x2 * ceil_div(src->rows, (uint32_t)B2_R)));
+        hipLaunchKernelGGL(k_cols_f32, grid2, dim3(256), 0, s, (const uint32_t *)temp, (uint8_t *)dst->data, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x2);
+    }
     const hipError_t e = hipGetLastError();
     scratch_free(temp, s);
     ZG_HIP(e);
