@@ -51,6 +51,29 @@ def test_resize_parity(oracle, kind, mname):
     assert not base.any()
 
 
+def test_grey_u8_bilinear_resize_four_pixels_per_lane(oracle):
+    """k_resize_bilinear_u8 (geom.hip): what ImagePyramid resizes with. Shrinking (every neighbour inside), growing (the outer ring
+    goes through the generic sampler), rows that end inside a lane's four pixels and inside a 256-pixel tile, a destination view
+    whose rows do not start on four bytes, and a batch of frames in one launch — all equal to the oracle's generic path."""
+    bil = om(oracle, I.bilinear)
+    for (sr, sc), (dr, dc) in (((600, 700), (500, 583)), ((301, 517), (150, 259)), ((64, 1030), (64, 257)), ((90, 130), (271, 521)),
+                               ((2, 2), (9, 1025)), ((1, 300), (3, 1)), ((1200, 1100), (335, 307))):
+        src = oracle.synth_u8(61, (sr, sc))
+        assert_bits_equal(sync(dev(src).resize((dr, dc), I.bilinear)), oracle.resize(src, (dr, dc), bil), f"grey {sr}x{sc}->{dr}x{dc}")
+    src = oracle.synth_u8(62, (333, 777))
+    base = torch.zeros((200, 515), dtype=torch.uint8, device="cuda")
+    for c0 in (0, 1, 2, 3):
+        out = zg.Image(base[5:5 + 170, c0:c0 + 401])
+        dev(src).resize(out, I.bilinear)
+        torch.cuda.synchronize()
+        assert_bits_equal(out.to_numpy(), oracle.resize(src, (170, 401), bil), f"into a view at column {c0}")
+    frames = oracle.synth_u8(63, (5, 120, 300))
+    got = zg.Pipeline([zg.Step.resize(77, 260, I.bilinear)]).run(torch.from_numpy(frames).cuda())
+    torch.cuda.synchronize()
+    for f in range(5):
+        assert_bits_equal(got[f].cpu().numpy(), oracle.resize(frames[f], (77, 260), bil), f"frame {f} of a batch")
+
+
 @pytest.mark.parametrize("kind", ("rgb_u8", "rgba_u8"))
 def test_resize_lanczos_with_caller_made_plane_weights(oracle, kind):
     """resizePlaneLanczosU8's weights come from @sin (channel_ops.zig:446-454): a caller may supply its own (R6). The library's own

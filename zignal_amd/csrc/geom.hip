@@ -22,6 +22,7 @@
 #include "zg_sample.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -202,6 +203,81 @@ static int check_pair(const zg_image *src, const zg_image *dst, const char *op) 
     return ZG_OK;
 }
 
+// ---- Image(u8).resize(.bilinear): a grey plane (what ImagePyramid resizes, src/image/pyramid.zig:88-99) -------------------------------
+// The reference sends a scalar u8 image through the generic sampler (interpolation.zig:313-407: f32 coordinates, fractions rounded
+// to 8 bits, integer lerp). k_geom<0, bilinear> spends ~115 VALU instructions per pixel on generality: a switch on the map, the
+// 64-bit index fall-back, four byte loads behind four index resolutions. Here a lane owns FOUR consecutive pixels of a row; the row
+// taps are the wave's (scalar); a pixel whose four neighbours are inside the image — all of them when shrinking — costs ~30
+// instructions, and the few that are not (growing: the outermost ring) call the generic sampler itself, so the bits are the same
+// by construction. Same XCD-major tile order and frame index as k_geom.
+__global__ __launch_bounds__(256) void k_resize_bilinear_u8(DImg src, DImg dst, float rx, float ry, int tiles_x, FrameSpan fr, int dword_rows) {
+    const int nwg = gridDim.x, per_xcd = nwg >> 3;
+    int wg = blockIdx.x;
+    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    const int frame = wg / fr.tiles_per_frame;
+    wg -= frame * fr.tiles_per_frame;
+    src.data = (char *)src.data + (size_t)frame * fr.src_frame;
+    dst.data = (char *)dst.data + (size_t)frame * fr.dst_frame;
+    const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
+    const int c0 = tx * 256 + (int)(threadIdx.x & 63) * 4;
+    const int r = __builtin_amdgcn_readfirstlane(ty * 4 + (int)(threadIdx.x >> 6));
+    if (r >= dst.rows || c0 >= dst.cols) return;
+    const float sy = ((float)r + 0.5f) * ry - 0.5f; // source_coord's GEOM_RESIZE, the same expression
+    const float ft = floorf(sy);
+    const int top = (int)ft;
+    const bool rows_inside = ft >= 0.0f && top + 1 < src.rows;
+    const int fy = (int)roundf((sy - ft) * 256);
+    const uint8_t *row0 = (const uint8_t *)src.data + (size_t)(rows_inside ? top : 0) * src.stride, *row1 = row0 + src.stride;
+    const MethodArg m{ZG_INTERP_BILINEAR, 0.0f, 0.0f, nullptr};
+    uint32_t packed = 0;
+    const int n = dst.cols - c0 < 4 ? dst.cols - c0 : 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (p < n) {
+            const float sx = ((float)(c0 + p) + 0.5f) * rx - 0.5f;
+            const float fl = floorf(sx);
+            const int left = (int)fl;
+            uint32_t v;
+            if (rows_inside && fl >= 0.0f && left + 1 < src.cols) {
+                const int tl = row0[left], tr = row0[left + 1], bl = row1[left], br = row1[left + 1];
+                const int fx = (int)roundf((sx - fl) * 256);
+                const int top_val = tl * (256 - fx) + tr * fx;
+                const int bottom_val = bl * (256 - fx) + br * fx;
+                v = (uint32_t)((top_val * (256 - fy) + bottom_val * fy + 32768) >> 16); // < 256: a convex combination of bytes
+            } else {
+                Px<ZG_PIXEL_U8>::Vec one;
+                if (!interpolate<ZG_PIXEL_U8, ZG_INTERP_BILINEAR>(src, sx, sy, m, ZG_BORDER_MIRROR, one)) one = Px<ZG_PIXEL_U8>::zero();
+                v = (uint32_t)one[0];
+            }
+            packed |= v << (8 * p);
+        }
+    }
+    uint8_t *o = (uint8_t *)dst.data + (size_t)r * dst.stride + (size_t)c0;
+    if (n == 4 && dword_rows) *(uint32_t *)o = packed;
+    else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (p < n) o[p] = (uint8_t)(packed >> (8 * p));
+    }
+}
+
+// n equally shaped u8 planes (n = 1: the one image); sizes the caller has already checked
+static int launch_resize_bilinear_u8(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s) {
+    const int tiles_x = (int)ceil_div(dst->cols, 256), tiles_y = (int)ceil_div(dst->rows, 4);
+    const uint64_t grid = (uint64_t)tiles_x * tiles_y * n;
+    ZG_REQUIRE(grid <= 0x7fffffffu, ZG_ERR_INVALID_ARGUMENT, "too many tiles in one launch (%llu)", (unsigned long long)grid);
+    const FrameSpan fr{src_frame, dst_frame, tiles_x * tiles_y};
+    const int dword_rows = ((uintptr_t)dst->data % 4 == 0 && dst->stride % 4 == 0 && dst_frame % 4 == 0) ? 1 : 0;
+    hipLaunchKernelGGL(k_resize_bilinear_u8, dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), (float)src->cols / (float)dst->cols,
+                       (float)src->rows / (float)dst->rows, tiles_x, fr, dword_rows);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+static bool resize_u8_plane_applies(const zg_image *src, const zg_image *dst, const zg_method *method) {
+    static const bool off = getenv("ZIGNAL_HIP_NO_U8_PLANE_RESIZE") != nullptr; // tuning hook
+    return !off && src->pixel == ZG_PIXEL_U8 && method->kind == ZG_INTERP_BILINEAR && src->rows > 0 && src->cols > 0 && dst->rows > 0 && dst->cols > 0;
+}
+
 // ---- resize (interpolation.zig:89-191) -----------------------------------------------------------
 int resize_impl(const zg_image *src, const zg_image *dst, const zg_method *method, hipStream_t s) {
     int rc;
@@ -210,6 +286,7 @@ int resize_impl(const zg_image *src, const zg_image *dst, const zg_method *metho
     if (src->rows == dst->rows && src->cols == dst->cols) return copy_impl(src, dst, s); // :91-108
     const bool is_rgb_u8 = src->pixel == ZG_PIXEL_RGB_U8 || src->pixel == ZG_PIXEL_RGBA_U8; // meta.isRgb(T)
     if (is_rgb_u8 && src->rows > 0 && src->cols > 0) return resize_planes_impl(src, dst, method, s);
+    if (resize_u8_plane_applies(src, dst, method)) return launch_resize_bilinear_u8(src, dst, 1, 0, 0, s);
     GeomParams g{};
     g.mode = GEOM_RESIZE;
     g.p[0] = (float)src->cols / (float)dst->cols;
@@ -226,6 +303,7 @@ int resize_frames(const zg_image *src, const zg_image *dst, const zg_method *met
     if (src->rows == dst->rows && src->cols == dst->cols) return -1; // a copy per frame
     const bool is_rgb_u8 = src->pixel == ZG_PIXEL_RGB_U8 || src->pixel == ZG_PIXEL_RGBA_U8;
     if (is_rgb_u8) return method->kind == ZG_INTERP_BILINEAR ? resize_bilinear_rgba8_frames(src, dst, n, src_frame, dst_frame, s) : -1;
+    if (resize_u8_plane_applies(src, dst, method)) return launch_resize_bilinear_u8(src, dst, n, src_frame, dst_frame, s);
     GeomParams g{};
     g.mode = GEOM_RESIZE;
     g.p[0] = (float)src->cols / (float)dst->cols;
