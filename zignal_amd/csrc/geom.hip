@@ -205,11 +205,14 @@ static int check_pair(const zg_image *src, const zg_image *dst, const char *op) 
 
 // ---- Image(u8).resize(.bilinear): a grey plane (what ImagePyramid resizes, src/image/pyramid.zig:88-99) -------------------------------
 // The reference sends a scalar u8 image through the generic sampler (interpolation.zig:313-407: f32 coordinates, fractions rounded
-// to 8 bits, integer lerp). k_geom<0, bilinear> spends ~115 VALU instructions per pixel on generality: a switch on the map, the
-// 64-bit index fall-back, four byte loads behind four index resolutions. Here a lane owns FOUR consecutive pixels of a row; the row
-// taps are the wave's (scalar); a pixel whose four neighbours are inside the image — all of them when shrinking — costs ~30
-// instructions, and the few that are not (growing: the outermost ring) call the generic sampler itself, so the bits are the same
-// by construction. Same XCD-major tile order and frame index as k_geom.
+// to 8 bits, integer lerp; resize hands it .mirror, :171). k_geom<0, bilinear> spends ~115 VALU instructions per pixel on
+// generality: a switch on the map, the 64-bit index fall-back of far-away coordinates, four byte loads behind four index
+// resolutions. A resize's coordinates stay within half a pixel of the image, so the only neighbours that can leave it are -1 and
+// `length`, the 32-bit resolveIndex covers them, and it is not needed at all for a pixel whose neighbours are inside — every pixel
+// when shrinking. A lane owns FOUR consecutive pixels of a row; the row taps are the wave's (scalar). Same expressions as the
+// generic path, in the same order. Same XCD-major tile order and frame index as k_geom.
+// (Staging the wave's two source rows in LDS instead of gathering bytes through L1 was built and measured: slower, 335 against
+// 312 us for the pyramid, profiles/r03_experiments.txt.)
 __global__ __launch_bounds__(256) void k_resize_bilinear_u8(DImg src, DImg dst, float rx, float ry, int tiles_x, FrameSpan fr, int dword_rows) {
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
@@ -225,32 +228,66 @@ __global__ __launch_bounds__(256) void k_resize_bilinear_u8(DImg src, DImg dst, 
     const float sy = ((float)r + 0.5f) * ry - 0.5f; // source_coord's GEOM_RESIZE, the same expression
     const float ft = floorf(sy);
     const int top = (int)ft;
-    const bool rows_inside = ft >= 0.0f && top + 1 < src.rows;
+    int r0 = top, r1 = top + 1;
+    if (top < 0 || top + 1 >= src.rows) { // wave-uniform
+        r0 = resolve_index(top, src.rows, ZG_BORDER_MIRROR);
+        r1 = resolve_index(top + 1, src.rows, ZG_BORDER_MIRROR);
+    }
     const int fy = (int)roundf((sy - ft) * 256);
-    const uint8_t *row0 = (const uint8_t *)src.data + (size_t)(rows_inside ? top : 0) * src.stride, *row1 = row0 + src.stride;
-    const MethodArg m{ZG_INTERP_BILINEAR, 0.0f, 0.0f, nullptr};
+    const uint8_t *row0 = (const uint8_t *)src.data + (size_t)r0 * src.stride, *row1 = (const uint8_t *)src.data + (size_t)r1 * src.stride;
+    // Loads are what bounds this kernel (every gather instruction is a full pass through the texture-address unit, whatever its width),
+    // so a row's taps of TWO neighbouring pixels come from one 8-byte load where they fit (both inside the row, at most 6 columns apart,
+    // 8 readable bytes left in the row) and from 2-byte / 1-byte loads otherwise. Global memory takes any alignment.
     uint32_t packed = 0;
     const int n = dst.cols - c0 < 4 ? dst.cols - c0 : 4;
+    float sx[4], fl[4];
+    int left[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        if (p < n) {
-            const float sx = ((float)(c0 + p) + 0.5f) * rx - 0.5f;
-            const float fl = floorf(sx);
-            const int left = (int)fl;
-            uint32_t v;
-            if (rows_inside && fl >= 0.0f && left + 1 < src.cols) {
-                const int tl = row0[left], tr = row0[left + 1], bl = row1[left], br = row1[left + 1];
-                const int fx = (int)roundf((sx - fl) * 256);
-                const int top_val = tl * (256 - fx) + tr * fx;
-                const int bottom_val = bl * (256 - fx) + br * fx;
-                v = (uint32_t)((top_val * (256 - fy) + bottom_val * fy + 32768) >> 16); // < 256: a convex combination of bytes
-            } else {
-                Px<ZG_PIXEL_U8>::Vec one;
-                if (!interpolate<ZG_PIXEL_U8, ZG_INTERP_BILINEAR>(src, sx, sy, m, ZG_BORDER_MIRROR, one)) one = Px<ZG_PIXEL_U8>::zero();
-                v = (uint32_t)one[0];
+        sx[p] = ((float)(c0 + p) + 0.5f) * rx - 0.5f;
+        fl[p] = floorf(sx[p]);
+        left[p] = (int)fl[p];
+    }
+    int tl[4], tr[4], bl[4], br[4];
+#pragma unroll
+    for (int p = 0; p < 4; p += 2) {
+        const int d = left[p + 1] - left[p];
+        if (p + 1 < n && left[p] >= 0 && d >= 0 && d <= 6 && left[p] + 8 <= src.cols) {
+            uint64_t a, b;
+            __builtin_memcpy(&a, row0 + left[p], 8);
+            __builtin_memcpy(&b, row1 + left[p], 8);
+            const uint32_t a1 = (uint32_t)(a >> (8 * d)), b1 = (uint32_t)(b >> (8 * d));
+            tl[p] = (int)(a & 255); tr[p] = (int)((a >> 8) & 255); bl[p] = (int)(b & 255); br[p] = (int)((b >> 8) & 255);
+            tl[p + 1] = (int)(a1 & 255); tr[p + 1] = (int)((a1 >> 8) & 255); bl[p + 1] = (int)(b1 & 255); br[p + 1] = (int)((b1 >> 8) & 255);
+        } else {
+#pragma unroll
+            for (int q = p; q < p + 2; ++q) {
+                tl[q] = tr[q] = bl[q] = br[q] = 0;
+                if (q < n) {
+                    int cl = left[q], cr = left[q] + 1;
+                    if (left[q] < 0 || left[q] + 1 >= src.cols) {
+                        cl = resolve_index(left[q], src.cols, ZG_BORDER_MIRROR);
+                        cr = resolve_index(left[q] + 1, src.cols, ZG_BORDER_MIRROR);
+                    }
+                    if (cr == cl + 1) {
+                        uint16_t a, b;
+                        __builtin_memcpy(&a, row0 + cl, 2);
+                        __builtin_memcpy(&b, row1 + cl, 2);
+                        tl[q] = a & 255; tr[q] = a >> 8; bl[q] = b & 255; br[q] = b >> 8;
+                    } else {
+                        tl[q] = row0[cl]; tr[q] = row0[cr]; bl[q] = row1[cl]; br[q] = row1[cr];
+                    }
+                }
             }
-            packed |= v << (8 * p);
         }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int fx = (int)roundf((sx[p] - fl[p]) * 256);
+        const int top_val = tl[p] * (256 - fx) + tr[p] * fx;
+        const int bottom_val = bl[p] * (256 - fx) + br[p] * fx;
+        const uint32_t v = (uint32_t)((top_val * (256 - fy) + bottom_val * fy + 32768) >> 16); // < 256: a convex combination of bytes
+        packed |= v << (8 * p);
     }
     uint8_t *o = (uint8_t *)dst.data + (size_t)r * dst.stride + (size_t)c0;
     if (n == 4 && dword_rows) *(uint32_t *)o = packed;
