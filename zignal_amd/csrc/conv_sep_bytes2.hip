@@ -45,6 +45,36 @@ template <int S, int NW> __device__ __forceinline__ u16x2 window_pair(const uint
     else return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(w[d + 1], w[d], 0x0c040c03u));
 }
 
+// One wave stages bytes xb0 - 128 .. xb0 + 1024 + 144 of a row in its own LDS row (the row passes below share this).
+template <int SP>
+__device__ __forceinline__ void stage_row(uint32_t *buf, const uint8_t *row, int xb0, int row_bytes, int lane, int hpad, bool edge, int cols, int border) {
+    // stage bytes xb0 - 128 .. xb0 + 1024 + 144 of the row: 64 main units and 17 halo units of 16 bytes; units are all
+    // inside or all outside the row (length % 16 == 0), outside ones are zeroed here and patched below
+    {
+        const int gb = xb0 + 16 * lane;
+        u32x4 v = *(const u32x4 *)(row + min(gb, row_bytes - 16));
+        if (gb + 16 > row_bytes) v = u32x4{0u, 0u, 0u, 0u};
+        const int hu = min(lane, 16);                              // halo unit: 0..7 left, 8..16 right
+        const int hb = hu < 8 ? xb0 - 128 + 16 * hu : xb0 + 1024 + 16 * (hu - 8);
+        u32x4 h = *(const u32x4 *)(row + min(max(hb, 0), row_bytes - 16));
+        if (hb < 0 || hb + 16 > row_bytes) h = u32x4{0u, 0u, 0u, 0u};
+        *(u32x4 *)(buf + B2_LEFT + 4 * lane) = v;
+        if (lane < 17) *(u32x4 *)(buf + (hu < 8 ? 4 * hu : B2_LEFT + 256 + 4 * (hu - 8))) = h;
+    }
+    if (edge) { // border rule for the columns, one byte per lane
+        const int reach = hpad * SP + 16;
+        for (int k = lane; k < 2 * reach; k += 64) {
+            const int b = k < reach ? -1 - k : row_bytes + (k - reach); // byte position in the row's stream
+            const int t = b - (xb0 - 128);                               // byte position in the LDS row
+            if (t < 0 || t >= B2_ROW * 4) continue;
+            const int px = b >= 0 ? b / SP : -((SP - 1 - b) / SP); // floor
+            const int gc = resolve_index(px, cols, border);
+            if (gc < 0) continue; // zero border: already 0
+            ((uint8_t *)buf)[t] = row[gc * SP + (b - px * SP)];
+        }
+    }
+}
+
 template <int SP>
 __global__ __launch_bounds__(256) void k_rows_u16(DImg src, uint32_t *temp, TapsRows taps, int hpad, int ngroups, int border,
                                                   int tiles_x, int rows_per_wave) {
@@ -62,31 +92,7 @@ __global__ __launch_bounds__(256) void k_rows_u16(DImg src, uint32_t *temp, Taps
         const int y = (ty * 4 + wave) * rows_per_wave + rr; // wave-uniform
         if (y >= src.rows) break;
         const uint8_t *row = (const uint8_t *)src.data + (size_t)y * src.stride * SP;
-        // stage bytes xb0 - 128 .. xb0 + 1024 + 144 of the row: 64 main units and 17 halo units of 16 bytes; units are all
-        // inside or all outside the row (length % 16 == 0), outside ones are zeroed here and patched below
-        {
-            const int gb = xb0 + 16 * lane;
-            u32x4 v = *(const u32x4 *)(row + min(gb, row_bytes - 16));
-            if (gb + 16 > row_bytes) v = u32x4{0u, 0u, 0u, 0u};
-            const int hu = min(lane, 16);                              // halo unit: 0..7 left, 8..16 right
-            const int hb = hu < 8 ? xb0 - 128 + 16 * hu : xb0 + 1024 + 16 * (hu - 8);
-            u32x4 h = *(const u32x4 *)(row + min(max(hb, 0), row_bytes - 16));
-            if (hb < 0 || hb + 16 > row_bytes) h = u32x4{0u, 0u, 0u, 0u};
-            *(u32x4 *)(buf + B2_LEFT + 4 * lane) = v;
-            if (lane < 17) *(u32x4 *)(buf + (hu < 8 ? 4 * hu : B2_LEFT + 256 + 4 * (hu - 8))) = h;
-        }
-        if (edge) { // border rule for the columns, one byte per lane
-            const int reach = hpad * SP + 16;
-            for (int k = lane; k < 2 * reach; k += 64) {
-                const int b = k < reach ? -1 - k : row_bytes + (k - reach); // byte position in the row's stream
-                const int t = b - (xb0 - 128);                               // byte position in the LDS row
-                if (t < 0 || t >= B2_ROW * 4) continue;
-                const int px = b >= 0 ? b / SP : -((SP - 1 - b) / SP); // floor
-                const int gc = resolve_index(px, src.cols, border);
-                if (gc < 0) continue; // zero border: already 0
-                ((uint8_t *)buf)[t] = row[gc * SP + (b - px * SP)];
-            }
-        }
+        stage_row<SP>(buf, row, xb0, row_bytes, lane, hpad, edge, src.cols, border);
         __builtin_amdgcn_wave_barrier(); // LDS is in order within a wave; this only stops the compiler from reordering
 
         u16x2 acc[4][2];
@@ -122,6 +128,65 @@ __global__ __launch_bounds__(256) void k_rows_u16(DImg src, uint32_t *temp, Taps
                 *(u32x2 *)(trow + 2 * (lane + 64 * m)) = u32x2{__builtin_bit_cast(uint32_t, acc[m][0]), __builtin_bit_cast(uint32_t, acc[m][1])};
         }
     }
+}
+
+// The row pass of a grey plane in f32 (exact: a temp is at most 255 * 257). A lane owns SIXTEEN consecutive bytes of the tile; it
+// converts the 16 + 2 HP bytes its taps reach once (v_cvt_f32_ubyteN) and every tap of every output is one v_fmac_f32 with the tap
+// in an SGPR — no byte-pair extraction, and an f32 multiply-add issues in half the time of a packed u16 one (tools/exp/valu_rate.hip).
+// HP (a multiple of 4, the kernel's half width rounded up) is a template parameter so that all register indices are compile-time;
+// taps past the kernel are zeros.
+struct TapsRowsF { float k[2 * B2_HMAX + 1]; }; // k[offset + HP]
+template <int HP>
+__global__ __launch_bounds__(256) void k_rows_f32(DImg src, uint32_t *temp, TapsRowsF taps, int border, int tiles_x, int rows_per_wave) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int ND = 4 + HP / 2; // dwords of a lane's window
+    __shared__ uint32_t lds[4][B2_ROW];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int xb0 = tx * 1024;
+    const int row_bytes = src.cols;
+    uint32_t *buf = lds[wave];
+    const bool edge = xb0 == 0 || xb0 + 1024 + HP + 16 > row_bytes;
+    float k[2 * HP + 1];
+#pragma unroll
+    for (int j = 0; j <= 2 * HP; ++j) k[j] = taps.k[j]; // scalar loads: the taps live in SGPRs
+    for (int rr = 0; rr < rows_per_wave; ++rr) {
+        const int y = (ty * 4 + wave) * rows_per_wave + rr; // wave-uniform
+        if (y >= src.rows) break;
+        const uint8_t *row = (const uint8_t *)src.data + (size_t)y * src.stride;
+        stage_row<1>(buf, row, xb0, row_bytes, lane, HP, edge, src.cols, border);
+        __builtin_amdgcn_wave_barrier();
+        float w[4 * ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const uint32_t v = buf[B2_LEFT + 4 * lane - HP / 4 + d];
+            w[4 * d] = (float)(v & 0xffu); w[4 * d + 1] = (float)((v >> 8) & 0xffu); w[4 * d + 2] = (float)((v >> 16) & 0xffu); w[4 * d + 3] = (float)(v >> 24);
+        }
+        __builtin_amdgcn_wave_barrier(); // the next row's staging must not overtake these reads
+        float acc[16];
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] = 0.0f;
+#pragma unroll
+        for (int j = 0; j <= 2 * HP; ++j) {
+#pragma unroll
+            for (int o = 0; o < 16; ++o) acc[o] = __builtin_fmaf(w[o + j], k[j], acc[o]);
+        }
+        if (xb0 + 16 * lane < row_bytes) {
+            uint32_t *trow = temp + ((size_t)y * row_bytes + xb0) / 2 + 8 * lane; // two bytes of the stream per packed u32
+            uint32_t pk[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pk[i] = (uint32_t)acc[2 * i] | ((uint32_t)acc[2 * i + 1] << 16);
+            *(u32x4 *)trow = u32x4{pk[0], pk[1], pk[2], pk[3]};
+            *(u32x4 *)(trow + 4) = u32x4{pk[4], pk[5], pk[6], pk[7]};
+        }
+    }
+}
+template <int HP>
+static void launch_rows_f32(const zg_image *src, uint32_t *temp, const int32_t *ix, int nkx, int border, int tiles_x, int rows_per_wave, dim3 grid, hipStream_t s) {
+    TapsRowsF t{};
+    for (int j = 0; j < nkx; ++j) t.k[j - nkx / 2 + HP] = (float)ix[j];
+    hipLaunchKernelGGL((k_rows_f32<HP>), grid, dim3(256), 0, s, dimg(src), temp, t, border, tiles_x, rows_per_wave);
 }
 
 template <bool CLAMP, bool INSIDE>
@@ -336,7 +401,19 @@ int try_sep_bytes2(const zg_image *src, const zg_image *dst, const int32_t *ix, 
     const int tiles_x = (int)ceil_div((uint32_t)row_bytes, 1024u);
     const int rows_per_wave = 4;
     const dim3 grid_rows((unsigned)(tiles_x * ceil_div(src->rows, 4u * rows_per_wave)));
-    if (sp == 1) hipLaunchKernelGGL((k_rows_u16<1>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave);
+    static const bool int_rows = getenv("ZIGNAL_HIP_ROWS_INT") != nullptr; // tuning hook: the packed-u16 row pass for grey planes too
+    if (sp == 1 && !int_rows) {
+        switch ((halfx + 3) / 4) {
+        case 0: case 1: launch_rows_f32<4>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
+        case 2: launch_rows_f32<8>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
+        case 3: launch_rows_f32<12>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
+        case 4: launch_rows_f32<16>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
+        case 5: launch_rows_f32<20>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
+        case 6: launch_rows_f32<24>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
+        case 7: launch_rows_f32<28>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
+        default: launch_rows_f32<32>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
+        }
+    } else if (sp == 1) hipLaunchKernelGGL((k_rows_u16<1>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave);
     else if (sp == 3) hipLaunchKernelGGL((k_rows_u16<3>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave);
     else hipLaunchKernelGGL((k_rows_u16<4>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave);
     const dim3 grid_cols((unsigned)(tiles_x * ceil_div(src->rows, (uint32_t)B2_R)));
