@@ -135,9 +135,9 @@ __global__ __launch_bounds__(256) void k_rows_u16(DImg src, uint32_t *temp, Taps
 // in an SGPR — no byte-pair extraction, and an f32 multiply-add issues in half the time of a packed u16 one (tools/exp/valu_rate.hip).
 // HP (a multiple of 4, the kernel's half width rounded up) is a template parameter so that all register indices are compile-time;
 // taps past the kernel are zeros.
-struct TapsRowsF { float k[2 * B2_HMAX + 1]; }; // k[offset + HP]
+struct TapsRowsU8F { float k[2 * B2_HMAX + 1]; }; // k[offset + HP]
 template <int HP>
-__global__ __launch_bounds__(256) void k_rows_f32(DImg src, uint32_t *temp, TapsRowsF taps, int border, int tiles_x, int rows_per_wave) {
+__global__ __launch_bounds__(256) void k_rows_u8f(DImg src, uint32_t *temp, TapsRowsU8F taps, int border, int tiles_x, int rows_per_wave) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     constexpr int ND = 4 + HP / 2; // dwords of a lane's window
     __shared__ uint32_t lds[4][B2_ROW];
@@ -183,10 +183,10 @@ __global__ __launch_bounds__(256) void k_rows_f32(DImg src, uint32_t *temp, Taps
     }
 }
 template <int HP>
-static void launch_rows_f32(const zg_image *src, uint32_t *temp, const int32_t *ix, int nkx, int border, int tiles_x, int rows_per_wave, dim3 grid, hipStream_t s) {
-    TapsRowsF t{};
+static void launch_rows_u8f(const zg_image *src, uint32_t *temp, const int32_t *ix, int nkx, int border, int tiles_x, int rows_per_wave, dim3 grid, hipStream_t s) {
+    TapsRowsU8F t{};
     for (int j = 0; j < nkx; ++j) t.k[j - nkx / 2 + HP] = (float)ix[j];
-    hipLaunchKernelGGL((k_rows_f32<HP>), grid, dim3(256), 0, s, dimg(src), temp, t, border, tiles_x, rows_per_wave);
+    hipLaunchKernelGGL((k_rows_u8f<HP>), grid, dim3(256), 0, s, dimg(src), temp, t, border, tiles_x, rows_per_wave);
 }
 
 template <bool CLAMP, bool INSIDE>
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void k_cols_u16(const uint32_t *temp, uint8_t 
 // per streamed row. A lane owns TWO adjacent bytes (one packed temp dword) of 32 output rows: 64 accumulator registers instead of
 // 128, so four waves fit a SIMD where the integer form fits two, and a 4096-byte row gives 4 096 waves instead of 2 048.
 template <bool INSIDE>
-__device__ __forceinline__ void cols_strip_f32(const uint32_t *temp, uint8_t *dst, size_t dst_pitch, int rows, int row_bytes,
+__device__ __forceinline__ void cols_strip_u8f(const uint32_t *temp, uint8_t *dst, size_t dst_pitch, int rows, int row_bytes,
                                                const TapsCols &taps, int nk, int half, int border, int tx, int ty) {
     const int xd = tx * 256 + (int)threadIdx.x; // this lane's packed temp dword of the row (2 bytes of output)
     const bool live = xd * 2 < row_bytes;
@@ -356,14 +356,14 @@ __device__ __forceinline__ void cols_strip_f32(const uint32_t *temp, uint8_t *ds
     }
 }
 
-__global__ __launch_bounds__(256) void k_cols_f32(const uint32_t *temp, uint8_t *dst, size_t dst_pitch, int rows, int row_bytes,
+__global__ __launch_bounds__(256) void k_cols_u8f(const uint32_t *temp, uint8_t *dst, size_t dst_pitch, int rows, int row_bytes,
                                                   TapsCols taps, int nk, int half, int border, int tiles_x) {
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int y0 = ty * B2_R;
     if (y0 - half >= 0 && y0 - half + B2_R + nk - 1 <= rows) // workgroup-uniform: every streamed row is inside the image
-        cols_strip_f32<true>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
+        cols_strip_u8f<true>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
     else
-        cols_strip_f32<false>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
+        cols_strip_u8f<false>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
 }
 
 // Returns -1 when the preconditions do not hold (caller falls back to the general kernels).
@@ -387,7 +387,7 @@ int try_sep_bytes2(const zg_image *src, const zg_image *dst, const int32_t *ix, 
     TapsRows tr{};
     for (int j = 0; j < nkx; ++j) tr.kk[j - halfx + hpad] = (uint32_t)ix[j] | ((uint32_t)ix[j] << 16);
     TapsCols tc{};
-    for (int j = 0; j < nky; ++j) { // k_cols_f32 (!clamp) reads its taps as floats; a zero is a zero either way
+    for (int j = 0; j < nky; ++j) { // k_cols_u8f (!clamp) reads its taps as floats; a zero is a zero either way
         const float f = (float)iy[j];
         uint32_t bits;
         memcpy(&bits, &f, 4);
@@ -404,14 +404,14 @@ int try_sep_bytes2(const zg_image *src, const zg_image *dst, const int32_t *ix, 
     static const bool int_rows = getenv("ZIGNAL_HIP_ROWS_INT") != nullptr; // tuning hook: the packed-u16 row pass for grey planes too
     if (sp == 1 && !int_rows) {
         switch ((halfx + 3) / 4) {
-        case 0: case 1: launch_rows_f32<4>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
-        case 2: launch_rows_f32<8>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
-        case 3: launch_rows_f32<12>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
-        case 4: launch_rows_f32<16>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
-        case 5: launch_rows_f32<20>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
-        case 6: launch_rows_f32<24>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
-        case 7: launch_rows_f32<28>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
-        default: launch_rows_f32<32>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
+        case 0: case 1: launch_rows_u8f<4>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
+        case 2: launch_rows_u8f<8>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
+        case 3: launch_rows_u8f<12>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
+        case 4: launch_rows_u8f<16>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
+        case 5: launch_rows_u8f<20>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
+        case 6: launch_rows_u8f<24>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
+        case 7: launch_rows_u8f<28>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
+        default: launch_rows_u8f<32>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
         }
     } else if (sp == 1) hipLaunchKernelGGL((k_rows_u16<1>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave);
     else if (sp == 3) hipLaunchKernelGGL((k_rows_u16<3>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave);
@@ -425,7 +425,7 @@ int try_sep_bytes2(const zg_image *src, const zg_image *dst, const int32_t *ix, 
     } else {
         const int tiles_x2 = (int)ceil_div((uint32_t)row_bytes, 512u);
         const dim3 grid2((unsigned)(tiles_x2 * ceil_div(src->rows, (uint32_t)B2_R)));
-        hipLaunchKernelGGL(k_cols_f32, grid2, dim3(256), 0, s, (const uint32_t *)temp, (uint8_t *)dst->data, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x2);
+        hipLaunchKernelGGL(k_cols_u8f, grid2, dim3(256), 0, s, (const uint32_t *)temp, (uint8_t *)dst->data, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x2);
     }
     const hipError_t e = hipGetLastError();
     scratch_free(temp, s);
