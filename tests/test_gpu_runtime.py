@@ -109,3 +109,47 @@ def test_role_split_sat_chain_equals_the_unfused_kernels(shape, oracle):
         other = np.load(os.path.join(d, "out.npz"))
         for i, got in enumerate(here["whole"]):
             assert np.array_equal(got, other[f"arr_{i}"]), (shape, i)
+
+
+ALTERNATIVE_FORMS = {
+    # hook: (what it switches back to, a snippet producing `got` and `want` for shapes that reach the kernel in question)
+    "ZIGNAL_HIP_NO_LAB4": "k_convert instead of k_u8_to_lab4",
+    "ZIGNAL_HIP_COLS_INT": "k_cols_u16 instead of k_cols_u8f",
+    "ZIGNAL_HIP_ROWS_INT": "k_rows_u16 instead of k_rows_u8f",
+    "ZIGNAL_HIP_NO_U8_PLANE_RESIZE": "k_geom instead of k_resize_bilinear_u8",
+    "ZIGNAL_HIP_NO_STREAM": "the tiled u8 Gaussians instead of k_sep_stream",
+    "ZIGNAL_HIP_STREAM_GREY": "k_sep_stream for a single grey plane too",
+}
+
+
+@pytest.mark.parametrize("hook", sorted(ALTERNATIVE_FORMS))
+def test_the_alternative_kernel_forms_behind_the_tuning_hooks_give_the_same_bits(hook):
+    """Every ZIGNAL_HIP_* hook that swaps one kernel form for another (they exist for A/B timing) must leave the results
+    untouched: the same calls, against the oracle, with the hook set (a child process: the hooks are read once)."""
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+import zignal_amd as zg
+from oracle import pyoracle as o
+o.lib()
+def dev(a): return zg.Image(torch.from_numpy(np.ascontiguousarray(a)).cuda())
+def same(got, want, what):
+    torch.cuda.synchronize()
+    g = got.to_numpy()
+    assert g.shape == want.shape and g.dtype == want.dtype, what
+    assert np.array_equal(g.view(np.uint8), want.view(np.uint8)), what
+rng = np.random.default_rng(5)
+rgba = rng.integers(0, 256, (70, 1100, 4), dtype=np.uint8)
+grey = rng.integers(0, 256, (300, 1296), dtype=np.uint8)
+same(dev(rgba).convert(zg.CS_OKLAB, np.float32), o.convert(rgba, o.CS_RGBA, o.CS_OKLAB, np.float32, 3), "oklab")
+same(dev(rgba[..., :3]).convert(zg.CS_XYZ, np.float32), o.convert(np.ascontiguousarray(rgba[..., :3]), o.CS_RGB, o.CS_XYZ, np.float32, 3), "xyz")
+for sigma in (0.6, 1.0, 2.25, 5.5):
+    same(dev(grey).gaussian_blur(sigma), o.gaussian_blur(grey, sigma), "grey blur %%g" %% sigma)
+    same(dev(rgba).gaussian_blur(sigma), o.gaussian_blur(rgba, sigma), "rgba blur %%g" %% sigma)
+for size in ((250, 1080), (97, 411), (640, 2600)):
+    same(dev(grey).resize(size, zg.Interpolation.bilinear), o.resize(grey, size, o.method(o.BILINEAR)), "grey resize")
+print("ok")
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **{hook: "1"}))
+    assert out.returncode == 0 and "ok" in out.stdout, (ALTERNATIVE_FORMS[hook], out.stdout[-400:], out.stderr[-1200:])
