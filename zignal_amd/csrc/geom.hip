@@ -42,6 +42,7 @@ enum : int { GEOM_RESIZE = 0, GEOM_PROJECTIVE = 1, GEOM_AFFINE = 2, GEOM_ROTATE 
 struct GeomParams {
     int mode;
     float p[12];
+    int stage; // wave-level staging of shared taps where the kernel has it (a tuning hook turns it off)
 };
 
 // Source coordinate of destination pixel (c, r).
@@ -95,7 +96,7 @@ __device__ inline void source_coord(const GeomParams &g, int c, int r, float &sx
     }
 }
 
-template <int PIX, int KIND>
+template <int PIX, int KIND, bool WAVE_STAGE = false>
 __global__ __launch_bounds__(256) void k_geom(DImg src, DImg dst, GeomParams g, MethodArg m, int border, int tiles_x, FrameSpan fr) {
     using P = Px<PIX>;
     using Vec = typename P::Vec;
@@ -115,7 +116,9 @@ __global__ __launch_bounds__(256) void k_geom(DImg src, DImg dst, GeomParams g, 
     float sx, sy;
     source_coord(g, c, r, sx, sy);
     Vec v;
-    if (!interpolate<PIX, KIND>(src, sx, sy, m, border, v)) v = P::zero();
+    // WAVE_STAGE (Rgba(f32) through a radius-2 kernel): each wave stages the source pixels its 64 windows share (zg_sample.h)
+    __shared__ Vec stage_mem[WAVE_STAGE ? 4 * WAVE_STAGE_ROWS * 64 : 1];
+    if (!interpolate<PIX, KIND, WAVE_STAGE>(src, sx, sy, m, border, v, stage_mem + (WAVE_STAGE ? (threadIdx.x >> 6) * (WAVE_STAGE_ROWS * 64) : 0))) v = P::zero();
     P::store(dst.data, (size_t)r * dst.stride + (size_t)c, v);
 }
 
@@ -168,6 +171,16 @@ static int launch_geom_k(const zg_image *src, const zg_image *dst, const GeomPar
     const uint64_t grid = (uint64_t)tiles_x * tiles_y * fb.n;
     ZG_REQUIRE(grid <= 0x7fffffffu, ZG_ERR_INVALID_ARGUMENT, "too many tiles in one launch (%llu)", (unsigned long long)grid);
     const FrameSpan fr{fb.src_frame, fb.dst_frame, tiles_x * tiles_y};
+    constexpr bool CAN_STAGE = PIX == ZG_PIXEL_RGBA_F32 && (KIND == ZG_INTERP_BICUBIC || KIND == ZG_INTERP_CATMULL_ROM || KIND == ZG_INTERP_MITCHELL);
+    if constexpr (CAN_STAGE) {
+        // for every map: where a wave cannot stage, this kernel's row-at-a-time gather (seven waves per SIMD) still beats the sixteen gathers
+        // in flight of the plain one — 2:1 reduction 101 -> 80 us, a 10-degree rotation 350 -> 304 us (profiles/r03_experiments.txt)
+        if (g.stage) {
+            hipLaunchKernelGGL((k_geom<PIX, KIND, true>), dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), g, m, border, tiles_x, fr);
+            ZG_HIP(hipGetLastError());
+            return ZG_OK;
+        }
+    }
     hipLaunchKernelGGL((k_geom<PIX, KIND>), dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), g, m, border, tiles_x, fr);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
@@ -181,15 +194,18 @@ static int launch_geom(const zg_image *src, const zg_image *dst, const GeomParam
     LutHolder lut;
     if ((rc = device_lanczos_lut(method, s, lut))) return rc;
     const MethodArg m{method->kind, method->b, method->c, lut.dev};
+    static const bool no_stage = getenv("ZIGNAL_HIP_NO_WARP_STAGE") != nullptr; // tuning hook
+    GeomParams gp = g;
+    gp.stage = no_stage ? 0 : 1;
     rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
         switch (method->kind) {
-        case ZG_INTERP_NEAREST: return launch_geom_k<PIX, ZG_INTERP_NEAREST>(src, dst, g, m, border, fb, s);
-        case ZG_INTERP_BILINEAR: return launch_geom_k<PIX, ZG_INTERP_BILINEAR>(src, dst, g, m, border, fb, s);
-        case ZG_INTERP_BICUBIC: return launch_geom_k<PIX, ZG_INTERP_BICUBIC>(src, dst, g, m, border, fb, s);
-        case ZG_INTERP_CATMULL_ROM: return launch_geom_k<PIX, ZG_INTERP_CATMULL_ROM>(src, dst, g, m, border, fb, s);
-        case ZG_INTERP_MITCHELL: return launch_geom_k<PIX, ZG_INTERP_MITCHELL>(src, dst, g, m, border, fb, s);
-        default: return launch_geom_k<PIX, ZG_INTERP_LANCZOS>(src, dst, g, m, border, fb, s);
+        case ZG_INTERP_NEAREST: return launch_geom_k<PIX, ZG_INTERP_NEAREST>(src, dst, gp, m, border, fb, s);
+        case ZG_INTERP_BILINEAR: return launch_geom_k<PIX, ZG_INTERP_BILINEAR>(src, dst, gp, m, border, fb, s);
+        case ZG_INTERP_BICUBIC: return launch_geom_k<PIX, ZG_INTERP_BICUBIC>(src, dst, gp, m, border, fb, s);
+        case ZG_INTERP_CATMULL_ROM: return launch_geom_k<PIX, ZG_INTERP_CATMULL_ROM>(src, dst, gp, m, border, fb, s);
+        case ZG_INTERP_MITCHELL: return launch_geom_k<PIX, ZG_INTERP_MITCHELL>(src, dst, gp, m, border, fb, s);
+        default: return launch_geom_k<PIX, ZG_INTERP_LANCZOS>(src, dst, gp, m, border, fb, s);
         }
     });
     release_lut(lut, s);

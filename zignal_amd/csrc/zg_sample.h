@@ -11,6 +11,8 @@
 
 namespace zg {
 
+constexpr int WAVE_STAGE_ROWS = 5; // rows a wave stages for its 64 windows (interpolate<..., WAVE_STAGE>): windows at most one row apart
+
 struct MethodArg {
     int kind;          // zg_interp
     float b, c;        // Mitchell
@@ -117,9 +119,16 @@ template <int KIND> __device__ inline float eval_kernel(const MethodArg &m, floa
 
 // ---- interpolate ---------------------------------------------------------------------------
 // Returns false for the reference's `null` (caller stores a zeroed pixel).
-template <int PIX, int KIND>
+// `stage` (WAVE_STAGE kernels: Rgba(f32) with the radius-2 kernels): WAVE_STAGE_ROWS x 64 pixels of LDS owned by the calling WAVE. When all
+// 64 lanes are here with their 4 x 4 windows inside the image, inside 64 consecutive columns and inside 5 consecutive rows (neighbouring
+// pixels of a row of a mild warp or an enlargement), the wave loads those 5 x 64 pixels once — five coalesced 16-byte loads per lane instead
+// of sixteen gathers — and every lane takes its taps out of LDS, a row at a time. Only where the pixels come from changes; measured, the sixteen gathers are what
+// bounds the f32 bicubic warp (221 us; 210 us with the arithmetic halved, 160 us with the loads removed: profiles/r03_experiments.txt).
+// WAVE_STAGE kernels keep few registers: where the wave cannot stage (a partial wave, windows too far apart, the image's rim) the taps
+// are gathered a row at a time.
+template <int PIX, int KIND, bool WAVE_STAGE = false>
 __device__ inline bool interpolate(const DImg &img, float x, float y, const MethodArg &m, int border,
-                                   typename Px<PIX>::Vec &out) {
+                                   typename Px<PIX>::Vec &out, typename Px<PIX>::Vec *stage = nullptr) {
     using P = Px<PIX>;
     using Vec = typename P::Vec;
     using Elem = typename P::Elem;
@@ -179,18 +188,22 @@ __device__ inline bool interpolate(const DImg &img, float x, float y, const Meth
         const BaseIdx ix(flx), iy(fly);
         const float fx = x - flx, fy = y - fly;
         float xw[W], yw[W];
+        auto make_weights = [&](float wfx, float wfy) {
 #pragma unroll
-        for (int i = 0; i < W; ++i) {
-            if constexpr (KIND == ZG_INTERP_BICUBIC || KIND == ZG_INTERP_CATMULL_ROM) {
-                const f32x2 f = {fx, fy};
-                const f32x2 w = cubic_tap_weight2<KIND>(i, (float)(i - (R - 1)) - f);
-                xw[i] = w.x;
-                yw[i] = w.y;
-            } else {
-                xw[i] = eval_kernel<KIND>(m, (float)(i - (R - 1)) - fx);
-                yw[i] = eval_kernel<KIND>(m, (float)(i - (R - 1)) - fy);
+            for (int i = 0; i < W; ++i) {
+                if constexpr (KIND == ZG_INTERP_BICUBIC || KIND == ZG_INTERP_CATMULL_ROM) {
+                    const f32x2 f = {wfx, wfy};
+                    const f32x2 w = cubic_tap_weight2<KIND>(i, (float)(i - (R - 1)) - f);
+                    xw[i] = w.x;
+                    yw[i] = w.y;
+                } else {
+                    xw[i] = eval_kernel<KIND>(m, (float)(i - (R - 1)) - wfx);
+                    yw[i] = eval_kernel<KIND>(m, (float)(i - (R - 1)) - wfy);
+                }
             }
-        }
+        };
+        // WAVE_STAGE: the staged path makes them AFTER it has issued its loads (they do not depend on the pixels), the others where they start
+        if constexpr (!WAVE_STAGE) make_weights(fx, fy);
         float sums[C];
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) sums[ch] = 0;
@@ -204,7 +217,85 @@ __device__ inline bool interpolate(const DImg &img, float x, float y, const Meth
             // the whole W x W window is inside the image (every pixel but a thin rim): straight-line code, all
             // W*W gathers independent and in flight together, same accumulation order as the general path
             Vec px[W][W];
-            if constexpr (BUF) {
+            bool staged = false;
+            if constexpr (WAVE_STAGE && BUF && PB == 16 && W == 4) {
+                if (__builtin_amdgcn_ballot_w64(true) == ~0ull) { // the whole wave is here
+                    const int bx0 = min(__builtin_amdgcn_readlane(bx, 0), __builtin_amdgcn_readlane(bx, 63));
+                    const int by0 = min(__builtin_amdgcn_readlane(by, 0), __builtin_amdgcn_readlane(by, 63));
+                    const bool fits = (unsigned)(bx - bx0) <= 60u && (unsigned)(by - by0) <= (unsigned)(WAVE_STAGE_ROWS - 4);
+                    if (__builtin_amdgcn_ballot_w64(fits) == ~0ull) { // wave-uniform
+                        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)img.data, (short)0, (int)(uint32_t)img_bytes, 0x00020000);
+                        const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+                        // columns / rows past the image are clamped: no window reaches them (every window is inside)
+                        const int voff = (by0 * (int)img.stride + min(bx0 + lane, img.cols - 1)) * PB;
+                        Vec fetched[WAVE_STAGE_ROWS];
+#pragma unroll
+                        for (int j = 0; j < WAVE_STAGE_ROWS; ++j) {
+                            const int soff = (min(by0 + j, img.rows - 1) - by0) * (int)img.stride * PB;
+                            fetched[j] = __builtin_bit_cast(Vec, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+                        }
+                        {
+                            float wfx = fx, wfy = fy;
+                            asm volatile("" : "+v"(wfx), "+v"(wfy)); // after the loads above, in program order
+                            make_weights(wfx, wfy);
+                        }
+#pragma unroll
+                        for (int j = 0; j < WAVE_STAGE_ROWS; ++j) stage[j * 64 + lane] = fetched[j];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier(); // LDS operations of one wave execute in order; this keeps the compiler from reordering them
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const Vec *mine = stage + (by - by0) * 64 + (bx - bx0);
+                        // row by row, a row's four taps read just before they are used (the scheduling barrier keeps hipcc from hoisting all
+                        // sixteen reads to the top: 64 registers of taps cost two waves per SIMD of occupancy)
+#pragma unroll
+                        for (int j = 0; j < W; ++j) {
+                            Vec row[W];
+#pragma unroll
+                            for (int i = 0; i < W; ++i) row[i] = mine[j * 64 + i];
+#pragma unroll
+                            for (int i = 0; i < W; ++i) {
+                                const float weight = xw[i] * yw[j];
+#pragma unroll
+                                for (int ch = 0; ch < C; ++ch) {
+                                    const float prod = (float)row[i][ch] * weight;
+                                    sums[ch] = sums[ch] + prod;
+                                }
+                                weight_sum = weight_sum + weight;
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        staged = true;
+                    }
+                }
+            }
+            if constexpr (WAVE_STAGE && BUF && PB == 16 && W == 4) {
+                if (!staged) {
+                    make_weights(fx, fy);
+                    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)img.data, (short)0, (int)(uint32_t)img_bytes, 0x00020000);
+                    const int voff = (by * img.stride + bx) * PB;
+#pragma unroll
+                    for (int j = 0; j < W; ++j) {
+                        const int soff = j * img.stride * PB;
+                        Vec row[W];
+#pragma unroll
+                        for (int i = 0; i < W; ++i) row[i] = __builtin_bit_cast(Vec, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + i * PB, soff, 0));
+#pragma unroll
+                        for (int i = 0; i < W; ++i) {
+                            const float weight = xw[i] * yw[j];
+#pragma unroll
+                            for (int ch = 0; ch < C; ++ch) {
+                                const float prod = (float)row[i][ch] * weight;
+                                sums[ch] = sums[ch] + prod;
+                            }
+                            weight_sum = weight_sum + weight;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    staged = true; // the sums are made
+                }
+            }
+            if (staged) {
+            } else if constexpr (BUF) {
                 // buffer loads: one 32-bit offset per lane, the row of a tap in the scalar offset, its column in the immediate:
                 // sixteen gathers without a single address instruction
                 const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)img.data, (short)0, (int)(uint32_t)img_bytes, 0x00020000);
@@ -224,6 +315,7 @@ __device__ inline bool interpolate(const DImg &img, float x, float y, const Meth
 #pragma unroll
                     for (int i = 0; i < W; ++i) px[j][i] = P::load(img.data, (size_t)(by + j) * img.stride + (size_t)(bx + i));
             }
+            if (!staged) {
 #pragma unroll
             for (int j = 0; j < W; ++j) {
 #pragma unroll
@@ -236,6 +328,7 @@ __device__ inline bool interpolate(const DImg &img, float x, float y, const Meth
                     }
                     weight_sum = weight_sum + weight;
                 }
+            }
             }
             if constexpr (!IS_F) {
                 // The C quotients share their divisor: the refined reciprocal of the IEEE division sequence (v_rcp + one Newton
@@ -256,6 +349,7 @@ __device__ inline bool interpolate(const DImg &img, float x, float y, const Meth
                 }
             }
         } else {
+            if constexpr (WAVE_STAGE) make_weights(fx, fy);
             int cols_idx[W];
 #pragma unroll
             for (int i = 0; i < W; ++i) cols_idx[i] = ix.resolve(i - (R - 1), img.cols, border);
