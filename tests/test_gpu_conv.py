@@ -342,3 +342,25 @@ def test_c_abi_without_torch_objects(oracle):
         L.check(lib.zg_stream_destroy(stream))
         L.check(lib.zg_free(src))
         L.check(lib.zg_free(dst))
+
+
+def test_convolve_u8_f32_accumulators_at_the_exactness_boundary(oracle):
+    """k_conv2d's MODE 3 (u8 pixels, f32 accumulators) is chosen when 255 * sum|round(256 k)| < 2^24; kernels just below and just
+    above that line, positive and mixed-sign, on frames of all-255 / all-0 / random bytes — sums that reach the largest partial
+    values — must equal the oracle's i64 arithmetic."""
+    rng = np.random.default_rng(9)
+    frames = {"ones": np.full((40, 300, 4), 255, np.uint8), "rand": rng.integers(0, 256, (37, 261, 4), dtype=np.uint8),
+              "grey": rng.integers(0, 256, (70, 515), dtype=np.uint8), "greymax": np.full((33, 200), 255, np.uint8)}
+    for n in (3, 5, 7):
+        line = (1 << 24) / 255 / 256 / (n * n)  # a tap value for which 255 * sum|.| sits on the line when all n^2 taps share it
+        for scale in (0.97, 0.999, 1.001, 1.05):
+            for signs in ("plus", "mixed"):
+                k = np.full((n, n), line * scale, np.float32)
+                if signs == "mixed":
+                    k[::2, 1::2] *= -1
+                    k[n // 2, n // 2] *= -1
+                for name, f in frames.items():
+                    want = oracle.convolve(f, k, oracle.MIRROR)
+                    got = dev(f).convolve(k)
+                    torch.cuda.synchronize()
+                    assert_bits_equal(got.to_numpy(), want, f"{n}x{n} scale {scale} {signs} {name}")

@@ -22,7 +22,10 @@ struct Kernel2D {
     union { float f[MAX_K2D]; int32_t i[MAX_K2D]; };
 };
 
-// MODE: 0 = f32, 1 = u8 with i32 accumulate (host proved it exact), 2 = u8 with i64 accumulate
+// MODE: 0 = f32, 1 = u8 with i32 accumulate (host proved it exact), 2 = u8 with i64 accumulate,
+//       3 = u8 with f32 accumulate: 255 * sum|k| < 2^24, so every partial sum is an integer f32 holds exactly — the tile is converted to f32
+//           once per staged pixel and each tap is one v_fmac_f32 (half the issue time of an integer multiply-add, no byte extraction:
+//           tools/exp/valu_rate.hip); taps travel as floats
 //
 // One workgroup per 64 x 16 output tile. The (16 + kh - 1) x (64 + kw - 1) source tile is staged in LDS once — the
 // border rule is evaluated per staged pixel (and not at all for tiles whose halo lies inside the image), with
@@ -39,7 +42,8 @@ __global__ __launch_bounds__(256) void k_conv2d(DImg src, DImg dst, Kernel2D k, 
     constexpr int C = P::C;
     constexpr int MAXK = KH > 0 ? KH : 15, MAXKW = KW > 0 ? KW : 15;
     constexpr int LW = C2_TW + MAXKW - 1, LH = C2_TH + MAXK - 1;
-    __shared__ Vec tile[LH * LW];
+    using TVec = typename std::conditional<MODE == 3, typename VecOf<float, C>::type, Vec>::type; // what the tile holds
+    __shared__ TVec tile[LH * LW];
     const int kh = KH > 0 ? KH : k.kh, kw = KW > 0 ? KW : k.kw;
     const int hh = kh / 2, hw = kw / 2;
     const int lw = C2_TW + kw - 1, lh = C2_TH + kh - 1;
@@ -64,24 +68,35 @@ __global__ __launch_bounds__(256) void k_conv2d(DImg src, DImg dst, Kernel2D k, 
         }
         Vec v = P::load(src.data, (size_t)gr * src.stride + (size_t)gc);
         if (!ok) v = P::zero();
-        tile[tr * LW + tc] = v;
+        if constexpr (MODE == 3) {
+            TVec f;
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) f[ch] = (float)v[ch];
+            tile[tr * LW + tc] = f;
+        } else {
+            tile[tr * LW + tc] = v;
+        }
     }
     __syncthreads();
 
     const int lx = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = x0 + lx, r0 = y0 + wave * C2_RPT;
-    using Acc = typename std::conditional<MODE == 0, float, typename std::conditional<MODE == 1, int32_t, int64_t>::type>::type;
+    using Acc = typename std::conditional<MODE == 0 || MODE == 3, float, typename std::conditional<MODE == 1, int32_t, int64_t>::type>::type;
     Acc acc[C2_RPT][C];
 #pragma unroll
     for (int o = 0; o < C2_RPT; ++o)
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) acc[o][ch] = 0;
 
-    auto tap = [&](int o, int ky, int kx, const Vec &v) {
+    auto tap = [&](int o, int ky, int kx, const TVec &v) {
         if constexpr (MODE == 0) {
             const float w = k.f[ky * kw + kx];
 #pragma unroll
             for (int ch = 0; ch < C; ++ch) { const float p = v[ch] * w; acc[o][ch] = acc[o][ch] + p; }
+        } else if constexpr (MODE == 3) {
+            const float w = k.f[ky * kw + kx];
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) acc[o][ch] = __builtin_fmaf(v[ch], w, acc[o][ch]); // exact either way: integers below 2^24
         } else {
             const int32_t w = k.i[ky * kw + kx];
 #pragma unroll
@@ -93,7 +108,7 @@ __global__ __launch_bounds__(256) void k_conv2d(DImg src, DImg dst, Kernel2D k, 
         for (int j = 0; j < C2_RPT + KH - 1; ++j)
 #pragma unroll
             for (int kx = 0; kx < KW; ++kx) {
-                const Vec v = tile[(wave * C2_RPT + j) * LW + lx + kx];
+                const TVec v = tile[(wave * C2_RPT + j) * LW + lx + kx];
 #pragma unroll
                 for (int o = 0; o < C2_RPT; ++o)
                     if (j - o >= 0 && j - o < KH) tap(o, j - o, kx, v);
@@ -101,7 +116,7 @@ __global__ __launch_bounds__(256) void k_conv2d(DImg src, DImg dst, Kernel2D k, 
     } else {
         for (int j = 0; j < C2_RPT + kh - 1; ++j)
             for (int kx = 0; kx < kw; ++kx) {
-                const Vec v = tile[(wave * C2_RPT + j) * LW + lx + kx];
+                const TVec v = tile[(wave * C2_RPT + j) * LW + lx + kx];
 #pragma unroll
                 for (int o = 0; o < C2_RPT; ++o)
                     if (j - o >= 0 && j - o < kh) tap(o, j - o, kx, v); // wave-uniform
@@ -117,9 +132,10 @@ __global__ __launch_bounds__(256) void k_conv2d(DImg src, DImg dst, Kernel2D k, 
         for (int ch = 0; ch < C; ++ch) {
             if constexpr (MODE == 0) out[ch] = acc[o][ch];
             else { // divClampU8(256): symmetric rounding divide, clamp
-                const Acc a = acc[o][ch];
+                using IAcc = typename std::conditional<MODE == 3, int32_t, Acc>::type;
+                const IAcc a = (IAcc)acc[o][ch]; // MODE 3: an integer-valued float, exact
                 if (a < 0) out[ch] = 0; // (a - 128) / 256 truncates to <= 0
-                else { const Acc q = (a + 128) >> 8; out[ch] = (uint8_t)(q > 255 ? 255 : q); }
+                else { const IAcc q = (a + 128) >> 8; out[ch] = (uint8_t)(q > 255 ? 255 : q); }
             }
         }
         P::store(dst.data, (size_t)r * dst.stride + (size_t)c, out);
@@ -178,8 +194,10 @@ static int launch_conv2d(const zg_image *src, const zg_image *dst, const Kernel2
 #define ZG_C2(KH, KW) hipLaunchKernelGGL((k_conv2d<PIX, MODE, KH, KW>), grid, dim3(256), 0, s, dimg(src), dimg(dst), k, border, tiles_x)
     if (k.kh == 3 && k.kw == 3) ZG_C2(3, 3);
     else if (k.kh == 5 && k.kw == 5) ZG_C2(5, 5);
-    else if (k.kh == 7 && k.kw == 7) ZG_C2(7, 7);
-    else ZG_C2(0, 0);
+    else if (k.kh == 7 && k.kw == 7) {
+        if constexpr (MODE == 3 && Px<PIX>::C > 1) ZG_C2(0, 0); // never launched (convolve_impl): unrolled, this form wants 288 registers
+        else ZG_C2(7, 7);
+    } else ZG_C2(0, 0);
 #undef ZG_C2
     ZG_HIP(hipGetLastError());
     return ZG_OK;
@@ -208,16 +226,22 @@ static int convolve_impl(const zg_image *src, const zg_image *dst, const float *
             sum_abs += std::llabs((long long)ik[i]);
         }
         mode = (255 * sum_abs < (int64_t)INT32_MAX - 256) ? 1 : 2;
+        static const bool no_f32 = getenv("ZIGNAL_HIP_CONV2D_INT") != nullptr; // tuning hook: integer accumulators for every u8 kernel
+        // every partial sum an integer below 2^24: f32 multiply-adds are exact. Used where it was measured faster — the unrolled 3 x 3 and
+        // 5 x 5 kernels and the one-channel 7 x 7 (4096^2 Rgba(u8): 78.6 -> 72.9 and 155 -> 127 us; grey 31.9 / 43.2 / 59.1 -> 30.6 / 39.0 / 54.2 us);
+        // the run-time-size kernel and 7 x 7 on three or four channels (288 registers when unrolled) keep the integer form
+        const bool unrolled = (kh == 3 && kw == 3) || (kh == 5 && kw == 5) || (kh == 7 && kw == 7 && pixel_channels(src->pixel) == 1);
+        if (255 * sum_abs < (1 << 24) && unrolled && !no_f32) mode = 3;
     }
     if (kh <= 15 && kw <= 15) { // tiled kernels, taps as a kernel argument
         Kernel2D k;
         k.kh = (int)kh;
         k.kw = (int)kw;
-        for (size_t i = 0; i < nk; ++i) { if (is_float) k.f[i] = kernel[i]; else k.i[i] = ik[i]; }
+        for (size_t i = 0; i < nk; ++i) { if (is_float) k.f[i] = kernel[i]; else if (mode == 3) k.f[i] = (float)ik[i]; else k.i[i] = ik[i]; }
         return dispatch_pixel(src->pixel, [&](auto tag) -> int {
             constexpr int PIX = decltype(tag)::value;
             if constexpr (std::is_same<typename Px<PIX>::Elem, float>::value) return launch_conv2d<PIX, 0>(src, dst, k, border, s);
-            else return mode == 1 ? launch_conv2d<PIX, 1>(src, dst, k, border, s) : launch_conv2d<PIX, 2>(src, dst, k, border, s);
+            else return mode == 3 ? launch_conv2d<PIX, 3>(src, dst, k, border, s) : mode == 1 ? launch_conv2d<PIX, 1>(src, dst, k, border, s) : launch_conv2d<PIX, 2>(src, dst, k, border, s);
         });
     }
     void *taps = nullptr; // larger: taps from device memory (uploaded synchronously: not capturable)
