@@ -119,6 +119,8 @@ ALTERNATIVE_FORMS = {
     "ZIGNAL_HIP_NO_U8_PLANE_RESIZE": "k_geom instead of k_resize_bilinear_u8",
     "ZIGNAL_HIP_NO_STREAM": "the tiled u8 Gaussians instead of k_sep_stream",
     "ZIGNAL_HIP_STREAM_GREY": "k_sep_stream for a single grey plane too",
+    "ZIGNAL_HIP_NO_WARP_STAGE": "sixteen gathers in flight instead of the wave-staged Rgba(f32) resampler",
+    "ZIGNAL_HIP_CONV2D_INT": "integer accumulators in k_conv2d",
 }
 
 
@@ -149,6 +151,14 @@ for sigma in (0.6, 1.0, 2.25, 5.5):
     same(dev(rgba).gaussian_blur(sigma), o.gaussian_blur(rgba, sigma), "rgba blur %%g" %% sigma)
 for size in ((250, 1080), (97, 411), (640, 2600)):
     same(dev(grey).resize(size, zg.Interpolation.bilinear), o.resize(grey, size, o.method(o.BILINEAR)), "grey resize")
+f32 = rng.random((90, 700, 4), dtype=np.float32)
+for size, kind, okind in (((120, 930), zg.Interpolation.bicubic, o.BICUBIC), ((45, 350), zg.Interpolation.catmull_rom, o.CATMULL_ROM), ((95, 705), zg.Interpolation.mitchell(1 / 3, 1 / 3), o.MITCHELL)):
+    same(dev(f32).resize(size, kind), o.resize(f32, size, o.method(okind, kind.b, kind.c)), "f32 resize")
+for n in (3, 5, 7):
+    k = rng.random((n, n), dtype=np.float32) / (n * n)
+    k[0, 0] *= -1
+    same(dev(rgba).convolve(k), o.convolve(rgba, k, o.MIRROR), "convolve rgba")
+    same(dev(grey).convolve(k), o.convolve(grey, k, o.MIRROR), "convolve grey")
 print("ok")
 ''' % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **{hook: "1"}))
