@@ -217,6 +217,8 @@ struct StreamJob {
     bool down2;                            // dst is (rows / 2) x (cols / 2): blur then 2:1 bilinear (sp == 4)
 };
 int try_sep_stream(const StreamJob &j, const int32_t *ix, const int32_t *iy, int nk, int border, hipStream_t s);
+// the same job with both passes on the matrix pipe (conv_sep_mfma.hip); -1 when its preconditions do not hold
+int try_sep_mfma(const StreamJob &j, const int32_t *ix, const int32_t *iy, int nk, int border, hipStream_t s);
 
 // scratch blocks from the library's caching allocator, ordered on stream s (zg_runtime.cpp)
 int scratch_alloc(void **out, size_t bytes, hipStream_t s);
