@@ -330,6 +330,18 @@ __global__ __launch_bounds__(64) void k_sep_stream(StreamArgs a, TapsU8<NK> kx, 
 #pragma unroll
             for (int u = 0; u < D; ++u) {
                 const int q = qb + u;
+#ifdef ZG_STREAM_NOARITH // tools/exp/stream_batch.hip: the loads and the stores alone, in the kernel's order and with its read-ahead
+                {
+                    const RowIn<HB> c0 = ahead[u % D][0], c1 = ahead[u % D][1];
+                    ahead[u % D][0] = load_row(y0 - H + 2 * (q + D));
+                    ahead[u % D][1] = load_row(y0 - H + 2 * (q + D) + 1);
+                    if (q < H) continue;
+                    const int gy = y0 + 2 * (q - H);
+                    if constexpr (DOWN2) store_row(u32x2{c0.v[0] ^ c1.v[1] ^ c0.h[0], c0.v[2] ^ c1.v[3] ^ c1.h[HB - 1]}, gy >> 1);
+                    else { store_row(u32x4{c0.v[0] ^ c0.h[0], c0.v[1], c0.v[2], c0.v[3]}, gy); store_row(u32x4{c1.v[0] ^ c1.h[HB - 1], c1.v[1], c1.v[2], c1.v[3]}, gy + 1); }
+                    continue;
+                }
+#endif
                 uint32_t q0[12], q1[12];
                 widen(edge_tag, ahead[u % D][0], q0);
                 widen(edge_tag, ahead[u % D][1], q1);
