@@ -52,7 +52,8 @@ def parse_args():
     ap.add_argument("--eager", action="store_true", help="launch every step from Python instead of replaying a HIP graph")
     ap.add_argument("--scatter-gather", action="store_true",
                     help="also time BASELINE configs[4] end to end (RCCL scatter -> blur+resize -> gather), 128 frames per GPU; "
-                         "with one GPU the shard loops back through a one-rank RCCL communicator")
+                         "with one GPU the shard loops back through a one-rank RCCL communicator. With --gpus N > 1 this leg runs by default")
+    ap.add_argument("--no-scatter-gather", action="store_true", help="N > 1: skip the configs[4] scatter / compute / gather leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true", help="take roofline.traffic from profiles/traffic.json instead of two rocprofv3 counter passes")
     ap.add_argument("--no-extras", action="store_true")
@@ -106,6 +107,8 @@ def launch_ranks(args) -> int:
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and not args.no_scatter_gather:
+        args.scatter_gather = True  # the N-GPU run is the one that can put bytes on xGMI: BASELINE configs[4] is part of it unless switched off
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     # stdout carries exactly one line, the JSON: everything libraries print on the way (RCCL's version banner, for one) goes to stderr
@@ -241,10 +244,12 @@ def main():
                    "parallelism": f"frame-sharded x{world}, no data-path collective"},
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0:
         # Kernel time per launch = HIP events around the timed region (above) / launches in it: device time on the launch stream,
         # inter-launch gaps included, so it can only overstate the kernel. Cross-check: event pairs around 200 single eager
         # launches (each pair also brackets its launch overhead), and the rocprofv3 mean under profiles/.
+        # With N > 1 this is rank 0's own GPU (the ranks run the same launches on frames of their own), so the N = 1 line and
+        # SCALE's first point agree by construction; the counter passes (a second process on the GPU) are an N = 1 matter.
         n = min(args.steps, 200)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
         for i, (a, b) in enumerate(evs):
@@ -257,7 +262,8 @@ def main():
         mean_ms = region_ms_per_launch
         alg_bytes = 32 * pixels  # 16 B read + 16 B written per pixel
         achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
-        traffic, traffic_source = (None if args.no_live_traffic else live_traffic("blur_f32", "k_sep_fused")), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, this run"
+        live = world == 1 and not args.no_live_traffic
+        traffic, traffic_source = (live_traffic("blur_f32", "k_sep_fused") if live else None), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, this run"
         if traffic is None:
             traffic_source = "profiles/traffic.json (an earlier rocprofv3 measurement of the same kernel)"
             try:
@@ -267,10 +273,11 @@ def main():
         result["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                               "kernel": "k_sep_fused<RGBA_F32,5>", "kernel_ms_mean": round(mean_ms, 5),
-                              "kernel_ms_source": "HIP events around the timed region / launches in it",
+                              "kernel_ms_source": "HIP events around the timed region / launches in it" + (" (rank 0's GPU)" if world > 1 else ""),
                               "kernel_ms_eager_event_pairs_mean": round(eager_mean_ms, 5),
                               "kernel_ms_eager_event_pairs_median": round(kernel_ms[len(kernel_ms) // 2], 5),
                               "algorithmic_bytes_per_launch": alg_bytes}
+    if rank == 0 and world == 1:
         # The metric names two ops: the bilinear resize of BASELINE configs[2] stands beside the blur, same arithmetic.
         try:
             result["resize"] = resize_headline(zg, torch, not args.no_live_traffic)

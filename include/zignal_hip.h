@@ -469,14 +469,15 @@ typedef void *zg_multi;
 ZG_API int zg_multi_create(const int *devices, int n_devices, zg_multi *out);
 ZG_API int zg_multi_destroy(zg_multi m);
 ZG_API int zg_multi_device_count(zg_multi m);
-/* Orders the context's next call behind everything enqueued so far on `producer`, a stream of the ROOT device (NULL = its legacy
- * default stream, which the batch call waits for anyway). No host synchronisation. */
+/* Orders the context's next batch call behind everything enqueued so far on `producer`, a stream of the ROOT device (NULL = its legacy
+ * default stream), without host synchronisation; may be called once per producing stream. A batch call that was NOT preceded by this
+ * synchronises the root device instead, so it is safe whatever stream produced its frames. */
 ZG_API int zg_multi_wait_stream(zg_multi m, zg_stream producer);
 /* zg_batch_blur_resize over the context's devices. src_frames_root / dst_frames_root are device pointers ON THE ROOT DEVICE holding
  * all n_frames input frames / receiving all output frames. Device i owns a contiguous block of frames (sizes differ by at
  * most one) and receives it in up to four pieces: transfer, kernel and return trip of consecutive pieces overlap. Synchronous:
- * results are complete on return. The call orders itself behind the root device's legacy default stream (hence behind every
- * blocking stream of that device); a producer on a non-blocking stream is named beforehand with zg_multi_wait_stream. times_ms
+ * results are complete on return. The call waits for whatever produced src_frames_root: the streams named with zg_multi_wait_stream
+ * since the previous batch call (stream waits, the host does not block), or, when none was named, the whole root device. times_ms
  * (may be NULL) receives milliseconds of {the scatter stream from first to last send (device events), the busiest device's kernels
  * from first to last piece (device events), the whole call (host clock)} — the three overlap, they do not add up. After a failure
  * inside the exchange the context refuses further calls (ZG_ERR_INVALID_ARGUMENT): destroy and re-create it. */

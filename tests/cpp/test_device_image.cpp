@@ -266,6 +266,29 @@ int main(int argc, char **argv) {
                 EXPECT(got == want);
                 if (!call) std::printf(mode.loop ? "multi_1gpu_rccl_loopback_%s_pieces_ms=%.3f %.3f %.3f\n" : "multi_1gpu_%s_ms=%.3f %.3f %.3f\n", mode.chunks, t[0], t[1], t[2]);
             }
+            { // frames produced on a NON-BLOCKING stream (zg_stream_create makes those): unnamed, the call synchronises the root device;
+              // named with zg_multi_wait_stream, it waits for that stream. Either way it must not read the source before the copy has run.
+                void *dsrc2 = nullptr, *big = nullptr;
+                check(zg_malloc(&dsrc2, in_bytes)); check(zg_malloc(&big, (size_t)2048 * 2048 * 4 * 2));
+                zg_stream st = nullptr;
+                check(zg_stream_create(&st));
+                const zg_image all = {dsrc, cols, n * rows, cols, ZG_PIXEL_RGBA_U8}, all2 = {dsrc2, cols, n * rows, cols, ZG_PIXEL_RGBA_U8};
+                const zg_image b0 = {big, 2048, 2048, 2048, ZG_PIXEL_RGBA_U8}, b1 = {(char *)big + (size_t)2048 * 2048 * 4, 2048, 2048, 2048, ZG_PIXEL_RGBA_U8};
+                for (int named = 0; named < 2; ++named) {
+                    std::vector<uint8_t> zeros(in_bytes, 0);
+                    check(zg_memcpy_h2d(dsrc2, zeros.data(), in_bytes, nullptr));
+                    check(zg_memcpy_h2d(dout, fill.data(), out_bytes, nullptr));
+                    for (int k = 0; k < 20; ++k) check(zg_gaussian_blur(k & 1 ? &b1 : &b0, k & 1 ? &b0 : &b1, 2.5f, st)); // keeps the stream busy for a while
+                    check(zg_copy(&all, &all2, st));
+                    if (named) check(zg_multi_wait_stream(ctx, st));
+                    check(zg_multi_batch_blur_resize(ctx, dsrc2, n, rows, cols, ZG_PIXEL_RGBA_U8, sigma, dout, rows / 2, cols / 2, &bil, nullptr));
+                    check(zg_memcpy_d2h(got.data(), dout, out_bytes, nullptr));
+                    EXPECT(got == want);
+                }
+                check(zg_stream_synchronize(st));
+                check(zg_stream_destroy(st));
+                check(zg_free(dsrc2)); check(zg_free(big));
+            }
             // argument errors leave the context usable
             EXPECT(zg_multi_batch_blur_resize(ctx, dsrc, n, rows, cols, 99, sigma, dout, rows / 2, cols / 2, &bil, nullptr) == ZG_ERR_INVALID_ARGUMENT);
             check(zg_multi_batch_blur_resize(ctx, dsrc, 1, rows, cols, ZG_PIXEL_RGBA_U8, sigma, dout, rows / 2, cols / 2, &bil, nullptr));

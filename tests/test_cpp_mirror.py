@@ -101,3 +101,21 @@ def test_bare_process_is_stable_over_twenty_runs():
     for i in range(20):
         rc, log = _run([BIN_DEV, "quick"], 120)
         assert rc == 0 and "device image ok" in log, f"run {i}:\n{log}"
+
+
+@pytest.mark.gpu
+def test_zg_multi_world_gt_1_runs_wherever_two_gpus_are_visible():
+    """zg_multi's world > 1 branches (shard ownership, staging on the owners, both communicators, 1 and 4 pieces per shard) against the
+    one-device result, from a bare C++ process. Needs two GPUs; the one-GPU boxes of the test tier skip it — visibly, by this test's
+    own decision rather than the program's."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"{torch.cuda.device_count()} GPU visible: the world > 1 branches of zg_multi need two")
+    _ensure_built()
+    rc, log = _run([BIN_DEV], 900)
+    assert rc == 0 and "device image ok" in log, log
+    assert "multi_world_gt_1=skipped" not in log, log
+    world = torch.cuda.device_count()
+    for pieces in ("1", "4"):
+        assert re.search(rf"^multi_{world}gpu_{pieces}_pieces_ms=", log, re.M), log

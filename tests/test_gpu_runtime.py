@@ -118,6 +118,7 @@ ALTERNATIVE_FORMS = {
     "ZIGNAL_HIP_ROWS_INT": "k_rows_u16 instead of k_rows_u8f",
     "ZIGNAL_HIP_NO_U8_PLANE_RESIZE": "k_geom instead of k_resize_bilinear_u8",
     "ZIGNAL_HIP_NO_STREAM": "the tiled u8 Gaussians instead of k_sep_stream",
+    "ZIGNAL_HIP_MFMA": "k_sep_mfma (both passes of the u8 Gaussian on the matrix pipe) instead of k_sep_stream",
     "ZIGNAL_HIP_STREAM_GREY": "k_sep_stream for a single grey plane too",
     "ZIGNAL_HIP_NO_WARP_STAGE": "sixteen gathers in flight instead of the wave-staged Rgba(f32) resampler",
     "ZIGNAL_HIP_CONV2D_INT": "integer accumulators in k_conv2d",

@@ -79,7 +79,7 @@ template <int NT> __device__ __forceinline__ void st_lane(const uint32_t (&o)[NT
 }
 
 template <int NT, bool SPLIT, bool CLAMP, int PD, int EXP = 0>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PD > 4 ? 3 : 4))) void k_sep_mfma(MfmaArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_sep_mfma(MfmaArgs a) {
     constexpr int NS = SPLIT ? 2 : 1;
     const int H = a.half, OR = 16 - 2 * H; // output rows of a band
     constexpr int UW = 16 * NT, OFF_MID = (64 - UW) / 2;
@@ -373,7 +373,6 @@ template <int NT> static int launch_mfma(const StreamJob &j, const int32_t *ix, 
     const uint64_t items = (uint64_t)a.bands * a.segs_x * j.n_frames;
     if (items > 0x7fffffffu) return -1;
     const dim3 grid((unsigned)items), block(64);
-    const bool deep = env_int("ZIGNAL_HIP_MFMA_PD", 4) > 4;
     if (const int ex = env_int("ZIGNAL_HIP_MFMA_EXP", 0)) { // experiments (profiles/r04_mfma_blur.txt): 1 = no stores, 2 = no loads, 3 = neither
         if constexpr (NT == 3) if (hold->split && !clamp) {
             if (ex == 1) hipLaunchKernelGGL((k_sep_mfma<3, true, false, 4, 1>), grid, block, 0, s, a);
@@ -383,7 +382,7 @@ template <int NT> static int launch_mfma(const StreamJob &j, const int32_t *ix, 
             return ZG_OK;
         }
     }
-#define ZG_MF(SPLIT, CLAMP) do { if (deep) hipLaunchKernelGGL((k_sep_mfma<NT, SPLIT, CLAMP, 6>), grid, block, 0, s, a); else hipLaunchKernelGGL((k_sep_mfma<NT, SPLIT, CLAMP, 4>), grid, block, 0, s, a); } while (0)
+#define ZG_MF(SPLIT, CLAMP) hipLaunchKernelGGL((k_sep_mfma<NT, SPLIT, CLAMP, 4>), grid, block, 0, s, a)
     if (hold->split) { if (clamp) ZG_MF(true, true); else ZG_MF(true, false); }
     else { if (clamp) ZG_MF(false, true); else ZG_MF(false, false); }
 #undef ZG_MF
@@ -393,6 +392,8 @@ template <int NT> static int launch_mfma(const StreamJob &j, const int32_t *ix, 
 
 // Returns -1 when the preconditions do not hold (the caller falls back to the VALU kernels).
 int try_sep_mfma(const StreamJob &j, const int32_t *ix, const int32_t *iy, int nk, int border, hipStream_t s) {
+    // Tuning hook, off by default: bit-exact, but the fragment layout makes its loads and stores 16- and 12-byte pieces, one row per lane, and it runs at a
+    // third of k_sep_stream's speed (profiles/r04_mfma_blur.txt). Kept as the record of that experiment and as the base of an LDS-staged form.
     static const bool on = getenv("ZIGNAL_HIP_MFMA") != nullptr;
     if (!on) return -1;
     if (j.down2) return -1;

@@ -96,6 +96,7 @@ struct Multi {
     hipEvent_t ready = nullptr;  // root: whatever produced the caller's frames
     bool loopback = false;       // one device: still pass the root's shard through ncclSend / ncclRecv (diagnostics)
     bool poisoned = false;       // a call failed half-way: streams and communicators are in an unknown state
+    bool producer_named = false; // zg_multi_wait_stream was called since the last batch: the caller has said what produces its frames
     int chunks = 4;
 };
 
@@ -247,6 +248,7 @@ int zg_multi_wait_stream(zg_multi handle, zg_stream producer) {
     ZG_HIP(hipSetDevice(root.device));
     ZG_HIP(hipEventRecord(m->ready, as_stream(producer)));
     for (hipStream_t s : {root.s_in, root.s_run, root.s_out}) ZG_HIP(hipStreamWaitEvent(s, m->ready, 0));
+    m->producer_named = true;
     return ZG_OK;
 }
 
@@ -407,13 +409,16 @@ int zg_multi_batch_blur_resize(zg_multi handle, const void *src_frames_root, uin
         if ((rc = ensure(&root.in, &root.in_bytes, (size_t)n_frames * in_frame))) return rc;
         if ((rc = ensure(&root.out, &root.out_bytes, (size_t)n_frames * out_frame))) return rc;
     }
-    // Whatever produced the caller's frames: an event on the root's legacy default stream, which is ordered behind every blocking stream
-    // of the device, holds the three root streams back — no host synchronisation. Producers on non-blocking streams (PyTorch's side
-    // streams) are named with zg_multi_wait_stream, or synchronised by the caller.
-    {
-        const int rc = zg_multi_wait_stream(handle, nullptr);
-        if (rc) return rc;
+    // Whatever produced the caller's frames. A caller that named its producer stream(s) with zg_multi_wait_stream since the last batch has
+    // already ordered the three root streams behind them: nothing more to do, and no host synchronisation. Otherwise the producer is unknown —
+    // it may be a non-blocking stream (this library's own zg_stream_create makes those, and so do PyTorch's side streams), which an event on
+    // the legacy default stream would NOT order behind — so the root device is synchronised: the documented "synchronous call" stays safe
+    // whatever stream filled src_frames_root.
+    if (!m->producer_named) {
+        ZG_HIP(hipSetDevice(root.device));
+        ZG_HIP(hipDeviceSynchronize());
     }
+    m->producer_named = false;
     int rc = run_batch(m, src_frames_root, n_frames, rows, cols, pixel, sigma, dst_frames_root, out_rows, out_cols, method, times_ms != nullptr);
     const int src = sync_all(m); // results are complete on return; after a failure this also drains what was already enqueued
     if (rc != ZG_OK || src != ZG_OK) {

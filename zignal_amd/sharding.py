@@ -139,8 +139,13 @@ def scatter_compute_gather(batch: Optional[torch.Tensor], n_frames: int, frame_s
         if ops:
             reqs = dist.batch_isend_irecv(ops)
             if rank in peers and c < len(chunk_ranges(sizes[rank], chunks)):
-                recv_reqs[c] = reqs.pop()  # the receive was appended last; it is waited for below, once (gloo hangs on a second wait)
-            pending.extend(reqs)
+                # Everything this launch returned is waited for before piece c is computed, each request once (gloo hangs on a second
+                # wait): a backend may hand back one request per op in any order, or one for the whole group (NCCL coalesces), so no
+                # single element can be taken for "the receive". A peer's launch holds nothing but its receive; the loop-back root's
+                # also holds its sends of piece c, and waiting for those is a stream wait behind work that is already queued.
+                recv_reqs[c] = list(reqs)
+            else:
+                pending.extend(reqs)
 
     # ---- gather, root side: piece c of every (other) peer, posted before any local work so that nothing orders them behind it ---
     if rank == root:
@@ -163,7 +168,8 @@ def scatter_compute_gather(batch: Optional[torch.Tensor], n_frames: int, frame_s
     # ---- peers: piece by piece, the result straight back on the second communicator --------------------------------------------
     if rank in peers:
         for c, (c0, c1) in enumerate(chunk_ranges(sizes[rank], chunks)):
-            recv_reqs[c].wait()  # orders the current stream behind the arrival; the host carries on
+            for req in recv_reqs[c]:
+                req.wait()  # orders the current stream behind the arrival; the host carries on
             compute(mine_in[c0:c1], mine_out[c0:c1])
             ops = [dist.P2POp(dist.isend, mine_out[c0:c1], root, group=gather_group)]
             if rank == root:  # loop-back: the send and its matching receive go into one group
