@@ -487,8 +487,9 @@ def scatter_gather_leg(zg, torch, sharding, rank, world, local_rank, frames_per_
         for label, k in (("end_to_end_xgmi", chunks), ("end_to_end_xgmi_unchunked", 1)):
             sec = clock(lambda: sharding.scatter_compute_gather(batch, n, (rows, cols, 4), (540, 960, 4), torch.uint8, dev, blur_resize, chunks=k,
                                                                 loopback=loop, gather_group=second, out=gathered))
-            out[label] = {"seconds": round(sec, 6), "Mpixels/s": round(px_all / sec / 1e6, 1),
-                          "GB/s_scattered": round((n - (0 if loop else frames_per_gpu)) * rows * cols * 4 / sec / 1e9, 1)}
+            sent = (n - (0 if loop else frames_per_gpu)) * rows * cols * 4  # bytes that leave rank 0 (a quarter as many come back)
+            out[label] = {"seconds": round(sec, 6), "Mpixels/s": round(px_all / sec / 1e6, 1), "GB/s_scattered": round(sent / sec / 1e9, 1),
+                          "GB/s_scattered_per_link": round(sent / max(1, world - 1) / sec / 1e9, 1), "links": max(1, world - 1)}
         out["note"] = ("one rank: the shard loops back through the communicator (ncclSend / ncclRecv to itself), so this times RCCL's "
                        "device-local copy path, not xGMI" if world == 1 else
                        "rank 0 sends 8.3 MB per frame to the frame's owner and receives 2.1 MB back, each peer over its own xGMI link")

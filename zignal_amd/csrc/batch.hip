@@ -223,6 +223,8 @@ int zg_batch_pipeline(const void *src_frames, uint32_t n_frames, uint32_t rows, 
                 default: { // warp: the same map for every frame, one launch
                     const zg_image a = cur.frame(0), b = next.frame(0);
                     rc = warp_frames(&a, &b, st.transform, st.m, &st.method, gn, cur.frame_bytes(), next.frame_bytes(), s);
+                    if (rc == -1) // more frames than one launch takes: frame by frame
+                        rc = per_frame(cur, next, [&](const zg_image *fa, const zg_image *fb) { return zg_warp(fa, fb, st.transform, st.m, &st.method, stream); });
                     break;
                 }
                 }

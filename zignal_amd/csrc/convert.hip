@@ -351,10 +351,8 @@ __global__ __launch_bounds__(256) void k_resize_bilinear_rgba8_to_lab(DImg src, 
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
     if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
-    const int frame = wg / fr.tiles_per_frame; // a batch of equally shaped frames in one launch (batch.hip)
-    wg -= frame * fr.tiles_per_frame;
-    src.data = (char *)src.data + (size_t)frame * fr.src_frame;
-    dst.data = (char *)dst.data + (size_t)frame * fr.dst_frame;
+    src.data = (char *)src.data + (size_t)blockIdx.y * fr.src_frame; // a batch of equally shaped frames in one launch (batch.hip)
+    dst.data = (char *)dst.data + (size_t)blockIdx.y * fr.dst_frame;
     const int tyi = wg / tiles_x, txi = wg - tyi * tiles_x;
     const int c = txi * 64 + (int)(threadIdx.x & 63);
     const int r = __builtin_amdgcn_readfirstlane(tyi * 4 + (int)(threadIdx.x >> 6));
@@ -384,20 +382,21 @@ int resize_convert_rgba8_frames(const zg_image *src, const zg_image *dst, int ds
                        src->cols >= 2 && dst->rows > 0 && dst->cols > 0 && n > 0 && !(src->rows == dst->rows && src->cols == dst->cols);
     if (!fused) return -1;
     const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, 4);
-    const uint64_t grid = (uint64_t)tiles_x * tiles_y * n;
-    if (grid > 0x7fffffffu) return -1;
+    const uint64_t tiles = (uint64_t)tiles_x * tiles_y;
+    if (tiles > 0x7fffffffu || n > MAX_FRAMES_PER_LAUNCH) return -1;
+    const dim3 grid((unsigned)tiles, n);
     const float *lut_dev = nullptr;
     float *owned = nullptr;
     bool plain_table = false;
     if (int rc = device_srgb_lut(srgb_lut, s, &lut_dev, &owned, &plain_table)) return rc;
     const float ratio_x = (float)src->cols / (float)dst->cols, ratio_y = (float)src->rows / (float)dst->rows;
-    const FrameSpan fr{src_frame, dst_frame, tiles_x * tiles_y};
+    const FrameSpan fr{src_frame, dst_frame};
     if (dst_space != ZG_CS_OKLAB)
-        hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<0>, dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr);
+        hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<0>, grid, dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr);
     else if (plain_table)
-        hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<2>, dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr);
+        hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<2>, grid, dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr);
     else
-        hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<1>, dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr);
+        hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<1>, grid, dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr);
     const hipError_t e = hipGetLastError();
     if (owned) scratch_free(owned, s);
     ZG_HIP(e);

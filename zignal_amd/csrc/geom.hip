@@ -105,10 +105,8 @@ __global__ __launch_bounds__(256) void k_geom(DImg src, DImg dst, GeomParams g, 
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
     if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
-    const int frame = wg / fr.tiles_per_frame; // a batch of equally shaped frames, the same map for each (zg_batch_pipeline)
-    wg -= frame * fr.tiles_per_frame;
-    src.data = (char *)src.data + (size_t)frame * fr.src_frame;
-    dst.data = (char *)dst.data + (size_t)frame * fr.dst_frame;
+    src.data = (char *)src.data + (size_t)blockIdx.y * fr.src_frame; // a batch of equally shaped frames, the same map for each (zg_batch_pipeline)
+    dst.data = (char *)dst.data + (size_t)blockIdx.y * fr.dst_frame;
     const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
     const int c = tx * 64 + (int)(threadIdx.x & 63);
     const int r = ty * 4 + (int)(threadIdx.x >> 6);
@@ -168,20 +166,22 @@ struct FrameBatch { // n frames src_frame / dst_frame bytes apart (defaults: the
 template <int PIX, int KIND>
 static int launch_geom_k(const zg_image *src, const zg_image *dst, const GeomParams &g, const MethodArg &m, int border, const FrameBatch &fb, hipStream_t s) {
     const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, 4);
-    const uint64_t grid = (uint64_t)tiles_x * tiles_y * fb.n;
-    ZG_REQUIRE(grid <= 0x7fffffffu, ZG_ERR_INVALID_ARGUMENT, "too many tiles in one launch (%llu)", (unsigned long long)grid);
-    const FrameSpan fr{fb.src_frame, fb.dst_frame, tiles_x * tiles_y};
+    const uint64_t tiles = (uint64_t)tiles_x * tiles_y;
+    ZG_REQUIRE(tiles <= 0x7fffffffu, ZG_ERR_INVALID_ARGUMENT, "too many tiles in one launch (%llu)", (unsigned long long)tiles);
+    if (fb.n > MAX_FRAMES_PER_LAUNCH) return -1; // the caller goes frame by frame
+    const dim3 grid((unsigned)tiles, fb.n);
+    const FrameSpan fr{fb.src_frame, fb.dst_frame};
     constexpr bool CAN_STAGE = PIX == ZG_PIXEL_RGBA_F32 && (KIND == ZG_INTERP_BICUBIC || KIND == ZG_INTERP_CATMULL_ROM || KIND == ZG_INTERP_MITCHELL);
     if constexpr (CAN_STAGE) {
         // for every map: where a wave cannot stage, this kernel's row-at-a-time gather (seven waves per SIMD) still beats the sixteen gathers
         // in flight of the plain one — 2:1 reduction 101 -> 80 us, a 10-degree rotation 350 -> 304 us (profiles/r03_experiments.txt)
         if (g.stage) {
-            hipLaunchKernelGGL((k_geom<PIX, KIND, true>), dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), g, m, border, tiles_x, fr);
+            hipLaunchKernelGGL((k_geom<PIX, KIND, true>), grid, dim3(256), 0, s, dimg(src), dimg(dst), g, m, border, tiles_x, fr);
             ZG_HIP(hipGetLastError());
             return ZG_OK;
         }
     }
-    hipLaunchKernelGGL((k_geom<PIX, KIND>), dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), g, m, border, tiles_x, fr);
+    hipLaunchKernelGGL((k_geom<PIX, KIND>), grid, dim3(256), 0, s, dimg(src), dimg(dst), g, m, border, tiles_x, fr);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -233,10 +233,8 @@ __global__ __launch_bounds__(256) void k_resize_bilinear_u8(DImg src, DImg dst, 
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
     if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
-    const int frame = wg / fr.tiles_per_frame;
-    wg -= frame * fr.tiles_per_frame;
-    src.data = (char *)src.data + (size_t)frame * fr.src_frame;
-    dst.data = (char *)dst.data + (size_t)frame * fr.dst_frame;
+    src.data = (char *)src.data + (size_t)blockIdx.y * fr.src_frame;
+    dst.data = (char *)dst.data + (size_t)blockIdx.y * fr.dst_frame;
     const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
     const int c0 = tx * 256 + (int)(threadIdx.x & 63) * 4;
     const int r = __builtin_amdgcn_readfirstlane(ty * 4 + (int)(threadIdx.x >> 6));
@@ -317,11 +315,12 @@ __global__ __launch_bounds__(256) void k_resize_bilinear_u8(DImg src, DImg dst, 
 // n equally shaped u8 planes (n = 1: the one image); sizes the caller has already checked
 static int launch_resize_bilinear_u8(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s) {
     const int tiles_x = (int)ceil_div(dst->cols, 256), tiles_y = (int)ceil_div(dst->rows, 4);
-    const uint64_t grid = (uint64_t)tiles_x * tiles_y * n;
-    ZG_REQUIRE(grid <= 0x7fffffffu, ZG_ERR_INVALID_ARGUMENT, "too many tiles in one launch (%llu)", (unsigned long long)grid);
-    const FrameSpan fr{src_frame, dst_frame, tiles_x * tiles_y};
+    const uint64_t tiles = (uint64_t)tiles_x * tiles_y;
+    ZG_REQUIRE(tiles <= 0x7fffffffu, ZG_ERR_INVALID_ARGUMENT, "too many tiles in one launch (%llu)", (unsigned long long)tiles);
+    if (n > MAX_FRAMES_PER_LAUNCH) return -1; // the caller goes frame by frame
+    const FrameSpan fr{src_frame, dst_frame};
     const int dword_rows = ((uintptr_t)dst->data % 4 == 0 && dst->stride % 4 == 0 && dst_frame % 4 == 0) ? 1 : 0;
-    hipLaunchKernelGGL(k_resize_bilinear_u8, dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), (float)src->cols / (float)dst->cols,
+    hipLaunchKernelGGL(k_resize_bilinear_u8, dim3((unsigned)tiles, n), dim3(256), 0, s, dimg(src), dimg(dst), (float)src->cols / (float)dst->cols,
                        (float)src->rows / (float)dst->rows, tiles_x, fr, dword_rows);
     ZG_HIP(hipGetLastError());
     return ZG_OK;

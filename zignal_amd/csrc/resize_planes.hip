@@ -312,10 +312,8 @@ __global__ __launch_bounds__(256) void k_resize_bilinear_rgba8(DImg src, DImg ds
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
     if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
-    const int frame = wg / fr.tiles_per_frame;
-    wg -= frame * fr.tiles_per_frame;
-    src.data = (char *)src.data + (size_t)frame * fr.src_frame;
-    dst.data = (char *)dst.data + (size_t)frame * fr.dst_frame;
+    src.data = (char *)src.data + (size_t)blockIdx.y * fr.src_frame;
+    dst.data = (char *)dst.data + (size_t)blockIdx.y * fr.dst_frame;
     const int tyi = wg / tiles_x, txi = wg - tyi * tiles_x;
     const int c0 = (txi * 64 + (int)(threadIdx.x & 63)) * NPX;
     const int r = __builtin_amdgcn_readfirstlane(tyi * 4 + (int)(threadIdx.x >> 6)); // one row per wave
@@ -352,11 +350,12 @@ int resize_bilinear_rgba8_frames(const zg_image *src, const zg_image *dst, uint3
     const float ratio_x = (float)src->cols / (float)dst->cols, ratio_y = (float)src->rows / (float)dst->rows;
     const bool x4 = ratio_x <= 1.5f && dst->cols % 4 == 0 && dst->stride % 4 == 0 && ((uintptr_t)dst->data & 15) == 0 && dst_frame % 16 == 0;
     const int tx = x4 ? (int)ceil_div(dst->cols, 256) : tiles_x;
-    const uint64_t grid = (uint64_t)tx * tiles_y * n;
-    if (grid > 0x7fffffffu) return -1;
-    const FrameSpan fr{src_frame, dst_frame, tx * tiles_y};
-    if (x4) hipLaunchKernelGGL(k_resize_bilinear_rgba8<4>, dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr);
-    else hipLaunchKernelGGL(k_resize_bilinear_rgba8<1>, dim3((unsigned)grid), dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr);
+    const uint64_t tiles = (uint64_t)tx * tiles_y;
+    if (tiles > 0x7fffffffu || n > MAX_FRAMES_PER_LAUNCH) return -1;
+    const dim3 grid((unsigned)tiles, n);
+    const FrameSpan fr{src_frame, dst_frame};
+    if (x4) hipLaunchKernelGGL(k_resize_bilinear_rgba8<4>, grid, dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr);
+    else hipLaunchKernelGGL(k_resize_bilinear_rgba8<1>, grid, dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

@@ -194,11 +194,14 @@ int upload_pageable_rows(void *dst_dev, const void *src_host, size_t spitch, siz
 int download_pageable(void *dst_host, const void *src_dev, size_t bytes, hipStream_t s);
 int download_pageable_rows(void *dst_host, size_t dpitch, const void *src_dev, size_t width, size_t rows, hipStream_t s);
 
-// Frames of a batch inside one launch: bytes from one frame to the next on both sides, workgroups (tiles) per frame.
+// Frames of a batch inside one launch: bytes from one frame to the next on both sides. The frame index is blockIdx.y (grids are
+// tiles-per-frame x frames), so a one-image launch pays nothing for it: round 3 carried the index in blockIdx.x and every workgroup
+// divided by the tiles per frame — forty scalar instructions behind an extra kernel-argument load, 12 % of the bicubic warp and
+// 15 % of the 2:1 resize (profiles/r04_experiments.txt).
 struct FrameSpan {
     size_t src_frame, dst_frame;
-    int tiles_per_frame;
 };
+constexpr uint32_t MAX_FRAMES_PER_LAUNCH = 65535; // gridDim.y
 int resize_bilinear_rgba8_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s);              // resize_planes.hip
 int resize_frames(const zg_image *src, const zg_image *dst, const zg_method *method, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s);       // geom.hip
 int warp_frames(const zg_image *src, const zg_image *dst, int kind, const float *mat, const zg_method *method, uint32_t n, size_t src_frame, size_t dst_frame,
