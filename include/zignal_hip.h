@@ -429,24 +429,39 @@ ZG_API int zg_batch_blur_resize(const void *src_frames, uint32_t n_frames,
  * every conversion; a frame is too short a launch to fill the chip), frame by frame otherwise; consecutive steps the library has a
  * fused kernel for ([gaussian blur, resize to half size] and [resize, convert to Oklab / Xyz] on Rgba(u8)) run as that kernel, the
  * rest hands frames on through scratch. Results equal the per-frame calls bit for bit.
- * Steps mirror the CLI's (blur: src/cli/blur.zig:98-128, resize: src/cli/resize.zig:77-99) plus convert and warp. */
+ * Steps are the CLI's three (src/cli/pipeline.zig:170-172) with every variant each of them has — resize (src/cli/resize.zig:77-99);
+ * blur: box, gaussian, median, motion_linear, motion_zoom, motion_spin (src/cli/blur.zig:98-170); edges: sobel, canny, shen_castan
+ * through the grey bridge (src/cli/edges.zig:85-135) — plus convert and warp. */
 typedef enum zg_step_kind {
     ZG_STEP_GAUSSIAN_BLUR = 0, /* Image.gaussianBlur(sigma) */
     ZG_STEP_BOX_BLUR = 1,      /* Image.boxBlur(radius) */
     ZG_STEP_RESIZE = 2,        /* Image.resize(out_rows x out_cols, method) */
     ZG_STEP_CONVERT = 3,       /* Image.convert(dst_pixel / dst_space) */
-    ZG_STEP_WARP = 4           /* Image.warp(transform, m, method) into out_rows x out_cols */
+    ZG_STEP_WARP = 4,          /* Image.warp(transform, m, method) into out_rows x out_cols */
+    ZG_STEP_MEDIAN_BLUR = 5,   /* Image.medianBlur(radius) */
+    ZG_STEP_MOTION_BLUR = 6,   /* Image.motionBlur(.linear / .radial_zoom / .radial_spin) */
+    ZG_STEP_EDGES = 7          /* edges.apply (src/cli/edges.zig:126-135): frame.convert(u8) -> detector -> .convert(the frames' own type) */
 } zg_step_kind;
+typedef enum zg_motion_kind { ZG_MOTION_LINEAR = 0, ZG_MOTION_RADIAL_ZOOM = 1, ZG_MOTION_RADIAL_SPIN = 2 } zg_motion_kind;
+typedef enum zg_edges_kind { ZG_EDGES_SOBEL = 0, ZG_EDGES_CANNY = 1, ZG_EDGES_SHEN_CASTAN = 2 } zg_edges_kind;
 typedef struct zg_step {
     int kind;                    /* zg_step_kind */
-    float sigma;                 /* GAUSSIAN_BLUR */
-    uint32_t radius;             /* BOX_BLUR */
+    float sigma;                 /* GAUSSIAN_BLUR; EDGES: canny's sigma, Shen-Castan's smooth */
+    uint32_t radius;             /* BOX_BLUR, MEDIAN_BLUR */
     uint32_t out_rows, out_cols; /* RESIZE, WARP: the shape of the step's output frames */
     zg_method method;            /* RESIZE, WARP */
     int dst_pixel, dst_space;    /* CONVERT: zg_pixel, zg_colorspace of the step's output */
     const float *srgb_lut;       /* CONVERT: as zg_convert (host pointer, may be NULL) */
     int transform;               /* WARP: zg_transform */
     float m[9];                  /* WARP: as zg_warp */
+    int motion;                  /* MOTION_BLUR: zg_motion_kind */
+    float angle, cos_a, sin_a;   /* MOTION_BLUR linear: as zg_motion_blur_linear (the caller's cos / sin of the angle) */
+    uint32_t distance;           /* MOTION_BLUR linear */
+    float center_x, center_y, strength; /* MOTION_BLUR radial */
+    int edges;                   /* EDGES: zg_edges_kind */
+    float low, high;             /* EDGES: canny's low / high threshold, Shen-Castan's low_rel / high_ratio */
+    uint32_t window;             /* EDGES: Shen-Castan's window_size */
+    int use_nms;                 /* EDGES: Shen-Castan's use_nms (hysteresis stays at its default, on, as in the CLI) */
 } zg_step;
 /* Host only: shape and type of the frames after the steps (what dst_frames of zg_batch_pipeline must hold, n_frames times). */
 ZG_API int zg_batch_pipeline_shape(uint32_t rows, uint32_t cols, int pixel, int space, const zg_step *steps, uint32_t n_steps,

@@ -209,7 +209,37 @@ def pipeline_case(rng, kind):
     steps, refs, desc = [], [], []
     cur_kind, r, c = kind, rows, cols
     for _ in range(int(rng.integers(1, 5))):
-        what = str(rng.choice(["blur", "blur", "resize", "resize", "box", "convert", "half"]))
+        what = str(rng.choice(["blur", "blur", "resize", "resize", "box", "convert", "half", "median", "motion", "edges"]))
+        u8_kind = cur_kind in ("u8", "rgb_u8", "rgba_u8")
+        if what == "median" and u8_kind:
+            rad = int(rng.integers(0, 4))
+            steps.append(zg.Step.median_blur(rad)); refs.append(lambda a, rad=rad: o.order_statistic_blur(a, rad, 0, 0.5)); desc.append(f"median{rad}")
+            continue
+        if what == "motion" and u8_kind:
+            if rng.random() < 0.5:
+                ang, dist = float(rng.uniform(-3.2, 3.2)) if rng.random() < 0.7 else 0.0, int(rng.integers(0, 12))
+                cs = o.cos_sin(ang)
+                steps.append(zg.Step.motion_blur_linear(ang, dist, cos_sin=cs)); refs.append(lambda a, ang=ang, dist=dist, cs=cs: o.motion_blur_linear(a, ang, dist, cos_sin=cs)); desc.append(f"motionlin{ang:.3f}:{dist}")
+            else:
+                cx, cy, st, spin = float(rng.uniform(0, 1)), float(rng.uniform(0, 1)), float(rng.uniform(0, 1)), bool(rng.random() < 0.5)
+                steps.append(zg.Step.motion_blur_radial(cx, cy, st, spin)); refs.append(lambda a, cx=cx, cy=cy, st=st, spin=spin: o.motion_blur_radial(a, cx, cy, st, spin)); desc.append(f"motionrad{cx:.2f}:{cy:.2f}:{st:.2f}:{int(spin)}")
+            continue
+        if what == "edges" and u8_kind:
+            space, ch = {"u8": (o.CS_GRAY, 1), "rgb_u8": (o.CS_RGB, 3), "rgba_u8": (o.CS_RGBA, 4)}[cur_kind]
+            which = int(rng.integers(0, 3))
+            if which == 0:
+                step, det, name = zg.Step.edges_sobel(), o.sobel, "sobel"
+            elif which == 1:
+                sg, lo = float(rng.choice([0.8, 1.0, 1.4])), float(rng.uniform(10, 80))
+                hi = lo + float(rng.uniform(0, 120))
+                step, det, name = zg.Step.edges_canny(sg, lo, hi), (lambda g, sg=sg, lo=lo, hi=hi: o.canny(g, sg, lo, hi)), f"canny{sg}:{lo:.1f}:{hi:.1f}"
+            else:
+                nms = bool(rng.random() < 0.5)
+                step, det, name = zg.Step.edges_shen_castan(use_nms=nms), (lambda g, nms=nms: o.shen_castan(g, use_nms=nms)), f"shen{int(nms)}"
+            steps.append(step)
+            refs.append(lambda a, det=det, space=space, ch=ch: o.convert(det(a if ch == 1 else o.convert(a, space, o.CS_GRAY, np.uint8, 1)), o.CS_GRAY, space, np.uint8, ch) if ch != 1 else det(a))
+            desc.append(name)
+            continue
         if what == "blur":
             sigma = float(rng.choice([0.0, 0.3, 0.6, 1.0, 1.4, 2.25]))
             steps.append(zg.Step.gaussian_blur(sigma)); refs.append(lambda a, sigma=sigma: o.gaussian_blur(a, sigma) if sigma > 0 else a.copy()); desc.append(f"blur{sigma}")

@@ -107,3 +107,97 @@ def test_large_batch_goes_through_in_groups(oracle):
     for f in (0, 17, 39):
         want = zg.Image(torch.from_numpy(host[f]).cuda()).gaussian_blur(0.6).resize((540, 960), I.bilinear).gaussian_blur(0.6).to_numpy()
         assert np.array_equal(got[f], want), f
+
+
+def _edges_bridge(oracle, frame, detector):
+    """edges.apply (src/cli/edges.zig:126-135) with the oracle: convert(u8) -> detector -> convert(Rgba(u8)), three separate calls."""
+    grey = oracle.convert(frame, oracle.CS_RGBA, oracle.CS_GRAY, np.uint8, 1)
+    return oracle.convert(detector(grey), oracle.CS_GRAY, oracle.CS_RGBA, np.uint8, 4)
+
+
+def test_the_reference_example_recipe_resize_lanczos_blur_sobel(oracle):
+    """The recipe in the CLI's own help text (src/cli/pipeline.zig:58-67): resize with .lanczos, blur gaussian sigma 2, edges sobel — one
+    zg_batch_pipeline call over the batch against the oracle doing the calls one by one."""
+    host = frames_u8(oracle, 71, 6, 120, 200)
+    steps = [zg.Step.resize(90, 150, I.lanczos), zg.Step.gaussian_blur(2.0), zg.Step.edges_sobel()]
+    got = zg.Pipeline(steps).run(torch.from_numpy(host).cuda())
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    assert got.shape == (6, 90, 150, 4) and got.dtype == np.uint8
+    lan = oracle.method(oracle.LANCZOS)
+    for f in range(host.shape[0]):
+        want = _edges_bridge(oracle, oracle.gaussian_blur(oracle.resize(host[f], (90, 150), lan), 2.0), oracle.sobel)
+        assert np.array_equal(got[f], want), f"frame {f}"
+
+
+def test_the_reference_example_recipe_on_64_frames_of_1080p(oracle):
+    """VERDICT r03 item 4's bar: the same recipe over 64 x 1080p frames (the CLI's --width 800 keeps the aspect: 450 x 800); every
+    frame against the per-frame device calls, a sample of frames against the oracle."""
+    n = 64
+    rng = np.random.default_rng(9)
+    base = frames_u8(oracle, 90, 4, 1080, 1920)
+    host = np.stack([np.roll(base[i % 4], (7 * i, 13 * i), axis=(0, 1)) ^ np.uint8(i) for i in range(n)])
+    steps = [zg.Step.resize(450, 800, I.lanczos), zg.Step.gaussian_blur(2.0), zg.Step.edges_sobel()]
+    dev = torch.from_numpy(host).cuda()
+    got = zg.Pipeline(steps).run(dev)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    grey = lambda im: im.resize((450, 800), I.lanczos).gaussian_blur(2.0).convert(zg.CS_GRAY, np.uint8).sobel().convert(zg.CS_RGBA, np.uint8, src_space=zg.CS_GRAY)
+    for f in range(n):
+        want = grey(zg.Image(dev[f])).to_numpy()
+        assert np.array_equal(got[f], want), f"frame {f} differs from the per-frame calls"
+    lan = oracle.method(oracle.LANCZOS)
+    for f in (0, 17, 63):
+        want = _edges_bridge(oracle, oracle.gaussian_blur(oracle.resize(host[f], (450, 800), lan), 2.0), oracle.sobel)
+        assert np.array_equal(got[f], want), f"frame {f} differs from the oracle"
+
+
+def test_every_blur_type_and_edge_detector_of_the_cli_as_a_step(oracle):
+    """blur: box, gaussian, median, motion_linear, motion_zoom, motion_spin (src/cli/blur.zig:98-170); edges: sobel, canny, shen_castan
+    through the grey bridge (src/cli/edges.zig:85-135) — each as one step over a batch, against the oracle per frame."""
+    host = frames_u8(oracle, 23, 3, 72, 104)
+    cs = oracle.cos_sin(0.6)  # one pair for both sides: the angle's cos / sin are the caller's (a Zig host brings Zig's)
+    cases = [
+        ("median r=1", zg.Step.median_blur(1), lambda a: oracle.order_statistic_blur(a, 1, 0, 0.5)),
+        ("median r=2", zg.Step.median_blur(2), lambda a: oracle.order_statistic_blur(a, 2, 0, 0.5)),
+        ("motion linear", zg.Step.motion_blur_linear(0.6, 7, cos_sin=cs), lambda a: oracle.motion_blur_linear(a, 0.6, 7, cos_sin=cs)),
+        ("motion linear axis", zg.Step.motion_blur_linear(0.0, 9, cos_sin=(1.0, 0.0)), lambda a: oracle.motion_blur_linear(a, 0.0, 9, cos_sin=(1.0, 0.0))),
+        ("motion zoom", zg.Step.motion_blur_radial(0.4, 0.6, 0.5), lambda a: oracle.motion_blur_radial(a, 0.4, 0.6, 0.5, False)),
+        ("motion spin", zg.Step.motion_blur_radial(0.5, 0.5, 0.3, spin=True), lambda a: oracle.motion_blur_radial(a, 0.5, 0.5, 0.3, True)),
+        ("sobel", zg.Step.edges_sobel(), lambda a: _edges_bridge(oracle, a, oracle.sobel)),
+        ("canny", zg.Step.edges_canny(1.0, 50.0, 100.0), lambda a: _edges_bridge(oracle, a, lambda g: oracle.canny(g, 1.0, 50.0, 100.0))),
+        ("shen-castan", zg.Step.edges_shen_castan(), lambda a: _edges_bridge(oracle, a, oracle.shen_castan)),
+        ("shen-castan nms", zg.Step.edges_shen_castan(0.8, 9, 0.95, 0.4, True), lambda a: _edges_bridge(oracle, a, lambda g: oracle.shen_castan(g, 0.8, 9, 0.95, 0.4, True, True))),
+    ]
+    dev = torch.from_numpy(host).cuda()
+    for what, step, ref in cases:
+        got = zg.Pipeline([step]).run(dev)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        assert got.shape == host.shape and got.dtype == np.uint8, what
+        for f in range(host.shape[0]):
+            assert np.array_equal(got[f], ref(host[f])), f"{what}: frame {f}"
+    # grey and Rgb frames keep their type through the bridge; an edges step in the middle of a recipe
+    grey = frames_u8(oracle, 31, 2, 64, 96, ch=1)
+    got = zg.Pipeline([zg.Step.edges_sobel()]).run(torch.from_numpy(grey).cuda()).cpu().numpy()
+    for f in range(2):
+        assert np.array_equal(got[f], oracle.sobel(grey[f]))
+    got = zg.Pipeline([zg.Step.gaussian_blur(1.0), zg.Step.edges_canny(1.4, 40.0, 120.0), zg.Step.resize(36, 52)]).run(dev).cpu().numpy()
+    bil = oracle.method(oracle.BILINEAR)
+    for f in range(host.shape[0]):
+        want = oracle.resize(_edges_bridge(oracle, oracle.gaussian_blur(host[f], 1.0), lambda g: oracle.canny(g, 1.4, 40.0, 120.0)), (36, 52), bil)
+        assert np.array_equal(got[f], want), f"[blur, canny, resize]: frame {f}"
+
+
+def test_new_steps_are_validated_before_anything_runs():
+    dev = torch.zeros((2, 32, 32, 4), dtype=torch.uint8, device="cuda")
+    bad = zg.Step.edges_sobel()
+    bad.c.edges = 7
+    with pytest.raises(zg.InvalidArgument):
+        zg.Pipeline([zg.Step.gaussian_blur(1.0), bad]).run(dev)
+    bad = zg.Step.motion_blur_radial()
+    bad.c.motion = -1
+    with pytest.raises(zg.InvalidArgument):
+        zg.Pipeline([bad]).run(dev)
+    with pytest.raises(zg.InvalidArgument):
+        zg.Pipeline([zg.Step.median_blur(300)]).run(dev)

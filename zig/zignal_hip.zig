@@ -26,7 +26,60 @@ pub const Pipeline = struct {
     steps: []const c.ZgStep,
 
     pub fn gaussianBlur(sigma: f32) c.ZgStep {
-        return .{ .kind = 0, .sigma = sigma, .radius = 0, .out_rows = 0, .out_cols = 0, .method = .{ .kind = 0, .b = 0, .c = 0, .lanczos_lut = null }, .dst_pixel = 0, .dst_space = 0, .srgb_lut = null, .transform = 0, .m = [_]f32{0} ** 9 };
+        return .{ .kind = 0, .sigma = sigma, .radius = 0, .out_rows = 0, .out_cols = 0, .method = .{ .kind = 0, .b = 0, .c = 0, .lanczos_lut = null }, .dst_pixel = 0, .dst_space = 0, .srgb_lut = null, .transform = 0, .m = [_]f32{0} ** 9, .motion = 0, .angle = 0, .cos_a = 1, .sin_a = 0, .distance = 0, .center_x = 0.5, .center_y = 0.5, .strength = 0.5, .edges = 0, .low = 0, .high = 0, .window = 7, .use_nms = 0 };
+    }
+    /// blur --type median (src/cli/blur.zig:116-123)
+    pub fn medianBlur(radius: u32) c.ZgStep {
+        var s = gaussianBlur(0);
+        s.kind = 5;
+        s.radius = radius;
+        return s;
+    }
+    /// blur --type motion_linear (src/cli/blur.zig:124-146): angle in radians; the cosine and sine are Zig's own
+    pub fn motionBlurLinear(angle: f32, distance: u32) c.ZgStep {
+        var s = gaussianBlur(0);
+        s.kind = 6;
+        s.motion = 0;
+        s.angle = angle;
+        s.cos_a = @cos(angle);
+        s.sin_a = @sin(angle);
+        s.distance = distance;
+        return s;
+    }
+    /// blur --type motion_zoom / motion_spin (src/cli/blur.zig:147-170)
+    pub fn motionBlurRadial(center_x: f32, center_y: f32, strength: f32, spin: bool) c.ZgStep {
+        var s = gaussianBlur(0);
+        s.kind = 6;
+        s.motion = if (spin) 2 else 1;
+        s.center_x = center_x;
+        s.center_y = center_y;
+        s.strength = strength;
+        return s;
+    }
+    /// edges --filter sobel through edges.apply's grey bridge (src/cli/edges.zig:126-135); the frames keep their type
+    pub fn edgesSobel() c.ZgStep {
+        var s = gaussianBlur(0);
+        s.kind = 7;
+        s.edges = 0;
+        return s;
+    }
+    pub fn edgesCanny(sigma: f32, low: f32, high: f32) c.ZgStep {
+        var s = gaussianBlur(sigma);
+        s.kind = 7;
+        s.edges = 1;
+        s.low = low;
+        s.high = high;
+        return s;
+    }
+    pub fn edgesShenCastan(opts: zignal.ShenCastan) c.ZgStep {
+        var s = gaussianBlur(opts.smooth);
+        s.kind = 7;
+        s.edges = 2;
+        s.window = @intCast(opts.window_size);
+        s.high = opts.high_ratio;
+        s.low = opts.low_rel;
+        s.use_nms = @intFromBool(opts.use_nms);
+        return s;
     }
     pub fn boxBlur(radius: u32) c.ZgStep {
         var s = gaussianBlur(0);
@@ -66,8 +119,8 @@ pub const Pipeline = struct {
 pub const c = struct {
     pub const ZgImage = extern struct { data: ?*anyopaque, stride: usize, rows: u32, cols: u32, pixel: i32 };
     pub const ZgMethod = extern struct { kind: i32, b: f32, c: f32, lanczos_lut: ?[*]const f32 };
-    /// zg_step: one step of zg_batch_pipeline (kind: 0 gaussian blur, 1 box blur, 2 resize, 3 convert, 4 warp)
-    pub const ZgStep = extern struct { kind: c_int, sigma: f32, radius: u32, out_rows: u32, out_cols: u32, method: ZgMethod, dst_pixel: c_int, dst_space: c_int, srgb_lut: ?[*]const f32, transform: c_int, m: [9]f32 };
+    /// zg_step: one step of zg_batch_pipeline (kind: 0 gaussian blur, 1 box blur, 2 resize, 3 convert, 4 warp, 5 median blur, 6 motion blur, 7 edges)
+    pub const ZgStep = extern struct { kind: c_int, sigma: f32, radius: u32, out_rows: u32, out_cols: u32, method: ZgMethod, dst_pixel: c_int, dst_space: c_int, srgb_lut: ?[*]const f32, transform: c_int, m: [9]f32, motion: c_int, angle: f32, cos_a: f32, sin_a: f32, distance: u32, center_x: f32, center_y: f32, strength: f32, edges: c_int, low: f32, high: f32, window: u32, use_nms: c_int };
     pub extern fn zg_init(device: c_int) c_int;
     pub extern fn zg_last_error() [*:0]const u8;
     pub extern fn zg_conv_separable_host(src: *const ZgImage, dst: *const ZgImage, kx: [*]const f32, nkx: u32, ky: [*]const f32, nky: u32, border: c_int) c_int;

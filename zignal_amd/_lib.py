@@ -34,10 +34,14 @@ class ZgStep(C.Structure):
     """zg_step: one step of zg_batch_pipeline (the CLI's `pipeline` recipe steps, src/cli/pipeline.zig:20-24, plus convert and warp)."""
     _fields_ = [("kind", C.c_int), ("sigma", C.c_float), ("radius", C.c_uint32), ("out_rows", C.c_uint32), ("out_cols", C.c_uint32),
                 ("method", ZgMethod), ("dst_pixel", C.c_int), ("dst_space", C.c_int), ("srgb_lut", C.c_void_p), ("transform", C.c_int),
-                ("m", C.c_float * 9)]
+                ("m", C.c_float * 9), ("motion", C.c_int), ("angle", C.c_float), ("cos_a", C.c_float), ("sin_a", C.c_float), ("distance", C.c_uint32),
+                ("center_x", C.c_float), ("center_y", C.c_float), ("strength", C.c_float), ("edges", C.c_int), ("low", C.c_float), ("high", C.c_float),
+                ("window", C.c_uint32), ("use_nms", C.c_int)]
 
 
-STEP_GAUSSIAN_BLUR, STEP_BOX_BLUR, STEP_RESIZE, STEP_CONVERT, STEP_WARP = range(5)
+STEP_GAUSSIAN_BLUR, STEP_BOX_BLUR, STEP_RESIZE, STEP_CONVERT, STEP_WARP, STEP_MEDIAN_BLUR, STEP_MOTION_BLUR, STEP_EDGES = range(8)
+MOTION_LINEAR, MOTION_RADIAL_ZOOM, MOTION_RADIAL_SPIN = range(3)
+EDGES_SOBEL, EDGES_CANNY, EDGES_SHEN_CASTAN = range(3)
 
 
 class ZgPngHeader(C.Structure):

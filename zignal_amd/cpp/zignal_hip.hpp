@@ -466,6 +466,24 @@ struct Pipeline {
     std::vector<zg_step> steps;
     Pipeline &gaussianBlur(float sigma) { zg_step s{}; s.kind = ZG_STEP_GAUSSIAN_BLUR; s.sigma = sigma; steps.push_back(s); return *this; }              // cli/blur.zig:113-120
     Pipeline &boxBlur(uint32_t radius) { zg_step s{}; s.kind = ZG_STEP_BOX_BLUR; s.radius = radius; steps.push_back(s); return *this; }                  // cli/blur.zig:109-112
+    Pipeline &medianBlur(uint32_t radius = 1) { zg_step s{}; s.kind = ZG_STEP_MEDIAN_BLUR; s.radius = radius; steps.push_back(s); return *this; }          // cli/blur.zig:116-123
+    // cli/blur.zig:124-146; the angle is in radians, cos_a / sin_a are the caller's own cosine and sine of it (as in Image::motionBlurLinear)
+    Pipeline &motionBlurLinear(float angle, float cos_a, float sin_a, uint32_t distance) {
+        zg_step s{}; s.kind = ZG_STEP_MOTION_BLUR; s.motion = ZG_MOTION_LINEAR; s.angle = angle; s.cos_a = cos_a; s.sin_a = sin_a; s.distance = distance; steps.push_back(s); return *this;
+    }
+    Pipeline &motionBlurRadial(float center_x = 0.5f, float center_y = 0.5f, float strength = 0.5f, bool spin = false) {                             // cli/blur.zig:147-170
+        zg_step s{}; s.kind = ZG_STEP_MOTION_BLUR; s.motion = spin ? ZG_MOTION_RADIAL_SPIN : ZG_MOTION_RADIAL_ZOOM;
+        s.center_x = center_x; s.center_y = center_y; s.strength = strength; steps.push_back(s); return *this;
+    }
+    // edges.apply (cli/edges.zig:126-135): convert(u8) -> detector -> convert back; the frames keep their type
+    Pipeline &edgesSobel() { zg_step s{}; s.kind = ZG_STEP_EDGES; s.edges = ZG_EDGES_SOBEL; steps.push_back(s); return *this; }
+    Pipeline &edgesCanny(float sigma = 1.0f, float low = 50.0f, float high = 100.0f) {                                                                // cli/edges.zig:98-104
+        zg_step s{}; s.kind = ZG_STEP_EDGES; s.edges = ZG_EDGES_CANNY; s.sigma = sigma; s.low = low; s.high = high; steps.push_back(s); return *this;
+    }
+    Pipeline &edgesShenCastan(float smooth = 0.9f, uint32_t window_size = 7, float high_ratio = 0.99f, float low_rel = 0.5f, bool use_nms = false) { // cli/edges.zig:105-118
+        zg_step s{}; s.kind = ZG_STEP_EDGES; s.edges = ZG_EDGES_SHEN_CASTAN; s.sigma = smooth; s.window = window_size; s.high = high_ratio; s.low = low_rel; s.use_nms = use_nms;
+        steps.push_back(s); return *this;
+    }
     Pipeline &resize(uint32_t rows, uint32_t cols, Interpolation method = Interpolation::bilinear()) {                                                // cli/resize.zig:77-99
         zg_step s{}; s.kind = ZG_STEP_RESIZE; s.out_rows = rows; s.out_cols = cols; s.method = method.c_method(); steps.push_back(s); return *this;
     }

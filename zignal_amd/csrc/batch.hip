@@ -58,6 +58,15 @@ int apply_shape(const zg_step &st, Frames &f) { // what a step does to shape and
         ZG_REQUIRE(st.sigma >= 0, ZG_ERR_INVALID_ARGUMENT, "pipeline: InvalidSigma (%g)", st.sigma);
         return ZG_OK;
     case ZG_STEP_BOX_BLUR: return ZG_OK;
+    case ZG_STEP_MEDIAN_BLUR: // the CLI's own limit (src/cli/blur.zig:118-121); the kernel's is lower and reported when the step runs
+        ZG_REQUIRE(st.radius <= 256, ZG_ERR_INVALID_ARGUMENT, "pipeline: median blur radius %u exceeds 256", st.radius);
+        return ZG_OK;
+    case ZG_STEP_MOTION_BLUR:
+        ZG_REQUIRE(st.motion >= ZG_MOTION_LINEAR && st.motion <= ZG_MOTION_RADIAL_SPIN, ZG_ERR_INVALID_ARGUMENT, "pipeline: invalid motion blur kind %d", st.motion);
+        return ZG_OK;
+    case ZG_STEP_EDGES:
+        ZG_REQUIRE(st.edges >= ZG_EDGES_SOBEL && st.edges <= ZG_EDGES_SHEN_CASTAN, ZG_ERR_INVALID_ARGUMENT, "pipeline: invalid edge detector %d", st.edges);
+        return ZG_OK;
     case ZG_STEP_RESIZE:
     case ZG_STEP_WARP:
         ZG_REQUIRE(st.method.kind >= ZG_INTERP_NEAREST && st.method.kind <= ZG_INTERP_LANCZOS, ZG_ERR_INVALID_ARGUMENT, "pipeline: invalid interpolation method %d", st.method.kind);
@@ -116,6 +125,37 @@ int run_convert(const Frames &in, const Frames &out, const float *lut, hipStream
         return convert_impl(&a, in.space, &b, out.space, lut, s);
     }
     return per_frame(in, out, [&](const zg_image *a, const zg_image *b) { return convert_impl(a, in.space, b, out.space, lut, s); });
+}
+
+// The CLI's edges step (src/cli/edges.zig:126-135): gray = frame.convert(u8); detector(gray) -> Image(u8); .convert(frame type). The
+// detectors take any pixel type and start with that very conversion per pixel (edges.zig:36-45: as(f32, convertColor(u8, px))), so they
+// read the frames directly; the edge maps of the whole batch go to one grey scratch plane and come back through ONE conversion launch.
+int run_edges(const zg_step &st, const Frames &in, const Frames &out, hipStream_t s) {
+    void *grey = nullptr;
+    const size_t plane = (size_t)in.rows * in.cols;
+    if (const int rc = scratch_alloc(&grey, plane * in.n, s)) return rc;
+    const Frames g{grey, in.n, in.rows, in.cols, ZG_PIXEL_U8, ZG_CS_GRAY};
+    int rc = -1;
+    if (st.edges == ZG_EDGES_SOBEL && in.n > 0) {
+        const zg_image a = in.frame(0), b = g.frame(0);
+        rc = sobel_frames(&a, &b, in.n, in.frame_bytes(), plane, s); // one launch over the batch
+    }
+    if (rc == -1)
+        rc = per_frame(in, g, [&](const zg_image *a, const zg_image *b) {
+            if (st.edges == ZG_EDGES_SOBEL) return zg_sobel(a, b, (zg_stream)s);
+            if (st.edges == ZG_EDGES_CANNY) return zg_canny(a, b, st.sigma, st.low, st.high, (zg_stream)s);
+            return zg_shen_castan(a, b, st.sigma, st.window, st.high, st.low, 1, st.use_nms, (zg_stream)s);
+        });
+    if (rc == ZG_OK) rc = run_convert(g, out, nullptr, s);
+    scratch_free(grey, s);
+    return rc;
+}
+
+int run_motion(const zg_step &st, const Frames &in, const Frames &out, hipStream_t s) {
+    return per_frame(in, out, [&](const zg_image *a, const zg_image *b) {
+        if (st.motion == ZG_MOTION_LINEAR) return zg_motion_blur_linear(a, b, st.angle, st.cos_a, st.sin_a, st.distance, (zg_stream)s);
+        return zg_motion_blur_radial(a, b, st.center_x, st.center_y, st.strength, st.motion == ZG_MOTION_RADIAL_SPIN, (zg_stream)s);
+    });
 }
 
 // steps [i, i + 2) as one fused launch over the batch, or -1
@@ -177,8 +217,6 @@ int zg_batch_pipeline(const void *src_frames, uint32_t n_frames, uint32_t rows, 
         ZG_HIP(hipMemcpyAsync(dst_frames, src_frames, (size_t)n_frames * shape[0].frame_bytes(), hipMemcpyDeviceToDevice, s));
         return ZG_OK;
     }
-    // which steps run fused with their successor
-    std::vector<char> fused_with_next(n_steps, 0);
     // Frames go through in groups: two ping-pong scratch blocks of at most ~1 GiB each hold a group's intermediates (a 1024-frame
     // 1080p batch has 8.5 GB of them; nothing is gained by keeping more than a chip-filling group in flight).
     const size_t budget = (size_t)1 << 30;
@@ -220,6 +258,11 @@ int zg_batch_pipeline(const void *src_frames, uint32_t n_frames, uint32_t rows, 
                 case ZG_STEP_BOX_BLUR: rc = per_frame(cur, next, [&](const zg_image *a, const zg_image *b) { return zg_box_blur(a, b, st.radius, stream); }); break;
                 case ZG_STEP_RESIZE: rc = run_resize(cur, next, st.method, s); break;
                 case ZG_STEP_CONVERT: rc = run_convert(cur, next, st.srgb_lut, s); break;
+                case ZG_STEP_MEDIAN_BLUR:
+                    rc = per_frame(cur, next, [&](const zg_image *a, const zg_image *b) { return zg_order_statistic_blur(a, b, st.radius, 0, 0.5, ZG_BORDER_MIRROR, stream); });
+                    break;
+                case ZG_STEP_MOTION_BLUR: rc = run_motion(st, cur, next, s); break;
+                case ZG_STEP_EDGES: rc = run_edges(st, cur, next, s); break;
                 default: { // warp: the same map for every frame, one launch
                     const zg_image a = cur.frame(0), b = next.frame(0);
                     rc = warp_frames(&a, &b, st.transform, st.m, &st.method, gn, cur.frame_bytes(), next.frame_bytes(), s);

@@ -43,11 +43,13 @@ __device__ inline void sobel_3x3(const float (&p)[3][3], float &gx, float &gy) {
 // four consecutive rows of one column, whose windows share six rows of three values; output bytes leave as dwords through LDS.
 // (Round 1: 64 x 4 tile, nine clamped taps per pixel, byte stores: 67 us per 4096^2 Rgba(u8) frame.)
 template <int PIX>
-__global__ __launch_bounds__(256) void k_sobel(DImg src, DImg dst, int tiles_x) {
+__global__ __launch_bounds__(256) void k_sobel(DImg src, DImg dst, int tiles_x, FrameSpan fr) {
     using P = Px<PIX>;
     constexpr int TH = 16;
     __shared__ float g[TH + 2][68];
     __shared__ uint8_t ob[TH][64];
+    src.data = (char *)src.data + (size_t)blockIdx.y * fr.src_frame; // a batch of equally shaped frames (zg_batch_pipeline's edges step)
+    dst.data = (char *)dst.data + (size_t)blockIdx.y * fr.dst_frame;
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
     if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void k_sobel(DImg src, DImg dst, int tiles_x) 
     }
 }
 
-static int sobel_impl(const zg_image *src, const zg_image *dst, hipStream_t s) {
+static int sobel_impl(const zg_image *src, const zg_image *dst, hipStream_t s, uint32_t n = 1, size_t src_frame = 0, size_t dst_frame = 0) {
     int rc;
     if ((rc = check_image(src, "src")) || (rc = check_image(dst, "dst"))) return rc;
     ZG_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, ZG_ERR_DIMENSION_MISMATCH, "sobel: %ux%u vs %ux%u",
@@ -99,12 +101,18 @@ static int sobel_impl(const zg_image *src, const zg_image *dst, hipStream_t s) {
     ZG_REQUIRE(dst->pixel == ZG_PIXEL_U8, ZG_ERR_INVALID_ARGUMENT, "sobel: the output is Image(u8)");
     if (src->rows == 0 || src->cols == 0) return ZG_OK;
     const int tiles_x = (int)ceil_div(src->cols, 64), tiles_y = (int)ceil_div(src->rows, 16);
+    if (n > MAX_FRAMES_PER_LAUNCH) return -1; // the caller goes frame by frame
+    const FrameSpan fr{src_frame, dst_frame};
     return dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
-        hipLaunchKernelGGL((k_sobel<PIX>), dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, dimg(src), dimg(dst), tiles_x);
+        hipLaunchKernelGGL((k_sobel<PIX>), dim3((unsigned)(tiles_x * tiles_y), n), dim3(256), 0, s, dimg(src), dimg(dst), tiles_x, fr);
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     });
+}
+// Image.sobel of n equally shaped frames in one launch (-1: too many frames for one grid)
+int sobel_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s) {
+    return sobel_impl(src, dst, s, n, src_frame, dst_frame);
 }
 
 

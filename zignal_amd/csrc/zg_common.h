@@ -206,6 +206,7 @@ int resize_bilinear_rgba8_frames(const zg_image *src, const zg_image *dst, uint3
 int resize_frames(const zg_image *src, const zg_image *dst, const zg_method *method, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s);       // geom.hip
 int warp_frames(const zg_image *src, const zg_image *dst, int kind, const float *mat, const zg_method *method, uint32_t n, size_t src_frame, size_t dst_frame,
                 hipStream_t s);                                                                                                                        // geom.hip
+int sobel_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s);                                        // edges.hip
 int resize_convert_rgba8_frames(const zg_image *src, const zg_image *dst, int dst_space, uint32_t n, size_t src_frame, size_t dst_frame, const float *srgb_lut,
                                 hipStream_t s);                                                                                                       // convert.hip
 

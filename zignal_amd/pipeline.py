@@ -22,7 +22,8 @@ _LAYOUT_BY_PIXEL = {v: k for k, v in _PIXEL_BY_LAYOUT.items()}
 
 
 class Step:
-    """One recipe step; the constructors mirror the CLI's step options (blur: src/cli/blur.zig, resize: src/cli/resize.zig)."""
+    """One recipe step; the constructors mirror the CLI's step options (resize: src/cli/resize.zig; blur with its six types:
+    src/cli/blur.zig:98-170; edges with its three detectors: src/cli/edges.zig:85-135) plus convert and warp."""
 
     def __init__(self, c_step: L.ZgStep, keep=None):
         self.c = c_step
@@ -38,6 +39,50 @@ class Step:
     def box_blur(radius: int) -> "Step":
         s = L.ZgStep()
         s.kind, s.radius = L.STEP_BOX_BLUR, int(radius)
+        return Step(s)
+
+    @staticmethod
+    def median_blur(radius: int = 1) -> "Step":
+        """blur --type median (blur.zig:116-123): Image.medianBlur(radius)."""
+        s = L.ZgStep()
+        s.kind, s.radius = L.STEP_MEDIAN_BLUR, int(radius)
+        return Step(s)
+
+    @staticmethod
+    def motion_blur_linear(angle: float = 0.0, distance: int = 10, cos_sin=None) -> "Step":
+        """blur --type motion_linear (blur.zig:124-146): Image.motionBlur(.{ .linear = .{ .angle (radians), .distance } }). cos_sin: the host's
+        own (cos, sin) of the angle, as in Image.motion_blur_linear."""
+        from .image import _cos_sin
+        ca, sa = cos_sin if cos_sin is not None else _cos_sin(angle)
+        s = L.ZgStep()
+        s.kind, s.motion, s.angle, s.cos_a, s.sin_a, s.distance = L.STEP_MOTION_BLUR, L.MOTION_LINEAR, float(angle), float(ca), float(sa), int(distance)
+        return Step(s)
+
+    @staticmethod
+    def motion_blur_radial(center_x: float = 0.5, center_y: float = 0.5, strength: float = 0.5, spin: bool = False) -> "Step":
+        """blur --type motion_zoom / motion_spin (blur.zig:147-170)."""
+        s = L.ZgStep()
+        s.kind, s.motion = L.STEP_MOTION_BLUR, (L.MOTION_RADIAL_SPIN if spin else L.MOTION_RADIAL_ZOOM)
+        s.center_x, s.center_y, s.strength = float(center_x), float(center_y), float(strength)
+        return Step(s)
+
+    @staticmethod
+    def edges_sobel() -> "Step":
+        """edges --filter sobel through the pipeline's grey bridge (edges.zig:126-135): the frames keep their type."""
+        s = L.ZgStep()
+        s.kind, s.edges = L.STEP_EDGES, L.EDGES_SOBEL
+        return Step(s)
+
+    @staticmethod
+    def edges_canny(sigma: float = 1.0, low: float = 50.0, high: float = 100.0) -> "Step":
+        s = L.ZgStep()
+        s.kind, s.edges, s.sigma, s.low, s.high = L.STEP_EDGES, L.EDGES_CANNY, float(sigma), float(low), float(high)
+        return Step(s)
+
+    @staticmethod
+    def edges_shen_castan(smooth: float = 0.9, window_size: int = 7, high_ratio: float = 0.99, low_rel: float = 0.5, use_nms: bool = False) -> "Step":
+        s = L.ZgStep()
+        s.kind, s.edges, s.sigma, s.window, s.high, s.low, s.use_nms = L.STEP_EDGES, L.EDGES_SHEN_CASTAN, float(smooth), int(window_size), float(high_ratio), float(low_rel), int(bool(use_nms))
         return Step(s)
 
     @staticmethod
