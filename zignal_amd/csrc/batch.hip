@@ -217,9 +217,10 @@ int zg_batch_pipeline(const void *src_frames, uint32_t n_frames, uint32_t rows, 
         ZG_HIP(hipMemcpyAsync(dst_frames, src_frames, (size_t)n_frames * shape[0].frame_bytes(), hipMemcpyDeviceToDevice, s));
         return ZG_OK;
     }
-    // Frames go through in groups: two ping-pong scratch blocks of at most ~1 GiB each hold a group's intermediates (a 1024-frame
-    // 1080p batch has 8.5 GB of them; nothing is gained by keeping more than a chip-filling group in flight).
-    const size_t budget = (size_t)1 << 30;
+    // Frames go through in groups: two ping-pong scratch blocks hold a group's intermediates (a 1024-frame 1080p batch has 8.5 GB of
+    // them; nothing is gained by keeping more than a chip-filling group in flight). A block takes at most a quarter of the scratch
+    // cache (512 MiB by default), so both stay cached from call to call beside whatever else lives there.
+    const size_t budget = std::min<size_t>((size_t)1 << 30, scratch_block_budget());
     const uint32_t group = widest ? (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, budget / widest)) : n_frames;
     void *ping[2] = {nullptr, nullptr};
     int rc = ZG_OK;

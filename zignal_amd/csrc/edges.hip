@@ -9,6 +9,7 @@
 #include "zg_hostmath.h"
 
 #include <cmath>
+#include <map>
 #include <vector>
 
 #pragma clang fp contract(off)
@@ -1170,20 +1171,33 @@ int zg_pyramid_build_level(const zg_image *source, const zg_image *level, float 
 extern "C++" {
 namespace {
 struct LevelStreams {
-    int device = -1;
     hipStream_t s[3] = {nullptr, nullptr, nullptr};
 };
+// The helper streams the levels fork over: per thread (a stream can sit in one capture at a time, so two threads recording pyramids must not
+// share them) and per device, created the first time a build on that device wants to fork, destroyed when the thread ends. A stream that
+// cannot be created leaves its lane out (the build then forks over fewer lanes, or not at all): forking is an optimisation.
+struct LevelStreamPool {
+    std::map<int, LevelStreams> by_device;
+    ~LevelStreamPool() {
+        for (auto &kv : by_device)
+            for (hipStream_t st : kv.second.s)
+                if (st) (void)hipStreamDestroy(st);
+    }
+};
 LevelStreams &level_streams() {
-    static thread_local LevelStreams pool[16];
+    static thread_local LevelStreamPool pool;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    LevelStreams &p = pool[dev & 15];
-    if (p.device != dev) {
-        for (hipStream_t &st : p.s)
+    auto it = pool.by_device.find(dev);
+    if (it == pool.by_device.end()) {
+        it = pool.by_device.emplace(dev, LevelStreams{}).first;
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed; // creating a stream is an "unsafe" call while a capture is in progress
+        const bool swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+        for (hipStream_t &st : it->second.s)
             if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }
-        p.device = dev;
+        if (swapped) (void)hipThreadExchangeStreamCaptureMode(&mode);
     }
-    return p;
+    return it->second;
 }
 } // namespace
 } // extern "C++"
@@ -1192,18 +1206,20 @@ int zg_pyramid_build(const zg_image *source, const zg_image *levels, const float
     ZG_REQUIRE(source && (n_levels == 0 || (levels && sigmas)), ZG_ERR_INVALID_ARGUMENT, "pyramid build: null argument");
     if (n_levels == 0) return ZG_OK;
     hipStream_t main = as_stream(stream);
-    LevelStreams &pool = level_streams();
-    hipStream_t lanes[4] = {main, pool.s[0], pool.s[1], pool.s[2]};
-    int n_lanes = 1;
-    for (int i = 1; i < 4 && lanes[i]; ++i) n_lanes = i + 1;
     // Forking pays when the device is the bottleneck — a graph replay: 445 us on one stream, 351 us on four for ORB's default pyramid of
     // a 4096^2 plane — and costs when the host is (eager launches: 508 us on one stream, 661 us on four: every cross-stream hand-off
     // is host work). So the levels fork under stream capture and stay on `stream` otherwise. ZIGNAL_HIP_PYRAMID_LANES overrides.
     static const int lane_env = [] { const char *e = getenv("ZIGNAL_HIP_PYRAMID_LANES"); return e ? std::max(1, std::min(4, atoi(e))) : 0; }();
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(main, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusNone; }
-    n_lanes = std::min(n_lanes, lane_env ? lane_env : (capturing == hipStreamCaptureStatusActive ? 4 : 1));
-    if (n_levels < (uint32_t)n_lanes) n_lanes = (int)n_levels;
+    int want = lane_env ? lane_env : (capturing == hipStreamCaptureStatusActive ? 4 : 1);
+    if (n_levels < (uint32_t)want) want = (int)n_levels;
+    hipStream_t lanes[4] = {main, nullptr, nullptr, nullptr};
+    int n_lanes = 1;
+    if (want > 1) { // the pool is only touched (and its streams only created) by a build that forks
+        const LevelStreams &pool = level_streams();
+        for (int i = 1; i < want && pool.s[i - 1]; ++i) { lanes[i] = pool.s[i - 1]; n_lanes = i + 1; }
+    }
     hipEvent_t fork = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
     int rc = ZG_OK;
     auto hip = [&](hipError_t e, const char *what) {

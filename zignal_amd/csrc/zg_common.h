@@ -228,5 +228,6 @@ int try_sep_mfma(const StreamJob &j, const int32_t *ix, const int32_t *iy, int n
 int scratch_alloc(void **out, size_t bytes, hipStream_t s);
 int host_threads(); // ZIGNAL_HIP_HOST_THREADS, else min(16, hardware threads)
 void scratch_free(void *p, hipStream_t s);
+size_t scratch_block_budget(); // bytes one long-lived scratch block may take so that a few of them stay cached (a quarter of the cache limit)
 
 } // namespace zg

@@ -95,7 +95,8 @@ size_t scratch_cache_limit() {
     }();
     return limit;
 }
-void release_blocks(std::vector<CachedBlock> &drop) {
+void release_blocks(std::vector<CachedBlock> &drop); // defined below RelaxedCapture
+void release_blocks_impl(std::vector<CachedBlock> &drop) {
     for (const CachedBlock &b : drop) {
         (void)hipEventSynchronize(b.done);
         (void)hipEventDestroy(b.done);
@@ -126,6 +127,28 @@ struct RelaxedCapture { // allocation calls are "unsafe" while ANY thread captur
     RelaxedCapture() { if (hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) (void)hipGetLastError(); }
     ~RelaxedCapture() { if (hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) (void)hipGetLastError(); }
 };
+// hipEventSynchronize / hipFree are "unsafe" calls while another thread captures in global mode: relaxed for the duration
+void release_blocks(std::vector<CachedBlock> &drop) {
+    if (drop.empty()) return;
+    RelaxedCapture relaxed;
+    release_blocks_impl(drop);
+}
+// Oldest idle blocks out until the cache holds at most `limit` bytes and 64 blocks. Called where the caller is about to pay a
+// hipMalloc anyway (a cache miss) and from scratch_free only past TWICE the limit: freeing is a device-wide synchronisation, and a
+// steady state whose working set sits a little above the limit (the pipeline's two ping-pong blocks plus a table) must not pay one
+// per call.
+void evict_down_to(size_t limit) {
+    std::vector<CachedBlock> evict;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        while (!g_scratch_free.empty() && (g_scratch_free.size() > 64 || g_scratch_cached_bytes > limit)) {
+            evict.push_back(g_scratch_free.front());
+            g_scratch_cached_bytes -= g_scratch_free.front().bytes;
+            g_scratch_free.erase(g_scratch_free.begin());
+        }
+    }
+    release_blocks(evict);
+}
 size_t scratch_round(size_t bytes) {
     const size_t unit = (size_t)1 << 20;
     return (bytes + unit - 1) / unit * unit + (bytes == 0 ? unit : 0);
@@ -182,6 +205,7 @@ int scratch_alloc(void **out, size_t bytes, hipStream_t s) {
         if (e != hipSuccess) (void)hipEventSynchronize(take.done); // still ordered, just not asynchronously
         (void)hipEventDestroy(take.done);
     } else {
+        evict_down_to(scratch_cache_limit() > need ? scratch_cache_limit() - need : 0); // make room for the block this call will bring back
         hipError_t e = hipMalloc(&take.p, need);
         if (e == hipErrorOutOfMemory) { // give the cache back to the driver and try once more
             (void)hipGetLastError();
@@ -221,19 +245,18 @@ void scratch_free(void *p, hipStream_t s) {
         (void)hipFree(p);
         return;
     }
-    std::vector<CachedBlock> evict; // oldest first, until the cache is back under its byte and block limits
+    bool far_over;
     {
         std::lock_guard<std::mutex> lock(g_scratch_mu);
         g_scratch_free.push_back(b);
         g_scratch_cached_bytes += b.bytes;
-        while (!g_scratch_free.empty() && (g_scratch_free.size() > 64 || g_scratch_cached_bytes > scratch_cache_limit())) {
-            evict.push_back(g_scratch_free.front());
-            g_scratch_cached_bytes -= g_scratch_free.front().bytes;
-            g_scratch_free.erase(g_scratch_free.begin());
-        }
+        far_over = g_scratch_free.size() > 64 || g_scratch_cached_bytes > 2 * scratch_cache_limit();
     }
-    release_blocks(evict);
+    if (far_over) evict_down_to(scratch_cache_limit()); // the hard bound; between the limit and twice the limit the next cache miss trims
 }
+
+// What one scratch block of a long-lived working set may take so that a few of them stay inside the cache (batch.hip's ping-pong blocks).
+size_t scratch_block_budget() { return std::max<size_t>(scratch_cache_limit() / 4, (size_t)64 << 20); }
 
 // How many host threads the codecs' host halves may use for one call (deflate pieces, entropy-coding bands).
 int host_threads() {
