@@ -364,3 +364,37 @@ def test_convolve_u8_f32_accumulators_at_the_exactness_boundary(oracle):
                     got = dev(f).convolve(k)
                     torch.cuda.synchronize()
                     assert_bits_equal(got.to_numpy(), want, f"{n}x{n} scale {scale} {signs} {name}")
+
+
+def test_convolve_3x3_5x5_u8_register_stream_kernel(oracle):
+    """k_conv2d_stream (conv2d_stream.hip): shapes that meet its preconditions (row bytes % 16 == 0, >= 64 pixels, >= 16 rows) over one
+    and several strips across and down, every border rule, every u8 pixel type, positive and mixed-sign taps (negative sums clamp to 0,
+    large ones to 255), and a view whose pitch is wider than its rows."""
+    rng = np.random.default_rng(31)
+    shapes = {"u8": [(16, 64), (33, 1040), (70, 2064), (200, 4096)], "rgb_u8": [(16, 64), (45, 352), (37, 1024)], "rgba_u8": [(16, 64), (40, 300), (97, 260), (130, 1028), (300, 516)]}
+    for kind, shp in shapes.items():
+        ch = {"u8": (), "rgb_u8": (3,), "rgba_u8": (4,)}[kind]
+        for shape in shp:
+            src = rng.integers(0, 256, shape + ch, dtype=np.uint8)
+            for n in (3, 5):
+                for signs in ("blur", "mixed", "big"):
+                    k = rng.random((n, n), dtype=np.float32) / (n * n)
+                    if signs == "mixed":
+                        k[::2, 1::2] *= -2
+                    if signs == "big":
+                        k *= 3
+                    for border in range(4):
+                        got = dev(src).convolve(k, border)
+                        torch.cuda.synchronize()
+                        assert_bits_equal(got.to_numpy(), oracle.convolve(src, k, border), f"{kind} {shape} {n}x{n} {signs} border {border}")
+    # a view: 16-byte aligned origin, pitch of the parent
+    parent = rng.integers(0, 256, (90, 400, 4), dtype=np.uint8)
+    k = rng.random((3, 3), dtype=np.float32) / 9
+    t = torch.from_numpy(parent).cuda()
+    out = torch.full((90, 400, 4), 7, dtype=torch.uint8, device="cuda")
+    zg.Image(t).view((8, 5, 8 + 256, 5 + 60)).convolve(k, 2, out=zg.Image(out).view((8, 5, 8 + 256, 5 + 60)))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert_bits_equal(got[5:65, 8:264], oracle.convolve(np.ascontiguousarray(parent[5:65, 8:264]), k, 2), "view")
+    got[5:65, 8:264] = 7
+    assert (got == 7).all(), "pixels outside the destination view were written"

@@ -122,6 +122,7 @@ ALTERNATIVE_FORMS = {
     "ZIGNAL_HIP_STREAM_GREY": "k_sep_stream for a single grey plane too",
     "ZIGNAL_HIP_NO_WARP_STAGE": "sixteen gathers in flight instead of the wave-staged Rgba(f32) resampler",
     "ZIGNAL_HIP_CONV2D_INT": "integer accumulators in k_conv2d",
+    "ZIGNAL_HIP_NO_CONV2D_STREAM": "the LDS-tiled k_conv2d instead of k_conv2d_stream",
 }
 
 

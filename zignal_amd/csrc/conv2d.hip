@@ -15,6 +15,8 @@
 
 namespace zg {
 
+int try_conv2d_stream(const zg_image *src, const zg_image *dst, const float *taps, int kh, int kw, int border, hipStream_t s); // conv2d_stream.hip
+
 constexpr int MAX_K2D = 15 * 15;
 
 struct Kernel2D {
@@ -232,6 +234,13 @@ static int convolve_impl(const zg_image *src, const zg_image *dst, const float *
         // the run-time-size kernel and 7 x 7 on three or four channels (288 registers when unrolled) keep the integer form
         const bool unrolled = (kh == 3 && kw == 3) || (kh == 5 && kw == 5) || (kh == 7 && kw == 7 && pixel_channels(src->pixel) == 1);
         if (255 * sum_abs < (1 << 24) && unrolled && !no_f32) mode = 3;
+        if (255 * sum_abs < (1 << 24) && kh == kw && (kh == 3 || kh == 5)) {
+            // every partial sum an integer below 2^24: one wave per column strip, rows resident in registers (conv2d_stream.hip)
+            float fk[25];
+            for (size_t i = 0; i < nk; ++i) fk[i] = (float)ik[i];
+            const int rcs = try_conv2d_stream(src, dst, fk, (int)kh, (int)kw, border, s);
+            if (rcs >= 0) return rcs;
+        }
     }
     if (kh <= 15 && kw <= 15) { // tiled kernels, taps as a kernel argument
         Kernel2D k;
