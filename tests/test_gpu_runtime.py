@@ -123,6 +123,7 @@ ALTERNATIVE_FORMS = {
     "ZIGNAL_HIP_NO_WARP_STAGE": "sixteen gathers in flight instead of the wave-staged Rgba(f32) resampler",
     "ZIGNAL_HIP_CONV2D_INT": "integer accumulators in k_conv2d",
     "ZIGNAL_HIP_NO_CONV2D_STREAM": "the LDS-tiled k_conv2d instead of k_conv2d_stream",
+    "ZIGNAL_HIP_NO_SOBEL_STREAM": "the LDS-tiled k_sobel instead of k_sobel_stream",
 }
 
 
@@ -161,6 +162,8 @@ for n in (3, 5, 7):
     k[0, 0] *= -1
     same(dev(rgba).convolve(k), o.convolve(rgba, k, o.MIRROR), "convolve rgba")
     same(dev(grey).convolve(k), o.convolve(grey, k, o.MIRROR), "convolve grey")
+same(dev(rgba).sobel(), o.sobel(rgba), "sobel rgba")
+same(dev(grey).sobel(), o.sobel(grey), "sobel grey")
 print("ok")
 ''' % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **{hook: "1"}))

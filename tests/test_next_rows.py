@@ -80,6 +80,42 @@ def test_sobel_parity(oracle, kind):
 
 
 @pytest.mark.gpu
+def test_sobel_register_stream_kernel(oracle):
+    """k_sobel_stream (sobel_stream.hip): u8 and Rgba(u8) sources whose rows are multiples of 16 bytes — one and several strips across
+    and down, rows that end inside a strip, saturated patterns (the largest gradients: |gx| = |gy| = 1020), a view with the parent's
+    pitch, and a batch through the pipeline's edges step."""
+    rng = np.random.default_rng(12)
+    for kind, shapes in (("u8", [(16, 64), (33, 1040), (50, 2064), (130, 4096)]), ("rgba_u8", [(16, 64), (40, 300), (97, 260), (64, 1028), (300, 516)])):
+        for shape in shapes:
+            full = shape + ((4,) if kind == "rgba_u8" else ())
+            for what in ("random", "checker", "steps"):
+                if what == "random":
+                    src = rng.integers(0, 256, full, dtype=np.uint8)
+                elif what == "checker":
+                    yy, xx = np.indices(shape)
+                    src = np.broadcast_to((((yy // 3 + xx // 2) & 1) * 255).astype(np.uint8).reshape(shape + ((1,) if kind == "rgba_u8" else ())), full).copy()
+                else:
+                    src = np.zeros(full, np.uint8)
+                    src[shape[0] // 2:, ...] = 255
+                    src[:, shape[1] // 3:, ...] ^= 255
+                out = dev(src).sobel()
+                torch.cuda.synchronize()
+                assert_bits_equal(out.to_numpy(), oracle.sobel(src), f"sobel stream {kind} {shape} {what}")
+    parent = rng.integers(0, 256, (90, 400, 4), dtype=np.uint8)
+    out = torch.full((90, 400), 9, dtype=torch.uint8, device="cuda")
+    zg.Image(torch.from_numpy(parent).cuda()).view((8, 5, 264, 65)).sobel(out=zg.Image(out).view((16, 7, 272, 67)))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert_bits_equal(got[7:67, 16:272], oracle.sobel(np.ascontiguousarray(parent[5:65, 8:264])), "sobel stream view")
+    got[7:67, 16:272] = 9
+    assert (got == 9).all()
+    frames = rng.integers(0, 256, (5, 48, 128, 4), dtype=np.uint8)
+    got = zg.Pipeline([zg.Step.edges_sobel()]).run(torch.from_numpy(frames).cuda()).cpu().numpy()
+    for f in range(5):
+        assert np.array_equal(got[f][..., 0], oracle.sobel(frames[f])) and (got[f][..., 3] == 255).all()
+
+
+@pytest.mark.gpu
 def test_sobel_4k(oracle):
     src = oracle.synth_u8(81, (2048, 4096, 4))
     out = dev(src).sobel()

@@ -16,6 +16,8 @@
 
 namespace zg {
 
+int try_sobel_stream(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s); // sobel_stream.hip
+
 __device__ inline float gray_as_f32(uint8_t v) { return (float)v; }
 
 template <int PIX> __device__ inline float sobel_gray(typename Px<PIX>::Vec v) {
@@ -101,6 +103,7 @@ static int sobel_impl(const zg_image *src, const zg_image *dst, hipStream_t s, u
                src->rows, src->cols, dst->rows, dst->cols);
     ZG_REQUIRE(dst->pixel == ZG_PIXEL_U8, ZG_ERR_INVALID_ARGUMENT, "sobel: the output is Image(u8)");
     if (src->rows == 0 || src->cols == 0) return ZG_OK;
+    if (const int rcs = try_sobel_stream(src, dst, n, src_frame, dst_frame, s); rcs >= 0) return rcs; // u8 / Rgba(u8): one wave per column strip
     const int tiles_x = (int)ceil_div(src->cols, 64), tiles_y = (int)ceil_div(src->rows, 16);
     if (n > MAX_FRAMES_PER_LAUNCH) return -1; // the caller goes frame by frame
     const FrameSpan fr{src_frame, dst_frame};

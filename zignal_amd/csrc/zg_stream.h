@@ -30,6 +30,7 @@ template <> struct HaloLoad<4> { __device__ static __forceinline__ void run(__am
 // hipcc pads as usual. Loads have no such window and do use soffset.
 __device__ __forceinline__ void st_unit(u32x4 o, __amdgpu_buffer_rsrc_t r, int off) { __builtin_amdgcn_raw_buffer_store_b128(o, r, off, 0, 2); }
 __device__ __forceinline__ void st_unit(u32x2 o, __amdgpu_buffer_rsrc_t r, int off) { __builtin_amdgcn_raw_buffer_store_b64(o, r, off, 0, 2); }
+__device__ __forceinline__ void st_unit(uint32_t o, __amdgpu_buffer_rsrc_t r, int off) { __builtin_amdgcn_raw_buffer_store_b32(o, r, off, 0, 2); }
 
 // Byte j (0..15) of the outer lane's own unit that supplies halo byte `pos` of a border halo, or -1 when no tap reaches it.
 // Left halo: HB dwords covering stream positions -4 HB .. -1. Right halo: positions rb .. rb + 4 HB - 1, the own unit being
