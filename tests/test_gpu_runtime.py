@@ -124,6 +124,7 @@ ALTERNATIVE_FORMS = {
     "ZIGNAL_HIP_CONV2D_INT": "integer accumulators in k_conv2d",
     "ZIGNAL_HIP_NO_CONV2D_STREAM": "the LDS-tiled k_conv2d instead of k_conv2d_stream",
     "ZIGNAL_HIP_NO_SOBEL_STREAM": "the LDS-tiled k_sobel instead of k_sobel_stream",
+    "ZIGNAL_HIP_ISEF_TRANSPOSE": "two transposes around k_isef_cols instead of the role-split k_isef along the rows",
 }
 
 
@@ -164,6 +165,8 @@ for n in (3, 5, 7):
     same(dev(grey).convolve(k), o.convolve(grey, k, o.MIRROR), "convolve grey")
 same(dev(rgba).sobel(), o.sobel(rgba), "sobel rgba")
 same(dev(grey).sobel(), o.sobel(grey), "sobel grey")
+same(dev(grey).shen_castan(), o.shen_castan(grey), "shen-castan grey")
+same(dev(rgba).shen_castan(smooth=0.6, use_nms=True), o.shen_castan(rgba, smooth=0.6, use_nms=True), "shen-castan rgba")
 print("ok")
 ''' % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **{hook: "1"}))

@@ -596,6 +596,7 @@ static int canny_impl(const zg_image *src, const zg_image *dst, float sigma, flo
 // and a one-workgroup kernel), so nothing but the hysteresis fixed-point test synchronises the stream.
 
 int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer_valued, size_t plane_stride = 0); // box_blur.hip (0: planes contiguous)
+int isef_2d(const float *gray, float *sm, float *tmp, uint32_t rows, uint32_t cols, float smooth, hipStream_t s); // isef.hip
 int sat_planes_multi(const zg_image *const *srcs, float *const *sats, int count, hipStream_t s); // box_blur.hip
 
 // The recursions along ROWS run as the column kernel on the transposed plane: a row chain needs lanes = rows, i.e. a transpose
@@ -1054,10 +1055,15 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
     if (rc == ZG_OK) {
         // rows: transpose, column recursions on the cols x rows plane (in place on `grad`, `sat_g` between the passes: both are
         // free until the gradient stage), transpose back into `sm`; then the columns proper
-        hipLaunchKernelGGL(k_transpose_f32, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, s, (const float *)gray, grad, (int)rows, (int)cols);
-        hipLaunchKernelGGL(k_isef_cols, dim3(ceil_div(rows, 64)), dim3(576), 0, s, grad, sat_g, (int)cols, (int)rows, smooth);
-        hipLaunchKernelGGL(k_transpose_f32, dim3(ceil_div(rows, 64), ceil_div(cols, 64)), dim3(256), 0, s, (const float *)grad, sm, (int)cols, (int)rows);
-        hipLaunchKernelGGL(k_isef_cols, dim3(ceil_div(cols, 64)), dim3(576), 0, s, sm, temp, (int)rows, (int)cols, smooth);
+        // role-split recursions along the rows and then the columns (isef.hip); planes whose rows are not whole 16-byte chunks take round 3's
+        // route: transpose, column recursions on the cols x rows plane (in place on `grad`, `sat_g` between the passes: both are free until
+        // the gradient stage), transpose back into `sm`, then the columns proper
+        if (isef_2d(gray, sm, temp, rows, cols, smooth, s) < 0) {
+            hipLaunchKernelGGL(k_transpose_f32, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, s, (const float *)gray, grad, (int)rows, (int)cols);
+            hipLaunchKernelGGL(k_isef_cols, dim3(ceil_div(rows, 64)), dim3(576), 0, s, grad, sat_g, (int)cols, (int)rows, smooth);
+            hipLaunchKernelGGL(k_transpose_f32, dim3(ceil_div(rows, 64), ceil_div(cols, 64)), dim3(256), 0, s, (const float *)grad, sm, (int)cols, (int)rows);
+            hipLaunchKernelGGL(k_isef_cols, dim3(ceil_div(cols, 64)), dim3(576), 0, s, sm, temp, (int)rows, (int)cols, smooth);
+        }
         if (cols % 4 == 0) { // four pixels per lane (the planes start 16 bytes aligned)
             const dim3 g4(ceil_div(cols, 256), ceil_div(rows, 64));
             if (!use_nms) hipLaunchKernelGGL(k_sc_bli4<0>, g4, dim3(256), 0, s, (const float *)gray, (const float *)sm, bli, temp /* grey * BLI */, cand, (int)rows, (int)cols);
