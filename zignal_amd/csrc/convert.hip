@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_convert(DImg src, DImg dst, ConvertArgs
 // rows on the u8 side (the launcher checks; anything else stays on k_convert).
 typedef uint32_t lab4_u32x4 __attribute__((ext_vector_type(4)));
 typedef float lab4_f32x4 __attribute__((ext_vector_type(4)));
-template <int SC, int MODE> // MODE 0: Xyz, 1: Oklab, 2: Oklab from a table whose entries are +0 or within [2^-60, 2^60] (xyz_to_oklab<true>)
+template <int SC, int MODE> // MODE 0: Xyz, 1: Oklab, 2: Oklab from a table whose entries are +0 or within [2^-60, 2^60] (xyz_to_oklab<true>), 3 / 4: Lab likewise
 __global__ __launch_bounds__(256) void k_u8_to_lab4(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint64_t src_pitch, uint64_t dst_pitch,
                                                     int rows, int cols, const float *__restrict__ lut_global) {
     __shared__ float lut[256];
@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256) void k_u8_to_lab4(const uint8_t *__restrict__ 
         float X, Y, Z;
         linear_rgb_to_xyz(lin, X, Y, Z);
         if constexpr (MODE == 0) { out[3 * p] = X; out[3 * p + 1] = Y; out[3 * p + 2] = Z; }
-        else xyz_to_oklab<MODE == 2>(X, Y, Z, out[3 * p], out[3 * p + 1], out[3 * p + 2]);
+        else if constexpr (MODE <= 2) xyz_to_oklab<MODE == 2>(X, Y, Z, out[3 * p], out[3 * p + 1], out[3 * p + 2]);
+        else xyz_to_lab<MODE == 4>(X, Y, Z, out[3 * p], out[3 * p + 1], out[3 * p + 2]);
     }
     // a lane's 48 bytes are contiguous but the next lane's start 48 bytes on: stored as they are, every dwordx4 store of the wave touches
     // 24 cache lines and fills a third of each. When all 64 lanes hold four pixels the wave turns its 3 KiB through LDS instead (each
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void k_u8_to_lab4(const uint8_t *__restrict__ 
 }
 
 static bool lab4_applies(const zg_image *src, const zg_image *dst, int src_space, int dst_space) {
-    if (dst->pixel != ZG_PIXEL_RGB_F32 || (dst_space != ZG_CS_XYZ && dst_space != ZG_CS_OKLAB)) return false;
+    if (dst->pixel != ZG_PIXEL_RGB_F32 || (dst_space != ZG_CS_XYZ && dst_space != ZG_CS_OKLAB && dst_space != ZG_CS_LAB)) return false;
     if (!((src->pixel == ZG_PIXEL_RGBA_U8 && src_space == ZG_CS_RGBA) || (src->pixel == ZG_PIXEL_RGB_U8 && src_space == ZG_CS_RGB))) return false;
     const uint64_t sc = src->pixel == ZG_PIXEL_RGBA_U8 ? 4 : 3, need = sc == 4 ? 16 : 4;
     if (((uintptr_t)src->data % need) || ((uint64_t)src->stride * sc % need)) return false;
@@ -239,10 +240,10 @@ static int launch_lab4(const zg_image *src, const zg_image *dst, int dst_space, 
     const bool four = src->pixel == ZG_PIXEL_RGBA_U8, oklab = dst_space == ZG_CS_OKLAB;
     const uint64_t spitch = (uint64_t)src->stride * (four ? 4 : 3), dpitch = (uint64_t)dst->stride * 12;
     const int rows = (int)src->rows, cols = (int)src->cols;
-    const int mode = !oklab ? 0 : (plain_table ? 2 : 1);
+    const int mode = dst_space == ZG_CS_LAB ? (plain_table ? 4 : 3) : !oklab ? 0 : (plain_table ? 2 : 1);
 #define ZG_LAB4(SC, MODE) hipLaunchKernelGGL((k_u8_to_lab4<SC, MODE>), grid, dim3(256), 0, s, sp, dp, spitch, dpitch, rows, cols, lut)
-    if (four) { if (mode == 0) ZG_LAB4(4, 0); else if (mode == 1) ZG_LAB4(4, 1); else ZG_LAB4(4, 2); }
-    else { if (mode == 0) ZG_LAB4(3, 0); else if (mode == 1) ZG_LAB4(3, 1); else ZG_LAB4(3, 2); }
+    if (four) { if (mode == 0) ZG_LAB4(4, 0); else if (mode == 1) ZG_LAB4(4, 1); else if (mode == 2) ZG_LAB4(4, 2); else if (mode == 3) ZG_LAB4(4, 3); else ZG_LAB4(4, 4); }
+    else { if (mode == 0) ZG_LAB4(3, 0); else if (mode == 1) ZG_LAB4(3, 1); else if (mode == 2) ZG_LAB4(3, 2); else if (mode == 3) ZG_LAB4(3, 3); else ZG_LAB4(3, 4); }
 #undef ZG_LAB4
     ZG_HIP(hipGetLastError());
     return ZG_OK;
@@ -303,7 +304,13 @@ int convert_impl(const zg_image *src, int src_space, const zg_image *dst, int ds
         if (src_space == dst_space && src->pixel == dst->pixel) return copy_impl(src, dst, s);
         const float *lut_dev = nullptr; // gammaToLinear(u8 / 255): the caller's table if given, else the library's
         float *lut_owned = nullptr;
-        if (!sf && (rc = device_srgb_lut(srgb_lut, s, &lut_dev, &lut_owned))) return rc;
+        bool plain_lut = false;
+        if (!sf && (rc = device_srgb_lut(srgb_lut, s, &lut_dev, &lut_owned, &plain_lut))) return rc;
+        if (lab4_applies(src, dst, src_space, dst_space)) { // Rgb(u8) / Rgba(u8) -> Lab(f32): the route Rgb -> Xyz -> Lab, four pixels per lane
+            rc = launch_lab4(src, dst, dst_space, lut_dev, plain_lut, s);
+            if (lut_owned) scratch_free(lut_owned, s);
+            return rc;
+        }
         rc = convert_spaces_impl(src, src_space, dst, dst_space, lut_dev, s);
         if (lut_owned) scratch_free(lut_owned, s);
         return rc;
@@ -444,7 +451,13 @@ __global__ __launch_bounds__(256) void k_devmath_apply(int fn, const float *x, c
         case 8: r = dev_gamma_to_linear(a); break;
         case 9: r = dev_cbrtf_musl(a); break;
         case 10: r = a / 100.0f; break;
-        default: r = dev_div100(a); break;
+        case 11: r = dev_div100(a); break;
+        case 12: r = dev_lab_forward(a); break;
+        case 13: { bool redo; r = dev_lab_forward_fast(a, redo); if (redo) r = dev_lab_forward(a); break; }
+        case 14: r = a / LAB_XN; break;
+        case 15: { bool redo; r = dev_div_const_fast(a, LAB_XN, LAB_XN_R, redo); if (redo) r = a / LAB_XN; break; }
+        case 16: r = a / LAB_ZN; break;
+        default: { bool redo; r = dev_div_const_fast(a, LAB_ZN, LAB_ZN_R, redo); if (redo) r = a / LAB_ZN; break; }
         }
         out[i] = r;
     }
@@ -480,7 +493,7 @@ int zg_convert_host(const zg_image *src, int src_space, const zg_image *dst, int
 // fn: 0 cbrt, 1 pow(x, 2.4), 2 exp, 3 log, 4 sin, 5 cos, 6 atan2(x, y), 7 pow(x, y), 8 gammaToLinear, 9 cbrt by musl's own steps (what 0 is
 // checked against over all 2^32 inputs). y may be NULL for unary fn.
 int zg_devmath_apply(int fn, const float *x_dev, const float *y_dev, float *out_dev, size_t n, zg_stream stream) {
-    ZG_REQUIRE(fn >= 0 && fn <= 11, ZG_ERR_INVALID_ARGUMENT, "zg_devmath_apply: unknown function %d", fn);
+    ZG_REQUIRE(fn >= 0 && fn <= 17, ZG_ERR_INVALID_ARGUMENT, "zg_devmath_apply: unknown function %d", fn);
     ZG_REQUIRE((x_dev && out_dev) || n == 0, ZG_ERR_INVALID_ARGUMENT, "zg_devmath_apply: null array");
     ZG_REQUIRE((fn != 6 && fn != 7) || y_dev || n == 0, ZG_ERR_INVALID_ARGUMENT, "zg_devmath_apply: function %d needs y", fn);
     if (n == 0) return ZG_OK;

@@ -48,4 +48,32 @@ __device__ inline void xyz_to_oklab(float X, float Y, float Z, float &L, float &
     B = 0.0259040371f * l_dash + 0.7827717662f * m_dash - 0.8086757660f * s_dash;
 }
 
+// Xyz -> Lab (color.zig:1294-1308) with the divisions by the white point and labForward's power in their fast forms (zg_devmath.h: each
+// equal to the plain form on every f32). IN_RANGE as in xyz_to_oklab: X, Y, Z each +0 or normal within [2^-100, 2^120), so no form
+// ever asks for its plain twin.
+template <bool IN_RANGE = false>
+__device__ inline void xyz_to_lab(float X, float Y, float Z, float &L, float &A, float &B) {
+    bool rx, ry, rz;
+    float tx = dev_div_const_fast(X, LAB_XN, LAB_XN_R, rx), ty = dev_div100_fast(Y, ry), tz = dev_div_const_fast(Z, LAB_ZN, LAB_ZN_R, rz);
+    if constexpr (!IN_RANGE) {
+        if (rx | ry | rz) { // one rare branch for all three
+            if (rx) tx = X / LAB_XN;
+            if (ry) ty = Y / LAB_YN;
+            if (rz) tz = Z / LAB_ZN;
+        }
+    }
+    bool px, py, pz;
+    float fx = dev_lab_forward_fast(tx, px), fy = dev_lab_forward_fast(ty, py), fz = dev_lab_forward_fast(tz, pz);
+    if constexpr (!IN_RANGE) {
+        if (px | py | pz) {
+            if (px) fx = dev_lab_forward(tx);
+            if (py) fy = dev_lab_forward(ty);
+            if (pz) fz = dev_lab_forward(tz);
+        }
+    }
+    L = fmaxf(0.0f, 116.0f * fy - 16.0f);
+    A = 500.0f * (fx - fy);
+    B = 200.0f * (fy - fz);
+}
+
 } // namespace zg

@@ -151,6 +151,72 @@ __device__ inline float dev_logf(float x) { // musl logf
     const float hfsq = 0.5f * f * f, dk = (float)k;
     return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
 }
+// a / b for operands whose quotient and remainder stay in the normal range (the callers' ranges are stated where they call): the IEEE
+// division expansion without its scaling and fix-up steps — reciprocal, one Newton step on it, quotient, two exact-remainder corrections.
+__device__ inline float dev_div_normal(float a, float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float r = __builtin_fmaf(__builtin_fmaf(-b, r0, 1.0f), r0, r0);
+    float q = a * r;
+    q = __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+}
+// x / D for a constant D with R = the correctly rounded 1 / D: quotient by the reciprocal, the exact remainder with one FMA, one
+// correction (dev_div100's form). `redo` comes back true where the quotient or the remainder could leave the normal range (|x| < 2^-100,
+// |x| >= 2^120, -0, inf, nan): there the caller divides. Checked against x / D over all 2^32 inputs for every D in use (tests/test_math_pin.py).
+__device__ inline float dev_div_const_fast(float x, float D, float R, bool &redo) {
+    const uint32_t u = __float_as_uint(x), ax = u & 0x7fffffffu;
+    redo = (ax - 0x0d800000u >= 0x7b800000u - 0x0d800000u) & (u != 0);
+    const float q = x * R;
+    return __builtin_fmaf(__builtin_fmaf(-q, D, x), R, q);
+}
+// std.math.pow(f32, t, 1.0 / 3.0) for 2^-100 <= t < 2^120 — labForward's power (color.zig:1289-1291), Go's algorithm with yi = 0:
+// exp(yf * log(t)), yf = 0.33333334f, musl's expf and logf — with every branch of the two functions turned into selects and their two
+// divisions into dev_div_normal (2 + f in (1.7, 2.42), 2 - c in (1.6, 2.4); numerators 0 or normal). The same operations in the same
+// order as dev_powf(t, 1 / 3.0f): equal bit for bit on every t of the range (tests/test_math_pin.py sweeps all of them).
+__device__ inline float dev_pow_third_fast(float t) {
+    // logf(t), t positive and normal
+    const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
+    const float Lg1 = 0xaaaaaa.0p-24f, Lg2 = 0xccce13.0p-25f, Lg3 = 0x91e9ee.0p-25f, Lg4 = 0xf89e26.0p-26f;
+    uint32_t ix = __float_as_uint(t);
+    ix += 0x3f800000u - 0x3f3504f3u;
+    const int kl = (int)(ix >> 23) - 0x7f;
+    ix = (ix & 0x007fffffu) + 0x3f3504f3u;
+    const float xm = __uint_as_float(ix);
+    const float f = xm - 1.0f, s = dev_div_normal(f, 2.0f + f), z = s * s, w = z * z;
+    const float t1 = w * (Lg2 + w * Lg4), t2 = z * (Lg1 + w * Lg3), R = t2 + t1;
+    const float hfsq = 0.5f * f * f, dk = (float)kl;
+    const float lg = s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+    // expf(yf * lg): |argument| < 80 over the range, so no overflow / underflow exits
+    float x = 0.33333334f * lg;
+    const float ln2hi = 6.9314575195e-1f, ln2lo = 1.4286067653e-6f, invln2 = 1.4426950216e+0f;
+    const float P1 = 1.6666625440e-1f, P2 = -2.7667332906e-3f;
+    const uint32_t hx = __float_as_uint(x) & 0x7fffffffu;
+    const bool neg = (__float_as_uint(x) >> 31) != 0;
+    const int k_far = (int)(invln2 * x + (neg ? -0.5f : 0.5f));
+    const int k = hx > 0x3f851592u ? k_far : (hx > 0x3eb17218u ? (neg ? -1 : 1) : 0);
+    const float fk = (float)k;
+    const float hi = x - fk * ln2hi, lo = fk * ln2lo; // k = 0: hi = x, lo = +0, as musl's middle branch sets them
+    const float xr = hi - lo;
+    const float xx = xr * xr;
+    const float c = xr - xx * (P1 + xx * P2);
+    const float y = 1 + (dev_div_normal(xr * c, 2 - c) - lo + hi);
+    const float scaled = y * __uint_as_float((uint32_t)(0x7f + k) << 23); // scalbnf(y, k), |k| < 120; k = 0: y * 1
+    return hx > 0x39000000u ? scaled : 1 + x; // |argument| <= 2^-13: musl returns 1 + x
+}
+
+// labForward (color.zig:1289-1291) as the route walker evaluates it, and the fast form: equal on every f32 (tests/test_math_pin.py).
+__device__ inline float dev_powf(float x, float y);
+__device__ inline float dev_lab_forward(float t) {
+    return t > 0.008856f ? dev_powf(t, 0.33333333333333333333333333333333f) : 7.787f * t + 0.13793103448275862068965517241379f;
+}
+__device__ inline float dev_lab_forward_fast(float t, bool &redo) { // `redo`: t >= 2^120, inf or nan — the caller takes dev_lab_forward
+    redo = !(t < 0x1p120f);
+    const float p = dev_pow_third_fast(t); // garbage for t <= 0.008856 (zero, negative, tiny), never selected there
+    return t > 0.008856f ? p : 7.787f * t + 0.13793103448275862068965517241379f;
+}
+constexpr float LAB_XN = 95.047f, LAB_YN = 100.000f, LAB_ZN = 108.883f; // d65 white (color.zig:1296-1298)
+constexpr float LAB_XN_R = 1.0f / 95.047f, LAB_ZN_R = 1.0f / 108.883f;   // correctly rounded by the compiler
+
 // pow(x, 2.4) for finite x > 0 the way Zig's std.math.pow computes it: yi = 2, yf = 0.4.
 __device__ inline float dev_pow_2p4(float x) {
     if (x == 1) return 1;
