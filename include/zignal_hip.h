@@ -318,7 +318,8 @@ ZG_API int zg_resize_convert_host(const zg_image *src, int src_space, const zg_i
  * device arrays of n floats. fn: 0 cbrt, 1 pow(x, 2.4), 2 exp, 3 log, 4 sin, 5 cos, 6 atan2(x, y), 7 pow(x, y), 8 gammaToLinear
  * (src/color.zig:1252-1258), 9 cbrt by musl's steps verbatim (the device's faster cbrt, fn 0, is checked against it over all 2^32 inputs), 10 x / 100.0f, 11 the
  * device's division-free form of it (likewise), 12 / 13 labForward (src/color.zig:1289-1291) plain and in its branch-free form, 14 / 15 x / 95.047f and
- * 16 / 17 x / 108.883f by division and by the reciprocal-and-remainder form (each pair equal on all 2^32 inputs). y_dev may be NULL for the unary functions. This is how the transcendental boundary is swept against
+ * 16 / 17 x / 108.883f by division and by the reciprocal-and-remainder form, 18 / 19 linearToGamma (src/color.zig:1243-1249) plain and branch-free,
+ * 20 / 21, 22 / 23, 24 / 25 x / 116, x / 500, x / 200 likewise (each pair equal on all 2^32 inputs). y_dev may be NULL for the unary functions. This is how the transcendental boundary is swept against
  * the oracle and against correctly rounded values (tests/test_math_pin.py). */
 ZG_API int zg_devmath_apply(int fn, const float *x_dev, const float *y_dev, float *out_dev, size_t n, zg_stream stream);
 

@@ -106,7 +106,7 @@ def test_u8_to_xyz_and_oklab_four_pixels_per_lane(oracle):
         for ch, space in ((4, zg.CS_RGBA), (3, zg.CS_RGB)):
             src = rng.integers(0, 256, (rows, cols, ch), dtype=np.uint8)
             src[0, : min(cols, 9)] = 0  # black pixels: cbrt(0) takes the reference's own early return
-            for dst in (zg.CS_OKLAB, zg.CS_XYZ):
+            for dst in (zg.CS_OKLAB, zg.CS_XYZ, zg.CS_LAB):
                 want = oracle.convert(src, space, dst, np.float32, 3)
                 assert_bits_equal(run(src, space, dst, np.float32), want, f"{rows}x{cols}x{ch} -> {dst}")
     # views: a 1024-wide window of a wider frame (pitch a multiple of four pixels: the four-pixel kernel) and one shifted by a pixel
@@ -128,3 +128,27 @@ def test_u8_to_xyz_and_oklab_four_pixels_per_lane(oracle):
     got = dev(ramp).convert(zg.CS_OKLAB, np.float32, srgb_lut=odd)
     torch.cuda.synchronize()
     assert_bits_equal(got.to_numpy(), want, "odd table")
+    with np.errstate(all="ignore"):  # the route's two hops with the caller's table in the first (the oracle's one-call Lab route linearises by itself)
+        want = oracle.convert(oracle.convert(ramp, zg.CS_RGB, zg.CS_XYZ, np.float32, 3, srgb_lut=odd), zg.CS_XYZ, zg.CS_LAB, np.float32, 3)
+    got = dev(ramp).convert(zg.CS_LAB, np.float32, srgb_lut=odd)
+    torch.cuda.synchronize()
+    assert_bits_equal(got.to_numpy(), want, "odd table -> Lab")
+
+
+def test_lab_to_u8_four_pixels_per_lane(oracle):
+    """k_lab4_to_u8 (convert.hip): Lab(f32) -> Rgb(u8) / Rgba(u8) over ragged and full rows, in-gamut colours (the forward conversion of
+    random pixels), colours far outside the gamut, the dark linear piece of labToXyz, and non-finite components."""
+    rng = np.random.default_rng(78)
+    for rows, cols in ((1, 4), (3, 8), (5, 256), (4, 260), (2, 1024), (3, 1028), (1, 4096 + 64)):
+        rgb = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+        rgb[0, : min(cols, 6)] = (0, 0, 0)
+        rgb[0, min(cols, 6): min(cols, 10)] = (3, 2, 1)
+        lab = oracle.convert(rgb, zg.CS_RGB, zg.CS_LAB, np.float32, 3)
+        wild = lab.copy()
+        wild[..., 1:] *= np.float32(3.0)  # out of gamut: the clamps
+        wild[-1, -1] = (np.float32(np.nan), np.float32(1e30), np.float32(-np.inf))
+        for src, name in ((lab, "in gamut"), (wild, "wild")):
+            for space, ch in ((zg.CS_RGBA, 4), (zg.CS_RGB, 3)):
+                with np.errstate(all="ignore"):
+                    want = oracle.convert(src, zg.CS_LAB, space, np.uint8, ch)
+                assert_bits_equal(run(src, zg.CS_LAB, space, np.uint8), want, f"{rows}x{cols} {name} -> {ch} channels")

@@ -113,7 +113,7 @@ def test_role_split_sat_chain_equals_the_unfused_kernels(shape, oracle):
 
 ALTERNATIVE_FORMS = {
     # hook: (what it switches back to, a snippet producing `got` and `want` for shapes that reach the kernel in question)
-    "ZIGNAL_HIP_NO_LAB4": "k_convert instead of k_u8_to_lab4",
+    "ZIGNAL_HIP_NO_LAB4": "k_convert / the route walker instead of k_u8_to_lab4 and k_lab4_to_u8",
     "ZIGNAL_HIP_COLS_INT": "k_cols_u16 instead of k_cols_u8f",
     "ZIGNAL_HIP_ROWS_INT": "k_rows_u16 instead of k_rows_u8f",
     "ZIGNAL_HIP_NO_U8_PLANE_RESIZE": "k_geom instead of k_resize_bilinear_u8",
@@ -150,6 +150,9 @@ rgba = rng.integers(0, 256, (70, 1100, 4), dtype=np.uint8)
 grey = rng.integers(0, 256, (300, 1296), dtype=np.uint8)
 same(dev(rgba).convert(zg.CS_OKLAB, np.float32), o.convert(rgba, o.CS_RGBA, o.CS_OKLAB, np.float32, 3), "oklab")
 same(dev(rgba[..., :3]).convert(zg.CS_XYZ, np.float32), o.convert(np.ascontiguousarray(rgba[..., :3]), o.CS_RGB, o.CS_XYZ, np.float32, 3), "xyz")
+lab = o.convert(rgba, o.CS_RGBA, o.CS_LAB, np.float32, 3)
+same(dev(rgba).convert(zg.CS_LAB, np.float32), lab, "lab")
+same(dev(lab).convert(zg.CS_RGBA, np.uint8, src_space=zg.CS_LAB), o.convert(lab, o.CS_LAB, o.CS_RGBA, np.uint8, 4), "lab back")
 for sigma in (0.6, 1.0, 2.25, 5.5):
     same(dev(grey).gaussian_blur(sigma), o.gaussian_blur(grey, sigma), "grey blur %%g" %% sigma)
     same(dev(rgba).gaussian_blur(sigma), o.gaussian_blur(rgba, sigma), "rgba blur %%g" %% sigma)

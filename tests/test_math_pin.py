@@ -101,7 +101,8 @@ def test_device_maths_equals_the_oracle_bit_for_bit(fn, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fast,ref,what", [(0, 9, "cbrt"), (11, 10, "x / 100"), (13, 12, "labForward"), (15, 14, "x / 95.047"), (17, 16, "x / 108.883")])
+@pytest.mark.parametrize("fast,ref,what", [(0, 9, "cbrt"), (11, 10, "x / 100"), (13, 12, "labForward"), (15, 14, "x / 95.047"), (17, 16, "x / 108.883"),
+                                           (19, 18, "linearToGamma"), (21, 20, "x / 116"), (23, 22, "x / 500"), (25, 24, "x / 200")])
 def test_fast_device_forms_equal_the_plain_ones_on_every_f32(fast, ref, what):
     """dev_cbrtf (exp2(log2 |x| / 3) from the hardware transcendentals, one Halley correction whose residual is exact through FMA
     splits, musl's own steps next to rounding midpoints and outside [2^-60, 2^60)) against musl's cbrtf restated step for step,

@@ -249,6 +249,86 @@ static int launch_lab4(const zg_image *src, const zg_image *dst, int dst_space, 
     return ZG_OK;
 }
 
+// The way back, Lab(f32) -> Rgb(u8) / Rgba(u8) (route Lab -> Xyz -> Rgb -> u8, colorspaces.hip's hops: color.zig:1311-1330, :1275-1286, then
+// @round(255 * clamp(c, 0, 1))), four pixels per lane: a wave's 3 KiB of Lab values arrive as three coalesced 1 KiB loads and are turned
+// through LDS so that every lane holds its own four pixels; 16 (or 12) bytes out per lane.
+template <int DC>
+__global__ __launch_bounds__(256) void k_lab4_to_u8(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint64_t src_pitch, uint64_t dst_pitch, int rows, int cols) {
+    __shared__ __attribute__((aligned(16))) float turn[4 * 768];
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int wave_c0 = (int)(blockIdx.x * 256 + (threadIdx.x & ~63u)) * 4, c0 = wave_c0 + lane * 4, r = grid_row();
+    if (r >= rows || wave_c0 >= cols) return; // wave-uniform
+    const float *row = (const float *)(src + (uint64_t)r * src_pitch);
+    float in[12];
+    if (wave_c0 + 256 <= cols) {
+        lab4_f32x4 *mine = (lab4_f32x4 *)(turn + wave * 768);
+        const lab4_f32x4 *wave_sp = (const lab4_f32x4 *)(row + (size_t)wave_c0 * 3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) mine[k * 64 + lane] = wave_sp[k * 64 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const lab4_f32x4 v = mine[lane * 3 + k];
+            in[4 * k] = v.x; in[4 * k + 1] = v.y; in[4 * k + 2] = v.z; in[4 * k + 3] = v.w;
+        }
+    } else { // the ragged end of a row
+        const int n = min(max(cols - c0, 0), 4);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) in[i] = i < 3 * n ? row[(size_t)c0 * 3 + i] : 0.0f;
+    }
+    const int n = min(max(cols - c0, 0), 4);
+    uint32_t px[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        float rgb[3];
+        lab_to_rgb_unit(in[3 * p], in[3 * p + 1], in[3 * p + 2], rgb);
+        uint32_t w = DC == 4 ? 0xff000000u : 0u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float v = rgb[i];
+            v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); // xyzToRgb's clamp, then the u8 conversion's own (the same function twice)
+            w |= (uint32_t)(uint8_t)(int)roundf(255.0f * v) << (8 * i);
+        }
+        px[p] = w;
+    }
+    if constexpr (DC == 4) {
+        uint32_t *dp = (uint32_t *)(dst + (uint64_t)r * dst_pitch) + c0;
+        if (n == 4) *(lab4_u32x4 *)dp = lab4_u32x4{px[0], px[1], px[2], px[3]};
+        else for (int p = 0; p < n; ++p) dp[p] = px[p];
+    } else {
+        uint8_t *dp = dst + (uint64_t)r * dst_pitch + (uint64_t)c0 * 3;
+        if (n == 4) { // twelve bytes as three dwords (rows are 4-byte aligned)
+            uint32_t *d32 = (uint32_t *)dp;
+            d32[0] = (px[0] & 0xffffffu) | (px[1] << 24);
+            d32[1] = ((px[1] >> 8) & 0xffffu) | (px[2] << 16);
+            d32[2] = ((px[2] >> 16) & 0xffu) | (px[3] << 8);
+        } else {
+            for (int p = 0; p < n; ++p) { dp[3 * p] = (uint8_t)px[p]; dp[3 * p + 1] = (uint8_t)(px[p] >> 8); dp[3 * p + 2] = (uint8_t)(px[p] >> 16); }
+        }
+    }
+}
+static bool lab4_back_applies(const zg_image *src, const zg_image *dst, int src_space, int dst_space) {
+    if (src->pixel != ZG_PIXEL_RGB_F32 || src_space != ZG_CS_LAB) return false;
+    if (!((dst->pixel == ZG_PIXEL_RGBA_U8 && dst_space == ZG_CS_RGBA) || (dst->pixel == ZG_PIXEL_RGB_U8 && dst_space == ZG_CS_RGB))) return false;
+    const uint64_t dc = dst->pixel == ZG_PIXEL_RGBA_U8 ? 4 : 3, need = dc == 4 ? 16 : 4;
+    if (((uintptr_t)dst->data % need) || ((uint64_t)dst->stride * dc % need)) return false;
+    if (((uintptr_t)src->data % 16) || ((uint64_t)src->stride * 12 % 16)) return false;
+    static const bool off = getenv("ZIGNAL_HIP_NO_LAB4") != nullptr; // tuning hook (the same one as the forward kernel's)
+    return !off;
+}
+static int launch_lab4_back(const zg_image *src, const zg_image *dst, hipStream_t s) {
+    const dim3 grid = row_grid(ceil_div(ceil_div((unsigned)src->cols, 4u), 256u), (unsigned)src->rows);
+    const uint64_t spitch = (uint64_t)src->stride * 12;
+    if (dst->pixel == ZG_PIXEL_RGBA_U8)
+        hipLaunchKernelGGL(k_lab4_to_u8<4>, grid, dim3(256), 0, s, (const uint8_t *)src->data, (uint8_t *)dst->data, spitch, (uint64_t)dst->stride * 4, (int)src->rows, (int)src->cols);
+    else
+        hipLaunchKernelGGL(k_lab4_to_u8<3>, grid, dim3(256), 0, s, (const uint8_t *)src->data, (uint8_t *)dst->data, spitch, (uint64_t)dst->stride * 3, (int)src->rows, (int)src->cols);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
 // `plain` (optional) comes back true when every entry of the table is +0 or a positive number within [2^-60, 2^60]: what
 // xyz_to_oklab<true> asks for. The library's own sRGB table is (entry 1 is 3.0e-4).
 static int device_srgb_lut(const float *host_lut, hipStream_t s, const float **out, float **owned, bool *plain = nullptr) {
@@ -302,6 +382,7 @@ int convert_impl(const zg_image *src, int src_space, const zg_image *dst, int ds
     if (!fast_pair) { // every other pair of colour spaces: the route-walking kernel (colorspaces.hip)
         if (src->rows == 0 || src->cols == 0) return ZG_OK;
         if (src_space == dst_space && src->pixel == dst->pixel) return copy_impl(src, dst, s);
+        if (lab4_back_applies(src, dst, src_space, dst_space)) return launch_lab4_back(src, dst, s); // Lab(f32) -> Rgb(u8) / Rgba(u8), four pixels per lane
         const float *lut_dev = nullptr; // gammaToLinear(u8 / 255): the caller's table if given, else the library's
         float *lut_owned = nullptr;
         bool plain_lut = false;
@@ -457,7 +538,15 @@ __global__ __launch_bounds__(256) void k_devmath_apply(int fn, const float *x, c
         case 14: r = a / LAB_XN; break;
         case 15: { bool redo; r = dev_div_const_fast(a, LAB_XN, LAB_XN_R, redo); if (redo) r = a / LAB_XN; break; }
         case 16: r = a / LAB_ZN; break;
-        default: { bool redo; r = dev_div_const_fast(a, LAB_ZN, LAB_ZN_R, redo); if (redo) r = a / LAB_ZN; break; }
+        case 17: { bool redo; r = dev_div_const_fast(a, LAB_ZN, LAB_ZN_R, redo); if (redo) r = a / LAB_ZN; break; }
+        case 18: r = dev_linear_to_gamma(a); break;
+        case 19: { bool redo; r = dev_linear_to_gamma_fast(a, redo); if (redo) r = dev_linear_to_gamma(a); break; }
+        case 20: r = a / 116.0f; break;
+        case 21: { bool redo; r = dev_div_const_fast(a, 116.0f, 1.0f / 116.0f, redo); if (redo) r = a / 116.0f; break; }
+        case 22: r = a / 500.0f; break;
+        case 23: { bool redo; r = dev_div_const_fast(a, 500.0f, 1.0f / 500.0f, redo); if (redo) r = a / 500.0f; break; }
+        case 24: r = a / 200.0f; break;
+        default: { bool redo; r = dev_div_const_fast(a, 200.0f, 1.0f / 200.0f, redo); if (redo) r = a / 200.0f; break; }
         }
         out[i] = r;
     }
@@ -493,7 +582,7 @@ int zg_convert_host(const zg_image *src, int src_space, const zg_image *dst, int
 // fn: 0 cbrt, 1 pow(x, 2.4), 2 exp, 3 log, 4 sin, 5 cos, 6 atan2(x, y), 7 pow(x, y), 8 gammaToLinear, 9 cbrt by musl's own steps (what 0 is
 // checked against over all 2^32 inputs). y may be NULL for unary fn.
 int zg_devmath_apply(int fn, const float *x_dev, const float *y_dev, float *out_dev, size_t n, zg_stream stream) {
-    ZG_REQUIRE(fn >= 0 && fn <= 17, ZG_ERR_INVALID_ARGUMENT, "zg_devmath_apply: unknown function %d", fn);
+    ZG_REQUIRE(fn >= 0 && fn <= 25, ZG_ERR_INVALID_ARGUMENT, "zg_devmath_apply: unknown function %d", fn);
     ZG_REQUIRE((x_dev && out_dev) || n == 0, ZG_ERR_INVALID_ARGUMENT, "zg_devmath_apply: null array");
     ZG_REQUIRE((fn != 6 && fn != 7) || y_dev || n == 0, ZG_ERR_INVALID_ARGUMENT, "zg_devmath_apply: function %d needs y", fn);
     if (n == 0) return ZG_OK;

@@ -76,4 +76,44 @@ __device__ inline void xyz_to_lab(float X, float Y, float Z, float &L, float &A,
     B = 200.0f * (fy - fz);
 }
 
+// Lab -> Xyz -> Rgb in [0, 1] (color.zig:1311-1330 labToXyz: f32 quotients widened to f64, the cubes and the white-point products in f64;
+// :1275-1286 xyzToRgb), the constant divisions and linearToGamma's power in their fast forms (zg_devmath.h: each equal to the plain
+// form on every f32; where a fast form hands a value back the plain one runs — one rare branch per group).
+__device__ inline void lab_to_rgb_unit(float L, float A, float B, float (&rgb)[3]) {
+    bool r0, r1, r2;
+    const float l16 = L + 16.0f;
+    float qy = dev_div_const_fast(l16, 116.0f, 1.0f / 116.0f, r0), qa = dev_div_const_fast(A, 500.0f, 1.0f / 500.0f, r1), qb = dev_div_const_fast(B, 200.0f, 1.0f / 200.0f, r2);
+    if (r0 | r1 | r2) {
+        if (r0) qy = l16 / 116.0f;
+        if (r1) qa = A / 500.0f;
+        if (r2) qb = B / 200.0f;
+    }
+    const double fy = (double)qy, fx = (double)qa + fy, fz = fy - (double)qb;
+    const double y3 = fy * fy * fy, x3 = fx * fx * fx, z3 = fz * fz * fz;
+    const double eps = 0.008856, delta = 0.13793103448275862068965517241379, kappa = 7.787;
+    double y = y3, x = x3, z = z3;
+    if (!(y3 > eps) | !(x3 > eps) | !(z3 > eps)) { // dark colours: the linear piece, a true f64 division
+        if (!(y3 > eps)) y = (fy - delta) / kappa;
+        if (!(x3 > eps)) x = (fx - delta) / kappa;
+        if (!(z3 > eps)) z = (fz - delta) / kappa;
+    }
+    const float X = (float)(x * 95.047), Y = (float)(y * 100.000), Z = (float)(z * 108.883);
+    const float sr = X * 3.2406f + Y * -1.5372f + Z * -0.4986f, sg = X * -0.9689f + Y * 1.8758f + Z * 0.0415f, sb = X * 0.0557f + Y * -0.2040f + Z * 1.0570f;
+    bool d0, d1, d2;
+    float lr = dev_div100_fast(sr, d0), lg = dev_div100_fast(sg, d1), lb = dev_div100_fast(sb, d2);
+    if (d0 | d1 | d2) {
+        if (d0) lr = sr / 100.0f;
+        if (d1) lg = sg / 100.0f;
+        if (d2) lb = sb / 100.0f;
+    }
+    bool g0, g1, g2;
+    float cr = dev_linear_to_gamma_fast(lr, g0), cg = dev_linear_to_gamma_fast(lg, g1), cb = dev_linear_to_gamma_fast(lb, g2);
+    if (g0 | g1 | g2) {
+        if (g0) cr = dev_linear_to_gamma(lr);
+        if (g1) cg = dev_linear_to_gamma(lg);
+        if (g2) cb = dev_linear_to_gamma(lb);
+    }
+    rgb[0] = cr; rgb[1] = cg; rgb[2] = cb;
+}
+
 } // namespace zg

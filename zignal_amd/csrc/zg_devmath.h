@@ -169,11 +169,12 @@ __device__ inline float dev_div_const_fast(float x, float D, float R, bool &redo
     const float q = x * R;
     return __builtin_fmaf(__builtin_fmaf(-q, D, x), R, q);
 }
-// std.math.pow(f32, t, 1.0 / 3.0) for 2^-100 <= t < 2^120 — labForward's power (color.zig:1289-1291), Go's algorithm with yi = 0:
-// exp(yf * log(t)), yf = 0.33333334f, musl's expf and logf — with every branch of the two functions turned into selects and their two
-// divisions into dev_div_normal (2 + f in (1.7, 2.42), 2 - c in (1.6, 2.4); numerators 0 or normal). The same operations in the same
-// order as dev_powf(t, 1 / 3.0f): equal bit for bit on every t of the range (tests/test_math_pin.py sweeps all of them).
-__device__ inline float dev_pow_third_fast(float t) {
+// std.math.pow(f32, t, yf) for 2^-100 <= t < 2^120 and a fractional exponent 0 < yf <= 0.5 — labForward's 1 / 3 (color.zig:1289-1291) and
+// linearToGamma's 1 / 2.4 (:1243-1249) — Go's algorithm with yi = 0: exp(yf * log(t)), musl's expf and logf — with every branch of the
+// two functions turned into selects and their two divisions into dev_div_normal (2 + f in (1.7, 2.42), 2 - c in (1.6, 2.4); numerators
+// 0 or normal). The same operations in the same order as dev_powf(t, yf): equal bit for bit on every t of the range
+// (tests/test_math_pin.py sweeps all of them, through labForward and linearToGamma).
+__device__ inline float dev_pow_frac_fast(float t, float yf) {
     // logf(t), t positive and normal
     const float ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f;
     const float Lg1 = 0xaaaaaa.0p-24f, Lg2 = 0xccce13.0p-25f, Lg3 = 0x91e9ee.0p-25f, Lg4 = 0xf89e26.0p-26f;
@@ -187,7 +188,7 @@ __device__ inline float dev_pow_third_fast(float t) {
     const float hfsq = 0.5f * f * f, dk = (float)kl;
     const float lg = s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
     // expf(yf * lg): |argument| < 80 over the range, so no overflow / underflow exits
-    float x = 0.33333334f * lg;
+    float x = yf * lg;
     const float ln2hi = 6.9314575195e-1f, ln2lo = 1.4286067653e-6f, invln2 = 1.4426950216e+0f;
     const float P1 = 1.6666625440e-1f, P2 = -2.7667332906e-3f;
     const uint32_t hx = __float_as_uint(x) & 0x7fffffffu;
@@ -211,8 +212,17 @@ __device__ inline float dev_lab_forward(float t) {
 }
 __device__ inline float dev_lab_forward_fast(float t, bool &redo) { // `redo`: t >= 2^120, inf or nan — the caller takes dev_lab_forward
     redo = !(t < 0x1p120f);
-    const float p = dev_pow_third_fast(t); // garbage for t <= 0.008856 (zero, negative, tiny), never selected there
+    const float p = dev_pow_frac_fast(t, 0.33333333333333333333333333333333f); // garbage for t <= 0.008856 (zero, negative, tiny), never selected there
     return t > 0.008856f ? p : 7.787f * t + 0.13793103448275862068965517241379f;
+}
+// linearToGamma (color.zig:1243-1249; 1.0 / 2.4 is a comptime division) plain and fast, likewise
+__device__ inline float dev_linear_to_gamma(float c) {
+    return c > 0.0031308f ? 1.055f * dev_powf(c, 0.41666666666666666666666666666667f) - 0.055f : c * 12.92f;
+}
+__device__ inline float dev_linear_to_gamma_fast(float c, bool &redo) {
+    redo = !(c < 0x1p120f);
+    const float p = dev_pow_frac_fast(c, 0.41666666666666666666666666666667f);
+    return c > 0.0031308f ? 1.055f * p - 0.055f : c * 12.92f;
 }
 constexpr float LAB_XN = 95.047f, LAB_YN = 100.000f, LAB_ZN = 108.883f; // d65 white (color.zig:1296-1298)
 constexpr float LAB_XN_R = 1.0f / 95.047f, LAB_ZN_R = 1.0f / 108.883f;   // correctly rounded by the compiler
