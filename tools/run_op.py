@@ -70,6 +70,24 @@ elif op in ("shen", "canny", "sobel"):
     t = torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")
     s = zg.Image(t); d = zg.Image(torch.empty((R, R), dtype=torch.uint8, device="cuda"))
     f = {"shen": lambda: s.shen_castan(out=d), "canny": lambda: s.canny(1.4, 50, 150, out=d), "sobel": lambda: s.sobel(out=d)}[op]
+elif op in ("lab", "lab_back"):
+    t = torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")
+    s = zg.Image(t); d = zg.Image(torch.empty((R, R, 3), dtype=torch.float32, device="cuda"))
+    s.convert(zg.CS_LAB, np.float32, out=d)
+    b = zg.Image(torch.empty_like(t))
+    f = (lambda: s.convert(zg.CS_LAB, np.float32, out=d)) if op == "lab" else (lambda: d.convert(zg.CS_RGBA, np.uint8, src_space=zg.CS_LAB, out=b))
+elif op == "resize16":  # sixteen 4096^2 -> 1024^2 frames per launch, two batches alternating (2 GiB of sources)
+    srcs = [torch.randint(0, 256, (16, R, R, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    outs = [torch.empty((16, 1024, 1024, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    p = zg.Pipeline([zg.Step.resize(1024, 1024)])
+    it = [0]
+    def f():
+        it[0] += 1
+        p.run(srcs[it[0] % 2], out=outs[it[0] % 2])
+elif op == "conv5_u8":
+    t = torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")
+    s = zg.Image(t); d = zg.Image(torch.empty_like(t)); k5 = np.full((5, 5), 1 / 25, np.float32)
+    f = lambda: s.convolve(k5, 1, out=d)
 elif op in ("conv3_u8", "conv3_f32"):
     t = torch.rand((R, R, 4), dtype=torch.float32, device="cuda") if op.endswith("f32") else torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")
     s = zg.Image(t); d = zg.Image(torch.empty_like(t)); k3 = np.full((3, 3), 1 / 9, np.float32)
