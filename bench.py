@@ -810,6 +810,29 @@ def extras(zg, torch, np):
         r["frames_per_launch"] = nb
         return r
 
+    def recipe_example():
+        """The recipe of the CLI's own help text (src/cli/pipeline.zig:58-67): resize --width 800 with .lanczos, blur gaussian sigma 2, edges sobel,
+        over 64 frames of 1080p in one zg_batch_pipeline call."""
+        nb, rows, cols = 64, 1080, 1920
+        srcs = [torch.randint(0, 256, (nb, rows, cols, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        outs = [torch.empty((nb, 450, 800, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        pipe = zg.Pipeline([zg.Step.resize(450, 800, I.lanczos), zg.Step.gaussian_blur(2.0), zg.Step.edges_sobel()])
+        ms = _time_kernel(torch, lambda i: pipe.run(srcs[i % 2], out=outs[i % 2]), n=6, warm=2)
+        r = rate(ms, nb * rows * cols, nb * (rows * cols * 4 + 450 * 800 * 4))  # bound: every source frame read once, every result written once
+        r["frames"] = nb
+        return r
+
+    def conv5x5():
+        ring = 8
+        k = np.full((5, 5), 1.0 / 25.0, np.float32)
+        k[2, 2] += 0.25
+        k[0, 0] -= 0.25
+        im = [(zg.Image(s), zg.Image(torch.empty_like(s))) for s in u8_frames(ring, (ROWS, COLS, 4))]
+        ms = _time_kernel(torch, lambda i: im[i % ring][0].convolve(k, out=im[i % ring][1]))
+        return rate(ms, ROWS * COLS, 8 * ROWS * COLS)
+
+    leg("pipeline_example_recipe_64x1080p_rgba_u8", recipe_example)
+    leg("s4_convolve_5x5_rgba_u8_4096", conv5x5)
     leg("s5_box_blur_r2_rgba_u8_4096", lambda: box("rgba"))
     leg("s5_box_blur_r2_u8_4096", lambda: box("grey"))
     leg("s5_box_blur_r1_u8_4096", lambda: box("grey", 1))

@@ -33,7 +33,12 @@ def test_bench_two_rank_path_on_one_gpu():
     assert res["n_gpus"] == 2 and res["steps"] == 100 and res["scaling"] == "weak" and res["value"] > 0
     assert res["ranks"]["ranks_seen"] == 2 and len(res["ranks"]["ms_per_step_per_rank"]) == 2 and len(res["ranks"]["devices"]) == 2
     assert abs(max(res["ranks"]["ms_per_step_per_rank"]) - res["ms_per_step"]) < 1e-3  # the slowest rank is the clock
-    assert "roofline" not in res  # N = 1 legs only
+    # rank 0 reports its own GPU's roofline at every N (so that N = 1 here and the driver's first scaling point agree by construction) and the
+    # N-GPU run carries BASELINE configs[4]'s scatter / compute / gather leg without a flag; extras and the CPU baseline stay N = 1 legs
+    assert res["roofline"]["bound"] == "hbm" and res["roofline"]["achieved"] > 0 and "extras" not in res and "cpu_baseline" not in res
+    sg = res["scatter_gather_config5"]
+    assert sg["frames"] == 256 and sg["kernel_only"]["Mpixels/s"] > 0 and sg["host_staged_pcie"]["Mpixels/s"] > 0
+    assert "skipped" in sg["end_to_end_xgmi"]  # every rank shares cuda:0 under the test hook: RCCL needs one GPU per rank
 
 
 def test_bench_counts_its_rccl_ranks_and_times_the_three_distribution_routes():
