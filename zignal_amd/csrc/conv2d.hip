@@ -228,12 +228,11 @@ static int convolve_impl(const zg_image *src, const zg_image *dst, const float *
             sum_abs += std::llabs((long long)ik[i]);
         }
         mode = (255 * sum_abs < (int64_t)INT32_MAX - 256) ? 1 : 2;
-        static const bool no_f32 = getenv("ZIGNAL_HIP_CONV2D_INT") != nullptr; // tuning hook: integer accumulators for every u8 kernel
         // every partial sum an integer below 2^24: f32 multiply-adds are exact. Used where it was measured faster — the unrolled 3 x 3 and
         // 5 x 5 kernels and the one-channel 7 x 7 (4096^2 Rgba(u8): 78.6 -> 72.9 and 155 -> 127 us; grey 31.9 / 43.2 / 59.1 -> 30.6 / 39.0 / 54.2 us);
         // the run-time-size kernel and 7 x 7 on three or four channels (288 registers when unrolled) keep the integer form
         const bool unrolled = (kh == 3 && kw == 3) || (kh == 5 && kw == 5) || (kh == 7 && kw == 7 && pixel_channels(src->pixel) == 1);
-        if (255 * sum_abs < (1 << 24) && unrolled && !no_f32) mode = 3;
+        if (255 * sum_abs < (1 << 24) && unrolled) mode = 3;
         if (255 * sum_abs < (1 << 24) && kh == kw && (kh == 3 || kh == 5)) {
             // every partial sum an integer below 2^24: one wave per column strip, rows resident in registers (conv2d_stream.hip)
             float fk[25];

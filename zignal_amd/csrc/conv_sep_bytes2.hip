@@ -401,8 +401,7 @@ int try_sep_bytes2(const zg_image *src, const zg_image *dst, const int32_t *ix, 
     const int tiles_x = (int)ceil_div((uint32_t)row_bytes, 1024u);
     const int rows_per_wave = 4;
     const dim3 grid_rows((unsigned)(tiles_x * ceil_div(src->rows, 4u * rows_per_wave)));
-    static const bool int_rows = getenv("ZIGNAL_HIP_ROWS_INT") != nullptr; // tuning hook: the packed-u16 row pass for grey planes too
-    if (sp == 1 && !int_rows) {
+    if (sp == 1) { // grey planes: the f32 row pass (the packed-u16 one lost by a third: profiles/r03_experiments.txt)
         switch ((halfx + 3) / 4) {
         case 0: case 1: launch_rows_u8f<4>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
         case 2: launch_rows_u8f<8>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
@@ -413,16 +412,11 @@ int try_sep_bytes2(const zg_image *src, const zg_image *dst, const int32_t *ix, 
         case 7: launch_rows_u8f<28>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
         default: launch_rows_u8f<32>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
         }
-    } else if (sp == 1) hipLaunchKernelGGL((k_rows_u16<1>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave);
-    else if (sp == 3) hipLaunchKernelGGL((k_rows_u16<3>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave);
+    } else if (sp == 3) hipLaunchKernelGGL((k_rows_u16<3>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave);
     else hipLaunchKernelGGL((k_rows_u16<4>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave);
     const dim3 grid_cols((unsigned)(tiles_x * ceil_div(src->rows, (uint32_t)B2_R)));
-    static const bool int_cols = getenv("ZIGNAL_HIP_COLS_INT") != nullptr; // tuning hook: the integer column pass for every kernel
     if (clamp) hipLaunchKernelGGL((k_cols_u16<true>), grid_cols, dim3(256), 0, s, (const uint32_t *)temp, (uint8_t *)dst->data, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x);
-    else if (int_cols) {
-        for (int j = 0; j < nky; ++j) tc.k[B2_R + j] = (uint32_t)iy[j];
-        hipLaunchKernelGGL((k_cols_u16<false>), grid_cols, dim3(256), 0, s, (const uint32_t *)temp, (uint8_t *)dst->data, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x);
-    } else {
+    else {
         const int tiles_x2 = (int)ceil_div((uint32_t)row_bytes, 512u);
         const dim3 grid2((unsigned)(tiles_x2 * ceil_div(src->rows, (uint32_t)B2_R)));
         hipLaunchKernelGGL(k_cols_u8f, grid2, dim3(256), 0, s, (const uint32_t *)temp, (uint8_t *)dst->data, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x2);

@@ -404,12 +404,10 @@ static int launch_stream(const StreamJob &j, const int32_t *ix, const int32_t *i
 
 // Returns -1 when the preconditions do not hold (caller falls back to the tiled kernels).
 int try_sep_stream(const StreamJob &j, const int32_t *ix, const int32_t *iy, int nk, int border, hipStream_t s) {
-    static const bool off = getenv("ZIGNAL_HIP_NO_STREAM") != nullptr;
-    if (off) return -1;
     if (j.sp != 1 && j.sp != 3 && j.sp != 4) return -1;
     // a single grey plane is the one case the LDS-tiled kernel still wins (10.4 against 11.9 us at 4096^2): 16 pixels per lane leave
     // it little halo to re-convolve, and a 4 KiB-wide row gives this kernel only four strips across
-    if (j.sp == 1 && j.n_frames == 1 && !getenv("ZIGNAL_HIP_STREAM_GREY")) return -1;
+    if (j.sp == 1 && j.n_frames == 1) return -1;
     if (nk != 3 && nk != 5 && nk != 7 && nk != 9) return -1;
     if ((nk / 2 + 1) * j.sp > 16) return -1;
     const uint64_t rb = (uint64_t)j.cols * (uint64_t)j.sp;

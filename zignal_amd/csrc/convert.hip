@@ -229,8 +229,7 @@ static bool lab4_applies(const zg_image *src, const zg_image *dst, int src_space
     const uint64_t sc = src->pixel == ZG_PIXEL_RGBA_U8 ? 4 : 3, need = sc == 4 ? 16 : 4;
     if (((uintptr_t)src->data % need) || ((uint64_t)src->stride * sc % need)) return false;
     if (((uintptr_t)dst->data % 16) || ((uint64_t)dst->stride * 12 % 16)) return false;
-    static const bool off = getenv("ZIGNAL_HIP_NO_LAB4") != nullptr; // tuning hook
-    return !off;
+    return true;
 }
 
 static int launch_lab4(const zg_image *src, const zg_image *dst, int dst_space, const float *lut, bool plain_table, hipStream_t s) {
@@ -315,8 +314,7 @@ static bool lab4_back_applies(const zg_image *src, const zg_image *dst, int src_
     const uint64_t dc = dst->pixel == ZG_PIXEL_RGBA_U8 ? 4 : 3, need = dc == 4 ? 16 : 4;
     if (((uintptr_t)dst->data % need) || ((uint64_t)dst->stride * dc % need)) return false;
     if (((uintptr_t)src->data % 16) || ((uint64_t)src->stride * 12 % 16)) return false;
-    static const bool off = getenv("ZIGNAL_HIP_NO_LAB4") != nullptr; // tuning hook (the same one as the forward kernel's)
-    return !off;
+    return true;
 }
 static int launch_lab4_back(const zg_image *src, const zg_image *dst, hipStream_t s) {
     const dim3 grid = row_grid(ceil_div(ceil_div((unsigned)src->cols, 4u), 256u), (unsigned)src->rows);

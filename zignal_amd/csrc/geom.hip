@@ -175,13 +175,10 @@ static int launch_geom_k(const zg_image *src, const zg_image *dst, const GeomPar
     if constexpr (CAN_STAGE) {
         // for every map: where a wave cannot stage, this kernel's row-at-a-time gather (seven waves per SIMD) still beats the sixteen gathers
         // in flight of the plain one — 2:1 reduction 101 -> 80 us, a 10-degree rotation 350 -> 304 us (profiles/r03_experiments.txt)
-        if (g.stage) {
-            hipLaunchKernelGGL((k_geom<PIX, KIND, true>), grid, dim3(256), 0, s, dimg(src), dimg(dst), g, m, border, tiles_x, fr);
-            ZG_HIP(hipGetLastError());
-            return ZG_OK;
-        }
+        hipLaunchKernelGGL((k_geom<PIX, KIND, true>), grid, dim3(256), 0, s, dimg(src), dimg(dst), g, m, border, tiles_x, fr);
+    } else {
+        hipLaunchKernelGGL((k_geom<PIX, KIND>), grid, dim3(256), 0, s, dimg(src), dimg(dst), g, m, border, tiles_x, fr);
     }
-    hipLaunchKernelGGL((k_geom<PIX, KIND>), grid, dim3(256), 0, s, dimg(src), dimg(dst), g, m, border, tiles_x, fr);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -194,9 +191,8 @@ static int launch_geom(const zg_image *src, const zg_image *dst, const GeomParam
     LutHolder lut;
     if ((rc = device_lanczos_lut(method, s, lut))) return rc;
     const MethodArg m{method->kind, method->b, method->c, lut.dev};
-    static const bool no_stage = getenv("ZIGNAL_HIP_NO_WARP_STAGE") != nullptr; // tuning hook
     GeomParams gp = g;
-    gp.stage = no_stage ? 0 : 1;
+    gp.stage = 1;
     rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
         switch (method->kind) {
@@ -326,8 +322,7 @@ static int launch_resize_bilinear_u8(const zg_image *src, const zg_image *dst, u
     return ZG_OK;
 }
 static bool resize_u8_plane_applies(const zg_image *src, const zg_image *dst, const zg_method *method) {
-    static const bool off = getenv("ZIGNAL_HIP_NO_U8_PLANE_RESIZE") != nullptr; // tuning hook
-    return !off && src->pixel == ZG_PIXEL_U8 && method->kind == ZG_INTERP_BILINEAR && src->rows > 0 && src->cols > 0 && dst->rows > 0 && dst->cols > 0;
+    return src->pixel == ZG_PIXEL_U8 && method->kind == ZG_INTERP_BILINEAR && src->rows > 0 && src->cols > 0 && dst->rows > 0 && dst->cols > 0;
 }
 
 // ---- resize (interpolation.zig:89-191) -----------------------------------------------------------
