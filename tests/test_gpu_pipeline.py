@@ -152,6 +152,25 @@ def test_the_reference_example_recipe_on_64_frames_of_1080p(oracle):
         assert np.array_equal(got[f], want), f"frame {f} differs from the oracle"
 
 
+@pytest.mark.parametrize("ch", (1, 3, 4))
+def test_long_tap_blur_and_plane_resizers_run_with_the_frame_in_the_grid(oracle, ch):
+    """The two-pass u16 Gaussian (conv_sep_bytes2.hip) and the Rgb(u8) / Rgba(u8) plane resizers (resize_planes.hip) take the whole batch
+    per launch (frame = blockIdx.y): the same bits as the per-frame calls for every method and for sigmas on both sides of the u16 temp's
+    clamp, and frame 0 against the oracle."""
+    cols = {1: 512, 3: 336, 4: 192}[ch]  # row bytes a multiple of 16 and >= 256: the two-pass kernels' precondition
+    host = frames_u8(oracle, 300 + ch, 5, 77, cols, ch)
+    for sigma in (1.6, 2.0, 4.5):
+        got = check(host, [zg.Step.gaussian_blur(sigma)], lambda im: im.gaussian_blur(sigma), f"blur {sigma} ch {ch}")
+        assert np.array_equal(got[0], oracle.gaussian_blur(host[0], sigma))
+    if ch == 1:
+        return
+    for m, om in ((I.nearest, oracle.NEAREST), (I.bilinear, oracle.BILINEAR), (I.bicubic, oracle.BICUBIC), (I.catmull_rom, oracle.CATMULL_ROM),
+                  (I.mitchell_default, oracle.MITCHELL), (I.lanczos, oracle.LANCZOS)):
+        for shape in ((40, 100), (131, 333)):
+            got = check(host, [zg.Step.resize(*shape, m)], lambda im: im.resize(shape, m), f"resize {m} {shape} ch {ch}")
+            assert np.array_equal(got[0], oracle.resize(host[0], shape, oracle.method(om)))
+
+
 def test_every_blur_type_and_edge_detector_of_the_cli_as_a_step(oracle):
     """blur: box, gaussian, median, motion_linear, motion_zoom, motion_spin (src/cli/blur.zig:98-170); edges: sobel, canny, shen_castan
     through the grey bridge (src/cli/edges.zig:85-135) — each as one step over a batch, against the oracle per frame."""

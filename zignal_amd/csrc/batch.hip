@@ -103,6 +103,12 @@ int run_blur(const Frames &in, const Frames &out, float sigma, hipStream_t s) {
             const StreamJob job{in.data, out.data, in.n, in.rows, in.cols, (int)sp, in.cols * sp, in.cols * sp, in.frame_bytes(), in.frame_bytes(), false};
             const int rc = try_sep_stream(job, taps.data(), taps.data(), (int)taps.size(), ZG_BORDER_MIRROR, s);
             if (rc >= 0) return rc;
+            if (in.n > 1) { // longer kernels: the two passes through the u16 temp planes, the frame in the grid
+                const zg_image a = in.frame(0), b = out.frame(0);
+                const int rc2 = try_sep_bytes2_frames(&a, &b, in.n, in.frame_bytes(), in.frame_bytes(), taps.data(), (int)taps.size(), taps.data(),
+                                                      (int)taps.size(), ZG_BORDER_MIRROR, s);
+                if (rc2 >= 0) return rc2;
+            }
         }
     }
     return per_frame(in, out, [&](const zg_image *a, const zg_image *b) { return zg_gaussian_blur(a, b, sigma, (zg_stream)s); });

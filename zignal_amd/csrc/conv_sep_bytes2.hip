@@ -34,6 +34,9 @@ constexpr int B2_R = 32;     // output rows per lane in the column pass
 constexpr int B2_LEFT = 32;  // LDS halo dwords left of the tile (128 bytes >= hpad * SP)
 constexpr int B2_ROW = B2_LEFT + 256 + 36; // + right halo: hpad * SP <= 128 bytes and the 3 * SP + 3 bytes a group overshoots
 
+// Batches: frame f of the launch reads src + f * src_frame bytes, goes through temp + f * temp_frame dwords, writes dst + f * dst_frame.
+struct B2Frames { size_t src_frame, temp_frame, dst_frame; };
+
 struct TapsRows { uint32_t kk[4 * (B2_HMAX / 2 + 1)]; }; // tap | tap << 16, index = offset + hpad, zero padded
 struct TapsCols { uint32_t k[B2_NKMAX + 2 * B2_R]; };    // k[B2_R + j] = tap j, zeros around
 
@@ -77,7 +80,9 @@ __device__ __forceinline__ void stage_row(uint32_t *buf, const uint8_t *row, int
 
 template <int SP>
 __global__ __launch_bounds__(256) void k_rows_u16(DImg src, uint32_t *temp, TapsRows taps, int hpad, int ngroups, int border,
-                                                  int tiles_x, int rows_per_wave) {
+                                                  int tiles_x, int rows_per_wave, B2Frames fr) {
+    src.data = (uint8_t *)src.data + (size_t)blockIdx.y * fr.src_frame; // the frame is the grid's y
+    temp += (size_t)blockIdx.y * fr.temp_frame;
     constexpr int NW = SP == 1 ? 2 : 4; // window dwords of a group: 4 output bytes + 3 * SP bytes of tap reach
     __shared__ uint32_t lds[4][B2_ROW];
     const int lane = threadIdx.x & 63;
@@ -137,7 +142,9 @@ __global__ __launch_bounds__(256) void k_rows_u16(DImg src, uint32_t *temp, Taps
 // taps past the kernel are zeros.
 struct TapsRowsU8F { float k[2 * B2_HMAX + 1]; }; // k[offset + HP]
 template <int HP>
-__global__ __launch_bounds__(256) void k_rows_u8f(DImg src, uint32_t *temp, TapsRowsU8F taps, int border, int tiles_x, int rows_per_wave) {
+__global__ __launch_bounds__(256) void k_rows_u8f(DImg src, uint32_t *temp, TapsRowsU8F taps, int border, int tiles_x, int rows_per_wave, B2Frames fr) {
+    src.data = (uint8_t *)src.data + (size_t)blockIdx.y * fr.src_frame;
+    temp += (size_t)blockIdx.y * fr.temp_frame;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     constexpr int ND = 4 + HP / 2; // dwords of a lane's window
     __shared__ uint32_t lds[4][B2_ROW];
@@ -183,10 +190,10 @@ __global__ __launch_bounds__(256) void k_rows_u8f(DImg src, uint32_t *temp, Taps
     }
 }
 template <int HP>
-static void launch_rows_u8f(const zg_image *src, uint32_t *temp, const int32_t *ix, int nkx, int border, int tiles_x, int rows_per_wave, dim3 grid, hipStream_t s) {
+static void launch_rows_u8f(const zg_image *src, uint32_t *temp, const int32_t *ix, int nkx, int border, int tiles_x, int rows_per_wave, dim3 grid, const B2Frames &fr, hipStream_t s) {
     TapsRowsU8F t{};
     for (int j = 0; j < nkx; ++j) t.k[j - nkx / 2 + HP] = (float)ix[j];
-    hipLaunchKernelGGL((k_rows_u8f<HP>), grid, dim3(256), 0, s, dimg(src), temp, t, border, tiles_x, rows_per_wave);
+    hipLaunchKernelGGL((k_rows_u8f<HP>), grid, dim3(256), 0, s, dimg(src), temp, t, border, tiles_x, rows_per_wave, fr);
 }
 
 template <bool CLAMP, bool INSIDE>
@@ -276,7 +283,9 @@ __device__ __forceinline__ void cols_strip(const uint32_t *temp, uint8_t *dst, s
 
 template <bool CLAMP>
 __global__ __launch_bounds__(256) void k_cols_u16(const uint32_t *temp, uint8_t *dst, size_t dst_pitch, int rows, int row_bytes,
-                                                  TapsCols taps, int nk, int half, int border, int tiles_x) {
+                                                  TapsCols taps, int nk, int half, int border, int tiles_x, B2Frames fr) {
+    temp += (size_t)blockIdx.y * fr.temp_frame;
+    dst += (size_t)blockIdx.y * fr.dst_frame;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int y0 = ty * B2_R;
     if (y0 - half >= 0 && y0 - half + B2_R + nk - 1 <= rows) // workgroup-uniform: every streamed row is inside the image
@@ -357,7 +366,9 @@ __device__ __forceinline__ void cols_strip_u8f(const uint32_t *temp, uint8_t *ds
 }
 
 __global__ __launch_bounds__(256) void k_cols_u8f(const uint32_t *temp, uint8_t *dst, size_t dst_pitch, int rows, int row_bytes,
-                                                  TapsCols taps, int nk, int half, int border, int tiles_x) {
+                                                  TapsCols taps, int nk, int half, int border, int tiles_x, B2Frames fr) {
+    temp += (size_t)blockIdx.y * fr.temp_frame;
+    dst += (size_t)blockIdx.y * fr.dst_frame;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int y0 = ty * B2_R;
     if (y0 - half >= 0 && y0 - half + B2_R + nk - 1 <= rows) // workgroup-uniform: every streamed row is inside the image
@@ -368,6 +379,13 @@ __global__ __launch_bounds__(256) void k_cols_u8f(const uint32_t *temp, uint8_t 
 
 // Returns -1 when the preconditions do not hold (caller falls back to the general kernels).
 int try_sep_bytes2(const zg_image *src, const zg_image *dst, const int32_t *ix, int nkx, const int32_t *iy, int nky, int border, hipStream_t s) {
+    return try_sep_bytes2_frames(src, dst, 1, 0, 0, ix, nkx, iy, nky, border, s);
+}
+
+// n frames of src's geometry, src_frame / dst_frame BYTES apart: the two passes run once per chunk of frames whose temp planes fit the
+// scratch budget, frame = blockIdx.y.
+int try_sep_bytes2_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, const int32_t *ix, int nkx,
+                          const int32_t *iy, int nky, int border, hipStream_t s) {
     if (src->pixel != ZG_PIXEL_U8 && src->pixel != ZG_PIXEL_RGB_U8 && src->pixel != ZG_PIXEL_RGBA_U8) return -1;
     if (nkx < 1 || nky < 1 || nkx > B2_NKMAX || nky > B2_NKMAX) return -1;
     const size_t sp = pixel_size(src->pixel);
@@ -395,31 +413,42 @@ int try_sep_bytes2(const zg_image *src, const zg_image *dst, const int32_t *ix, 
     }
 
     const int row_bytes = (int)(src->cols * sp);
-    uint32_t *temp = nullptr;
     // + 16 slack rows: the column pass prefetches up to 15 rows past a strip's last one (their taps are zero)
-    if (int rc = scratch_alloc((void **)&temp, ((size_t)src->rows + 16) * row_bytes * 2, s)) return rc;
+    const size_t temp_bytes = ((size_t)src->rows + 16) * row_bytes * 2;
+    if (n > 1 && ((src_frame | dst_frame) & 15)) return -1;
+    const uint32_t per_launch = (uint32_t)std::min<size_t>(std::min(n, MAX_FRAMES_PER_LAUNCH), std::max<size_t>(1, scratch_block_budget() / 2 / temp_bytes));
+    uint32_t *temp = nullptr;
+    if (int rc = scratch_alloc((void **)&temp, temp_bytes * per_launch, s)) return rc;
     const int tiles_x = (int)ceil_div((uint32_t)row_bytes, 1024u);
     const int rows_per_wave = 4;
-    const dim3 grid_rows((unsigned)(tiles_x * ceil_div(src->rows, 4u * rows_per_wave)));
-    if (sp == 1) { // grey planes: the f32 row pass (the packed-u16 one lost by a third: profiles/r03_experiments.txt)
-        switch ((halfx + 3) / 4) {
-        case 0: case 1: launch_rows_u8f<4>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
-        case 2: launch_rows_u8f<8>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
-        case 3: launch_rows_u8f<12>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
-        case 4: launch_rows_u8f<16>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
-        case 5: launch_rows_u8f<20>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
-        case 6: launch_rows_u8f<24>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
-        case 7: launch_rows_u8f<28>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
-        default: launch_rows_u8f<32>(src, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, s); break;
+    for (uint32_t f0 = 0; f0 < n; f0 += per_launch) {
+        const uint32_t nf = std::min(per_launch, n - f0);
+        zg_image a = *src;
+        a.data = (uint8_t *)src->data + (size_t)f0 * src_frame;
+        uint8_t *out = (uint8_t *)dst->data + (size_t)f0 * dst_frame;
+        const B2Frames fr{src_frame, temp_bytes / 4, dst_frame};
+        const dim3 grid_rows((unsigned)(tiles_x * ceil_div(src->rows, 4u * rows_per_wave)), nf);
+        if (sp == 1) { // grey planes: the f32 row pass (the packed-u16 one lost by a third: profiles/r03_experiments.txt)
+            switch ((halfx + 3) / 4) {
+            case 0: case 1: launch_rows_u8f<4>(&a, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, fr, s); break;
+            case 2: launch_rows_u8f<8>(&a, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, fr, s); break;
+            case 3: launch_rows_u8f<12>(&a, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, fr, s); break;
+            case 4: launch_rows_u8f<16>(&a, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, fr, s); break;
+            case 5: launch_rows_u8f<20>(&a, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, fr, s); break;
+            case 6: launch_rows_u8f<24>(&a, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, fr, s); break;
+            case 7: launch_rows_u8f<28>(&a, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, fr, s); break;
+            default: launch_rows_u8f<32>(&a, temp, ix, nkx, border, tiles_x, rows_per_wave, grid_rows, fr, s); break;
+            }
+        } else if (sp == 3) hipLaunchKernelGGL((k_rows_u16<3>), grid_rows, dim3(256), 0, s, dimg(&a), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave, fr);
+        else hipLaunchKernelGGL((k_rows_u16<4>), grid_rows, dim3(256), 0, s, dimg(&a), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave, fr);
+        if (clamp) {
+            const dim3 grid_cols((unsigned)(tiles_x * ceil_div(src->rows, (uint32_t)B2_R)), nf);
+            hipLaunchKernelGGL((k_cols_u16<true>), grid_cols, dim3(256), 0, s, (const uint32_t *)temp, out, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x, fr);
+        } else {
+            const int tiles_x2 = (int)ceil_div((uint32_t)row_bytes, 512u);
+            const dim3 grid2((unsigned)(tiles_x2 * ceil_div(src->rows, (uint32_t)B2_R)), nf);
+            hipLaunchKernelGGL(k_cols_u8f, grid2, dim3(256), 0, s, (const uint32_t *)temp, out, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x2, fr);
         }
-    } else if (sp == 3) hipLaunchKernelGGL((k_rows_u16<3>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave);
-    else hipLaunchKernelGGL((k_rows_u16<4>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, hpad, ngroups, border, tiles_x, rows_per_wave);
-    const dim3 grid_cols((unsigned)(tiles_x * ceil_div(src->rows, (uint32_t)B2_R)));
-    if (clamp) hipLaunchKernelGGL((k_cols_u16<true>), grid_cols, dim3(256), 0, s, (const uint32_t *)temp, (uint8_t *)dst->data, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x);
-    else {
-        const int tiles_x2 = (int)ceil_div((uint32_t)row_bytes, 512u);
-        const dim3 grid2((unsigned)(tiles_x2 * ceil_div(src->rows, (uint32_t)B2_R)));
-        hipLaunchKernelGGL(k_cols_u8f, grid2, dim3(256), 0, s, (const uint32_t *)temp, (uint8_t *)dst->data, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x2);
     }
     const hipError_t e = hipGetLastError();
     scratch_free(temp, s);

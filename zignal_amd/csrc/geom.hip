@@ -342,14 +342,14 @@ int resize_impl(const zg_image *src, const zg_image *dst, const zg_method *metho
 }
 
 // resize of n equally shaped frames in one launch where the path is a single kernel with a frame index (the generic interpolators of every
-// type that is not Rgb(u8) / Rgba(u8), and Rgba(u8) bilinear); -1 otherwise (zg_batch_pipeline then goes frame by frame).
+// type, and the Rgb(u8) / Rgba(u8) plane resizers); -1 otherwise (zg_batch_pipeline then goes frame by frame).
 int resize_frames(const zg_image *src, const zg_image *dst, const zg_method *method, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s) {
     int rc;
     if ((rc = check_pair(src, dst, "resize")) || (rc = check_method(method))) return rc;
     if (n == 0 || dst->rows == 0 || dst->cols == 0 || src->rows == 0 || src->cols == 0) return -1;
     if (src->rows == dst->rows && src->cols == dst->cols) return -1; // a copy per frame
     const bool is_rgb_u8 = src->pixel == ZG_PIXEL_RGB_U8 || src->pixel == ZG_PIXEL_RGBA_U8;
-    if (is_rgb_u8) return method->kind == ZG_INTERP_BILINEAR ? resize_bilinear_rgba8_frames(src, dst, n, src_frame, dst_frame, s) : -1;
+    if (is_rgb_u8) return resize_planes_frames(src, dst, method, n, src_frame, dst_frame, s); // every method: the frame is the grid's y
     if (resize_u8_plane_applies(src, dst, method)) return launch_resize_bilinear_u8(src, dst, n, src_frame, dst_frame, s);
     GeomParams g{};
     g.mode = GEOM_RESIZE;

@@ -91,8 +91,10 @@ __device__ inline void axis_taps(int d, float ratio, int n, int (&idx)[T], int (
 }
 
 template <int PIX, int CLS, int KIND, int T>
-__global__ __launch_bounds__(256) void k_resize_planes(DImg src, DImg dst, AxisTable tx, AxisTable ty, float ratio_x, float ratio_y, int tiles_x) {
+__global__ __launch_bounds__(256) void k_resize_planes(DImg src, DImg dst, AxisTable tx, AxisTable ty, float ratio_x, float ratio_y, int tiles_x, FrameSpan fr) {
     using P = Px<PIX>;
+    src.data = (uint8_t *)src.data + (size_t)blockIdx.y * fr.src_frame; // the frame is the grid's y
+    dst.data = (uint8_t *)dst.data + (size_t)blockIdx.y * fr.dst_frame;
     using Vec = typename P::Vec;
     constexpr int C = P::C;
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
@@ -361,33 +363,40 @@ int resize_bilinear_rgba8_frames(const zg_image *src, const zg_image *dst, uint3
 }
 
 template <int PIX, int CLS, int KIND, int T>
-static int launch_planes(const zg_image *src, const zg_image *dst, const AxisTable &tx, const AxisTable &ty, hipStream_t s) {
+static int launch_planes(const zg_image *src, const zg_image *dst, const AxisTable &tx, const AxisTable &ty, uint32_t n, const FrameSpan &fr, hipStream_t s) {
     const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, 4);
     const float ratio_x = (float)src->cols / (float)dst->cols, ratio_y = (float)src->rows / (float)dst->rows;
     if constexpr (PIX == ZG_PIXEL_RGBA_U8 && CLS == RC_BILINEAR) {
-        const int rcb = resize_bilinear_rgba8_frames(src, dst, 1, 0, 0, s);
+        const int rcb = resize_bilinear_rgba8_frames(src, dst, n, fr.src_frame, fr.dst_frame, s);
         if (rcb >= 0) return rcb;
     }
-    hipLaunchKernelGGL((k_resize_planes<PIX, CLS, KIND, T>), dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, s, dimg(src), dimg(dst), tx, ty,
-                       ratio_x, ratio_y, tiles_x);
+    if (n > MAX_FRAMES_PER_LAUNCH) return -1;
+    hipLaunchKernelGGL((k_resize_planes<PIX, CLS, KIND, T>), dim3((unsigned)(tiles_x * tiles_y), n), dim3(256), 0, s, dimg(src), dimg(dst), tx, ty,
+                       ratio_x, ratio_y, tiles_x, fr);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
 
 template <int PIX>
-static int resize_planes_pix(const zg_image *src, const zg_image *dst, int kind, const AxisTable &tx, const AxisTable &ty, hipStream_t s) {
+static int resize_planes_pix(const zg_image *src, const zg_image *dst, int kind, const AxisTable &tx, const AxisTable &ty, uint32_t n, const FrameSpan &fr, hipStream_t s) {
     switch (kind) {
-    case ZG_INTERP_NEAREST: return launch_planes<PIX, RC_NEAREST, ZG_INTERP_NEAREST, 1>(src, dst, tx, ty, s);
-    case ZG_INTERP_BILINEAR: return launch_planes<PIX, RC_BILINEAR, ZG_INTERP_BILINEAR, 2>(src, dst, tx, ty, s);
-    case ZG_INTERP_LANCZOS: return launch_planes<PIX, RC_LANCZOS, ZG_INTERP_LANCZOS, 6>(src, dst, tx, ty, s);
-    case ZG_INTERP_BICUBIC: return launch_planes<PIX, RC_CUBIC_INT, ZG_INTERP_BICUBIC, 4>(src, dst, tx, ty, s);
-    case ZG_INTERP_CATMULL_ROM: return launch_planes<PIX, RC_CUBIC_INT, ZG_INTERP_CATMULL_ROM, 4>(src, dst, tx, ty, s);
-    default: return launch_planes<PIX, RC_CUBIC_INT, ZG_INTERP_MITCHELL, 4>(src, dst, tx, ty, s);
+    case ZG_INTERP_NEAREST: return launch_planes<PIX, RC_NEAREST, ZG_INTERP_NEAREST, 1>(src, dst, tx, ty, n, fr, s);
+    case ZG_INTERP_BILINEAR: return launch_planes<PIX, RC_BILINEAR, ZG_INTERP_BILINEAR, 2>(src, dst, tx, ty, n, fr, s);
+    case ZG_INTERP_LANCZOS: return launch_planes<PIX, RC_LANCZOS, ZG_INTERP_LANCZOS, 6>(src, dst, tx, ty, n, fr, s);
+    case ZG_INTERP_BICUBIC: return launch_planes<PIX, RC_CUBIC_INT, ZG_INTERP_BICUBIC, 4>(src, dst, tx, ty, n, fr, s);
+    case ZG_INTERP_CATMULL_ROM: return launch_planes<PIX, RC_CUBIC_INT, ZG_INTERP_CATMULL_ROM, 4>(src, dst, tx, ty, n, fr, s);
+    default: return launch_planes<PIX, RC_CUBIC_INT, ZG_INTERP_MITCHELL, 4>(src, dst, tx, ty, n, fr, s);
     }
 }
 
 // Image(Rgb(u8) / Rgba(u8)).resize for differing sizes; caller (resize_impl) has validated the images.
 int resize_planes_impl(const zg_image *src, const zg_image *dst, const zg_method *method, hipStream_t s) {
+    return resize_planes_frames(src, dst, method, 1, 0, 0, s);
+}
+
+// n frames of the same two shapes in one launch (frame = blockIdx.y); -1 past the grid's limit.
+int resize_planes_frames(const zg_image *src, const zg_image *dst, const zg_method *method, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s) {
+    const FrameSpan fr{src_frame, dst_frame};
     const int kind = method->kind;
     const int taps = kind == ZG_INTERP_NEAREST ? 1 : (kind == ZG_INTERP_BILINEAR ? 2 : (kind == ZG_INTERP_LANCZOS ? 6 : 4));
     AxisTable tx{}, ty{};
@@ -397,8 +406,8 @@ int resize_planes_impl(const zg_image *src, const zg_image *dst, const zg_method
         if ((rc = axis_table(kind, src->cols, dst->cols, taps, tx, hold_x))) return rc;
         if ((rc = axis_table(kind, src->rows, dst->rows, taps, ty, hold_y))) return rc;
     }
-    if (src->pixel == ZG_PIXEL_RGB_U8) return resize_planes_pix<ZG_PIXEL_RGB_U8>(src, dst, kind, tx, ty, s);
-    return resize_planes_pix<ZG_PIXEL_RGBA_U8>(src, dst, kind, tx, ty, s);
+    if (src->pixel == ZG_PIXEL_RGB_U8) return resize_planes_pix<ZG_PIXEL_RGB_U8>(src, dst, kind, tx, ty, n, fr, s);
+    return resize_planes_pix<ZG_PIXEL_RGBA_U8>(src, dst, kind, tx, ty, n, fr, s);
 }
 
 
@@ -427,8 +436,8 @@ int resize_lanczos_weights_impl(const zg_image *src, const zg_image *dst, const 
     if ((rc = scratch_alloc((void **)&dev, host.size() * 4, s))) return rc;
     if ((rc = upload_pageable(dev, host.data(), host.size() * 4, s)) == ZG_OK) {
         const AxisTable tx{dev, dev + nx}, ty{dev + 2 * nx, dev + 2 * nx + ny};
-        rc = src->pixel == ZG_PIXEL_RGB_U8 ? resize_planes_pix<ZG_PIXEL_RGB_U8>(src, dst, ZG_INTERP_LANCZOS, tx, ty, s)
-                                           : resize_planes_pix<ZG_PIXEL_RGBA_U8>(src, dst, ZG_INTERP_LANCZOS, tx, ty, s);
+        rc = src->pixel == ZG_PIXEL_RGB_U8 ? resize_planes_pix<ZG_PIXEL_RGB_U8>(src, dst, ZG_INTERP_LANCZOS, tx, ty, 1, FrameSpan{0, 0}, s)
+                                           : resize_planes_pix<ZG_PIXEL_RGBA_U8>(src, dst, ZG_INTERP_LANCZOS, tx, ty, 1, FrameSpan{0, 0}, s);
     }
     scratch_free(dev, s);
     return rc;

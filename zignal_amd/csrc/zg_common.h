@@ -203,6 +203,7 @@ struct FrameSpan {
 };
 constexpr uint32_t MAX_FRAMES_PER_LAUNCH = 65535; // gridDim.y
 int resize_bilinear_rgba8_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s);              // resize_planes.hip
+int resize_planes_frames(const zg_image *src, const zg_image *dst, const zg_method *method, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s); // resize_planes.hip
 int resize_frames(const zg_image *src, const zg_image *dst, const zg_method *method, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s);       // geom.hip
 int warp_frames(const zg_image *src, const zg_image *dst, int kind, const float *mat, const zg_method *method, uint32_t n, size_t src_frame, size_t dst_frame,
                 hipStream_t s);                                                                                                                        // geom.hip
@@ -228,6 +229,8 @@ int try_sep_mfma(const StreamJob &j, const int32_t *ix, const int32_t *iy, int n
 int scratch_alloc(void **out, size_t bytes, hipStream_t s);
 int host_threads(); // ZIGNAL_HIP_HOST_THREADS, else min(16, hardware threads)
 void scratch_free(void *p, hipStream_t s);
+int try_sep_bytes2_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, const int32_t *ix, int nkx,
+                          const int32_t *iy, int nky, int border, hipStream_t s); // conv_sep_bytes2.hip
 size_t scratch_block_budget(); // bytes one long-lived scratch block may take so that a few of them stay cached (a quarter of the cache limit)
 
 } // namespace zg
