@@ -382,6 +382,13 @@ ZG_API int zg_morph_host(const zg_image *src, const zg_image *dst, const uint8_t
 ZG_API int zg_canny(const zg_image *src, const zg_image *dst, float sigma, float low_threshold, float high_threshold, zg_stream stream);
 ZG_API int zg_canny_host(const zg_image *src, const zg_image *dst, float sigma, float low_threshold, float high_threshold);
 
+/* Diagnostics, not part of Image(T): shenCastan's smoothing stage on its own — isefFilter2D (src/image/edges.zig:308-349, a private
+ * function there): isefFilter1D (:283-305) along every row, then along every column, of a contiguous Image(f32) plane on the device.
+ * src -> dst (dst may not alias src). The device runs the recursions in overlapping segments and proves each segment's start against its
+ * predecessor's exact value (zignal_amd/csrc/isef.hip); this entry point is how that is held to the sequential recursion bit for bit
+ * (tests/test_next_rows.py). */
+ZG_API int zg_isef_smooth(const zg_image *src, const zg_image *dst, float smooth, zg_stream stream);
+
 /* Image(T).shenCastan (src/image.zig:1015-1027 -> src/image/edges.zig:83-196; options src/image/ShenCastan.zig:9-45:
  * smooth 0.9, window_size 7, high_ratio 0.99, low_rel 0.5, hysteresis true, use_nms false by default). dst is Image(u8),
  * 0 or 255. InvalidBParameter / WindowSizeMustBeOdd / WindowSizeTooSmall / InvalidThreshold -> ZG_ERR_INVALID_ARGUMENT.

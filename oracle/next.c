@@ -270,6 +270,17 @@ static void isef_1d(float *data, size_t n, size_t stride, float b, float *temp) 
     if (n > 1)
         for (size_t i = n - 1; i-- > 0;) data[i * stride] = b * temp[i] + a * data[(i + 1) * stride];
 }
+/* isefFilter2D (edges.zig:308-349) on a contiguous f32 plane, in place: every row, then every column. Exposed so that the device's segmented
+ * recursions can be held to the sequential ones bit for bit (test infrastructure, like the rest of this file). */
+ZO_API int zo_isef_plane(float *plane, uint32_t rows, uint32_t cols, float smooth) {
+    if (!(smooth > 0 && smooth < 1)) return 3;
+    if (rows == 0 || cols == 0) return 0;
+    float *tmp = (float *)malloc((size_t)(rows > cols ? rows : cols) * 4);
+    for (size_t r = 0; r < rows; ++r) isef_1d(plane + r * cols, cols, 1, smooth, tmp);
+    for (size_t c = 0; c < cols; ++c) isef_1d(plane + c, rows, cols, smooth, tmp);
+    free(tmp);
+    return 0;
+}
 static float sc_sat_sum(const float *sat, size_t stride, size_t r1, size_t c1, size_t r2, size_t c2) { /* integral.zig:85-90 */
     return sat[r2 * stride + c2] - (c1 > 0 ? sat[r2 * stride + (c1 - 1)] : 0) - (r1 > 0 ? sat[(r1 - 1) * stride + c2] : 0) +
            ((r1 > 0 && c1 > 0) ? sat[(r1 - 1) * stride + (c1 - 1)] : 0);

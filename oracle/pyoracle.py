@@ -457,6 +457,15 @@ def shen_castan(src, smooth=0.9, window_size=7, high_ratio=0.99, low_rel=0.5, hy
     return out
 
 
+def isef_plane(plane, smooth=0.9):
+    """isefFilter2D (edges.zig:308-349) of a contiguous f32 plane; returns a new array."""
+    out = np.ascontiguousarray(plane, dtype=np.float32).copy()
+    fn = lib().zo_isef_plane
+    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float]
+    _check(fn(out.ctypes.data, out.shape[0], out.shape[1], C.c_float(smooth)), "isef_plane")
+    return out
+
+
 def motion_blur_linear(src, angle, distance, cos_sin=None):
     out = np.empty_like(src)
     ca, sa = cos_sin if cos_sin is not None else (float(np.cos(np.float32(angle), dtype=np.float32)), float(np.sin(np.float32(angle), dtype=np.float32)))

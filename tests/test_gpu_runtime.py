@@ -118,7 +118,9 @@ ALTERNATIVE_FORMS = {
     "ZIGNAL_HIP_MFMA": "k_sep_mfma (both passes of the u8 Gaussian on the matrix pipe) instead of k_sep_stream",
     "ZIGNAL_HIP_NO_CONV2D_STREAM": "the LDS-tiled k_conv2d instead of k_conv2d_stream",
     "ZIGNAL_HIP_NO_SOBEL_STREAM": "the LDS-tiled k_sobel instead of k_sobel_stream",
-    "ZIGNAL_HIP_ISEF_TRANSPOSE": "two transposes around k_isef_cols instead of the role-split k_isef along the rows",
+    "ZIGNAL_HIP_ISEF_TRANSPOSE": "two transposes around k_isef_cols instead of the recursions along the rows",
+    "ZIGNAL_HIP_ISEF_SERIAL": "the role-split k_isef (one chain per row / column from end to end) instead of the segmented k_isef_spec",
+    "ZIGNAL_HIP_ISEF_W=4": "k_isef_spec with a four-step warm-up: segments start wrong all over the plane and the repair launch redoes them",
 }
 
 
@@ -163,8 +165,11 @@ for n in (3, 5, 7):
 same(dev(rgba).sobel(), o.sobel(rgba), "sobel rgba")
 same(dev(grey).sobel(), o.sobel(grey), "sobel grey")
 same(dev(grey).shen_castan(), o.shen_castan(grey), "shen-castan grey")
+plane = rng.integers(0, 256, (333, 1296)).astype(np.float32)
+for smooth in (0.95, 0.9, 0.7, 0.4):
+    same(dev(plane).isef_smooth(smooth), o.isef_plane(plane, smooth), "isef %%g" %% smooth)
 same(dev(rgba).shen_castan(smooth=0.6, use_nms=True), o.shen_castan(rgba, smooth=0.6, use_nms=True), "shen-castan rgba")
 print("ok")
 ''' % ROOT
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **{hook: "1"}))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **{hook.partition("=")[0]: hook.partition("=")[2] or "1"}))
     assert out.returncode == 0 and "ok" in out.stdout, (ALTERNATIVE_FORMS[hook], out.stdout[-400:], out.stderr[-1200:])

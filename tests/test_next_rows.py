@@ -320,6 +320,26 @@ def _sc_square():
     return img
 
 
+@pytest.mark.gpu
+def test_isef_segments_equal_the_sequential_recursions(oracle):
+    """isefFilter2D (edges.zig:283-349) is two dependent recursions per row and per column; the device cuts them into overlapping segments
+    (k_isef_spec) and proves every segment's start against its predecessor (the repair launch). The smoothed plane itself, bit for bit, for
+    noise, a ramp, constants and signed values, for smoothing factors on both sides of the point where the warm-up outgrows a window (then the
+    sequential kernel runs), for shapes with partial windows, partial chain groups and rows the 16-byte loads exclude."""
+    rng = np.random.default_rng(77)
+    for rows, cols in ((1, 4), (3, 8), (64, 64), (65, 132), (130, 516), (257, 1028), (700, 900), (1080, 1920), (33, 30), (200, 131)):
+        planes = {
+            "noise": rng.integers(0, 256, (rows, cols)).astype(np.float32),
+            "signed": ((rng.random((rows, cols), dtype=np.float32) - 0.5) * 1e3).astype(np.float32),
+            "ramp": (np.arange(rows * cols, dtype=np.float32).reshape(rows, cols) % 251),
+            "zeros": np.zeros((rows, cols), np.float32),
+        }
+        for what, plane in planes.items():
+            for smooth in (0.9, 0.7, 0.97, 0.3):
+                got = zg.Image(torch.from_numpy(plane).cuda()).isef_smooth(smooth).to_numpy()
+                assert_bits_equal(got, oracle.isef_plane(plane, smooth), f"isef {what} {rows}x{cols} smooth {smooth}")
+
+
 def test_shen_castan_reference_known_answers_oracle(oracle):  # tests/shen_castan.zig:10-130, 60-86
     e = oracle.shen_castan(_sc_square(), 0.8, 7, 0.9, 0.3)
     assert 0 < (e > 0).sum() < 500 and set(np.unique(e).tolist()) <= {0, 255}

@@ -217,6 +217,7 @@ pub const c = struct {
     pub extern fn zg_resize(src: *const ZgImage, dst: *const ZgImage, method: *const ZgMethod, stream: ?*anyopaque) c_int;
     pub extern fn zg_rotate_into(src: *const ZgImage, dst: *const ZgImage, angle: f32, cos_a: f32, sin_a: f32, method: *const ZgMethod, border: c_int, stream: ?*anyopaque) c_int;
     pub extern fn zg_sharpen(src: *const ZgImage, dst: *const ZgImage, radius: u32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_isef_smooth(src: *const ZgImage, dst: *const ZgImage, smooth: f32, stream: ?*anyopaque) c_int;
     pub extern fn zg_shen_castan(src: *const ZgImage, dst: *const ZgImage, smooth: f32, window_size: u32, high_ratio: f32, low_rel: f32, hysteresis: c_int, use_nms: c_int, stream: ?*anyopaque) c_int;
     pub extern fn zg_sobel(src: *const ZgImage, dst: *const ZgImage, stream: ?*anyopaque) c_int;
     pub extern fn zg_threshold_adaptive_mean(src: *const ZgImage, dst: *const ZgImage, radius: u32, c: f32, stream: ?*anyopaque) c_int;

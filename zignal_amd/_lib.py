@@ -217,6 +217,7 @@ _SIGNATURES = {
     "zg_sobel_host": [_IMG, _IMG],
     "zg_canny": [_IMG, _IMG, C.c_float, C.c_float, C.c_float, C.c_void_p],
     "zg_canny_host": [_IMG, _IMG, C.c_float, C.c_float, C.c_float],
+    "zg_isef_smooth": [_IMG, _IMG, C.c_float, C.c_void_p],
     "zg_shen_castan": [_IMG, _IMG, C.c_float, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p],
     "zg_shen_castan_host": [_IMG, _IMG, C.c_float, C.c_uint32, C.c_float, C.c_float, C.c_int, C.c_int],
     "zg_motion_blur_linear": [_IMG, _IMG, C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_void_p],

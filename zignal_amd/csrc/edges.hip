@@ -596,7 +596,8 @@ static int canny_impl(const zg_image *src, const zg_image *dst, float sigma, flo
 // and a one-workgroup kernel), so nothing but the hysteresis fixed-point test synchronises the stream.
 
 int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer_valued, size_t plane_stride = 0); // box_blur.hip (0: planes contiguous)
-int isef_2d(const float *gray, float *sm, float *tmp, uint32_t rows, uint32_t cols, float smooth, hipStream_t s); // isef.hip
+int isef_2d(const float *gray, float *sm, float *tmp, uint32_t *check, uint32_t rows, uint32_t cols, float smooth, hipStream_t s); // isef.hip
+size_t isef_check_bytes(uint32_t rows, uint32_t cols);
 int sat_planes_multi(const zg_image *const *srcs, float *const *sats, int count, hipStream_t s); // box_blur.hip
 
 // The recursions along ROWS run as the column kernel on the transposed plane: a row chain needs lanes = rows, i.e. a transpose
@@ -1016,6 +1017,17 @@ __global__ __launch_bounds__(256) void k_sc_classify4(const uint8_t *cand, const
     }
 }
 
+// isefFilter2D (edges.zig:308-349): gray -> sm. The segmented recursions of isef.hip where its preconditions hold; planes whose rows are
+// not whole 16-byte chunks take round 3's route: transpose, column recursions on the cols x rows plane (in place on `t1`, `t2` between the
+// passes), transpose back into `sm`, then the columns proper. tmp, t1, t2: planes of the same size; check: isef_check_bytes().
+static void isef_plane(const float *gray, float *sm, float *tmp, float *t1, float *t2, uint32_t *check, uint32_t rows, uint32_t cols, float smooth, hipStream_t s) {
+    if (isef_2d(gray, sm, tmp, check, rows, cols, smooth, s) >= 0) return;
+    hipLaunchKernelGGL(k_transpose_f32, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, s, gray, t1, (int)rows, (int)cols);
+    hipLaunchKernelGGL(k_isef_cols, dim3(ceil_div(rows, 64)), dim3(576), 0, s, t1, t2, (int)cols, (int)rows, smooth);
+    hipLaunchKernelGGL(k_transpose_f32, dim3(ceil_div(rows, 64), ceil_div(cols, 64)), dim3(256), 0, s, (const float *)t1, sm, (int)cols, (int)rows);
+    hipLaunchKernelGGL(k_isef_cols, dim3(ceil_div(cols, 64)), dim3(576), 0, s, sm, tmp, (int)rows, (int)cols, smooth);
+}
+
 static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smooth, uint32_t window_size, float high_ratio, float low_rel, int hysteresis,
                             int use_nms, zg_stream stream) {
     hipStream_t s = as_stream(stream);
@@ -1038,7 +1050,8 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
     char *scratch = nullptr;
     const size_t f32_bytes = 7 * nf * sizeof(float), u8_off = f32_bytes, small_off = (u8_off + 4 * nf + 255) / 256 * 256;
     constexpr size_t small_bytes = SC_HIST_COPIES * 256 * sizeof(unsigned int) + 256; // histogram copies | thresholds
-    if ((rc = scratch_alloc((void **)&scratch, small_off + small_bytes + hysteresis_work_bytes(rows, cols), s))) return rc;
+    const size_t check_off = (small_off + small_bytes + hysteresis_work_bytes(rows, cols) + 255) / 256 * 256; // the segmented ISEF's check words
+    if ((rc = scratch_alloc((void **)&scratch, check_off + isef_check_bytes(rows, cols), s))) return rc;
     float *gray = (float *)scratch, *sm = gray + nf, *temp = sm + nf, *grad = temp + nf, *sat_g = grad + nf, *sat_m = sat_g + nf, *sat_gm = sat_m + nf;
     uint8_t *bli = (uint8_t *)(scratch + u8_off), *cand = bli + nf, *nms = cand + nf, *state = nms + nf;
     unsigned int *hist = (unsigned int *)(scratch + small_off);
@@ -1055,15 +1068,10 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
     if (rc == ZG_OK) {
         // rows: transpose, column recursions on the cols x rows plane (in place on `grad`, `sat_g` between the passes: both are
         // free until the gradient stage), transpose back into `sm`; then the columns proper
-        // role-split recursions along the rows and then the columns (isef.hip); planes whose rows are not whole 16-byte chunks take round 3's
+        // the recursions in segments along the rows and then the columns (isef.hip); planes whose rows are not whole 16-byte chunks take round 3's
         // route: transpose, column recursions on the cols x rows plane (in place on `grad`, `sat_g` between the passes: both are free until
         // the gradient stage), transpose back into `sm`, then the columns proper
-        if (isef_2d(gray, sm, temp, rows, cols, smooth, s) < 0) {
-            hipLaunchKernelGGL(k_transpose_f32, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, s, (const float *)gray, grad, (int)rows, (int)cols);
-            hipLaunchKernelGGL(k_isef_cols, dim3(ceil_div(rows, 64)), dim3(576), 0, s, grad, sat_g, (int)cols, (int)rows, smooth);
-            hipLaunchKernelGGL(k_transpose_f32, dim3(ceil_div(rows, 64), ceil_div(cols, 64)), dim3(256), 0, s, (const float *)grad, sm, (int)cols, (int)rows);
-            hipLaunchKernelGGL(k_isef_cols, dim3(ceil_div(cols, 64)), dim3(576), 0, s, sm, temp, (int)rows, (int)cols, smooth);
-        }
+        isef_plane(gray, sm, temp, grad, sat_g, (uint32_t *)(scratch + check_off), rows, cols, smooth, s);
         if (cols % 4 == 0) { // four pixels per lane (the planes start 16 bytes aligned)
             const dim3 g4(ceil_div(cols, 256), ceil_div(rows, 64));
             if (!use_nms) hipLaunchKernelGGL(k_sc_bli4<0>, g4, dim3(256), 0, s, (const float *)gray, (const float *)sm, bli, temp /* grey * BLI */, cand, (int)rows, (int)cols);
@@ -1133,6 +1141,26 @@ int zg_canny_host(const zg_image *src, const zg_image *dst, float sigma, float l
     if ((rc = canny_impl(&a.dev, &b.dev, sigma, low_threshold, high_threshold, nullptr))) return rc;
     ZG_HIP(hipStreamSynchronize(nullptr));
     return b.finish();
+}
+
+int zg_isef_smooth(const zg_image *src, const zg_image *dst, float smooth, zg_stream stream) {
+    ZG_REQUIRE(src && dst && src->data && dst->data, ZG_ERR_INVALID_ARGUMENT, "isef: null image");
+    ZG_REQUIRE(src->pixel == ZG_PIXEL_F32 && dst->pixel == ZG_PIXEL_F32, ZG_ERR_INVALID_ARGUMENT, "isef: f32 planes");
+    ZG_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, ZG_ERR_DIMENSION_MISMATCH, "isef: %ux%u vs %ux%u", src->rows, src->cols, dst->rows, dst->cols);
+    ZG_REQUIRE(src->stride == src->cols && dst->stride == dst->cols, ZG_ERR_UNSUPPORTED, "isef: contiguous planes");
+    ZG_REQUIRE(smooth > 0 && smooth < 1, ZG_ERR_INVALID_ARGUMENT, "isef: InvalidBParameter (smooth %g not in (0, 1))", (double)smooth);
+    if (src->rows == 0 || src->cols == 0) return ZG_OK;
+    hipStream_t s = as_stream(stream);
+    const uint32_t rows = src->rows, cols = src->cols;
+    const size_t nf = ((size_t)rows * cols + 3) / 4 * 4;
+    char *scratch = nullptr;
+    if (const int rc = scratch_alloc((void **)&scratch, 3 * nf * sizeof(float) + isef_check_bytes(rows, cols), s)) return rc;
+    float *tmp = (float *)scratch, *t1 = tmp + nf, *t2 = t1 + nf;
+    isef_plane((const float *)src->data, (float *)dst->data, tmp, t1, t2, (uint32_t *)(t2 + nf), rows, cols, smooth, s);
+    const hipError_t e = hipGetLastError();
+    scratch_free(scratch, s);
+    ZG_HIP(e);
+    return ZG_OK;
 }
 
 int zg_shen_castan(const zg_image *src, const zg_image *dst, float smooth, uint32_t window_size, float high_ratio, float low_rel, int hysteresis,

@@ -18,6 +18,8 @@
 // block), the b * x products and a global store per row: 137 us per direction + 23 us per transpose for a 4096^2 plane.
 #include "zg_common.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #pragma clang fp contract(off)
@@ -37,11 +39,30 @@ constexpr int ISEF_NL = 4, ISEF_NS = 4, ISEF_D = 4;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4i __attribute__((ext_vector_type(4)));
 
+// What the segmented kernel (k_isef_spec below) leaves for the repair launch: four values per (segment, chain), as bits.
+struct SpecCheck {
+    uint32_t *v = nullptr;
+    int n_seg = 0, n_chains = 0;
+    __device__ uint32_t &at(int what, int seg, int chain) const { return v[((size_t)what * n_seg + seg) * n_chains + chain]; }
+};
+enum { SC_FWD_SPEC = 0, SC_FWD_TRUE = 1, SC_BWD_SPEC = 2, SC_BWD_TRUE = 3 };
+
 // ROWS: a chain per image row, steps along the columns (cols % 4 == 0, 16-byte aligned planes); otherwise a chain per column.
 // Pass 0: src -> tmp (forward), pass 1: tmp -> dst (backward). dst may be src.
 template <bool ROWS>
-__global__ __launch_bounds__(64 * (1 + ISEF_NL + ISEF_NS)) void k_isef(const float *src, float *tmp, float *dst, int rows, int cols, float b) {
+__global__ __launch_bounds__(64 * (1 + ISEF_NL + ISEF_NS)) void k_isef(const float *src, float *tmp, float *dst, int rows, int cols, float b, SpecCheck chk) {
     constexpr int SB = ISEF_SB, P = ISEF_PITCH, NL = ISEF_NL, NS = ISEF_NS, D = ISEF_D;
+    if (chk.v != nullptr) { // the REPAIR launch behind k_isef_spec: this workgroup's 64 chains are redone only if a segment of theirs started wrong
+        const int nc = ROWS ? rows : cols, c0 = (int)blockIdx.x * 64;
+        int bad = 0;
+        for (int i = (int)threadIdx.x; i < chk.n_seg * 64; i += (int)blockDim.x) {
+            const int j = i >> 6, c = c0 + (i & 63);
+            if (c >= nc) continue;
+            if (j >= 1) bad |= chk.at(SC_FWD_SPEC, j, c) != chk.at(SC_FWD_TRUE, j - 1, c);
+            if (j + 1 < chk.n_seg) bad |= chk.at(SC_BWD_SPEC, j, c) != chk.at(SC_BWD_TRUE, j + 1, c);
+        }
+        if (!__syncthreads_or(bad)) return;
+    }
     constexpr int PER = SB / NL; // COLS: steps a loader / storer wave owns per block; ROWS: chains it owns
     const size_t ld = (size_t)cols;
     __shared__ __attribute__((aligned(16))) float in_ring[2][64 * P];
@@ -214,15 +235,253 @@ __global__ __launch_bounds__(64 * (1 + ISEF_NL + ISEF_NS)) void k_isef(const flo
     }
 }
 
+
+// ---- the recursions cut into segments ----------------------------------------------------------------------------------------------------
+// a = 1 - b < 1 makes the recursion a contraction: two runs over the same inputs from different starting values close in on each other by
+// the factor a per step, and once their f32 values are equal they stay equal for good (same inputs, same operations). So a segment of a
+// chain need not wait for the one before it: it starts W steps early from zero, and by the time it reaches its first own step its value IS
+// the sequential one — unless the two runs still straddle a rounding boundary, which after W steps has probability ~ a^(W - log_a 2^-24) per
+// segment (measured: tools/exp/isef_merge.py). That is not left to chance: every segment records the value it arrived with at its first own
+// step and the value it hands to the next segment, for both recursions; the REPAIR launch (k_isef with a SpecCheck) compares them bit for
+// bit and redoes a workgroup's 64 chains sequentially if any segment of theirs started from anything but its predecessor's exact value. By
+// induction from the chain's true first (last) step every segment that passes holds exactly the sequential values; W is chosen so that a
+// repair is expected once in ~10^4 planes of 4096^2. What the segments buy: a pass is no longer 4 096 dependent steps (the 135 us a direction above)
+// but (S + 2 W) of them per wave with thousands of waves in flight, i.e. the plane's bytes through HBM.
+//
+// One wave owns a window of up to SPEC_WIN steps of 64 chains in LDS, in place: the products b * x come in (coalesced along the rows, a
+// chain per lane afterwards), the forward recursion overwrites them with temp, the backward one with the results, and the S own steps go out.
+constexpr int SPEC_WIN = 128;                 // steps a window holds
+constexpr uint32_t SPEC_WAVES = 4 * 256;      // resident one-wave workgroups: four windows of 33 KB fit a CU's LDS
+constexpr int SPEC_PITCH = SPEC_WIN + 4;      // ROWS layout [chain][step]: 16-byte aligned rows, lanes 4 banks apart (b128 accesses conflict-free)
+
+template <bool ROWS>
+__global__ __launch_bounds__(64) void k_isef_spec(const float *in, float *out, int rows, int cols, float b, int W, int S, SpecCheck chk) {
+    __shared__ __attribute__((aligned(16))) float buf[ROWS ? 64 * SPEC_PITCH : SPEC_WIN * 64];
+    const int lane = (int)threadIdx.x;
+    const int n_chains = ROWS ? rows : cols, n = ROWS ? cols : rows;
+    const int n_groups = (n_chains + 63) / 64, n_win = chk.n_seg * n_groups;
+    const size_t ld = (size_t)cols;
+    const float a = 1.0f - b;
+    struct Win { int seg, ch0, w0, w1, len, own0, own1; };
+    auto window = [&](int t) { // rows: the segments of a chain group follow each other (their windows overlap); columns: the groups of a segment do
+        Win w;
+        w.seg = ROWS ? t % chk.n_seg : t / n_groups;
+        w.ch0 = (ROWS ? t / chk.n_seg : t % n_groups) * 64;
+        const int s0 = w.seg * S, e0 = min(s0 + S, n); // the own steps
+        w.w0 = max(s0 - W, 0), w.w1 = min(e0 + W, n);
+        w.len = w.w1 - w.w0, w.own0 = s0 - w.w0, w.own1 = e0 - w.w0;
+        return w;
+    };
+    // A window's 32 KB come in as 32 loads of 16 bytes per lane, all in flight at once, and wait in registers while the window before it is
+    // worked on: the wave's memory latency is hidden behind its own recursions.
+    // ROWS: lane l of load i: chain 2 i + (l >> 5), steps 4 (l & 31) .. + 4 of the window (512 contiguous bytes per chain);
+    // columns: step 4 i + (l >> 4), chains 4 (l & 15) .. + 4 (256 contiguous bytes per step).
+    f32x4 pre[32];
+    auto fetch = [&](const Win &w) {
+        if constexpr (ROWS) {
+            const int st = 4 * (lane & 31);
+            const float *p = in + w.w0 + min(st, w.len - 4); // clamped: what lies past the window is re-read from inside it and never used
+#pragma unroll
+            for (int i = 0; i < 32; ++i) pre[i] = *(const f32x4 *)(p + (size_t)min(w.ch0 + 2 * i + (lane >> 5), n_chains - 1) * ld);
+        } else {
+            const float *p = in + min(w.ch0 + 4 * (lane & 15), n_chains - 4); // cols % 4 == 0
+#pragma unroll
+            for (int i = 0; i < 32; ++i) pre[i] = *(const f32x4 *)(p + (size_t)(w.w0 + min(4 * i + (lane >> 4), w.len - 1)) * ld);
+        }
+    };
+    auto publish = [&]() { // b * x into the window, chain-major (ROWS) or step-major (columns)
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if constexpr (ROWS) *(f32x4 *)(buf + (2 * i + (lane >> 5)) * SPEC_PITCH + 4 * (lane & 31)) = pre[i] * b;
+            else *(f32x4 *)(buf + (4 * i + (lane >> 4)) * 64 + 4 * (lane & 15)) = pre[i] * b;
+        }
+    };
+
+    int t = (int)blockIdx.x;
+    if (t >= n_win) return;
+    Win nxt = window(t);
+    fetch(nxt);
+    for (; t < n_win; t += (int)gridDim.x) {
+    const Win w = nxt;
+    const int seg = w.seg, ch0 = w.ch0, w0 = w.w0, w1 = w.w1, len = w.len, own0 = w.own0, own1 = w.own1;
+    publish();
+    if (t + (int)gridDim.x < n_win) { nxt = window(t + (int)gridDim.x); fetch(nxt); }
+    __builtin_amdgcn_s_waitcnt(0xc07f); // this wave's LDS writes have landed (the LDS is in order within a wave; one wave per workgroup)
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- the two recursions: lane = chain. Sixteen steps at a time: their LDS reads go out together, the dependent arithmetic follows -------
+    // What the repair launch compares is read back from the window: temp[s0 - 1] is never overwritten (the backward recursion stops at s0),
+    // temp[e0 - 1] is read between the two recursions.
+    uint32_t fwd_spec = 0, fwd_true = 0, bwd_spec = 0, bwd_true = 0;
+    if constexpr (ROWS) { // len, own0, own1 are multiples of 4 (cols, S, W are)
+        float *row = buf + lane * SPEC_PITCH;
+        const int ng = len / 4;
+        float run = 0.0f;
+        int g = 0;
+        if (w0 == 0) { // the chain's first step: temp[0] = b * data[0]
+            const f32x4 v = *(const f32x4 *)row;
+            f32x4 r;
+            run = v[0];
+            r[0] = run;
+#pragma unroll
+            for (int e = 1; e < 4; ++e) { const float ar = a * run; run = v[e] + ar; r[e] = run; }
+            *(f32x4 *)row = r;
+            g = 1;
+        }
+        for (; g + 4 <= ng; g += 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = *(const f32x4 *)(row + 4 * (g + k));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                f32x4 r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float ar = a * run; run = v[k][e] + ar; r[e] = run; }
+                *(f32x4 *)(row + 4 * (g + k)) = r;
+            }
+        }
+        for (; g < ng; ++g) {
+            const f32x4 v = *(const f32x4 *)(row + 4 * g);
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float ar = a * run; run = v[e] + ar; r[e] = run; }
+            *(f32x4 *)(row + 4 * g) = r;
+        }
+        fwd_true = __float_as_uint(row[own1 - 1]);
+        run = 0.0f;
+        g = ng - 1;
+        const int g_lo = own0 / 4;
+        if (w1 == n) { // the chain's last step: data[n - 1] = temp[n - 1]
+            const f32x4 v = *(const f32x4 *)(row + 4 * g);
+            f32x4 r;
+            run = v[3];
+            r[3] = run;
+#pragma unroll
+            for (int e = 2; e >= 0; --e) { const float bt = b * v[e], ar = a * run; run = bt + ar; r[e] = run; }
+            *(f32x4 *)(row + 4 * g) = r;
+            --g;
+        }
+        for (; g - 3 >= g_lo; g -= 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = *(const f32x4 *)(row + 4 * (g - k));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                f32x4 r;
+#pragma unroll
+                for (int e = 3; e >= 0; --e) { const float bt = b * v[k][e], ar = a * run; run = bt + ar; r[e] = run; }
+                *(f32x4 *)(row + 4 * (g - k)) = r;
+            }
+        }
+        for (; g >= g_lo; --g) {
+            const f32x4 v = *(const f32x4 *)(row + 4 * g);
+            f32x4 r;
+#pragma unroll
+            for (int e = 3; e >= 0; --e) { const float bt = b * v[e], ar = a * run; run = bt + ar; r[e] = run; }
+            *(f32x4 *)(row + 4 * g) = r;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        fwd_spec = own0 > 0 ? __float_as_uint(row[own0 - 1]) : 0u;
+        bwd_spec = own1 < len ? __float_as_uint(row[own1]) : 0u;
+        bwd_true = __float_as_uint(row[own0]);
+    } else {
+        float *col = buf + lane;
+        float run = 0.0f;
+        int i = 0;
+        if (w0 == 0) { run = col[0]; i = 1; } // the chain's first step: temp[0] = b * data[0]
+        for (; i + 16 <= len; i += 16) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = col[(i + k) * 64];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { const float ar = a * run; run = v[k] + ar; col[(i + k) * 64] = run; }
+        }
+        for (; i < len; ++i) { const float ar = a * run; run = col[i * 64] + ar; col[i * 64] = run; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        fwd_true = __float_as_uint(col[(own1 - 1) * 64]);
+        run = 0.0f;
+        i = len - 1;
+        if (w1 == n) { run = col[i * 64]; --i; } // the chain's last step: data[n - 1] = temp[n - 1]
+        for (; i - 15 >= own0; i -= 16) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = col[(i - k) * 64];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { const float bt = b * v[k], ar = a * run; run = bt + ar; col[(i - k) * 64] = run; }
+        }
+        for (; i >= own0; --i) { const float bt = b * col[i * 64], ar = a * run; run = bt + ar; col[i * 64] = run; }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        fwd_spec = own0 > 0 ? __float_as_uint(col[(own0 - 1) * 64]) : 0u;
+        bwd_spec = own1 < len ? __float_as_uint(col[own1 * 64]) : 0u;
+        bwd_true = __float_as_uint(col[own0 * 64]);
+    }
+    if (ch0 + lane < n_chains) {
+        chk.at(SC_FWD_SPEC, seg, ch0 + lane) = fwd_spec;
+        chk.at(SC_FWD_TRUE, seg, ch0 + lane) = fwd_true;
+        chk.at(SC_BWD_SPEC, seg, ch0 + lane) = bwd_spec;
+        chk.at(SC_BWD_TRUE, seg, ch0 + lane) = bwd_true;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- out: the own steps ---------------------------------------------------------------------------------------------------------------
+    if constexpr (ROWS) {
+        const int st = 4 * (lane & 31);
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+            const int cl = 2 * i + (lane >> 5);
+            if (st >= own0 && st < own1 && ch0 + cl < n_chains)
+                __builtin_nontemporal_store(*(const f32x4 *)(buf + cl * SPEC_PITCH + st), (f32x4 *)(out + (size_t)(ch0 + cl) * ld + w0 + st));
+        }
+    } else {
+        const int c4 = 4 * (lane & 15);
+        const bool live = ch0 + c4 < n_chains;
+        for (int i = own0 / 4; i < (own1 + 3) / 4; ++i) {
+            const int st = 4 * i + (lane >> 4);
+            if (st >= own0 && st < own1 && live)
+                __builtin_nontemporal_store(*(const f32x4 *)(buf + st * 64 + c4), (f32x4 *)(out + (size_t)(w0 + st) * ld + ch0 + c4));
+        }
+    }
+    __builtin_amdgcn_wave_barrier(); // the next window's b * x follow these reads (in order within the wave)
+    }
+}
+
+// Warm-up steps for the contraction factor a: a^W <= 2^-24 (the runs within an ulp) x 10^-10 (then still apart), a multiple of 4:
+// ~10^6 checks a 4096^2 plane -> one repair (the time of the sequential kernel for that direction) in ~10^4 planes.
+static int spec_warmup(float a) {
+    if (!(a > 0.0f)) return 4;
+    const double w = std::ceil((std::log(0x1p-24) + std::log(1e-10)) / std::log((double)a));
+    return w > 1e6 ? 1 << 20 : ((int)w + 3) / 4 * 4;
+}
+
+size_t isef_check_bytes(uint32_t rows, uint32_t cols) { // the SpecCheck plane isef_2d wants: four words per (segment, chain), S >= 32
+    const size_t by_rows = (size_t)(ceil_div(cols, 32u) + 1) * rows, by_cols = (size_t)(ceil_div(rows, 32u) + 1) * cols;
+    return 4 * sizeof(uint32_t) * (by_rows > by_cols ? by_rows : by_cols);
+}
+
 // The smoothing of a rows x cols f32 plane: gray -> sm, with `tmp` (same size) between the passes. Returns -1 when the row kernel's
 // preconditions do not hold (cols % 4, alignment): the caller then takes the transposing route.
-int isef_2d(const float *gray, float *sm, float *tmp, uint32_t rows, uint32_t cols, float smooth, hipStream_t s) {
+int isef_2d(const float *gray, float *sm, float *tmp, uint32_t *check, uint32_t rows, uint32_t cols, float smooth, hipStream_t s) {
     static const bool off = getenv("ZIGNAL_HIP_ISEF_TRANSPOSE") != nullptr; // tuning hook: round 3's route
+    static const bool serial = getenv("ZIGNAL_HIP_ISEF_SERIAL") != nullptr; // tuning hook: one chain per row / column from end to end
+    static const int w_env = getenv("ZIGNAL_HIP_ISEF_W") ? atoi(getenv("ZIGNAL_HIP_ISEF_W")) : 0; // tests: a short warm-up makes the repair launch work
     if (off || cols % 4 || cols < 4 || ((uintptr_t)gray & 15) || ((uintptr_t)sm & 15) || ((uintptr_t)tmp & 15)) return -1;
     if ((uint64_t)rows * cols * 4 >= 0x40000000u) return -1; // 32-bit buffer offsets (the masked lanes' 0x80000000 stays out of range of whatever is added)
     const dim3 block(64 * (1 + ISEF_NL + ISEF_NS));
-    hipLaunchKernelGGL(k_isef<true>, dim3(ceil_div(rows, 64)), block, 0, s, gray, tmp, sm, (int)rows, (int)cols, smooth);
-    hipLaunchKernelGGL(k_isef<false>, dim3(ceil_div(cols, 64)), block, 0, s, (const float *)sm, tmp, sm, (int)rows, (int)cols, smooth);
+    const int W = w_env >= 4 ? w_env / 4 * 4 : spec_warmup(1.0f - smooth);
+    if (serial || check == nullptr || 2 * W > SPEC_WIN - 32) { // a close to 1: the windows would be mostly warm-up
+        hipLaunchKernelGGL(k_isef<true>, dim3(ceil_div(rows, 64)), block, 0, s, gray, tmp, sm, (int)rows, (int)cols, smooth, SpecCheck{});
+        hipLaunchKernelGGL(k_isef<false>, dim3(ceil_div(cols, 64)), block, 0, s, (const float *)sm, tmp, sm, (int)rows, (int)cols, smooth, SpecCheck{});
+        ZG_HIP(hipGetLastError());
+        return ZG_OK;
+    }
+    const int S = SPEC_WIN - 2 * W;
+    // rows: gray -> tmp (repair: gray -> sm -> tmp); columns: tmp -> sm (repair: tmp -> sm -> sm, the backward recursion in place)
+    const SpecCheck cr{check, (int)ceil_div(cols, (uint32_t)S), (int)rows}, cc{check, (int)ceil_div(rows, (uint32_t)S), (int)cols};
+    hipLaunchKernelGGL(k_isef_spec<true>, dim3(std::min<uint32_t>(cr.n_seg * ceil_div(rows, 64), SPEC_WAVES)), dim3(64), 0, s, gray, tmp, (int)rows, (int)cols, smooth, W, S, cr);
+    hipLaunchKernelGGL(k_isef<true>, dim3(ceil_div(rows, 64)), block, 0, s, gray, sm, tmp, (int)rows, (int)cols, smooth, cr);
+    hipLaunchKernelGGL(k_isef_spec<false>, dim3(std::min<uint32_t>(cc.n_seg * ceil_div(cols, 64), SPEC_WAVES)), dim3(64), 0, s, (const float *)tmp, sm, (int)rows, (int)cols, smooth, W, S, cc);
+    hipLaunchKernelGGL(k_isef<false>, dim3(ceil_div(cols, 64)), block, 0, s, (const float *)tmp, sm, sm, (int)rows, (int)cols, smooth, cc);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

@@ -578,6 +578,17 @@ class Image:
                    int(bool(hysteresis)), int(bool(use_nms)))
         return out
 
+    def isef_smooth(self, smooth: float = 0.9, out: Optional["Image"] = None) -> "Image":
+        """Diagnostics: shenCastan's smoothing stage alone (isefFilter2D, edges.zig:308-349) on a device Image(f32) plane (zg_isef_smooth)."""
+        if not self.on_device:
+            raise ValueError("isef_smooth is a device-side diagnostic")
+        if out is None:
+            out = self._like()
+        self._same_side(out)
+        s, d = self._desc(), out._desc()
+        self._call("isef_smooth", C.byref(s), C.byref(d), C.c_float(smooth))
+        return out
+
     def motion_blur_linear(self, angle: float, distance: int, out: Optional["Image"] = None,
                            cos_sin: Optional[Tuple[float, float]] = None) -> "Image":
         """Image.motionBlur(.{ .linear = .{ .angle, .distance } }) (image.zig:1077, motion_blur.zig:65-236)."""
