@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_canny_gray(DImg src, float *gray) {
 
 // four pixels per lane: one 16-byte load of Rgba(u8) (when the rows are 16-byte aligned), one float4 store
 template <int PIX>
-__global__ __launch_bounds__(256) void k_canny_gray4(DImg src, float *gray, int wide) { // cols % 4 == 0, gray 16-byte aligned
+__global__ __launch_bounds__(256) void k_canny_gray4(DImg src, float *gray, uint8_t *gray8, int wide) { // cols % 4 == 0, gray 16-byte aligned; gray8: the same values as bytes, or null
     using P = Px<PIX>;
     const int c = (blockIdx.x * 256 + threadIdx.x) * 4, r = grid_row();
     if (c >= src.cols || r >= src.rows) return;
@@ -164,13 +164,15 @@ __global__ __launch_bounds__(256) void k_canny_gray4(DImg src, float *gray, int 
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = P::load(src.data, (size_t)r * src.stride + (size_t)(c + k));
     }
-    *(float4 *)(gray + (size_t)r * src.cols + c) = make_float4(canny_gray<PIX>(v[0]), canny_gray<PIX>(v[1]), canny_gray<PIX>(v[2]), canny_gray<PIX>(v[3]));
+    const float4 g = make_float4(canny_gray<PIX>(v[0]), canny_gray<PIX>(v[1]), canny_gray<PIX>(v[2]), canny_gray<PIX>(v[3]));
+    *(float4 *)(gray + (size_t)r * src.cols + c) = g;
+    if (gray8) *(uint32_t *)(gray8 + (size_t)r * src.cols + c) = (uint32_t)g.x | ((uint32_t)g.y << 8) | ((uint32_t)g.z << 16) | ((uint32_t)g.w << 24); // integers 0 .. 255
 }
 template <int PIX>
-static void launch_canny_gray(const zg_image *src, float *gray, hipStream_t s) {
+static void launch_canny_gray(const zg_image *src, float *gray, hipStream_t s, uint8_t *gray8 = nullptr) { // gray8 only where cols % 4 == 0
     if (src->cols % 4 == 0 && ((uintptr_t)gray & 15) == 0) {
         const int wide = ((size_t)src->stride * 4) % 16 == 0 && ((uintptr_t)src->data & 15) == 0;
-        hipLaunchKernelGGL((k_canny_gray4<PIX>), row_grid(ceil_div(src->cols, 1024), src->rows), dim3(256), 0, s, dimg(src), gray, wide);
+        hipLaunchKernelGGL((k_canny_gray4<PIX>), row_grid(ceil_div(src->cols, 1024), src->rows), dim3(256), 0, s, dimg(src), gray, gray8, wide);
     } else {
         hipLaunchKernelGGL((k_canny_gray<PIX>), row_grid(ceil_div(src->cols, 256), src->rows), dim3(256), 0, s, dimg(src), gray);
     }
@@ -748,7 +750,7 @@ __global__ __launch_bounds__(256) void k_sc_bli(const float *gray, const float *
 // A wave walks 16 rows, two rows of loads ahead. MODE 0: forward; 1: four-neighbour, interior only; 2: four-neighbour, bounded.
 // (The lane-per-pixel kernel evaluates BLI five times per pixel, ten loads: 97 us per 4096^2 frame against 45 us.)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_sc_bli4(const float *gray, const float *sm, uint8_t *bli, float *gm, uint8_t *cand, int rows, int cols) {
+__global__ __launch_bounds__(256) void k_sc_bli4(const uint8_t *gray, const float *sm, uint8_t *bli, uint8_t *gm, uint8_t *cand, int rows, int cols) { // gray, gm: bytes
     constexpr int RW = 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x0 = blockIdx.x * 256 + lane * 4;
@@ -765,14 +767,16 @@ __global__ __launch_bounds__(256) void k_sc_bli4(const float *gray, const float 
         if (x0 + j > 0) mW |= 1u << j;
         if (x0 + j >= 1 && x0 + j < cols - 1) mI |= 1u << j;
     }
-    struct Raw { float4 s, g; float es, eg; };
+    struct Raw { float4 s, g; float es, eg; uint32_t g8; };
     auto load = [&](int r, Raw &w) { // row clamped into the image: rows outside are masked where they are used
         r = r < 0 ? 0 : (r > rows - 1 ? rows - 1 : r);
         const size_t i = (size_t)r * cols;
         w.s = *(const float4 *)(sm + i + xc);
-        w.g = *(const float4 *)(gray + i + xc);
+        const uint32_t g4 = *(const uint32_t *)(gray + i + xc);
+        w.g8 = g4;
+        w.g = make_float4((float)(g4 & 255u), (float)((g4 >> 8) & 255u), (float)((g4 >> 16) & 255u), (float)(g4 >> 24));
         w.es = 0.0f; w.eg = 0.0f;
-        if (is_edge) { w.es = sm[i + ecol]; w.eg = gray[i + ecol]; }
+        if (is_edge) { w.es = sm[i + ecol]; w.eg = (float)gray[i + ecol]; }
     };
     auto ext_of = [&](const Raw &w) -> uint32_t { // bit k: BLI of column x0 - 1 + k
         const uint32_t nib = ((w.s.x - w.g.x) >= 0 ? 1u : 0u) | ((w.s.y - w.g.y) >= 0 ? 2u : 0u) | ((w.s.z - w.g.z) >= 0 ? 4u : 0u) | ((w.s.w - w.g.w) >= 0 ? 8u : 0u);
@@ -787,7 +791,7 @@ __global__ __launch_bounds__(256) void k_sc_bli4(const float *gray, const float 
     load(y0 - 1, q0);
     load(y0, q1);
     uint32_t ext_n = ext_of(q0), ext_c = ext_of(q1);
-    float4 g_c = q1.g;
+    uint32_t g_c = q1.g8;
     load(y0 + 1, q0);
     load(y0 + 2, q1);
 #pragma unroll
@@ -796,7 +800,7 @@ __global__ __launch_bounds__(256) void k_sc_bli4(const float *gray, const float 
         if (r >= rows) break; // wave-uniform
         Raw &cur = (k & 1) ? q1 : q0; // row r + 1
         const uint32_t ext_s = ext_of(cur);
-        const float4 g_s = cur.g;
+        const uint32_t g_s = cur.g8;
         load(r + 3, cur);
         const uint32_t C = (ext_c >> 1) & 15u, Eb = (ext_c >> 2) & 15u, Wb = ext_c & 15u;
         const uint32_t Sb = (ext_s >> 1) & 15u, Nb = (ext_n >> 1) & 15u;
@@ -815,7 +819,7 @@ __global__ __launch_bounds__(256) void k_sc_bli4(const float *gray, const float 
             const uint32_t cb = (C * 0x00204081u) & 0x01010101u; // bit j -> byte j
             *(uint32_t *)(bli + i) = cb;
             *(uint32_t *)(cand + i) = ((mark * 0x00204081u) & 0x01010101u) * 255u;
-            *(float4 *)(gm + i) = make_float4(g_c.x * (float)(C & 1u), g_c.y * (float)((C >> 1) & 1u), g_c.z * (float)((C >> 2) & 1u), g_c.w * (float)(C >> 3));
+            *(uint32_t *)(gm + i) = g_c & (cb * 255u); // grey * BLI
         }
         ext_n = ext_c;
         ext_c = ext_s;
@@ -1048,19 +1052,22 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
     // scratch: f32 planes grey | smoothed | temp (ISEF) then grey*BLI | gradient | three SATs; u8 planes BLI | candidates | NMS | state;
     // histogram (256) | thresholds (2) | hysteresis work
     char *scratch = nullptr;
-    const size_t f32_bytes = 7 * nf * sizeof(float), u8_off = f32_bytes, small_off = (u8_off + 4 * nf + 255) / 256 * 256;
+    const size_t f32_bytes = 7 * nf * sizeof(float), u8_off = f32_bytes, small_off = (u8_off + 6 * nf + 255) / 256 * 256;
     constexpr size_t small_bytes = SC_HIST_COPIES * 256 * sizeof(unsigned int) + 256; // histogram copies | thresholds
     const size_t check_off = (small_off + small_bytes + hysteresis_work_bytes(rows, cols) + 255) / 256 * 256; // the segmented ISEF's check words
     if ((rc = scratch_alloc((void **)&scratch, check_off + isef_check_bytes(rows, cols), s))) return rc;
     float *gray = (float *)scratch, *sm = gray + nf, *temp = sm + nf, *grad = temp + nf, *sat_g = grad + nf, *sat_m = sat_g + nf, *sat_gm = sat_m + nf;
-    uint8_t *bli = (uint8_t *)(scratch + u8_off), *cand = bli + nf, *nms = cand + nf, *state = nms + nf;
+    uint8_t *bli = (uint8_t *)(scratch + u8_off), *cand = bli + nf, *nms = cand + nf, *state = nms + nf, *gray8 = state + nf, *gm8 = gray8 + nf;
     unsigned int *hist = (unsigned int *)(scratch + small_off);
     float *thr = (float *)(hist + SC_HIST_COPIES * 256);
     char *work = scratch + small_off + small_bytes;
+    // Rows of whole dwords: grey and grey * BLI (integers 0 .. 255) also live as BYTES, and that is what the BLI kernel and the three integral
+    // images read — a quarter of the f32 planes' traffic (the recursions keep the f32 plane).
+    const bool bytes = cols % 4 == 0;
 
     rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
-        launch_canny_gray<PIX>(src, gray, s);
+        launch_canny_gray<PIX>(src, gray, s, bytes ? gray8 : nullptr);
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     });
@@ -1074,16 +1081,17 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
         isef_plane(gray, sm, temp, grad, sat_g, (uint32_t *)(scratch + check_off), rows, cols, smooth, s);
         if (cols % 4 == 0) { // four pixels per lane (the planes start 16 bytes aligned)
             const dim3 g4(ceil_div(cols, 256), ceil_div(rows, 64));
-            if (!use_nms) hipLaunchKernelGGL(k_sc_bli4<0>, g4, dim3(256), 0, s, (const float *)gray, (const float *)sm, bli, temp /* grey * BLI */, cand, (int)rows, (int)cols);
-            else if (rows >= 3 && cols >= 3) hipLaunchKernelGGL(k_sc_bli4<1>, g4, dim3(256), 0, s, (const float *)gray, (const float *)sm, bli, temp, cand, (int)rows, (int)cols);
-            else hipLaunchKernelGGL(k_sc_bli4<2>, g4, dim3(256), 0, s, (const float *)gray, (const float *)sm, bli, temp, cand, (int)rows, (int)cols);
+            if (!use_nms) hipLaunchKernelGGL(k_sc_bli4<0>, g4, dim3(256), 0, s, (const uint8_t *)gray8, (const float *)sm, bli, gm8 /* grey * BLI */, cand, (int)rows, (int)cols);
+            else if (rows >= 3 && cols >= 3) hipLaunchKernelGGL(k_sc_bli4<1>, g4, dim3(256), 0, s, (const uint8_t *)gray8, (const float *)sm, bli, gm8, cand, (int)rows, (int)cols);
+            else hipLaunchKernelGGL(k_sc_bli4<2>, g4, dim3(256), 0, s, (const uint8_t *)gray8, (const float *)sm, bli, gm8, cand, (int)rows, (int)cols);
         } else {
             hipLaunchKernelGGL(k_sc_bli, g64, dim3(256), 0, s, (const float *)gray, (const float *)sm, bli, temp /* grey * BLI */, cand, (int)rows, (int)cols, use_nms ? 0 : 1);
         }
         if (hipGetLastError() != hipSuccess) rc = ZG_ERR_HIP;
     }
     if (rc == ZG_OK) {
-        const zg_image gi{gray, cols, rows, cols, ZG_PIXEL_F32}, mi{bli, cols, rows, cols, ZG_PIXEL_U8}, gmi{temp, cols, rows, cols, ZG_PIXEL_F32};
+        const zg_image gi{bytes ? (void *)gray8 : (void *)gray, cols, rows, cols, bytes ? ZG_PIXEL_U8 : ZG_PIXEL_F32}, mi{bli, cols, rows, cols, ZG_PIXEL_U8},
+            gmi{bytes ? (void *)gm8 : (void *)temp, cols, rows, cols, bytes ? ZG_PIXEL_U8 : ZG_PIXEL_F32};
         // grey is as(f32, u8), BLI is 0 / 1, grey * BLI is their product: integer-valued planes, exact row sums
         const zg_image *srcs[3] = {&gi, &mi, &gmi};
         float *sats[3] = {sat_g, sat_m, sat_gm};
