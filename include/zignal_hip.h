@@ -383,8 +383,9 @@ ZG_API int zg_canny(const zg_image *src, const zg_image *dst, float sigma, float
 ZG_API int zg_canny_host(const zg_image *src, const zg_image *dst, float sigma, float low_threshold, float high_threshold);
 
 /* Diagnostics, not part of Image(T): shenCastan's smoothing stage on its own — isefFilter2D (src/image/edges.zig:308-349, a private
- * function there): isefFilter1D (:283-305) along every row, then along every column, of a contiguous Image(f32) plane on the device.
- * src -> dst (dst may not alias src). The device runs the recursions in overlapping segments and proves each segment's start against its
+ * function there): isefFilter1D (:283-305) along every row, then along every column, of a contiguous plane on the device: Image(f32), or
+ * Image(u8) taken as as(f32, u8) (what shenCastan feeds it, and how the detector's byte plane reaches the row pass). src -> dst (Image(f32);
+ * dst may not alias src). The device runs the recursions in overlapping segments and proves each segment's start against its
  * predecessor's exact value (zignal_amd/csrc/isef.hip); this entry point is how that is held to the sequential recursion bit for bit
  * (tests/test_next_rows.py). */
 ZG_API int zg_isef_smooth(const zg_image *src, const zg_image *dst, float smooth, zg_stream stream);

@@ -338,6 +338,11 @@ def test_isef_segments_equal_the_sequential_recursions(oracle):
             for smooth in (0.9, 0.7, 0.97, 0.3):
                 got = zg.Image(torch.from_numpy(plane).cuda()).isef_smooth(smooth).to_numpy()
                 assert_bits_equal(got, oracle.isef_plane(plane, smooth), f"isef {what} {rows}x{cols} smooth {smooth}")
+        # the detector's own form: the grey as bytes, converted as the row pass loads it
+        grey = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+        for smooth in (0.9, 0.6, 0.2):
+            got = zg.Image(torch.from_numpy(grey).cuda()).isef_smooth(smooth).to_numpy()
+            assert_bits_equal(got, oracle.isef_plane(grey.astype(np.float32), smooth), f"isef bytes {rows}x{cols} smooth {smooth}")
 
 
 def test_shen_castan_reference_known_answers_oracle(oracle):  # tests/shen_castan.zig:10-130, 60-86

@@ -39,10 +39,10 @@ int main(int argc, char **argv) {
             for (int r = 0; r < rows; ++r) isef1d(&wr[(size_t)r * cols], cols, 1, b, t);
             for (int c = 0; c < cols; ++c) isef1d(&wc[c], rows, cols, b, t);
             const dim3 block(64 * (1 + zg::ISEF_NL + zg::ISEF_NS));
-            hipLaunchKernelGGL(zg::k_isef<true>, dim3((rows + 63) / 64), block, 0, 0, (const float *)dg, dt, ds, rows, cols, b, zg::SpecCheck{});
+            hipLaunchKernelGGL(zg::k_isef<true>, dim3((rows + 63) / 64), block, 0, 0, (const void *)dg, dt, ds, rows, cols, b, zg::SpecCheck{});
             (void)hipMemcpy(g2.data(), ds, n * 4, hipMemcpyDeviceToHost);
             size_t br = 0; for (size_t i = 0; i < n; ++i) br += memcmp(&g2[i], &wr[i], 4) != 0;
-            hipLaunchKernelGGL(zg::k_isef<false>, dim3((cols + 63) / 64), block, 0, 0, (const float *)dg, dt, ds, rows, cols, b, zg::SpecCheck{});
+            hipLaunchKernelGGL(zg::k_isef<false>, dim3((cols + 63) / 64), block, 0, 0, (const void *)dg, dt, ds, rows, cols, b, zg::SpecCheck{});
             (void)hipMemcpy(g2.data(), ds, n * 4, hipMemcpyDeviceToHost);
             size_t bc = 0, fc = 0; for (size_t i = 0; i < n; ++i) if (memcmp(&g2[i], &wc[i], 4) && !bc++) fc = i;
             if (n <= 16) {
@@ -58,7 +58,7 @@ int main(int argc, char **argv) {
             if (bc) printf(" (first row %zu col %zu got %g want %g)", fc / cols, fc % cols, g2[fc], wc[fc]);
             printf("\n");
         }
-        const int rc = zg::isef_2d(dg, ds, dt, dk, (uint32_t)rows, (uint32_t)cols, b, nullptr);
+        const int rc = zg::isef_2d(dg, false, ds, dt, dk, (uint32_t)rows, (uint32_t)cols, b, nullptr);
         (void)hipMemcpy(got.data(), ds, n * 4, hipMemcpyDeviceToHost);
         size_t bad = 0, first = 0;
         for (size_t i = 0; i < n; ++i) if (memcmp(&got[i], &want[i], 4) && !bad++) first = i;
@@ -80,10 +80,10 @@ int main(int argc, char **argv) {
             (void)hipMemcpy(dg, h.data(), n * 4, hipMemcpyHostToDevice);
         }
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-        for (int i = 0; i < 30; ++i) zg::isef_2d(dg, ds, dt, dk, R, R, b, nullptr);
+        for (int i = 0; i < 30; ++i) zg::isef_2d(dg, false, ds, dt, dk, R, R, b, nullptr);
         (void)hipDeviceSynchronize();
         (void)hipEventRecord(e0);
-        for (int i = 0; i < 10; ++i) zg::isef_2d(dg, ds, dt, dk, R, R, b, nullptr);
+        for (int i = 0; i < 10; ++i) zg::isef_2d(dg, false, ds, dt, dk, R, R, b, nullptr);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
         printf("isef_2d 4096 x 4096: %.1f us (rows + columns, forward + backward)\n", ms * 100);

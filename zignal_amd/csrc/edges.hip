@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_canny_gray(DImg src, float *gray) {
 
 // four pixels per lane: one 16-byte load of Rgba(u8) (when the rows are 16-byte aligned), one float4 store
 template <int PIX>
-__global__ __launch_bounds__(256) void k_canny_gray4(DImg src, float *gray, uint8_t *gray8, int wide) { // cols % 4 == 0, gray 16-byte aligned; gray8: the same values as bytes, or null
+__global__ __launch_bounds__(256) void k_canny_gray4(DImg src, float *gray, uint8_t *gray8, int wide) { // cols % 4 == 0, gray 16-byte aligned; gray8: the same values as bytes; either may be null
     using P = Px<PIX>;
     const int c = (blockIdx.x * 256 + threadIdx.x) * 4, r = grid_row();
     if (c >= src.cols || r >= src.rows) return;
@@ -165,11 +165,11 @@ __global__ __launch_bounds__(256) void k_canny_gray4(DImg src, float *gray, uint
         for (int k = 0; k < 4; ++k) v[k] = P::load(src.data, (size_t)r * src.stride + (size_t)(c + k));
     }
     const float4 g = make_float4(canny_gray<PIX>(v[0]), canny_gray<PIX>(v[1]), canny_gray<PIX>(v[2]), canny_gray<PIX>(v[3]));
-    *(float4 *)(gray + (size_t)r * src.cols + c) = g;
+    if (gray) *(float4 *)(gray + (size_t)r * src.cols + c) = g;
     if (gray8) *(uint32_t *)(gray8 + (size_t)r * src.cols + c) = (uint32_t)g.x | ((uint32_t)g.y << 8) | ((uint32_t)g.z << 16) | ((uint32_t)g.w << 24); // integers 0 .. 255
 }
 template <int PIX>
-static void launch_canny_gray(const zg_image *src, float *gray, hipStream_t s, uint8_t *gray8 = nullptr) { // gray8 only where cols % 4 == 0
+static void launch_canny_gray(const zg_image *src, float *gray, hipStream_t s, uint8_t *gray8 = nullptr) { // gray8 (and a null gray) only where cols % 4 == 0
     if (src->cols % 4 == 0 && ((uintptr_t)gray & 15) == 0) {
         const int wide = ((size_t)src->stride * 4) % 16 == 0 && ((uintptr_t)src->data & 15) == 0;
         hipLaunchKernelGGL((k_canny_gray4<PIX>), row_grid(ceil_div(src->cols, 1024), src->rows), dim3(256), 0, s, dimg(src), gray, gray8, wide);
@@ -598,7 +598,8 @@ static int canny_impl(const zg_image *src, const zg_image *dst, float sigma, flo
 // and a one-workgroup kernel), so nothing but the hysteresis fixed-point test synchronises the stream.
 
 int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer_valued, size_t plane_stride = 0); // box_blur.hip (0: planes contiguous)
-int isef_2d(const float *gray, float *sm, float *tmp, uint32_t *check, uint32_t rows, uint32_t cols, float smooth, hipStream_t s); // isef.hip
+int isef_2d(const void *gray, bool gray_is_bytes, float *sm, float *tmp, uint32_t *check, uint32_t rows, uint32_t cols, float smooth, hipStream_t s); // isef.hip
+bool isef_2d_applies(uint32_t rows, uint32_t cols);
 size_t isef_check_bytes(uint32_t rows, uint32_t cols);
 int sat_planes_multi(const zg_image *const *srcs, float *const *sats, int count, hipStream_t s); // box_blur.hip
 
@@ -1024,8 +1025,11 @@ __global__ __launch_bounds__(256) void k_sc_classify4(const uint8_t *cand, const
 // isefFilter2D (edges.zig:308-349): gray -> sm. The segmented recursions of isef.hip where its preconditions hold; planes whose rows are
 // not whole 16-byte chunks take round 3's route: transpose, column recursions on the cols x rows plane (in place on `t1`, `t2` between the
 // passes), transpose back into `sm`, then the columns proper. tmp, t1, t2: planes of the same size; check: isef_check_bytes().
-static void isef_plane(const float *gray, float *sm, float *tmp, float *t1, float *t2, uint32_t *check, uint32_t rows, uint32_t cols, float smooth, hipStream_t s) {
-    if (isef_2d(gray, sm, tmp, check, rows, cols, smooth, s) >= 0) return;
+// gray8: the same plane as bytes, or null; gray (f32) may be null when gray8 is given and isef_2d_applies().
+static void isef_plane(const float *gray, const uint8_t *gray8, float *sm, float *tmp, float *t1, float *t2, uint32_t *check, uint32_t rows, uint32_t cols, float smooth,
+                       hipStream_t s) {
+    if (gray8 && isef_2d((const void *)gray8, true, sm, tmp, check, rows, cols, smooth, s) >= 0) return;
+    if (isef_2d((const void *)gray, false, sm, tmp, check, rows, cols, smooth, s) >= 0) return;
     hipLaunchKernelGGL(k_transpose_f32, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, s, gray, t1, (int)rows, (int)cols);
     hipLaunchKernelGGL(k_isef_cols, dim3(ceil_div(rows, 64)), dim3(576), 0, s, t1, t2, (int)cols, (int)rows, smooth);
     hipLaunchKernelGGL(k_transpose_f32, dim3(ceil_div(rows, 64), ceil_div(cols, 64)), dim3(256), 0, s, (const float *)t1, sm, (int)cols, (int)rows);
@@ -1064,10 +1068,11 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
     // Rows of whole dwords: grey and grey * BLI (integers 0 .. 255) also live as BYTES, and that is what the BLI kernel and the three integral
     // images read — a quarter of the f32 planes' traffic (the recursions keep the f32 plane).
     const bool bytes = cols % 4 == 0;
+    const bool gray_f32 = !(bytes && isef_2d_applies(rows, cols)); // nothing reads the f32 grey when the recursions take the bytes too
 
     rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
-        launch_canny_gray<PIX>(src, gray, s, bytes ? gray8 : nullptr);
+        launch_canny_gray<PIX>(src, gray_f32 ? gray : nullptr, s, bytes ? gray8 : nullptr);
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     });
@@ -1078,7 +1083,7 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
         // the recursions in segments along the rows and then the columns (isef.hip); planes whose rows are not whole 16-byte chunks take round 3's
         // route: transpose, column recursions on the cols x rows plane (in place on `grad`, `sat_g` between the passes: both are free until
         // the gradient stage), transpose back into `sm`, then the columns proper
-        isef_plane(gray, sm, temp, grad, sat_g, (uint32_t *)(scratch + check_off), rows, cols, smooth, s);
+        isef_plane(gray_f32 ? gray : nullptr, bytes ? gray8 : nullptr, sm, temp, grad, sat_g, (uint32_t *)(scratch + check_off), rows, cols, smooth, s);
         if (cols % 4 == 0) { // four pixels per lane (the planes start 16 bytes aligned)
             const dim3 g4(ceil_div(cols, 256), ceil_div(rows, 64));
             if (!use_nms) hipLaunchKernelGGL(k_sc_bli4<0>, g4, dim3(256), 0, s, (const uint8_t *)gray8, (const float *)sm, bli, gm8 /* grey * BLI */, cand, (int)rows, (int)cols);
@@ -1153,7 +1158,7 @@ int zg_canny_host(const zg_image *src, const zg_image *dst, float sigma, float l
 
 int zg_isef_smooth(const zg_image *src, const zg_image *dst, float smooth, zg_stream stream) {
     ZG_REQUIRE(src && dst && src->data && dst->data, ZG_ERR_INVALID_ARGUMENT, "isef: null image");
-    ZG_REQUIRE(src->pixel == ZG_PIXEL_F32 && dst->pixel == ZG_PIXEL_F32, ZG_ERR_INVALID_ARGUMENT, "isef: f32 planes");
+    ZG_REQUIRE((src->pixel == ZG_PIXEL_F32 || src->pixel == ZG_PIXEL_U8) && dst->pixel == ZG_PIXEL_F32, ZG_ERR_INVALID_ARGUMENT, "isef: an f32 or u8 plane into an f32 plane");
     ZG_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, ZG_ERR_DIMENSION_MISMATCH, "isef: %ux%u vs %ux%u", src->rows, src->cols, dst->rows, dst->cols);
     ZG_REQUIRE(src->stride == src->cols && dst->stride == dst->cols, ZG_ERR_UNSUPPORTED, "isef: contiguous planes");
     ZG_REQUIRE(smooth > 0 && smooth < 1, ZG_ERR_INVALID_ARGUMENT, "isef: InvalidBParameter (smooth %g not in (0, 1))", (double)smooth);
@@ -1162,9 +1167,20 @@ int zg_isef_smooth(const zg_image *src, const zg_image *dst, float smooth, zg_st
     const uint32_t rows = src->rows, cols = src->cols;
     const size_t nf = ((size_t)rows * cols + 3) / 4 * 4;
     char *scratch = nullptr;
-    if (const int rc = scratch_alloc((void **)&scratch, 3 * nf * sizeof(float) + isef_check_bytes(rows, cols), s)) return rc;
-    float *tmp = (float *)scratch, *t1 = tmp + nf, *t2 = t1 + nf;
-    isef_plane((const float *)src->data, (float *)dst->data, tmp, t1, t2, (uint32_t *)(t2 + nf), rows, cols, smooth, s);
+    if (const int rc = scratch_alloc((void **)&scratch, 4 * nf * sizeof(float) + isef_check_bytes(rows, cols), s)) return rc;
+    float *tmp = (float *)scratch, *t1 = tmp + nf, *t2 = t1 + nf, *as_f32 = t2 + nf;
+    const float *gray = (const float *)src->data;
+    const uint8_t *gray8 = nullptr;
+    if (src->pixel == ZG_PIXEL_U8) { // as the detector has it: bytes for the segmented row pass, f32 only where that does not apply
+        gray8 = (const uint8_t *)src->data;
+        gray = nullptr;
+        if (!isef_2d_applies(rows, cols) || ((uintptr_t)gray8 & 15)) {
+            launch_canny_gray<ZG_PIXEL_U8>(src, as_f32, s); // as(f32, u8)
+            gray = as_f32;
+            gray8 = nullptr;
+        }
+    }
+    isef_plane(gray, gray8, (float *)dst->data, tmp, t1, t2, (uint32_t *)(as_f32 + nf), rows, cols, smooth, s);
     const hipError_t e = hipGetLastError();
     scratch_free(scratch, s);
     ZG_HIP(e);

@@ -49,9 +49,14 @@ enum { SC_FWD_SPEC = 0, SC_FWD_TRUE = 1, SC_BWD_SPEC = 2, SC_BWD_TRUE = 3 };
 
 // ROWS: a chain per image row, steps along the columns (cols % 4 == 0, 16-byte aligned planes); otherwise a chain per column.
 // Pass 0: src -> tmp (forward), pass 1: tmp -> dst (backward). dst may be src.
-template <bool ROWS>
-__global__ __launch_bounds__(64 * (1 + ISEF_NL + ISEF_NS)) void k_isef(const float *src, float *tmp, float *dst, int rows, int cols, float b, SpecCheck chk) {
-    constexpr int SB = ISEF_SB, P = ISEF_PITCH, NL = ISEF_NL, NS = ISEF_NS, D = ISEF_D;
+// SRC8 (rows only): src is the plane as bytes (integers 0 .. 255, what the detector's grey is); the forward pass converts as it loads.
+__device__ __forceinline__ f32x4 f32_of_bytes(uint32_t v) {
+    return f32x4{(float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24)};
+}
+template <bool ROWS, bool SRC8 = false>
+__global__ __launch_bounds__(64 * (1 + ISEF_NL + ISEF_NS)) void k_isef(const void *src, float *tmp, float *dst, int rows, int cols, float b, SpecCheck chk) {
+    static_assert(ROWS || !SRC8, "bytes come in along the rows");
+    constexpr int SB = ISEF_SB, P = ISEF_PITCH, NL = ISEF_NL, D = ISEF_D;
     if (chk.v != nullptr) { // the REPAIR launch behind k_isef_spec: this workgroup's 64 chains are redone only if a segment of theirs started wrong
         const int nc = ROWS ? rows : cols, c0 = (int)blockIdx.x * 64;
         int bad = 0;
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(64 * (1 + ISEF_NL + ISEF_NS)) void k_isef(const flo
     const float a = 1.0f - b;
 
     for (int pass = 0; pass < 2; ++pass) {
-        const float *in = pass == 0 ? src : tmp;
+        const float *in = pass == 0 ? (const float *)src : tmp;
         float *out = pass == 0 ? tmp : dst;
         auto block_of = [&](int k) { return pass == 0 ? k : nb - 1 - k; }; // the k-th block this pass processes
 
@@ -149,7 +154,8 @@ __global__ __launch_bounds__(64 * (1 + ISEF_NL + ISEF_NS)) void k_isef(const flo
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int q = 64 * j + lane, chain = min(ch0 + sub * PER + (q >> 4), n_chains - 1), st = min(s0 + 4 * (q & 15), n_steps - 4);
-                        g.v[j] = *(const f32x4 *)(in + (size_t)chain * ld + st);
+                        if (SRC8 && pass == 0) g.v[j] = f32_of_bytes(*(const uint32_t *)((const uint8_t *)src + (size_t)chain * ld + st));
+                        else g.v[j] = *(const f32x4 *)(in + (size_t)chain * ld + st);
                     }
                 } else {
                     const int chain = min(ch0 + lane, n_chains - 1);
@@ -254,8 +260,10 @@ constexpr int SPEC_WIN = 128;                 // steps a window holds
 constexpr uint32_t SPEC_WAVES = 4 * 256;      // resident one-wave workgroups: four windows of 33 KB fit a CU's LDS
 constexpr int SPEC_PITCH = SPEC_WIN + 4;      // ROWS layout [chain][step]: 16-byte aligned rows, lanes 4 banks apart (b128 accesses conflict-free)
 
-template <bool ROWS>
-__global__ __launch_bounds__(64) void k_isef_spec(const float *in, float *out, int rows, int cols, float b, int W, int S, SpecCheck chk) {
+template <bool ROWS, bool SRC8 = false>
+__global__ __launch_bounds__(64) void k_isef_spec(const void *src, float *out, int rows, int cols, float b, int W, int S, SpecCheck chk) {
+    static_assert(ROWS || !SRC8, "bytes come in along the rows");
+    const float *in = (const float *)src;
     __shared__ __attribute__((aligned(16))) float buf[ROWS ? 64 * SPEC_PITCH : SPEC_WIN * 64];
     const int lane = (int)threadIdx.x;
     const int n_chains = ROWS ? rows : cols, n = ROWS ? cols : rows;
@@ -276,9 +284,15 @@ __global__ __launch_bounds__(64) void k_isef_spec(const float *in, float *out, i
     // worked on: the wave's memory latency is hidden behind its own recursions.
     // ROWS: lane l of load i: chain 2 i + (l >> 5), steps 4 (l & 31) .. + 4 of the window (512 contiguous bytes per chain);
     // columns: step 4 i + (l >> 4), chains 4 (l & 15) .. + 4 (256 contiguous bytes per step).
-    f32x4 pre[32];
+    // SRC8: the same lanes take the same four steps as four bytes.
+    f32x4 pre[SRC8 ? 1 : 32];
+    uint32_t pre8[SRC8 ? 32 : 1];
     auto fetch = [&](const Win &w) {
-        if constexpr (ROWS) {
+        if constexpr (SRC8) {
+            const uint8_t *p = (const uint8_t *)src + w.w0 + min(4 * (lane & 31), w.len - 4);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) pre8[i] = *(const uint32_t *)(p + (size_t)min(w.ch0 + 2 * i + (lane >> 5), n_chains - 1) * ld);
+        } else if constexpr (ROWS) {
             const int st = 4 * (lane & 31);
             const float *p = in + w.w0 + min(st, w.len - 4); // clamped: what lies past the window is re-read from inside it and never used
 #pragma unroll
@@ -292,7 +306,8 @@ __global__ __launch_bounds__(64) void k_isef_spec(const float *in, float *out, i
     auto publish = [&]() { // b * x into the window, chain-major (ROWS) or step-major (columns)
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-            if constexpr (ROWS) *(f32x4 *)(buf + (2 * i + (lane >> 5)) * SPEC_PITCH + 4 * (lane & 31)) = pre[i] * b;
+            if constexpr (SRC8) *(f32x4 *)(buf + (2 * i + (lane >> 5)) * SPEC_PITCH + 4 * (lane & 31)) = f32_of_bytes(pre8[i]) * b;
+            else if constexpr (ROWS) *(f32x4 *)(buf + (2 * i + (lane >> 5)) * SPEC_PITCH + 4 * (lane & 31)) = pre[i] * b;
             else *(f32x4 *)(buf + (4 * i + (lane >> 4)) * 64 + 4 * (lane & 15)) = pre[i] * b;
         }
     };
@@ -461,27 +476,36 @@ size_t isef_check_bytes(uint32_t rows, uint32_t cols) { // the SpecCheck plane i
 
 // The smoothing of a rows x cols f32 plane: gray -> sm, with `tmp` (same size) between the passes. Returns -1 when the row kernel's
 // preconditions do not hold (cols % 4, alignment): the caller then takes the transposing route.
-int isef_2d(const float *gray, float *sm, float *tmp, uint32_t *check, uint32_t rows, uint32_t cols, float smooth, hipStream_t s) {
+bool isef_2d_applies(uint32_t rows, uint32_t cols) {
     static const bool off = getenv("ZIGNAL_HIP_ISEF_TRANSPOSE") != nullptr; // tuning hook: round 3's route
+    return !off && cols % 4 == 0 && cols >= 4 && (uint64_t)rows * cols * 4 < 0x40000000u; // 32-bit buffer offsets (the masked lanes' 0x80000000 stays out of range of whatever is added)
+}
+
+template <bool SRC8>
+static void isef_2d_launch(const void *gray, float *sm, float *tmp, uint32_t *check, uint32_t rows, uint32_t cols, float smooth, hipStream_t s) {
     static const bool serial = getenv("ZIGNAL_HIP_ISEF_SERIAL") != nullptr; // tuning hook: one chain per row / column from end to end
     static const int w_env = getenv("ZIGNAL_HIP_ISEF_W") ? atoi(getenv("ZIGNAL_HIP_ISEF_W")) : 0; // tests: a short warm-up makes the repair launch work
-    if (off || cols % 4 || cols < 4 || ((uintptr_t)gray & 15) || ((uintptr_t)sm & 15) || ((uintptr_t)tmp & 15)) return -1;
-    if ((uint64_t)rows * cols * 4 >= 0x40000000u) return -1; // 32-bit buffer offsets (the masked lanes' 0x80000000 stays out of range of whatever is added)
     const dim3 block(64 * (1 + ISEF_NL + ISEF_NS));
     const int W = w_env >= 4 ? w_env / 4 * 4 : spec_warmup(1.0f - smooth);
     if (serial || check == nullptr || 2 * W > SPEC_WIN - 32) { // a close to 1: the windows would be mostly warm-up
-        hipLaunchKernelGGL(k_isef<true>, dim3(ceil_div(rows, 64)), block, 0, s, gray, tmp, sm, (int)rows, (int)cols, smooth, SpecCheck{});
-        hipLaunchKernelGGL(k_isef<false>, dim3(ceil_div(cols, 64)), block, 0, s, (const float *)sm, tmp, sm, (int)rows, (int)cols, smooth, SpecCheck{});
-        ZG_HIP(hipGetLastError());
-        return ZG_OK;
+        hipLaunchKernelGGL((k_isef<true, SRC8>), dim3(ceil_div(rows, 64)), block, 0, s, gray, tmp, sm, (int)rows, (int)cols, smooth, SpecCheck{});
+        hipLaunchKernelGGL((k_isef<false>), dim3(ceil_div(cols, 64)), block, 0, s, (const void *)sm, tmp, sm, (int)rows, (int)cols, smooth, SpecCheck{});
+        return;
     }
     const int S = SPEC_WIN - 2 * W;
     // rows: gray -> tmp (repair: gray -> sm -> tmp); columns: tmp -> sm (repair: tmp -> sm -> sm, the backward recursion in place)
     const SpecCheck cr{check, (int)ceil_div(cols, (uint32_t)S), (int)rows}, cc{check, (int)ceil_div(rows, (uint32_t)S), (int)cols};
-    hipLaunchKernelGGL(k_isef_spec<true>, dim3(std::min<uint32_t>(cr.n_seg * ceil_div(rows, 64), SPEC_WAVES)), dim3(64), 0, s, gray, tmp, (int)rows, (int)cols, smooth, W, S, cr);
-    hipLaunchKernelGGL(k_isef<true>, dim3(ceil_div(rows, 64)), block, 0, s, gray, sm, tmp, (int)rows, (int)cols, smooth, cr);
-    hipLaunchKernelGGL(k_isef_spec<false>, dim3(std::min<uint32_t>(cc.n_seg * ceil_div(cols, 64), SPEC_WAVES)), dim3(64), 0, s, (const float *)tmp, sm, (int)rows, (int)cols, smooth, W, S, cc);
-    hipLaunchKernelGGL(k_isef<false>, dim3(ceil_div(cols, 64)), block, 0, s, (const float *)tmp, sm, sm, (int)rows, (int)cols, smooth, cc);
+    hipLaunchKernelGGL((k_isef_spec<true, SRC8>), dim3(std::min<uint32_t>(cr.n_seg * ceil_div(rows, 64), SPEC_WAVES)), dim3(64), 0, s, gray, tmp, (int)rows, (int)cols, smooth, W, S, cr);
+    hipLaunchKernelGGL((k_isef<true, SRC8>), dim3(ceil_div(rows, 64)), block, 0, s, gray, sm, tmp, (int)rows, (int)cols, smooth, cr);
+    hipLaunchKernelGGL((k_isef_spec<false>), dim3(std::min<uint32_t>(cc.n_seg * ceil_div(cols, 64), SPEC_WAVES)), dim3(64), 0, s, (const void *)tmp, sm, (int)rows, (int)cols, smooth, W, S, cc);
+    hipLaunchKernelGGL((k_isef<false>), dim3(ceil_div(cols, 64)), block, 0, s, (const void *)tmp, sm, sm, (int)rows, (int)cols, smooth, cc);
+}
+
+// gray: the plane as f32, or — gray_is_bytes — as bytes (the detector's grey: integers 0 .. 255), converted as the row pass loads it.
+int isef_2d(const void *gray, bool gray_is_bytes, float *sm, float *tmp, uint32_t *check, uint32_t rows, uint32_t cols, float smooth, hipStream_t s) {
+    if (!isef_2d_applies(rows, cols) || ((uintptr_t)gray & 15) || ((uintptr_t)sm & 15) || ((uintptr_t)tmp & 15)) return -1;
+    if (gray_is_bytes) isef_2d_launch<true>(gray, sm, tmp, check, rows, cols, smooth, s);
+    else isef_2d_launch<false>(gray, sm, tmp, check, rows, cols, smooth, s);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

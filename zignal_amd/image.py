@@ -579,11 +579,11 @@ class Image:
         return out
 
     def isef_smooth(self, smooth: float = 0.9, out: Optional["Image"] = None) -> "Image":
-        """Diagnostics: shenCastan's smoothing stage alone (isefFilter2D, edges.zig:308-349) on a device Image(f32) plane (zg_isef_smooth)."""
+        """Diagnostics: shenCastan's smoothing stage alone (isefFilter2D, edges.zig:308-349) on a device Image(f32) or Image(u8) plane, into Image(f32) (zg_isef_smooth)."""
         if not self.on_device:
             raise ValueError("isef_smooth is a device-side diagnostic")
         if out is None:
-            out = self._like()
+            out = self._like(dtype=torch.float32)
         self._same_side(out)
         s, d = self._desc(), out._desc()
         self._call("isef_smooth", C.byref(s), C.byref(d), C.c_float(smooth))
