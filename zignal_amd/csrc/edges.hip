@@ -277,12 +277,12 @@ __global__ __launch_bounds__(256) void k_canny_nms(const float *blur, uint8_t *s
 //   k_cc_tile    a workgroup labels one 64 x 64 tile entirely in LDS (runs from a ballot, unions with LDS atomics). A component that
 //                does not reach the tile's edge is finished there and then: its pixels are written to the output (strong, or weak with
 //                a strong pixel in the component) and leave the state plane. Only the components on a tile edge stay PENDING: their
-//                pixels keep their state and get a label (the global index of the tile root), their roots a cleared flag.
+//                pixels keep their state and get a label (the global index of the tile root), their roots a cleared flag and CC_ROOT (| CC_ROOT_STRONG) in their state byte.
 //   k_cc_border  the pixels on tile edges are united with their neighbours in the next tile through global memory: 1/32 of
 //                the pixels; roots only ever move to smaller indices (atomicMin), so the structure stays a forest whatever
 //                the interleaving
-//   k_cc_flag    every pending strong pixel marks its root
-//   k_cc_emit    every pending weak pixel of a marked root becomes an edge
+//   k_cc_mark    the root of every pending tile component that holds a strong pixel marks the root of its global component
+//   k_cc_emit_tile  a tile's roots look their global verdicts up; every pending weak pixel reads its own root's in LDS
 // The label plane is only touched where components cross tiles, and the two last passes read a byte per pixel.
 // (Round 1 united every pixel pair through global memory: 177 - 296 us of the detectors' time on 4096^2 noise; labelling tiles but
 // still writing a label per pixel and resolving every weak pixel in a separate pass took 149 us on canny's frame.)
@@ -311,6 +311,8 @@ __device__ inline void cc_unite(int *label, int a, int b) {
 // structure already implies are skipped: with S a candidate, SW and SE hang off S's run, and S itself is implied when W and
 // SW are both candidates (the pixel to the left makes the same link); without S, SW is implied by W and SE by E.
 constexpr int CC_T = 64; // tile edge
+// state bytes after k_cc_tile: 0 resolved / not a candidate, 1 weak and pending, 2 strong and pending; on the root pixel of a pending tile component also:
+constexpr uint8_t CC_ROOT = 0x80, CC_ROOT_STRONG = 0x40;
 __global__ __launch_bounds__(256) void k_cc_tile(uint8_t *state, int *label, uint8_t *flag, DImg dst, int rows, int cols) {
     __shared__ int lab[CC_T * CC_T];
     __shared__ uint8_t st[CC_T + 1][CC_T]; // one spare row of zeros below
@@ -395,7 +397,10 @@ __global__ __launch_bounds__(256) void k_cc_tile(uint8_t *state, int *label, uin
                     const size_t gi = (size_t)(y0 + r) * cols + x0 + lane;
                     const int groot = (y0 + (root[k] >> 6)) * cols + x0 + (root[k] & 63);
                     label[gi] = groot;
-                    if ((int)gi == groot) flag[gi] = 0;
+                    if ((int)gi == groot) { // the root pixel of a pending tile component says so in its state byte, and whether the component holds a strong pixel
+                        ns = s | CC_ROOT | ((a & STRONG) ? CC_ROOT_STRONG : 0);
+                        flag[gi] = 0;
+                    }
                 }
             } else {
                 o = (s == 2 || (a & STRONG)) ? 255 : 0;
@@ -453,26 +458,74 @@ __global__ __launch_bounds__(256) void k_cc_border(const uint8_t *state, int *la
         }
     }
 }
-// The pending pixels of four adjacent bytes of the state plane: strong ones mark their root (EMIT false), weak ones of a marked
-// root become edges (EMIT true). Most dwords are zero.
-template <bool EMIT>
-__global__ __launch_bounds__(256) void k_cc_pending(const uint8_t *state, int *label, uint8_t *flag, DImg dst, size_t n, int cols) {
+// After the border links: every pending tile component that holds a strong pixel marks the root of its global component (flag[root] = 1; the flags of
+// all tile roots were cleared by k_cc_tile). Four state bytes per lane; most dwords have no root.
+__global__ __launch_bounds__(256) void k_cc_mark(const uint8_t *state, int *label, uint8_t *flag, size_t n) {
     const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 >= n) return;
     uint32_t s4 = 0;
     if (i0 + 4 <= n && ((uintptr_t)state & 3) == 0) s4 = *(const uint32_t *)(state + i0);
     else for (size_t k = i0; k < n; ++k) s4 |= (uint32_t)state[k] << (8 * (k - i0));
-    if (s4 == 0) return;
+    if ((s4 & (0x01010101u * CC_ROOT_STRONG)) == 0) return;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t s = (s4 >> (8 * j)) & 0xffu;
-        if (s != (EMIT ? 1u : 2u)) continue;
-        const size_t i = i0 + j;
-        const int root = cc_find(label, (int)i);
-        if (!EMIT) flag[root] = 1;
-        else if (flag[root]) {
-            const size_t r = i / (size_t)cols, c = i - r * (size_t)cols;
-            ((uint8_t *)dst.data)[r * dst.stride + c] = 255;
+    for (int j = 0; j < 4; ++j)
+        if ((s4 >> (8 * j)) & CC_ROOT_STRONG) flag[cc_find(label, (int)(i0 + j))] = 1;
+}
+// The weak pending pixels of a 64 x 64 tile become edges where their global component is marked. A pending pixel's label is the root pixel of
+// its tile component — a pixel of the same tile — unless a find through it moved it on to an ancestor (tile-edge pixels only): the roots of the
+// tile look their global roots up once (that is where the tree walks are: a few dozen per tile instead of one per pixel), the verdicts
+// sit in LDS at the roots' places, and a pixel reads its own there. The pixels' labels are asked for before the roots walk, so the two round trips
+// overlap. (One find per weak pixel through global memory: 56 us per 4096^2 frame of noise, 39 on a photo-like frame.)
+__global__ __launch_bounds__(256) void k_cc_emit_tile(const uint8_t *state, int *label, const uint8_t *flag, DImg dst, int rows, int cols) {
+    __shared__ uint8_t verdict[CC_T][CC_T];
+    const int t = threadIdx.x;
+    const int x0 = blockIdx.x * CC_T, y0 = blockIdx.y * CC_T;
+    const bool whole = x0 + CC_T <= cols && y0 + CC_T <= rows && (((uintptr_t)state | (uintptr_t)cols) & 3) == 0;
+    uint32_t st4[4]; // this lane's pixels: rows k * 16 + (t >> 4), columns (t & 15) * 4 .. + 4
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = k * 16 + (t >> 4), c = (t & 15) * 4;
+        st4[k] = 0;
+        if (whole) st4[k] = *(const uint32_t *)(state + (size_t)(y0 + r) * cols + x0 + c);
+        else if (y0 + r < rows)
+            for (int j = 0; j < 4 && x0 + c + j < cols; ++j) st4[k] |= (uint32_t)state[(size_t)(y0 + r) * cols + x0 + c + j] << (8 * j);
+    }
+    int lab[4][4];
+    bool any_weak = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = k * 16 + (t >> 4), c = (t & 15) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lab[k][j] = 0;
+            if (((st4[k] >> (8 * j)) & 3u) == 1u) { lab[k][j] = label[(y0 + r) * cols + x0 + c + j]; any_weak = true; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if ((st4[k] & (0x01010101u * CC_ROOT)) == 0) continue;
+        const int r = k * 16 + (t >> 4), c = (t & 15) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((st4[k] >> (8 * j)) & CC_ROOT) verdict[r][c + j] = flag[cc_find(label, (y0 + r) * cols + x0 + c + j)];
+    }
+    if (!__syncthreads_or(any_weak)) return;
+    const int base = y0 * cols + x0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = k * 16 + (t >> 4), c = (t & 15) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (((st4[k] >> (8 * j)) & 3u) != 1u) continue;
+            const int d = lab[k][j] - base; // the root's offset from the tile's corner: dr * cols + dc
+            int dr = (int)((float)d / (float)cols);
+            int dc = d - dr * cols;
+            if (dc < 0) { --dr; dc += cols; }
+            if (dc >= cols) { ++dr; dc -= cols; }
+            bool edge;
+            if (d >= 0 && dr < CC_T && dc < CC_T) edge = verdict[dr][dc] != 0;                       // the tile's own root
+            else edge = flag[cc_find(label, (y0 + r) * cols + x0 + c + j)] != 0;                    // moved on by a find: walk from here
+            if (edge) ((uint8_t *)dst.data)[(size_t)(y0 + r) * dst.stride + x0 + c + j] = 255;
         }
     }
 }
@@ -485,11 +538,12 @@ static int run_hysteresis(uint8_t *state, uint32_t rows, uint32_t cols, char *wo
     uint8_t *flag = (uint8_t *)(label + n);
     const unsigned nb = (unsigned)((n + 1023) / 1024);
     const unsigned nvb = (cols - 1) / CC_T, nhb = (rows - 1) / CC_T;
-    hipLaunchKernelGGL(k_cc_tile, dim3(ceil_div(cols, (unsigned)CC_T), ceil_div(rows, (unsigned)CC_T)), dim3(256), 0, s, state, label, flag, dimg(dst), (int)rows, (int)cols);
+    const dim3 tiles(ceil_div(cols, (unsigned)CC_T), ceil_div(rows, (unsigned)CC_T));
+    hipLaunchKernelGGL(k_cc_tile, tiles, dim3(256), 0, s, state, label, flag, dimg(dst), (int)rows, (int)cols);
     if (nvb + nhb)
         hipLaunchKernelGGL(k_cc_border, dim3(ceil_div(rows > cols ? rows : cols, 256u), nvb + nhb), dim3(256), 0, s, (const uint8_t *)state, label, (int)rows, (int)cols, (int)nvb);
-    hipLaunchKernelGGL(k_cc_pending<false>, dim3(nb), dim3(256), 0, s, (const uint8_t *)state, label, flag, dimg(dst), n, (int)cols);
-    hipLaunchKernelGGL(k_cc_pending<true>, dim3(nb), dim3(256), 0, s, (const uint8_t *)state, label, flag, dimg(dst), n, (int)cols);
+    hipLaunchKernelGGL(k_cc_mark, dim3(nb), dim3(256), 0, s, (const uint8_t *)state, label, flag, n);
+    hipLaunchKernelGGL(k_cc_emit_tile, tiles, dim3(256), 0, s, (const uint8_t *)state, label, (const uint8_t *)flag, dimg(dst), (int)rows, (int)cols);
     if (hipGetLastError() != hipSuccess) { set_error("%s: hysteresis launch failed", who); return ZG_ERR_HIP; }
     return ZG_OK;
 }
