@@ -296,10 +296,21 @@ __device__ inline int cc_find(int *label, int x) {
     }
     return x;
 }
-__device__ inline void cc_unite(int *label, int a, int b) {
+template <bool PAIRED>
+__device__ inline void cc_unite_t(int *label, int a, int b) {
     for (;;) {
-        a = cc_find(label, a);
-        b = cc_find(label, b);
+        if constexpr (PAIRED) { // cc_find of both at once: through global memory the two walks are independent chains of loads, and a union's
+                                // time is their latency (k_cc_border 91 -> 74 us on noise; in LDS the extra instructions cost more than they hide)
+            int pa = label[a], pb = label[b];
+            while (pa != a || pb != b) {
+                const int ga = label[pa], gb = label[pb];
+                if (pa != a) { if (ga != pa) label[a] = ga; a = pa; pa = ga; }
+                if (pb != b) { if (gb != pb) label[b] = gb; b = pb; pb = gb; }
+            }
+        } else {
+            a = cc_find(label, a);
+            b = cc_find(label, b);
+        }
         if (a == b) return;
         if (a < b) { const int t = a; a = b; b = t; } // a > b: hang a under b
         const int old = atomicMin(&label[a], b);
@@ -307,6 +318,8 @@ __device__ inline void cc_unite(int *label, int a, int b) {
         a = old;              // someone re-rooted a in the meantime: retry from its new parent
     }
 }
+__device__ inline void cc_unite(int *label, int a, int b) { cc_unite_t<false>(label, a, b); }        // LDS
+__device__ inline void cc_unite_global(int *label, int a, int b) { cc_unite_t<true>(label, a, b); }
 // Links to the row below (SW / S / SE; the upward directions are the same pairs seen from the other side). Links the run
 // structure already implies are skipped: with S a candidate, SW and SE hang off S's run, and S itself is implied when W and
 // SW are both candidates (the pixel to the left makes the same link); without S, SW is implied by W and SE by E.
@@ -336,29 +349,32 @@ __global__ __launch_bounds__(256) void k_cc_tile(uint8_t *state, int *label, uin
     __syncthreads();
     // a candidate starts under the first pixel of its horizontal run (ballot + count-leading-zeros)
     uint32_t mine = 0; // bit k: my pixel of row w * 16 + k is a candidate
+    unsigned long long rowm[17]; // the candidates of my sixteen rows and of the row below them, a bit a column: wave-uniform
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int r = w * 16 + k;
         const bool cand = st[r][lane] != 0;
-        const unsigned long long gaps = ~__ballot(cand) & ((1ull << lane) - 1); // non-candidates to my left
+        rowm[k] = __ballot(cand);
+        const unsigned long long gaps = ~rowm[k] & ((1ull << lane) - 1); // non-candidates to my left
         const int start = gaps ? 64 - __clzll(gaps) : 0;
         lab[r * CC_T + lane] = r * CC_T + (cand ? start : lane);
         mine |= (uint32_t)cand << k;
     }
+    rowm[16] = __ballot(st[w * 16 + 16][lane] != 0); // row 64 is zeros
     __syncthreads();
-    if (mine) {
-        for (int k = 0; k < 16; ++k) {
-            if (!((mine >> k) & 1)) continue;
-            const int r = w * 16 + k, i = r * CC_T + lane;
-            const bool wc = lane > 0 && st[r][lane - 1], ec = lane < 63 && st[r][lane + 1];
-            const bool sw = lane > 0 && st[r + 1][lane - 1], so = st[r + 1][lane], se = lane < 63 && st[r + 1][lane + 1]; // row 64 is zeros
-            if (so) {
-                if (!(wc && sw)) cc_unite(lab, i, i + CC_T);
-            } else {
-                if (sw && !wc) cc_unite(lab, i, i + CC_T - 1);
-                if (se && !ec) cc_unite(lab, i, i + CC_T + 1);
-            }
-        }
+    // The links of a row are bit operations on two row masks (scalar): which pixels link to S, to SW, to SE under the skip rules above. Rows
+    // without a link cost nothing, and no pixel reads its neighbours' bytes.
+    const unsigned long long me = 1ull << lane;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const unsigned long long C = rowm[k], S = rowm[k + 1], W = C << 1, E = C >> 1, SW = S << 1, SE = S >> 1;
+        const unsigned long long to_s = C & S & ~(W & SW), to_sw = C & ~S & SW & ~W, to_se = C & ~S & SE & ~E;
+        if ((to_s | to_sw | to_se) == 0) continue; // wave-uniform
+        const int i = (w * 16 + k) * CC_T + lane;
+        // one pass of the union loop serves all three directions (a lane has S, or SW and / or SE); the few lanes with both diagonals go again
+        const bool d_s = (to_s & me) != 0, d_sw = (to_sw & me) != 0, d_se = (to_se & me) != 0;
+        if (d_s | d_sw | d_se) cc_unite(lab, i, i + CC_T + (d_s ? 0 : (d_sw ? -1 : 1)));
+        if ((to_sw & to_se) != 0 && d_sw && d_se) cc_unite(lab, i, i + CC_T + 1);
     }
     __syncthreads();
     // every candidate straight under its root ...
@@ -439,9 +455,9 @@ __global__ __launch_bounds__(256) void k_cc_border(const uint8_t *state, int *la
         if (r >= rows) return;
         const int i = r * cols + x;
         if (!state[i]) return;
-        if (state[i + 1]) { cc_unite(label, i, i + 1); return; } // NE and SE hang off E
-        if (r > 0 && state[i - cols + 1] && !state[i - cols]) cc_unite(label, i, i - cols + 1);
-        if (r + 1 < rows && state[i + cols + 1] && !state[i + cols]) cc_unite(label, i, i + cols + 1);
+        if (state[i + 1]) { cc_unite_global(label, i, i + 1); return; } // NE and SE hang off E
+        if (r > 0 && state[i - cols + 1] && !state[i - cols]) cc_unite_global(label, i, i - cols + 1);
+        if (r + 1 < rows && state[i + cols + 1] && !state[i + cols]) cc_unite_global(label, i, i + cols + 1);
     } else {
         b -= nvb;
         const int y = b * CC_T + CC_T - 1, c = j; // y + 1 < rows by construction
@@ -451,10 +467,10 @@ __global__ __launch_bounds__(256) void k_cc_border(const uint8_t *state, int *la
         const bool wc = c > 0 && state[i - 1], ec = c + 1 < cols && state[i + 1];
         const bool sw = c > 0 && state[i + cols - 1], so = state[i + cols], se = c + 1 < cols && state[i + cols + 1];
         if (so) {
-            if (!(wc && sw)) cc_unite(label, i, i + cols);
+            if (!(wc && sw)) cc_unite_global(label, i, i + cols);
         } else {
-            if (sw && !wc) cc_unite(label, i, i + cols - 1);
-            if (se && !ec) cc_unite(label, i, i + cols + 1);
+            if (sw && !wc) cc_unite_global(label, i, i + cols - 1);
+            if (se && !ec) cc_unite_global(label, i, i + cols + 1);
         }
     }
 }
