@@ -173,7 +173,8 @@ def test_canny_gpu_parity(oracle, kind):
         f = (f - f.min()) / (f.max() - f.min() + 1e-9)
         return f
 
-    for (rows, cols, sigma, lo, hi) in ((10, 10, 1.0, 50, 100), (97, 211, 1.4, 10, 30), (300, 517, 0.0, 5, 12), (2, 9, 1.0, 5, 10), (130, 70, 2.5, 2, 6)):
+    for (rows, cols, sigma, lo, hi) in ((10, 10, 1.0, 50, 100), (97, 211, 1.4, 10, 30), (300, 517, 0.0, 5, 12), (2, 9, 1.0, 5, 10), (130, 70, 2.5, 2, 6),
+                                         (180, 512, 1.4, 10, 30), (70, 260, 0.8, 8, 20)):  # the last two: rows of whole 16-byte chunks — u8 / Rgba(u8) sources give the blur's row pass their grey directly
         base = blobs(rows, cols, rows + cols)
         if kind == "u8":
             img = (base * 255).astype(np.uint8)

@@ -32,8 +32,35 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct TapsRowsF { float k[FL_NKMAX]; };
 struct TapsColsF { float k[FL_NKMAX + 2 * FL_R + 8]; }; // k[FL_R + j] = tap j, zeros around
 
-template <int SP>
+// GREY (SP == 1 only): the source is not the f32 plane itself but the image the detectors take their grey from — 1: Image(u8), as(f32, u8);
+// 4: Image(Rgba(u8)), BT.709 in 16.16 fixed point (color.zig:1031-1042, edges.zig:231-240) — converted as it is staged, so canny's grey plane is
+// never written or read back (k_canny_gray4's 22 us per 4096^2 frame).
+template <int GREY>
+__device__ __forceinline__ float grey_of_rgba(uint32_t px) {
+    const int y = (13933 * (int)(px & 255u) + 46871 * (int)((px >> 8) & 255u) + 4732 * (int)((px >> 16) & 255u) + 32768) >> 16;
+    return (float)(y < 0 ? 0 : (y > 255 ? 255 : y));
+}
+template <int GREY>
+__device__ __forceinline__ f32x4 row_load4(const void *row, int e) { // elements e .. e + 3 of the row's f32 stream
+    if constexpr (GREY == 0) return *(const f32x4 *)((const float *)row + e);
+    else if constexpr (GREY == 1) {
+        const uint32_t v = *(const uint32_t *)((const uint8_t *)row + e);
+        return f32x4{(float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24)};
+    } else {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 q = *(const u32x4 *)((const uint8_t *)row + 4 * (size_t)e);
+        return f32x4{grey_of_rgba<GREY>(q[0]), grey_of_rgba<GREY>(q[1]), grey_of_rgba<GREY>(q[2]), grey_of_rgba<GREY>(q[3])};
+    }
+}
+template <int GREY>
+__device__ __forceinline__ float row_load1(const void *row, int e) {
+    if constexpr (GREY == 0) return ((const float *)row)[e];
+    else if constexpr (GREY == 1) return (float)((const uint8_t *)row)[e];
+    else return grey_of_rgba<GREY>(((const uint32_t *)row)[e]);
+}
+template <int SP, int GREY = 0>
 __global__ __launch_bounds__(256) void k_rows_f32(DImg src, float *temp, TapsRowsF taps, int nk, int half, int border, int tiles_x, int rows_per_wave) {
+    static_assert(GREY == 0 || SP == 1, "a grey source is one plane");
     __shared__ float lds[4][FL_ROW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -47,14 +74,14 @@ __global__ __launch_bounds__(256) void k_rows_f32(DImg src, float *temp, TapsRow
     for (int rr = 0; rr < rows_per_wave; ++rr) {
         const int y = (ty * 4 + wave) * rows_per_wave + rr; // wave-uniform
         if (y >= src.rows) break;
-        const float *row = (const float *)src.data + (size_t)y * src.stride * SP;
+        const void *row = (const uint8_t *)src.data + (size_t)y * src.stride * (GREY == 0 ? SP * sizeof(float) : (size_t)GREY);
         {   // 64 main units of four elements and 64 halo units (32 left, 32 right); units are all inside or all outside the
             // row (length % 4 == 0); outside ones are zeroed here and patched below. Unpredicated loads from clamped addresses.
             const int gm = xf0 + 4 * lane;
-            f32x4 v = *(const f32x4 *)(row + min(gm, row_f - 4));
+            f32x4 v = row_load4<GREY>(row, min(gm, row_f - 4));
             if (gm + 4 > row_f) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             const int gh = lane < 32 ? xf0 - FL_LEFT + 4 * lane : xf0 + 256 + 4 * (lane - 32);
-            f32x4 h = *(const f32x4 *)(row + min(max(gh, 0), row_f - 4));
+            f32x4 h = row_load4<GREY>(row, min(max(gh, 0), row_f - 4));
             if (gh < 0 || gh + 4 > row_f) h = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             *(f32x4 *)(buf + FL_LEFT + 4 * lane) = v;
             *(f32x4 *)(buf + (lane < 32 ? 4 * lane : FL_LEFT + 256 + 4 * (lane - 32))) = h;
@@ -67,7 +94,7 @@ __global__ __launch_bounds__(256) void k_rows_f32(DImg src, float *temp, TapsRow
                 const int px = e >= 0 ? e / SP : -((SP - 1 - e) / SP);   // floor
                 const int gc = resolve_index(px, src.cols, border);
                 if (gc < 0) continue; // zero border: already 0
-                buf[t] = row[gc * SP + (e - px * SP)];
+                buf[t] = row_load1<GREY>(row, gc * SP + (e - px * SP));
             }
         }
         __builtin_amdgcn_wave_barrier(); // LDS is in order within a wave; this only stops the compiler from reordering
@@ -181,12 +208,11 @@ __global__ __launch_bounds__(256) void k_cols_f32(const float *temp, float *dst,
         cols_strip_f32<false>(temp, dst, dst_pitch_f, rows, row_f, taps, nk, half, border, tx, ty);
 }
 
-// Returns -1 when the preconditions do not hold (caller falls back to the general kernels).
-int try_sep_f32long(const zg_image *src, const zg_image *dst, const float *fx, int nkx, const float *fy, int nky, int border, hipStream_t s) {
-    if (src->pixel != ZG_PIXEL_F32 && src->pixel != ZG_PIXEL_RGB_F32 && src->pixel != ZG_PIXEL_RGBA_F32) return -1;
+// grey: 0 = src is the f32 image itself (sp channels); 1 / 4 = src is Image(u8) / Image(Rgba(u8)) and the plane convolved is its grey (sp = 1).
+static int run_sep_f32long(const zg_image *src, int grey, size_t sp, const zg_image *dst, const float *fx, int nkx, const float *fy, int nky, int border, hipStream_t s) {
     if (nkx < 1 || nky < 1 || nkx > FL_NKMAX || nky > FL_NKMAX) return -1;
-    const size_t sp = pixel_channels(src->pixel);
-    if ((src->cols * sp) % 4 || (src->stride * sp) % 4 || (dst->stride * sp) % 4 || ((uintptr_t)src->data & 15) || ((uintptr_t)dst->data & 15)) return -1;
+    const size_t src_bytes = grey ? (size_t)grey : sp * sizeof(float);
+    if ((src->cols * sp) % 4 || (src->stride * src_bytes) % 16 || (dst->stride * sp) % 4 || ((uintptr_t)src->data & 15) || ((uintptr_t)dst->data & 15)) return -1;
     if (src->cols * sp < 256 || (uint64_t)src->cols * sp > 0x1fffffffu) return -1;
     for (int i = 0; i < nkx; ++i) if (!(std::fabs(fx[i]) >= 1e-10f)) return -1; // negligible (or NaN) taps: the general kernels know the skip rule
     for (int i = 0; i < nky; ++i) if (!(std::fabs(fy[i]) >= 1e-10f)) return -1;
@@ -204,7 +230,9 @@ int try_sep_f32long(const zg_image *src, const zg_image *dst, const float *fx, i
     const int tiles_rx = (int)ceil_div((uint32_t)row_f, 256u);
     const int rows_per_wave = 4;
     const dim3 grid_rows((unsigned)(tiles_rx * ceil_div(src->rows, 4u * rows_per_wave)));
-    if (sp == 1) hipLaunchKernelGGL((k_rows_f32<1>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, nkx, halfx, border, tiles_rx, rows_per_wave);
+    if (grey == 1) hipLaunchKernelGGL((k_rows_f32<1, 1>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, nkx, halfx, border, tiles_rx, rows_per_wave);
+    else if (grey == 4) hipLaunchKernelGGL((k_rows_f32<1, 4>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, nkx, halfx, border, tiles_rx, rows_per_wave);
+    else if (sp == 1) hipLaunchKernelGGL((k_rows_f32<1>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, nkx, halfx, border, tiles_rx, rows_per_wave);
     else if (sp == 3) hipLaunchKernelGGL((k_rows_f32<3>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, nkx, halfx, border, tiles_rx, rows_per_wave);
     else hipLaunchKernelGGL((k_rows_f32<4>), grid_rows, dim3(256), 0, s, dimg(src), temp, tr, nkx, halfx, border, tiles_rx, rows_per_wave);
     const int tiles_cx = (int)ceil_div((uint32_t)row_f, 1024u);
@@ -214,6 +242,19 @@ int try_sep_f32long(const zg_image *src, const zg_image *dst, const float *fx, i
     scratch_free(temp, s);
     ZG_HIP(e);
     return ZG_OK;
+}
+
+// Returns -1 when the preconditions do not hold (caller falls back to the general kernels).
+int try_sep_f32long(const zg_image *src, const zg_image *dst, const float *fx, int nkx, const float *fy, int nky, int border, hipStream_t s) {
+    if (src->pixel != ZG_PIXEL_F32 && src->pixel != ZG_PIXEL_RGB_F32 && src->pixel != ZG_PIXEL_RGBA_F32) return -1;
+    return run_sep_f32long(src, 0, pixel_channels(src->pixel), dst, fx, nkx, fy, nky, border, s);
+}
+
+// The detectors' "grey of src as f32, convolved" in one go: src is Image(u8) or Image(Rgba(u8)), dst an Image(f32) plane of the same size; the
+// row pass converts as it stages. -1 when the form does not apply (the caller converts first).
+int try_sep_f32long_grey(const zg_image *src, const zg_image *dst, const float *fx, int nkx, const float *fy, int nky, int border, hipStream_t s) {
+    if ((src->pixel != ZG_PIXEL_U8 && src->pixel != ZG_PIXEL_RGBA_U8) || dst->pixel != ZG_PIXEL_F32) return -1;
+    return run_sep_f32long(src, src->pixel == ZG_PIXEL_U8 ? 1 : 4, 1, dst, fx, nkx, fy, nky, border, s);
 }
 
 } // namespace zg

@@ -18,6 +18,8 @@ namespace zg {
 
 int try_sobel_stream(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s); // sobel_stream.hip
 
+int try_sep_f32long_grey(const zg_image *src, const zg_image *dst, const float *fx, int nkx, const float *fy, int nky, int border, hipStream_t s); // conv_sep_f32long.hip
+
 __device__ inline float gray_as_f32(uint8_t v) { return (float)v; }
 
 template <int PIX> __device__ inline float sobel_gray(typename Px<PIX>::Vec v) {
@@ -625,13 +627,18 @@ static int canny_impl(const zg_image *src, const zg_image *dst, float sigma, flo
     uint8_t *state = (uint8_t *)(scratch + state_off);
     char *work = scratch + work_off;
 
-    rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
-        constexpr int PIX = decltype(tag)::value;
-        launch_canny_gray<PIX>(src, gray, s);
-        ZG_HIP(hipGetLastError());
-        return ZG_OK;
-    });
     const float *blurred = gray;
+    bool have_gray = false;
+    auto make_gray = [&]() -> int {
+        have_gray = true;
+        return dispatch_pixel(src->pixel, [&](auto tag) -> int {
+            constexpr int PIX = decltype(tag)::value;
+            launch_canny_gray<PIX>(src, gray, s);
+            ZG_HIP(hipGetLastError());
+            return ZG_OK;
+        });
+    };
+    if (sigma == 0) rc = make_gray();
     if (rc == ZG_OK && sigma != 0) { // blurGaussian (edges.zig:663-687): its own taps, .replicate
         const size_t radius = (size_t)std::ceil(3.0f * sigma), ks = 2 * radius + 1;
         // any length the separable convolution takes (kernels past 255 taps are read from device memory); the reference has no limit
@@ -645,7 +652,12 @@ static int canny_impl(const zg_image *src, const zg_image *dst, float sigma, flo
         }
         for (size_t i = 0; i < ks; ++i) k[i] /= sum;
         const zg_image gi{gray, cols, rows, cols, ZG_PIXEL_F32}, bi{blur, cols, rows, cols, ZG_PIXEL_F32};
-        rc = zg_conv_separable(&gi, &bi, k.data(), (uint32_t)ks, k.data(), (uint32_t)ks, ZG_BORDER_REPLICATE, stream);
+        // Image(u8) / Image(Rgba(u8)) sources, up to 65 taps: the blur's row pass takes the grey straight from the source
+        rc = ks <= 65 ? try_sep_f32long_grey(src, &bi, k.data(), (int)ks, k.data(), (int)ks, ZG_BORDER_REPLICATE, s) : -1;
+        if (rc == -1) {
+            rc = make_gray();
+            if (rc == ZG_OK) rc = zg_conv_separable(&gi, &bi, k.data(), (uint32_t)ks, k.data(), (uint32_t)ks, ZG_BORDER_REPLICATE, stream);
+        }
         blurred = blur;
     }
     if (rc == ZG_OK) {
