@@ -50,7 +50,7 @@ def same(a, b):
 
 def case(rng):
     kind = str(rng.choice(KINDS))
-    op = str(rng.choice(["blur", "sep", "conv2d", "box", "resize", "warp", "rotate", "convert", "sobel", "canny", "shen", "motion", "insert_flip", "letterbox_extract", "misc8", "codec", "pipeline", "pipeline"]))
+    op = str(rng.choice(["blur", "sep", "conv2d", "box", "resize", "warp", "rotate", "convert", "sobel", "canny", "shen", "isef", "motion", "insert_flip", "letterbox_extract", "misc8", "codec", "pipeline", "pipeline"]))
     rows, cols = dim(rng, MAX_ROWS), dim(rng, MAX_COLS)
     img = synth(rng, kind, rows, cols)
     border = int(rng.integers(0, 4))
@@ -116,6 +116,10 @@ def case(rng):
         kw = dict(smooth=float(rng.uniform(0.5, 0.95)), window_size=int(rng.choice([3, 5, 7, 11])), high_ratio=float(rng.uniform(0.5, 0.99)),
                   low_rel=float(rng.uniform(0.1, 0.9)), hysteresis=bool(rng.integers(0, 2)), use_nms=bool(rng.integers(0, 2)))
         return f"shen {kind} {rows}x{cols} {kw}", D(img).shen_castan(**kw), o.shen_castan(img, **kw)
+    if op == "isef":  # shenCastan's smoothing stage alone (the segmented recursions and their repair launch), bytes or f32 in, the f32 plane out
+        plane = rng.integers(0, 256, (rows, cols), dtype=np.uint8) if rng.random() < 0.5 else ((rng.random((rows, cols), dtype=np.float32) - 0.3) * 300).astype(np.float32)
+        smooth = float(rng.choice([0.95, 0.9, 0.8, 0.7, 0.6, 0.45, 0.2]))
+        return f"isef {plane.dtype} {rows}x{cols} {smooth}", dev(plane).isef_smooth(smooth), o.isef_plane(plane.astype(np.float32), smooth)
     if op == "motion":
         if rng.random() < 0.5:
             ang, d = float(rng.choice([0.0, math.pi / 2, 0.4, 2.2, -0.9])), int(rng.integers(0, 25))

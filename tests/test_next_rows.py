@@ -206,6 +206,27 @@ def test_canny_gpu_parity(oracle, kind):
 
 
 @pytest.mark.gpu
+def test_hysteresis_on_narrow_frames_whose_tile_roots_sit_left_of_the_tile(oracle):
+    """Found by tests/fuzz_parity.py (canny rgb_f32 511x67): k_cc_emit_tile decides from a pixel's label whether its root is a pixel of the same
+    64 x 64 tile; on frames narrower than two tiles a root in the tile to the LEFT, one row further down, has the same offset from the tile's
+    corner as a pixel inside it. Noise and blobs on widths 65 .. 127 (and one wide frame), several tile rows, both detectors."""
+    import torch
+    import zignal_amd as zg
+    from tests.util import assert_bits_equal
+    rng = np.random.default_rng(4004)
+    for rows, cols in ((511, 67), (200, 100), (130, 65), (257, 127), (300, 96), (140, 700)):
+        noise = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        blobs = ((np.sin(yy / 9.0) + np.cos(xx / 7.0) + np.sin((xx + yy) / 13.0)) * 40 + 128 + noise * 0.1).clip(0, 255).astype(np.uint8)
+        for name, img in (("noise", noise), ("blobs", blobs)):
+            d = zg.Image(torch.from_numpy(img).cuda())
+            for sg, lo, hi in ((1.4, 27.8, 95.5), (0.0, 20.0, 60.0), (1.0, 5.0, 12.0)):
+                assert_bits_equal(d.canny(sg, lo, hi).to_numpy(), oracle.canny(img, sg, lo, hi), f"canny {name} {rows}x{cols} {sg}")
+            for kw in (dict(), dict(smooth=0.7, high_ratio=0.8, low_rel=0.3), dict(use_nms=True, high_ratio=0.9)):
+                assert_bits_equal(d.shen_castan(**kw).to_numpy(), oracle.shen_castan(img, **kw), f"shen {name} {rows}x{cols} {kw}")
+
+
+@pytest.mark.gpu
 def test_canny_long_chain_across_tiles(oracle):
     """A one-pixel spiral whose only strong pixel is at one end: hysteresis must follow it through every tile."""
     import torch

@@ -528,20 +528,27 @@ __global__ __launch_bounds__(256) void k_cc_emit_tile(const uint8_t *state, int 
             if ((st4[k] >> (8 * j)) & CC_ROOT) verdict[r][c + j] = flag[cc_find(label, (y0 + r) * cols + x0 + c + j)];
     }
     if (!__syncthreads_or(any_weak)) return;
-    const int base = y0 * cols + x0;
+    const int row_base = y0 * cols;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int r = k * 16 + (t >> 4), c = (t & 15) * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (((st4[k] >> (8 * j)) & 3u) != 1u) continue;
-            const int d = lab[k][j] - base; // the root's offset from the tile's corner: dr * cols + dc
-            int dr = (int)((float)d / (float)cols);
-            int dc = d - dr * cols;
-            if (dc < 0) { --dr; dc += cols; }
-            if (dc >= cols) { ++dr; dc -= cols; }
-            bool edge;
-            if (d >= 0 && dr < CC_T && dc < CC_T) edge = verdict[dr][dc] != 0;                       // the tile's own root
+            // where the label points: e = offset from the start of the tile's first row; inside the tile's rows it is dr * cols + column, both
+            // exact from one float division (e < 64 * cols <= 2^22) and a correction step
+            const int e = lab[k][j] - row_base;
+            bool edge, mine = false;
+            int dr = 0, dc = 0;
+            if (e >= 0 && (int64_t)e < (int64_t)CC_T * cols) {
+                dr = (int)((float)e / (float)cols);
+                int cx = e - dr * cols;
+                if (cx < 0) { --dr; cx += cols; }
+                if (cx >= cols) { ++dr; cx -= cols; }
+                dc = cx - x0;
+                mine = dc >= 0 && dc < CC_T;
+            }
+            if (mine) edge = verdict[dr][dc] != 0;                                                  // the tile's own root
             else edge = flag[cc_find(label, (y0 + r) * cols + x0 + c + j)] != 0;                    // moved on by a find: walk from here
             if (edge) ((uint8_t *)dst.data)[(size_t)(y0 + r) * dst.stride + x0 + c + j] = 255;
         }
