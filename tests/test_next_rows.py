@@ -227,6 +227,27 @@ def test_hysteresis_on_narrow_frames_whose_tile_roots_sit_left_of_the_tile(oracl
 
 
 @pytest.mark.gpu
+def test_detectors_at_frame_sizes(oracle):
+    """Canny and Shen-Castan on whole frames (1080p Rgba(u8), 2048 x 4096 u8): every stage at the sizes its tiling is written for — dozens of ISEF
+    segments per chain, thousands of hysteresis tiles with components crossing them, the integral images past 2^24 — against the oracle."""
+    import torch
+    import zignal_amd as zg
+    from tests.util import assert_bits_equal
+    for shape, seed in (((1080, 1920, 4), 31), ((2048, 4096), 32)):
+        noise = oracle.synth_u8(seed, shape)
+        rows, cols = shape[:2]
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        field = ((np.sin(yy / 37.0) * np.cos(xx / 53.0) + (((xx // 160) + (yy // 120)) % 2)) * 70 + 90).astype(np.float32)
+        field = field[..., None] if len(shape) == 3 else field
+        img = (field + noise.astype(np.float32) * 0.08).clip(0, 255).astype(np.uint8)  # shapes with hard edges, a little sensor noise
+        for name, frame in (("photo-like", img), ("noise", noise)):
+            d = zg.Image(torch.from_numpy(np.ascontiguousarray(frame)).cuda())
+            assert_bits_equal(d.canny(1.4, 50, 150).to_numpy(), oracle.canny(frame, 1.4, 50, 150), f"canny {name} {shape}")
+            assert_bits_equal(d.shen_castan().to_numpy(), oracle.shen_castan(frame), f"shenCastan {name} {shape}")
+        assert_bits_equal(zg.Image(torch.from_numpy(img).cuda()).shen_castan(smooth=0.7, use_nms=True).to_numpy(), oracle.shen_castan(img, smooth=0.7, use_nms=True), f"shenCastan nms {shape}")
+
+
+@pytest.mark.gpu
 def test_canny_long_chain_across_tiles(oracle):
     """A one-pixel spiral whose only strong pixel is at one end: hysteresis must follow it through every tile."""
     import torch
