@@ -303,10 +303,35 @@ __device__ inline bool interpolate(const DImg &img, float x, float y, const Meth
 #pragma unroll
                 for (int j = 0; j < W; ++j) {
                     const int soff = j * img.stride * PB;
+                    if constexpr (PB == 4 && W == 4) {
+                        // the four taps of a window row are sixteen adjacent bytes: ONE gather per row (dword-aligned 16-byte buffer load) instead of
+                        // four — a gather costs the texture path per lane ADDRESS, not per byte
+                        typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+                        const u32x4s q = __builtin_bit_cast(u32x4s, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
 #pragma unroll
-                    for (int i = 0; i < W; ++i) {
-                        if constexpr (PB == 4) px[j][i] = __builtin_bit_cast(Vec, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + i * PB, soff, 0));
-                        else px[j][i] = __builtin_bit_cast(Vec, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + i * PB, soff, 0));
+                        for (int i = 0; i < W; ++i) {
+                            const uint32_t tap = q[i]; // (a bit_cast of the element expression itself reads element 0: clang)
+                            px[j][i] = __builtin_bit_cast(Vec, tap);
+                        }
+                    } else if constexpr (PB == 4 && W == 6) { // Lanczos3: sixteen bytes and eight
+                        typedef uint32_t u32x4s __attribute__((ext_vector_type(4)));
+                        typedef uint32_t u32x2s __attribute__((ext_vector_type(2)));
+                        const u32x4s q = __builtin_bit_cast(u32x4s, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+                        const u32x2s q2 = __builtin_bit_cast(u32x2s, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff + 16, soff, 0));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const uint32_t tap = q[i];
+                            px[j][i] = __builtin_bit_cast(Vec, tap);
+                        }
+                        const uint32_t t4 = q2[0], t5 = q2[1];
+                        px[j][4] = __builtin_bit_cast(Vec, t4);
+                        px[j][5] = __builtin_bit_cast(Vec, t5);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < W; ++i) {
+                            if constexpr (PB == 4) px[j][i] = __builtin_bit_cast(Vec, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + i * PB, soff, 0));
+                            else px[j][i] = __builtin_bit_cast(Vec, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + i * PB, soff, 0));
+                        }
                     }
                 }
             } else {
