@@ -84,6 +84,11 @@ elif op == "resize16":  # sixteen 4096^2 -> 1024^2 frames per launch, two batche
     def f():
         it[0] += 1
         p.run(srcs[it[0] % 2], out=outs[it[0] % 2])
+elif op == "recipe":  # the CLI's example recipe over 64 x 1080p Rgba(u8): resize lanczos -> gaussian sigma 2 -> edges sobel
+    src = torch.randint(0, 256, (64, 1080, 1920, 4), dtype=torch.uint8, device="cuda")
+    out = torch.empty((64, 450, 800, 4), dtype=torch.uint8, device="cuda")
+    p = zg.Pipeline([zg.Step.resize(450, 800, I.lanczos), zg.Step.gaussian_blur(2.0), zg.Step.edges_sobel()])
+    f = lambda: p.run(src, out=out)
 elif op == "conv5_u8":
     t = torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")
     s = zg.Image(t); d = zg.Image(torch.empty_like(t)); k5 = np.full((5, 5), 1 / 25, np.float32)
