@@ -2,7 +2,15 @@
 // recursion temp[i] = b * data[i] + a * temp[i - 1] (temp[0] = b * data[0]) and a backward one data[i] = b * temp[i] + a * data[i + 1]
 // (data[n - 1] = temp[n - 1]), a = 1 - b, separate f32 multiplies and additions in exactly that order.
 //
-// A pass is one dependent chain per row (or column): 4 096 chains of 4 096 steps for a 4096^2 plane, two dependent operations a step,
+// Two kernels, one result:
+//   k_isef_spec   (further down) the recursions cut into overlapping SEGMENTS that run side by side — the recursion contracts by a per step, so
+//                 a segment started a few steps early from zero arrives with the sequential value — each leaving behind what the next kernel
+//                 needs to PROVE that it did: 83 us for a 4096^2 plane;
+//   k_isef        the sequential formulation, one dependent chain per row (column) from end to end, role-split so that the chain's wave
+//                 issues nothing but the chain: 251 us. It is the repair launch behind k_isef_spec (it checks every segment's start bit for bit
+//                 and redoes the 64-chain groups that fail, normally none) and the route for smoothing factors whose warm-up outgrows a window.
+//
+// k_isef. A pass is one dependent chain per row (or column): 4 096 chains of 4 096 steps for a 4096^2 plane, two dependent operations a step,
 // and nothing may be re-associated. The time of a pass is therefore steps x (instructions the chain's wave issues per step) x ~4.2
 // cycles, whatever else the chip does — so the chain's wave must issue nothing but the chain. One workgroup owns 64 chains:
 //   wave 0          the CHAIN: lane = chain. Per four steps one ds_read_b128 (the products b * x, already formed), four times
