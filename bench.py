@@ -706,6 +706,26 @@ def extras(zg, torch, np):
         ms = _time_kernel(torch, lambda i: im[i % ring][0].shen_castan(out=im[i % ring][1]), n=4, warm=1)
         return rate(ms, ROWS * COLS, 5 * ROWS * COLS)
 
+    def photo_like():
+        # smooth colour fields, a few hundred hard-edged discs, a little sensor noise: what the detectors usually see. The noise frames above
+        # are their worst case (a quarter to 40 % of the pixels are candidates and the components percolate across the hysteresis tiles).
+        g = torch.Generator(device="cuda").manual_seed(7)
+        yy, xx = torch.meshgrid(torch.arange(ROWS, device="cuda"), torch.arange(COLS, device="cuda"), indexing="ij")
+        pic = torch.stack([128 + 90 * torch.sin(xx / 310.0) * torch.cos(yy / 270.0), 128 + 80 * torch.cos(xx / 190.0 + yy / 400.0), 128 + 100 * torch.sin((xx + yy) / 520.0)], -1)
+        for cx, cy, rad in torch.randint(0, min(ROWS, COLS), (300, 3), generator=g, device="cuda").tolist():
+            m = ((xx - cx) ** 2 + (yy - cy) ** 2) < (20 + rad % 180) ** 2
+            pic[m] = pic[m] * 0.5 + torch.randint(0, 256, (3,), generator=g, device="cuda").float() * 0.5
+        pic = (pic + 2.0 * torch.randn(pic.shape, generator=g, device="cuda")).clamp(0, 255)
+        return torch.cat([pic, torch.full((ROWS, COLS, 1), 255.0, device="cuda")], -1).to(torch.uint8).contiguous()
+
+    def detectors_photo():
+        src = zg.Image(photo_like())
+        out = zg.Image(torch.empty((ROWS, COLS), dtype=torch.uint8, device="cuda"))
+        r = rate(_time_kernel(torch, lambda i: src.canny(1.4, 50, 150, out=out), n=8, warm=2), ROWS * COLS, 5 * ROWS * COLS)
+        r["shen_castan_ms"] = round(_time_kernel(torch, lambda i: src.shen_castan(out=out), n=4, warm=1), 5)
+        r["note"] = "ms = Image.canny(1.4, 50, 150); one frame re-read (it fits the Infinity Cache): compare with the noise legs for the hysteresis' share, not for bandwidth"
+        return r
+
     def pyramid_build():
         # ImagePyramid.build(source, 8, 1.2, 1.6) — ORB's default — on a grey frame: seven blur + resize levels from the
         # original (sigma up to 5.5: 35 taps), one C call (zg_pyramid_build: the levels fork over internal streams under capture)
@@ -844,6 +864,7 @@ def extras(zg, torch, np):
     leg("next_pyramid_build_default_u8_4096", pyramid_build)
     leg("next_canny_rgba_u8_4096", canny)
     leg("next_shen_castan_rgba_u8_4096", shen)
+    leg("next_canny_and_shen_castan_photo_like_rgba_u8_4096", detectors_photo)
     leg("next_pyramid_level3_blur_u8_4096", pyramid_blur)
     leg("next_convert_rgba_u8_to_lab_f32_4096", lambda: lab(True))
     leg("next_convert_lab_f32_to_rgba_u8_4096", lambda: lab(False))

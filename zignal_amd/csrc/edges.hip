@@ -834,13 +834,16 @@ __global__ __launch_bounds__(256) void k_sc_bli(const float *gray, const float *
     cand[idx] = mark ? 255 : 0;
 }
 
+constexpr int SC_HIST_COPIES = 64;
 // The same, four pixels per lane (cols % 4 == 0): a lane loads float4s, keeps the BLI of its columns and of the two beside
 // them as six bits per row (the neighbours' come over with DPP wave shifts, a workgroup's outer columns with one extra load),
 // and the marks of four pixels are a few bitwise operations on the rows above, at and below; dword and float4 stores.
 // A wave walks 16 rows, two rows of loads ahead. MODE 0: forward; 1: four-neighbour, interior only; 2: four-neighbour, bounded.
 // (The lane-per-pixel kernel evaluates BLI five times per pixel, ten loads: 97 us per 4096^2 frame against 45 us.)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_sc_bli4(const uint8_t *gray, const float *sm, uint8_t *bli, uint8_t *gm, uint8_t *cand, int rows, int cols) { // gray, gm: bytes
+__global__ __launch_bounds__(256) void k_sc_bli4(const uint8_t *gray, const float *sm, uint8_t *bli, uint8_t *gm, uint8_t *cand, int rows, int cols, unsigned int *hist_to_clear) { // gray, gm: bytes
+    if (blockIdx.x == 0 && blockIdx.y == 0) // the gradient kernel's histogram copies start from zero: cleared here, two launches earlier, instead of by a memset of its own
+        for (int i = threadIdx.x; i < SC_HIST_COPIES * 256; i += 256) hist_to_clear[i] = 0;
     constexpr int RW = 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x0 = blockIdx.x * 256 + lane * 4;
@@ -917,7 +920,6 @@ __global__ __launch_bounds__(256) void k_sc_bli4(const uint8_t *gray, const floa
     }
 }
 
-constexpr int SC_HIST_COPIES = 64;
 // adaptive gradient at the candidates (edges.zig:462-496) + the histogram of its rounded values (:139-150)
 // BUF: the planes are below 4 GiB, so a corner read is a buffer load (scalar row offset + per-lane column offset: no vector
 // address arithmetic at all; with 64-bit pointers a third of the kernel's instructions computed addresses).
@@ -1175,9 +1177,9 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
         isef_plane(gray_f32 ? gray : nullptr, bytes ? gray8 : nullptr, sm, temp, grad, sat_g, (uint32_t *)(scratch + check_off), rows, cols, smooth, s);
         if (cols % 4 == 0) { // four pixels per lane (the planes start 16 bytes aligned)
             const dim3 g4(ceil_div(cols, 256), ceil_div(rows, 64));
-            if (!use_nms) hipLaunchKernelGGL(k_sc_bli4<0>, g4, dim3(256), 0, s, (const uint8_t *)gray8, (const float *)sm, bli, gm8 /* grey * BLI */, cand, (int)rows, (int)cols);
-            else if (rows >= 3 && cols >= 3) hipLaunchKernelGGL(k_sc_bli4<1>, g4, dim3(256), 0, s, (const uint8_t *)gray8, (const float *)sm, bli, gm8, cand, (int)rows, (int)cols);
-            else hipLaunchKernelGGL(k_sc_bli4<2>, g4, dim3(256), 0, s, (const uint8_t *)gray8, (const float *)sm, bli, gm8, cand, (int)rows, (int)cols);
+            if (!use_nms) hipLaunchKernelGGL(k_sc_bli4<0>, g4, dim3(256), 0, s, (const uint8_t *)gray8, (const float *)sm, bli, gm8 /* grey * BLI */, cand, (int)rows, (int)cols, hist);
+            else if (rows >= 3 && cols >= 3) hipLaunchKernelGGL(k_sc_bli4<1>, g4, dim3(256), 0, s, (const uint8_t *)gray8, (const float *)sm, bli, gm8, cand, (int)rows, (int)cols, hist);
+            else hipLaunchKernelGGL(k_sc_bli4<2>, g4, dim3(256), 0, s, (const uint8_t *)gray8, (const float *)sm, bli, gm8, cand, (int)rows, (int)cols, hist);
         } else {
             hipLaunchKernelGGL(k_sc_bli, g64, dim3(256), 0, s, (const float *)gray, (const float *)sm, bli, temp /* grey * BLI */, cand, (int)rows, (int)cols, use_nms ? 0 : 1);
         }
@@ -1192,7 +1194,7 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
         rc = sat_planes_multi(srcs, sats, 3, s);
     }
     if (rc == ZG_OK) {
-        if (hipMemsetAsync(hist, 0, SC_HIST_COPIES * 256 * sizeof(unsigned int), s) != hipSuccess) rc = ZG_ERR_HIP;
+        if (!bytes && hipMemsetAsync(hist, 0, SC_HIST_COPIES * 256 * sizeof(unsigned int), s) != hipSuccess) rc = ZG_ERR_HIP; // (k_sc_bli4 cleared it otherwise)
         if (n < (1u << 30))
             hipLaunchKernelGGL(k_sc_gradient<true>, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, s, (const uint8_t *)cand, (const float *)sat_g, (const float *)sat_m, (const float *)sat_gm, grad, hist,
                                (int)rows, (int)cols, (int)(window_size / 2));

@@ -68,11 +68,24 @@ __global__ __launch_bounds__(64 * (1 + ISEF_NL + ISEF_NS)) void k_isef(const voi
     if (chk.v != nullptr) { // the REPAIR launch behind k_isef_spec: this workgroup's 64 chains are redone only if a segment of theirs started wrong
         const int nc = ROWS ? rows : cols, c0 = (int)blockIdx.x * 64;
         int bad = 0;
-        for (int i = (int)threadIdx.x; i < chk.n_seg * 64; i += (int)blockDim.x) {
-            const int j = i >> 6, c = c0 + (i & 63);
-            if (c >= nc) continue;
-            if (j >= 1) bad |= chk.at(SC_FWD_SPEC, j, c) != chk.at(SC_FWD_TRUE, j - 1, c);
-            if (j + 1 < chk.n_seg) bad |= chk.at(SC_BWD_SPEC, j, c) != chk.at(SC_BWD_TRUE, j + 1, c);
+        const int total = chk.n_seg * 64, step = (int)blockDim.x;
+        for (int i0 = (int)threadIdx.x; i0 < total; i0 += 4 * step) { // four entries a round: their sixteen loads go out together (the launch is one round trip, not n_seg / 9)
+            uint32_t fs[4], ft[4], bs[4], bt[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u * step, total - 1), j = i >> 6, c = min(c0 + (i & 63), nc - 1);
+                fs[u] = chk.at(SC_FWD_SPEC, j, c);
+                ft[u] = chk.at(SC_FWD_TRUE, max(j - 1, 0), c);
+                bs[u] = chk.at(SC_BWD_SPEC, j, c);
+                bt[u] = chk.at(SC_BWD_TRUE, min(j + 1, chk.n_seg - 1), c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * step, j = i >> 6;
+                if (i >= total || c0 + (i & 63) >= nc) continue;
+                if (j >= 1) bad |= fs[u] != ft[u];
+                if (j + 1 < chk.n_seg) bad |= bs[u] != bt[u];
+            }
         }
         if (!__syncthreads_or(bad)) return;
     }
