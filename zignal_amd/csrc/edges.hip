@@ -328,7 +328,7 @@ __device__ inline void cc_unite_global(int *label, int a, int b) { cc_unite_t<tr
 constexpr int CC_T = 64; // tile edge
 // state bytes after k_cc_tile: 0 resolved / not a candidate, 1 weak and pending, 2 strong and pending; on the root pixel of a pending tile component also:
 constexpr uint8_t CC_ROOT = 0x80, CC_ROOT_STRONG = 0x40;
-__global__ __launch_bounds__(256) void k_cc_tile(uint8_t *state, int *label, uint8_t *flag, DImg dst, int rows, int cols) {
+__global__ __launch_bounds__(256) void k_cc_tile(uint8_t *state, int *label, uint16_t *label16, uint8_t *flag, DImg dst, int rows, int cols) {
     __shared__ int lab[CC_T * CC_T];
     __shared__ uint8_t st[CC_T + 1][CC_T]; // one spare row of zeros below
     __shared__ uint8_t out[CC_T][CC_T];
@@ -414,8 +414,12 @@ __global__ __launch_bounds__(256) void k_cc_tile(uint8_t *state, int *label, uin
                 if (col_ok && y0 + r < rows) {
                     const size_t gi = (size_t)(y0 + r) * cols + x0 + lane;
                     const int groot = (y0 + (root[k] >> 6)) * cols + x0 + (root[k] & 63);
-                    label[gi] = groot;
-                    if ((int)gi == groot) { // the root pixel of a pending tile component says so in its state byte, and whether the component holds a strong pixel
+                    // every pending pixel: its root's place IN THE TILE (two bytes; what k_cc_emit_tile reads). The global label — a node of the forest the
+                    // border links build — only where the forest can touch it: the tile's edge pixels (a find starts there) and the root itself.
+                    label16[gi] = (uint16_t)root[k];
+                    const bool is_root = (int)gi == groot;
+                    if (is_root || r == 0 || r == CC_T - 1 || lane == 0 || lane == CC_T - 1) label[gi] = groot;
+                    if (is_root) { // the root pixel of a pending tile component says so in its state byte, and whether the component holds a strong pixel
                         ns = s | CC_ROOT | ((a & STRONG) ? CC_ROOT_STRONG : 0);
                         flag[gi] = 0;
                     }
@@ -489,92 +493,92 @@ __global__ __launch_bounds__(256) void k_cc_mark(const uint8_t *state, int *labe
     for (int j = 0; j < 4; ++j)
         if ((s4 >> (8 * j)) & CC_ROOT_STRONG) flag[cc_find(label, (int)(i0 + j))] = 1;
 }
-// The weak pending pixels of a 64 x 64 tile become edges where their global component is marked. A pending pixel's label is the root pixel of
-// its tile component — a pixel of the same tile — unless a find through it moved it on to an ancestor (tile-edge pixels only): the roots of the
-// tile look their global roots up once (that is where the tree walks are: a few dozen per tile instead of one per pixel), the verdicts
-// sit in LDS at the roots' places, and a pixel reads its own there. The pixels' labels are asked for before the roots walk, so the two round trips
-// overlap. (One find per weak pixel through global memory: 56 us per 4096^2 frame of noise, 39 on a photo-like frame.)
-__global__ __launch_bounds__(256) void k_cc_emit_tile(const uint8_t *state, int *label, const uint8_t *flag, DImg dst, int rows, int cols) {
+// The weak pending pixels of a 64 x 64 tile become edges where their global component is marked. The roots of the tile's pending components look
+// their global roots up once (that is where the tree walks are: a few dozen per tile instead of one per pixel) and leave the verdicts in LDS at
+// the roots' places; a weak pixel reads the verdict at the place its two-byte label names. The pixels' labels are asked for before the roots walk,
+// so the two round trips overlap. (One find per weak pixel through global memory: 56 us per 4096^2 frame of noise, 39 on a photo-like frame;
+// with four-byte global labels decoded per pixel: 37 / 22.)
+__global__ __launch_bounds__(256) void k_cc_emit_tile(const uint8_t *state, int *label, const uint16_t *label16, const uint8_t *flag, DImg dst, int rows, int cols) {
     __shared__ uint8_t verdict[CC_T][CC_T];
     const int t = threadIdx.x;
     const int x0 = blockIdx.x * CC_T, y0 = blockIdx.y * CC_T;
     const bool whole = x0 + CC_T <= cols && y0 + CC_T <= rows && (((uintptr_t)state | (uintptr_t)cols) & 3) == 0;
-    uint32_t st4[4]; // this lane's pixels: rows k * 16 + (t >> 4), columns (t & 15) * 4 .. + 4
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int r = k * 16 + (t >> 4), c = (t & 15) * 4;
-        st4[k] = 0;
-        if (whole) st4[k] = *(const uint32_t *)(state + (size_t)(y0 + r) * cols + x0 + c);
-        else if (y0 + r < rows)
-            for (int j = 0; j < 4 && x0 + c + j < cols; ++j) st4[k] |= (uint32_t)state[(size_t)(y0 + r) * cols + x0 + c + j] << (8 * j);
-    }
-    int lab[4][4];
+    const int c = (t & 15) * 4; // this lane's pixels: rows k * 16 + (t >> 4), columns c .. c + 4
+    uint32_t st4[4];
+    uint16_t l16[4][4];
     bool any_weak = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int r = k * 16 + (t >> 4), c = (t & 15) * 4;
+        const int r = k * 16 + (t >> 4);
+        const size_t gi = (size_t)(y0 + r) * cols + x0 + c;
+        st4[k] = 0;
+        if (whole) st4[k] = *(const uint32_t *)(state + gi);
+        else if (y0 + r < rows)
+            for (int j = 0; j < 4 && x0 + c + j < cols; ++j) st4[k] |= (uint32_t)state[gi + j] << (8 * j);
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            lab[k][j] = 0;
-            if (((st4[k] >> (8 * j)) & 3u) == 1u) { lab[k][j] = label[(y0 + r) * cols + x0 + c + j]; any_weak = true; }
+    for (int k = 0; k < 4; ++k) {
+        const int r = k * 16 + (t >> 4);
+        const size_t gi = (size_t)(y0 + r) * cols + x0 + c;
+        const uint32_t weak = (st4[k] & 0x01010101u) & ~((st4[k] >> 1) & 0x01010101u); // a byte is 1 exactly where the pixel is weak and pending
+#pragma unroll
+        for (int j = 0; j < 4; ++j) l16[k][j] = 0;
+        if (weak) {
+            any_weak = true;
+            if (whole && ((uintptr_t)label16 & 7) == 0) { // four labels in one load (cols % 4 == 0)
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 v = *(const u32x2 *)(label16 + gi);
+                const uint32_t v0 = v[0], v1 = v[1];
+                l16[k][0] = (uint16_t)v0; l16[k][1] = (uint16_t)(v0 >> 16); l16[k][2] = (uint16_t)v1; l16[k][3] = (uint16_t)(v1 >> 16);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((weak >> (8 * j)) & 1u) l16[k][j] = label16[gi + j];
+            }
         }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if ((st4[k] & (0x01010101u * CC_ROOT)) == 0) continue;
-        const int r = k * 16 + (t >> 4), c = (t & 15) * 4;
+        const int r = k * 16 + (t >> 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if ((st4[k] >> (8 * j)) & CC_ROOT) verdict[r][c + j] = flag[cc_find(label, (y0 + r) * cols + x0 + c + j)];
     }
     if (!__syncthreads_or(any_weak)) return;
-    const int row_base = y0 * cols;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int r = k * 16 + (t >> 4), c = (t & 15) * 4;
+        const uint32_t weak = (st4[k] & 0x01010101u) & ~((st4[k] >> 1) & 0x01010101u);
+        if (!weak) continue;
+        const int r = k * 16 + (t >> 4);
+        uint8_t *drow = (uint8_t *)dst.data + (size_t)(y0 + r) * dst.stride + x0 + c;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (((st4[k] >> (8 * j)) & 3u) != 1u) continue;
-            // where the label points: e = offset from the start of the tile's first row; inside the tile's rows it is dr * cols + column, both
-            // exact from one float division (e < 64 * cols <= 2^22) and a correction step
-            const int e = lab[k][j] - row_base;
-            bool edge, mine = false;
-            int dr = 0, dc = 0;
-            if (e >= 0 && (int64_t)e < (int64_t)CC_T * cols) {
-                dr = (int)((float)e / (float)cols);
-                int cx = e - dr * cols;
-                if (cx < 0) { --dr; cx += cols; }
-                if (cx >= cols) { ++dr; cx -= cols; }
-                dc = cx - x0;
-                mine = dc >= 0 && dc < CC_T;
-            }
-            if (mine) edge = verdict[dr][dc] != 0;                                                  // the tile's own root
-            else edge = flag[cc_find(label, (y0 + r) * cols + x0 + c + j)] != 0;                    // moved on by a find: walk from here
-            if (edge) ((uint8_t *)dst.data)[(size_t)(y0 + r) * dst.stride + x0 + c + j] = 255;
-        }
+        for (int j = 0; j < 4; ++j)
+            if (((weak >> (8 * j)) & 1u) && (&verdict[0][0])[l16[k][j]] != 0) drow[j] = 255;
     }
 }
-// Writes the edge map of `state` (0 none / 1 weak / 2 strong) into dst; `state` is consumed. `work` holds an int label and a
-// flag byte per pixel (touched only where components cross tiles).
+// Writes the edge map of `state` (0 none / 1 weak / 2 strong) into dst; `state` is consumed. `work` holds an int label, a two-byte in-tile
+// label and a flag byte per pixel (touched only where components cross tiles).
 static int run_hysteresis(uint8_t *state, uint32_t rows, uint32_t cols, char *work, const zg_image *dst, hipStream_t s, const char *who) {
     const size_t n = (size_t)rows * cols;
     if (n > 0x7fffffffu) { set_error("%s: hysteresis labels are 32-bit (rows * cols must stay below 2^31)", who); return ZG_ERR_UNSUPPORTED; }
     int *label = (int *)work;
-    uint8_t *flag = (uint8_t *)(label + n);
+    uint16_t *label16 = (uint16_t *)(label + n);
+    uint8_t *flag = (uint8_t *)(label16 + (n + 3) / 4 * 4);
     const unsigned nb = (unsigned)((n + 1023) / 1024);
     const unsigned nvb = (cols - 1) / CC_T, nhb = (rows - 1) / CC_T;
     const dim3 tiles(ceil_div(cols, (unsigned)CC_T), ceil_div(rows, (unsigned)CC_T));
-    hipLaunchKernelGGL(k_cc_tile, tiles, dim3(256), 0, s, state, label, flag, dimg(dst), (int)rows, (int)cols);
+    hipLaunchKernelGGL(k_cc_tile, tiles, dim3(256), 0, s, state, label, label16, flag, dimg(dst), (int)rows, (int)cols);
     if (nvb + nhb)
         hipLaunchKernelGGL(k_cc_border, dim3(ceil_div(rows > cols ? rows : cols, 256u), nvb + nhb), dim3(256), 0, s, (const uint8_t *)state, label, (int)rows, (int)cols, (int)nvb);
     hipLaunchKernelGGL(k_cc_mark, dim3(nb), dim3(256), 0, s, (const uint8_t *)state, label, flag, n);
-    hipLaunchKernelGGL(k_cc_emit_tile, tiles, dim3(256), 0, s, (const uint8_t *)state, label, (const uint8_t *)flag, dimg(dst), (int)rows, (int)cols);
+    hipLaunchKernelGGL(k_cc_emit_tile, tiles, dim3(256), 0, s, (const uint8_t *)state, label, (const uint16_t *)label16, (const uint8_t *)flag, dimg(dst), (int)rows, (int)cols);
     if (hipGetLastError() != hipSuccess) { set_error("%s: hysteresis launch failed", who); return ZG_ERR_HIP; }
     return ZG_OK;
 }
 static size_t hysteresis_work_bytes(uint32_t rows, uint32_t cols) {
     const size_t n = (size_t)rows * cols;
-    return n * sizeof(int) + n + 64;
+    return n * sizeof(int) + (n + 3) / 4 * 4 * sizeof(uint16_t) + n + 64; // global labels | two-byte in-tile labels | flags
 }
 
 // out = 255 on edges, 0 elsewhere (edges.zig:511-515). A strong pixel is an edge; a weak one is an edge when hysteresis
