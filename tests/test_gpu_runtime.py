@@ -120,6 +120,7 @@ ALTERNATIVE_FORMS = {
     "ZIGNAL_HIP_NO_SOBEL_STREAM": "the LDS-tiled k_sobel instead of k_sobel_stream",
     "ZIGNAL_HIP_ISEF_TRANSPOSE": "two transposes around k_isef_cols instead of the recursions along the rows",
     "ZIGNAL_HIP_ISEF_SERIAL": "the role-split k_isef (one chain per row / column from end to end) instead of the segmented k_isef_spec",
+    "ZIGNAL_HIP_SC_THREE_SATS": "shenCastan's window count from the mask's integral image (three SATs, twelve corner loads) instead of k_sc_count",
     "ZIGNAL_HIP_ISEF_W=4": "k_isef_spec with a four-step warm-up: segments start wrong all over the plane and the repair launch redoes them",
 }
 
@@ -169,6 +170,8 @@ plane = rng.integers(0, 256, (333, 1296)).astype(np.float32)
 for smooth in (0.95, 0.9, 0.7, 0.4):
     same(dev(plane).isef_smooth(smooth), o.isef_plane(plane, smooth), "isef %%g" %% smooth)
 same(dev(rgba).shen_castan(smooth=0.6, use_nms=True), o.shen_castan(rgba, smooth=0.6, use_nms=True), "shen-castan rgba")
+for w in (3, 5, 11, 15):
+    same(dev(grey).shen_castan(window_size=w, high_ratio=0.9), o.shen_castan(grey, window_size=w, high_ratio=0.9), "shen-castan window %%d" %% w)
 print("ok")
 ''' % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **{hook.partition("=")[0]: hook.partition("=")[2] or "1"}))

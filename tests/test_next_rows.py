@@ -222,7 +222,8 @@ def test_hysteresis_on_narrow_frames_whose_tile_roots_sit_left_of_the_tile(oracl
             d = zg.Image(torch.from_numpy(img).cuda())
             for sg, lo, hi in ((1.4, 27.8, 95.5), (0.0, 20.0, 60.0), (1.0, 5.0, 12.0)):
                 assert_bits_equal(d.canny(sg, lo, hi).to_numpy(), oracle.canny(img, sg, lo, hi), f"canny {name} {rows}x{cols} {sg}")
-            for kw in (dict(), dict(smooth=0.7, high_ratio=0.8, low_rel=0.3), dict(use_nms=True, high_ratio=0.9)):
+            for kw in (dict(), dict(smooth=0.7, high_ratio=0.8, low_rel=0.3), dict(use_nms=True, high_ratio=0.9), dict(window_size=3), dict(window_size=5, high_ratio=0.9),
+                       dict(window_size=15, high_ratio=0.95)):  # windows 3 / 5 / 7: the streamed count; 15: the general one
                 assert_bits_equal(d.shen_castan(**kw).to_numpy(), oracle.shen_castan(img, **kw), f"shen {name} {rows}x{cols} {kw}")
 
 

@@ -927,7 +927,9 @@ __global__ __launch_bounds__(256) void k_sc_bli4(const uint8_t *gray, const floa
 // adaptive gradient at the candidates (edges.zig:462-496) + the histogram of its rounded values (:139-150)
 // BUF: the planes are below 4 GiB, so a corner read is a buffer load (scalar row offset + per-lane column offset: no vector
 // address arithmetic at all; with 64-bit pointers a third of the kernel's instructions computed addresses).
-template <bool BUF>
+// CNT: sat_m is not an integral image but the window's count itself, one byte per pixel (k_sc_count below): one byte load per pixel instead of four
+// corner loads, and one integral image fewer to build.
+template <bool BUF, bool CNT = false>
 __global__ __launch_bounds__(256) void k_sc_gradient(const uint8_t *cand, const float *sat_g, const float *sat_m, const float *sat_gm, float *grad,
                                                      unsigned int *hist, int rows, int cols, int hw) {
     // sixteen copies of the block histogram: neighbouring pixels have similar gradients, and 64 lanes hitting one LDS counter
@@ -950,8 +952,12 @@ __global__ __launch_bounds__(256) void k_sc_gradient(const uint8_t *cand, const 
     const uint32_t oc2 = (uint32_t)c2 * 4u, ocl = (uint32_t)cl * 4u;
     const uint32_t plane_bytes = BUF ? (uint32_t)((size_t)rows * cols * 4) : 0u;
     uint8_t cb[16];
+    [[maybe_unused]] uint8_t cnt[16];
 #pragma unroll
-    for (int st = 0; st < 16; ++st) cb[st] = cand[(size_t)min(wrow + st * 4, rows - 1) * cols + cc];
+    for (int st = 0; st < 16; ++st) {
+        cb[st] = cand[(size_t)min(wrow + st * 4, rows - 1) * cols + cc];
+        if constexpr (CNT) cnt[st] = ((const uint8_t *)sat_m)[(size_t)min(wrow + st * 4, rows - 1) * cols + cc];
+    }
     // out-of-range buffer offsets read as zero: the corners that do not exist (c1 == 0, r1 == 0) need no select afterwards
     constexpr uint32_t OOR = 0xfffffff0u;
     const uint32_t ocl_z = c1 > 0 ? ocl : OOR;
@@ -968,7 +974,7 @@ __global__ __launch_bounds__(256) void k_sc_gradient(const uint8_t *cand, const 
                 const int r1 = r > hw ? r - hw : 0, r2 = min(r + hw, rows - 1);
                 const size_t bot = (size_t)r2 * cols, top = (size_t)(r1 > 0 ? r1 - 1 : 0) * cols;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = CNT ? 1 : 0; p < 3; ++p) {
                     if constexpr (BUF) {
                         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)planes[p], (short)0, (int)plane_bytes, 0x00020000);
                         // readfirstlane: the row offsets are wave-uniform, and saying so spares a waterfall loop around every load
@@ -1004,7 +1010,8 @@ __global__ __launch_bounds__(256) void k_sc_gradient(const uint8_t *cand, const 
                 const float area = (float)((size_t)(r2 - r1 + 1) * (size_t)(c2 - c1 + 1));
                 float sum[3];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) sum[p] = ((g.v[u][p * 4 + 0] - g.v[u][p * 4 + 1]) - g.v[u][p * 4 + 2]) + g.v[u][p * 4 + 3]; // integral.zig:85-90, in that order
+                for (int p = CNT ? 1 : 0; p < 3; ++p) sum[p] = ((g.v[u][p * 4 + 0] - g.v[u][p * 4 + 1]) - g.v[u][p * 4 + 2]) + g.v[u][p * 4 + 3]; // integral.zig:85-90, in that order
+                if constexpr (CNT) sum[0] = (float)cnt[grp * U + u];
                 const float count1 = sum[0], count0 = area - count1;
                 if (count0 > 0 && count1 > 0) {
                     const float sum1 = sum[1], sum_total = sum[2];
@@ -1037,6 +1044,85 @@ __global__ __launch_bounds__(256) void k_sc_gradient(const uint8_t *cand, const 
     // up at the L2 atomic units (about half of this kernel's time on a 4096^2 frame); k_sc_thresholds sums the copies
     if (total) atomicAdd(&hist[((blockIdx.y * gridDim.x + blockIdx.x) % SC_HIST_COPIES) * 256 + threadIdx.x], total);
 }
+// The number of BLI pixels in each pixel's clipped (2 hw + 1)^2 window, as a byte (hw <= 7: at most 225). The reference takes it from the integral
+// image of the mask, ((A - B) - C) + D (integral.zig:85-90): on frames of at most 2^24 pixels every value of that image is an integer f32 holds
+// exactly, so the four-corner expression IS the count — computed here directly (two 1-D sums through LDS), which spares the detector one of its
+// three integral images (a third of k_sat_chain_planes' stores) and k_sc_gradient four of its twelve corner loads per pixel.
+__global__ __launch_bounds__(256) void k_sc_count(const uint8_t *bli, uint8_t *cnt, int rows, int cols, int hw) {
+    constexpr int TW = 64, TH = 32, HMAX = 7;
+    __shared__ uint8_t in[TH + 2 * HMAX][TW + 2 * HMAX + 2];
+    __shared__ uint8_t hs[TH + 2 * HMAX][TW];
+    const int t = threadIdx.x, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int nr = TH + 2 * hw, nc = TW + 2 * hw;
+    for (int i = t; i < nr * nc; i += 256) {
+        const int rr = i / nc, cc = i - rr * nc, gy = y0 - hw + rr, gx = x0 - hw + cc;
+        in[rr][cc] = (gy >= 0 && gy < rows && gx >= 0 && gx < cols) ? bli[(size_t)gy * cols + gx] : 0; // outside the frame: not in any clipped window
+    }
+    __syncthreads();
+    for (int i = t; i < nr * TW; i += 256) {
+        const int rr = i >> 6, cc = i & 63;
+        int sum = 0;
+        for (int k = 0; k <= 2 * hw; ++k) sum += in[rr][cc + k];
+        hs[rr][cc] = (uint8_t)sum;
+    }
+    __syncthreads();
+    for (int i = t; i < TH * TW; i += 256) {
+        const int rr = i >> 6, cc = i & 63;
+        int sum = 0;
+        for (int k = 0; k <= 2 * hw; ++k) sum += hs[rr + k][cc];
+        if (y0 + rr < rows && x0 + cc < cols) cnt[(size_t)(y0 + rr) * cols + x0 + cc] = (uint8_t)sum;
+    }
+}
+
+// The same for windows up to 7 x 7 (cols % 4 == 0), streaming: a lane owns four adjacent columns as the bytes of a dword and walks down a 32-row
+// segment. The horizontal sums of its four pixels are 2 HW + 1 byte-shifted copies of { left neighbour's dword, its own, right neighbour's } added
+// as packed bytes (sums <= 7: no carry between bytes; the neighbours' dwords come over with DPP wave shifts, a wave's outer lanes fetch theirs);
+// the vertical sum is a running packed sum over a ring of 2 HW + 1 rows (<= 49 per byte). One dword in, one dword out per four pixels.
+constexpr int SC_COUNT_SEG = 32; // rows a wave walks (+ 2 HW of run-in)
+template <int HW>
+__global__ __launch_bounds__(256) void k_sc_count_stream(const uint8_t *bli, uint8_t *cnt, int rows, int cols) {
+    constexpr int N = 2 * HW + 1, SEG = SC_COUNT_SEG;
+    const int lane = threadIdx.x & 63, strip = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int x0 = strip * 256 + lane * 4;
+    if (strip * 256 >= cols) return; // wave-uniform
+    const bool live = x0 < cols;
+    const int y0 = (int)blockIdx.y * SEG, y1 = min(y0 + SEG, rows);
+    const int ex = lane == 0 ? x0 - 4 : x0 + 4; // the dword beside the wave's columns that this lane fetches if it is an outer lane
+    const bool outer = (lane == 0 || lane == 63) && ex >= 0 && ex < cols;
+    uint32_t ring[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) ring[k] = 0;
+    uint32_t v = 0;
+    for (int rb = y0 - HW; rb < y1 + HW; rb += N) {
+        uint32_t curs[N], sides[N]; // a ring's worth of rows asked for together: the walk is one memory round trip per N rows, not per row
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int r = rb + j;
+            curs[j] = sides[j] = 0;
+            if (r >= 0 && r < rows && r < y1 + HW) {
+                if (live) curs[j] = *(const uint32_t *)(bli + (size_t)r * cols + x0);
+                if (outer) sides[j] = *(const uint32_t *)(bli + (size_t)r * cols + ex);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) { // row rb + j goes into ring slot j: (rb - (y0 - HW)) is a multiple of N
+            const int r = rb + j;
+            const uint32_t cur = curs[j];
+            uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur, 0x138, 0xf, 0xf, true); // wave_shr:1: lane - 1's dword
+            uint32_t next = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur, 0x130, 0xf, 0xf, true); // wave_shl:1: lane + 1's
+            if (lane == 0) prev = sides[j];
+            if (lane == 63) next = sides[j];
+            uint32_t h = cur;
+#pragma unroll
+            for (int k = 1; k <= HW; ++k) h += __builtin_amdgcn_alignbyte(next, cur, k) + __builtin_amdgcn_alignbyte(cur, prev, 4 - k);
+            v += h - ring[j]; // the row 2 HW + 1 above leaves the window, per byte: it was in the sum, so no borrow
+            ring[j] = h;
+            const int ro = r - HW; // the row whose window is now complete
+            if (ro >= y0 && ro < y1 && live) *(uint32_t *)(cnt + (size_t)ro * cols + x0) = v;
+        }
+    }
+}
+
 // thr[0] = t_high, thr[1] = t_low (edges.zig:160-166): the reference walks the histogram until the running count reaches
 // floor(total * high_ratio); the number of steps it takes is the number of bins whose EXCLUSIVE prefix is below that target.
 // One workgroup of 256 threads, a bin each (a single thread walking 256 global loads took 12 us).
@@ -1189,17 +1275,38 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
         }
         if (hipGetLastError() != hipSuccess) rc = ZG_ERR_HIP;
     }
+    // frames of at most 2^24 pixels, windows up to 15 x 15: the mask's window count is exact in the reference's f32 integral image, so it is
+    // counted directly (k_sc_count) and only grey and grey * BLI go through integral images
+    static const bool three_sats = getenv("ZIGNAL_HIP_SC_THREE_SATS") != nullptr; // tuning hook: the mask's integral image as well
+    const bool counted = bytes && !three_sats && n <= ((size_t)1 << 24) && window_size / 2 <= 7 && n < (1u << 30);
+    uint8_t *cnt8 = (uint8_t *)sat_m; // the plane the mask's integral image would take
     if (rc == ZG_OK) {
         const zg_image gi{bytes ? (void *)gray8 : (void *)gray, cols, rows, cols, bytes ? ZG_PIXEL_U8 : ZG_PIXEL_F32}, mi{bli, cols, rows, cols, ZG_PIXEL_U8},
             gmi{bytes ? (void *)gm8 : (void *)temp, cols, rows, cols, bytes ? ZG_PIXEL_U8 : ZG_PIXEL_F32};
         // grey is as(f32, u8), BLI is 0 / 1, grey * BLI is their product: integer-valued planes, exact row sums
-        const zg_image *srcs[3] = {&gi, &mi, &gmi};
-        float *sats[3] = {sat_g, sat_m, sat_gm};
-        rc = sat_planes_multi(srcs, sats, 3, s);
+        if (counted) {
+            const zg_image *srcs[2] = {&gi, &gmi};
+            float *sats[2] = {sat_g, sat_gm};
+            rc = sat_planes_multi(srcs, sats, 2, s);
+            const dim3 gs(ceil_div(cols, 1024), ceil_div(rows, (uint32_t)SC_COUNT_SEG));
+            switch (window_size / 2) { // cols % 4 == 0 here
+            case 1: hipLaunchKernelGGL(k_sc_count_stream<1>, gs, dim3(256), 0, s, (const uint8_t *)bli, cnt8, (int)rows, (int)cols); break;
+            case 2: hipLaunchKernelGGL(k_sc_count_stream<2>, gs, dim3(256), 0, s, (const uint8_t *)bli, cnt8, (int)rows, (int)cols); break;
+            case 3: hipLaunchKernelGGL(k_sc_count_stream<3>, gs, dim3(256), 0, s, (const uint8_t *)bli, cnt8, (int)rows, (int)cols); break;
+            default: hipLaunchKernelGGL(k_sc_count, dim3(ceil_div(cols, 64), ceil_div(rows, 32)), dim3(256), 0, s, (const uint8_t *)bli, cnt8, (int)rows, (int)cols, (int)(window_size / 2));
+            }
+        } else {
+            const zg_image *srcs[3] = {&gi, &mi, &gmi};
+            float *sats[3] = {sat_g, sat_m, sat_gm};
+            rc = sat_planes_multi(srcs, sats, 3, s);
+        }
     }
     if (rc == ZG_OK) {
         if (!bytes && hipMemsetAsync(hist, 0, SC_HIST_COPIES * 256 * sizeof(unsigned int), s) != hipSuccess) rc = ZG_ERR_HIP; // (k_sc_bli4 cleared it otherwise)
-        if (n < (1u << 30))
+        if (counted)
+            hipLaunchKernelGGL((k_sc_gradient<true, true>), dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, s, (const uint8_t *)cand, (const float *)sat_g, (const float *)cnt8, (const float *)sat_gm, grad, hist,
+                               (int)rows, (int)cols, (int)(window_size / 2));
+        else if (n < (1u << 30))
             hipLaunchKernelGGL(k_sc_gradient<true>, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, s, (const uint8_t *)cand, (const float *)sat_g, (const float *)sat_m, (const float *)sat_gm, grad, hist,
                                (int)rows, (int)cols, (int)(window_size / 2));
         else
