@@ -246,6 +246,10 @@ def test_detectors_at_frame_sizes(oracle):
             assert_bits_equal(d.canny(1.4, 50, 150).to_numpy(), oracle.canny(frame, 1.4, 50, 150), f"canny {name} {shape}")
             assert_bits_equal(d.shen_castan().to_numpy(), oracle.shen_castan(frame), f"shenCastan {name} {shape}")
         assert_bits_equal(zg.Image(torch.from_numpy(img).cuda()).shen_castan(smooth=0.7, use_nms=True).to_numpy(), oracle.shen_castan(img, smooth=0.7, use_nms=True), f"shenCastan nms {shape}")
+    # 4096^2 = 2^24 pixels exactly: the largest frame on which the mask's window count is taken directly (every value of its f32 integral image is
+    # still an exact integer), and BASELINE's frame size
+    big = oracle.synth_u8(33, (4096, 4096))
+    assert_bits_equal(zg.Image(torch.from_numpy(big).cuda()).shen_castan().to_numpy(), oracle.shen_castan(big), "shenCastan noise 4096x4096")
 
 
 @pytest.mark.gpu
