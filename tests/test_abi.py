@@ -117,6 +117,14 @@ def test_error_convention_without_a_gpu():
     rgb = _img(4, 4, L.PIXEL_RGB_U8)
     assert lib.zg_convert(ctypes.byref(a), L.CS_RGB, ctypes.byref(rgb), L.CS_RGB, None, None) == L.ERR_INVALID_ARGUMENT  # layout != space
     assert lib.zg_convert(ctypes.byref(rgb), L.CS_RGB, ctypes.byref(rgb), L.CS_OKLAB, None, None) == L.ERR_UNSUPPORTED   # Oklab needs floats
+    # the detectors' options (ShenCastan.zig:35-45) and the smoothing stage's diagnostic entry point
+    f2 = _img(4, 4, L.PIXEL_F32, data=0x2000)
+    assert lib.zg_isef_smooth(ctypes.byref(f), ctypes.byref(a), ctypes.c_float(0.9), None) == L.ERR_INVALID_ARGUMENT      # the plane comes out as f32
+    assert lib.zg_isef_smooth(ctypes.byref(f), ctypes.byref(f2), ctypes.c_float(1.0), None) == L.ERR_INVALID_ARGUMENT
+    assert b"InvalidBParameter" in lib.zg_last_error()
+    assert lib.zg_isef_smooth(ctypes.byref(f), ctypes.byref(_img(4, 5, L.PIXEL_F32, data=0x2000)), ctypes.c_float(0.9), None) == L.ERR_DIMENSION_MISMATCH
+    assert lib.zg_shen_castan(ctypes.byref(a), ctypes.byref(a), ctypes.c_float(0.9), 4, ctypes.c_float(0.99), ctypes.c_float(0.5), 1, 0, None) == L.ERR_INVALID_ARGUMENT
+    assert b"WindowSizeMustBeOdd" in lib.zg_last_error()
     # empty images are legal and do nothing (Image.empty)
     e = _img(0, 0, L.PIXEL_U8, data=None)
     assert lib.zg_conv_separable(ctypes.byref(e), ctypes.byref(e), k, 3, k, 3, 0, None) == L.OK
