@@ -961,7 +961,7 @@ __global__ __launch_bounds__(256) void k_sc_gradient(const uint8_t *cand, const 
     // out-of-range buffer offsets read as zero: the corners that do not exist (c1 == 0, r1 == 0) need no select afterwards
     constexpr uint32_t OOR = 0xfffffff0u;
     const uint32_t ocl_z = c1 > 0 ? ocl : OOR;
-    constexpr int U = 2, NG = 16 / U;
+    constexpr int U = CNT ? 4 : 2, NG = 16 / U; // steps per group (two groups in flight): the counted form has the registers for four
     struct Group { float v[U][12]; };
     auto issue = [&](int grp, Group &g) { // the 24 corner reads of steps grp * U .. + U
         bool some = false;
