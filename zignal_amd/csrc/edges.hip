@@ -839,6 +839,7 @@ __global__ __launch_bounds__(256) void k_sc_bli(const float *gray, const float *
 }
 
 constexpr int SC_HIST_COPIES = 64;
+constexpr int SC_BLI_ROWS = 16; // rows a wave of k_sc_bli4 walks (+ one above and two below): 8 -> 31.8 us, 16 -> 31.2, 32 -> 49.3 (unrolled: code and registers)
 // The same, four pixels per lane (cols % 4 == 0): a lane loads float4s, keeps the BLI of its columns and of the two beside
 // them as six bits per row (the neighbours' come over with DPP wave shifts, a workgroup's outer columns with one extra load),
 // and the marks of four pixels are a few bitwise operations on the rows above, at and below; dword and float4 stores.
@@ -848,7 +849,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_sc_bli4(const uint8_t *gray, const float *sm, uint8_t *bli, uint8_t *gm, uint8_t *cand, int rows, int cols, unsigned int *hist_to_clear) { // gray, gm: bytes
     if (blockIdx.x == 0 && blockIdx.y == 0) // the gradient kernel's histogram copies start from zero: cleared here, two launches earlier, instead of by a memset of its own
         for (int i = threadIdx.x; i < SC_HIST_COPIES * 256; i += 256) hist_to_clear[i] = 0;
-    constexpr int RW = 16;
+    constexpr int RW = SC_BLI_ROWS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x0 = blockIdx.x * 256 + lane * 4;
     const int y0 = (blockIdx.y * 4 + wave) * RW;
@@ -1266,7 +1267,7 @@ static int shen_castan_impl(const zg_image *src, const zg_image *dst, float smoo
         // the gradient stage), transpose back into `sm`, then the columns proper
         isef_plane(gray_f32 ? gray : nullptr, bytes ? gray8 : nullptr, sm, temp, grad, sat_g, (uint32_t *)(scratch + check_off), rows, cols, smooth, s);
         if (cols % 4 == 0) { // four pixels per lane (the planes start 16 bytes aligned)
-            const dim3 g4(ceil_div(cols, 256), ceil_div(rows, 64));
+            const dim3 g4(ceil_div(cols, 256), ceil_div(rows, 4u * SC_BLI_ROWS));
             if (!use_nms) hipLaunchKernelGGL(k_sc_bli4<0>, g4, dim3(256), 0, s, (const uint8_t *)gray8, (const float *)sm, bli, gm8 /* grey * BLI */, cand, (int)rows, (int)cols, hist);
             else if (rows >= 3 && cols >= 3) hipLaunchKernelGGL(k_sc_bli4<1>, g4, dim3(256), 0, s, (const uint8_t *)gray8, (const float *)sm, bli, gm8, cand, (int)rows, (int)cols, hist);
             else hipLaunchKernelGGL(k_sc_bli4<2>, g4, dim3(256), 0, s, (const uint8_t *)gray8, (const float *)sm, bli, gm8, cand, (int)rows, (int)cols, hist);
