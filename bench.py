@@ -668,6 +668,17 @@ def extras(zg, torch, np):
         ms = _time_kernel(torch, lambda i: im[i % ring][0].gaussian_blur(SIGMA, out=im[i % ring][1]))
         return rate(ms, ROWS * COLS, 8 * ROWS * COLS)  # one f32 plane: 4 B read + 4 B written per pixel
 
+    def blur_planes4():
+        # BASELINE configs[1] in the one form a zignal caller can express for f32 data: four Image(f32) planes (convolveSeparable rejects
+        # Rgba(f32) at comptime, convolution.zig:431-435), all four in ONE launch (zg_gaussian_blur_planes). 2 GiB of planes.
+        ring = 4
+        quads = [([zg.Image(torch.rand((ROWS, COLS), dtype=torch.float32, device="cuda")) for _ in range(4)],
+                  [zg.Image(torch.empty((ROWS, COLS), dtype=torch.float32, device="cuda")) for _ in range(4)]) for _ in range(ring)]
+        ms = _time_kernel(torch, lambda i: zg.gaussian_blur_planes(quads[i % ring][0], SIGMA, outs=quads[i % ring][1]), n=20, warm=4)
+        r = rate(ms, ROWS * COLS, 32 * ROWS * COLS)  # per RGBA pixel: 16 B read + 16 B written
+        r["planes_per_launch"] = 4
+        return r
+
     def sobel():
         ring = 8
         im = [(zg.Image(s), zg.Image(torch.empty((ROWS, COLS), dtype=torch.uint8, device="cuda"))) for s in u8_frames(ring, (ROWS, COLS, 4))]
@@ -873,6 +884,7 @@ def extras(zg, torch, np):
     leg("io_png_file_rgba_u8_4096", png_files)
     leg("io_jpeg_file_420_q90_4096", jpeg_files)
     leg("config2a_gaussian_blur_one_f32_plane_4096", blur_planes)
+    leg("config2a_gaussian_blur_four_f32_planes_one_launch_4096", blur_planes4)
     leg("config2b_gaussian_blur_rgba_u8_4096", blur_u8)
     leg("config3_resize_bilinear_rgba_u8_4096_to_1024", resize_u8)
     leg("resize_bilinear_rgba_u8_8192_to_4096", lambda: resize_dense(8192, 4096))

@@ -197,6 +197,19 @@ ZG_API int zg_gaussian_blur_host(const zg_image *src, const zg_image *dst, float
  * or a negative zg_status. `taps` may be NULL to query the count. */
 ZG_API int zg_gaussian_kernel(float sigma, float *taps, uint32_t capacity);
 
+/* convolveSeparable / gaussianBlur over n_planes images of one shape in ONE launch where the device has a kernel for it. The
+ * reference's f32 route is per plane: Image(f32).convolveSeparable works, Image(Rgba(f32)) is a compile error
+ * (src/image/convolution.zig:431-435), so a host that holds RGBA f32 data as four Image(f32) planes (the layout
+ * splitChannels, src/image/channel_ops.zig:56-136, produces for the u8 structs) calls these with n_planes = 4 instead of
+ * paying four launches. src / dst are host arrays of n_planes descriptors (device pixels); plane i goes src[i] -> dst[i],
+ * each pair checked exactly as zg_conv_separable / zg_gaussian_blur check theirs (DimensionMismatch, InvalidSigma, ...)
+ * before anything is launched. Any pixel type is accepted; planes that do not share a launch run one after the other on
+ * `stream`. The result of every plane equals the single-plane call bit for bit. */
+ZG_API int zg_conv_separable_planes(const zg_image *src, const zg_image *dst, uint32_t n_planes,
+                                    const float *kx, uint32_t nkx, const float *ky, uint32_t nky,
+                                    int border, zg_stream stream);
+ZG_API int zg_gaussian_blur_planes(const zg_image *src, const zg_image *dst, uint32_t n_planes, float sigma, zg_stream stream);
+
 /* Image(T).convolve (src/image.zig:917-932 -> src/image/convolution.zig:76-301); kernel is
  * row-major kh x kw f32 on the host. */
 ZG_API int zg_convolve(const zg_image *src, const zg_image *dst,

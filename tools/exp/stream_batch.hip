@@ -2,7 +2,7 @@
 // HIP events over a ring of batches, with pieces of the kernel compiled out: -DZG_STREAM_NOLOAD (constants instead of loads),
 // -DZG_STREAM_NOSTORE (results kept alive, nothing written), both; -DZG_STREAM_NOARITH (the loads and the stores alone). Includes the product kernel source.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DZG_STREAM_NOLOAD] [-DZG_STREAM_NOSTORE] -I zignal_amd/csrc -o tools/exp/stream_batch_<v> tools/exp/stream_batch.hip
-// usage: stream_batch [frames=128] [rows=1080] [cols=1920] [down2=1] [strip_rows=44]
+// usage: stream_batch [frames=128] [rows=1080] [cols=1920] [down2=1] [strip_rows=44] [unit=1: the folded row pass of round 5]
 #include "../../zignal_amd/csrc/conv_sep_stream.hip"
 #include <cstdio>
 #include <vector>
@@ -14,6 +14,7 @@ int main(int argc, char **argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 128, rows = argc > 2 ? atoi(argv[2]) : 1080, cols = argc > 3 ? atoi(argv[3]) : 1920;
     const bool down2 = argc > 4 ? atoi(argv[4]) != 0 : true;
     const int strip_rows = argc > 5 ? atoi(argv[5]) : 44;
+    const bool unit = argc > 6 ? atoi(argv[6]) != 0 : true;
     const size_t in_frame = (size_t)rows * cols * 4, out_frame = down2 ? in_frame / 4 : in_frame;
     const int ring = 3;
     uint8_t *src, *dst;
@@ -34,8 +35,10 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     auto launch = [&](int r) {
         a.src = src + (size_t)(r % ring) * in_frame * n; a.dst = dst + (size_t)(r % ring) * out_frame * n;
-        if (down2) hipLaunchKernelGGL((k_sep_stream<4, 5, false, true, 1>), dim3(items), dim3(64), 0, 0, a, k, k);
-        else hipLaunchKernelGGL((k_sep_stream<4, 5, false, false, 1>), dim3(items), dim3(64), 0, 0, a, k, k);
+        if (down2 && unit) hipLaunchKernelGGL((k_sep_stream<4, 5, false, true, 1, true>), dim3(items), dim3(64), 0, 0, a, k, k);
+        else if (down2) hipLaunchKernelGGL((k_sep_stream<4, 5, false, true, 1, false>), dim3(items), dim3(64), 0, 0, a, k, k);
+        else if (unit) hipLaunchKernelGGL((k_sep_stream<4, 5, false, false, 1, true>), dim3(items), dim3(64), 0, 0, a, k, k);
+        else hipLaunchKernelGGL((k_sep_stream<4, 5, false, false, 1, false>), dim3(items), dim3(64), 0, 0, a, k, k);
     };
     for (int r = 0; r < 900; ++r) launch(r); // ~0.3 s: the clocks have ramped
     (void)hipDeviceSynchronize();
@@ -56,6 +59,6 @@ int main(int argc, char **argv) {
 #else
         "whole kernel";
 #endif
-    printf("%-20s %d x %d x %d down2=%d strip_rows=%d: %u waves, %.1f us per launch\n", variant, n, rows, cols, (int)down2, strip_rows, items, ms * 1e3 / reps);
+    printf("%-20s %d x %d x %d down2=%d strip_rows=%d fold=%d: %u waves, %.1f us per launch\n", variant, n, rows, cols, (int)down2, strip_rows, (int)unit, items, ms * 1e3 / reps);
     return 0;
 }

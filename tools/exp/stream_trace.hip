@@ -26,7 +26,7 @@ int main(int argc, char **argv) {
     for (int rep = 0; rep < 12; ++rep) {
         a.src = src + (size_t)(rep & 3) * R * R * 4; a.dst = dst + (size_t)(rep & 3) * R * R * 4;
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k_sep_stream<4, 5, false, false, 1>), dim3(items), dim3(64), 0, 0, a, k, k);
+        hipLaunchKernelGGL((k_sep_stream<4, 5, false, false, 1, false>), dim3(items), dim3(64), 0, 0, a, k, k);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         hipMemcpy(h.data(), a.trace, (size_t)items * 32, hipMemcpyDeviceToHost);

@@ -196,6 +196,8 @@ pub const c = struct {
     pub extern fn zg_set_border(img: *const ZgImage, rect: *const [4]u32, pixel_value: *const anyopaque, stream: ?*anyopaque) c_int;
     pub extern fn zg_crop(src: *const ZgImage, dst: *const ZgImage, rect: *const [4]f32, stream: ?*anyopaque) c_int;
     pub extern fn zg_gaussian_blur(src: *const ZgImage, dst: *const ZgImage, sigma: f32, stream: ?*anyopaque) c_int;
+    pub extern fn zg_conv_separable_planes(src: [*]const ZgImage, dst: [*]const ZgImage, n_planes: u32, kx: [*]const f32, nkx: u32, ky: [*]const f32, nky: u32, border: c_int, stream: ?*anyopaque) c_int;
+    pub extern fn zg_gaussian_blur_planes(src: [*]const ZgImage, dst: [*]const ZgImage, n_planes: u32, sigma: f32, stream: ?*anyopaque) c_int;
     pub extern fn zg_autocontrast(img: *const ZgImage, cutoff: f32, stream: ?*anyopaque) c_int;
     pub extern fn zg_box_blur(src: *const ZgImage, dst: *const ZgImage, radius: u32, stream: ?*anyopaque) c_int;
     pub extern fn zg_canny(src: *const ZgImage, dst: *const ZgImage, sigma: f32, low_threshold: f32, high_threshold: f32, stream: ?*anyopaque) c_int;
@@ -778,6 +780,42 @@ pub fn DeviceImage(comptime T: type) type {
             }
             for (kernel) |*k| k.* /= sum;
             try self.convolveSeparable(out, allocator, kernel, kernel, .mirror);
+        }
+        /// convolveSeparable over several planes of one shape in one launch (zg_conv_separable_planes). The reference's f32 route
+        /// is per plane — Image(Rgba(f32)).convolveSeparable is a compile error (src/image/convolution.zig:431-435) — so a host that
+        /// keeps RGBA f32 data as four Image(f32) planes calls this with all four instead of paying four launches. Asynchronous on
+        /// planes[0].stream; every pair is checked like the single-plane call.
+        pub fn convolveSeparablePlanes(planes: []const Self, outs: []const Self, allocator: std.mem.Allocator, kernel_x: []const f32, kernel_y: []const f32, border: BorderMode) !void {
+            if (planes.len != outs.len) return error.DimensionMismatch;
+            if (planes.len == 0) return;
+            const descs = try allocator.alloc(c.ZgImage, 2 * planes.len);
+            defer allocator.free(descs);
+            for (planes, outs, 0..) |p, o, i| {
+                if (!p.hasSameShape(o)) return error.DimensionMismatch;
+                descs[i] = p.desc();
+                descs[planes.len + i] = o.desc();
+            }
+            try check(c.zg_conv_separable_planes(descs.ptr, descs.ptr + planes.len, @intCast(planes.len), kernel_x.ptr, @intCast(kernel_x.len), kernel_y.ptr, @intCast(kernel_y.len), @intFromEnum(border), planes[0].stream));
+        }
+        /// gaussianBlur (reference src/image.zig:954-994) over several planes in one launch; the taps are Zig's own (@exp), as in gaussianBlur.
+        pub fn gaussianBlurPlanes(planes: []const Self, outs: []const Self, allocator: std.mem.Allocator, sigma: f32) !void {
+            if (planes.len != outs.len) return error.DimensionMismatch;
+            if (sigma < 0) return error.InvalidSigma;
+            if (sigma == 0) {
+                for (planes, outs) |p, o| try p.gaussianBlur(o, allocator, 0);
+                return;
+            }
+            const radius: usize = @ceil(3.0 * sigma);
+            const kernel = try allocator.alloc(f32, 2 * radius + 1);
+            defer allocator.free(kernel);
+            var sum: f32 = 0;
+            for (kernel, 0..) |*k, i| {
+                const x = @as(f32, @floatFromInt(i)) - @as(f32, @floatFromInt(radius));
+                k.* = @exp(-(x * x) / (2.0 * sigma * sigma));
+                sum += k.*;
+            }
+            for (kernel) |*k| k.* /= sum;
+            try convolveSeparablePlanes(planes, outs, allocator, kernel, kernel, .mirror);
         }
         /// reference src/image.zig:917-932
         pub fn convolve(self: Self, out: Self, allocator: std.mem.Allocator, kernel: anytype, border: BorderMode) !void {

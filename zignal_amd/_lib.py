@@ -164,6 +164,8 @@ _SIGNATURES = {
     "zg_gaussian_blur": [_IMG, _IMG, C.c_float, C.c_void_p],
     "zg_gaussian_blur_host": [_IMG, _IMG, C.c_float],
     "zg_gaussian_kernel": [C.c_float, _F32P, C.c_uint32],
+    "zg_conv_separable_planes": [_IMG, _IMG, C.c_uint32, _F32P, C.c_uint32, _F32P, C.c_uint32, C.c_int, C.c_void_p],
+    "zg_gaussian_blur_planes": [_IMG, _IMG, C.c_uint32, C.c_float, C.c_void_p],
     "zg_convolve": [_IMG, _IMG, _F32P, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p],
     "zg_convolve_host": [_IMG, _IMG, _F32P, C.c_uint32, C.c_uint32, C.c_int],
     "zg_box_blur": [_IMG, _IMG, C.c_uint32, C.c_void_p],

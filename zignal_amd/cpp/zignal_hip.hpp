@@ -387,6 +387,25 @@ template <typename T> class DeviceImage : public detail::Ops<DeviceImage, T> {
         const zg_image d = host.desc(), s = this->desc();
         check(zg_image_download(&d, &s, stream_));
     }
+    // convolveSeparable / gaussianBlur over several planes of one shape in one launch (zg_conv_separable_planes / zg_gaussian_blur_planes):
+    // the reference's f32 route is per plane (Image(Rgba(f32)).convolveSeparable is a compile error, convolution.zig:431-435), so RGBA f32
+    // data held as four Image(f32) planes goes through here. Asynchronous on planes[0]'s stream.
+    static void convolveSeparablePlanes(const std::vector<const DeviceImage *> &planes, const std::vector<const DeviceImage *> &outs,
+                                        const std::vector<float> &kx, const std::vector<float> &ky, BorderMode border) {
+        if (planes.size() != outs.size()) throw DimensionMismatch(1, "convolveSeparablePlanes");
+        if (planes.empty()) return;
+        std::vector<zg_image> s, d;
+        for (size_t i = 0; i < planes.size(); ++i) { s.push_back(planes[i]->desc()); d.push_back(outs[i]->desc()); }
+        check(zg_conv_separable_planes(s.data(), d.data(), (uint32_t)s.size(), kx.data(), (uint32_t)kx.size(), ky.data(), (uint32_t)ky.size(), (int)border,
+                                       planes[0]->stream()));
+    }
+    static void gaussianBlurPlanes(const std::vector<const DeviceImage *> &planes, const std::vector<const DeviceImage *> &outs, float sigma) {
+        if (planes.size() != outs.size()) throw DimensionMismatch(1, "gaussianBlurPlanes");
+        if (planes.empty()) return;
+        std::vector<zg_image> s, d;
+        for (size_t i = 0; i < planes.size(); ++i) { s.push_back(planes[i]->desc()); d.push_back(outs[i]->desc()); }
+        check(zg_gaussian_blur_planes(s.data(), d.data(), (uint32_t)s.size(), sigma, planes[0]->stream()));
+    }
     Image<T> toHost() const {
         Image<T> out = Image<T>::init(rows, cols);
         download(out);

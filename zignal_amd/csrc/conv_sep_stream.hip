@@ -47,6 +47,7 @@ struct StreamArgs {
     int32_t border;
     uint32_t src_span, dst_span;   // bytes from a frame's first byte to the end of its last row
     int32_t fast_ok;               // both spans fit 32 bits: whole-frame descriptors may be used
+    int32_t addr_order;            // work items in address order (no XCD-major renumbering)
 #ifdef ZG_STREAM_TRACE
     unsigned long long *trace;     // tools/exp/stream_trace.hip: per wave {start, end} of the 100 MHz clock + shader cycles
 #endif
@@ -93,11 +94,33 @@ template <int SP, int NK, int N> __device__ __forceinline__ void row_pass_tap_ma
         for (int t = 0; t < 16; ++t) out[t] = i == 0 ? P[t] * kk : out[t] + P[t + SP * i] * kk; // <= 65535 by the preconditions: exact
     }
 }
+// Symmetric taps with unit ends (gaussianBlur(0.6) is [1, 42, 170, 42, 1], the metric's own kernel): the mirrored positions are added
+// first — bytes, so the sums stay far inside 16 bits — and the end pair needs no multiply at all: four packed operations per byte pair
+// and row pair instead of five (5 taps), two instead of three (3 taps), six instead of seven (7 taps). Integer sums: same value, bit for bit.
+template <int SP, int NK, int N> __device__ __forceinline__ void row_pass_unit_sym(const u16x2 (&P)[N], const TapsU8<NK> &kx, u16x2 (&out)[16]) {
+    constexpr int H = NK / 2;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) out[t] = P[t] + P[t + SP * (NK - 1)];
+#pragma unroll
+    for (int i = 1; i < H; ++i) {
+        const uint16_t k = (uint16_t)kx.k[i];
+        const u16x2 kk = {k, k};
+        u16x2 s[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s[t] = P[t + SP * i] + P[t + SP * (NK - 1 - i)];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) out[t] = out[t] + s[t] * kk;
+    }
+    const uint16_t kc = (uint16_t)kx.k[H];
+    const u16x2 kkc = {kc, kc};
+#pragma unroll
+    for (int t = 0; t < 16; ++t) out[t] = out[t] + P[t + SP * H] * kkc;
+}
 __device__ __forceinline__ uint32_t dot2_u16_s(uint32_t packed, uint32_t kpair, uint32_t acc) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, packed), __builtin_bit_cast(u16x2, kpair), acc, false);
 }
 
-template <int SP, int NK, bool CLAMP, bool DOWN2, int DM>
+template <int SP, int NK, bool CLAMP, bool DOWN2, int DM, bool UNIT>
 __global__ __launch_bounds__(64) void k_sep_stream(StreamArgs a, TapsU8<NK> kx, TapsU8<NK> ky) {
     constexpr int H = NK / 2;
     constexpr int HB = (H * SP + 3) / 4;  // halo dwords per side
@@ -111,7 +134,7 @@ __global__ __launch_bounds__(64) void k_sep_stream(StreamArgs a, TapsU8<NK> kx, 
 #endif
     const uint32_t nwg = gridDim.x, per_xcd = nwg >> 3;
     uint32_t w = blockIdx.x;
-    if (w < (per_xcd << 3)) w = (w & 7) * per_xcd + (w >> 3); // XCD-major: an XCD's L2 sees whole bands of neighbouring strips
+    if (!a.addr_order && w < (per_xcd << 3)) w = (w & 7) * per_xcd + (w >> 3); // XCD-major: an XCD's L2 sees whole bands of neighbouring strips
     const uint32_t per_frame = (uint32_t)(a.strips_x * a.strips_y);
     const uint32_t frame = w / per_frame, t = w - frame * per_frame;
     const int sy = (int)(t / (uint32_t)a.strips_x), sx = (int)(t - (uint32_t)sy * (uint32_t)a.strips_x);
@@ -277,7 +300,8 @@ __global__ __launch_bounds__(64) void k_sep_stream(StreamArgs a, TapsU8<NK> kx, 
                 // tap-major: consecutive instructions write different accumulators. (Byte-major — one byte's five taps in a row — is a
                 // chain of dependent packed operations, and gfx950 needs a wait state between those: hipcc put an s_nop after every one,
                 // ~50 issue slots per row pair.)
-                row_pass_tap_major<SP, NK, NP>(P, kx, win[u % NQ]);
+                if constexpr (UNIT) row_pass_unit_sym<SP, NK, NP>(P, kx, win[u % NQ]);
+                else row_pass_tap_major<SP, NK, NP>(P, kx, win[u % NQ]);
                 if (q < H) continue; // wave-uniform: the strip's first H pairs only feed the window
 
                 // output rows 2m, 2m + 1 of the strip, m = q - H: source row pairs m .. m + H = slots (u + 1) % NQ .. u % NQ, oldest first
@@ -285,7 +309,12 @@ __global__ __launch_bounds__(64) void k_sep_stream(StreamArgs a, TapsU8<NK> kx, 
                 // divClampU8(65536, a) for a >= 0 is min(255, (a + 32768) >> 16): the rounding term seeds the accumulator. Tap-major here too.
                 uint32_t ve[16], vo[16];
 #pragma unroll
-                for (int t2 = 0; t2 < 16; ++t2) vo[t2] = mad_hi16(__builtin_bit_cast(uint32_t, win[(u + 1) % NQ][t2]), ky.k[0], 32768u);
+                for (int t2 = 0; t2 < 16; ++t2) {
+                    // unit end taps (UNIT: the host checked both kernels): the end rows are plain 32-bit additions with a word select (SDWA)
+                    // where the general form is a 16 x 16 multiply-add — half the issue time (profiles/r03_valu_rates.txt)
+                    if constexpr (UNIT) vo[t2] = (__builtin_bit_cast(uint32_t, win[(u + 1) % NQ][t2]) >> 16) + 32768u;
+                    else vo[t2] = mad_hi16(__builtin_bit_cast(uint32_t, win[(u + 1) % NQ][t2]), ky.k[0], 32768u);
+                }
 #pragma unroll
                 for (int t2 = 0; t2 < 16; ++t2) ve[t2] = dot2_u16_s(__builtin_bit_cast(uint32_t, win[(u + 1) % NQ][t2]), ky.k[0] | (ky.k[1] << 16), 32768u);
 #pragma unroll
@@ -299,15 +328,14 @@ __global__ __launch_bounds__(64) void k_sep_stream(StreamArgs a, TapsU8<NK> kx, 
                 }
 #pragma unroll
                 for (int t2 = 0; t2 < 16; ++t2) {
-                    uint32_t e = mad_lo16(__builtin_bit_cast(uint32_t, win[u % NQ][t2]), ky.k[NK - 1], ve[t2]), o = vo[t2];
+                    uint32_t e, o = vo[t2];
+                    if constexpr (UNIT) e = (__builtin_bit_cast(uint32_t, win[u % NQ][t2]) & 0xffffu) + ve[t2];
+                    else e = mad_lo16(__builtin_bit_cast(uint32_t, win[u % NQ][t2]), ky.k[NK - 1], ve[t2]);
                     if constexpr (CLAMP) {
                         e >>= 16; o >>= 16;
                         ve[t2] = e > 255u ? 255u : e;
                         vo[t2] = o > 255u ? 255u : o;
-                    } else if constexpr (DOWN2) { // host proved acc < 2^24: the value is byte 2
-                        ve[t2] = e >> 16;
-                        vo[t2] = o >> 16;
-                    } else { // ... extracted by the packing below
+                    } else { // host proved acc < 2^24: the value is byte 2, extracted by the packing (or by the 2 x 2 mean's word selects) below
                         ve[t2] = e;
                         vo[t2] = o;
                     }
@@ -332,7 +360,11 @@ __global__ __launch_bounds__(64) void k_sep_stream(StreamArgs a, TapsU8<NK> kx, 
                     for (int o2 = 0; o2 < 2; ++o2) {
                         uint32_t c[4];
 #pragma unroll
-                        for (int ch = 0; ch < 4; ++ch) c[ch] = (ve[8 * o2 + ch] + ve[8 * o2 + 4 + ch] + vo[8 * o2 + ch] + vo[8 * o2 + 4 + ch]) >> 2;
+                        for (int ch = 0; ch < 4; ++ch) {
+                            if constexpr (CLAMP) c[ch] = (ve[8 * o2 + ch] + ve[8 * o2 + 4 + ch] + vo[8 * o2 + ch] + vo[8 * o2 + 4 + ch]) >> 2;
+                            else // the four values are the high words of their accumulators: additions with word selects, no shifts of their own
+                                c[ch] = (((ve[8 * o2 + ch] >> 16) + (ve[8 * o2 + 4 + ch] >> 16)) + ((vo[8 * o2 + ch] >> 16) + (vo[8 * o2 + 4 + ch] >> 16))) >> 2;
+                        }
                         o[o2] = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
                     }
                     store_row(o, gy >> 1);
@@ -390,6 +422,7 @@ static int launch_stream(const StreamJob &j, const int32_t *ix, const int32_t *i
     a.strip_rows = stream_strip_rows(j, (uint32_t)a.strips_x, NK / 2, NK / 2 + 1);
     a.strips_y = (int32_t)ceil_div(j.rows, (unsigned)a.strip_rows);
     a.border = border;
+    a.addr_order = getenv("ZIGNAL_HIP_STREAM_ADDR_ORDER") != nullptr; // experiment hook of round 5
     const uint64_t sspan = (uint64_t)(j.rows - 1) * j.src_pitch + (uint64_t)a.row_bytes;
     const uint64_t dspan = j.down2 ? (uint64_t)(j.rows / 2 - 1) * j.dst_pitch + (uint64_t)(a.row_bytes / 2) : (uint64_t)(j.rows - 1) * j.dst_pitch + (uint64_t)a.row_bytes;
     a.fast_ok = sspan <= 0xffffffffu && dspan <= 0xffffffffu;
@@ -397,7 +430,17 @@ static int launch_stream(const StreamJob &j, const int32_t *ix, const int32_t *i
     a.dst_span = (uint32_t)dspan;
     const uint64_t items = (uint64_t)a.strips_x * a.strips_y * j.n_frames;
     if (items > 0x7fffffffu) return -1;
-    hipLaunchKernelGGL((k_sep_stream<SP, NK, CLAMP, DOWN2, 1>), dim3((unsigned)items), dim3(64), 0, s, a, kx, ky);
+    // row taps symmetric with unit ends: the folded row pass (the CLAMP instantiations — tap sums past 256 — keep the plain one)
+    bool unit = ix[0] == 1 && iy[0] == 1 && iy[NK - 1] == 1 && !getenv("ZIGNAL_HIP_STREAM_NO_FOLD"); // A/B hook of this round
+    for (int i = 0; i < NK; ++i) unit = unit && ix[i] == ix[NK - 1 - i];
+    if constexpr (!CLAMP) {
+        if (unit) {
+            hipLaunchKernelGGL((k_sep_stream<SP, NK, CLAMP, DOWN2, 1, true>), dim3((unsigned)items), dim3(64), 0, s, a, kx, ky);
+            ZG_HIP(hipGetLastError());
+            return ZG_OK;
+        }
+    }
+    hipLaunchKernelGGL((k_sep_stream<SP, NK, CLAMP, DOWN2, 1, false>), dim3((unsigned)items), dim3(64), 0, s, a, kx, ky);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

@@ -546,6 +546,9 @@ int try_sep_f32long(const zg_image *src, const zg_image *dst, const float *fx, i
 int try_sep_bytes2(const zg_image *src, const zg_image *dst, const int32_t *ix, int nkx, const int32_t *iy, int nky, int border, hipStream_t s);
 int try_sep_f32x4(const zg_image *src, const zg_image *dst, const float *fx, const float *fy, int nk, uint32_t skipx, uint32_t skipy,
                   int border, hipStream_t s);
+constexpr uint32_t SF_MAX_PLANES = 8; // planes per launch of conv_sep_tile_f32.hip
+int try_sep_tile_f32(const zg_image *src, const zg_image *dst, uint32_t n, const float *fx, const float *fy, int nk, uint32_t skipx, uint32_t skipy,
+                       int border, hipStream_t s);
 
 static int conv_separable_impl(const zg_image *src, const zg_image *dst, const float *kx, uint32_t nkx,
                                const float *ky, uint32_t nky, int border, hipStream_t s) {
@@ -570,6 +573,8 @@ static int conv_separable_impl(const zg_image *src, const zg_image *dst, const f
         for (uint32_t i = 0; i < nkx && i < 32; ++i) if (std::fabs(kx[i]) < 1e-10f) p.skipx |= 1u << i;
         for (uint32_t i = 0; i < nky && i < 32; ++i) if (std::fabs(ky[i]) < 1e-10f) p.skipy |= 1u << i;
         if (src->pixel == ZG_PIXEL_F32 && p.nkx == p.nky) { // single-channel planes: four pixels per lane
+            const int rcs = try_sep_tile_f32(src, dst, 1, p.fx.data(), p.fy.data(), p.nkx, p.skipx, p.skipy, border, s); // one wave per tile, no LDS
+            if (rcs >= 0) return rcs;
             const int rc4 = try_sep_f32x4(src, dst, p.fx.data(), p.fy.data(), p.nkx, p.skipx, p.skipy, border, s);
             if (rc4 >= 0) return rc4;
         }
@@ -627,6 +632,47 @@ static int conv_separable_impl(const zg_image *src, const zg_image *dst, const f
     });
 }
 
+// n planes of one shape through convolveSeparable: one launch per SF_MAX_PLANES of them where the f32 tile kernel applies (the planes
+// then only have to agree in shape, strides and alignment), plane by plane otherwise. Every plane is validated before anything is launched.
+static int conv_separable_planes_impl(const zg_image *src, const zg_image *dst, uint32_t n, const float *kx, uint32_t nkx,
+                                      const float *ky, uint32_t nky, int border, hipStream_t s) {
+    ZG_REQUIRE(n == 0 || (src && dst), ZG_ERR_INVALID_ARGUMENT, "convolveSeparable (planes): null plane array");
+    ZG_REQUIRE(kx && ky && nkx >= 1 && nky >= 1 && nkx <= MAX_TAPS_MEM && nky <= MAX_TAPS_MEM, ZG_ERR_INVALID_ARGUMENT,
+               "convolveSeparable: kernel lengths %u, %u (1..%d supported)", nkx, nky, MAX_TAPS_MEM);
+    ZG_REQUIRE(border >= ZG_BORDER_ZERO && border <= ZG_BORDER_WRAP, ZG_ERR_INVALID_ARGUMENT, "invalid border %d", border);
+    for (uint32_t p = 0; p < n; ++p) {
+        int rc;
+        if ((rc = check_image(&src[p], "src")) || (rc = check_image(&dst[p], "dst"))) return rc;
+        ZG_REQUIRE(src[p].rows == dst[p].rows && src[p].cols == dst[p].cols, ZG_ERR_DIMENSION_MISMATCH,
+                   "convolveSeparable: plane %u is %ux%u vs %ux%u", p, src[p].rows, src[p].cols, dst[p].rows, dst[p].cols);
+        ZG_REQUIRE(src[p].pixel == dst[p].pixel, ZG_ERR_INVALID_ARGUMENT, "convolveSeparable: pixel types of plane %u differ", p);
+    }
+    uint32_t p = 0;
+    while (p < n) {
+        uint32_t run = 1; // planes p .. p + run - 1 share a launch
+        if (src[p].pixel == ZG_PIXEL_F32 && nkx == nky && src[p].rows && src[p].cols) {
+            uint32_t skipx = 0, skipy = 0;
+            for (uint32_t i = 0; i < nkx && i < 32; ++i) {
+                if (std::fabs(kx[i]) < 1e-10f) skipx |= 1u << i;
+                if (std::fabs(ky[i]) < 1e-10f) skipy |= 1u << i;
+            }
+            while (run < SF_MAX_PLANES && p + run < n && src[p + run].pixel == ZG_PIXEL_F32 && src[p + run].rows == src[p].rows &&
+                   src[p + run].cols == src[p].cols && src[p + run].stride == src[p].stride && dst[p + run].stride == dst[p].stride)
+                ++run;
+            const int rcs = try_sep_tile_f32(src + p, dst + p, run, kx, ky, (int)nkx, skipx, skipy, border, s);
+            if (rcs >= 0) {
+                if (rcs != ZG_OK) return rcs;
+                p += run;
+                continue;
+            }
+            run = 1;
+        }
+        if (int rc = conv_separable_impl(&src[p], &dst[p], kx, nkx, ky, nky, border, s)) return rc;
+        p += run;
+    }
+    return ZG_OK;
+}
+
 int copy_impl(const zg_image *src, const zg_image *dst, hipStream_t s);
 
 } // namespace zg
@@ -655,6 +701,11 @@ int zg_conv_separable_host(const zg_image *src, const zg_image *dst, const float
     if ((rc = conv_separable_impl(&a.dev, &b.dev, kx, nkx, ky, nky, border, nullptr))) return rc;
     ZG_HIP(hipStreamSynchronize(nullptr));
     return b.finish();
+}
+
+int zg_conv_separable_planes(const zg_image *src, const zg_image *dst, uint32_t n_planes, const float *kx, uint32_t nkx,
+                             const float *ky, uint32_t nky, int border, zg_stream stream) {
+    return conv_separable_planes_impl(src, dst, n_planes, kx, nkx, ky, nky, border, as_stream(stream));
 }
 
 // image.zig:973-990
@@ -691,6 +742,27 @@ static int gaussian_impl(const zg_image *src, const zg_image *dst, float sigma, 
 
 int zg_gaussian_blur(const zg_image *src, const zg_image *dst, float sigma, zg_stream stream) {
     return gaussian_impl(src, dst, sigma, as_stream(stream));
+}
+
+int zg_gaussian_blur_planes(const zg_image *src, const zg_image *dst, uint32_t n_planes, float sigma, zg_stream stream) {
+    hipStream_t s = as_stream(stream);
+    ZG_REQUIRE(n_planes == 0 || (src && dst), ZG_ERR_INVALID_ARGUMENT, "gaussianBlur (planes): null plane array");
+    if (!(sigma > 0)) { // sigma == 0 copies, anything else is error.InvalidSigma: per plane, exactly as zg_gaussian_blur
+        for (uint32_t p = 0; p < n_planes; ++p)
+            if (int rc = gaussian_impl(&src[p], &dst[p], sigma, s)) return rc;
+        return ZG_OK;
+    }
+    for (uint32_t p = 0; p < n_planes; ++p) {
+        int rc;
+        if ((rc = check_image(&src[p], "src")) || (rc = check_image(&dst[p], "dst"))) return rc;
+        ZG_REQUIRE(src[p].rows == dst[p].rows && src[p].cols == dst[p].cols, ZG_ERR_DIMENSION_MISMATCH,
+                   "gaussianBlur: plane %u is %ux%u vs %ux%u", p, src[p].rows, src[p].cols, dst[p].rows, dst[p].cols);
+    }
+    const int n = zg_gaussian_kernel(sigma, nullptr, 0);
+    if (n < 0) return -n;
+    std::vector<float> taps((size_t)n);
+    if (zg_gaussian_kernel(sigma, taps.data(), (uint32_t)n) != n) return ZG_ERR_INVALID_ARGUMENT;
+    return conv_separable_planes_impl(src, dst, n_planes, taps.data(), (uint32_t)n, taps.data(), (uint32_t)n, ZG_BORDER_MIRROR, s);
 }
 
 int zg_gaussian_blur_host(const zg_image *src, const zg_image *dst, float sigma) {

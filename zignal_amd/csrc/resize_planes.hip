@@ -18,6 +18,7 @@
 #include "zg_bilinear_u8.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <list>
 #include <map>
@@ -343,18 +344,20 @@ static int axis_table(int kind, uint32_t src_n, uint32_t dst_n, int taps, AxisTa
 // A launch covers `frames` equally shaped images laid out `src_frame` / `dst_frame` bytes apart (a batch of the pipeline, batch.hip):
 // a 4096^2 -> 1024^2 frame is 4 096 workgroups of one gather each, i.e. launch ramp and tail; sixteen of them in one grid keep the chip
 // full (profiles/r03_batched_resize.txt).
-template <int NPX>
-__global__ __launch_bounds__(256) void k_resize_bilinear_rgba8(DImg src, DImg dst, float ratio_x, float ratio_y, int tiles_x, FrameSpan fr) {
+template <int NPX, int WAVES, bool XCD>
+__global__ __launch_bounds__(64 * WAVES) void k_resize_bilinear_rgba8(DImg src, DImg dst, float ratio_x, float ratio_y, int tiles_x, FrameSpan fr) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
-    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    if constexpr (XCD) {
+        const int nwg = gridDim.x, per_xcd = nwg >> 3;
+        if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    }
     src.data = (char *)src.data + (size_t)blockIdx.y * fr.src_frame;
     dst.data = (char *)dst.data + (size_t)blockIdx.y * fr.dst_frame;
     const int tyi = wg / tiles_x, txi = wg - tyi * tiles_x;
     const int c0 = (txi * 64 + (int)(threadIdx.x & 63)) * NPX;
-    const int r = __builtin_amdgcn_readfirstlane(tyi * 4 + (int)(threadIdx.x >> 6)); // one row per wave
+    const int r = __builtin_amdgcn_readfirstlane(tyi * WAVES + (int)(threadIdx.x >> 6)); // one row per wave
     if (r >= dst.rows || c0 >= dst.cols) return;
     int y0, y1, fy;
     bilinear_taps(r, ratio_y, src.rows, y0, y1, fy);
@@ -384,7 +387,10 @@ __global__ __launch_bounds__(256) void k_resize_bilinear_rgba8(DImg src, DImg ds
 int resize_bilinear_rgba8_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s) {
     if (src->pixel != ZG_PIXEL_RGBA_U8 || dst->pixel != ZG_PIXEL_RGBA_U8 || src->cols < 2 || src->rows == 0 || dst->rows == 0 || dst->cols == 0 || n == 0) return -1;
     if (src->rows == dst->rows && src->cols == dst->cols) return -1; // equal sizes are a copy (interpolation.zig:100-108)
-    const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, 4);
+    int form = 0; // experiment hook of round 5: 0 = 4 rows per workgroup, XCD-major; 1 = 4 rows, address order; 2 = 1 row (one wave), address order; 3 = 1 row, XCD-major
+    if (const char *e = getenv("ZIGNAL_HIP_RESIZE_FORM")) form = atoi(e);
+    const int waves = form >= 2 ? 1 : 4;
+    const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, (unsigned)waves);
     const float ratio_x = (float)src->cols / (float)dst->cols, ratio_y = (float)src->rows / (float)dst->rows;
     const bool x4 = ratio_x <= 1.5f && dst->cols % 4 == 0 && dst->stride % 4 == 0 && ((uintptr_t)dst->data & 15) == 0 && dst_frame % 16 == 0;
     const int tx = x4 ? (int)ceil_div(dst->cols, 256) : tiles_x;
@@ -392,8 +398,15 @@ int resize_bilinear_rgba8_frames(const zg_image *src, const zg_image *dst, uint3
     if (tiles > 0x7fffffffu || n > MAX_FRAMES_PER_LAUNCH) return -1;
     const dim3 grid((unsigned)tiles, n);
     const FrameSpan fr{src_frame, dst_frame};
-    if (x4) hipLaunchKernelGGL(k_resize_bilinear_rgba8<4>, grid, dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr);
-    else hipLaunchKernelGGL(k_resize_bilinear_rgba8<1>, grid, dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr);
+#define ZG_RB(NPX) \
+    switch (form) { \
+    case 1: hipLaunchKernelGGL((k_resize_bilinear_rgba8<NPX, 4, false>), grid, dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr); break; \
+    case 2: hipLaunchKernelGGL((k_resize_bilinear_rgba8<NPX, 1, false>), grid, dim3(64), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr); break; \
+    case 3: hipLaunchKernelGGL((k_resize_bilinear_rgba8<NPX, 1, true>), grid, dim3(64), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr); break; \
+    default: hipLaunchKernelGGL((k_resize_bilinear_rgba8<NPX, 4, true>), grid, dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr); \
+    }
+    if (x4) { ZG_RB(4) } else { ZG_RB(1) }
+#undef ZG_RB
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

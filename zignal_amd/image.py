@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Optional, Sequence, Tuple, Union
+from typing import List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 
@@ -676,6 +676,48 @@ def gaussian_kernel(sigma: float) -> np.ndarray:
     out = np.empty(n, np.float32)
     lib.zg_gaussian_kernel(C.c_float(sigma), out.ctypes.data_as(C.POINTER(C.c_float)), n)
     return out
+
+
+def _plane_arrays(planes: Sequence["Image"], outs: Optional[Sequence["Image"]]):
+    planes = [Image._wrap(p) for p in planes]
+    outs = [p._like() for p in planes] if outs is None else [Image._wrap(o) for o in outs]
+    if len(outs) != len(planes):
+        raise ValueError(f"{len(planes)} source planes but {len(outs)} destination planes")
+    for p, o in zip(planes, outs):
+        p._same_side(o)
+    n = len(planes)
+    src = (L.ZgImage * max(n, 1))(*[p._desc() for p in planes])
+    dst = (L.ZgImage * max(n, 1))(*[o._desc() for o in outs])
+    return planes, outs, src, dst
+
+
+def convolve_separable_planes(planes: Sequence["Image"], kernel_x, kernel_y, border: int = BorderMode.mirror,
+                              outs: Optional[Sequence["Image"]] = None) -> List["Image"]:
+    """Image.convolveSeparable (image.zig:935-951) on several planes of one shape in one device launch (zg_conv_separable_planes):
+    how RGBA f32 data goes through the reference's API, which has no Rgba(f32) convolution (convolution.zig:431-435) — four
+    Image(f32) planes. Host-side planes run one after the other through the host layer."""
+    planes, outs, src, dst = _plane_arrays(planes, outs)
+    kx, kxp = _f32_array(kernel_x)
+    ky, kyp = _f32_array(kernel_y)
+    if planes and planes[0].on_device:
+        with torch.cuda.device(planes[0].data.device):
+            L.check(L.lib().zg_conv_separable_planes(src, dst, len(planes), kxp, len(kx), kyp, len(ky), int(border), planes[0]._stream()))
+    else:
+        for p, o in zip(planes, outs):
+            p.convolve_separable(kx, ky, border, out=o)
+    return outs
+
+
+def gaussian_blur_planes(planes: Sequence["Image"], sigma: float, outs: Optional[Sequence["Image"]] = None) -> List["Image"]:
+    """Image.gaussianBlur (image.zig:954-994) on several planes of one shape in one device launch (zg_gaussian_blur_planes)."""
+    planes, outs, src, dst = _plane_arrays(planes, outs)
+    if planes and planes[0].on_device:
+        with torch.cuda.device(planes[0].data.device):
+            L.check(L.lib().zg_gaussian_blur_planes(src, dst, len(planes), C.c_float(sigma), planes[0]._stream()))
+    else:
+        for p, o in zip(planes, outs):
+            p.gaussian_blur(sigma, out=o)
+    return outs
 
 
 def lanczos_plane_weights(src_n: int, dst_n: int) -> np.ndarray:
