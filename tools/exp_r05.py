@@ -76,7 +76,8 @@ if what & {"resize"}:
     srcs = [torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda") for _ in range(ring)]
     im = [(zg.Image(x), zg.Image(torch.empty((1024, 1024, 4), dtype=torch.uint8, device="cuda"))) for x in srcs]
     one = lambda i: im[i % ring][0].resize(im[i % ring][1], zg.Interpolation.bilinear)
-    names = {0: "4 rows per workgroup, XCD-major (round 4)", 1: "4 rows per workgroup, address order", 2: "one wave per workgroup, address order", 3: "one wave per workgroup, XCD-major"}
+    names = {0: "4 rows per workgroup, XCD-major (round 4)", 1: "one wave per workgroup, 1 row, address order", 2: "one wave per workgroup, 2 rows, address order",
+             4: "one wave per workgroup, 4 rows, address order"}
     res = {k: [] for k in names}
     for rep in range(4):
         for k in names:
@@ -84,6 +85,16 @@ if what & {"resize"}:
                 res[k].append(bench._time_kernel(torch, one, n=64, warm=8))
     for k, n in names.items():
         report("resize 4096^2 -> 1024^2 Rgba(u8) bilinear: " + n, res[k])
+    lab = [(zg.Image(x), zg.Image(torch.empty((1024, 1024, 3), dtype=torch.float32, device="cuda"))) for x in srcs]
+    fused = lambda i: lab[i % ring][0].resize_convert(lab[i % ring][1], zg.CS_OKLAB)
+    res = {0: [], 1: []}
+    for rep in range(4):
+        for k in res:
+            with knob(ZIGNAL_HIP_RESIZE_FORM=k):
+                res[k].append(bench._time_kernel(torch, fused, n=64, warm=8))
+    report("fused resize -> Oklab 4096^2 -> 1024^2: 4 rows per workgroup, XCD-major (round 4)", res[0])
+    report("fused resize -> Oklab 4096^2 -> 1024^2: one wave per workgroup, address order", res[1])
+    del lab
     big = [(zg.Image(torch.randint(0, 256, (2 * R, 2 * R, 4), dtype=torch.uint8, device="cuda")), zg.Image(torch.empty((R, R, 4), dtype=torch.uint8, device="cuda"))) for _ in range(4)]
     two = lambda i: big[i % 4][0].resize(big[i % 4][1], zg.Interpolation.bilinear)
     res = {k: [] for k in names}
@@ -93,7 +104,17 @@ if what & {"resize"}:
                 res[k].append(bench._time_kernel(torch, two, n=16, warm=4))
     for k, n in names.items():
         report("resize 8192^2 -> 4096^2 Rgba(u8) bilinear: " + n, res[k])
-    del big, im, srcs
+    del big
+    up = [(zg.Image(torch.randint(0, 256, (R // 2, R // 2, 4), dtype=torch.uint8, device="cuda")), zg.Image(torch.empty((R, R, 4), dtype=torch.uint8, device="cuda"))) for _ in range(12)]
+    upf = lambda i: up[i % 12][0].resize(up[i % 12][1], zg.Interpolation.bilinear)
+    res = {k: [] for k in names}
+    for rep in range(2):
+        for k in names:
+            with knob(ZIGNAL_HIP_RESIZE_FORM=k):
+                res[k].append(bench._time_kernel(torch, upf, n=24, warm=4))
+    for k, n in names.items():
+        report("resize 2048^2 -> 4096^2 Rgba(u8) bilinear: " + n, res[k])
+    del up, im, srcs
 
 if what & {"u8o"}:
     ring = 8

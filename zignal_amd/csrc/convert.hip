@@ -450,17 +450,19 @@ int convert_impl(const zg_image *src, int src_space, const zg_image *dst, int ds
 // result equals the two calls bit for bit. Algorithmic bytes: 16 read + 12 written per output pixel (28 B).
 int resize_impl(const zg_image *src, const zg_image *dst, const zg_method *method, hipStream_t s);
 
-template <int MODE> // as k_u8_to_lab4's
-__global__ __launch_bounds__(256) void k_resize_bilinear_rgba8_to_lab(DImg src, DImg dst, float ratio_x, float ratio_y, int tiles_x, const float *srgb_lut, FrameSpan fr) {
+template <int MODE, int WAVES> // MODE as k_u8_to_lab4's; WAVES 4: four rows per workgroup in XCD-major order (round 4), 1: one-wave workgroups in address order
+__global__ __launch_bounds__(64 * WAVES) void k_resize_bilinear_rgba8_to_lab(DImg src, DImg dst, float ratio_x, float ratio_y, int tiles_x, const float *srgb_lut, FrameSpan fr) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
-    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    if constexpr (WAVES == 4) {
+        const int nwg = gridDim.x, per_xcd = nwg >> 3;
+        if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    }
     src.data = (char *)src.data + (size_t)blockIdx.y * fr.src_frame; // a batch of equally shaped frames in one launch (batch.hip)
     dst.data = (char *)dst.data + (size_t)blockIdx.y * fr.dst_frame;
     const int tyi = wg / tiles_x, txi = wg - tyi * tiles_x;
     const int c = txi * 64 + (int)(threadIdx.x & 63);
-    const int r = __builtin_amdgcn_readfirstlane(tyi * 4 + (int)(threadIdx.x >> 6));
+    const int r = __builtin_amdgcn_readfirstlane(tyi * WAVES + (int)(threadIdx.x >> 6));
     if (r >= dst.rows || c >= dst.cols) return;
     int y0, y1, fy, x0, x1, fx;
     bilinear_taps(r, ratio_y, src.rows, y0, y1, fy);
@@ -486,7 +488,10 @@ int resize_convert_rgba8_frames(const zg_image *src, const zg_image *dst, int ds
     const bool fused = src->pixel == ZG_PIXEL_RGBA_U8 && dst->pixel == ZG_PIXEL_RGB_F32 && (dst_space == ZG_CS_OKLAB || dst_space == ZG_CS_XYZ) && src->rows > 0 &&
                        src->cols >= 2 && dst->rows > 0 && dst->cols > 0 && n > 0 && !(src->rows == dst->rows && src->cols == dst->cols);
     if (!fused) return -1;
-    const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, 4);
+    // reductions: one-wave workgroups in address order, as the plain resize (resize_planes.hip); 0 / 1 in ZIGNAL_HIP_RESIZE_FORM force a form
+    bool one_wave = (float)src->cols / (float)dst->cols > 1.5f;
+    if (const char *e = getenv("ZIGNAL_HIP_RESIZE_FORM")) one_wave = atoi(e) != 0;
+    const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, one_wave ? 1u : 4u);
     const uint64_t tiles = (uint64_t)tiles_x * tiles_y;
     if (tiles > 0x7fffffffu || n > MAX_FRAMES_PER_LAUNCH) return -1;
     const dim3 grid((unsigned)tiles, n);
@@ -496,12 +501,14 @@ int resize_convert_rgba8_frames(const zg_image *src, const zg_image *dst, int ds
     if (int rc = device_srgb_lut(srgb_lut, s, &lut_dev, &owned, &plain_table)) return rc;
     const float ratio_x = (float)src->cols / (float)dst->cols, ratio_y = (float)src->rows / (float)dst->rows;
     const FrameSpan fr{src_frame, dst_frame};
-    if (dst_space != ZG_CS_OKLAB)
-        hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<0>, grid, dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr);
-    else if (plain_table)
-        hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<2>, grid, dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr);
-    else
-        hipLaunchKernelGGL(k_resize_bilinear_rgba8_to_lab<1>, grid, dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr);
+    const int mode = dst_space != ZG_CS_OKLAB ? 0 : (plain_table ? 2 : 1);
+#define ZG_RL(MODE) \
+    if (mode == MODE) { \
+        if (one_wave) hipLaunchKernelGGL((k_resize_bilinear_rgba8_to_lab<MODE, 1>), grid, dim3(64), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr); \
+        else hipLaunchKernelGGL((k_resize_bilinear_rgba8_to_lab<MODE, 4>), grid, dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tiles_x, lut_dev, fr); \
+    }
+    ZG_RL(0) ZG_RL(1) ZG_RL(2)
+#undef ZG_RL
     const hipError_t e = hipGetLastError();
     if (owned) scratch_free(owned, s);
     ZG_HIP(e);

@@ -344,7 +344,7 @@ static int axis_table(int kind, uint32_t src_n, uint32_t dst_n, int taps, AxisTa
 // A launch covers `frames` equally shaped images laid out `src_frame` / `dst_frame` bytes apart (a batch of the pipeline, batch.hip):
 // a 4096^2 -> 1024^2 frame is 4 096 workgroups of one gather each, i.e. launch ramp and tail; sixteen of them in one grid keep the chip
 // full (profiles/r03_batched_resize.txt).
-template <int NPX, int WAVES, bool XCD>
+template <int NPX, int WAVES, bool XCD, int RPW>
 __global__ __launch_bounds__(64 * WAVES) void k_resize_bilinear_rgba8(DImg src, DImg dst, float ratio_x, float ratio_y, int tiles_x, FrameSpan fr) {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -357,40 +357,58 @@ __global__ __launch_bounds__(64 * WAVES) void k_resize_bilinear_rgba8(DImg src, 
     dst.data = (char *)dst.data + (size_t)blockIdx.y * fr.dst_frame;
     const int tyi = wg / tiles_x, txi = wg - tyi * tiles_x;
     const int c0 = (txi * 64 + (int)(threadIdx.x & 63)) * NPX;
-    const int r = __builtin_amdgcn_readfirstlane(tyi * WAVES + (int)(threadIdx.x >> 6)); // one row per wave
-    if (r >= dst.rows || c0 >= dst.cols) return;
-    int y0, y1, fy;
-    bilinear_taps(r, ratio_y, src.rows, y0, y1, fy);
-    const uint32_t *row0 = (const uint32_t *)src.data + (size_t)y0 * src.stride, *row1 = (const uint32_t *)src.data + (size_t)y1 * src.stride;
-    uint32_t out[NPX];
-    int x0[NPX], x1[NPX], fx[NPX];
-    u32x2 p0[NPX], p1[NPX];
+    const int r0 = __builtin_amdgcn_readfirstlane((tyi * WAVES + (int)(threadIdx.x >> 6)) * RPW); // RPW consecutive rows per wave
+    if (r0 >= dst.rows || c0 >= dst.cols) return;
+    int x0[NPX], x1[NPX], fx[NPX], xp[NPX];
 #pragma unroll
     for (int p = 0; p < NPX; ++p) {
         bilinear_taps(c0 + p, ratio_x, src.cols, x0[p], x1[p], fx[p]);
-        const int xp = min(x0[p], src.cols - 2); // the pair (xp, xp + 1) is always inside the row (cols >= 2)
-        p0[p] = *(const u32x2 *)(row0 + xp);     // 4-byte aligned 8-byte loads
-        p1[p] = *(const u32x2 *)(row1 + xp);
+        xp[p] = min(x0[p], src.cols - 2); // the pair (xp, xp + 1) is always inside the row (cols >= 2)
+    }
+    const uint32_t *row0[RPW], *row1[RPW];
+    int fy[RPW];
+    u32x2 p0[RPW][NPX], p1[RPW][NPX];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) { // every load of the wave is asked for before the first is used
+        int y0, y1;
+        bilinear_taps(min(r0 + k, dst.rows - 1), ratio_y, src.rows, y0, y1, fy[k]);
+        row0[k] = (const uint32_t *)src.data + (size_t)y0 * src.stride;
+        row1[k] = (const uint32_t *)src.data + (size_t)y1 * src.stride;
+#pragma unroll
+        for (int p = 0; p < NPX; ++p) {
+            p0[k][p] = *(const u32x2 *)(row0[k] + xp[p]); // 4-byte aligned 8-byte loads
+            p1[k][p] = *(const u32x2 *)(row1[k] + xp[p]);
+        }
     }
 #pragma unroll
-    for (int p = 0; p < NPX; ++p) {
-        uint32_t tl = p0[p][0], tr = p0[p][1], bl = p1[p][0], br = p1[p][1];
-        if (x1[p] != x0[p] + 1 || x0[p] > src.cols - 2) { tl = row0[x0[p]]; tr = row0[x1[p]]; bl = row1[x0[p]]; br = row1[x1[p]]; } // mirrored taps
-        out[p] = bilinear_rgba8(tl, tr, bl, br, fx[p], fy);
+    for (int k = 0; k < RPW; ++k) {
+        if (r0 + k >= dst.rows) break; // wave-uniform
+        uint32_t out[NPX];
+#pragma unroll
+        for (int p = 0; p < NPX; ++p) {
+            uint32_t tl = p0[k][p][0], tr = p0[k][p][1], bl = p1[k][p][0], br = p1[k][p][1];
+            if (x1[p] != x0[p] + 1 || x0[p] > src.cols - 2) { tl = row0[k][x0[p]]; tr = row0[k][x1[p]]; bl = row1[k][x0[p]]; br = row1[k][x1[p]]; } // mirrored taps
+            out[p] = bilinear_rgba8(tl, tr, bl, br, fx[p], fy[k]);
+        }
+        uint32_t *o = (uint32_t *)dst.data + (size_t)(r0 + k) * dst.stride + c0;
+        if constexpr (NPX == 4) *(u32x4 *)o = u32x4{out[0], out[1], out[2], out[3]}; // dst.cols % 4 == 0, 16-byte aligned rows
+        else o[0] = out[0];
     }
-    uint32_t *o = (uint32_t *)dst.data + (size_t)r * dst.stride + c0;
-    if constexpr (NPX == 4) *(u32x4 *)o = u32x4{out[0], out[1], out[2], out[3]}; // dst.cols % 4 == 0, 16-byte aligned rows
-    else o[0] = out[0];
 }
 
 // Image(Rgba(u8)).resize(.bilinear) of n frames in one launch; -1 when the fast kernel does not apply (the caller goes frame by frame).
 int resize_bilinear_rgba8_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s) {
     if (src->pixel != ZG_PIXEL_RGBA_U8 || dst->pixel != ZG_PIXEL_RGBA_U8 || src->cols < 2 || src->rows == 0 || dst->rows == 0 || dst->cols == 0 || n == 0) return -1;
     if (src->rows == dst->rows && src->cols == dst->cols) return -1; // equal sizes are a copy (interpolation.zig:100-108)
-    int form = 0; // experiment hook of round 5: 0 = 4 rows per workgroup, XCD-major; 1 = 4 rows, address order; 2 = 1 row (one wave), address order; 3 = 1 row, XCD-major
+    // Launch form (profiles/r05_experiments.txt; tools/exp/copy_floor.hip is why): strong reductions read a few bytes per output pixel, and there
+    // a grid of one-wave workgroups handed out in address order keeps the request stream a moving front — 4096^2 -> 1024^2: 9.6 -> 8.4 us per
+    // launch; two rows per wave for 2 : 1 (61 -> 59 us at 8192^2 -> 4096^2). Enlargements keep round 4's four-row workgroups in XCD-major
+    // order (their neighbouring rows share source rows: 35.9 against 37-40 us at 2048^2 -> 4096^2). 0 / 1 / 2 / 4 force a form (the tests do).
+    const float ry = (float)src->rows / (float)dst->rows, rx = (float)src->cols / (float)dst->cols;
+    int form = rx <= 1.5f ? 0 : (ry >= 3.0f ? 1 : 2);
     if (const char *e = getenv("ZIGNAL_HIP_RESIZE_FORM")) form = atoi(e);
-    const int waves = form >= 2 ? 1 : 4;
-    const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, (unsigned)waves);
+    const int waves = form == 0 ? 4 : 1, rpw = form == 0 ? 1 : form;
+    const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, (unsigned)(waves * rpw));
     const float ratio_x = (float)src->cols / (float)dst->cols, ratio_y = (float)src->rows / (float)dst->rows;
     const bool x4 = ratio_x <= 1.5f && dst->cols % 4 == 0 && dst->stride % 4 == 0 && ((uintptr_t)dst->data & 15) == 0 && dst_frame % 16 == 0;
     const int tx = x4 ? (int)ceil_div(dst->cols, 256) : tiles_x;
@@ -400,10 +418,10 @@ int resize_bilinear_rgba8_frames(const zg_image *src, const zg_image *dst, uint3
     const FrameSpan fr{src_frame, dst_frame};
 #define ZG_RB(NPX) \
     switch (form) { \
-    case 1: hipLaunchKernelGGL((k_resize_bilinear_rgba8<NPX, 4, false>), grid, dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr); break; \
-    case 2: hipLaunchKernelGGL((k_resize_bilinear_rgba8<NPX, 1, false>), grid, dim3(64), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr); break; \
-    case 3: hipLaunchKernelGGL((k_resize_bilinear_rgba8<NPX, 1, true>), grid, dim3(64), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr); break; \
-    default: hipLaunchKernelGGL((k_resize_bilinear_rgba8<NPX, 4, true>), grid, dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr); \
+    case 1: hipLaunchKernelGGL((k_resize_bilinear_rgba8<NPX, 1, false, 1>), grid, dim3(64), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr); break; \
+    case 2: hipLaunchKernelGGL((k_resize_bilinear_rgba8<NPX, 1, false, 2>), grid, dim3(64), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr); break; \
+    case 4: hipLaunchKernelGGL((k_resize_bilinear_rgba8<NPX, 1, false, 4>), grid, dim3(64), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr); break; \
+    default: hipLaunchKernelGGL((k_resize_bilinear_rgba8<NPX, 4, true, 1>), grid, dim3(256), 0, s, dimg(src), dimg(dst), ratio_x, ratio_y, tx, fr); \
     }
     if (x4) { ZG_RB(4) } else { ZG_RB(1) }
 #undef ZG_RB
