@@ -27,6 +27,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -60,9 +61,32 @@ def parse_args():
     return ap.parse_args()
 
 
-def cpu_baseline(budget_s: float = 12.0):
-    """Oracle ('port') timed on this box's host cores, one thread, on a bounded sample: whole 4096x4096 f32
-    planes (the reference has no Rgba(f32) convolution, so an RGBA f32 frame is four Image(f32) planes)."""
+def _pin_to_one_core():
+    """the CPU leg runs pinned (taskset -c): this process's affinity shrinks to one allowed core for the duration. Returns
+    (previous affinity, core) or (None, None) where the platform has no affinity call."""
+    try:
+        before = os.sched_getaffinity(0)
+        core = max(before)  # away from core 0, where the launcher and the HIP runtime's helper threads tend to sit
+        os.sched_setaffinity(0, {core})
+        return before, core
+    except (AttributeError, OSError):
+        return None, None
+
+
+def parity_metrics(got, want):
+    """PSNR and mean pixel error with the reference's formulas (src/image/metrics.zig:10-54, 114-171): every component as f64, the
+    component maximum 255 for u8 and 1.0 for floats, PSNR = inf when the mean squared error is 0."""
+    import numpy as np
+    a, b = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    mx = 255.0 if np.asarray(got).dtype == np.uint8 else 1.0
+    mse = float(np.mean((a - b) ** 2))
+    psnr = float("inf") if mse == 0.0 else 20.0 * np.log10(mx) - 10.0 * np.log10(mse)
+    return psnr, float(np.mean(np.abs(a - b)) / mx)
+
+
+def cpu_baseline(budget_s: float = 12.0, gpu_blur=None):
+    """Oracle ('port') timed on this box's host cores, one thread pinned to one core (taskset, best of 5 after a warm-up), on a
+    bounded sample: whole 4096x4096 f32 planes (the reference has no Rgba(f32) convolution, so an RGBA f32 frame is four Image(f32) planes)."""
     import numpy as np
     from oracle import pyoracle as oracle  # checker / baseline only — never on the product path
 
@@ -74,18 +98,29 @@ def cpu_baseline(budget_s: float = 12.0):
     k = oracle.gaussian_kernel(SIGMA)
     plane = oracle.synth_f32(2, (ROWS, COLS))
     out = np.empty_like(plane)
-    oracle.conv_separable(plane, k, k, oracle.MIRROR, out=out, native=native)  # warm-up (page faults)
-    times = []
-    t_start = time.perf_counter()
-    while len(times) < 8 and (time.perf_counter() - t_start) < budget_s:
-        t0 = time.perf_counter()
-        oracle.conv_separable(plane, k, k, oracle.MIRROR, out=out, native=native)
-        times.append(time.perf_counter() - t0)
+    before, core = _pin_to_one_core()
+    try:
+        oracle.conv_separable(plane, k, k, oracle.MIRROR, out=out, native=native)  # the warm-up run (page faults, clocks)
+        times = []
+        t_start = time.perf_counter()
+        while len(times) < 5 and (not times or (time.perf_counter() - t_start) < budget_s):
+            t0 = time.perf_counter()
+            oracle.conv_separable(plane, k, k, oracle.MIRROR, out=out, native=native)
+            times.append(time.perf_counter() - t0)
+    finally:
+        if before is not None:
+            os.sched_setaffinity(0, before)
     best = min(times)
     mpix = ROWS * COLS / (4 * best) / 1e6  # an RGBA frame = 4 planes
-    return {"value": round(mpix, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-            "sample": f"{len(times)} x gaussianBlur(0.6) on one 4096x4096 f32 plane (best of), x4 planes per RGBA frame; "
-                      f"oracle/conv.c {'-march=native' if native else '-march=x86-64-v3'} -O3 -ffp-contract=off; "
+    parity = None
+    if gpu_blur is not None:  # the same plane through the product: the reference's own image metrics between the two results
+        psnr, mpe = parity_metrics(gpu_blur(plane), out)
+        parity = {"psnr_db": "inf" if psnr == float("inf") else round(psnr, 2), "mean_pixel_error": mpe,
+                  "formulas": "src/image/metrics.zig:10-54, 114-171", "sample": "the timed 4096x4096 f32 plane, GPU result vs CPU port"}
+    return {"value": round(mpix, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port", "parity_gpu_vs_cpu_port": parity,
+            "sample": f"best of {len(times)} x gaussianBlur(0.6) on one 4096x4096 f32 plane after one warm-up run, x4 planes per RGBA frame; "
+                      f"restated zignal CPU path (C, oracle/conv.c {'-march=native' if native else '-march=x86-64-v3'} -O3 -ffp-contract=off), not Zig-compiled; "
+                      f"{'pinned to core %d (sched_setaffinity)' % core if core is not None else 'not pinned (no affinity call here)'}; "
                       f"host has {os.cpu_count()} logical cores"}
 
 
@@ -286,7 +321,11 @@ def main():
         if not args.no_extras:
             result["extras"] = extras(zg, torch, np)
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline()
+            def gpu_blur(plane):
+                out = zg.Image(torch.from_numpy(plane).cuda()).gaussian_blur(SIGMA)
+                torch.cuda.synchronize()
+                return out.to_numpy()
+            result["cpu_baseline"] = cpu_baseline(gpu_blur=gpu_blur)
             try:
                 result["cpu_baseline_config5_all_cores"] = cpu_config5_all_cores()
             except Exception as e:
@@ -582,7 +621,11 @@ def extras(zg, torch, np):
     out = {}
     I = zg.Interpolation
 
+    only = os.environ.get("ZG_BENCH_EXTRAS")  # a regular expression: run only the legs whose name matches (A/B runs of library variants)
+
     def leg(name, fn):
+        if only and not re.search(only, name):
+            return
         try:
             out[name] = fn()
         except Exception as e:  # an extra must never take the headline down

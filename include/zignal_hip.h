@@ -486,6 +486,10 @@ typedef struct zg_step {
     uint32_t window;             /* EDGES: Shen-Castan's window_size */
     int use_nms;                 /* EDGES: Shen-Castan's use_nms (hysteresis stays at its default, on, as in the CLI) */
 } zg_step;
+/* sizeof(zg_step) as this library was built. zg_step grows with the recipe language (round 4 added thirteen fields) and carries no size field of
+ * its own: a binding compares its own struct's size with this at load time and refuses to run on a mismatch (zignal_amd/_lib.py, the Zig shim's
+ * init and zignal_hip.hpp do), so a caller built against another header can never hand over arrays with the wrong stride. */
+ZG_API size_t zg_sizeof_step(void);
 /* Host only: shape and type of the frames after the steps (what dst_frames of zg_batch_pipeline must hold, n_frames times). */
 ZG_API int zg_batch_pipeline_shape(uint32_t rows, uint32_t cols, int pixel, int space, const zg_step *steps, uint32_t n_steps,
                                    uint32_t *out_rows, uint32_t *out_cols, int *out_pixel, int *out_space);
@@ -522,6 +526,15 @@ ZG_API int zg_multi_wait_stream(zg_multi m, zg_stream producer);
 ZG_API int zg_multi_batch_blur_resize(zg_multi m, const void *src_frames_root, uint32_t n_frames, uint32_t rows, uint32_t cols, int pixel,
                                       float sigma, void *dst_frames_root, uint32_t out_rows, uint32_t out_cols, const zg_method *method,
                                       float times_ms[3]);
+/* zg_batch_pipeline over the context's devices: every frame through the recipe's steps (src/cli/pipeline.zig:153-179), the frames sharded
+ * exactly as above (contiguous blocks, pieces, two communicators). dst_frames_root holds n_frames frames of the shape and type
+ * zg_batch_pipeline_shape reports. Same waiting, timing and failure rules as zg_multi_batch_blur_resize. */
+ZG_API int zg_multi_batch_pipeline(zg_multi m, const void *src_frames_root, uint32_t n_frames, uint32_t rows, uint32_t cols, int pixel, int space,
+                                   const zg_step *steps, uint32_t n_steps, void *dst_frames_root, float times_ms[3]);
+/* Host only, no device touched: frames [*begin, *end) of the batch that form piece `piece` of device `device`'s shard when n_frames frames go
+ * to `world` devices in up to `chunks` (1..8) pieces per shard — the arithmetic the two calls above use (zignal_amd/sharding.py cuts the same
+ * way). Pieces past a shard's last are empty (*begin == *end). */
+ZG_API int zg_multi_piece_range(uint32_t n_frames, int world, int chunks, int device, int piece, uint32_t *begin, uint32_t *end);
 
 /* ---- the host I/O edge: PNG (src/codecs/png.zig) -------------------------- */
 

@@ -266,6 +266,32 @@ int main(int argc, char **argv) {
                 EXPECT(got == want);
                 if (!call) std::printf(mode.loop ? "multi_1gpu_rccl_loopback_%s_pieces_ms=%.3f %.3f %.3f\n" : "multi_1gpu_%s_ms=%.3f %.3f %.3f\n", mode.chunks, t[0], t[1], t[2]);
             }
+            { // any recipe, not just [blur, resize]: zg_multi_batch_pipeline behind Pipeline::runMulti, against the one-device zg_batch_pipeline
+                Pipeline three;
+                three.resize(rows / 2, cols / 2).gaussianBlur(sigma).convert<Rgb<float>>();
+                uint32_t orows = 0, ocols = 0; int opix = -1;
+                three.outShape(rows, cols, ZG_PIXEL_RGBA_U8, ZG_CS_RGBA, orows, ocols, opix);
+                const size_t lab_bytes = (size_t)n * orows * ocols * 12;
+                void *dwant = nullptr, *dgot = nullptr;
+                check(zg_malloc(&dwant, lab_bytes)); check(zg_malloc(&dgot, lab_bytes));
+                three.run((const Rgba<uint8_t> *)dsrc, n, rows, cols, dwant);
+                std::vector<uint8_t> a(lab_bytes), b(lab_bytes, 0x77);
+                check(zg_memcpy_d2h(a.data(), dwant, lab_bytes, nullptr));
+                check(zg_memcpy_h2d(dgot, b.data(), lab_bytes, nullptr));
+                float t[3] = {0, 0, 0};
+                three.runMulti(ctx, (const Rgba<uint8_t> *)dsrc, n, rows, cols, dgot, t);
+                check(zg_memcpy_d2h(b.data(), dgot, lab_bytes, nullptr));
+                EXPECT(a == b);
+                std::printf(mode.loop ? "multi_1gpu_rccl_loopback_%s_pieces_pipeline_ms=%.3f %.3f %.3f\n" : "multi_1gpu_%s_pipeline_ms=%.3f %.3f %.3f\n", mode.chunks, t[0], t[1], t[2]);
+                // a recipe the shape function rejects fails before anything is enqueued and leaves the context usable
+                Pipeline bad;
+                bad.gaussianBlur(-1.0f);
+                EXPECT(zg_multi_batch_pipeline(ctx, dsrc, n, rows, cols, ZG_PIXEL_RGBA_U8, ZG_CS_RGBA, bad.steps.data(), 1, dgot, nullptr) != ZG_OK);
+                three.runMulti(ctx, (const Rgba<uint8_t> *)dsrc, n, rows, cols, dgot);
+                check(zg_memcpy_d2h(b.data(), dgot, lab_bytes, nullptr));
+                EXPECT(a == b);
+                check(zg_free(dwant)); check(zg_free(dgot));
+            }
             { // frames produced on a NON-BLOCKING stream (zg_stream_create makes those): unnamed, the call synchronises the root device;
               // named with zg_multi_wait_stream, it waits for that stream. Either way it must not read the source before the copy has run.
                 void *dsrc2 = nullptr, *big = nullptr;
@@ -312,6 +338,15 @@ int main(int argc, char **argv) {
                 check(zg_memcpy_d2h(got.data(), dout, out_bytes, nullptr));
                 EXPECT(got == want);
                 std::printf("multi_%dgpu_%s_pieces_ms=%.3f %.3f %.3f\n", world, chunks, t[0], t[1], t[2]);
+                { // the general recipe over every device
+                    Pipeline recipe;
+                    recipe.gaussianBlur(sigma).resize(rows / 2, cols / 2);
+                    check(zg_memcpy_h2d(dout, fill.data(), out_bytes, nullptr));
+                    recipe.runMulti(ctx, (const Rgba<uint8_t> *)dsrc, n, rows, cols, dout, t);
+                    check(zg_memcpy_d2h(got.data(), dout, out_bytes, nullptr));
+                    EXPECT(got == want);
+                    std::printf("multi_%dgpu_%s_pieces_pipeline_ms=%.3f %.3f %.3f\n", world, chunks, t[0], t[1], t[2]);
+                }
                 check(zg_multi_destroy(ctx));
             }
             unsetenv("ZIGNAL_HIP_MULTI_CHUNKS");

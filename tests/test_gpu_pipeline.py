@@ -208,6 +208,58 @@ def test_every_blur_type_and_edge_detector_of_the_cli_as_a_step(oracle):
         assert np.array_equal(got[f], want), f"[blur, canny, resize]: frame {f}"
 
 
+def test_edges_step_bridges_float_frames_and_other_colour_spaces(oracle):
+    """edges.apply is frame.convert(u8) -> detector -> .convert(frame type) (src/cli/edges.zig:126-135). Float frames must go through that
+    conversion (Image(f32).sobel on raw [0, 1] floats is a different picture), and so must frames an earlier CONVERT step left in Oklab."""
+    rng = np.random.default_rng(9)
+    f32 = rng.random((3, 48, 80), dtype=np.float32)
+    for step, det in ((zg.Step.edges_sobel(), oracle.sobel), (zg.Step.edges_canny(1.0, 50.0, 100.0), lambda g: oracle.canny(g, 1.0, 50.0, 100.0))):
+        got = zg.Pipeline([step]).run(torch.from_numpy(f32).cuda())
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        assert got.dtype == np.float32 and got.shape == f32.shape
+        for f in range(3):
+            g8 = oracle.convert(f32[f], oracle.CS_GRAY, oracle.CS_GRAY, np.uint8, 1)
+            want = oracle.convert(det(g8), oracle.CS_GRAY, oracle.CS_GRAY, np.float32, 1)
+            assert np.array_equal(got[f].view(np.uint32), want.view(np.uint32)), f"f32 grey frame {f}"
+        assert got.max() > 0.2, "edges of a [0, 1] float image must not vanish"
+    rgbf = rng.random((2, 40, 64, 3), dtype=np.float32)
+    got = zg.Pipeline([zg.Step.edges_sobel()]).run(torch.from_numpy(rgbf).cuda()).cpu().numpy()
+    for f in range(2):
+        g8 = oracle.convert(rgbf[f], oracle.CS_RGB, oracle.CS_GRAY, np.uint8, 1)
+        want = oracle.convert(oracle.sobel(g8), oracle.CS_GRAY, oracle.CS_RGB, np.float32, 3)
+        assert np.array_equal(got[f].view(np.uint32), want.view(np.uint32)), f"Rgb(f32) frame {f}"
+    host = frames_u8(oracle, 41, 2, 40, 64)
+    got = zg.Pipeline([zg.Step.convert(zg.CS_OKLAB), zg.Step.edges_sobel()]).run(torch.from_numpy(host).cuda()).cpu().numpy()
+    assert got.dtype == np.float32 and got.shape == (2, 40, 64, 3)
+    for f in range(2):
+        lab = oracle.convert(host[f], oracle.CS_RGBA, oracle.CS_OKLAB, np.float32, 3)
+        g8 = oracle.convert(lab, oracle.CS_OKLAB, oracle.CS_GRAY, np.uint8, 1)
+        want = oracle.convert(oracle.sobel(g8), oracle.CS_GRAY, oracle.CS_OKLAB, np.float32, 3)
+        assert np.array_equal(got[f].view(np.uint32), want.view(np.uint32)), f"Oklab frame {f}"
+
+
+def test_run_multi_equals_run_on_the_devices_this_box_has(oracle):
+    """zg_multi_batch_pipeline behind Pipeline.run_multi: any recipe over a zg_multi context. One GPU here, so world 1 (the root works in place);
+    the C++ program (tests/cpp/test_device_image.cpp) adds the RCCL loop-back and, where two GPUs are visible, the world > 1 branches."""
+    host = frames_u8(oracle, 61, 7, 60, 88)
+    dev = torch.from_numpy(host).cuda()
+    recipes = ([zg.Step.gaussian_blur(0.6), zg.Step.resize(30, 44)], [zg.Step.resize(45, 66, I.bicubic), zg.Step.gaussian_blur(1.5), zg.Step.convert(zg.CS_OKLAB)],
+               [zg.Step.box_blur(2), zg.Step.edges_sobel()])
+    with zg.Multi([0]) as ctx:
+        assert ctx.device_count() == 1
+        for steps in recipes:
+            p = zg.Pipeline(steps)
+            want = p.run(dev)
+            got, times = p.run_multi(ctx, dev)
+            assert torch.equal(got, want)
+            assert len(times) == 3 and times[2] > 0
+        with pytest.raises(zg.InvalidArgument):
+            zg.Pipeline([zg.Step.gaussian_blur(-1.0)]).run_multi(ctx, dev)
+        got, _ = zg.Pipeline(recipes[0]).run_multi(ctx, dev)  # an argument error leaves the context usable
+        assert torch.equal(got, zg.Pipeline(recipes[0]).run(dev))
+
+
 def test_new_steps_are_validated_before_anything_runs():
     dev = torch.zeros((2, 32, 32, 4), dtype=torch.uint8, device="cuda")
     bad = zg.Step.edges_sobel()

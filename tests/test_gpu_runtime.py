@@ -115,9 +115,11 @@ ALTERNATIVE_FORMS = {
     # hook: what it switches back to. Round 4 dropped the hooks of the forms that had lost by more than a tenth and whose numbers are on file
     # (profiles/r03_experiments.txt, r04_experiments.txt): NO_STREAM, STREAM_GREY, ROWS_INT, COLS_INT, NO_LAB4, NO_U8_PLANE_RESIZE, NO_WARP_STAGE, CONV2D_INT.
     # The forms themselves stay where ordinary inputs still reach them (shapes a fast kernel's preconditions exclude) and are tested there.
-    "ZIGNAL_HIP_MFMA": "k_sep_mfma (both passes of the u8 Gaussian on the matrix pipe) instead of k_sep_stream",
-    "ZIGNAL_HIP_NO_CONV2D_STREAM": "the LDS-tiled k_conv2d instead of k_conv2d_stream",
-    "ZIGNAL_HIP_NO_SOBEL_STREAM": "the LDS-tiled k_sobel instead of k_sobel_stream",
+    # Round 5 dropped NO_CONV2D_STREAM, NO_SOBEL_STREAM (27 / 20 us against 75 / 55: r04_experiments.txt), the strip-height knobs and MFMA (the matrix-pipe
+    # Gaussian left the library: tools/exp/conv_sep_mfma.hip), and added this round's three.
+    "ZIGNAL_HIP_STREAM_NO_FOLD": "k_sep_stream's plain row pass and end-tap multiplies instead of the folded unit-end form (gaussianBlur(0.6)'s taps)",
+    "ZIGNAL_HIP_NO_TILE_F32": "the LDS-tiled k_sep_f32x4 instead of the tile-per-wave k_sep_tile_f32 for Image(f32) planes",
+    "ZIGNAL_HIP_RESIZE_FORM=0": "round 4's four-row workgroups in XCD-major order for every bilinear Rgba(u8) resize (reductions use one-wave workgroups in address order)",
     "ZIGNAL_HIP_ISEF_TRANSPOSE": "two transposes around k_isef_cols instead of the recursions along the rows",
     "ZIGNAL_HIP_ISEF_SERIAL": "the role-split k_isef (one chain per row / column from end to end) instead of the segmented k_isef_spec",
     "ZIGNAL_HIP_SC_THREE_SATS": "shenCastan's window count from the mask's integral image (three SATs, twelve corner loads) instead of k_sc_count",
@@ -156,6 +158,13 @@ for sigma in (0.6, 1.0, 2.25, 5.5):
 for size in ((250, 1080), (97, 411), (640, 2600)):
     same(dev(grey).resize(size, zg.Interpolation.bilinear), o.resize(grey, size, o.method(o.BILINEAR)), "grey resize")
 f32 = rng.random((90, 700, 4), dtype=np.float32)
+plane = rng.random((90, 700), dtype=np.float32) - np.float32(0.5)
+for sigma in (0.3, 0.6, 1.0):
+    same(dev(plane).gaussian_blur(sigma), o.gaussian_blur(plane, sigma), "f32 plane blur %%g" %% sigma)
+for size in ((20, 300), (35, 550), (140, 2200)):
+    same(dev(rgba).resize(size, zg.Interpolation.bilinear), o.resize(rgba, size, o.method(o.BILINEAR)), "rgba resize")
+small = o.resize(rgba, (20, 300), o.method(o.BILINEAR))
+same(dev(rgba).resize_convert((20, 300), zg.CS_OKLAB), o.convert(small, o.CS_RGBA, o.CS_OKLAB, np.float32, 3), "resize + oklab")
 for size, kind, okind in (((120, 930), zg.Interpolation.bicubic, o.BICUBIC), ((45, 350), zg.Interpolation.catmull_rom, o.CATMULL_ROM), ((95, 705), zg.Interpolation.mitchell(1 / 3, 1 / 3), o.MITCHELL)):
     same(dev(f32).resize(size, kind), o.resize(f32, size, o.method(okind, kind.b, kind.c)), "f32 resize")
 for n in (3, 5, 7):

@@ -393,6 +393,57 @@ def test_isef_segments_equal_the_sequential_recursions(oracle):
             assert_bits_equal(got, oracle.isef_plane(grey.astype(np.float32), smooth), f"isef bytes {rows}x{cols} smooth {smooth}")
 
 
+@pytest.mark.gpu
+def test_isef_smooth_into_a_destination_that_is_not_16_byte_aligned(oracle):
+    """A u8 source whose f32 destination starts 4 bytes into an allocation: the segmented kernels want 16-byte aligned planes, so the call
+    takes the transposing route — which reads the grey as f32, and that plane has to be made first (it was a null pointer)."""
+    rng = np.random.default_rng(78)
+    for rows, cols in ((64, 64), (130, 516), (33, 32)):
+        grey = rng.integers(0, 256, (rows, cols), dtype=np.uint8)
+        buf = torch.zeros(rows * cols + 4, dtype=torch.float32, device="cuda")
+        out = zg.Image(buf[1:1 + rows * cols].view(rows, cols))
+        assert out.data.data_ptr() % 16 == 4
+        zg.Image(torch.from_numpy(grey).cuda()).isef_smooth(0.9, out=out)
+        torch.cuda.synchronize()
+        assert_bits_equal(out.to_numpy(), oracle.isef_plane(grey.astype(np.float32), 0.9), f"isef bytes -> unaligned f32 {rows}x{cols}")
+        f32 = rng.random((rows, cols), dtype=np.float32)
+        zg.Image(torch.from_numpy(f32).cuda()).isef_smooth(0.7, out=out)
+        torch.cuda.synchronize()
+        assert_bits_equal(out.to_numpy(), oracle.isef_plane(f32, 0.7), f"isef f32 -> unaligned f32 {rows}x{cols}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w", (8, 12, 16))
+def test_isef_repair_launch_when_only_some_groups_start_wrong(oracle, w):
+    """ZIGNAL_HIP_ISEF_W forces a warm-up shorter than the contraction needs: with W = 4 every segment fails its check; with 8 - 16 steps and
+    a mild smoothing factor only SOME 64-chain groups do (a rough region beside flat ones), so the repair launch redoes a subset — rows
+    and, in place on the column pass, columns — and the rest keeps the segmented result. A child process: the hook is read once."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+import zignal_amd as zg
+from oracle import pyoracle as o
+o.lib()
+rng = np.random.default_rng(5)
+for rows, cols in ((256, 1024), (300, 772)):
+    plane = np.full((rows, cols), 100.0, np.float32)
+    plane[64:128, 200:600] = rng.integers(0, 256, (64, 400)).astype(np.float32) * 1e3   # rough block: its neighbours' short warm-ups cannot settle
+    plane[200:, cols - 100:] = rng.random((rows - 200, 100), dtype=np.float32)
+    for smooth in (0.4, 0.6):
+        got = zg.Image(torch.from_numpy(plane).cuda()).isef_smooth(smooth).to_numpy()
+        want = o.isef_plane(plane, smooth)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (rows, cols, smooth)
+print("ok")
+''' % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, ZIGNAL_HIP_ISEF_W=str(w)))
+    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-300:], out.stderr[-1200:])
+
+
 def test_shen_castan_reference_known_answers_oracle(oracle):  # tests/shen_castan.zig:10-130, 60-86
     e = oracle.shen_castan(_sc_square(), 0.8, 7, 0.9, 0.3)
     assert 0 < (e > 0).sum() < 500 and set(np.unique(e).tolist()) <= {0, 255}

@@ -1,3 +1,6 @@
+// ARCHIVED EXPERIMENT (round 4, out of libzignal_hip.so since round 5): the u8 Gaussian with both passes on the matrix pipe. It is bit-exact and loses
+// (92 us against 30: profiles/r04_mfma_blur.txt), and north_star rules MFMA out for this path. To run it again, copy it back into zignal_amd/csrc/ and
+// call try_sep_mfma from conv_separable.hip ahead of try_sep_stream, as commit 4d02f76 did (exp_mfma.py beside this file is its driver).
 // conv_sep_mfma.hip — the u8 separable convolution with both passes on the matrix pipe (v_mfma_i32_16x16x64_i8), exact in i32.
 //
 // Same arithmetic contract as conv_sep_stream.hip (reference src/image/convolution.zig:441-647, u8 path: taps round(k * 256) in
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
     const int lane = (int)threadIdx.x, li = lane & 15, lg = lane >> 4;
     const uint32_t nwg = gridDim.x, per_xcd = nwg >> 3;
     uint32_t w = blockIdx.x;
-    if (w < (per_xcd << 3)) w = (w & 7) * per_xcd + (w >> 3); // XCD-major: an XCD's L2 sees neighbouring bands
+    if (ZG_XCD_ORDER && w < (per_xcd << 3)) w = (w & 7) * per_xcd + (w >> 3); // XCD-major: an XCD's L2 sees neighbouring bands
     const uint32_t per_frame = (uint32_t)(a.bands * a.segs_x);
     const uint32_t frame = w / per_frame, t = w - frame * per_frame;
     const int band = (int)(t / (uint32_t)a.segs_x), seg = (int)(t - (uint32_t)band * (uint32_t)a.segs_x);

@@ -116,30 +116,11 @@ if what & {"resize"}:
         report("resize 2048^2 -> 4096^2 Rgba(u8) bilinear: " + n, res[k])
     del up, im, srcs
 
-if what & {"u8o"}:
-    ring = 8
-    fr = [(zg.Image(torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")), zg.Image(torch.empty((R, R, 4), dtype=torch.uint8, device="cuda"))) for _ in range(ring)]
-    one = lambda i: fr[i % ring][0].gaussian_blur(0.6, out=fr[i % ring][1])
-    variants = [("default (32 rows, XCD-major)", {})]
-    for rows in (8, 12, 16, 20, 32):
-        variants.append((f"strip rows={rows}, address order", dict(ZIGNAL_HIP_STREAM_ROWS=rows, ZIGNAL_HIP_STREAM_ADDR_ORDER=1)))
-        variants.append((f"strip rows={rows}, XCD-major", dict(ZIGNAL_HIP_STREAM_ROWS=rows)))
-    res = {n: [] for n, _ in variants}
-    for rep in range(3):
-        for n, kv in variants:
-            with knob(**kv):
-                res[n].append(bench._time_kernel(torch, one, n=48, warm=8))
-    for n, _ in variants:
-        report("Rgba(u8) 4096^2 gaussianBlur(0.6): " + n, res[n])
-    del fr
-
 if what & {"all", "u8"}:
     ring = 8
     fr = [(zg.Image(torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")), zg.Image(torch.empty((R, R, 4), dtype=torch.uint8, device="cuda"))) for _ in range(ring)]
     one = lambda i: fr[i % ring][0].gaussian_blur(0.6, out=fr[i % ring][1])
     variants = [("plain taps", dict(ZIGNAL_HIP_STREAM_NO_FOLD=1)), ("folded unit-end taps", {})]
-    for rows in (24, 40, 48, 64):
-        variants.append((f"folded, strip rows={rows}", dict(ZIGNAL_HIP_STREAM_ROWS=rows)))
     res = {n: [] for n, _ in variants}
     for rep in range(3):
         for n, kv in variants:

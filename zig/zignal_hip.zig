@@ -114,6 +114,11 @@ pub const Pipeline = struct {
     pub fn run(self: Pipeline, src: *const anyopaque, n_frames: u32, rows: u32, cols: u32, pixel: c_int, space: c_int, dst: *anyopaque, stream: ?*anyopaque) !void {
         try check(c.zg_batch_pipeline(src, n_frames, rows, cols, pixel, space, self.steps.ptr, @intCast(self.steps.len), dst, stream));
     }
+    /// The same over every device of a zg_multi context (zg_multi_batch_pipeline): src / dst live on the context's root device; frames shard in
+    /// contiguous blocks, no halo, no collective on the data path. Synchronous.
+    pub fn runMulti(self: Pipeline, ctx: ?*anyopaque, src_root: *const anyopaque, n_frames: u32, rows: u32, cols: u32, pixel: c_int, space: c_int, dst_root: *anyopaque, times_ms: ?*[3]f32) !void {
+        try check(c.zg_multi_batch_pipeline(ctx, src_root, n_frames, rows, cols, pixel, space, self.steps.ptr, @intCast(self.steps.len), dst_root, times_ms));
+    }
 };
 
 pub const c = struct {
@@ -187,6 +192,9 @@ pub const c = struct {
     pub extern fn zg_multi_destroy(m: ?*anyopaque) c_int;
     pub extern fn zg_multi_device_count(m: ?*anyopaque) c_int;
     pub extern fn zg_multi_wait_stream(m: ?*anyopaque, producer: ?*anyopaque) c_int;
+    pub extern fn zg_multi_batch_pipeline(m: ?*anyopaque, src_frames_root: *const anyopaque, n_frames: u32, rows: u32, cols: u32, pixel: c_int, space: c_int, steps: [*]const ZgStep, n_steps: u32, dst_frames_root: *anyopaque, times_ms: ?*[3]f32) c_int;
+    pub extern fn zg_multi_piece_range(n_frames: u32, world: c_int, chunks: c_int, device: c_int, piece: c_int, begin: *u32, end: *u32) c_int;
+    pub extern fn zg_sizeof_step() usize;
     pub extern fn zg_multi_batch_blur_resize(m: ?*anyopaque, src_frames_root: *const anyopaque, n_frames: u32, rows: u32, cols: u32, pixel: c_int, sigma: f32, dst_frames_root: *anyopaque, out_rows: u32, out_cols: u32, method: *const ZgMethod, times_ms: ?*[3]f32) c_int;
     pub extern fn zg_stream_create(out: *?*anyopaque) c_int;
     pub extern fn zg_stream_destroy(stream: ?*anyopaque) c_int;

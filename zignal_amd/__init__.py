@@ -8,9 +8,9 @@ from ._lib import (BORDER_MIRROR, BORDER_REPLICATE, BORDER_WRAP, BORDER_ZERO, CS
                    CS_RGBA, CS_XYB, CS_XYZ, CS_YCBCR, CodecError, DimensionMismatch, InvalidArgument, ZignalError, lib)
 from .image import (AffineTransform, Blending, BorderMode, Image, ImagePyramid, Interpolation, ProjectiveTransform,
                     SimilarityTransform, convolve_separable_planes, gaussian_blur_planes, gaussian_kernel, lanczos_plane_weights)
-from .pipeline import Pipeline, Step
+from .pipeline import Multi, Pipeline, Step
 
 __all__ = ["Image", "ImagePyramid", "Interpolation", "BorderMode", "Blending", "ProjectiveTransform", "AffineTransform",
-           "SimilarityTransform", "Pipeline", "Step", "gaussian_kernel", "gaussian_blur_planes", "convolve_separable_planes", "lanczos_plane_weights", "DimensionMismatch", "InvalidArgument", "CodecError", "ZignalError", "lib", "png", "jpeg"]
+           "SimilarityTransform", "Pipeline", "Step", "Multi", "gaussian_kernel", "gaussian_blur_planes", "convolve_separable_planes", "lanczos_plane_weights", "DimensionMismatch", "InvalidArgument", "CodecError", "ZignalError", "lib", "png", "jpeg"]
 
 from . import jpeg, png  # noqa: E402,F401

@@ -155,6 +155,9 @@ _SIGNATURES = {
     "zg_multi_device_count": [C.c_void_p],
     "zg_multi_wait_stream": [C.c_void_p, C.c_void_p],
     "zg_multi_batch_blur_resize": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_float, C.c_void_p, C.c_uint32, C.c_uint32, _METHOD, _F32P],
+    "zg_multi_batch_pipeline": [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(ZgStep), C.c_uint32, C.c_void_p, _F32P],
+    "zg_multi_piece_range": [C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, _U32P, _U32P],
+    "zg_sizeof_step": [],
     "zg_stream_create": [C.POINTER(C.c_void_p)],
     "zg_stream_destroy": [C.c_void_p],
     "zg_stream_synchronize": [C.c_void_p],
@@ -255,7 +258,7 @@ _SIGNATURES = {
     "zg_jpeg_encode_blocks": [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(ZgJpegEncodeOptions), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)],
     "zg_jpeg_free": [C.c_void_p],
 }
-_RESTYPES = {"zg_last_error": C.c_char_p, "zg_shutdown": None, "zg_pixel_size": C.c_size_t, "zg_pyramid_scale": C.c_float,
+_RESTYPES = {"zg_last_error": C.c_char_p, "zg_shutdown": None, "zg_pixel_size": C.c_size_t, "zg_sizeof_step": C.c_size_t, "zg_pyramid_scale": C.c_float,
              "zg_png_default_limits": None, "zg_png_default_encode_options": None, "zg_png_free": None, "zg_jpeg_default_limits": None, "zg_jpeg_default_encode_options": None, "zg_jpeg_free": None}
 
 # every symbol include/zignal_hip.h declares; tests check the library exports all of them
@@ -274,6 +277,8 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)  # AttributeError if the library does not export it
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, C.c_int)
+        if l.zg_sizeof_step() != C.sizeof(ZgStep):  # zg_step has no size field: a library built from another header must not be handed ZgStep arrays
+            raise ImportError(f"{LIB_PATH}: sizeof(zg_step) is {l.zg_sizeof_step()} in the library, {C.sizeof(ZgStep)} in this binding: rebuild the library")
         _lib = l
     return _lib
 

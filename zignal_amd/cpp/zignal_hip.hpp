@@ -522,6 +522,11 @@ struct Pipeline {
     template <typename Src> void run(const Src *src, uint32_t n_frames, uint32_t rows, uint32_t cols, void *dst, zg_stream stream = nullptr) const {
         check(zg_batch_pipeline(src, n_frames, rows, cols, PixelTraits<Src>::pixel, PixelTraits<Src>::space, steps.data(), (uint32_t)steps.size(), dst, stream));
     }
+    // the same over every device of a zg_multi context: src / dst live on the context's root device, the call returns when the results are complete
+    template <typename Src> void runMulti(zg_multi ctx, const Src *src_root, uint32_t n_frames, uint32_t rows, uint32_t cols, void *dst_root, float times_ms[3] = nullptr) const {
+        check(zg_multi_batch_pipeline(ctx, src_root, n_frames, rows, cols, PixelTraits<Src>::pixel, PixelTraits<Src>::space, steps.data(), (uint32_t)steps.size(), dst_root,
+                                      times_ms));
+    }
 };
 
 } // namespace zignal

@@ -136,10 +136,21 @@ int run_convert(const Frames &in, const Frames &out, const float *lut, hipStream
 // The CLI's edges step (src/cli/edges.zig:126-135): gray = frame.convert(u8); detector(gray) -> Image(u8); .convert(frame type). The
 // detectors take any pixel type and start with that very conversion per pixel (edges.zig:36-45: as(f32, convertColor(u8, px))), so they
 // read the frames directly; the edge maps of the whole batch go to one grey scratch plane and come back through ONE conversion launch.
-int run_edges(const zg_step &st, const Frames &in, const Frames &out, hipStream_t s) {
-    void *grey = nullptr;
-    const size_t plane = (size_t)in.rows * in.cols;
-    if (const int rc = scratch_alloc(&grey, plane * in.n, s)) return rc;
+// That shortcut holds for u8 frames in Gray / Rgb / Rgba. Float frames do not: Image(f32).sobel works on the raw floats (edges.zig:36-45 casts, it does
+// not scale), where the bridge's frame.convert(u8) maps [0, 1] to [0, 255] first; and frames a CONVERT step left in another colour space (Oklab, Lab, Hsv ...)
+// are not RGB at all. Those frames go through the bridge literally: one conversion launch to a grey u8 plane, the detector on that.
+int run_edges(const zg_step &st, const Frames &in_frames, const Frames &out, hipStream_t s) {
+    void *grey = nullptr, *bridged = nullptr;
+    const size_t plane = (size_t)in_frames.rows * in_frames.cols;
+    if (const int rc = scratch_alloc(&grey, plane * in_frames.n, s)) return rc;
+    Frames in = in_frames;
+    const bool direct = !pixel_is_float(in.pixel) && (in.space == ZG_CS_GRAY || in.space == ZG_CS_RGB || in.space == ZG_CS_RGBA);
+    if (!direct) {
+        if (const int rc = scratch_alloc(&bridged, plane * in.n, s)) { scratch_free(grey, s); return rc; }
+        const Frames b8{bridged, in.n, in.rows, in.cols, ZG_PIXEL_U8, ZG_CS_GRAY};
+        if (const int rc = run_convert(in, b8, nullptr, s)) { scratch_free(bridged, s); scratch_free(grey, s); return rc; }
+        in = b8;
+    }
     const Frames g{grey, in.n, in.rows, in.cols, ZG_PIXEL_U8, ZG_CS_GRAY};
     int rc = -1;
     if (st.edges == ZG_EDGES_SOBEL && in.n > 0) {
@@ -153,6 +164,7 @@ int run_edges(const zg_step &st, const Frames &in, const Frames &out, hipStream_
             return zg_shen_castan(a, b, st.sigma, st.window, st.high, st.low, 1, st.use_nms, (zg_stream)s);
         });
     if (rc == ZG_OK) rc = run_convert(g, out, nullptr, s);
+    scratch_free(bridged, s);
     scratch_free(grey, s);
     return rc;
 }
@@ -187,6 +199,8 @@ int run_fused_pair(const zg_step &s0, const zg_step &s1, const Frames &in, const
 using namespace zg;
 
 extern "C" {
+
+size_t zg_sizeof_step(void) { return sizeof(zg_step); }
 
 int zg_batch_pipeline_shape(uint32_t rows, uint32_t cols, int pixel, int space, const zg_step *steps, uint32_t n_steps, uint32_t *out_rows, uint32_t *out_cols,
                             int *out_pixel, int *out_space) {

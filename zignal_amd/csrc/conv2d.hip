@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_conv2d(DImg src, DImg dst, Kernel2D k, 
 
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
-    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    if (ZG_XCD_ORDER && wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
     const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
     const int x0 = tx * C2_TW, y0 = ty * C2_TH;
 

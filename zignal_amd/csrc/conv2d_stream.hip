@@ -52,7 +52,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 3 ? 4 :
 
     const uint32_t nwg = gridDim.x, per_xcd = nwg >> 3;
     uint32_t w = blockIdx.x;
-    if (w < (per_xcd << 3)) w = (w & 7) * per_xcd + (w >> 3); // XCD-major: an XCD's L2 sees whole bands of neighbouring strips
+    if (ZG_XCD_ORDER && w < (per_xcd << 3)) w = (w & 7) * per_xcd + (w >> 3); // XCD-major: an XCD's L2 sees whole bands of neighbouring strips
     const int sy = (int)(w / (uint32_t)a.strips_x), sx = (int)(w - (uint32_t)sy * (uint32_t)a.strips_x);
 
     const int lx = (int)threadIdx.x;
@@ -214,8 +214,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 3 ? 4 :
 
 static int c2s_strip_rows(uint32_t rows, uint32_t strips_x, int k, int d) {
     int r;
-    if (const char *e = getenv("ZIGNAL_HIP_C2S_ROWS")) r = std::max(2, atoi(e)); // tuning hook
-    else {
+    {
         const uint64_t all_rows = (uint64_t)rows * strips_x;
         r = (int)std::min<uint64_t>(std::max<uint64_t>((all_rows + 4095) / 4096, 16), 64); // ~four waves per SIMD of the chip when one image has to fill it
     }
@@ -251,8 +250,6 @@ static int launch_c2s(const zg_image *src, const zg_image *dst, const float *tap
 
 // taps: round(k * 256) as floats, kh x kw. Returns -1 when the preconditions do not hold (the caller runs k_conv2d).
 int try_conv2d_stream(const zg_image *src, const zg_image *dst, const float *taps, int kh, int kw, int border, hipStream_t s) {
-    static const bool off = getenv("ZIGNAL_HIP_NO_CONV2D_STREAM") != nullptr; // tuning hook
-    if (off) return -1;
     if (kh != kw || (kh != 3 && kh != 5)) return -1; // 7 x 7 wants 261 to 373 registers in this form (one wave per SIMD): it stays on k_conv2d
     const int sp = (int)pixel_size(src->pixel);
     if (pixel_is_float(src->pixel) || (sp != 1 && sp != 3 && sp != 4)) return -1;

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_sep_bytes(DImg src, DImg dst, TapsU8<NK
 
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
-    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3); // XCD-major order
+    if (ZG_XCD_ORDER && wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3); // XCD-major order
     const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
     const int xb0 = tx * 1024, y0 = ty * TH;
     const int lx = threadIdx.x & 63;

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_sep_f32x4(DImg src, DImg dst, TapsF32<N
 
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
-    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3); // XCD-major tile order
+    if (ZG_XCD_ORDER && wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3); // XCD-major tile order
     const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
     const int x0 = tx * F4_TW, y0 = ty * TH;
     const int lx = threadIdx.x & 63;

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void k_sep_rgba8(DImg src, DImg dst, size_t sr
 
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
-    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3); // XCD-major order
+    if (ZG_XCD_ORDER && wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3); // XCD-major order
     const int frame = wg / tiles_per_frame, t = wg - frame * tiles_per_frame;
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
     src.data = (uint32_t *)src.data + (size_t)frame * src_frame_px;

@@ -47,7 +47,6 @@ struct StreamArgs {
     int32_t border;
     uint32_t src_span, dst_span;   // bytes from a frame's first byte to the end of its last row
     int32_t fast_ok;               // both spans fit 32 bits: whole-frame descriptors may be used
-    int32_t addr_order;            // work items in address order (no XCD-major renumbering)
 #ifdef ZG_STREAM_TRACE
     unsigned long long *trace;     // tools/exp/stream_trace.hip: per wave {start, end} of the 100 MHz clock + shader cycles
 #endif
@@ -134,7 +133,7 @@ __global__ __launch_bounds__(64) void k_sep_stream(StreamArgs a, TapsU8<NK> kx, 
 #endif
     const uint32_t nwg = gridDim.x, per_xcd = nwg >> 3;
     uint32_t w = blockIdx.x;
-    if (!a.addr_order && w < (per_xcd << 3)) w = (w & 7) * per_xcd + (w >> 3); // XCD-major: an XCD's L2 sees whole bands of neighbouring strips
+    if (ZG_XCD_ORDER && w < (per_xcd << 3)) w = (w & 7) * per_xcd + (w >> 3); // XCD-major: an XCD's L2 sees whole bands of neighbouring strips
     const uint32_t per_frame = (uint32_t)(a.strips_x * a.strips_y);
     const uint32_t frame = w / per_frame, t = w - frame * per_frame;
     const int sy = (int)(t / (uint32_t)a.strips_x), sx = (int)(t - (uint32_t)sy * (uint32_t)a.strips_x);
@@ -395,10 +394,6 @@ __global__ __launch_bounds__(64) void k_sep_stream(StreamArgs a, TapsU8<NK> kx, 
 // convolves for its upper neighbour are the only waste (measured on MI355X, profiles/r03_stream_kernel.txt: 4096^2 Rgba 32 rows,
 // 128 x 1080p 44). The count is then nudged so that a strip's row pairs fill whole blocks of the kernel's unrolled loop.
 static int stream_strip_rows(const StreamJob &j, uint32_t strips_x, int h, int d) {
-    if (const char *e = getenv("ZIGNAL_HIP_STREAM_ROWS")) { // tuning hook
-        const int v = atoi(e);
-        if (v >= 2) return (v + 1) & ~1;
-    }
     const uint64_t all_rows = (uint64_t)j.rows * strips_x * j.n_frames;
     uint64_t r = (all_rows + 2047) / 2048;
     r = std::min<uint64_t>(std::max<uint64_t>(r, 16), 44);
@@ -422,7 +417,6 @@ static int launch_stream(const StreamJob &j, const int32_t *ix, const int32_t *i
     a.strip_rows = stream_strip_rows(j, (uint32_t)a.strips_x, NK / 2, NK / 2 + 1);
     a.strips_y = (int32_t)ceil_div(j.rows, (unsigned)a.strip_rows);
     a.border = border;
-    a.addr_order = getenv("ZIGNAL_HIP_STREAM_ADDR_ORDER") != nullptr; // experiment hook of round 5
     const uint64_t sspan = (uint64_t)(j.rows - 1) * j.src_pitch + (uint64_t)a.row_bytes;
     const uint64_t dspan = j.down2 ? (uint64_t)(j.rows / 2 - 1) * j.dst_pitch + (uint64_t)(a.row_bytes / 2) : (uint64_t)(j.rows - 1) * j.dst_pitch + (uint64_t)a.row_bytes;
     a.fast_ok = sspan <= 0xffffffffu && dspan <= 0xffffffffu;

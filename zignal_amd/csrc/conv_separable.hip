@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void k_sep_fused(DImg src, DImg dst, TapsArg<N
     const int nwg = gridDim.x;
     const int per_xcd = nwg >> 3;
     int wg = blockIdx.x;
-    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    if (ZG_XCD_ORDER && wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
 
     Stage st;
     if constexpr (!PERSIST) { // one tile per workgroup; the hardware dispatcher overlaps load and compute phases
@@ -609,8 +609,6 @@ static int conv_separable_impl(const zg_image *src, const zg_image *dst, const f
         if (p.nkx == p.nky) { // small non-negative taps: packed-u16 arithmetic on the row as a byte stream, 16 bytes / lane
             const size_t sp = pixel_size(src->pixel);
             const StreamJob job{src->data, dst->data, 1, src->rows, src->cols, (int)sp, src->stride * sp, dst->stride * sp, 0, 0, false};
-            const int rcm = try_sep_mfma(job, p.ix.data(), p.iy.data(), p.nkx, border, s); // both passes as Toeplitz products on the matrix pipe
-            if (rcm >= 0) return rcm;
             const int rcs = try_sep_stream(job, p.ix.data(), p.iy.data(), p.nkx, border, s); // one wave per column strip, no LDS
             if (rcs >= 0) return rcs;
             const int rcb = try_sep_bytes(src, dst, p.ix.data(), p.iy.data(), p.nkx, border, s);

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_resize_bilinear_rgba8_to_lab(DIm
     int wg = blockIdx.x;
     if constexpr (WAVES == 4) {
         const int nwg = gridDim.x, per_xcd = nwg >> 3;
-        if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+        if (ZG_XCD_ORDER && wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
     }
     src.data = (char *)src.data + (size_t)blockIdx.y * fr.src_frame; // a batch of equally shaped frames in one launch (batch.hip)
     dst.data = (char *)dst.data + (size_t)blockIdx.y * fr.dst_frame;

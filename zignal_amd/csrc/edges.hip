@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_sobel(DImg src, DImg dst, int tiles_x, 
     dst.data = (char *)dst.data + (size_t)blockIdx.y * fr.dst_frame;
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
-    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    if (ZG_XCD_ORDER && wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
     const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
     const int x0 = tx * 64, y0 = ty * TH;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_canny_nms(const float *blur, uint8_t *s
     __shared__ uint8_t st[TH][64];
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
-    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    if (ZG_XCD_ORDER && wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
     const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
     const int x0 = tx * 64, y0 = ty * TH;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1377,7 +1377,9 @@ int zg_isef_smooth(const zg_image *src, const zg_image *dst, float smooth, zg_st
     if (src->pixel == ZG_PIXEL_U8) { // as the detector has it: bytes for the segmented row pass, f32 only where that does not apply
         gray8 = (const uint8_t *)src->data;
         gray = nullptr;
-        if (!isef_2d_applies(rows, cols) || ((uintptr_t)gray8 & 15)) {
+        // isef_2d also wants a 16-byte aligned destination; when it is not, isef_plane falls through to the transposing route, which reads the
+        // f32 plane: it has to exist then (the null plane was an illegal access)
+        if (!isef_2d_applies(rows, cols) || ((uintptr_t)gray8 & 15) || ((uintptr_t)dst->data & 15)) {
             launch_canny_gray<ZG_PIXEL_U8>(src, as_f32, s); // as(f32, u8)
             gray = as_f32;
             gray8 = nullptr;
@@ -1472,11 +1474,10 @@ int zg_pyramid_build(const zg_image *source, const zg_image *levels, const float
     hipStream_t main = as_stream(stream);
     // Forking pays when the device is the bottleneck — a graph replay: 445 us on one stream, 351 us on four for ORB's default pyramid of
     // a 4096^2 plane — and costs when the host is (eager launches: 508 us on one stream, 661 us on four: every cross-stream hand-off
-    // is host work). So the levels fork under stream capture and stay on `stream` otherwise. ZIGNAL_HIP_PYRAMID_LANES overrides.
-    static const int lane_env = [] { const char *e = getenv("ZIGNAL_HIP_PYRAMID_LANES"); return e ? std::max(1, std::min(4, atoi(e))) : 0; }();
+    // is host work). So the levels fork under stream capture and stay on `stream` otherwise.
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(main, &capturing) != hipSuccess) { (void)hipGetLastError(); capturing = hipStreamCaptureStatusNone; }
-    int want = lane_env ? lane_env : (capturing == hipStreamCaptureStatusActive ? 4 : 1);
+    int want = capturing == hipStreamCaptureStatusActive ? 4 : 1;
     if (n_levels < (uint32_t)want) want = (int)n_levels;
     hipStream_t lanes[4] = {main, nullptr, nullptr, nullptr};
     int n_lanes = 1;

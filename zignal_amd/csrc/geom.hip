@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_geom(DImg src, DImg dst, GeomParams g, 
     // contiguous band of destination (hence, for smooth maps, of source) rows.
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
-    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    if (ZG_XCD_ORDER && wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
     src.data = (char *)src.data + (size_t)blockIdx.y * fr.src_frame; // a batch of equally shaped frames, the same map for each (zg_batch_pipeline)
     dst.data = (char *)dst.data + (size_t)blockIdx.y * fr.dst_frame;
     const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
@@ -228,7 +228,7 @@ static int check_pair(const zg_image *src, const zg_image *dst, const char *op) 
 __global__ __launch_bounds__(256) void k_resize_bilinear_u8(DImg src, DImg dst, float rx, float ry, int tiles_x, FrameSpan fr, int dword_rows) {
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
-    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    if (ZG_XCD_ORDER && wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
     src.data = (char *)src.data + (size_t)blockIdx.y * fr.src_frame;
     dst.data = (char *)dst.data + (size_t)blockIdx.y * fr.dst_frame;
     const int ty = wg / tiles_x, tx = wg - ty * tiles_x;

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_resize_planes(DImg src, DImg dst, AxisT
     constexpr int C = P::C;
     const int nwg = gridDim.x, per_xcd = nwg >> 3;
     int wg = blockIdx.x;
-    if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    if (ZG_XCD_ORDER && wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
     const int tyi = wg / tiles_x, txi = wg - tyi * tiles_x;
     const int c = txi * 64 + (int)(threadIdx.x & 63);
     const int r = __builtin_amdgcn_readfirstlane(tyi * 4 + (int)(threadIdx.x >> 6)); // one row per wave
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_resize_bilinear_rgba8(DImg src, 
     int wg = blockIdx.x;
     if constexpr (XCD) {
         const int nwg = gridDim.x, per_xcd = nwg >> 3;
-        if (wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+        if (ZG_XCD_ORDER && wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
     }
     src.data = (char *)src.data + (size_t)blockIdx.y * fr.src_frame;
     dst.data = (char *)dst.data + (size_t)blockIdx.y * fr.dst_frame;

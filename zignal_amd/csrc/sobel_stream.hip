@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64) void k_sobel_stream(SobelStreamArgs a) {
 
     const uint32_t nwg = gridDim.x, per_xcd = nwg >> 3;
     uint32_t w = blockIdx.x;
-    if (w < (per_xcd << 3)) w = (w & 7) * per_xcd + (w >> 3);
+    if (ZG_XCD_ORDER && w < (per_xcd << 3)) w = (w & 7) * per_xcd + (w >> 3);
     const int sy = (int)(w / (uint32_t)a.strips_x), sx = (int)(w - (uint32_t)sy * (uint32_t)a.strips_x);
     const uint8_t *srcf = a.src + (size_t)blockIdx.y * a.src_frame;
     uint8_t *dstf = a.dst + (size_t)blockIdx.y * a.dst_frame;
@@ -208,9 +208,7 @@ static int launch_sobel_stream(const zg_image *src, const zg_image *dst, uint32_
     a.rows = (int32_t)src->rows;
     a.row_bytes = (int32_t)(src->cols * (uint32_t)SP);
     a.strips_x = (int32_t)ceil_div((unsigned)a.row_bytes, 1024u);
-    int r;
-    if (const char *e = getenv("ZIGNAL_HIP_SOBEL_ROWS")) r = std::max(2, atoi(e)); // tuning hook
-    else r = (int)std::min<uint64_t>(std::max<uint64_t>(((uint64_t)src->rows * a.strips_x * n + 4095) / 4096, 16), 64);
+    int r = (int)std::min<uint64_t>(std::max<uint64_t>(((uint64_t)src->rows * a.strips_x * n + 4095) / 4096, 16), 64);
     while ((r + 2) % 3) ++r; // (strip rows + 2) % D == 0
     a.strip_rows = r;
     a.strips_y = (int32_t)ceil_div(src->rows, (unsigned)a.strip_rows);
@@ -227,8 +225,6 @@ static int launch_sobel_stream(const zg_image *src, const zg_image *dst, uint32_
 
 // Returns -1 when the preconditions do not hold (the caller runs k_sobel).
 int try_sobel_stream(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s) {
-    static const bool off = getenv("ZIGNAL_HIP_NO_SOBEL_STREAM") != nullptr; // tuning hook
-    if (off) return -1;
     if (src->pixel != ZG_PIXEL_U8 && src->pixel != ZG_PIXEL_RGBA_U8) return -1;
     const int sp = src->pixel == ZG_PIXEL_U8 ? 1 : 4;
     const uint64_t rb = (uint64_t)src->cols * (uint64_t)sp, sp_pitch = (uint64_t)src->stride * sp;

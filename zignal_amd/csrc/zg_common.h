@@ -159,6 +159,12 @@ __device__ inline uint8_t clamp_u8_f32(float v) {
 }
 __device__ inline uint8_t clamp_u8_i32(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
+// Kernels whose neighbouring workgroups share source lines renumber their workgroups XCD-major (block b runs on XCD b % 8, each XCD has
+// its own L2). tools/build_variant.sh-style builds with -DZG_XCD_ORDER=0 run every kernel in plain address order instead: the A/B of round 5.
+#ifndef ZG_XCD_ORDER
+#define ZG_XCD_ORDER 1
+#endif
+
 // ---- launch helpers ------------------------------------------------------------------------
 inline unsigned ceil_div(unsigned a, unsigned b) { return (a + b - 1) / b; }
 // One workgroup row per image row: HIP caps gridDim.y at 65535, so rows past that continue in gridDim.z. Kernels read their
@@ -222,8 +228,6 @@ struct StreamJob {
     bool down2;                            // dst is (rows / 2) x (cols / 2): blur then 2:1 bilinear (sp == 4)
 };
 int try_sep_stream(const StreamJob &j, const int32_t *ix, const int32_t *iy, int nk, int border, hipStream_t s);
-// the same job with both passes on the matrix pipe (conv_sep_mfma.hip); -1 when its preconditions do not hold
-int try_sep_mfma(const StreamJob &j, const int32_t *ix, const int32_t *iy, int nk, int border, hipStream_t s);
 
 // scratch blocks from the library's caching allocator, ordered on stream s (zg_runtime.cpp)
 int scratch_alloc(void **out, size_t bytes, hipStream_t s);

@@ -22,6 +22,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <vector>
 
@@ -127,6 +128,22 @@ void shard_range(uint32_t n, int i, int world, uint32_t *begin, uint32_t *end) {
     *begin = (uint32_t)i * base + ((uint32_t)i < extra ? (uint32_t)i : extra);
     *end = *begin + base + ((uint32_t)i < extra ? 1u : 0u);
 }
+
+// Frames [*begin, *end) of the batch: piece c of device i's shard, when every shard travels in (up to) `chunks` pieces. Pieces of a shard are
+// contiguous, ordered and differ by at most one frame; a shard shorter than `chunks` frames has one frame per piece and empty pieces after them.
+void piece_range(uint32_t n_frames, int world, int chunks, int i, int c, uint32_t *begin, uint32_t *end) {
+    uint32_t sb, se, cb, ce;
+    shard_range(n_frames, i, world, &sb, &se);
+    const uint32_t k = se - sb;
+    const int pieces = (int)std::min<uint32_t>((uint32_t)chunks, std::max<uint32_t>(k, 1));
+    if (c >= pieces || k == 0) { *begin = *end = sb; return; }
+    shard_range(k, c, pieces, &cb, &ce);
+    *begin = sb + cb;
+    *end = sb + ce;
+}
+
+// What a device does with a piece of its shard once it has arrived: n frames at `src` -> n frames at `dst`, enqueued on `s` (the device is current).
+typedef std::function<int(const void *src, uint32_t n, void *dst, zg_stream s)> PieceOp;
 
 int ensure(void **p, size_t *have, size_t need) {
     if (*have >= need) return ZG_OK;
@@ -259,23 +276,12 @@ namespace {
 // once the kernel is done. One grouped launch per piece index and direction, so every xGMI link carries its own peer's pieces back to
 // back and no transfer rings through a third device. Issue order = piece order on every device, which is what RCCL needs from a single
 // thread driving several communicators.
-int run_batch(Multi *m, const void *src_root, uint32_t n_frames, uint32_t rows, uint32_t cols, int pixel, float sigma, void *dst_root,
-              uint32_t out_rows, uint32_t out_cols, const zg_method *method, bool timed) {
+int run_batch(Multi *m, const void *src_root, uint32_t n_frames, size_t in_frame, void *dst_root, size_t out_frame, const PieceOp &op, bool timed) {
     const int world = (int)m->dev.size();
-    const size_t ps = pixel_size(pixel), in_frame = (size_t)rows * cols * ps, out_frame = (size_t)out_rows * out_cols * ps;
     DeviceSlot &root = m->dev[0];
     const bool loop = world == 1 && m->loopback;
     const int first_peer = loop ? 0 : 1;
-    auto piece = [&](int i, int c, uint32_t *b, uint32_t *e) { // frames [b, e) of the batch: piece c of device i's shard
-        uint32_t sb, se, cb, ce;
-        shard_range(n_frames, i, world, &sb, &se);
-        const uint32_t k = se - sb;
-        const int pieces = (int)std::min<uint32_t>((uint32_t)m->chunks, std::max<uint32_t>(k, 1));
-        if (c >= pieces || k == 0) { *b = *e = sb; return; }
-        shard_range(k, c, pieces, &cb, &ce);
-        *b = sb + cb;
-        *e = sb + ce;
-    };
+    auto piece = [&](int i, int c, uint32_t *b, uint32_t *e) { piece_range(n_frames, world, m->chunks, i, c, b, e); };
     auto staged = [&](int i, uint32_t frame, bool input) -> char * { // where device i keeps `frame` of its shard
         uint32_t sb, se;
         shard_range(n_frames, i, world, &sb, &se);
@@ -294,8 +300,7 @@ int run_batch(Multi *m, const void *src_root, uint32_t n_frames, uint32_t rows, 
         ZG_HIP(hipSetDevice(root.device));
         if (timed) ZG_HIP(hipEventRecord(root.t_run0, root.s_run));
         if (e > b) {
-            const int rc = zg_batch_blur_resize((const char *)src_root + (size_t)b * in_frame, e - b, rows, cols, pixel, sigma,
-                                                (char *)dst_root + (size_t)b * out_frame, out_rows, out_cols, method, (zg_stream)root.s_run);
+            const int rc = op((const char *)src_root + (size_t)b * in_frame, e - b, (char *)dst_root + (size_t)b * out_frame, (zg_stream)root.s_run);
             if (rc) return rc;
         }
         if (timed) ZG_HIP(hipEventRecord(root.t_run1, root.s_run));
@@ -327,8 +332,7 @@ int run_batch(Multi *m, const void *src_root, uint32_t n_frames, uint32_t rows, 
             ZG_HIP(hipEventRecord(d.arrived[c], d.s_in));
             ZG_HIP(hipStreamWaitEvent(d.s_run, d.arrived[c], 0));
             if (timed && c == 0) ZG_HIP(hipEventRecord(d.t_run0, d.s_run));
-            const int rc = zg_batch_blur_resize(staged(i, b, true), e - b, rows, cols, pixel, sigma, staged(i, b, false), out_rows, out_cols, method,
-                                                (zg_stream)d.s_run);
+            const int rc = op(staged(i, b, true), e - b, staged(i, b, false), (zg_stream)d.s_run);
             if (rc) return rc;
             ZG_HIP(hipEventRecord(d.done[c], d.s_run));
             ZG_HIP(hipStreamWaitEvent(d.s_out, d.done[c], 0));
@@ -378,18 +382,18 @@ int sync_all(Multi *m) {
 
 } // namespace
 
-int zg_multi_batch_blur_resize(zg_multi handle, const void *src_frames_root, uint32_t n_frames, uint32_t rows, uint32_t cols, int pixel, float sigma,
-                               void *dst_frames_root, uint32_t out_rows, uint32_t out_cols, const zg_method *method, float times_ms[3]) {
-    ZG_REQUIRE(handle != nullptr, ZG_ERR_INVALID_ARGUMENT, "zg_multi_batch_blur_resize: null context");
-    ZG_REQUIRE(pixel_valid(pixel), ZG_ERR_INVALID_ARGUMENT, "batch: invalid pixel type %d", pixel);
-    ZG_REQUIRE(method != nullptr, ZG_ERR_INVALID_ARGUMENT, "batch: null method");
-    if (times_ms) times_ms[0] = times_ms[1] = times_ms[2] = 0.0f;
-    if (n_frames == 0 || rows == 0 || cols == 0 || out_rows == 0 || out_cols == 0) return ZG_OK;
-    ZG_REQUIRE(src_frames_root && dst_frames_root, ZG_ERR_INVALID_ARGUMENT, "batch: null frame pointer");
-    Multi *m = (Multi *)handle;
+namespace {
+
+// The part every batch entry point shares: staging on the owners, the wait for whatever produced the caller's frames, the exchange, the final
+// wait, the timings. Synchronous: results are complete on return.
+int multi_batch(Multi *m, const void *src_frames_root, uint32_t n_frames, size_t in_frame, void *dst_frames_root, size_t out_frame, const PieceOp &op,
+                float times_ms[3]) {
+    // The caller's statement about its producer stream(s) covers exactly ONE batch call: take it and clear it first, so that a call that fails
+    // its checks below cannot leave it behind for a later batch whose frames come from some other stream.
+    const bool producer_named = m->producer_named;
+    m->producer_named = false;
     ZG_REQUIRE(!m->poisoned, ZG_ERR_INVALID_ARGUMENT, "zg_multi: an earlier call on this context failed half-way; destroy it and create a new one");
     const int world = (int)m->dev.size();
-    const size_t ps = pixel_size(pixel), in_frame = (size_t)rows * cols * ps, out_frame = (size_t)out_rows * out_cols * ps;
     DeviceScope scope;
     DeviceSlot &root = m->dev[0];
     const double wall0 = now_ms();
@@ -414,12 +418,11 @@ int zg_multi_batch_blur_resize(zg_multi handle, const void *src_frames_root, uin
     // it may be a non-blocking stream (this library's own zg_stream_create makes those, and so do PyTorch's side streams), which an event on
     // the legacy default stream would NOT order behind — so the root device is synchronised: the documented "synchronous call" stays safe
     // whatever stream filled src_frames_root.
-    if (!m->producer_named) {
+    if (!producer_named) {
         ZG_HIP(hipSetDevice(root.device));
         ZG_HIP(hipDeviceSynchronize());
     }
-    m->producer_named = false;
-    int rc = run_batch(m, src_frames_root, n_frames, rows, cols, pixel, sigma, dst_frames_root, out_rows, out_cols, method, times_ms != nullptr);
+    int rc = run_batch(m, src_frames_root, n_frames, in_frame, dst_frames_root, out_frame, op, times_ms != nullptr);
     const int src = sync_all(m); // results are complete on return; after a failure this also drains what was already enqueued
     if (rc != ZG_OK || src != ZG_OK) {
         m->poisoned = true; // shards may be half-way: no later call may trust the streams or the communicators
@@ -438,6 +441,63 @@ int zg_multi_batch_blur_resize(zg_multi handle, const void *src_frames_root, uin
         }
         times_ms[2] = (float)(now_ms() - wall0);
     }
+    return ZG_OK;
+}
+
+} // namespace
+
+int zg_multi_batch_blur_resize(zg_multi handle, const void *src_frames_root, uint32_t n_frames, uint32_t rows, uint32_t cols, int pixel, float sigma,
+                               void *dst_frames_root, uint32_t out_rows, uint32_t out_cols, const zg_method *method, float times_ms[3]) {
+    ZG_REQUIRE(handle != nullptr, ZG_ERR_INVALID_ARGUMENT, "zg_multi_batch_blur_resize: null context");
+    Multi *m = (Multi *)handle;
+    if (times_ms) times_ms[0] = times_ms[1] = times_ms[2] = 0.0f;
+    const bool named = m->producer_named; // an argument error or an empty batch consumes the caller's producer statement too
+    m->producer_named = false;
+    ZG_REQUIRE(pixel_valid(pixel), ZG_ERR_INVALID_ARGUMENT, "batch: invalid pixel type %d", pixel);
+    ZG_REQUIRE(method != nullptr, ZG_ERR_INVALID_ARGUMENT, "batch: null method");
+    if (n_frames == 0 || rows == 0 || cols == 0 || out_rows == 0 || out_cols == 0) return ZG_OK;
+    ZG_REQUIRE(src_frames_root && dst_frames_root, ZG_ERR_INVALID_ARGUMENT, "batch: null frame pointer");
+    m->producer_named = named;
+    const size_t ps = pixel_size(pixel);
+    const zg_method mt = *method;
+    return multi_batch(m, src_frames_root, n_frames, (size_t)rows * cols * ps, dst_frames_root, (size_t)out_rows * out_cols * ps,
+                       [=](const void *src, uint32_t n, void *dst, zg_stream s) {
+                           return zg_batch_blur_resize(src, n, rows, cols, pixel, sigma, dst, out_rows, out_cols, &mt, s);
+                       },
+                       times_ms);
+}
+
+// zg_batch_pipeline over the context's devices: any recipe, not just [blur, resize] (the reference's unit of batch work is "every
+// image through the recipe's steps", src/cli/pipeline.zig:153-179).
+int zg_multi_batch_pipeline(zg_multi handle, const void *src_frames_root, uint32_t n_frames, uint32_t rows, uint32_t cols, int pixel, int space,
+                            const zg_step *steps, uint32_t n_steps, void *dst_frames_root, float times_ms[3]) {
+    ZG_REQUIRE(handle != nullptr, ZG_ERR_INVALID_ARGUMENT, "zg_multi_batch_pipeline: null context");
+    Multi *m = (Multi *)handle;
+    if (times_ms) times_ms[0] = times_ms[1] = times_ms[2] = 0.0f;
+    const bool named = m->producer_named;
+    m->producer_named = false;
+    uint32_t out_rows = 0, out_cols = 0;
+    int out_pixel = 0, out_space = 0;
+    if (int rc = zg_batch_pipeline_shape(rows, cols, pixel, space, steps, n_steps, &out_rows, &out_cols, &out_pixel, &out_space)) return rc; // validates the recipe
+    if (n_frames == 0 || rows == 0 || cols == 0) return ZG_OK;
+    ZG_REQUIRE(src_frames_root && dst_frames_root, ZG_ERR_INVALID_ARGUMENT, "batch: null frame pointer");
+    m->producer_named = named;
+    const std::vector<zg_step> recipe(steps, steps + n_steps); // the caller's array need not outlive the call's set-up
+    return multi_batch(m, src_frames_root, n_frames, (size_t)rows * cols * pixel_size(pixel), dst_frames_root, (size_t)out_rows * out_cols * pixel_size(out_pixel),
+                       [&](const void *src, uint32_t n, void *dst, zg_stream s) {
+                           return zg_batch_pipeline(src, n, rows, cols, pixel, space, recipe.data(), (uint32_t)recipe.size(), dst, s);
+                       },
+                       times_ms);
+}
+
+// Host only: the frames of piece `piece` of device `device`'s shard when n_frames frames go to `world` devices in up to `chunks` pieces per shard
+// (the context's own arithmetic; zignal_amd/sharding.py cuts the same way). A CPU test holds the two to each other and to the partition
+// properties (disjoint, covering, ordered, sizes within one frame) without a GPU.
+int zg_multi_piece_range(uint32_t n_frames, int world, int chunks, int device, int piece, uint32_t *begin, uint32_t *end) {
+    ZG_REQUIRE(begin && end, ZG_ERR_INVALID_ARGUMENT, "zg_multi_piece_range: null output");
+    ZG_REQUIRE(world >= 1 && device >= 0 && device < world && chunks >= 1 && chunks <= MAX_CHUNKS && piece >= 0, ZG_ERR_INVALID_ARGUMENT,
+               "zg_multi_piece_range: world %d, device %d, chunks %d (1..%d), piece %d", world, device, chunks, MAX_CHUNKS, piece);
+    piece_range(n_frames, world, chunks, device, piece, begin, end);
     return ZG_OK;
 }
 

@@ -6,7 +6,7 @@ kernel, fused with its neighbour where it has a fused one, and equals the per-fr
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -144,3 +144,65 @@ class Pipeline:
             L.check(L.lib().zg_batch_pipeline(C.c_void_p(frames.data_ptr()), n, rows, cols, pixel, int(space), self._c, len(self.steps),
                                               C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(frames.device).cuda_stream)))
         return out
+
+    def run_multi(self, ctx: "Multi", frames, space: Optional[int] = None, out=None):
+        """`run` over every GPU of a zg_multi context (zg_multi_batch_pipeline): `frames` and the result live on the context's root device,
+        frames shard in contiguous blocks with no halo and no collective on the data path; returns when the results are complete.
+        Returns (result, (scatter_ms, busiest_device_kernels_ms, whole_call_ms))."""
+        if torch is None or not isinstance(frames, torch.Tensor) or not frames.is_cuda or frames.ndim not in (3, 4) or not frames.is_contiguous():
+            raise ValueError("expected contiguous device frames (n, rows, cols[, channels])")
+        n, rows, cols = (int(v) for v in frames.shape[:3])
+        ch = 1 if frames.ndim == 3 else int(frames.shape[3])
+        pixel = _PIXEL_BY_LAYOUT[(str(frames.dtype).replace("torch.", ""), ch)]
+        if space is None:
+            space = {1: L.CS_GRAY, 3: L.CS_RGB, 4: L.CS_RGBA}[ch]
+        orows, ocols, opixel, _ = self.out_layout(rows, cols, pixel, space)
+        odtype, och = _LAYOUT_BY_PIXEL[opixel]
+        shape = (n, orows, ocols) if och == 1 else (n, orows, ocols, och)
+        tdtype = {"uint8": torch.uint8, "float32": torch.float32}[odtype]
+        if out is None:
+            out = torch.empty(shape, dtype=tdtype, device=frames.device)
+        elif tuple(out.shape) != shape or out.dtype != tdtype or not out.is_contiguous() or out.device != frames.device:
+            raise L.DimensionMismatch(f"out must be a contiguous {tdtype} tensor of shape {shape} on {frames.device}")
+        times = (C.c_float * 3)()
+        ctx.wait_stream(torch.cuda.current_stream(frames.device).cuda_stream)  # what filled `frames` was enqueued on torch's current stream
+        L.check(L.lib().zg_multi_batch_pipeline(ctx.handle, C.c_void_p(frames.data_ptr()), n, rows, cols, pixel, int(space), self._c, len(self.steps),
+                                                C.c_void_p(out.data_ptr()), times))
+        return out, tuple(times)
+
+
+class Multi:
+    """A zg_multi context: ONE host thread drives several GPUs (include/zignal_hip.h; zg_multi.cpp). devices=None means every visible device."""
+
+    def __init__(self, devices: Optional[Sequence[int]] = None):
+        h = C.c_void_p()
+        if devices is None:
+            L.check(L.lib().zg_multi_create(None, 0, C.byref(h)))
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            L.check(L.lib().zg_multi_create(arr, len(devices), C.byref(h)))
+        self.handle = h
+
+    def device_count(self) -> int:
+        return int(L.lib().zg_multi_device_count(self.handle))
+
+    def wait_stream(self, stream: int) -> None:
+        L.check(L.lib().zg_multi_wait_stream(self.handle, C.c_void_p(stream)))
+
+    def close(self) -> None:
+        if self.handle:
+            L.lib().zg_multi_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def piece_range(n_frames: int, world: int, chunks: int, device: int, piece: int) -> Tuple[int, int]:
+    """zg_multi's piece arithmetic (host only): frames [begin, end) of the batch that form piece `piece` of device `device`'s shard."""
+    b, e = C.c_uint32(), C.c_uint32()
+    L.check(L.lib().zg_multi_piece_range(n_frames, world, chunks, device, piece, C.byref(b), C.byref(e)))
+    return b.value, e.value
