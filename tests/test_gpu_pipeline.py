@@ -208,6 +208,28 @@ def test_every_blur_type_and_edge_detector_of_the_cli_as_a_step(oracle):
         assert np.array_equal(got[f], want), f"[blur, canny, resize]: frame {f}"
 
 
+@pytest.mark.parametrize("ch", (1, 3, 4))
+def test_box_blur_step_takes_the_batch_in_the_grid(oracle, ch):
+    """boxBlur as a pipeline step (src/cli/blur.zig:109-112): the three kernels (strip carries, SAT chain, window means) take the whole batch per
+    launch, frame index in the grid, in groups whose integral images fit a scratch block — against Image.boxBlur of the oracle frame by frame,
+    bright frames included (SAT values past 2^24: the column recurrence's rounding order is what is checked)."""
+    rng = np.random.default_rng(30 + ch)
+    shape = (7, 200, 328) + ((ch,) if ch > 1 else ())
+    host = rng.integers(0, 256, shape, dtype=np.uint8)
+    host[3] = 255 - (host[3] >> 5)  # a bright frame
+    dev = torch.from_numpy(host).cuda()
+    for radius in (1, 2, 9):
+        got = zg.Pipeline([zg.Step.box_blur(radius)]).run(dev)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        for f in range(shape[0]):
+            assert np.array_equal(got[f], oracle.box_blur(host[f], radius)), f"box r={radius} ch={ch}: frame {f}"
+    f32 = rng.random((3, 64, 96), dtype=np.float32)  # f32 frames: the per-image SAT kernels, frame by frame
+    got = zg.Pipeline([zg.Step.box_blur(2)]).run(torch.from_numpy(f32).cuda()).cpu().numpy()
+    for f in range(3):
+        assert np.array_equal(got[f].view(np.uint32), oracle.box_blur(f32[f], 2).view(np.uint32)), f"box f32: frame {f}"
+
+
 def test_edges_step_bridges_float_frames_and_other_colour_spaces(oracle):
     """edges.apply is frame.convert(u8) -> detector -> .convert(frame type) (src/cli/edges.zig:126-135). Float frames must go through that
     conversion (Image(f32).sobel on raw [0, 1] floats is a different picture), and so must frames an earlier CONVERT step left in Oklab."""

@@ -169,11 +169,17 @@ int run_edges(const zg_step &st, const Frames &in_frames, const Frames &out, hip
     return rc;
 }
 
+// motion blur and box blur over the batch: the frame index is in the grid (round 5; they launched once per frame before)
 int run_motion(const zg_step &st, const Frames &in, const Frames &out, hipStream_t s) {
-    return per_frame(in, out, [&](const zg_image *a, const zg_image *b) {
-        if (st.motion == ZG_MOTION_LINEAR) return zg_motion_blur_linear(a, b, st.angle, st.cos_a, st.sin_a, st.distance, (zg_stream)s);
-        return zg_motion_blur_radial(a, b, st.center_x, st.center_y, st.strength, st.motion == ZG_MOTION_RADIAL_SPIN, (zg_stream)s);
-    });
+    if (in.n == 0) return ZG_OK;
+    const zg_image a = in.frame(0), b = out.frame(0);
+    if (st.motion == ZG_MOTION_LINEAR) return motion_linear_frames(&a, &b, in.n, in.frame_bytes(), out.frame_bytes(), st.cos_a, st.sin_a, st.distance, s);
+    return motion_radial_frames(&a, &b, in.n, in.frame_bytes(), out.frame_bytes(), st.center_x, st.center_y, st.strength, st.motion == ZG_MOTION_RADIAL_SPIN, s);
+}
+int run_box(const zg_step &st, const Frames &in, const Frames &out, hipStream_t s) {
+    if (in.n == 0) return ZG_OK;
+    const zg_image a = in.frame(0), b = out.frame(0);
+    return box_blur_frames(&a, &b, in.n, in.frame_bytes(), out.frame_bytes(), st.radius, s);
 }
 
 // steps [i, i + 2) as one fused launch over the batch, or -1
@@ -276,7 +282,7 @@ int zg_batch_pipeline(const void *src_frames, uint32_t n_frames, uint32_t rows, 
                 const zg_step &st = steps[i];
                 switch (st.kind) {
                 case ZG_STEP_GAUSSIAN_BLUR: rc = run_blur(cur, next, st.sigma, s); break;
-                case ZG_STEP_BOX_BLUR: rc = per_frame(cur, next, [&](const zg_image *a, const zg_image *b) { return zg_box_blur(a, b, st.radius, stream); }); break;
+                case ZG_STEP_BOX_BLUR: rc = run_box(st, cur, next, as_stream(stream)); break;
                 case ZG_STEP_RESIZE: rc = run_resize(cur, next, st.method, s); break;
                 case ZG_STEP_CONVERT: rc = run_convert(cur, next, st.srgb_lut, s); break;
                 case ZG_STEP_MEDIAN_BLUR:

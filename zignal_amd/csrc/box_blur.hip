@@ -21,6 +21,7 @@
 //   k_box_mean   one thread per pixel: four SAT taps (buffer loads), divide by the clipped area, clamp.
 #include "zg_common.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 #pragma clang fp contract(off)
@@ -128,9 +129,17 @@ __global__ __launch_bounds__(64) void k_sat_cols(float *sat, int rows, int cols)
 // sequence (v_rcp + one Newton step) is computed once, each quotient is the sequence's remaining five operations, bit for bit what
 // `/` expands to when v_div_scale has nothing to scale (a finite sum of 8-bit samples over an area >= 1).
 // (One thread per pixel with 64-bit addresses and four full divisions was VALU-bound: 81 us per 4096^2 Rgba(u8) frame.)
+// A launch covers a batch of equally shaped frames (the pipeline's box-blur step, batch.hip): frame f = blockIdx.z / zpf, its SAT planes
+// sat_frame elements and its pixels fr.src_frame / fr.dst_frame bytes after the previous frame's; zpf = gridDim.z slices per frame (1 below 65 536
+// workgroup rows).
 template <int PIX, bool SHARPEN, bool BUF>
-__global__ __launch_bounds__(256) void k_box_mean(const float *sat, size_t plane, DImg src, DImg dst, int radius) { // plane: elements from one channel's SAT to the next
+__global__ __launch_bounds__(256) void k_box_mean(const float *sat, size_t plane, DImg src, DImg dst, int radius, size_t sat_frame, FrameSpan fr, int zpf) { // plane: elements from one channel's SAT to the next
     using P = Px<PIX>;
+    const int frame = (int)blockIdx.z / zpf, zrow = (int)blockIdx.z - frame * zpf;
+    sat += (size_t)frame * sat_frame;
+    src.data = (char *)src.data + (size_t)frame * fr.src_frame;
+    dst.data = (char *)dst.data + (size_t)frame * fr.dst_frame;
+    const int grow = zrow * (int)GRID_Y_MAX + (int)blockIdx.y; // grid_row() of this frame
     using Vec = typename P::Vec;
     constexpr int C = P::C;
     constexpr bool IS_F = std::is_same<typename P::Elem, float>::value;
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(256) void k_box_mean(const float *sat, size_t plane
     // Several planes: 256 columns of one row; their tiles no longer fit (64 x 16: 108 us, 64 x 4: 96 us, 256 x 1: 77 us for Rgba(u8)).
     constexpr int STEPS = C == 1 ? 4 : 1;
     const int c = C == 1 ? blockIdx.x * 64 + (int)(threadIdx.x & 63) : blockIdx.x * 256 + (int)threadIdx.x;
-    const int wrow = C == 1 ? grid_row() * 16 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : grid_row();
+    const int wrow = C == 1 ? grow * 16 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : grow;
     if (c >= dst.cols) return;
     const int rows = dst.rows, cols = dst.cols;
     const int c1 = max(c - radius, 0), c2 = (int)min((long long)c + radius, (long long)cols - 1);
@@ -328,9 +337,10 @@ __device__ __forceinline__ void strip_carries_body(const DImg &src, float *carri
     }
 }
 template <int PIX, int LOG2G = 4>
-__global__ __launch_bounds__(256) void k_strip_carries(DImg src, float *carries, int nstrips) {
+__global__ __launch_bounds__(256) void k_strip_carries(DImg src, float *carries, int nstrips, size_t src_frame) { // blockIdx.y: the frame of a batch
     __shared__ uint32_t wsum[2][4][Px<PIX>::C];
-    strip_carries_body<PIX, LOG2G>(src, carries, nstrips, wsum);
+    src.data = (char *)src.data + (size_t)blockIdx.y * src_frame;
+    strip_carries_body<PIX, LOG2G>(src, carries + (size_t)blockIdx.y * src.rows * nstrips * Px<PIX>::C, nstrips, wsum);
 }
 
 // A workgroup owns four adjacent 16-column strips of ONE channel for the whole height (64 columns: 256 contiguous bytes of SAT
@@ -555,9 +565,10 @@ __device__ __forceinline__ void sat_chain_body(const DImg &src, const float *car
     sat_loader<PIX, false>(src, carries, nstrips, ch, ring, role, lane, nblocks);
 }
 template <int PIX>
-__global__ __launch_bounds__(SAT_THREADS) void k_sat_chain(DImg src, const float *carries, float *sat, size_t pstride, int nstrips) {
+__global__ __launch_bounds__(SAT_THREADS) void k_sat_chain(DImg src, const float *carries, float *sat, size_t pstride, int nstrips, size_t src_frame, size_t sat_frame) {
     __shared__ float ring[2][SAT_SB][64], oring[2][SAT_SB][64];
-    sat_chain_body<PIX>(src, carries, sat, pstride, nstrips, (int)blockIdx.y, ring, oring);
+    src.data = (char *)src.data + (size_t)blockIdx.z * src_frame; // blockIdx.z: the frame of a batch
+    sat_chain_body<PIX>(src, carries + (size_t)blockIdx.z * src.rows * nstrips * Px<PIX>::C, sat + (size_t)blockIdx.z * sat_frame, pstride, nstrips, (int)blockIdx.y, ring, oring);
 }
 
 // Several single-channel planes of one size in one launch (blockIdx.y picks the plane): a lone plane gives the chain kernel only
@@ -596,20 +607,31 @@ static bool sat_fused_applies(const zg_image *src, bool integer_valued) {
 // k_box_mean's corner reads) queue up there. Scratch planes are spread by 4352 bytes per channel instead.
 static size_t sat_plane_stride(const zg_image *src, bool padded) { return (size_t)src->rows * src->cols + (padded ? 1088 : 0); }
 
-int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer_valued, size_t pstride) {
+// n_frames equally shaped frames src_frame bytes apart (their SATs sat_frame elements apart) in one launch pair where the fused kernels apply;
+// the unfused kernels (f32 sources) go frame by frame.
+static int sat_planes_frames_impl(const zg_image *src, float *sat, hipStream_t s, bool integer_valued, size_t pstride, uint32_t n_frames, size_t src_frame, size_t sat_frame) {
     const int C = pixel_channels(src->pixel);
     if (pstride == 0) pstride = (size_t)src->rows * src->cols;
+    if (n_frames > 1 && !sat_fused_applies(src, integer_valued)) {
+        for (uint32_t f = 0; f < n_frames; ++f) {
+            zg_image one = *src;
+            one.data = (char *)src->data + (size_t)f * src_frame;
+            if (int rc = sat_planes_frames_impl(&one, sat + (size_t)f * sat_frame, s, integer_valued, pstride, 1, 0, 0)) return rc;
+        }
+        return ZG_OK;
+    }
     const bool exact_rows = (integer_valued || !pixel_is_float(src->pixel)) && src->cols <= 65536; // 65536 * 255 < 2^24
     // exact rows: carries of the 16-column strips (a small table), then prefix + chain + store in one pass over the source
     if (sat_fused_applies(src, integer_valued)) {
         const int nstrips = (int)ceil_div(src->cols, 16u);
         float *carries = nullptr;
-        if (int rc = scratch_alloc((void **)&carries, (size_t)src->rows * nstrips * C * sizeof(float), s)) return rc;
+        if (int rc = scratch_alloc((void **)&carries, (size_t)n_frames * src->rows * nstrips * C * sizeof(float), s)) return rc;
         const int rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
             constexpr int PIX = decltype(tag)::value;
             constexpr int PC = Px<PIX>::C;
-            hipLaunchKernelGGL((k_strip_carries<PIX>), dim3(src->rows), dim3(256), 0, s, dimg(src), carries, nstrips);
-            hipLaunchKernelGGL((k_sat_chain<PIX>), dim3(ceil_div((unsigned)nstrips, 4u), (unsigned)PC), dim3(SAT_THREADS), 0, s, dimg(src), (const float *)carries, sat, pstride, nstrips);
+            hipLaunchKernelGGL((k_strip_carries<PIX>), dim3(src->rows, n_frames), dim3(256), 0, s, dimg(src), carries, nstrips, src_frame);
+            hipLaunchKernelGGL((k_sat_chain<PIX>), dim3(ceil_div((unsigned)nstrips, 4u), (unsigned)PC, n_frames), dim3(SAT_THREADS), 0, s, dimg(src), (const float *)carries, sat, pstride,
+                               nstrips, src_frame, sat_frame);
             ZG_HIP(hipGetLastError());
             return ZG_OK;
         });
@@ -624,6 +646,10 @@ int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     });
+}
+
+int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer_valued, size_t pstride) {
+    return sat_planes_frames_impl(src, sat, s, integer_valued, pstride, 1, 0, 0);
 }
 
 // Integral images of up to three single-channel planes (u8 or integer-valued f32) of one size, one launch pair for all of them.
@@ -655,33 +681,63 @@ int sat_planes_multi(const zg_image *const *srcs, float *const *sats, int count,
 }
 
 
-static int box_blur_impl(const zg_image *src, const zg_image *dst, uint32_t radius, bool sharpen, hipStream_t s) {
+// n equally shaped frames, src_frame / dst_frame bytes apart (n = 1: one image). Batches of frames go through the three kernels in groups whose SATs fit
+// a scratch block; one-plane images taller than 65 535 x 16 rows, and f32 sources, whose SAT kernels are per image, go frame by frame.
+static int box_blur_frames_impl(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, uint32_t radius, bool sharpen, hipStream_t s) {
     int rc;
     if ((rc = check_image(src, "src")) || (rc = check_image(dst, "dst"))) return rc;
     ZG_REQUIRE(src->rows == dst->rows && src->cols == dst->cols, ZG_ERR_DIMENSION_MISMATCH, "%s: %ux%u vs %ux%u", sharpen ? "sharpen" : "boxBlur",
                src->rows, src->cols, dst->rows, dst->cols);
     ZG_REQUIRE(src->pixel == dst->pixel, ZG_ERR_INVALID_ARGUMENT, "boxBlur / sharpen: pixel types differ");
-    if (radius == 0) return copy_impl(src, dst, s); // image.zig:639-642
-    if (src->rows == 0 || src->cols == 0) return ZG_OK;
+    auto frame_of = [](const zg_image *im, size_t step, uint32_t f) { zg_image one = *im; one.data = (char *)im->data + (size_t)f * step; return one; };
+    if (radius == 0) { // image.zig:639-642
+        for (uint32_t f = 0; f < n; ++f) {
+            const zg_image a = frame_of(src, src_frame, f), b = frame_of(dst, dst_frame, f);
+            if ((rc = copy_impl(&a, &b, s))) return rc;
+        }
+        return ZG_OK;
+    }
+    if (src->rows == 0 || src->cols == 0 || n == 0) return ZG_OK;
     ZG_REQUIRE(radius < (1u << 30), ZG_ERR_INVALID_ARGUMENT, "boxBlur: radius too large");
     const int C = pixel_channels(src->pixel);
-    float *sat = nullptr;
     const size_t plane = sat_plane_stride(src, sat_fused_applies(src, false));
-    if ((rc = scratch_alloc((void **)&sat, (size_t)C * plane * sizeof(float), s))) return rc;
-    if ((rc = sat_planes_impl(src, sat, s, false, plane)) == ZG_OK)
+    const size_t sat_frame = (size_t)C * plane; // elements
+    const bool buf = sat_frame * sizeof(float) < (1ull << 32);
+    const unsigned grid_rows = C == 1 ? ceil_div(dst->rows, 16) : dst->rows;
+    const unsigned zpf = ceil_div(grid_rows, GRID_Y_MAX);
+    // frames per group: their SATs in one scratch block; gridDim.z <= 65 535
+    uint32_t group = (uint32_t)std::max<size_t>(1, std::min<size_t>(n, scratch_block_budget() / (sat_frame * sizeof(float))));
+    group = std::min<uint32_t>(group, 65535u / zpf);
+    if (!sat_fused_applies(src, false)) group = 1;
+    float *sat = nullptr;
+    if ((rc = scratch_alloc((void **)&sat, (size_t)group * sat_frame * sizeof(float), s))) return rc;
+    for (uint32_t f0 = 0; f0 < n && rc == ZG_OK; f0 += group) {
+        const uint32_t k = std::min(group, n - f0);
+        const zg_image a = frame_of(src, src_frame, f0), b = frame_of(dst, dst_frame, f0);
+        if ((rc = sat_planes_frames_impl(&a, sat, s, false, plane, k, src_frame, sat_frame)) != ZG_OK) break;
         rc = dispatch_pixel(src->pixel, [&](auto tag) -> int {
             constexpr int PIX = decltype(tag)::value;
-            const dim3 grid = C == 1 ? row_grid(ceil_div(dst->cols, 64), ceil_div(dst->rows, 16)) : row_grid(ceil_div(dst->cols, 256), dst->rows);
-            const bool buf = (size_t)C * plane * sizeof(float) < (1ull << 32);
-            if (buf && sharpen) hipLaunchKernelGGL((k_box_mean<PIX, true, true>), grid, dim3(256), 0, s, (const float *)sat, plane, dimg(src), dimg(dst), (int)radius);
-            else if (buf) hipLaunchKernelGGL((k_box_mean<PIX, false, true>), grid, dim3(256), 0, s, (const float *)sat, plane, dimg(src), dimg(dst), (int)radius);
-            else if (sharpen) hipLaunchKernelGGL((k_box_mean<PIX, true, false>), grid, dim3(256), 0, s, (const float *)sat, plane, dimg(src), dimg(dst), (int)radius);
-            else hipLaunchKernelGGL((k_box_mean<PIX, false, false>), grid, dim3(256), 0, s, (const float *)sat, plane, dimg(src), dimg(dst), (int)radius);
+            const dim3 grid(C == 1 ? ceil_div(dst->cols, 64) : ceil_div(dst->cols, 256), std::min(grid_rows, GRID_Y_MAX), zpf * k);
+            const FrameSpan fr{src_frame, dst_frame};
+            if (buf && sharpen) hipLaunchKernelGGL((k_box_mean<PIX, true, true>), grid, dim3(256), 0, s, (const float *)sat, plane, dimg(&a), dimg(&b), (int)radius, sat_frame, fr, (int)zpf);
+            else if (buf) hipLaunchKernelGGL((k_box_mean<PIX, false, true>), grid, dim3(256), 0, s, (const float *)sat, plane, dimg(&a), dimg(&b), (int)radius, sat_frame, fr, (int)zpf);
+            else if (sharpen) hipLaunchKernelGGL((k_box_mean<PIX, true, false>), grid, dim3(256), 0, s, (const float *)sat, plane, dimg(&a), dimg(&b), (int)radius, sat_frame, fr, (int)zpf);
+            else hipLaunchKernelGGL((k_box_mean<PIX, false, false>), grid, dim3(256), 0, s, (const float *)sat, plane, dimg(&a), dimg(&b), (int)radius, sat_frame, fr, (int)zpf);
             ZG_HIP(hipGetLastError());
             return ZG_OK;
         });
+    }
     scratch_free(sat, s);
     return rc;
+}
+
+static int box_blur_impl(const zg_image *src, const zg_image *dst, uint32_t radius, bool sharpen, hipStream_t s) {
+    return box_blur_frames_impl(src, dst, 1, 0, 0, radius, sharpen, s);
+}
+
+// the pipeline's box-blur step over a batch (batch.hip)
+int box_blur_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, uint32_t radius, hipStream_t s) {
+    return box_blur_frames_impl(src, dst, n, src_frame, dst_frame, radius, false, s);
 }
 
 } // namespace zg

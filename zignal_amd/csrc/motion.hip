@@ -11,6 +11,8 @@
 // and every field accumulates its own sum in the same sample order: same bits. f32 arithmetic as written in the
 // reference (separate mul / add). Integer fields: @round, clamp to the type, @trunc.
 #include "zg_common.h"
+
+#include <algorithm>
 #include "zg_devmath.h"
 #include "zg_hostmath.h"
 
@@ -62,8 +64,11 @@ template <int PIX> struct MbAcc {
     }
 };
 
+// blockIdx.z: the frame of a batch (the pipeline's motion-blur step, batch.hip), fr.src_frame / fr.dst_frame bytes from one frame to the next
 template <int PIX>
-__global__ __launch_bounds__(256) void k_motion_linear(DImg src, DImg dst, float cos_a, float sin_a, float half_dist, uint32_t loop_limit) {
+__global__ __launch_bounds__(256) void k_motion_linear(DImg src, DImg dst, float cos_a, float sin_a, float half_dist, uint32_t loop_limit, FrameSpan fr) {
+    src.data = (char *)src.data + (size_t)blockIdx.z * fr.src_frame;
+    dst.data = (char *)dst.data + (size_t)blockIdx.z * fr.dst_frame;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (c >= src.cols || r >= src.rows) return;
     MbAcc<PIX> acc;
@@ -79,7 +84,9 @@ __global__ __launch_bounds__(256) void k_motion_linear(DImg src, DImg dst, float
 }
 
 template <int PIX, bool SPIN>
-__global__ __launch_bounds__(256) void k_motion_radial(DImg src, DImg dst, float cx, float cy, float strength, int num_samples) {
+__global__ __launch_bounds__(256) void k_motion_radial(DImg src, DImg dst, float cx, float cy, float strength, int num_samples, FrameSpan fr) {
+    src.data = (char *)src.data + (size_t)blockIdx.z * fr.src_frame;
+    dst.data = (char *)dst.data + (size_t)blockIdx.z * fr.dst_frame;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (c >= src.cols || r >= src.rows) return;
     const float dx = (float)c - cx, dy = (float)r - cy;
@@ -120,47 +127,90 @@ static int motion_check(const zg_image *src, const zg_image *dst, const char *wh
     return ZG_OK;
 }
 
-static int motion_linear_impl(const zg_image *src, const zg_image *dst, float angle, float cos_a, float sin_a, uint32_t distance, zg_stream stream) {
-    (void)angle;
+// n equally shaped frames src_frame / dst_frame bytes apart (n = 1: one image). The gather kernels take the batch in gridDim.z (up to 65 535 frames
+// per launch); the axis-aligned linear case is the separable convolution, frame by frame.
+static int motion_linear_frames_impl(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, float cos_a, float sin_a, uint32_t distance,
+                                     zg_stream stream) {
     hipStream_t s = as_stream(stream);
     int rc;
     if ((rc = motion_check(src, dst, "motionBlur.linear"))) return rc;
-    if (distance == 0) return copy_impl(src, dst, s);
-    if (src->rows == 0 || src->cols == 0) return ZG_OK;
-    if (std::fabs(sin_a) < 0.001f || std::fabs(cos_a) < 0.001f) { // motion_blur.zig:77-118
-        ZG_REQUIRE(distance <= (1u << 22), ZG_ERR_INVALID_ARGUMENT, "motionBlur.linear: distance %u is out of range", distance); // any length the separable convolution takes
-        std::vector<float> k(distance, 1.0f / (float)distance);
+    auto frame_of = [](const zg_image *im, size_t step, uint32_t f) { zg_image one = *im; one.data = (char *)im->data + (size_t)f * step; return one; };
+    const bool axis = std::fabs(sin_a) < 0.001f || std::fabs(cos_a) < 0.001f; // motion_blur.zig:77-118
+    if (distance != 0 && axis) ZG_REQUIRE(distance <= (1u << 22), ZG_ERR_INVALID_ARGUMENT, "motionBlur.linear: distance %u is out of range", distance); // any length the separable convolution takes
+    if (distance == 0 || axis) {
+        std::vector<float> k(distance, distance ? 1.0f / (float)distance : 0.0f);
         const float identity = 1.0f;
-        return std::fabs(sin_a) < 0.001f ? zg_conv_separable(src, dst, k.data(), distance, &identity, 1, ZG_BORDER_REPLICATE, stream)
-                                         : zg_conv_separable(src, dst, &identity, 1, k.data(), distance, ZG_BORDER_REPLICATE, stream);
+        for (uint32_t f = 0; f < n; ++f) {
+            const zg_image a = frame_of(src, src_frame, f), b = frame_of(dst, dst_frame, f);
+            if (distance == 0) rc = copy_impl(&a, &b, s);
+            else if (src->rows == 0 || src->cols == 0) rc = ZG_OK;
+            else rc = std::fabs(sin_a) < 0.001f ? zg_conv_separable(&a, &b, k.data(), distance, &identity, 1, ZG_BORDER_REPLICATE, stream)
+                                               : zg_conv_separable(&a, &b, &identity, 1, k.data(), distance, ZG_BORDER_REPLICATE, stream);
+            if (rc) return rc;
+        }
+        return ZG_OK;
     }
-    const dim3 grid(ceil_div(src->cols, 64), ceil_div(src->rows, 4));
+    if (src->rows == 0 || src->cols == 0 || n == 0) return ZG_OK;
+    const FrameSpan fr{src_frame, dst_frame};
     return dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
-        hipLaunchKernelGGL((k_motion_linear<PIX>), grid, dim3(256), 0, s, dimg(src), dimg(dst), cos_a, sin_a, (float)distance / 2.0f, distance + 2);
+        for (uint32_t f0 = 0; f0 < n; f0 += 65535u) {
+            const zg_image a = frame_of(src, src_frame, f0), b = frame_of(dst, dst_frame, f0);
+            const dim3 grid(ceil_div(src->cols, 64), ceil_div(src->rows, 4), std::min(n - f0, 65535u));
+            hipLaunchKernelGGL((k_motion_linear<PIX>), grid, dim3(256), 0, s, dimg(&a), dimg(&b), cos_a, sin_a, (float)distance / 2.0f, distance + 2, fr);
+        }
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     });
 }
 
-static int motion_radial_impl(const zg_image *src, const zg_image *dst, float center_x, float center_y, float strength, int spin, zg_stream stream) {
+static int motion_radial_frames_impl(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, float center_x, float center_y, float strength,
+                                     int spin, zg_stream stream) {
     hipStream_t s = as_stream(stream);
     int rc;
     if ((rc = motion_check(src, dst, "motionBlur.radial"))) return rc;
     ZG_REQUIRE(spin == 0 || spin == 1, ZG_ERR_INVALID_ARGUMENT, "motionBlur.radial: type %d (0 zoom, 1 spin)", spin);
-    if (strength == 0) return copy_impl(src, dst, s);
-    if (src->rows == 0 || src->cols == 0) return ZG_OK;
+    auto frame_of = [](const zg_image *im, size_t step, uint32_t f) { zg_image one = *im; one.data = (char *)im->data + (size_t)f * step; return one; };
+    if (strength == 0) {
+        for (uint32_t f = 0; f < n; ++f) {
+            const zg_image a = frame_of(src, src_frame, f), b = frame_of(dst, dst_frame, f);
+            if ((rc = copy_impl(&a, &b, s))) return rc;
+        }
+        return ZG_OK;
+    }
+    if (src->rows == 0 || src->cols == 0 || n == 0) return ZG_OK;
     const float cx = center_x * (float)(src->cols - 1), cy = center_y * (float)(src->rows - 1);
     const float clamped = std::fmax(0.0f, std::fmin(1.0f, strength));
     const int num_samples = 8 + (int)std::trunc(clamped * 24.0f);
-    const dim3 grid(ceil_div(src->cols, 64), ceil_div(src->rows, 4));
+    const FrameSpan fr{src_frame, dst_frame};
     return dispatch_pixel(src->pixel, [&](auto tag) -> int {
         constexpr int PIX = decltype(tag)::value;
-        if (spin) hipLaunchKernelGGL((k_motion_radial<PIX, true>), grid, dim3(256), 0, s, dimg(src), dimg(dst), cx, cy, clamped, num_samples);
-        else hipLaunchKernelGGL((k_motion_radial<PIX, false>), grid, dim3(256), 0, s, dimg(src), dimg(dst), cx, cy, clamped, num_samples);
+        for (uint32_t f0 = 0; f0 < n; f0 += 65535u) {
+            const zg_image a = frame_of(src, src_frame, f0), b = frame_of(dst, dst_frame, f0);
+            const dim3 grid(ceil_div(src->cols, 64), ceil_div(src->rows, 4), std::min(n - f0, 65535u));
+            if (spin) hipLaunchKernelGGL((k_motion_radial<PIX, true>), grid, dim3(256), 0, s, dimg(&a), dimg(&b), cx, cy, clamped, num_samples, fr);
+            else hipLaunchKernelGGL((k_motion_radial<PIX, false>), grid, dim3(256), 0, s, dimg(&a), dimg(&b), cx, cy, clamped, num_samples, fr);
+        }
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     });
+}
+
+static int motion_linear_impl(const zg_image *src, const zg_image *dst, float angle, float cos_a, float sin_a, uint32_t distance, zg_stream stream) {
+    (void)angle;
+    return motion_linear_frames_impl(src, dst, 1, 0, 0, cos_a, sin_a, distance, stream);
+}
+static int motion_radial_impl(const zg_image *src, const zg_image *dst, float center_x, float center_y, float strength, int spin, zg_stream stream) {
+    return motion_radial_frames_impl(src, dst, 1, 0, 0, center_x, center_y, strength, spin, stream);
+}
+
+// the pipeline's motion-blur step over a batch (batch.hip)
+int motion_linear_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, float cos_a, float sin_a, uint32_t distance, hipStream_t s) {
+    return motion_linear_frames_impl(src, dst, n, src_frame, dst_frame, cos_a, sin_a, distance, (zg_stream)s);
+}
+int motion_radial_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, float center_x, float center_y, float strength, int spin,
+                         hipStream_t s) {
+    return motion_radial_frames_impl(src, dst, n, src_frame, dst_frame, center_x, center_y, strength, spin, (zg_stream)s);
 }
 
 } // namespace zg

@@ -213,6 +213,11 @@ int resize_planes_frames(const zg_image *src, const zg_image *dst, const zg_meth
 int resize_frames(const zg_image *src, const zg_image *dst, const zg_method *method, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s);       // geom.hip
 int warp_frames(const zg_image *src, const zg_image *dst, int kind, const float *mat, const zg_method *method, uint32_t n, size_t src_frame, size_t dst_frame,
                 hipStream_t s);                                                                                                                        // geom.hip
+int box_blur_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, uint32_t radius, hipStream_t s);                   // box_blur.hip
+int motion_linear_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, float cos_a, float sin_a, uint32_t distance,
+                         hipStream_t s);                                                                                                                 // motion.hip
+int motion_radial_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, float center_x, float center_y, float strength,
+                         int spin, hipStream_t s);                                                                                                       // motion.hip
 int sobel_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s);                                        // edges.hip
 int resize_convert_rgba8_frames(const zg_image *src, const zg_image *dst, int dst_space, uint32_t n, size_t src_frame, size_t dst_frame, const float *srgb_lut,
                                 hipStream_t s);                                                                                                       // convert.hip
