@@ -461,25 +461,59 @@ __global__ __launch_bounds__(64 * WAVES) void k_resize_bilinear_rgba8_to_lab(DIm
     src.data = (char *)src.data + (size_t)blockIdx.y * fr.src_frame; // a batch of equally shaped frames in one launch (batch.hip)
     dst.data = (char *)dst.data + (size_t)blockIdx.y * fr.dst_frame;
     const int tyi = wg / tiles_x, txi = wg - tyi * tiles_x;
-    const int c = txi * 64 + (int)(threadIdx.x & 63);
+    const int c_raw = txi * 64 + (int)(threadIdx.x & 63);
     const int r = __builtin_amdgcn_readfirstlane(tyi * WAVES + (int)(threadIdx.x >> 6));
-    if (r >= dst.rows || c >= dst.cols) return;
+    if (r >= dst.rows) return; // wave-uniform
+    if constexpr (WAVES == 4) {
+        if (c_raw >= dst.cols) return;
+    }
+    // WAVES == 1 (round 5): the wave works as a whole. Its sRGB table comes into LDS with ONE 1 KiB load issued beside the tap loads (three
+    // table gathers from memory behind the taps were a second dependent round trip per wave), and its 768 bytes of results are turned
+    // through LDS into three coalesced 256-byte stores (three dword stores 12 bytes apart per lane were three partial sweeps of the same
+    // six lines). Lanes past the row's end compute a duplicate of its last pixel and store nothing. LDS operations of one wave execute in
+    // order; the fences keep the compiler from reordering them.
+    __shared__ float lds[WAVES == 1 ? 256 + 192 : 1];
+    const int lane = (int)(threadIdx.x & 63);
+    const int c = WAVES == 1 ? min(c_raw, dst.cols - 1) : c_raw;
+    typedef float f32x4s __attribute__((ext_vector_type(4)));
+    f32x4s lut4 = {0, 0, 0, 0};
+    if constexpr (WAVES == 1) lut4 = *(const f32x4s *)(srgb_lut + 4 * lane);
     int y0, y1, fy, x0, x1, fx;
     bilinear_taps(r, ratio_y, src.rows, y0, y1, fy);
     bilinear_taps(c, ratio_x, src.cols, x0, x1, fx);
     const uint32_t *row0 = (const uint32_t *)src.data + (size_t)y0 * src.stride, *row1 = (const uint32_t *)src.data + (size_t)y1 * src.stride;
     const int xp = min(x0, src.cols - 2);
     const u32x2 p0 = *(const u32x2 *)(row0 + xp), p1 = *(const u32x2 *)(row1 + xp);
+    if constexpr (WAVES == 1) {
+        *(f32x4s *)(lds + 4 * lane) = lut4;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     uint32_t tl = p0[0], tr = p0[1], bl = p1[0], br = p1[1];
     if (x1 != x0 + 1 || x0 > src.cols - 2) { tl = row0[x0]; tr = row0[x1]; bl = row1[x0]; br = row1[x1]; }
     const uint32_t px = bilinear_rgba8(tl, tr, bl, br, fx, fy);
-    const float lin[3] = {srgb_lut[px & 0xffu], srgb_lut[(px >> 8) & 0xffu], srgb_lut[(px >> 16) & 0xffu]};
+    const float *table = WAVES == 1 ? (const float *)lds : srgb_lut;
+    const float lin[3] = {table[px & 0xffu], table[(px >> 8) & 0xffu], table[(px >> 16) & 0xffu]};
     float X, Y, Z, o0, o1, o2;
     linear_rgb_to_xyz(lin, X, Y, Z);
     if constexpr (MODE == 0) { o0 = X; o1 = Y; o2 = Z; }
     else xyz_to_oklab<MODE == 2>(X, Y, Z, o0, o1, o2);
-    float *o = (float *)dst.data + ((size_t)r * dst.stride + (size_t)c) * 3;
-    o[0] = o0; o[1] = o1; o[2] = o2;
+    if constexpr (WAVES == 1) {
+        float *stage = lds + 256;
+        stage[3 * lane] = o0; stage[3 * lane + 1] = o1; stage[3 * lane + 2] = o2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int valid = 3 * min(64, dst.cols - txi * 64); // floats of this wave's row segment that exist
+        float *o = (float *)dst.data + ((size_t)r * dst.stride + (size_t)txi * 64) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (lane + 64 * k < valid) o[lane + 64 * k] = stage[lane + 64 * k];
+    } else {
+        float *o = (float *)dst.data + ((size_t)r * dst.stride + (size_t)c) * 3;
+        o[0] = o0; o[1] = o1; o[2] = o2;
+    }
 }
 
 // [resize(.bilinear), convert(Oklab | Xyz f32)] of n Rgba(u8) frames in one launch; -1 when the fused kernel does not apply.
