@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+XGMI_LINK_GBS = 153.0  # per xGMI link and direction (MI355X: 7 links per GPU; the task statement's and SURVEY 8e's figure)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 PREWARM_S = 0.5  # untimed clock-ramp phase before the --warmup steps (see main)
 ROWS = COLS = 4096
@@ -527,8 +528,17 @@ def scatter_gather_leg(zg, torch, sharding, rank, world, local_rank, frames_per_
             sec = clock(lambda: sharding.scatter_compute_gather(batch, n, (rows, cols, 4), (540, 960, 4), torch.uint8, dev, blur_resize, chunks=k,
                                                                 loopback=loop, gather_group=second, out=gathered))
             sent = (n - (0 if loop else frames_per_gpu)) * rows * cols * 4  # bytes that leave rank 0 (a quarter as many come back)
+            links = max(1, world - 1)
+            # SURVEY 8e's bound: every peer's shard on its own xGMI link in parallel (XGMI_LINK_GBS per link and direction), the results (a quarter of the
+            # bytes) coming back on the links' other direction at the same time: the scatter of one shard is the floor of the whole exchange
+            per_link_bytes = sent / links
+            bound_s = per_link_bytes / (XGMI_LINK_GBS * 1e9)
             out[label] = {"seconds": round(sec, 6), "Mpixels/s": round(px_all / sec / 1e6, 1), "GB/s_scattered": round(sent / sec / 1e9, 1),
-                          "GB/s_scattered_per_link": round(sent / max(1, world - 1) / sec / 1e9, 1), "links": max(1, world - 1)}
+                          "GB/s_scattered_per_link": round(per_link_bytes / sec / 1e9, 1), "links": links,
+                          "xgmi_bound": None if loop else {"per_link_GB/s": XGMI_LINK_GBS, "bytes_per_link": int(per_link_bytes), "seconds": round(bound_s, 6),
+                                                           "frac_of_bound": round(bound_s / sec, 4),
+                                                           "meaning": "time to move one peer's shard over its own link at the link's rate / the measured end-to-end time "
+                                                                      "(1.0 = transfer-bound with compute and the return trip fully hidden)"}}
         out["note"] = ("one rank: the shard loops back through the communicator (ncclSend / ncclRecv to itself), so this times RCCL's "
                        "device-local copy path, not xGMI" if world == 1 else
                        "rank 0 sends 8.3 MB per frame to the frame's owner and receives 2.1 MB back, each peer over its own xGMI link")

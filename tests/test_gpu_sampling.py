@@ -384,6 +384,27 @@ def test_box_blur_config1(oracle):
     s = np.pad(src.astype(np.int64), 1)
     sums = sum(s[1 + dy:257 + dy, 1 + dx:257 + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1))
     assert np.array_equal(want[1:-1, 1:-1], np.floor(sums[1:-1, 1:-1] / 9 + 0.5).astype(np.uint8))
+    # images of rows * cols * 255 < 2^24 take no integral image at all (k_box_direct: the window's integer sum, which is what the reference's then-exact
+    # f32 SAT yields): the largest such image all white, every radius the direct kernel takes, every u8 type, sharpen, a view as destination; one pixel
+    # more and the SAT kernels run — both against the oracle
+    white = np.full((256, 257), 255, np.uint8)
+    assert white.size * 255 < 1 << 24 <= 257 * 257 * 255
+    for radius in (1, 2, 3, 7):
+        assert_bits_equal(sync(dev(white).box_blur(radius)), oracle.box_blur(white, radius), f"direct, all white r={radius}")
+    big = np.full((257, 257), 255, np.uint8)
+    assert_bits_equal(sync(dev(big).box_blur(2)), oracle.box_blur(big, 2), "one pixel past the direct path")
+    for kind in ("u8", "rgb_u8", "rgba_u8"):
+        img = synth(oracle, kind, 57, 120, 136)
+        for radius in (1, 4, 7, 8):  # 8: past the direct kernel's windows
+            assert_bits_equal(sync(dev(img).box_blur(radius)), oracle.box_blur(img, radius), f"direct {kind} r={radius}")
+        assert_bits_equal(sync(dev(img).sharpen(2)), oracle.sharpen(img, 2), f"direct sharpen {kind}")
+    img = oracle.synth_u8(58, (90, 100, 4))
+    td = torch.full((100, 120, 4), 0x5A, dtype=torch.uint8, device="cuda")
+    dev(img).box_blur(2, out=zg.Image(td).view((10, 5, 110, 95)))
+    got = sync(zg.Image(td))
+    assert_bits_equal(got[5:95, 10:110], oracle.box_blur(img, 2), "direct into a view")
+    got[5:95, 10:110] = 0x5A
+    assert np.all(got == 0x5A)
     f = oracle.synth_f32(55, (300, 300)) * np.float32(1000)  # f32 SAT is inexact here: order must match
     assert_bits_equal(sync(dev(f).box_blur(4)), oracle.box_blur(f, 4), "f32 SAT order")
 

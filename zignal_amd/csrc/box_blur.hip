@@ -681,6 +681,49 @@ int sat_planes_multi(const zg_image *const *srcs, float *const *sats, int count,
 }
 
 
+// Small u8 images — rows * cols * 255 < 2^24, BASELINE configs[0] itself (256 x 256) — need no integral image at all: every SAT value is an
+// integer below 2^24, so the reference's f32 SAT is exact, ((a - b) - d) + e is the window's integer sum whatever the order, and the sum can be taken
+// straight from the pixels: one launch, the source read once through L1, no scratch (three launches and 2 x 4 B per element of SAT before). The
+// mean and the rounding are k_box_mean's. One thread per pixel; windows up to 15 x 15 (225 loads a pixel at most, on at most 65 793 pixels).
+template <int PIX, bool SHARPEN>
+__global__ __launch_bounds__(256) void k_box_direct(DImg src, DImg dst, int radius) {
+    using P = Px<PIX>;
+    using Vec = typename P::Vec;
+    constexpr int C = P::C;
+    const int c = blockIdx.x * 64 + (int)(threadIdx.x & 63), r = blockIdx.y * 4 + (int)(threadIdx.x >> 6);
+    if (c >= dst.cols || r >= dst.rows) return;
+    const int r1 = max(r - radius, 0), r2 = min(r + radius, dst.rows - 1), c1 = max(c - radius, 0), c2 = min(c + radius, dst.cols - 1);
+    uint32_t acc[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) acc[ch] = 0;
+    for (int y = r1; y <= r2; ++y)
+        for (int x = c1; x <= c2; ++x) {
+            const Vec v = P::load(src.data, (size_t)y * src.stride + (size_t)x);
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) acc[ch] += (uint32_t)v[ch];
+        }
+    const float area = (float)((r2 - r1 + 1) * (c2 - c1 + 1));
+    const float nd = -area, r0 = __builtin_amdgcn_rcpf(area);
+    const float r1f = __builtin_fmaf(__builtin_fmaf(nd, r0, 1.0f), r0, r0);
+    Vec o, orig = P::zero();
+    if constexpr (SHARPEN) orig = P::load(src.data, (size_t)r * src.stride + (size_t)c);
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) {
+        const float sum = (float)acc[ch]; // < 2^24: exact, and equal to the reference's ((a - b) - d) + e on its exact SAT
+        const float q0 = sum * r1f;
+        const float q1 = __builtin_fmaf(__builtin_fmaf(nd, q0, sum), r1f, q0);
+        float val = __builtin_fmaf(__builtin_fmaf(nd, q1, sum), r1f, q1); // sum / area, bit for bit (see k_box_mean)
+        if constexpr (SHARPEN) {
+            const float original = (float)orig[ch];
+            const float twice = 2 * original;
+            val = twice - val;
+        }
+        const float u = fminf(fmaxf(val, 0.0f), 255.0f), t = truncf(u);
+        o[ch] = (uint8_t)((int)t + ((u - t) >= 0.5f ? 1 : 0));
+    }
+    P::store(dst.data, (size_t)r * dst.stride + (size_t)c, o);
+}
+
 // n equally shaped frames, src_frame / dst_frame bytes apart (n = 1: one image). Batches of frames go through the three kernels in groups whose SATs fit
 // a scratch block; one-plane images taller than 65 535 x 16 rows, and f32 sources, whose SAT kernels are per image, go frame by frame.
 static int box_blur_frames_impl(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, uint32_t radius, bool sharpen, hipStream_t s) {
@@ -700,6 +743,23 @@ static int box_blur_frames_impl(const zg_image *src, const zg_image *dst, uint32
     if (src->rows == 0 || src->cols == 0 || n == 0) return ZG_OK;
     ZG_REQUIRE(radius < (1u << 30), ZG_ERR_INVALID_ARGUMENT, "boxBlur: radius too large");
     const int C = pixel_channels(src->pixel);
+    if (n == 1 && !pixel_is_float(src->pixel) && radius <= 7 && (uint64_t)src->rows * src->cols * 255u < (1u << 24)) {
+        // the in-place call (examples/src/face_alignment.zig:95) keeps the integral-image route: there every output is written after every input is read
+        const char *sb = (const char *)src->data, *se = sb + ((size_t)(src->rows - 1) * src->stride + src->cols) * pixel_size(src->pixel);
+        const char *db = (const char *)dst->data, *de = db + ((size_t)(dst->rows - 1) * dst->stride + dst->cols) * pixel_size(dst->pixel);
+        if (se <= db || de <= sb) {
+            const dim3 grid(ceil_div(dst->cols, 64), ceil_div(dst->rows, 4));
+            return dispatch_pixel(src->pixel, [&](auto tag) -> int {
+                constexpr int PIX = decltype(tag)::value;
+                if constexpr (!std::is_same<typename Px<PIX>::Elem, float>::value) {
+                    if (sharpen) hipLaunchKernelGGL((k_box_direct<PIX, true>), grid, dim3(256), 0, s, dimg(src), dimg(dst), (int)radius);
+                    else hipLaunchKernelGGL((k_box_direct<PIX, false>), grid, dim3(256), 0, s, dimg(src), dimg(dst), (int)radius);
+                    ZG_HIP(hipGetLastError());
+                }
+                return ZG_OK;
+            });
+        }
+    }
     const size_t plane = sat_plane_stride(src, sat_fused_applies(src, false));
     const size_t sat_frame = (size_t)C * plane; // elements
     const bool buf = sat_frame * sizeof(float) < (1ull << 32);

@@ -357,14 +357,28 @@ __global__ __launch_bounds__(64) void k_sep_stream(StreamArgs a, TapsU8<NK> kx, 
                     u32x2 o;
 #pragma unroll
                     for (int o2 = 0; o2 < 2; ++o2) {
-                        uint32_t c[4];
+                        if constexpr (CLAMP) {
+                            uint32_t c[4];
 #pragma unroll
-                        for (int ch = 0; ch < 4; ++ch) {
-                            if constexpr (CLAMP) c[ch] = (ve[8 * o2 + ch] + ve[8 * o2 + 4 + ch] + vo[8 * o2 + ch] + vo[8 * o2 + 4 + ch]) >> 2;
-                            else // the four values are the high words of their accumulators: additions with word selects, no shifts of their own
-                                c[ch] = (((ve[8 * o2 + ch] >> 16) + (ve[8 * o2 + 4 + ch] >> 16)) + ((vo[8 * o2 + ch] >> 16) + (vo[8 * o2 + 4 + ch] >> 16))) >> 2;
+                            for (int ch = 0; ch < 4; ++ch) c[ch] = (ve[8 * o2 + ch] + ve[8 * o2 + 4 + ch] + vo[8 * o2 + ch] + vo[8 * o2 + 4 + ch]) >> 2;
+                            o[o2] = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+                        } else {
+                            // The four values of a channel are the HIGH WORDS of their accumulators (acc < 2^24): a row's two pixels are one addition
+                            // with word selects on both operands (v_add_u32_sdwa, a plain-rate instruction; kept apart from the second addition — the
+                            // empty asm — or hipcc folds three shifts and a v_add3_u32 out of it: 10 cycles a channel against 6), the channels are
+                            // then paired (0, 2) and (1, 3) in 16-bit halves so that the divide by four and the byte packing each happen once per
+                            // pair instead of once per channel. 5.5 instructions a channel -> 3.4; config 5 is bound by exactly this arithmetic.
+                            uint32_t t[4];
+#pragma unroll
+                            for (int ch = 0; ch < 4; ++ch) {
+                                uint32_t se = (ve[8 * o2 + ch] >> 16) + (ve[8 * o2 + 4 + ch] >> 16);
+                                uint32_t so = (vo[8 * o2 + ch] >> 16) + (vo[8 * o2 + 4 + ch] >> 16);
+                                asm volatile("" : "+v"(se), "+v"(so));
+                                t[ch] = se + so; // <= 1020
+                            }
+                            const uint32_t p02 = ((t[0] | (t[2] << 16)) >> 2) & 0x00ff00ffu, p13 = ((t[1] | (t[3] << 16)) >> 2) & 0x00ff00ffu;
+                            o[o2] = p02 | (p13 << 8);
                         }
-                        o[o2] = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
                     }
                     store_row(o, gy >> 1);
                 }
