@@ -155,6 +155,9 @@ __global__ __launch_bounds__(256) void k_convert(DImg src, DImg dst, ConvertArgs
 // rows on the u8 side (the launcher checks; anything else stays on k_convert).
 typedef uint32_t lab4_u32x4 __attribute__((ext_vector_type(4)));
 typedef float lab4_f32x4 __attribute__((ext_vector_type(4)));
+#ifndef LAB4_NT
+#define LAB4_NT 1 // streaming stores for the three 1 KiB rows a wave writes (A/B: tools/build_variant.sh lab4_plain convert.hip -DLAB4_NT=0)
+#endif
 template <int SC, int MODE> // MODE 0: Xyz, 1: Oklab, 2: Oklab from a table whose entries are +0 or within [2^-60, 2^60] (xyz_to_oklab<true>), 3 / 4: Lab likewise
 __global__ __launch_bounds__(256) void k_u8_to_lab4(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint64_t src_pitch, uint64_t dst_pitch,
                                                     int rows, int cols, const float *__restrict__ lut_global) {
@@ -212,7 +215,10 @@ __global__ __launch_bounds__(256) void k_u8_to_lab4(const uint8_t *__restrict__ 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         lab4_f32x4 *wave_dp = (lab4_f32x4 *)(dp - (size_t)lane * 12);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) wave_dp[k * 64 + lane] = mine[k * 64 + lane];
+        for (int k = 0; k < 3; ++k) {
+            if (LAB4_NT) __builtin_nontemporal_store(mine[k * 64 + lane], &wave_dp[k * 64 + lane]); // written once, never read here: 12 of the 16 bytes a pixel moves
+            else wave_dp[k * 64 + lane] = mine[k * 64 + lane];
+        }
     } else if (n == 4) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) ((lab4_f32x4 *)dp)[k] = lab4_f32x4{out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]};
