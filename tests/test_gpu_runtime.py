@@ -116,10 +116,11 @@ ALTERNATIVE_FORMS = {
     # (profiles/r03_experiments.txt, r04_experiments.txt): NO_STREAM, STREAM_GREY, ROWS_INT, COLS_INT, NO_LAB4, NO_U8_PLANE_RESIZE, NO_WARP_STAGE, CONV2D_INT.
     # The forms themselves stay where ordinary inputs still reach them (shapes a fast kernel's preconditions exclude) and are tested there.
     # Round 5 dropped NO_CONV2D_STREAM, NO_SOBEL_STREAM (27 / 20 us against 75 / 55: r04_experiments.txt), the strip-height knobs and MFMA (the matrix-pipe
-    # Gaussian left the library: tools/exp/conv_sep_mfma.hip), and added this round's three.
+    # Gaussian left the library: tools/exp/conv_sep_mfma.hip), and added this round's four.
     "ZIGNAL_HIP_STREAM_NO_FOLD": "k_sep_stream's plain row pass and end-tap multiplies instead of the folded unit-end form (gaussianBlur(0.6)'s taps)",
     "ZIGNAL_HIP_NO_TILE_F32": "the LDS-tiled k_sep_f32x4 instead of the tile-per-wave k_sep_tile_f32 for Image(f32) planes",
     "ZIGNAL_HIP_RESIZE_FORM=0": "round 4's four-row workgroups in XCD-major order for every bilinear Rgba(u8) resize (reductions use one-wave workgroups in address order)",
+    "ZIGNAL_HIP_NO_PYRAMID_FUSE": "gaussianBlur into a blurred plane then resize for every level of an Image(u8) pyramid instead of the column pass fused with the bilinear taps",
     "ZIGNAL_HIP_ISEF_TRANSPOSE": "two transposes around k_isef_cols instead of the recursions along the rows",
     "ZIGNAL_HIP_ISEF_SERIAL": "the role-split k_isef (one chain per row / column from end to end) instead of the segmented k_isef_spec",
     "ZIGNAL_HIP_SC_THREE_SATS": "shenCastan's window count from the mask's integral image (three SATs, twelve corner loads) instead of k_sc_count",
@@ -179,6 +180,8 @@ plane = rng.integers(0, 256, (333, 1296)).astype(np.float32)
 for smooth in (0.95, 0.9, 0.7, 0.4):
     same(dev(plane).isef_smooth(smooth), o.isef_plane(plane, smooth), "isef %%g" %% smooth)
 same(dev(rgba).shen_castan(smooth=0.6, use_nms=True), o.shen_castan(rgba, smooth=0.6, use_nms=True), "shen-castan rgba")
+for got, want in zip(zg.ImagePyramid.build(dev(grey), 6, 1.2, 1.6).levels, o.pyramid(grey, 6, 1.2, 1.6)):
+    same(got, want, "pyramid level")
 for w in (3, 5, 11, 15):
     same(dev(grey).shen_castan(window_size=w, high_ratio=0.9), o.shen_castan(grey, window_size=w, high_ratio=0.9), "shen-castan window %%d" %% w)
 print("ok")

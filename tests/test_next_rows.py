@@ -137,6 +137,63 @@ def test_pyramid_parity(oracle, kind):
     assert zg.ImagePyramid.build(dev(np.zeros((32, 32), np.uint8)), 10, 2.0, 1.0).n_levels < 10  # pyramid.zig:236-252
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ((33, 256), (31, 272), (32, 256), (64, 1040), (95, 1024), (500, 2064), (1080, 1920), (20, 640)))
+def test_pyramid_u8_fused_levels(oracle, shape):
+    """Image(u8) levels come from k_rows_u8f + k_cols_bilinear_u8 (the column pass evaluated at the resize's taps, 31-row bands): band seams, the
+    anchored last band, planes shorter than a band, mirrored right / bottom taps, scale 1 (a blurred copy) and both band-loop forms (inside / edge)."""
+    src = oracle.synth_u8(90 + shape[0], shape)
+    for n, sf, sigma in ((4, 1.2, 1.6), (6, 1.5, 1.0), (3, 1.05, 0.8), (3, 2.0, 3.0), (3, 2.1, 2.91), (9, 1.2, 1.6)):
+        want = oracle.pyramid(src, n, sf, sigma)
+        pyr = zg.ImagePyramid.build(dev(src), n, sf, sigma)
+        torch.cuda.synchronize()
+        assert pyr.n_levels == len(want)
+        for i, (g, w) in enumerate(zip(pyr.levels, want)):
+            assert_bits_equal(g.to_numpy(), w, f"pyramid u8 {shape} ({n},{sf},{sigma}) level {i}")
+
+
+@pytest.mark.gpu
+def test_pyramid_u8_fused_levels_full_size_and_views(oracle):
+    src = oracle.synth_u8(93, (2048, 4096))
+    want = oracle.pyramid(src, 8, 1.2, 1.6)
+    pyr = zg.ImagePyramid.build_default(dev(src))
+    torch.cuda.synchronize()
+    for i, (g, w) in enumerate(zip(pyr.levels, want)):
+        assert_bits_equal(g.to_numpy(), w, f"default pyramid of 2048x4096 level {i}")
+    # a view whose pitch is not its width (stride 4096, 2048 columns) and one the fused path must refuse (unaligned start): same bits either way
+    for view in (src[100:900, 1024:3072], src[5:700, 3:1027]):
+        want = oracle.pyramid(np.ascontiguousarray(view), 4, 1.3, 1.2)
+        whole = dev(src)
+        r0, c0 = (100, 1024) if view.shape[1] == 2048 else (5, 3)
+        pyr = zg.ImagePyramid.build(whole.view((c0, r0, c0 + view.shape[1], r0 + view.shape[0])), 4, 1.3, 1.2)
+        torch.cuda.synchronize()
+        for i, (g, w) in enumerate(zip(pyr.levels, want)):
+            assert_bits_equal(g.to_numpy(), w, f"pyramid of a view level {i}")
+
+
+@pytest.mark.gpu
+def test_u8_blur_whose_rounded_taps_sum_to_257_clamps_like_divClampU8(oracle):
+    """sigma = 1.6 sqrt(1.2^8 - 1) (ORB's level 4): the taps round to a sum of 257, so a saturated neighbourhood reaches (257 * 65535 + 32768) >> 16 = 257
+    and divClampU8 clamps it. The f32 column pass holds those sums with its accumulators started 2^23 lower (conv_sep_bytes2.hip, WIDE)."""
+    sigma = 1.6 * float(np.sqrt(1.2 ** 8 - 1))
+    img = oracle.synth_u8(97, (200, 1024))
+    img[40:120, 100:700] = 255
+    img[150:, :] = 255
+    want = oracle.gaussian_blur(img, sigma)
+    assert want.max() == 255
+    got = dev(img).gaussian_blur(sigma)
+    torch.cuda.synchronize()
+    assert_bits_equal(got.to_numpy(), want, "blur with a tap sum of 257 on saturated pixels")
+    rgba = np.repeat(img[:, :256, None], 4, axis=2).copy()
+    got = dev(rgba).gaussian_blur(sigma)
+    torch.cuda.synchronize()
+    assert_bits_equal(got.to_numpy(), oracle.gaussian_blur(rgba, sigma), "rgba, same taps")
+    want = oracle.pyramid(img, 3, 2.1, 2.91)  # the fused level kernel with the same taps
+    for g, w in zip(zg.ImagePyramid.build(dev(img), 3, 2.1, 2.91).levels, want):
+        torch.cuda.synchronize()
+        assert_bits_equal(g.to_numpy(), w, "pyramid level with a tap sum of 257")
+
+
 # ---- Canny (image.zig:1047-1063 -> edges.zig:212-277) ---------------------------------------------------------------
 def test_canny_reference_known_answers_oracle(oracle):  # tests/filters.zig:1182-1300
     img = np.zeros((10, 10), np.uint8)

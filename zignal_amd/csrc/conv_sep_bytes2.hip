@@ -299,7 +299,13 @@ __global__ __launch_bounds__(256) void k_cols_u16(const uint32_t *temp, uint8_t 
 // per instruction where v_mad_u32_u16 does one at the same issue cost (tools/exp/valu_rate.hip) — and the temps are converted once
 // per streamed row. A lane owns TWO adjacent bytes (one packed temp dword) of 32 output rows: 64 accumulator registers instead of
 // 128, so four waves fit a SIMD where the integer form fits two, and a 4096-byte row gives 4 096 waves instead of 2 048.
-template <bool INSIDE>
+//
+// WIDE: tap sums of 257 (what rounding the taps to 1/256 can leave: ORB's pyramid level 4) take the sum to 2^24 + 98 047 at most, where
+// divClampU8 starts to clamp and f32 stops being exact. The accumulators then start 2^23 lower — every partial sum lies in
+// [-2^23, 2^23 + 98 047], all exact — the clamp is a v_min against 255.99.. (as an integer: 2^24 - 1 - 2^23) before the conversion, and
+// adding the 2^23 back is flipping the top bit of byte 2, the byte that is the result.
+constexpr float U8F_BIAS = 8388608.0f;
+template <bool INSIDE, bool WIDE>
 __device__ __forceinline__ void cols_strip_u8f(const uint32_t *temp, uint8_t *dst, size_t dst_pitch, int rows, int row_bytes,
                                                const TapsCols &taps, int nk, int half, int border, int tx, int ty) {
     const int xd = tx * 256 + (int)threadIdx.x; // this lane's packed temp dword of the row (2 bytes of output)
@@ -309,7 +315,7 @@ __device__ __forceinline__ void cols_strip_u8f(const uint32_t *temp, uint8_t *ds
     const size_t trow = (size_t)row_bytes / 2;
     float acc[B2_R][2];
 #pragma unroll
-    for (int o = 0; o < B2_R; ++o) acc[o][0] = acc[o][1] = 32768.0f; // divClampU8's rounding term
+    for (int o = 0; o < B2_R; ++o) acc[o][0] = acc[o][1] = WIDE ? 32768.0f - U8F_BIAS : 32768.0f; // divClampU8's rounding term
     const int nrows_in = B2_R + nk - 1;
     const uint32_t *tcol = temp + (size_t)xdc;
     const uint32_t *next_row = tcol + (size_t)(INSIDE ? y0 - half : 0) * trow;
@@ -359,12 +365,18 @@ __device__ __forceinline__ void cols_strip_u8f(const uint32_t *temp, uint8_t *ds
     for (int o = 0; o < B2_R; ++o) {
         const int y = y0 + o;
         if (y >= rows) break;
-        // acc < 2^24: the value is byte 2 of the (exact) integer
-        const uint32_t out = __builtin_amdgcn_perm((uint32_t)acc[o][1], (uint32_t)acc[o][0], 0x0c0c0602u);
+        uint32_t out;
+        if constexpr (WIDE) {
+            const int v0 = (int)fminf(acc[o][0], 16777215.0f - U8F_BIAS), v1 = (int)fminf(acc[o][1], 16777215.0f - U8F_BIAS);
+            out = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x0c0c0602u) ^ 0x8080u;
+        } else { // acc < 2^24: the value is byte 2 of the (exact) integer
+            out = __builtin_amdgcn_perm((uint32_t)acc[o][1], (uint32_t)acc[o][0], 0x0c0c0602u);
+        }
         *(uint16_t *)(dst + (size_t)y * dst_pitch + 2 * (size_t)xd) = (uint16_t)out;
     }
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_cols_u8f(const uint32_t *temp, uint8_t *dst, size_t dst_pitch, int rows, int row_bytes,
                                                   TapsCols taps, int nk, int half, int border, int tiles_x, B2Frames fr) {
     temp += (size_t)blockIdx.y * fr.temp_frame;
@@ -372,9 +384,205 @@ __global__ __launch_bounds__(256) void k_cols_u8f(const uint32_t *temp, uint8_t 
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int y0 = ty * B2_R;
     if (y0 - half >= 0 && y0 - half + B2_R + nk - 1 <= rows) // workgroup-uniform: every streamed row is inside the image
-        cols_strip_u8f<true>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
+        cols_strip_u8f<true, WIDE>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
     else
-        cols_strip_u8f<false>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
+        cols_strip_u8f<false, WIDE>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
+}
+
+// ---- one pyramid level: gaussianBlur then resize(.bilinear) of an Image(u8), the column pass fused with the resize (round 5) -------------------------
+// ImagePyramid.build blurs the WHOLE source for every level and then samples a shrinking part of it (reference src/image/pyramid.zig:76-92): the bilinear
+// resize of level i reads two blurred rows and two blurred columns per output row / column — 4 / scale^2 of the blurred pixels (31 % at level 7), and the
+// blurred plane itself is only ever an intermediate. So the row pass runs as it is (k_rows_u8f: u8 -> u16 temp), and the column pass is evaluated where the
+// resize looks: a lane owns the two source COLUMNS its output column taps (adjacent: one unaligned 4-byte gather per streamed temp row), keeps 32 consecutive
+// blurred rows of them as f32 accumulators exactly as cols_strip_u8f does (the reference's integer sums, exact in f32 below 2^24), leaves the 32 x 2 bytes in
+// its own LDS column and interpolates every output row whose two source rows lie in the band — Image(u8).resize's expressions (interpolation.zig:313-407 via
+// k_resize_bilinear_u8: fx = round(frac * 256), (top (256 - fy) + bottom fy + 32768) >> 16, mirror-resolved neighbours). No blurred plane, no resize launch,
+// 2 / scale of the column pass's arithmetic. Bands of 32 source rows advance by 31 so that both rows of every output row share a band (the last band is
+// anchored at the bottom). Integer arithmetic throughout, so evaluating the passes where they are needed changes no bit.
+struct PyrLevelArgs {
+    const uint16_t *temp; // k_rows_u8f's plane: u16 per source byte, rows x cols (+ slack rows)
+    uint8_t *dst;
+    size_t dst_pitch;
+    int rows, cols, drows, dcols;
+    float rx, ry;         // (float)cols / dcols, (float)rows / drows: Image.resize's ratios
+    int nk, half, tiles_x, nbands;
+};
+
+template <bool INSIDE, bool WIDE>
+__device__ __forceinline__ void cols_bilinear_band(const PyrLevelArgs &a, const TapsCols &taps, uint16_t (*bt)[256], int tx, int band) {
+    constexpr int BAND = B2_R - 1;
+    const int tid = (int)threadIdx.x;
+    const int c = tx * 256 + tid;
+    const bool live = c < a.dcols;
+    const int cc = live ? c : a.dcols - 1;
+    const int y0 = band == a.nbands - 1 ? max(0, a.rows - B2_R) : band * BAND;
+    // the output column's taps (k_resize_bilinear_u8's expressions)
+    const float sx = ((float)cc + 0.5f) * a.rx - 0.5f;
+    const float fl = floorf(sx);
+    const int left = (int)fl;
+    int cl = left, cr = left + 1;
+    if (left < 0 || left + 1 >= a.cols) {
+        cl = resolve_index(left, a.cols, ZG_BORDER_MIRROR);
+        cr = resolve_index(left + 1, a.cols, ZG_BORDER_MIRROR);
+    }
+    const int fx = (int)roundf((sx - fl) * 256);
+    const int base = min(cl, cr); // the two columns are neighbours (a reduction of a plane at least two columns wide): one 4-byte gather
+    const bool swapped = cl > cr; // at the mirrored right edge the left tap is the higher column
+
+    float acc[B2_R][2];
+#pragma unroll
+    for (int o = 0; o < B2_R; ++o) acc[o][0] = acc[o][1] = WIDE ? 32768.0f - U8F_BIAS : 32768.0f; // divClampU8's rounding term (WIDE: cols_strip_u8f)
+    const int nrows_in = B2_R + a.nk - 1;
+    const size_t trow = (size_t)a.cols; // u16 per temp row
+    const uint16_t *tcol = a.temp + base;
+    const uint16_t *next_row = tcol + (size_t)(INSIDE ? y0 - a.half : 0) * trow;
+    auto fetch = [&](int r) -> uint32_t { // temp row y0 - half + r; called with r = 0, 1, 2, ... in order
+        uint32_t p;
+        if constexpr (INSIDE) { // rows past the band's last (prefetch overshoot) fall in the temp plane's slack rows
+            __builtin_memcpy(&p, next_row, 4);
+            next_row += trow;
+        } else {
+            const int gr = resolve_index(y0 - a.half + min(r, nrows_in - 1), a.rows, ZG_BORDER_MIRROR); // scalar; gaussianBlur's border rule
+            __builtin_memcpy(&p, tcol + (size_t)max(gr, 0) * trow, 4);
+        }
+        return p;
+    };
+    uint32_t cur[8], nxt[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cur[i] = fetch(i);
+    for (int r0 = 0; r0 < nrows_in; r0 += 8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) nxt[i] = fetch(r0 + 8 + i);
+        uint32_t kw[40]; // as in cols_strip: entry 32 + i - o is the tap blurred row o takes from temp row r0 + i
+#pragma unroll
+        for (int k = 0; k < 40; ++k) kw[k] = taps.k[r0 + k];
+#pragma unroll
+        for (int ib = 0; ib < 8; ib += 4) {
+#pragma unroll
+            for (int ob = 0; ob < B2_R; ob += 4) {
+                if (r0 + ib + 3 >= ob && r0 + ib - ob - 3 < a.nk) {
+#pragma unroll
+                    for (int i = ib; i < ib + 4; ++i) {
+                        const float t0 = (float)(cur[i] & 0xffffu), t1 = (float)(cur[i] >> 16);
+#pragma unroll
+                        for (int o = ob; o < ob + 4; ++o) {
+                            const float k = __uint_as_float(__builtin_amdgcn_readfirstlane(kw[32 + i - o]));
+                            acc[o][0] = __builtin_fmaf(t0, k, acc[o][0]);
+                            acc[o][1] = __builtin_fmaf(t1, k, acc[o][1]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+    }
+    // the band's blurred values of this lane's two columns: acc < 2^24 (the host checked), so the value is bits 16..23 of the exact integer
+#pragma unroll
+    for (int o = 0; o < B2_R; ++o) {
+        uint32_t lo, hi;
+        if constexpr (WIDE) {
+            lo = (((uint32_t)(int)fminf(acc[o][0], 16777215.0f - U8F_BIAS) >> 16) & 255u) ^ 0x80u;
+            hi = (((uint32_t)(int)fminf(acc[o][1], 16777215.0f - U8F_BIAS) >> 16) & 255u) ^ 0x80u;
+        } else {
+            lo = (uint32_t)acc[o][0] >> 16;
+            hi = (uint32_t)acc[o][1] >> 16;
+        }
+        bt[o][tid] = (uint16_t)(swapped ? hi | (lo << 8) : lo | (hi << 8)); // left tap | right tap << 8
+    }
+    // every output row whose two source rows lie in this band (a lane reads back only its own column: no barrier)
+    const int first_owned = band * BAND;
+    int r = (int)floorf(((float)first_owned + 0.5f) / a.ry - 0.5f) - 2;
+    r = __builtin_amdgcn_readfirstlane(max(r, 0));
+    for (; r < a.drows; ++r) { // wave-uniform
+        const float sy = ((float)r + 0.5f) * a.ry - 0.5f;
+        const float ft = floorf(sy);
+        const int top = (int)ft;
+        int r0 = top, r1 = top + 1;
+        if (top < 0 || top + 1 >= a.rows) {
+            r0 = resolve_index(top, a.rows, ZG_BORDER_MIRROR);
+            r1 = resolve_index(top + 1, a.rows, ZG_BORDER_MIRROR);
+        }
+        const int owner = min(min(r0, r1) / BAND, a.nbands - 1);
+        if (owner < band) continue;
+        if (owner > band) break;
+        const int fy = (int)roundf((sy - ft) * 256);
+        const uint32_t p0 = bt[r0 - y0][tid], p1 = bt[r1 - y0][tid];
+        const int tl = (int)(p0 & 255u), tr = (int)(p0 >> 8), bl = (int)(p1 & 255u), br = (int)(p1 >> 8);
+        const int top_val = tl * (256 - fx) + tr * fx;
+        const int bottom_val = bl * (256 - fx) + br * fx;
+        const uint32_t v = (uint32_t)((top_val * (256 - fy) + bottom_val * fy + 32768) >> 16); // < 256: a convex combination of bytes
+        if (live) a.dst[(size_t)r * a.dst_pitch + (size_t)c] = (uint8_t)v;
+    }
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_cols_bilinear_u8(PyrLevelArgs a, TapsCols taps) {
+    __shared__ uint16_t bt[B2_R][256];
+    const int band = blockIdx.x / a.tiles_x, tx = blockIdx.x - band * a.tiles_x;
+    const int y0 = band == a.nbands - 1 ? max(0, a.rows - B2_R) : band * (B2_R - 1);
+    if (y0 - a.half >= 0 && y0 - a.half + B2_R + a.nk - 1 <= a.rows) // workgroup-uniform: every streamed row is inside the plane
+        cols_bilinear_band<true, WIDE>(a, taps, bt, tx, band);
+    else
+        cols_bilinear_band<false, WIDE>(a, taps, bt, tx, band);
+}
+
+// gaussianBlur(taps, .mirror) then resize(.bilinear) of an Image(u8) into `level`, without the blurred plane. -1 when the preconditions do not hold
+// (the caller blurs and resizes): contiguous-enough u8 planes as k_rows_u8f wants them, a reduction, odd tap counts <= 65, the f32-exact case.
+int try_pyramid_level_u8(const zg_image *src, const zg_image *level, const int32_t *taps, int nk, hipStream_t s) {
+    if (src->pixel != ZG_PIXEL_U8 || level->pixel != ZG_PIXEL_U8 || nk < 1 || nk > B2_NKMAX || !(nk & 1)) return -1;
+    if (getenv("ZIGNAL_HIP_NO_PYRAMID_FUSE")) return -1; // A/B hook of round 5
+    // A lane here owns the two columns of ONE output column, the dense column pass the two columns of a dword: 2 / scale of its arithmetic. Below
+    // a reduction of `min_scale` the dense pass and the separate resize are cheaper (measured: profiles/r05_experiments.txt).
+    static const float min_scale = getenv("ZIGNAL_HIP_PYRAMID_FUSE_FROM") ? (float)atof(getenv("ZIGNAL_HIP_PYRAMID_FUSE_FROM")) : 2.0f;
+    if ((float)src->cols < min_scale * (float)level->cols) return -1;
+    if (src->cols % 16 || src->stride % 16 || ((uintptr_t)src->data & 15) || src->cols < 256 || (uint64_t)src->cols > 0x3fffffffu) return -1;
+    if (level->rows == 0 || level->cols == 0 || level->rows > src->rows || level->cols > src->cols || src->rows < 2) return -1;
+    if ((uint64_t)(src->rows + 16) * src->cols * 2 > 0x7fffffffull) return -1;
+    int64_t sum = 0;
+    for (int i = 0; i < nk; ++i) { if (taps[i] < 0 || taps[i] > 255) return -1; sum += taps[i]; }
+    if (sum > 257) return -1; // temp fits u16
+    const bool wide = sum * sum * 255 + 32768 >= 256 * 65536; // a tap sum of 257: the biased accumulators of cols_strip_u8f<., true>
+
+    const int row_bytes = (int)src->cols, half = nk / 2;
+    const size_t temp_bytes = ((size_t)src->rows + 16) * row_bytes * 2; // + 16 slack rows: the column pass prefetches past a band's last row
+    uint32_t *temp = nullptr;
+    if (int rc = scratch_alloc((void **)&temp, temp_bytes, s)) return rc;
+    const int tiles_x = (int)ceil_div((uint32_t)row_bytes, 1024u);
+    const int rows_per_wave = 4;
+    const B2Frames fr{0, 0, 0};
+    const dim3 grid_rows((unsigned)(tiles_x * ceil_div(src->rows, 4u * rows_per_wave)), 1);
+    switch ((half + 3) / 4) {
+    case 0: case 1: launch_rows_u8f<4>(src, temp, taps, nk, ZG_BORDER_MIRROR, tiles_x, rows_per_wave, grid_rows, fr, s); break;
+    case 2: launch_rows_u8f<8>(src, temp, taps, nk, ZG_BORDER_MIRROR, tiles_x, rows_per_wave, grid_rows, fr, s); break;
+    case 3: launch_rows_u8f<12>(src, temp, taps, nk, ZG_BORDER_MIRROR, tiles_x, rows_per_wave, grid_rows, fr, s); break;
+    case 4: launch_rows_u8f<16>(src, temp, taps, nk, ZG_BORDER_MIRROR, tiles_x, rows_per_wave, grid_rows, fr, s); break;
+    case 5: launch_rows_u8f<20>(src, temp, taps, nk, ZG_BORDER_MIRROR, tiles_x, rows_per_wave, grid_rows, fr, s); break;
+    case 6: launch_rows_u8f<24>(src, temp, taps, nk, ZG_BORDER_MIRROR, tiles_x, rows_per_wave, grid_rows, fr, s); break;
+    case 7: launch_rows_u8f<28>(src, temp, taps, nk, ZG_BORDER_MIRROR, tiles_x, rows_per_wave, grid_rows, fr, s); break;
+    default: launch_rows_u8f<32>(src, temp, taps, nk, ZG_BORDER_MIRROR, tiles_x, rows_per_wave, grid_rows, fr, s); break;
+    }
+    TapsCols tc{};
+    for (int j = 0; j < nk; ++j) {
+        const float f = (float)taps[j];
+        memcpy(&tc.k[B2_R + j], &f, 4);
+    }
+    PyrLevelArgs a{};
+    a.temp = (const uint16_t *)temp;
+    a.dst = (uint8_t *)level->data;
+    a.dst_pitch = level->stride;
+    a.rows = (int)src->rows; a.cols = (int)src->cols; a.drows = (int)level->rows; a.dcols = (int)level->cols;
+    a.rx = (float)src->cols / (float)level->cols;
+    a.ry = (float)src->rows / (float)level->rows;
+    a.nk = nk; a.half = half;
+    a.tiles_x = (int)ceil_div(level->cols, 256u);
+    a.nbands = src->rows <= (uint32_t)B2_R ? 1 : (int)ceil_div(src->rows - 1, (uint32_t)(B2_R - 1));
+    if (wide) hipLaunchKernelGGL((k_cols_bilinear_u8<true>), dim3((unsigned)(a.tiles_x * a.nbands)), dim3(256), 0, s, a, tc);
+    else hipLaunchKernelGGL((k_cols_bilinear_u8<false>), dim3((unsigned)(a.tiles_x * a.nbands)), dim3(256), 0, s, a, tc);
+    const hipError_t e = hipGetLastError();
+    scratch_free(temp, s);
+    ZG_HIP(e);
+    return ZG_OK;
 }
 
 // Returns -1 when the preconditions do not hold (caller falls back to the general kernels).
@@ -395,7 +603,9 @@ int try_sep_bytes2_frames(const zg_image *src, const zg_image *dst, uint32_t n, 
     for (int i = 0; i < nkx; ++i) { if (ix[i] < 0 || ix[i] > 255) return -1; sx += ix[i]; }
     for (int i = 0; i < nky; ++i) { if (iy[i] < 0 || iy[i] > 255) return -1; sy += iy[i]; }
     if (sx > 257 || sy > 257) return -1; // temp must fit u16: 255 * 257 = 65535
-    const bool clamp = sx * sy * 255 + 32768 >= 256 * 65536; // only then can (acc >> 16) exceed 255
+    const bool over = sx * sy * 255 + 32768 >= 256 * 65536; // only then can (acc >> 16) exceed 255
+    const bool wide = over && sx * sy * 255 + 32768 - (int64_t)U8F_BIAS <= 16777216; // ... and the biased f32 form still holds every sum (always: sums <= 257)
+    const bool clamp = over && !wide; // the integer column pass
 
     // row pass taps: tap j reads offset j - nkx / 2; the padded window starts at offset -hpad
     const int halfx = nkx / 2, halfy = nky / 2;
@@ -447,7 +657,8 @@ int try_sep_bytes2_frames(const zg_image *src, const zg_image *dst, uint32_t n, 
         } else {
             const int tiles_x2 = (int)ceil_div((uint32_t)row_bytes, 512u);
             const dim3 grid2((unsigned)(tiles_x2 * ceil_div(src->rows, (uint32_t)B2_R)), nf);
-            hipLaunchKernelGGL(k_cols_u8f, grid2, dim3(256), 0, s, (const uint32_t *)temp, out, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x2, fr);
+            if (wide) hipLaunchKernelGGL((k_cols_u8f<true>), grid2, dim3(256), 0, s, (const uint32_t *)temp, out, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x2, fr);
+            else hipLaunchKernelGGL((k_cols_u8f<false>), grid2, dim3(256), 0, s, (const uint32_t *)temp, out, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x2, fr);
         }
     }
     const hipError_t e = hipGetLastError();

@@ -1421,6 +1421,20 @@ int zg_pyramid_build_level(const zg_image *source, const zg_image *level, float 
     const zg_method bilinear{ZG_INTERP_BILINEAR, 0.0f, 0.0f, nullptr};
     if (!(sigma > 0.5f) || source->rows == 0 || source->cols == 0) return zg_resize(source, level, &bilinear, stream);
     hipStream_t s = as_stream(stream);
+    if (source->pixel == ZG_PIXEL_U8 && sigma > 0) { // Image(u8), what ORB builds its pyramid on: the column pass evaluated where the resize looks (conv_sep_bytes2.hip)
+        const int n = zg_gaussian_kernel(sigma, nullptr, 0);
+        if (n > 0 && n <= 65) {
+            float taps[65];
+            int32_t itaps[65];
+            if (zg_gaussian_kernel(sigma, taps, 65) == n) {
+                for (int i = 0; i < n; ++i) itaps[i] = (int32_t)std::round(taps[i] * 256.0f); // scaleKernelToInt (convolution.zig:303-309)
+                int z = 0; // outer taps that rounded to zero add nothing to an integer sum (conv_separable.hip drops them the same way)
+                while (n - 2 * z > 2 && itaps[z] == 0 && itaps[n - 1 - z] == 0) ++z;
+                const int rcf = try_pyramid_level_u8(source, level, itaps + z, n - 2 * z, s);
+                if (rcf >= 0) return rcf;
+            }
+        }
+    }
     void *blurred = nullptr;
     if ((rc = scratch_alloc(&blurred, (size_t)source->rows * source->cols * pixel_size(source->pixel), s))) return rc;
     const zg_image tmp{blurred, source->cols, source->rows, source->cols, source->pixel};
