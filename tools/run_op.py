@@ -11,6 +11,10 @@ R = 4096
 if op == "blur_u8":
     s = zg.Image(torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")); d = zg.Image(torch.empty_like(s.data))
     f = lambda: s.gaussian_blur(0.6, out=d)
+elif op.startswith("greyblur_"):  # greyblur_2.25: gaussianBlur(sigma) of a 4096^2 Image(u8), the pyramid's long-tap two-pass path
+    s = zg.Image(torch.randint(0, 256, (R, R), dtype=torch.uint8, device="cuda")); d = zg.Image(torch.empty_like(s.data))
+    sg = float(op.split("_")[1])
+    f = lambda: s.gaussian_blur(sg, out=d)
 elif op == "blur_f32":
     s = zg.Image(torch.rand((R, R, 4), dtype=torch.float32, device="cuda")); d = zg.Image(torch.empty_like(s.data))
     f = lambda: s.gaussian_blur(0.6, out=d)

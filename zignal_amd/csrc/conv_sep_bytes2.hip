@@ -25,6 +25,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace zg {
 
@@ -305,18 +306,18 @@ __global__ __launch_bounds__(256) void k_cols_u16(const uint32_t *temp, uint8_t 
 // [-2^23, 2^23 + 98 047], all exact — the clamp is a v_min against 255.99.. (as an integer: 2^24 - 1 - 2^23) before the conversion, and
 // adding the 2^23 back is flipping the top bit of byte 2, the byte that is the result.
 constexpr float U8F_BIAS = 8388608.0f;
-template <bool INSIDE, bool WIDE>
+template <bool INSIDE, bool WIDE, int R>
 __device__ __forceinline__ void cols_strip_u8f(const uint32_t *temp, uint8_t *dst, size_t dst_pitch, int rows, int row_bytes,
                                                const TapsCols &taps, int nk, int half, int border, int tx, int ty) {
     const int xd = tx * 256 + (int)threadIdx.x; // this lane's packed temp dword of the row (2 bytes of output)
     const bool live = xd * 2 < row_bytes;
     const int xdc = live ? xd : 0;
-    const int y0 = ty * B2_R;
+    const int y0 = ty * R;
     const size_t trow = (size_t)row_bytes / 2;
-    float acc[B2_R][2];
+    float acc[R][2];
 #pragma unroll
-    for (int o = 0; o < B2_R; ++o) acc[o][0] = acc[o][1] = WIDE ? 32768.0f - U8F_BIAS : 32768.0f; // divClampU8's rounding term
-    const int nrows_in = B2_R + nk - 1;
+    for (int o = 0; o < R; ++o) acc[o][0] = acc[o][1] = WIDE ? 32768.0f - U8F_BIAS : 32768.0f; // divClampU8's rounding term
+    const int nrows_in = R + nk - 1;
     const uint32_t *tcol = temp + (size_t)xdc;
     const uint32_t *next_row = tcol + (size_t)(INSIDE ? y0 - half : 0) * trow;
     auto fetch = [&](int r) -> uint32_t { // temp row y0 - half + r; called with r = 0, 1, 2, ... in order
@@ -336,20 +337,20 @@ __device__ __forceinline__ void cols_strip_u8f(const uint32_t *temp, uint8_t *ds
     for (int r0 = 0; r0 < nrows_in; r0 += 8) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) nxt[i] = fetch(r0 + 8 + i);
-        uint32_t kw[40]; // as in cols_strip: entry 32 + i - o is the tap output row o takes from temp row r0 + i
+        uint32_t kw[R + 8]; // as in cols_strip: entry R + i - o is the tap output row o takes from temp row r0 + i
 #pragma unroll
-        for (int c = 0; c < 40; ++c) kw[c] = taps.k[r0 + c];
+        for (int c = 0; c < R + 8; ++c) kw[c] = taps.k[r0 + (B2_R - R) + c];
 #pragma unroll
         for (int ib = 0; ib < 8; ib += 4) {
 #pragma unroll
-            for (int ob = 0; ob < B2_R; ob += 4) {
+            for (int ob = 0; ob < R; ob += 4) {
                 if (r0 + ib + 3 >= ob && r0 + ib - ob - 3 < nk) {
 #pragma unroll
                     for (int i = ib; i < ib + 4; ++i) {
                         const float t0 = (float)(cur[i] & 0xffffu), t1 = (float)(cur[i] >> 16);
 #pragma unroll
                         for (int o = ob; o < ob + 4; ++o) {
-                            const float k = __uint_as_float(__builtin_amdgcn_readfirstlane(kw[32 + i - o]));
+                            const float k = __uint_as_float(__builtin_amdgcn_readfirstlane(kw[R + i - o]));
                             acc[o][0] = __builtin_fmaf(t0, k, acc[o][0]);
                             acc[o][1] = __builtin_fmaf(t1, k, acc[o][1]);
                         }
@@ -362,7 +363,7 @@ __device__ __forceinline__ void cols_strip_u8f(const uint32_t *temp, uint8_t *ds
     }
     if (!live) return;
 #pragma unroll
-    for (int o = 0; o < B2_R; ++o) {
+    for (int o = 0; o < R; ++o) {
         const int y = y0 + o;
         if (y >= rows) break;
         uint32_t out;
@@ -376,17 +377,93 @@ __device__ __forceinline__ void cols_strip_u8f(const uint32_t *temp, uint8_t *ds
     }
 }
 
-template <bool WIDE>
+template <bool WIDE, int R>
 __global__ __launch_bounds__(256) void k_cols_u8f(const uint32_t *temp, uint8_t *dst, size_t dst_pitch, int rows, int row_bytes,
                                                   TapsCols taps, int nk, int half, int border, int tiles_x, B2Frames fr) {
     temp += (size_t)blockIdx.y * fr.temp_frame;
     dst += (size_t)blockIdx.y * fr.dst_frame;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int y0 = ty * B2_R;
-    if (y0 - half >= 0 && y0 - half + B2_R + nk - 1 <= rows) // workgroup-uniform: every streamed row is inside the image
-        cols_strip_u8f<true, WIDE>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
+    const int y0 = ty * R;
+    if (y0 - half >= 0 && y0 - half + R + nk - 1 <= rows) // workgroup-uniform: every streamed row is inside the image
+        cols_strip_u8f<true, WIDE, R>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
     else
-        cols_strip_u8f<false, WIDE>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
+        cols_strip_u8f<false, WIDE, R>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
+}
+
+// The same column pass with the tap count a template parameter (rounded up to 4 m + 1, zero taps behind the kernel): k_cols_u8f spends two of
+// every five issue slots on scalar bookkeeping — "does this 4 x 4 block of (row, output) pairs meet a tap" sixteen times per eight rows, the tap
+// slice reloaded per chunk (PMC: 820 SALU against 1 220 VALU instructions per wave, and SALU shares the SIMD's issue slots: profiles/r05_experiments.txt).
+// With NK4 fixed every loop unrolls, the taps sit in SGPRs from the start and the bands inside the plane run the multiply-adds and nothing else.
+// Bands that touch the top or bottom rows take cols_strip_u8f's general form.
+template <int NK4, bool WIDE>
+__device__ __forceinline__ void cols_strip_u8f_static(const uint32_t *temp, uint8_t *dst, size_t dst_pitch, int row_bytes, const TapsCols &taps, int half,
+                                                      int tx, int ty) {
+    constexpr int R = B2_R, NR = R + NK4 - 1;
+    const int xd = tx * 256 + (int)threadIdx.x;
+    const bool live = xd * 2 < row_bytes;
+    const int xdc = live ? xd : 0;
+    const int y0 = ty * R;
+    const size_t trow = (size_t)row_bytes / 2;
+    float k[NK4];
+#pragma unroll
+    for (int j = 0; j < NK4; ++j) k[j] = __uint_as_float(taps.k[B2_R + j]); // kernel arguments: scalar loads, the taps live in SGPRs
+    float acc[R][2];
+#pragma unroll
+    for (int o = 0; o < R; ++o) acc[o][0] = acc[o][1] = WIDE ? 32768.0f - U8F_BIAS : 32768.0f;
+    const uint32_t *next_row = temp + (size_t)xdc + (size_t)(y0 - half) * trow;
+    uint32_t cur[8], nxt[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { cur[i] = *next_row; next_row += trow; }
+#pragma unroll
+    for (int r0 = 0; r0 < NR; r0 += 8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (r0 + 8 + i < NR) { nxt[i] = *next_row; next_row += trow; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = r0 + i; // temp row y0 - half + r meets output row o with tap r - o
+            if (r < NR) {
+                const float t0 = (float)(cur[i] & 0xffffu), t1 = (float)(cur[i] >> 16);
+#pragma unroll
+                for (int o = 0; o < R; ++o) {
+                    if (r - o >= 0 && r - o < NK4) {
+                        acc[o][0] = __builtin_fmaf(t0, k[r - o], acc[o][0]);
+                        acc[o][1] = __builtin_fmaf(t1, k[r - o], acc[o][1]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+    }
+    if (!live) return;
+    uint8_t *out_row = dst + (size_t)y0 * dst_pitch + 2 * (size_t)xd;
+#pragma unroll
+    for (int o = 0; o < R; ++o) {
+        uint32_t out;
+        if constexpr (WIDE) {
+            const int v0 = (int)fminf(acc[o][0], 16777215.0f - U8F_BIAS), v1 = (int)fminf(acc[o][1], 16777215.0f - U8F_BIAS);
+            out = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x0c0c0602u) ^ 0x8080u;
+        } else {
+            out = __builtin_amdgcn_perm((uint32_t)acc[o][1], (uint32_t)acc[o][0], 0x0c0c0602u);
+        }
+        *(uint16_t *)out_row = (uint16_t)out;
+        out_row += dst_pitch;
+    }
+}
+
+template <int NK4, bool WIDE>
+__global__ __launch_bounds__(256) void k_cols_u8f_static(const uint32_t *temp, uint8_t *dst, size_t dst_pitch, int rows, int row_bytes, TapsCols taps, int nk,
+                                                         int half, int border, int tiles_x, B2Frames fr) {
+    temp += (size_t)blockIdx.y * fr.temp_frame;
+    dst += (size_t)blockIdx.y * fr.dst_frame;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * B2_R;
+    if (y0 - half >= 0 && y0 - half + B2_R + NK4 - 1 <= rows) // workgroup-uniform: every streamed row (the padded ones too) is inside the plane
+        cols_strip_u8f_static<NK4, WIDE>(temp, dst, dst_pitch, row_bytes, taps, half, tx, ty);
+    else
+        cols_strip_u8f<false, WIDE, B2_R>(temp, dst, dst_pitch, rows, row_bytes, taps, nk, half, border, tx, ty);
 }
 
 // ---- one pyramid level: gaussianBlur then resize(.bilinear) of an Image(u8), the column pass fused with the resize (round 5) -------------------------
@@ -533,9 +610,8 @@ int try_pyramid_level_u8(const zg_image *src, const zg_image *level, const int32
     if (src->pixel != ZG_PIXEL_U8 || level->pixel != ZG_PIXEL_U8 || nk < 1 || nk > B2_NKMAX || !(nk & 1)) return -1;
     if (getenv("ZIGNAL_HIP_NO_PYRAMID_FUSE")) return -1; // A/B hook of round 5
     // A lane here owns the two columns of ONE output column, the dense column pass the two columns of a dword: 2 / scale of its arithmetic. Below
-    // a reduction of `min_scale` the dense pass and the separate resize are cheaper (measured: profiles/r05_experiments.txt).
-    static const float min_scale = getenv("ZIGNAL_HIP_PYRAMID_FUSE_FROM") ? (float)atof(getenv("ZIGNAL_HIP_PYRAMID_FUSE_FROM")) : 2.0f;
-    if ((float)src->cols < min_scale * (float)level->cols) return -1;
+    // a reduction by 2 the dense pass and the separate resize are cheaper (thresholds 1 / 1.7 / 2 / 2.4 / 2.9 measured: profiles/r05_experiments.txt).
+    if (src->cols < 2 * level->cols) return -1;
     if (src->cols % 16 || src->stride % 16 || ((uintptr_t)src->data & 15) || src->cols < 256 || (uint64_t)src->cols > 0x3fffffffu) return -1;
     if (level->rows == 0 || level->cols == 0 || level->rows > src->rows || level->cols > src->cols || src->rows < 2) return -1;
     if ((uint64_t)(src->rows + 16) * src->cols * 2 > 0x7fffffffull) return -1;
@@ -549,7 +625,7 @@ int try_pyramid_level_u8(const zg_image *src, const zg_image *level, const int32
     uint32_t *temp = nullptr;
     if (int rc = scratch_alloc((void **)&temp, temp_bytes, s)) return rc;
     const int tiles_x = (int)ceil_div((uint32_t)row_bytes, 1024u);
-    const int rows_per_wave = 4;
+    const int rows_per_wave = 4; // 1, 2 and 8 measured the same or worse (profiles/r05_experiments.txt)
     const B2Frames fr{0, 0, 0};
     const dim3 grid_rows((unsigned)(tiles_x * ceil_div(src->rows, 4u * rows_per_wave)), 1);
     switch ((half + 3) / 4) {
@@ -630,7 +706,7 @@ int try_sep_bytes2_frames(const zg_image *src, const zg_image *dst, uint32_t n, 
     uint32_t *temp = nullptr;
     if (int rc = scratch_alloc((void **)&temp, temp_bytes * per_launch, s)) return rc;
     const int tiles_x = (int)ceil_div((uint32_t)row_bytes, 1024u);
-    const int rows_per_wave = 4;
+    const int rows_per_wave = 4; // 1, 2 and 8 measured the same or worse (profiles/r05_experiments.txt)
     for (uint32_t f0 = 0; f0 < n; f0 += per_launch) {
         const uint32_t nf = std::min(per_launch, n - f0);
         zg_image a = *src;
@@ -656,9 +732,28 @@ int try_sep_bytes2_frames(const zg_image *src, const zg_image *dst, uint32_t n, 
             hipLaunchKernelGGL((k_cols_u16<true>), grid_cols, dim3(256), 0, s, (const uint32_t *)temp, out, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x, fr);
         } else {
             const int tiles_x2 = (int)ceil_div((uint32_t)row_bytes, 512u);
+            static const bool generic = getenv("ZIGNAL_HIP_B2_GENERIC_COLS") != nullptr; // A/B hook of round 5
+            if (!generic && nky <= 33) {
+                const dim3 grid2((unsigned)(tiles_x2 * ceil_div(src->rows, (uint32_t)B2_R)), nf);
+                auto st = [&](auto nk_tag) {
+                    constexpr int NK4 = decltype(nk_tag)::value;
+                    if (wide) hipLaunchKernelGGL((k_cols_u8f_static<NK4, true>), grid2, dim3(256), 0, s, (const uint32_t *)temp, out, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x2, fr);
+                    else hipLaunchKernelGGL((k_cols_u8f_static<NK4, false>), grid2, dim3(256), 0, s, (const uint32_t *)temp, out, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x2, fr);
+                };
+                switch ((nky + 2) / 4) { // 4 m + 1 >= nky
+                case 0: case 1: case 2: st(std::integral_constant<int, 9>{}); break;
+                case 3: st(std::integral_constant<int, 13>{}); break;
+                case 4: st(std::integral_constant<int, 17>{}); break;
+                case 5: st(std::integral_constant<int, 21>{}); break;
+                case 6: st(std::integral_constant<int, 25>{}); break;
+                case 7: st(std::integral_constant<int, 29>{}); break;
+                default: st(std::integral_constant<int, 33>{}); break;
+                }
+                continue;
+            }
             const dim3 grid2((unsigned)(tiles_x2 * ceil_div(src->rows, (uint32_t)B2_R)), nf);
-            if (wide) hipLaunchKernelGGL((k_cols_u8f<true>), grid2, dim3(256), 0, s, (const uint32_t *)temp, out, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x2, fr);
-            else hipLaunchKernelGGL((k_cols_u8f<false>), grid2, dim3(256), 0, s, (const uint32_t *)temp, out, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x2, fr);
+            if (wide) hipLaunchKernelGGL((k_cols_u8f<true, B2_R>), grid2, dim3(256), 0, s, (const uint32_t *)temp, out, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x2, fr);
+            else hipLaunchKernelGGL((k_cols_u8f<false, B2_R>), grid2, dim3(256), 0, s, (const uint32_t *)temp, out, dst->stride * sp, (int)src->rows, row_bytes, tc, nky, halfy, border, tiles_x2, fr);
         }
     }
     const hipError_t e = hipGetLastError();
