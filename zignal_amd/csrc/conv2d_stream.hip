@@ -38,12 +38,18 @@ struct C2StreamArgs {
     uint32_t src_span, dst_span; // bytes from the first byte to the end of the last row
     int32_t fast_ok;             // both spans fit 32 bits: whole-image descriptors may be used
 };
+#ifndef C2S_PLAIN_FMA
+#define C2S_PLAIN_FMA 0 // 1: v_fmac_f32 per byte for every pixel stride (the form before round 5; tools/build_variant.sh for A/B)
+#endif
+#ifndef C2S_WAVES
+#define C2S_WAVES (K == 3 ? 4 : 2)
+#endif
 template <int K> struct TapsF2D { float w[K * K]; }; // round(k * 256), integer-valued
 
 template <int B> __device__ __forceinline__ float byte_to_f32(uint32_t dword) { return (float)((dword >> (8 * B)) & 0xffu); } // v_cvt_f32_ubyteB
 
 template <int SP, int K, int DM>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 3 ? 4 : 2))) void k_conv2d_stream(C2StreamArgs a, TapsF2D<K> k) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C2S_WAVES))) void k_conv2d_stream(C2StreamArgs a, TapsF2D<K> k) {
     constexpr int H = K / 2;
     constexpr int HB = (H * SP + 3) / 4; // halo dwords per side
     constexpr int NP = 16 + 2 * H * SP;  // byte positions a lane converts per row
@@ -157,6 +163,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 3 ? 4 :
         }
         // acc[slot][byte]: output row m of the strip lives in slot m % K from the source row that brings its first kernel row (q = m) to
         // the one that brings its last (q = m + K - 1); source row q = qb + u of the strip is row y0 - H + q of the image.
+        // Even pixel strides (Rgba): two bytes per v_pk_fma_f32, the weight broadcast from one half of a scalar-register PAIR (op_sel). A packed
+        // multiply-add issues every 4.5 cycles whatever the multiplier's register file, a plain v_fmac_f32 with an SGPR operand every 4.1 — for ONE
+        // byte (tools/exp/pk_sgpr.hip, fmac_sgpr.hip) — and the weights keep costing no vector registers.
+        constexpr bool PACKED = SP % 2 == 0 && !C2S_PLAIN_FMA;
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        uint64_t wpair[(K * K + 1) / 2];
+        if constexpr (PACKED) {
+#pragma unroll
+            for (int i = 0; i < (K * K + 1) / 2; ++i)
+                wpair[i] = (uint64_t)__float_as_uint(k.w[2 * i]) | ((uint64_t)(2 * i + 1 < K * K ? __float_as_uint(k.w[2 * i + 1]) : 0u) << 32);
+        }
+        auto pk_mul = [&](f2 p, int wi) -> f2 {
+            f2 r;
+            if (wi & 1) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "s"(wpair[wi >> 1]), "v"(p));
+            else asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "s"(wpair[wi >> 1]), "v"(p));
+            return r;
+        };
+        auto pk_fma = [&](f2 p, int wi, f2 c) -> f2 {
+            if (wi & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(c) : "s"(wpair[wi >> 1]), "v"(p));
+            else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(c) : "s"(wpair[wi >> 1]), "v"(p));
+            return c;
+        };
         float acc[K][16];
 #pragma unroll
         for (int s = 0; s < K; ++s)
@@ -184,11 +212,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K == 3 ? 4 :
                     const int s = ((u - ky) % K + K) % K;
 #pragma unroll
                     for (int kx = 0; kx < K; ++kx) {
-                        const float wt = k.w[ky * K + kx];
+                        if constexpr (PACKED) {
 #pragma unroll
-                        for (int t = 0; t < 16; ++t) {
-                            if (ky == 0 && kx == 0) acc[s][t] = P[t] * wt; // the row's first tap starts the slot afresh
-                            else acc[s][t] = __builtin_fmaf(P[t + SP * kx], wt, acc[s][t]); // integers below 2^24: exact, any order
+                            for (int t = 0; t < 16; t += 2) {
+                                const f2 pp = f2{P[t + SP * kx], P[t + 1 + SP * kx]};
+                                f2 c = f2{acc[s][t], acc[s][t + 1]};
+                                c = ky == 0 && kx == 0 ? pk_mul(pp, 0) : pk_fma(pp, ky * K + kx, c);
+                                acc[s][t] = c.x;
+                                acc[s][t + 1] = c.y;
+                            }
+                        } else {
+                            const float wt = k.w[ky * K + kx];
+#pragma unroll
+                            for (int t = 0; t < 16; ++t) {
+                                if (ky == 0 && kx == 0) acc[s][t] = P[t] * wt; // the row's first tap starts the slot afresh
+                                else acc[s][t] = __builtin_fmaf(P[t + SP * kx], wt, acc[s][t]); // integers below 2^24: exact, any order
+                            }
                         }
                     }
                 }
