@@ -15,6 +15,23 @@ elif op.startswith("greyblur_"):  # greyblur_2.25: gaussianBlur(sigma) of a 4096
     s = zg.Image(torch.randint(0, 256, (R, R), dtype=torch.uint8, device="cuda")); d = zg.Image(torch.empty_like(s.data))
     sg = float(op.split("_")[1])
     f = lambda: s.gaussian_blur(sg, out=d)
+elif op in ("blur_f32plane", "blur_f32planes4"):  # Image(f32) planes: k_sep_tile_f32, one launch for one / four planes; eight sets so the sources pass the Infinity Cache
+    n_pl = 4 if op.endswith("4") else 1
+    sets = [([zg.Image(torch.rand((R, R), dtype=torch.float32, device="cuda")) for _ in range(n_pl)], [zg.Image(torch.empty((R, R), dtype=torch.float32, device="cuda")) for _ in range(n_pl)]) for _ in range(8 // n_pl * 2)]
+    it = [0]
+    def f():
+        it[0] += 1
+        a, b = sets[it[0] % len(sets)]
+        zg.gaussian_blur_planes(a, 0.6, outs=b)
+elif op == "resize_lab":  # the fused resize -> Oklab of one frame (config 3's pair of steps), eight sources
+    ss = [zg.Image(torch.randint(0, 256, (R, R, 4), dtype=torch.uint8, device="cuda")) for _ in range(8)]; d = zg.Image(torch.empty((1024, 1024, 3), dtype=torch.float32, device="cuda"))
+    it = [0]
+    def f():
+        it[0] += 1
+        ss[it[0] % 8].resize_convert(d, zg.CS_OKLAB)
+elif op == "box_small":  # boxBlur of a 256 x 256 Image(u8): rows * cols * 255 < 2^24, the direct kernel (no integral image)
+    s = zg.Image(torch.randint(0, 256, (256, 256), dtype=torch.uint8, device="cuda")); d = zg.Image(torch.empty_like(s.data))
+    f = lambda: s.box_blur(2, out=d)
 elif op == "blur_f32":
     s = zg.Image(torch.rand((R, R, 4), dtype=torch.float32, device="cuda")); d = zg.Image(torch.empty_like(s.data))
     f = lambda: s.gaussian_blur(0.6, out=d)
