@@ -50,7 +50,7 @@ def same(a, b):
 
 def case(rng):
     kind = str(rng.choice(KINDS))
-    op = str(rng.choice(["blur", "sep", "conv2d", "box", "resize", "warp", "rotate", "convert", "sobel", "canny", "shen", "isef", "motion", "insert_flip", "letterbox_extract", "misc8", "codec", "pipeline", "pipeline"]))
+    op = str(rng.choice(["blur", "sep", "conv2d", "box", "resize", "warp", "rotate", "convert", "sobel", "canny", "shen", "isef", "motion", "insert_flip", "letterbox_extract", "misc8", "codec", "pipeline", "pipeline", "pyramid", "planes", "resize_convert"]))
     rows, cols = dim(rng, MAX_ROWS), dim(rng, MAX_COLS)
     img = synth(rng, kind, rows, cols)
     border = int(rng.integers(0, 4))
@@ -62,6 +62,47 @@ def case(rng):
         return codec_case(rng)
     if op == "pipeline":
         return pipeline_case(rng, kind)
+    flat = lambda arrays: np.concatenate([np.ascontiguousarray(a).reshape(-1).view(np.uint8) for a in arrays]) if arrays else np.zeros(0, np.uint8)
+    if op == "pyramid":  # ImagePyramid.build: every level = blur of the source + bilinear resize (fused from a reduction by 2 up on Image(u8))
+        kind = str(rng.choice(["u8", "u8", "u8", "f32", "rgba_u8"]))
+        cols = max(cols, int(rng.choice([256, 272, 512, 640, 1040]))) if rng.random() < 0.7 else cols  # the packed two-pass path needs >= 256 columns
+        img = synth(rng, kind, rows, cols)
+        n, sf, sg = int(rng.integers(1, 9)), float(rng.choice([1.2, 1.3, 1.5, 2.0, 2.1, 3.0])), float(rng.choice([0.8, 1.0, 1.6, 2.91, 3.5]))
+        want = o.pyramid(img, n, sf, sg)
+        pyr = zg.ImagePyramid.build(D(img), n, sf, sg)
+        torch.cuda.synchronize()
+        if pyr.n_levels != len(want):
+            return f"pyramid {kind} {rows}x{cols} ({n},{sf},{sg}) level count", np.zeros(1, np.uint8), np.ones(1, np.uint8)
+        return f"pyramid {kind} {rows}x{cols} ({n},{sf},{sg})", flat([l.to_numpy() for l in pyr.levels]), flat(want)
+    if op == "planes":  # several Image(f32) planes through one launch (zg_conv_separable_planes / zg_gaussian_blur_planes), shapes and views mixed in
+        npl = int(rng.integers(1, 12))
+        cols4 = max(4, cols // 4 * 4) if rng.random() < 0.8 else cols
+        planes = [synth(rng, "f32", rows, cols4) - np.float32(0.5) for _ in range(npl)]
+        if npl > 2 and rng.random() < 0.3:
+            planes[1] = synth(rng, "f32", max(1, rows // 2), cols4)  # one plane of another shape breaks the run
+        devs = [D(pl) if rng.random() < 0.2 else dev(pl) for pl in planes]
+        if rng.random() < 0.5:
+            sigma = float(rng.choice([0.3, 0.6, 1.0]))
+            outs = zg.gaussian_blur_planes(devs, sigma)
+            want = [o.gaussian_blur(pl, sigma) for pl in planes]
+            name = f"planes f32 {npl}x{rows}x{cols4} sigma={sigma}"
+        else:
+            nk = int(rng.choice([1, 3, 5, 7, 9]))
+            kx = rng.random(nk).astype(np.float32) - np.float32(0.3); ky = rng.random(nk).astype(np.float32) - np.float32(0.3)
+            if rng.random() < 0.3: kx[0] = 0.0
+            outs = zg.convolve_separable_planes(devs, kx, ky, border)
+            want = [o.conv_separable(pl, kx, ky, border) for pl in planes]
+            name = f"planes f32 {npl}x{rows}x{cols4} n={nk} b={border}"
+        torch.cuda.synchronize()
+        return name, flat([x.to_numpy() for x in outs]), flat(want)
+    if op == "resize_convert":  # [resize, convert] as one call: the fused kernels (Rgba(u8), bilinear -> Oklab / Xyz) and the two-step route
+        kind = str(rng.choice(["rgba_u8", "rgba_u8", "rgb_u8", "u8"]))
+        img = synth(rng, kind, rows, cols)
+        dr, dc = dim(rng, 200), dim(rng, 600)
+        sp = int(rng.choice([zg.CS_OKLAB, zg.CS_XYZ, zg.CS_LAB]))
+        src_space = {"u8": o.CS_GRAY, "rgb_u8": o.CS_RGB, "rgba_u8": o.CS_RGBA}[kind]
+        small = o.resize(img, (dr, dc), o.method(o.BILINEAR))
+        return f"resize_convert {kind} {rows}x{cols}->{dr}x{dc} space={sp}", D(img).resize_convert((dr, dc), sp), o.convert(small, src_space, sp, np.float32, 3)
     if op == "blur":
         sigma = float(rng.choice([0.3, 0.6, 1.0, 1.4, 2.25, 3.3, 5.5]))
         return f"blur {kind} {rows}x{cols} sigma={sigma}", D(img).gaussian_blur(sigma), o.gaussian_blur(img, sigma)
