@@ -142,23 +142,21 @@ __global__ __launch_bounds__(256) void k_rows_u16(DImg src, uint32_t *temp, Taps
 // HP (a multiple of 4, the kernel's half width rounded up) is a template parameter so that all register indices are compile-time;
 // taps past the kernel are zeros.
 struct TapsRowsU8F { float k[2 * B2_HMAX + 1]; }; // k[offset + HP]
-template <int HP>
-__global__ __launch_bounds__(256) void k_rows_u8f(DImg src, uint32_t *temp, TapsRowsU8F taps, int border, int tiles_x, int rows_per_wave, B2Frames fr) {
-    src.data = (uint8_t *)src.data + (size_t)blockIdx.y * fr.src_frame;
-    temp += (size_t)blockIdx.y * fr.temp_frame;
+// tap(j) = the tap at offset j - HP (a scalar load out of the kernel arguments, compile-time j); bx = the workgroup's index within its plane
+template <int HP, typename TapFn>
+__device__ __forceinline__ void rows_u8f_body(DImg src, uint32_t *temp, TapFn tap, int border, int tiles_x, int rows_per_wave, uint32_t (*lds)[B2_ROW], int bx) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     constexpr int ND = 4 + HP / 2; // dwords of a lane's window
-    __shared__ uint32_t lds[4][B2_ROW];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
     const int xb0 = tx * 1024;
     const int row_bytes = src.cols;
     uint32_t *buf = lds[wave];
     const bool edge = xb0 == 0 || xb0 + 1024 + HP + 16 > row_bytes;
     float k[2 * HP + 1];
 #pragma unroll
-    for (int j = 0; j <= 2 * HP; ++j) k[j] = taps.k[j]; // scalar loads: the taps live in SGPRs
+    for (int j = 0; j <= 2 * HP; ++j) k[j] = tap(j); // scalar loads: the taps live in SGPRs
     for (int rr = 0; rr < rows_per_wave; ++rr) {
         const int y = (ty * 4 + wave) * rows_per_wave + rr; // wave-uniform
         if (y >= src.rows) break;
@@ -188,6 +186,31 @@ __global__ __launch_bounds__(256) void k_rows_u8f(DImg src, uint32_t *temp, Taps
             *(u32x4 *)trow = u32x4{pk[0], pk[1], pk[2], pk[3]};
             *(u32x4 *)(trow + 4) = u32x4{pk[4], pk[5], pk[6], pk[7]};
         }
+    }
+}
+template <int HP>
+__global__ __launch_bounds__(256) void k_rows_u8f(DImg src, uint32_t *temp, TapsRowsU8F taps, int border, int tiles_x, int rows_per_wave, B2Frames fr) {
+    src.data = (uint8_t *)src.data + (size_t)blockIdx.y * fr.src_frame;
+    temp += (size_t)blockIdx.y * fr.temp_frame;
+    __shared__ uint32_t lds[4][B2_ROW];
+    rows_u8f_body<HP>(src, temp, [&](int j) { return taps.k[j]; }, border, tiles_x, rows_per_wave, lds, (int)blockIdx.x);
+}
+// The row passes of SEVERAL Gaussians over ONE source in one launch (the levels of a pyramid: every level blurs the original with its own sigma):
+// blockIdx.y picks the job. One launch of n x 4 096 waves instead of n launches of 4 096: a launch of one round of waves is a memory phase and a
+// compute phase one after the other plus 4 us of ramp (profiles/r05_experiments.txt, section 5), several rounds overlap them.
+constexpr int PYR_MAX_JOBS = 8;
+constexpr int PYR_HMAX = 16; // padded half width of a batched row pass (taps <= 33)
+struct RowsJob { uint32_t *temp; int hp; float k[2 * PYR_HMAX + 1]; }; // k[offset + hp]
+struct RowsJobs { RowsJob j[PYR_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void k_rows_u8f_multi(DImg src, RowsJobs jobs, int border, int tiles_x, int rows_per_wave) {
+    __shared__ uint32_t lds[4][B2_ROW];
+    const RowsJob &job = jobs.j[blockIdx.y];
+    auto tap = [&](int j) { return job.k[j]; };
+    switch (job.hp) { // workgroup-uniform
+    case 4: rows_u8f_body<4>(src, job.temp, tap, border, tiles_x, rows_per_wave, lds, (int)blockIdx.x); break;
+    case 8: rows_u8f_body<8>(src, job.temp, tap, border, tiles_x, rows_per_wave, lds, (int)blockIdx.x); break;
+    case 12: rows_u8f_body<12>(src, job.temp, tap, border, tiles_x, rows_per_wave, lds, (int)blockIdx.x); break;
+    default: rows_u8f_body<16>(src, job.temp, tap, border, tiles_x, rows_per_wave, lds, (int)blockIdx.x); break;
     }
 }
 template <int HP>
@@ -659,6 +682,142 @@ int try_pyramid_level_u8(const zg_image *src, const zg_image *level, const int32
     scratch_free(temp, s);
     ZG_HIP(e);
     return ZG_OK;
+}
+
+// ---- the levels of a pyramid in three launches -----------------------------------------------------------------------------------------------------------
+// ImagePyramid.build makes every level from the ORIGINAL, so all the row passes read one source: k_rows_u8f_multi runs them as one launch, then the dense
+// column passes (levels reduced by less than 2: a blurred plane, resized afterwards) as one and the fused ones (k_cols_bilinear_u8) as one. Per job:
+struct DenseJob { const uint32_t *temp; uint8_t *dst; size_t dst_pitch; int nk, half, nk4; TapsCols taps; };
+struct DenseJobs { DenseJob j[4]; };
+__global__ __launch_bounds__(256) void k_cols_u8f_multi(DenseJobs jobs, int rows, int row_bytes, int tiles_x) {
+    const DenseJob &job = jobs.j[blockIdx.y];
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * B2_R;
+    if (!(y0 - job.half >= 0 && y0 - job.half + B2_R + job.nk4 - 1 <= rows)) { // bands at the top and bottom rows: the general form
+        cols_strip_u8f<false, false, B2_R>(job.temp, job.dst, job.dst_pitch, rows, row_bytes, job.taps, job.nk, job.half, ZG_BORDER_MIRROR, tx, ty);
+        return;
+    }
+    switch (job.nk4) { // workgroup-uniform
+    case 9: cols_strip_u8f_static<9, false>(job.temp, job.dst, job.dst_pitch, row_bytes, job.taps, job.half, tx, ty); break;
+    case 13: cols_strip_u8f_static<13, false>(job.temp, job.dst, job.dst_pitch, row_bytes, job.taps, job.half, tx, ty); break;
+    case 17: cols_strip_u8f_static<17, false>(job.temp, job.dst, job.dst_pitch, row_bytes, job.taps, job.half, tx, ty); break;
+    default: cols_strip_u8f_static<21, false>(job.temp, job.dst, job.dst_pitch, row_bytes, job.taps, job.half, tx, ty); break; // the host sends no longer kernel
+    }
+}
+struct FusedJob { PyrLevelArgs a; int wide; TapsCols taps; };
+struct FusedJobs { FusedJob j[4]; };
+__global__ __launch_bounds__(256) void k_cols_bilinear_u8_multi(FusedJobs jobs) {
+    __shared__ uint16_t bt[B2_R][256];
+    const FusedJob &job = jobs.j[blockIdx.y];
+    const PyrLevelArgs &a = job.a;
+    if ((int)blockIdx.x >= a.tiles_x * a.nbands) return; // the launch is as wide as its largest level
+    const int band = blockIdx.x / a.tiles_x, tx = blockIdx.x - band * a.tiles_x;
+    const int y0 = band == a.nbands - 1 ? max(0, a.rows - B2_R) : band * (B2_R - 1);
+    const bool inside = y0 - a.half >= 0 && y0 - a.half + B2_R + a.nk - 1 <= a.rows;
+    if (job.wide) {
+        if (inside) cols_bilinear_band<true, true>(a, job.taps, bt, tx, band);
+        else cols_bilinear_band<false, true>(a, job.taps, bt, tx, band);
+    } else {
+        if (inside) cols_bilinear_band<true, false>(a, job.taps, bt, tx, band);
+        else cols_bilinear_band<false, false>(a, job.taps, bt, tx, band);
+    }
+}
+
+int resize_impl_bilinear_u8(const zg_image *src, const zg_image *dst, hipStream_t s); // edges.hip: zg_resize(.bilinear)
+
+// Levels i with handled[i] set on return were enqueued here (on `s`); the others are the caller's. A caller with several streams asks for the fused levels on
+// one and the dense levels on another (two independent batches, each with its own row-pass launch and scratch block: no event between the streams). sigmas[i] <= 0.5 (a plain resize), other pixel types,
+// shapes the packed kernels exclude, kernels of <= 7 taps (the one-pass stream kernel is better there) and > 33 are left alone. -1: nothing was done.
+int try_pyramid_levels_u8(const zg_image *src, const zg_image *levels, const float *sigmas, uint32_t n, uint8_t *handled, int which, hipStream_t s) {
+    if (getenv("ZIGNAL_HIP_NO_PYRAMID_BATCH")) return -1; // A/B hook of round 5
+    if (src->pixel != ZG_PIXEL_U8 || src->cols % 16 || src->stride % 16 || ((uintptr_t)src->data & 15) || src->cols < 256 || (uint64_t)src->cols > 0x3fffffffu || src->rows < 2) return -1;
+    struct Plan { uint32_t level; int nk, half, hp, wide; bool fused; int32_t taps[33]; };
+    Plan plan[PYR_MAX_JOBS];
+    int np = 0, n_dense = 0, n_fused = 0;
+    for (uint32_t i = 0; i < n && np < PYR_MAX_JOBS; ++i) {
+        const zg_image &lv = levels[i];
+        if (!(sigmas[i] > 0.5f) || lv.pixel != ZG_PIXEL_U8 || lv.rows == 0 || lv.cols == 0 || lv.rows > src->rows || lv.cols > src->cols) continue;
+        const int nfull = zg_gaussian_kernel(sigmas[i], nullptr, 0);
+        if (nfull < 1 || nfull > 65) continue;
+        float ft[65];
+        if (zg_gaussian_kernel(sigmas[i], ft, 65) != nfull) continue;
+        int32_t it[65];
+        int64_t sum = 0;
+        bool ok = true;
+        for (int j = 0; j < nfull; ++j) { it[j] = (int32_t)std::round(ft[j] * 256.0f); ok = ok && it[j] >= 0 && it[j] <= 255; sum += it[j]; }
+        if (!ok || sum > 257) continue;
+        int z = 0;
+        while (nfull - 2 * z > 2 && it[z] == 0 && it[nfull - 1 - z] == 0) ++z;
+        const int nk = nfull - 2 * z;
+        if (nk <= 7 || nk > 33 || !(nk & 1)) continue;
+        Plan &p = plan[np];
+        p.level = i; p.nk = nk; p.half = nk / 2; p.hp = std::max(4, (p.half + 3) / 4 * 4);
+        p.wide = sum * sum * 255 + 32768 >= 256 * 65536;
+        p.fused = src->cols >= 2 * lv.cols;
+        if (handled[i] || (which == 0 && !p.fused) || (which == 1 && p.fused)) continue; // which: 0 = the fused levels, 1 = the dense ones, 2 = both
+        if (!p.fused && (p.wide || nk > 21)) continue;      // the batched dense column pass: sums <= 256, <= 21 taps (a reduction below 2 has sigma < 2.8 x blur_sigma;
+                                                            // longer instantiations would cost every job of the launch its occupancy)
+        if (p.fused ? n_fused == 4 : n_dense == 4) continue;
+        for (int j = 0; j < nk; ++j) p.taps[j] = it[z + j];
+        (p.fused ? n_fused : n_dense)++;
+        ++np;
+    }
+    if (np < 2) return -1; // one level gains nothing from a batch (the caller's level-by-level path takes it)
+
+    const int row_bytes = (int)src->cols;
+    const size_t temp_bytes = ((size_t)src->rows + 16) * row_bytes * 2, plane_bytes = (size_t)src->rows * src->cols;
+    uint8_t *block = nullptr;
+    if (int rc = scratch_alloc((void **)&block, temp_bytes * np + plane_bytes * n_dense, s)) return rc;
+    RowsJobs rj{};
+    DenseJobs dj{};
+    FusedJobs fj{};
+    uint8_t *blurred[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t dense_level[4] = {0, 0, 0, 0};
+    int di = 0, fi = 0, fused_grid = 0;
+    for (int q = 0; q < np; ++q) {
+        const Plan &p = plan[q];
+        uint32_t *temp = (uint32_t *)(block + temp_bytes * q);
+        rj.j[q].temp = temp;
+        rj.j[q].hp = p.hp;
+        for (int j = 0; j < p.nk; ++j) rj.j[q].k[j - p.half + p.hp] = (float)p.taps[j];
+        TapsCols tc{};
+        for (int j = 0; j < p.nk; ++j) { const float f = (float)p.taps[j]; memcpy(&tc.k[B2_R + j], &f, 4); }
+        const zg_image &lv = levels[p.level];
+        if (p.fused) {
+            FusedJob &f = fj.j[fi++];
+            f.a.temp = (const uint16_t *)temp; f.a.dst = (uint8_t *)lv.data; f.a.dst_pitch = lv.stride;
+            f.a.rows = (int)src->rows; f.a.cols = (int)src->cols; f.a.drows = (int)lv.rows; f.a.dcols = (int)lv.cols;
+            f.a.rx = (float)src->cols / (float)lv.cols; f.a.ry = (float)src->rows / (float)lv.rows;
+            f.a.nk = p.nk; f.a.half = p.half;
+            f.a.tiles_x = (int)ceil_div(lv.cols, 256u);
+            f.a.nbands = src->rows <= (uint32_t)B2_R ? 1 : (int)ceil_div(src->rows - 1, (uint32_t)(B2_R - 1));
+            f.wide = p.wide; f.taps = tc;
+            fused_grid = std::max(fused_grid, f.a.tiles_x * f.a.nbands);
+        } else {
+            blurred[di] = block + temp_bytes * np + plane_bytes * di;
+            dense_level[di] = p.level;
+            DenseJob &d = dj.j[di++];
+            d.temp = temp; d.dst = blurred[di - 1]; d.dst_pitch = src->cols; d.nk = p.nk; d.half = p.half; d.nk4 = std::max(9, (p.nk + 2) / 4 * 4 + 1); d.taps = tc;
+        }
+        handled[p.level] = 1;
+    }
+    const int tiles_x = (int)ceil_div((uint32_t)row_bytes, 1024u), rows_per_wave = 4;
+    hipLaunchKernelGGL(k_rows_u8f_multi, dim3((unsigned)(tiles_x * ceil_div(src->rows, 4u * rows_per_wave)), (unsigned)np), dim3(256), 0, s, dimg(src), rj, (int)ZG_BORDER_MIRROR, tiles_x,
+                       rows_per_wave);
+    int rc = ZG_OK;
+    if (fi) hipLaunchKernelGGL(k_cols_bilinear_u8_multi, dim3((unsigned)fused_grid, (unsigned)fi), dim3(256), 0, s, fj);
+    if (di) {
+        const int tiles_x2 = (int)ceil_div((uint32_t)row_bytes, 512u);
+        hipLaunchKernelGGL(k_cols_u8f_multi, dim3((unsigned)(tiles_x2 * ceil_div(src->rows, (uint32_t)B2_R)), (unsigned)di), dim3(256), 0, s, dj, (int)src->rows, row_bytes, tiles_x2);
+        for (int d = 0; d < di && rc == ZG_OK; ++d) {
+            const zg_image tmp{blurred[d], src->cols, src->rows, src->cols, ZG_PIXEL_U8};
+            rc = resize_impl_bilinear_u8(&tmp, &levels[dense_level[d]], s);
+        }
+    }
+    const hipError_t e = hipGetLastError();
+    scratch_free(block, s);
+    ZG_HIP(e);
+    return rc;
 }
 
 // Returns -1 when the preconditions do not hold (caller falls back to the general kernels).

@@ -1414,6 +1414,14 @@ float zg_pyramid_scale(float scale_factor, uint32_t level) { return hostmath::po
 
 // One level of ImagePyramid.build (pyramid.zig:76-92) in a single call: blur the ORIGINAL with `sigma` when sigma > 0.5
 // (library scratch holds the blurred copy), then bilinear resize into `level`. `sigma` is zg_pyramid_level's output.
+} // extern "C"
+namespace zg {
+int resize_impl_bilinear_u8(const zg_image *src, const zg_image *dst, hipStream_t s) {
+    const zg_method bilinear{ZG_INTERP_BILINEAR, 0.0f, 0.0f, nullptr};
+    return zg_resize(src, dst, &bilinear, (zg_stream)s);
+}
+} // namespace zg
+extern "C" {
 int zg_pyramid_build_level(const zg_image *source, const zg_image *level, float sigma, zg_stream stream) {
     int rc;
     if ((rc = check_image(source, "source")) || (rc = check_image(level, "level"))) return rc;
@@ -1509,8 +1517,28 @@ int zg_pyramid_build(const zg_image *source, const zg_image *levels, const float
         if (rc == ZG_OK) hip(hipEventRecord(fork, main), "hipEventRecord");
         for (int l = 1; l < n_lanes && rc == ZG_OK; ++l) hip(hipStreamWaitEvent(lanes[l], fork, 0), "hipStreamWaitEvent");
     }
+    // Image(u8): the long-tap levels as one batch on the last lane (three launches + the resizes of the dense levels), the rest level by level
+    std::vector<uint8_t> handled(n_levels, 0);
+    if (rc == ZG_OK && n_levels <= 64 && check_image(source, "source") == ZG_OK) {
+        bool all_ok = true;
+        for (uint32_t i = 0; i < n_levels; ++i) all_ok = all_ok && check_image(&levels[i], "level") == ZG_OK && levels[i].pixel == source->pixel;
+        if (all_ok) {
+            if (n_lanes >= 3) { // two independent batches on two lanes: levels reduced by 2 and more (fused column pass), and the others (dense + resize)
+                const int rcf = try_pyramid_levels_u8(source, levels, sigmas, n_levels, handled.data(), 0, lanes[n_lanes - 1]);
+                const int rcd = try_pyramid_levels_u8(source, levels, sigmas, n_levels, handled.data(), 1, lanes[n_lanes - 2]);
+                if (rcf > 0) rc = rcf; else if (rcd > 0) rc = rcd;
+            } else {
+                const int rcb = try_pyramid_levels_u8(source, levels, sigmas, n_levels, handled.data(), 2, lanes[n_lanes - 1]);
+                if (rcb > 0) rc = rcb;
+            }
+        }
+    }
     // the largest levels (the longest kernels) first, dealt round the lanes
-    for (uint32_t i = 0; i < n_levels && rc == ZG_OK; ++i) rc = zg_pyramid_build_level(source, &levels[i], sigmas[i], (zg_stream)lanes[i % (uint32_t)n_lanes]);
+    uint32_t dealt = 0;
+    for (uint32_t i = 0; i < n_levels && rc == ZG_OK; ++i) {
+        if (handled[i]) continue;
+        rc = zg_pyramid_build_level(source, &levels[i], sigmas[i], (zg_stream)lanes[dealt++ % (uint32_t)n_lanes]);
+    }
     for (int l = 1; l < n_lanes; ++l) { // always joined, also after a failure: a forked stream must not be left inside a capture
         if (hipEventCreateWithFlags(&join[l], hipEventDisableTiming) == hipSuccess && hipEventRecord(join[l], lanes[l]) == hipSuccess)
             hip(hipStreamWaitEvent(main, join[l], 0), "hipStreamWaitEvent");
