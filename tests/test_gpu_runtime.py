@@ -116,12 +116,14 @@ ALTERNATIVE_FORMS = {
     # (profiles/r03_experiments.txt, r04_experiments.txt): NO_STREAM, STREAM_GREY, ROWS_INT, COLS_INT, NO_LAB4, NO_U8_PLANE_RESIZE, NO_WARP_STAGE, CONV2D_INT.
     # The forms themselves stay where ordinary inputs still reach them (shapes a fast kernel's preconditions exclude) and are tested there.
     # Round 5 dropped NO_CONV2D_STREAM, NO_SOBEL_STREAM (27 / 20 us against 75 / 55: r04_experiments.txt), the strip-height knobs and MFMA (the matrix-pipe
-    # Gaussian left the library: tools/exp/conv_sep_mfma.hip), and added this round's seven.
+    # Gaussian left the library: tools/exp/conv_sep_mfma.hip), and added this round's eight.
     "ZIGNAL_HIP_STREAM_NO_FOLD": "k_sep_stream's plain row pass and end-tap multiplies instead of the folded unit-end form (gaussianBlur(0.6)'s taps)",
     "ZIGNAL_HIP_NO_TILE_F32": "the LDS-tiled k_sep_f32x4 instead of the tile-per-wave k_sep_tile_f32 for Image(f32) planes",
     "ZIGNAL_HIP_RESIZE_FORM=0": "round 4's four-row workgroups in XCD-major order for every bilinear Rgba(u8) resize (reductions use one-wave workgroups in address order)",
     "ZIGNAL_HIP_NO_PYRAMID_FUSE": "gaussianBlur into a blurred plane then resize for every level of an Image(u8) pyramid instead of the column pass fused with the bilinear taps",
     "ZIGNAL_HIP_NO_PYRAMID_BATCH": "every long-tap level of an Image(u8) pyramid with its own row- and column-pass launches instead of the multi-job kernels (k_rows_u8f_multi, k_cols_u8f_multi, k_cols_bilinear_u8_multi)",
+    "ZIGNAL_HIP_RESIZE_U8_ROWS=0": "k_resize_bilinear_u8 (one output row per wave, taps per pixel) for every Image(u8) bilinear resize instead of k_resize_bilinear_u8_rows<2> below a ratio of 2",
+    "ZIGNAL_HIP_RESIZE_U8_ROWS=4": "k_resize_bilinear_u8_rows<4>: four output rows per wave",
     "ZIGNAL_HIP_B2_GENERIC_COLS": "k_cols_u8f (tap count at run time) for every band instead of k_cols_u8f_static<NK4> (unrolled, taps in SGPRs) in the long-tap u8 column pass",
     "ZIGNAL_HIP_KEEP_ZERO_TAPS": "integer kernels with their zero outer taps kept (gaussianBlur's 3-sigma radius rounds them to zero from sigma 2.3 up)",
     "ZIGNAL_HIP_ISEF_TRANSPOSE": "two transposes around k_isef_cols instead of the recursions along the rows",

@@ -308,6 +308,95 @@ __global__ __launch_bounds__(256) void k_resize_bilinear_u8(DImg src, DImg dst, 
     }
 }
 
+// The same resize for horizontal ratios below 2 (what ImagePyramid's first levels and most thumbnails-of-thumbnails ask for), R output rows per wave: the
+// taps of a lane's four columns depend on the column only, so they are computed once and used for R rows (14 of the 45 instructions a pixel of the kernel
+// above costs), and with a ratio below 2 the four pixels' taps span at most 8 source bytes: ONE unaligned 8-byte load per source row and lane. A pixel's
+// two bytes of a row come out of the pair of dwords by v_perm_b32 with a per-lane selector, as the u16 pair (left, right); the horizontal lerp is a
+// v_dot2_u32_u16 against (256 - fx, fx), the vertical one two v_mad_u32_u24: 7 instructions a pixel. Lanes whose taps leave the row (the image's edges)
+// take the byte-by-byte form. Integer arithmetic, the same expressions: bit-identical to the kernel above.
+template <int R>
+__global__ __launch_bounds__(256) void k_resize_bilinear_u8_rows(DImg src, DImg dst, float rx, float ry, int tiles_x, FrameSpan fr, int dword_rows) {
+    const int nwg = gridDim.x, per_xcd = nwg >> 3;
+    int wg = blockIdx.x;
+    if (ZG_XCD_ORDER && wg < (per_xcd << 3)) wg = (wg & 7) * per_xcd + (wg >> 3);
+    src.data = (char *)src.data + (size_t)blockIdx.y * fr.src_frame;
+    dst.data = (char *)dst.data + (size_t)blockIdx.y * fr.dst_frame;
+    const int ty = wg / tiles_x, tx = wg - ty * tiles_x;
+    const int c0 = tx * 256 + (int)(threadIdx.x & 63) * 4;
+    const int rbase = __builtin_amdgcn_readfirstlane((ty * 4 + (int)(threadIdx.x >> 6)) * R);
+    if (rbase >= dst.rows || c0 >= dst.cols) return;
+    const int n = dst.cols - c0 < 4 ? dst.cols - c0 : 4;
+    int left[4], fx[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float sx = ((float)(c0 + p) + 0.5f) * rx - 0.5f;
+        const float fl = floorf(sx);
+        left[p] = (int)fl;
+        fx[p] = (int)roundf((sx - fl) * 256);
+    }
+    // every tap of the four pixels inside the row, within 8 bytes of the first, and 8 readable bytes there
+    const bool fast = n == 4 && left[0] >= 0 && left[3] + 2 <= src.cols && left[3] - left[0] <= 6 && left[1] >= left[0] && left[2] >= left[1] && left[3] >= left[2] &&
+                      left[0] + 8 <= src.cols;
+    uint32_t sel[4], wpair[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t o = (uint32_t)(left[p] - left[0]);
+        sel[p] = o * 0x00010001u + 0x0c010c00u;          // bytes (o, zero, o + 1, zero): the u16 pair (left tap, right tap)
+        wpair[p] = (uint32_t)fx[p] * 65535u + 256u;       // (256 - fx) | fx << 16
+    }
+    for (int rr = 0; rr < R; ++rr) {
+        const int r = rbase + rr; // wave-uniform
+        if (r >= dst.rows) break;
+        const float sy = ((float)r + 0.5f) * ry - 0.5f;
+        const float ft = floorf(sy);
+        const int top = (int)ft;
+        int r0 = top, r1 = top + 1;
+        if (top < 0 || top + 1 >= src.rows) {
+            r0 = resolve_index(top, src.rows, ZG_BORDER_MIRROR);
+            r1 = resolve_index(top + 1, src.rows, ZG_BORDER_MIRROR);
+        }
+        const int fy = (int)roundf((sy - ft) * 256);
+        const uint8_t *row0 = (const uint8_t *)src.data + (size_t)r0 * src.stride, *row1 = (const uint8_t *)src.data + (size_t)r1 * src.stride;
+        uint32_t packed = 0;
+        if (fast) {
+            uint32_t a[2], b[2];
+            __builtin_memcpy(a, row0 + left[0], 8);
+            __builtin_memcpy(b, row1 + left[0], 8);
+            uint32_t v[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t tp = __builtin_amdgcn_perm(a[1], a[0], sel[p]), bp = __builtin_amdgcn_perm(b[1], b[0], sel[p]);
+                uint32_t top_val, bottom_val;
+                asm("v_dot2_u32_u16 %0, %1, %2, 0" : "=v"(top_val) : "v"(tp), "v"(wpair[p]));
+                asm("v_dot2_u32_u16 %0, %1, %2, 0" : "=v"(bottom_val) : "v"(bp), "v"(wpair[p]));
+                v[p] = top_val * (uint32_t)(256 - fy) + bottom_val * (uint32_t)fy + 32768u; // < 2^24 + 2^15; the pixel is byte 2
+            }
+            packed = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u) | __builtin_amdgcn_perm(v[3], v[2], 0x06020c0cu);
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (p >= n) break;
+                int cl = left[p], cr = left[p] + 1;
+                if (left[p] < 0 || left[p] + 1 >= src.cols) {
+                    cl = resolve_index(left[p], src.cols, ZG_BORDER_MIRROR);
+                    cr = resolve_index(left[p] + 1, src.cols, ZG_BORDER_MIRROR);
+                }
+                const int tl = row0[cl], tr = row0[cr], bl = row1[cl], br = row1[cr];
+                const int top_val = tl * (256 - fx[p]) + tr * fx[p];
+                const int bottom_val = bl * (256 - fx[p]) + br * fx[p];
+                packed |= (uint32_t)((top_val * (256 - fy) + bottom_val * fy + 32768) >> 16) << (8 * p);
+            }
+        }
+        uint8_t *o = (uint8_t *)dst.data + (size_t)r * dst.stride + (size_t)c0;
+        if (n == 4 && dword_rows) *(uint32_t *)o = packed;
+        else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (p < n) o[p] = (uint8_t)(packed >> (8 * p));
+        }
+    }
+}
+
 // n equally shaped u8 planes (n = 1: the one image); sizes the caller has already checked
 static int launch_resize_bilinear_u8(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, hipStream_t s) {
     const int tiles_x = (int)ceil_div(dst->cols, 256), tiles_y = (int)ceil_div(dst->rows, 4);
@@ -316,8 +405,17 @@ static int launch_resize_bilinear_u8(const zg_image *src, const zg_image *dst, u
     if (n > MAX_FRAMES_PER_LAUNCH) return -1; // the caller goes frame by frame
     const FrameSpan fr{src_frame, dst_frame};
     const int dword_rows = ((uintptr_t)dst->data % 4 == 0 && dst->stride % 4 == 0 && dst_frame % 4 == 0) ? 1 : 0;
-    hipLaunchKernelGGL(k_resize_bilinear_u8, dim3((unsigned)tiles, n), dim3(256), 0, s, dimg(src), dimg(dst), (float)src->cols / (float)dst->cols,
-                       (float)src->rows / (float)dst->rows, tiles_x, fr, dword_rows);
+    const float rx = (float)src->cols / (float)dst->cols;
+    static const int rows_form = getenv("ZIGNAL_HIP_RESIZE_U8_ROWS") ? atoi(getenv("ZIGNAL_HIP_RESIZE_U8_ROWS")) : 2; // A/B hook of round 5: 0 = the one-row kernel; 4096^2 -> 3413^2: 21.3 / 18.2 / 20.4 us for 0 / 2 / 4 rows
+    if (rows_form > 0 && rx < 2.0f && src->cols >= 8) { // taps computed once for several rows, one 8-byte load per source row and lane
+        const int R = rows_form >= 4 ? 4 : 2;
+        const uint64_t tiles_r = (uint64_t)tiles_x * ceil_div(dst->rows, (uint32_t)(4 * R));
+        if (R == 4) hipLaunchKernelGGL((k_resize_bilinear_u8_rows<4>), dim3((unsigned)tiles_r, n), dim3(256), 0, s, dimg(src), dimg(dst), rx, (float)src->rows / (float)dst->rows, tiles_x, fr, dword_rows);
+        else hipLaunchKernelGGL((k_resize_bilinear_u8_rows<2>), dim3((unsigned)tiles_r, n), dim3(256), 0, s, dimg(src), dimg(dst), rx, (float)src->rows / (float)dst->rows, tiles_x, fr, dword_rows);
+        ZG_HIP(hipGetLastError());
+        return ZG_OK;
+    }
+    hipLaunchKernelGGL(k_resize_bilinear_u8, dim3((unsigned)tiles, n), dim3(256), 0, s, dimg(src), dimg(dst), rx, (float)src->rows / (float)dst->rows, tiles_x, fr, dword_rows);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
