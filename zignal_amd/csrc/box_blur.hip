@@ -29,6 +29,7 @@
 namespace zg {
 
 int copy_impl(const zg_image *src, const zg_image *dst, hipStream_t s);
+int try_box_fused(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, uint32_t radius, bool sharpen, hipStream_t s); // box_fused.hip
 
 // Row pass. The running sum along a row is a sequential f32 chain (f32 addition is not associative and the reference's
 // rounding must be reproduced), so the parallelism is rows x channels. One wave owns 64 rows of one channel: per chunk
@@ -760,6 +761,8 @@ static int box_blur_frames_impl(const zg_image *src, const zg_image *dst, uint32
             });
         }
     }
+    // u8 planes and Rgba(u8), radius 1..3: the SAT stays in LDS (box_fused.hip)
+    if ((rc = try_box_fused(src, dst, n, src_frame, dst_frame, radius, sharpen, s)) >= 0) return rc;
     const size_t plane = sat_plane_stride(src, sat_fused_applies(src, false));
     const size_t sat_frame = (size_t)C * plane; // elements
     const bool buf = sat_frame * sizeof(float) < (1ull << 32);
