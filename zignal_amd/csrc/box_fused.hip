@@ -36,6 +36,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <cstdio>
 
 #pragma clang fp contract(off)
 
@@ -49,7 +50,6 @@ constexpr int BF_RS = 68;       // 16-byte units from one group to the next in L
 constexpr int BF_NP = 2;        // row-prefix ring: block s - 1 is written (at the end of its loaders' second step) while block s - 2 is read
 constexpr int BF_NS = 3;        // SAT ring: block s - 2 is written while the means read s - 3 and its predecessor (history rows)
 constexpr int BF_THREADS = 1024;
-constexpr int BF_NL = 4;        // loader waves
 constexpr int BF_NM = 8;        // mean waves
 constexpr int BF_MAX_R = 3;
 
@@ -70,84 +70,79 @@ struct BoxFusedArgs {
     int nwg;              // strips
     int nwg8;             // ceil(nwg / 8): strips per XCD
     size_t src_frame, dst_frame;
+#ifdef BF_TIMING
+    unsigned long long *timing; // [strip][wave][2]: cycles a wave spent between barriers, cycles it waited in them (tools/build_variant.sh ... -DBF_TIMING)
+#endif
 };
 
 // ---- carries ---------------------------------------------------------------------------------------------------------------------------------------
-// K[(r * nwg + k) * C + ch] = sum over columns < k * W - R1 (strip k's first chained column) of row r, channel ch (0 for k = 0), exact in f32. One workgroup per row, four pixels per
-// thread and step, integer block scan (box_blur.hip's strip_carries_body with strip starts that are not multiples of a power of two).
-template <int PIX>
-__global__ __launch_bounds__(256) void k_box_carries(DImg src, float *K, int nwg, int W, int R1, uint32_t magic, size_t src_frame) {
-    using P = Px<PIX>;
-    constexpr int C = P::C;
-    __shared__ uint32_t wsum[2][4][C];
+// K[(r * nwg + k) * C + ch] = sum over columns < k * W - LEFT (strip k's first chained column) of row r, channel ch (0 for k = 0), exact in f32.
+// One WAVE per row, no LDS and no barrier. A lane takes one PIECE of the row — the W columns from one strip's first chained column to the next one's — and
+// sums it by itself (packed 16-bit pairs for four channels: 13 x 255 < 2^16; v_sad_u8 for one channel), so that the wave needs one scan per 64 pieces
+// (64 W pixels) instead of one per 256 pixels: the first versions (a block scan per 1024 pixels with a barrier; then a wave scan per 256 pixels) took 22 us
+// for a 4096^2 Rgba(u8) frame whatever their loads did — 85 instructions per 256 pixels, bound by issue.
+template <int C, int W, int LEFT>
+__global__ __launch_bounds__(256) void k_box_carries(DImg src, float *K, int nwg, size_t src_frame) {
     src.data = (char *)src.data + (size_t)blockIdx.y * src_frame;
     K += (size_t)blockIdx.y * src.rows * nwg * C;
-    const int r = blockIdx.x, t = threadIdx.x, w = t >> 6;
-    bool vec = false;
-    if constexpr (PIX == ZG_PIXEL_U8) vec = (src.stride & 3) == 0 && ((uintptr_t)src.data & 3) == 0;
-    if constexpr (PIX == ZG_PIXEL_RGBA_U8) vec = (src.stride & 3) == 0 && ((uintptr_t)src.data & 15) == 0;
-    const uint8_t *row = (const uint8_t *)src.data + (size_t)r * src.stride * C;
-    uint32_t carry[C];
+    const int lane = threadIdx.x & 63;
+    const int r = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (r >= src.rows) return;
+    const uint8_t *row = (const uint8_t *)src.data + (size_t)r * src.stride * C; // 4-byte aligned (checked by the host)
+    float *Kr = K + (size_t)r * nwg * C;
+    if (lane < C) Kr[lane] = 0.0f; // strip 0
+    uint32_t carry[C];                // the row's total left of the batch (wave-uniform)
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) carry[ch] = 0;
-    for (int c0 = 0, it = 0; c0 < src.cols; c0 += 1024, ++it) {
-        const int c = c0 + 4 * t;
-        uint32_t px[4]; // the four pixels, one per dword (a channel per byte; one-channel: the byte in bits 0..7)
-        if (vec && c0 + 1024 <= src.cols) { // workgroup-uniform
-            if constexpr (C == 1) {
-                const uint32_t v = *(const uint32_t *)(row + c);
-                px[0] = v & 0xffu; px[1] = (v >> 8) & 0xffu; px[2] = (v >> 16) & 0xffu; px[3] = v >> 24;
-            } else {
-                const uint4 v = *(const uint4 *)(row + (size_t)c * 4);
-                px[0] = v.x; px[1] = v.y; px[2] = v.z; px[3] = v.w;
+    constexpr int ND = W * C / 4; // dwords of a piece
+    static_assert((W * C) % 4 == 0 && (LEFT * C) % 4 == 0, "pieces are whole dwords");
+    // piece p = columns [p W - LEFT, (p + 1) W - LEFT): it ends where strip p + 1 starts, and the last one needed (p = nwg - 2) lies inside the row;
+    // only piece 0 starts left of the row (its first LEFT columns do not exist: masked)
+    for (int p0 = 0; p0 < nwg - 1; p0 += 64) {
+        const int p = min(p0 + lane, nwg - 2);
+        const uint32_t *d = (const uint32_t *)(row + ((ptrdiff_t)p * W - LEFT) * C);
+        uint32_t v[ND];
+        if (p0 == 0) { // wave-uniform: lane 0's piece starts at column -LEFT
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                const bool real = p > 0 || i >= LEFT * C / 4;
+                v[i] = d[real ? i : LEFT * C / 4] & (real ? 0xffffffffu : 0u);
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { // clamped, unpredicated
-                const size_t cc = (size_t)min(c + k, src.cols - 1);
-                uint32_t v;
-                if constexpr (C == 1) v = row[cc];
-                else v = *(const uint32_t *)(row + cc * 4);
-                px[k] = c + k < src.cols ? v : 0u;
+            for (int i = 0; i < ND; ++i) v[i] = d[i];
+        }
+        uint32_t x[C]; // my piece's sum per channel
+        if constexpr (C == 4) { // a dword is a pixel: ch0 | ch2 << 16 and ch1 | ch3 << 16 as packed 16-bit sums
+            uint32_t e = 0, o = 0;
+#pragma unroll
+            for (int i = 0; i < ND; ++i) {
+                e += __builtin_amdgcn_perm(0, v[i], 0x0c020c00);
+                o += __builtin_amdgcn_perm(0, v[i], 0x0c030c01);
             }
-        }
-        uint32_t x[C];
+            x[0] = e & 0xffffu; x[1] = o & 0xffffu; x[2] = e >> 16; x[3] = o >> 16;
+        } else {
+            uint32_t t = 0;
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-            x[ch] = ((px[0] >> (8 * ch)) & 0xffu) + ((px[1] >> (8 * ch)) & 0xffu) + ((px[2] >> (8 * ch)) & 0xffu) + ((px[3] >> (8 * ch)) & 0xffu);
-            uint32_t y = x[ch]; // inclusive scan over the wave
-            y += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0x111, 0xf, 0xf, true);  // row_shr:1
-            y += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0x112, 0xf, 0xf, true);  // row_shr:2
-            y += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0x114, 0xf, 0xf, true);  // row_shr:4
-            y += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0x118, 0xf, 0xf, true);  // row_shr:8
-            y += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1, 3
-            y += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2, 3
-            if ((t & 63) == 63) wsum[it & 1][w][ch] = y;
-            x[ch] = y - x[ch]; // exclusive
+            for (int i = 0; i < ND; ++i) t = __builtin_amdgcn_sad_u8(v[i], 0u, t);
+            x[0] = t;
         }
-        __syncthreads(); // one barrier per step: the totals alternate between two buffers
-        // the strip start, if any, in (c, c + 4]: strip k starts at k * W - R1
-        const uint32_t k = __umulhi((uint32_t)(c + 4 + R1), magic); // floor((c + 4 + R1) / W), exact below 2^32 / W
-        const int bpos = (int)k * W - R1;
-        const bool boundary = bpos > c && k >= 1 && (int)k < nwg && c < src.cols;
-        const int j = bpos - c; // 1..4 pixels of mine lie left of it
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) {
-            const uint32_t w0 = wsum[it & 1][0][ch], w1 = wsum[it & 1][1][ch], w2 = wsum[it & 1][2][ch], w3 = wsum[it & 1][3][ch];
-            uint32_t base = carry[ch] + x[ch];
-            if (w > 0) base += w0;
-            if (w > 1) base += w1;
-            if (w > 2) base += w2;
-            if (boundary) {
-                uint32_t v = base;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i < j) v += (px[i] >> (8 * ch)) & 0xffu;
-                K[((size_t)r * nwg + k) * C + ch] = (float)v; // < 2^24: exact
-            }
-            carry[ch] += w0 + w1 + w2 + w3;
+        for (int ch = 0; ch < C; ++ch) { // inclusive scan over the wave
+            uint32_t t = x[ch];
+            t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x111, 0xf, 0xf, true);  // row_shr:1
+            t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x112, 0xf, 0xf, true);  // row_shr:2
+            t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xf, 0xf, true);  // row_shr:4
+            t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x118, 0xf, 0xf, true);  // row_shr:8
+            t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1, 3
+            t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2, 3
+            x[ch] = t + carry[ch];                                                         // everything left of strip p + 1: < 2^24, exact as f32
+            carry[ch] += (uint32_t)__builtin_amdgcn_readlane((int)t, 63);
         }
-        if (c0 == 0 && t < C) K[(size_t)r * nwg * C + t] = 0.0f; // strip 0
+        if (p0 + lane < nwg - 1) {
+            if constexpr (C == 4) *(float4 *)(Kr + (size_t)(p + 1) * 4) = make_float4((float)x[0], (float)x[1], (float)x[2], (float)x[3]);
+            else Kr[p + 1] = (float)x[0];
+        }
     }
 }
 
@@ -165,6 +160,23 @@ __device__ __forceinline__ float box_quot(float sum, const BoxDiv &d) {
 }
 constexpr float BF_BIAS = 0x1p-10f; // see the header: turns v_cvt_pk_u8_f32's nearest-even into meta.clamp's half-away on this value set
 
+#ifdef BF_TIMING
+struct BfTimer {
+    unsigned long long busy = 0, wait = 0, last = 0;
+    __device__ __forceinline__ void sync() {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        __syncthreads();
+        const unsigned long long t1 = __builtin_readcyclecounter();
+        if (last) busy += t0 - last;
+        wait += t1 - t0;
+        last = t1;
+    }
+};
+#define BF_SYNC() bf_timer.sync()
+#else
+#define BF_SYNC() __syncthreads()
+#endif
+
 // ---- the fused kernel -------------------------------------------------------------------------------------------------------------------------------
 // The byte of a mean. Only the BYTE has to equal the reference's, and a window sum is an integer (sums and differences of integer-valued floats): sum / area
 // is then an exact tie k + 1/2 or at least 1 / (2 area) >= 1 / 98 away from one, far more than the error of one multiplication by the correctly rounded
@@ -174,6 +186,9 @@ constexpr float BF_BIAS = 0x1p-10f; // see the header: turns v_cvt_pk_u8_f32's n
 template <int C, bool EDGE>
 __device__ __forceinline__ void box_loader(const BoxFusedArgs &A, float4 (*Pr)[BF_G][BF_RS], int li, int lane, int k, const uint8_t *src, size_t spitch, const float *K, int a0,
                                            int nblocks, int nsteps) {
+#ifdef BF_TIMING
+    BfTimer bf_timer;
+#endif
     const int rows = A.src.rows, cols = A.src.cols;
     const int par = li & 1, h = li >> 1;    // my blocks: par, par + 2, ...; my rows of every four-row group: 2h, 2h + 1
     const int q = lane & 3, rg = lane >> 2; // my 16 bytes of the strip's rows, my four-row group of a block
@@ -260,7 +275,7 @@ __device__ __forceinline__ void box_loader(const BoxFusedArgs &A, float4 (*Pr)[B
     fetch(par, 0);
     fetch(par, 1);
     int done = 0;
-    if (par == 1) { __syncthreads(); done = 1; }
+    if (par == 1) { BF_SYNC(); done = 1; }
     auto step_a = [&](float (&va)[16]) {
 #if !defined(BF_NO_LOADERS) && !defined(BF_NO_PUBLISH)
         prefixes(0, va);
@@ -284,12 +299,12 @@ __device__ __forceinline__ void box_loader(const BoxFusedArgs &A, float4 (*Pr)[B
     const float *kq = K + ((size_t)min(r_next, rows - 1) * A.nwg + k) * C;
     for (; blk + 2 < nfull; blk += 2) {
         float va[16];
-        __syncthreads(); // step blk
+        BF_SYNC(); // step blk
         step_a(va);
 #if !defined(BF_NO_LOADERS) && !defined(BF_NO_FETCH)
         fetch_at(rp, kq, 0);
 #endif
-        __syncthreads(); // step blk + 1
+        BF_SYNC(); // step blk + 1
         step_b(va);
 #if !defined(BF_NO_LOADERS) && !defined(BF_NO_FETCH)
         fetch_at(rp + spitch, kq + (size_t)A.nwg * C, 1);
@@ -300,15 +315,18 @@ __device__ __forceinline__ void box_loader(const BoxFusedArgs &A, float4 (*Pr)[B
     }
     for (; blk < nblocks; blk += 2) { // the last blocks: what they fetch is partial or past the end (clamped, never used)
         float va[16];
-        __syncthreads(); // step blk
+        BF_SYNC(); // step blk
         step_a(va);
         fetch(blk + 2, 0);
-        __syncthreads(); // step blk + 1
+        BF_SYNC(); // step blk + 1
         step_b(va);
         fetch(blk + 2, 1);
         done += 2;
     }
-    for (; done < nsteps; ++done) __syncthreads();
+    for (; done < nsteps; ++done) BF_SYNC();
+#ifdef BF_TIMING
+    if (lane == 0) { A.timing[(k * 16 + (li == 3 ? 7 : li + 1)) * 2] = bf_timer.busy; A.timing[(k * 16 + (li == 3 ? 7 : li + 1)) * 2 + 1] = bf_timer.wait; }
+#endif
 }
 
 template <int C, int R, bool SHARPEN>
@@ -338,13 +356,16 @@ __global__ __launch_bounds__(BF_THREADS) void k_box_fused(BoxFusedArgs A) {
     const int a0 = x0 - LEFT;      // first chained column (may be negative: those columns hold zeros, which is what the reference's c1 == 0 case reads)
 
     if (wave == 0) { // ---- the chain ---------------------------------------------------------------------------------------------------------------
+#ifdef BF_TIMING
+        BfTimer bf_timer;
+#endif
         float run = 0.0f;
         const int pl = bf_pos(lane);
-        __syncthreads();
-        __syncthreads();
+        BF_SYNC();
+        BF_SYNC();
         int pslot = 0, sslot = 0;
         for (int blk = 0; blk < nblocks; ++blk) {
-            __syncthreads(); // step blk + 2
+            BF_SYNC(); // step blk + 2
 #ifdef BF_NO_CHAIN // removal timings (tools/build_variant.sh): profiles/r06_box_removal.txt
             continue;
 #endif
@@ -365,7 +386,10 @@ __global__ __launch_bounds__(BF_THREADS) void k_box_fused(BoxFusedArgs A) {
             pslot = pslot + 1 == BF_NP ? 0 : pslot + 1;
             sslot = sslot + 1 == BF_NS ? 0 : sslot + 1;
         }
-        __syncthreads(); // step nblocks + 2
+        BF_SYNC(); // step nblocks + 2
+#ifdef BF_TIMING
+        if (lane == 0) { A.timing[(k * 16) * 2] = bf_timer.busy; A.timing[(k * 16) * 2 + 1] = bf_timer.wait; }
+#endif
         return;
     }
 
@@ -381,11 +405,12 @@ __global__ __launch_bounds__(BF_THREADS) void k_box_fused(BoxFusedArgs A) {
     // two of a block's sixteen groups each. SIMD 1: waves 5, 9, 13 (+ loader 1); SIMD 2: 6, 10, 14 (+ loader 2); SIMD 3: 11, 15 (+ loaders 3, 7)
     const int mi = wave == 5 ? 0 : wave == 9 ? 1 : wave == 13 ? 2 : wave == 6 ? 3 : wave == 10 ? 4 : wave == 14 ? 5 : wave == 11 ? 6 : 7;
     const int gfirst = 2 * mi;
-    // my output byte column inside the strip. The byte columns past the strip's outputs (the re-chained neighbours) have nothing to store: their lanes
-    // repeat what the quads W * C - QDEAD .. do, address included, so that a store needs no execution mask (the same dword twice into one line)
-    constexpr int QDEAD = 64 - W * C; // 8 for one channel, 8 + 8 R for four
-    const bool tail_strip = (x0 + W) > cols || (C == 1 && (cols & 3) != 0 && x0 + W >= (cols & ~3)); // workgroup-uniform: the image ends inside my strip
-    const int m = (lane >= W * C && !tail_strip) ? lane - QDEAD : lane;
+    // my output byte column inside the strip. The byte columns past the strip's outputs (the re-chained neighbours; in the image's last strip also the
+    // columns past its edge) have nothing to store: their lanes repeat what quad 0 does, address included, so that a store needs no execution mask
+    // (the same dword several times into one line). Only a row whose last bytes are not a whole dword (one channel, cols % 4 != 0) takes the careful path.
+    const int live_bytes = min(W, cols - x0) * C;      // workgroup-uniform
+    const bool tail_strip = (live_bytes & 3) != 0;
+    const int m = (lane >= live_bytes && !tail_strip) ? (lane & 3) : lane;
     const int pxi = m / C, ch = m - pxi * C;  // its pixel and channel
     const int c = x0 + pxi;
     const bool live = m < W * C && c < cols;
@@ -526,15 +551,18 @@ __global__ __launch_bounds__(BF_THREADS) void k_box_fused(BoxFusedArgs A) {
         }
     };
 
-    __syncthreads();
-    __syncthreads();
-    __syncthreads();
+#ifdef BF_TIMING
+    BfTimer bf_timer;
+#endif
+    BF_SYNC();
+    BF_SYNC();
+    BF_SYNC();
     int sslot = 0;
     uint32_t so = 0, so_prev = (BF_NS - 1) * SLOT_BYTES;
     uint8_t *orow = dst + ((ptrdiff_t)(4 * gfirst) - R) * (ptrdiff_t)dpitch; // first output row of my groups of block 0 (negative rows are never touched)
     const uint8_t *srow = src + ((ptrdiff_t)(4 * gfirst) - R) * (ptrdiff_t)spitch;
     for (int blk = 0; blk < nblocks; ++blk) {
-        __syncthreads(); // step blk + 3
+        BF_SYNC(); // step blk + 3
 #ifdef BF_NO_MEANS
         continue;
 #endif
@@ -551,6 +579,9 @@ __global__ __launch_bounds__(BF_THREADS) void k_box_fused(BoxFusedArgs A) {
         srow += (size_t)BF_B * spitch;
     }
     // the clipped rows at the bottom: the ring still holds the last two blocks (every row they read is >= bot_start - R - 1)
+#ifdef BF_TIMING
+    if (lane == 0) { A.timing[(k * 16 + wave) * 2] = bf_timer.busy; A.timing[(k * 16 + wave) * 2 + 1] = bf_timer.wait; }
+#endif
     for (int r = max(bot_start, 0) + mi; r < rows; r += BF_NM) generic_row(r);
 }
 
@@ -599,13 +630,18 @@ int try_box_fused(const zg_image *src, const zg_image *dst, uint32_t n, size_t s
     }
     float *K = nullptr;
     if ((rc = scratch_alloc((void **)&K, kbytes, s))) { if (copy) scratch_free(copy, s); return rc; }
-    const uint32_t magic = (uint32_t)(((1ull << 32) + (uint32_t)W - 1) / (uint32_t)W);
+#ifdef BF_TIMING
+    static unsigned long long *timing = nullptr;
+    if (!timing) (void)hipMalloc((void **)&timing, 1024 * 16 * 2 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(timing, 0, 1024 * 16 * 2 * sizeof(unsigned long long), s);
+    BoxFusedArgs A{dimg(&from), dimg(dst), K, nwg, (int)ceil_div((unsigned)nwg, 8u), from_frame, dst_frame, timing};
+#else
     BoxFusedArgs A{dimg(&from), dimg(dst), K, nwg, (int)ceil_div((unsigned)nwg, 8u), from_frame, dst_frame};
+#endif
     const dim3 grid(ZG_XCD_ORDER ? (unsigned)A.nwg8 * 8u : (unsigned)nwg, n);
     auto launch = [&](auto ctag, auto rtag) {
         constexpr int CC = decltype(ctag)::value, RR = decltype(rtag)::value;
-        constexpr int PIX = CC == 4 ? ZG_PIXEL_RGBA_U8 : ZG_PIXEL_U8;
-        hipLaunchKernelGGL((k_box_carries<PIX>), dim3(from.rows, n), dim3(256), 0, s, dimg(&from), K, nwg, W, box_strip_left(CC, RR), magic, from_frame);
+        hipLaunchKernelGGL((k_box_carries<CC, box_strip_w(CC, RR), box_strip_left(CC, RR)>), dim3(ceil_div(from.rows, 4u), n), dim3(256), 0, s, dimg(&from), K, nwg, from_frame);
         if (sharpen) hipLaunchKernelGGL((k_box_fused<CC, RR, true>), grid, dim3(BF_THREADS), 0, s, A);
         else hipLaunchKernelGGL((k_box_fused<CC, RR, false>), grid, dim3(BF_THREADS), 0, s, A);
     };
@@ -619,6 +655,21 @@ int try_box_fused(const zg_image *src, const zg_image *dst, uint32_t n, size_t s
     if (C == 4) by_radius(std::integral_constant<int, 4>{});
     else by_radius(std::integral_constant<int, 1>{});
     const hipError_t e = hipGetLastError();
+#ifdef BF_TIMING
+    {
+        static int calls = 0;
+        if (++calls % 50 == 0) { // a warm call
+            (void)hipStreamSynchronize(s);
+            static unsigned long long host[1024 * 16 * 2];
+            (void)hipMemcpy(host, timing, sizeof(host), hipMemcpyDeviceToHost);
+            for (int kk : {0, 1, nwg / 2, nwg - 1}) {
+                printf("strip %d of %d (C=%d r=%u): busy / wait cycles per wave:", kk, nwg, C, radius);
+                for (int w = 0; w < 16; ++w) printf(" %d:%llu/%llu", w, host[(kk * 16 + w) * 2], host[(kk * 16 + w) * 2 + 1]);
+                printf("\n");
+            }
+        }
+    }
+#endif
     scratch_free(K, s);
     if (copy) scratch_free(copy, s);
     if (e != hipSuccess) { set_error("boxBlur: launch failed: %s", hipGetErrorString(e)); return ZG_ERR_HIP; }
