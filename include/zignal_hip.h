@@ -487,8 +487,8 @@ typedef struct zg_step {
     int use_nms;                 /* EDGES: Shen-Castan's use_nms (hysteresis stays at its default, on, as in the CLI) */
 } zg_step;
 /* sizeof(zg_step) as this library was built. zg_step grows with the recipe language (round 4 added thirteen fields) and carries no size field of
- * its own: a binding compares its own struct's size with this at load time and refuses to run on a mismatch (zignal_amd/_lib.py, the Zig shim's
- * init and zignal_hip.hpp do), so a caller built against another header can never hand over arrays with the wrong stride. */
+ * its own: a binding compares its own struct's size with this and refuses to run on a mismatch (zignal_amd/_lib.py at load time, zignal_hip.hpp in Pipeline's
+ * constructor, the Zig shim at the head of Pipeline.run / runMulti / outShape), so a caller built against another header can never hand over arrays with the wrong stride. */
 ZG_API size_t zg_sizeof_step(void);
 /* Host only: shape and type of the frames after the steps (what dst_frames of zg_batch_pipeline must hold, n_frames times). */
 ZG_API int zg_batch_pipeline_shape(uint32_t rows, uint32_t cols, int pixel, int space, const zg_step *steps, uint32_t n_steps,

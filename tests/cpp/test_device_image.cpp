@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <vector>
 
 extern "C" {
@@ -38,7 +39,8 @@ struct Events {
 };
 
 int main(int argc, char **argv) {
-    const bool quick = argc > 1 && std::strcmp(argv[1], "quick") == 0;
+    const bool virt = argc > 1 && std::strcmp(argv[1], "virtual") == 0; // quick sizes, but seven frames for the zg_multi section (two pieces per shard at world 3)
+    const bool quick = virt || (argc > 1 && std::strcmp(argv[1], "quick") == 0);
     if (zg_init(0) != ZG_OK) { std::printf("no gfx950 device: %s\n", zg_last_error()); return 77; }
     const float sigma = 0.6f; // gaussianBlur(0.6): the 5 x 5 kernel BASELINE.json names
     Stream stream = Stream::create();
@@ -190,7 +192,7 @@ int main(int argc, char **argv) {
 
     { // the node's GPUs from this one thread (zg_multi): on a one-GPU box the context has one device; with ZIGNAL_HIP_MULTI_LOOPBACK the
       // root's shard makes its round trip through an RCCL communicator (ncclCommInitAll, grouped ncclSend / ncclRecv) all the same
-        const uint32_t n = quick ? 3 : 7, rows = 270, cols = 480;
+        const uint32_t n = quick && !virt ? 3 : 7, rows = 270, cols = 480;
         std::vector<uint8_t> frames((size_t)n * rows * cols * 4);
         for (auto &b : frames) b = (uint8_t)lcg(seed);
         void *dsrc = nullptr, *dref = nullptr, *dout = nullptr;
@@ -354,6 +356,71 @@ int main(int argc, char **argv) {
             std::printf("multi_world_gt_1=skipped (%d device%s visible)\n", zg_device_count(), zg_device_count() == 1 ? "" : "s");
         }
         unsetenv("ZIGNAL_HIP_MULTI_LOOPBACK");
+        // Virtual worlds: with ZIGNAL_HIP_MULTI_VIRTUAL the same device may be listed N times, and ZIGNAL_HIP_RCCL_LIBRARY binds
+        // tests/c/rccl_double.cpp instead of librccl — every world > 1 line of zg_multi.cpp (owners' staging buffers and offsets, the grouped send / receive
+        // pairs of both communicators, per-piece events, piece arithmetic) then runs on this one GPU, against the one-device result; then a send fails
+        // half-way through a batch: the call must fail, the context must refuse further work, and a fresh context must be fine.
+        if (getenv("ZIGNAL_HIP_MULTI_VIRTUAL") && getenv("ZIGNAL_HIP_RCCL_LIBRARY")) {
+            typedef void (*stats_fn)(uint64_t *);
+            typedef void (*reset_fn)();
+            void *dbl = dlopen(getenv("ZIGNAL_HIP_RCCL_LIBRARY"), RTLD_NOW | RTLD_LOCAL);
+            EXPECT(dbl != nullptr);
+            stats_fn stats = dbl ? (stats_fn)dlsym(dbl, "rccl_double_stats") : nullptr;
+            reset_fn reset = dbl ? (reset_fn)dlsym(dbl, "rccl_double_reset") : nullptr;
+            EXPECT(stats && reset);
+            for (int world : {2, 3, 8}) {
+                for (const char *chunks : {"1", "4", "8"}) {
+                    setenv("ZIGNAL_HIP_MULTI_CHUNKS", chunks, 1);
+                    std::vector<int> devs((size_t)world, 0);
+                    zg_multi ctx = nullptr;
+                    check(zg_multi_create(devs.data(), world, &ctx));
+                    EXPECT(zg_multi_device_count(ctx) == world);
+                    if (reset) reset();
+                    std::vector<uint8_t> fill(out_bytes, 0x5A);
+                    check(zg_memcpy_h2d(dout, fill.data(), out_bytes, nullptr));
+                    float t[3] = {0, 0, 0};
+                    check(zg_multi_batch_blur_resize(ctx, dsrc, n, rows, cols, ZG_PIXEL_RGBA_U8, sigma, dout, rows / 2, cols / 2, &bil, t));
+                    check(zg_memcpy_d2h(got.data(), dout, out_bytes, nullptr));
+                    EXPECT(got == want);
+                    uint64_t st[5] = {0, 0, 0, 0, 0};
+                    if (stats) stats(st);
+                    // every frame that is not the root's crosses once in each direction
+                    const uint32_t root_frames = n / (uint32_t)world + (n % (uint32_t)world ? 1u : 0u);
+                    EXPECT(st[0] == st[1] && st[4] == st[0] && st[0] >= 2);
+                    EXPECT(st[2] == (uint64_t)(n - root_frames) * ((uint64_t)rows * cols * 4 + (uint64_t)(rows / 2) * (cols / 2) * 4));
+                    Pipeline recipe;
+                    recipe.gaussianBlur(sigma).resize(rows / 2, cols / 2);
+                    check(zg_memcpy_h2d(dout, fill.data(), out_bytes, nullptr));
+                    recipe.runMulti(ctx, (const Rgba<uint8_t> *)dsrc, n, rows, cols, dout, t);
+                    check(zg_memcpy_d2h(got.data(), dout, out_bytes, nullptr));
+                    EXPECT(got == want);
+                    check(zg_multi_destroy(ctx));
+                    std::printf("multi_virtual_world%d_%s_pieces=ok sends=%llu bytes=%llu\n", world, chunks, (unsigned long long)st[0], (unsigned long long)st[2]);
+                }
+            }
+            { // a send of piece 1 fails: world 3, four pieces per shard -> sends 1, 2 are piece 0's scatter, 3, 4 its gather, 5 piece 1's scatter
+                setenv("ZIGNAL_HIP_MULTI_CHUNKS", "4", 1);
+                const int devs[3] = {0, 0, 0};
+                zg_multi ctx = nullptr;
+                check(zg_multi_create(devs, 3, &ctx));
+                if (reset) reset();
+                setenv("RCCL_DOUBLE_FAIL_SEND", n >= 7 ? "5" : "3", 1); // three frames: one piece per shard, so its gather fails instead
+                EXPECT(zg_multi_batch_blur_resize(ctx, dsrc, n, rows, cols, ZG_PIXEL_RGBA_U8, sigma, dout, rows / 2, cols / 2, &bil, nullptr) == ZG_ERR_HIP);
+                EXPECT(std::strstr(zg_last_error(), "RCCL error") != nullptr);
+                unsetenv("RCCL_DOUBLE_FAIL_SEND");
+                // poisoned: no later call may trust the streams or the communicators
+                EXPECT(zg_multi_batch_blur_resize(ctx, dsrc, n, rows, cols, ZG_PIXEL_RGBA_U8, sigma, dout, rows / 2, cols / 2, &bil, nullptr) == ZG_ERR_INVALID_ARGUMENT);
+                EXPECT(std::strstr(zg_last_error(), "failed half-way") != nullptr);
+                check(zg_multi_destroy(ctx)); // drains what was enqueued
+                check(zg_multi_create(devs, 3, &ctx));
+                check(zg_multi_batch_blur_resize(ctx, dsrc, n, rows, cols, ZG_PIXEL_RGBA_U8, sigma, dout, rows / 2, cols / 2, &bil, nullptr));
+                check(zg_memcpy_d2h(got.data(), dout, out_bytes, nullptr));
+                EXPECT(got == want);
+                check(zg_multi_destroy(ctx));
+                std::printf("multi_virtual_failure_injection=ok\n");
+            }
+            unsetenv("ZIGNAL_HIP_MULTI_CHUNKS");
+        }
         zg_multi bad = nullptr;
         EXPECT(zg_multi_create(nullptr, 99, &bad) == ZG_ERR_INVALID_ARGUMENT && bad == nullptr); // more devices than the box has
         check(zg_free(dsrc)); check(zg_free(dref)); check(zg_free(dout));

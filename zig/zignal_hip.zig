@@ -102,8 +102,13 @@ pub const Pipeline = struct {
         s.dst_space = dst_space;
         return s;
     }
+    /// zg_step carries no size field: a library built from another header must not be handed arrays of this file's ZgStep (zignal_hip.h: zg_sizeof_step)
+    fn checkStepAbi() !void {
+        if (c.zg_sizeof_step() != @sizeOf(c.ZgStep)) return error.AbiMismatch;
+    }
     /// rows, cols, pixel type and colour space of the frames after the steps
     pub fn outShape(self: Pipeline, rows: u32, cols: u32, pixel: c_int, space: c_int) !struct { rows: u32, cols: u32, pixel: c_int, space: c_int } {
+        try checkStepAbi();
         var r: u32 = 0;
         var cc: u32 = 0;
         var p: c_int = 0;
@@ -112,11 +117,13 @@ pub const Pipeline = struct {
         return .{ .rows = r, .cols = cc, .pixel = p, .space = sp };
     }
     pub fn run(self: Pipeline, src: *const anyopaque, n_frames: u32, rows: u32, cols: u32, pixel: c_int, space: c_int, dst: *anyopaque, stream: ?*anyopaque) !void {
+        try checkStepAbi();
         try check(c.zg_batch_pipeline(src, n_frames, rows, cols, pixel, space, self.steps.ptr, @intCast(self.steps.len), dst, stream));
     }
     /// The same over every device of a zg_multi context (zg_multi_batch_pipeline): src / dst live on the context's root device; frames shard in
     /// contiguous blocks, no halo, no collective on the data path. Synchronous.
     pub fn runMulti(self: Pipeline, ctx: ?*anyopaque, src_root: *const anyopaque, n_frames: u32, rows: u32, cols: u32, pixel: c_int, space: c_int, dst_root: *anyopaque, times_ms: ?*[3]f32) !void {
+        try checkStepAbi();
         try check(c.zg_multi_batch_pipeline(ctx, src_root, n_frames, rows, cols, pixel, space, self.steps.ptr, @intCast(self.steps.len), dst_root, times_ms));
     }
 };

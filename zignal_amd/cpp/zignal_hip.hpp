@@ -483,6 +483,12 @@ template <typename T> struct ImagePyramid {
 // batch where the library has a batched kernel, fused neighbours where it has a fused one; equal to the per-frame methods bit for bit).
 struct Pipeline {
     std::vector<zg_step> steps;
+    // zg_step carries no size field: a library built from another header must not be handed arrays of this header's struct (zignal_hip.h: zg_sizeof_step)
+    Pipeline() {
+        if (zg_sizeof_step() != sizeof(zg_step))
+            throw Error(ZG_ERR_INVALID_ARGUMENT, "libzignal_hip: sizeof(zg_step) is " + std::to_string(zg_sizeof_step()) + " in the library, " + std::to_string(sizeof(zg_step)) +
+                                                     " in this header: rebuild one of them");
+    }
     Pipeline &gaussianBlur(float sigma) { zg_step s{}; s.kind = ZG_STEP_GAUSSIAN_BLUR; s.sigma = sigma; steps.push_back(s); return *this; }              // cli/blur.zig:113-120
     Pipeline &boxBlur(uint32_t radius) { zg_step s{}; s.kind = ZG_STEP_BOX_BLUR; s.radius = radius; steps.push_back(s); return *this; }                  // cli/blur.zig:109-112
     Pipeline &medianBlur(uint32_t radius = 1) { zg_step s{}; s.kind = ZG_STEP_MEDIAN_BLUR; s.radius = radius; steps.push_back(s); return *this; }          // cli/blur.zig:116-123

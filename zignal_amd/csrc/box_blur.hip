@@ -656,7 +656,8 @@ int sat_planes_impl(const zg_image *src, float *sat, hipStream_t s, bool integer
 // Integral images of up to three single-channel planes (u8 or integer-valued f32) of one size, one launch pair for all of them.
 int sat_planes_multi(const zg_image *const *srcs, float *const *sats, int count, hipStream_t s) {
     const zg_image *a = srcs[0];
-    bool ok = count >= 1 && count <= 3 && a->cols <= 65536 && getenv("ZIGNAL_HIP_SAT_UNFUSED") == nullptr;
+    static const bool fused_off = getenv("ZIGNAL_HIP_SAT_UNFUSED") != nullptr;
+    bool ok = count >= 1 && count <= 3 && a->cols <= 65536 && !fused_off;
     for (int i = 0; i < count && ok; ++i)
         ok = srcs[i]->rows == a->rows && srcs[i]->cols == a->cols && (srcs[i]->pixel == ZG_PIXEL_U8 || srcs[i]->pixel == ZG_PIXEL_F32);
     if (!ok) { // one at a time

@@ -631,7 +631,8 @@ __global__ __launch_bounds__(256) void k_cols_bilinear_u8(PyrLevelArgs a, TapsCo
 // (the caller blurs and resizes): contiguous-enough u8 planes as k_rows_u8f wants them, a reduction, odd tap counts <= 65, the f32-exact case.
 int try_pyramid_level_u8(const zg_image *src, const zg_image *level, const int32_t *taps, int nk, hipStream_t s) {
     if (src->pixel != ZG_PIXEL_U8 || level->pixel != ZG_PIXEL_U8 || nk < 1 || nk > B2_NKMAX || !(nk & 1)) return -1;
-    if (getenv("ZIGNAL_HIP_NO_PYRAMID_FUSE")) return -1; // A/B hook of round 5
+    static const bool no_fuse = getenv("ZIGNAL_HIP_NO_PYRAMID_FUSE") != nullptr; // A/B hook of round 5, read once
+    if (no_fuse) return -1;
     // A lane here owns the two columns of ONE output column, the dense column pass the two columns of a dword: 2 / scale of its arithmetic. Below
     // a reduction by 2 the dense pass and the separate resize are cheaper (thresholds 1 / 1.7 / 2 / 2.4 / 2.9 measured: profiles/r05_experiments.txt).
     if (src->cols < 2 * level->cols) return -1;
@@ -729,7 +730,8 @@ int resize_impl_bilinear_u8(const zg_image *src, const zg_image *dst, hipStream_
 // one and the dense levels on another (two independent batches, each with its own row-pass launch and scratch block: no event between the streams). sigmas[i] <= 0.5 (a plain resize), other pixel types,
 // shapes the packed kernels exclude, kernels of <= 7 taps (the one-pass stream kernel is better there) and > 33 are left alone. -1: nothing was done.
 int try_pyramid_levels_u8(const zg_image *src, const zg_image *levels, const float *sigmas, uint32_t n, uint8_t *handled, int which, hipStream_t s) {
-    if (getenv("ZIGNAL_HIP_NO_PYRAMID_BATCH")) return -1; // A/B hook of round 5
+    static const bool no_batch = getenv("ZIGNAL_HIP_NO_PYRAMID_BATCH") != nullptr; // A/B hook of round 5, read once
+    if (no_batch) return -1;
     if (src->pixel != ZG_PIXEL_U8 || src->cols % 16 || src->stride % 16 || ((uintptr_t)src->data & 15) || src->cols < 256 || (uint64_t)src->cols > 0x3fffffffu || src->rows < 2) return -1;
     struct Plan { uint32_t level; int nk, half, hp, wide; bool fused; int32_t taps[33]; };
     Plan plan[PYR_MAX_JOBS];

@@ -439,7 +439,8 @@ static int launch_stream(const StreamJob &j, const int32_t *ix, const int32_t *i
     const uint64_t items = (uint64_t)a.strips_x * a.strips_y * j.n_frames;
     if (items > 0x7fffffffu) return -1;
     // row taps symmetric with unit ends: the folded row pass (the CLAMP instantiations — tap sums past 256 — keep the plain one)
-    bool unit = ix[0] == 1 && iy[0] == 1 && iy[NK - 1] == 1 && !getenv("ZIGNAL_HIP_STREAM_NO_FOLD"); // A/B hook of this round
+    static const bool no_fold = getenv("ZIGNAL_HIP_STREAM_NO_FOLD") != nullptr; // A/B hook of round 5, read once
+    bool unit = ix[0] == 1 && iy[0] == 1 && iy[NK - 1] == 1 && !no_fold;
     for (int i = 0; i < NK; ++i) unit = unit && ix[i] == ix[NK - 1 - i];
     if constexpr (!CLAMP) {
         if (unit) {

@@ -74,6 +74,9 @@ __global__ __launch_bounds__(64) void k_sep_tile_f32(TileF32Args a, TapsSF<NK> k
     const int rb = a.row_bytes, x0 = tx * 1024;
     const int voff = x0 + 16 * lx;
     const int last_lane = (min(rb - x0, 1024) >> 4) - 1;
+    // What the lanes past the row's end load through the whole-plane descriptor (its range check sees the plane, not the row): the last unit again.
+    // Their values are never used, but an offset past the row reads the next row — and, in the plane's last row, up to 1 KiB past the plane's end.
+    const int voff_ld = min(voff, x0 + 16 * last_lane);
     const bool left_edge = tx == 0, right_edge = x0 + 1024 >= rb;
     const int border = a.border;
     const int off_left = left_edge ? rb - 4 * HB : x0 - 4 * HB, off_right = right_edge ? 0 : x0 + 1024; // at the plane's edges: the other end (.wrap)
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(64) void k_sep_tile_f32(TileF32Args a, TapsSF<NK> k
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
                 const int so = (int)(s0 + (uint32_t)i * (uint32_t)a.src_pitch);
-                in[i].v = __builtin_amdgcn_raw_buffer_load_b128(src_all, voff, so, 0);
+                in[i].v = __builtin_amdgcn_raw_buffer_load_b128(src_all, voff_ld, so, 0);
                 if constexpr (!OUTER) HaloLoad<HB>::run(src_all, lx == 0 ? off_left : off_right, so, in[i].h);
             }
             if constexpr (OUTER) {
@@ -231,7 +234,8 @@ static int launch_tile_f32(const zg_image *src, const zg_image *dst, uint32_t n,
 int try_sep_tile_f32(const zg_image *src, const zg_image *dst, uint32_t n, const float *fx, const float *fy, int nk, uint32_t skipx, uint32_t skipy,
                        int border, hipStream_t s) {
     if (n == 0 || n > SF_MAX_PLANES || (nk != 3 && nk != 5 && nk != 7) || (skipx | skipy)) return -1;
-    if (getenv("ZIGNAL_HIP_NO_TILE_F32")) return -1; // A/B hook of this round (the LDS-tiled kernel)
+    static const bool no_tile = getenv("ZIGNAL_HIP_NO_TILE_F32") != nullptr; // A/B hook of round 5 (the LDS-tiled kernel), read once
+    if (no_tile) return -1;
     for (uint32_t p = 0; p < n; ++p) {
         if (src[p].pixel != ZG_PIXEL_F32 || dst[p].pixel != ZG_PIXEL_F32) return -1;
         if (src[p].rows != src->rows || src[p].cols != src->cols || dst[p].rows != src->rows || dst[p].cols != src->cols) return -1;
@@ -242,8 +246,7 @@ int try_sep_tile_f32(const zg_image *src, const zg_image *dst, uint32_t n, const
     if (src->cols < 64 || src->rows < 16 || (uint64_t)src->cols * 4 > 0x3fffffffu) return -1;
     if ((uint64_t)src->stride * 4 > 0x7fffffffu || (uint64_t)dst->stride * 4 > 0x7fffffffu) return -1;
     if ((src->cols * 4u) % 1024u == 16u) return -1; // the last strip would be one lane wide: that lane is first and last at once
-    bool outer = n > 1;
-    if (const char *e = getenv("ZIGNAL_HIP_F32_TILE_HALO")) outer = e[0] == 'o'; // tuning hook: "outer" / "all" (the tests run both forms on every shape)
+    const bool outer = n > 1; // profiles/r05_experiments.txt section 1: each form is the better one where it is used (the tests reach both through the plane count)
     switch (nk) {
     case 3: return outer ? launch_tile_f32<3, 8, true>(src, dst, n, fx, fy, border, s) : launch_tile_f32<3, 8, false>(src, dst, n, fx, fy, border, s);
     case 5: return outer ? launch_tile_f32<5, 8, true>(src, dst, n, fx, fy, border, s) : launch_tile_f32<5, 8, false>(src, dst, n, fx, fy, border, s);

@@ -612,7 +612,8 @@ static int conv_separable_impl(const zg_image *src, const zg_image *dst, const f
                 nk -= 2 * z;
             }
         };
-        if (!getenv("ZIGNAL_HIP_KEEP_ZERO_TAPS")) { // A/B hook of round 5
+        static const bool keep_zero_taps = getenv("ZIGNAL_HIP_KEEP_ZERO_TAPS") != nullptr; // A/B hook of round 5, read once
+        if (!keep_zero_taps) {
             trim_zero_ends(p.ix, p.nkx);
             trim_zero_ends(p.iy, p.nky);
         }

@@ -530,7 +530,8 @@ int resize_convert_rgba8_frames(const zg_image *src, const zg_image *dst, int ds
     if (!fused) return -1;
     // reductions: one-wave workgroups in address order, as the plain resize (resize_planes.hip); 0 / 1 in ZIGNAL_HIP_RESIZE_FORM force a form
     bool one_wave = (float)src->cols / (float)dst->cols > 1.5f;
-    if (const char *e = getenv("ZIGNAL_HIP_RESIZE_FORM")) one_wave = atoi(e) != 0;
+    static const int forced_form = getenv("ZIGNAL_HIP_RESIZE_FORM") ? atoi(getenv("ZIGNAL_HIP_RESIZE_FORM")) : -1; // read once
+    if (forced_form >= 0) one_wave = forced_form != 0;
     const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, one_wave ? 1u : 4u);
     const uint64_t tiles = (uint64_t)tiles_x * tiles_y;
     if (tiles > 0x7fffffffu || n > MAX_FRAMES_PER_LAUNCH) return -1;

@@ -406,7 +406,8 @@ int resize_bilinear_rgba8_frames(const zg_image *src, const zg_image *dst, uint3
     // order (their neighbouring rows share source rows: 35.9 against 37-40 us at 2048^2 -> 4096^2). 0 / 1 / 2 / 4 force a form (the tests do).
     const float ry = (float)src->rows / (float)dst->rows, rx = (float)src->cols / (float)dst->cols;
     int form = rx <= 1.5f ? 0 : (ry >= 3.0f ? 1 : 2);
-    if (const char *e = getenv("ZIGNAL_HIP_RESIZE_FORM")) form = atoi(e);
+    static const int forced_form = getenv("ZIGNAL_HIP_RESIZE_FORM") ? atoi(getenv("ZIGNAL_HIP_RESIZE_FORM")) : -1; // read once
+    if (forced_form == 0 || forced_form == 1 || forced_form == 2 || forced_form == 4) form = forced_form; // the forms the launch switch has: anything else would leave rows unwritten
     const int waves = form == 0 ? 4 : 1, rpw = form == 0 ? 1 : form;
     const int tiles_x = (int)ceil_div(dst->cols, 64), tiles_y = (int)ceil_div(dst->rows, (unsigned)(waves * rpw));
     const float ratio_x = (float)src->cols / (float)dst->cols, ratio_y = (float)src->rows / (float)dst->rows;

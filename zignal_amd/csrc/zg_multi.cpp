@@ -50,9 +50,16 @@ int load_rccl() {
     std::lock_guard<std::mutex> lock(g_rccl_mu);
     if (g_rccl.handle) return ZG_OK;
     void *h = nullptr;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (h) break;
+    // ZIGNAL_HIP_RCCL_LIBRARY names the library to bind instead (tests: tests/c/rccl_double.cpp, a stand-in that turns grouped ncclSend / ncclRecv pairs
+    // into event-ordered copies, so that the world > 1 branches of this file run on a box with one GPU); if it is set, nothing else is tried
+    if (const char *forced = getenv("ZIGNAL_HIP_RCCL_LIBRARY")) {
+        h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        ZG_REQUIRE(h != nullptr, ZG_ERR_UNSUPPORTED, "multi-GPU: ZIGNAL_HIP_RCCL_LIBRARY=%s cannot be loaded (%s)", forced, dlerror());
+    } else {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
     }
     ZG_REQUIRE(h != nullptr, ZG_ERR_UNSUPPORTED, "multi-GPU: librccl.so not found (%s)", dlerror());
     Rccl r;
@@ -170,12 +177,18 @@ int zg_multi_create(const int *devices, int n_devices, zg_multi *out) {
     int visible = 0;
     ZG_HIP(hipGetDeviceCount(&visible));
     if (n_devices <= 0) n_devices = visible; // all of them
-    ZG_REQUIRE(n_devices >= 1 && n_devices <= visible, ZG_ERR_INVALID_ARGUMENT, "zg_multi_create: %d devices asked for, %d visible", n_devices, visible);
+    // Tests only (ZIGNAL_HIP_MULTI_VIRTUAL): one device may stand in for several — the same id listed N times makes a context of world N whose shards,
+    // staging buffers, streams, events and both "communicators" are all real and all on that device. RCCL itself refuses such a list; the stand-in
+    // of ZIGNAL_HIP_RCCL_LIBRARY does not.
+    const bool virtual_world = getenv("ZIGNAL_HIP_MULTI_VIRTUAL") != nullptr;
+    ZG_REQUIRE(n_devices >= 1 && (n_devices <= visible || (virtual_world && devices && n_devices <= 64)), ZG_ERR_INVALID_ARGUMENT,
+               "zg_multi_create: %d devices asked for, %d visible", n_devices, visible);
     std::vector<int> list((size_t)n_devices);
     for (int i = 0; i < n_devices; ++i) {
         list[(size_t)i] = devices ? devices[i] : i;
         ZG_REQUIRE(list[(size_t)i] >= 0 && list[(size_t)i] < visible, ZG_ERR_INVALID_ARGUMENT, "zg_multi_create: device %d out of range", list[(size_t)i]);
-        for (int j = 0; j < i; ++j) ZG_REQUIRE(list[(size_t)j] != list[(size_t)i], ZG_ERR_INVALID_ARGUMENT, "zg_multi_create: device %d listed twice", list[(size_t)i]);
+        for (int j = 0; j < i && !virtual_world; ++j)
+            ZG_REQUIRE(list[(size_t)j] != list[(size_t)i], ZG_ERR_INVALID_ARGUMENT, "zg_multi_create: device %d listed twice", list[(size_t)i]);
     }
     DeviceScope scope;
     Multi *m = new Multi();

@@ -151,6 +151,8 @@ class Pipeline:
         Returns (result, (scatter_ms, busiest_device_kernels_ms, whole_call_ms))."""
         if torch is None or not isinstance(frames, torch.Tensor) or not frames.is_cuda or frames.ndim not in (3, 4) or not frames.is_contiguous():
             raise ValueError("expected contiguous device frames (n, rows, cols[, channels])")
+        if frames.device.index != ctx.root_device:  # the root's kernels and RCCL would take the pointer for one of their own device's
+            raise ValueError(f"frames live on {frames.device}, the context's root device is cuda:{ctx.root_device}")
         n, rows, cols = (int(v) for v in frames.shape[:3])
         ch = 1 if frames.ndim == 3 else int(frames.shape[3])
         pixel = _PIXEL_BY_LAYOUT[(str(frames.dtype).replace("torch.", ""), ch)]
@@ -176,12 +178,20 @@ class Multi:
 
     def __init__(self, devices: Optional[Sequence[int]] = None):
         h = C.c_void_p()
+        self.handle = None
         if devices is None:
             L.check(L.lib().zg_multi_create(None, 0, C.byref(h)))
         else:
             arr = (C.c_int * len(devices))(*devices)
             L.check(L.lib().zg_multi_create(arr, len(devices), C.byref(h)))
         self.handle = h
+        self.root_device = int(devices[0]) if devices else 0  # dev[0] of the context: where the caller's frames and results live
+
+    def __del__(self):  # a context that was never closed still gives back its streams, communicators and staging buffers
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def device_count(self) -> int:
         return int(L.lib().zg_multi_device_count(self.handle))
