@@ -320,6 +320,8 @@ def main():
         except Exception as e:  # never take the headline down
             result["resize"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_extras:
+            if args.no_live_traffic:
+                os.environ["ZG_BENCH_NO_LIVE_TRAFFIC"] = "1"
             result["extras"] = extras(zg, torch, np)
         if not args.no_cpu_baseline:
             def gpu_blur(plane):
@@ -351,10 +353,11 @@ def main():
         json_out.flush()
 
 
-def live_traffic(op: str, kernel: str, launches: int = 5):
+def live_traffic(op: str, kernel, launches: int = 5):
     """HBM bytes per launch of `kernel` measured now, on this box: two rocprofv3 passes (--pmc FETCH_SIZE, then WRITE_SIZE, --kernel-trace
     only, as MI355X_MICROARCH.md prescribes) over tools/run_op.py <op>; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (the counters are in
-    KiB, and gfx950's FETCH_SIZE counts 32-byte units as 64). None when rocprofv3 is not on the box or a pass fails."""
+    KiB, and gfx950's FETCH_SIZE counts 32-byte units as 64). kernel=None: every kernel of the library ("zg::") the op launches, summed and
+    divided by the op's calls — the bytes ONE call of a multi-kernel op moves. None when rocprofv3 is not on the box or a pass fails."""
     import shutil
     import sqlite3
     import subprocess
@@ -373,10 +376,10 @@ def live_traffic(op: str, kernel: str, launches: int = 5):
                 if p.returncode != 0 or not dbs:
                     return None
                 vals = [v for k, name, v in sqlite3.connect(dbs[0]).execute("select kernel_name, counter_name, value from counters_collection")
-                        if kernel in k and name == ctr]
+                        if (kernel in k if kernel else "zg::" in k) and name == ctr]
                 if not vals:
                     return None
-                got[ctr] = sum(vals) / len(vals)
+                got[ctr] = sum(vals) / (len(vals) if kernel else launches)
         return int((2 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024)
     except Exception:
         return None
@@ -569,6 +572,8 @@ def cpu_extras(extras_out):
         native = False
     bil = oracle.method(oracle.BILINEAR)
     bic = oracle.method(oracle.BICUBIC)
+    small = oracle.synth_u8(1, (256, 256))
+    put("config1_box_blur_256_u8", timed(lambda: oracle.box_blur(small, 1), 256 * 256), "the whole 256 x 256 frame")
     u8 = oracle.synth_u8(2, (512, COLS, 4))
     put("config2b_gaussian_blur_rgba_u8_4096", timed(lambda: oracle.gaussian_blur(u8, SIGMA, native=native), 512 * COLS), "512 x 4096 strip")
     src = oracle.synth_u8(3, (1024, COLS, 4))
@@ -915,17 +920,99 @@ def extras(zg, torch, np):
         ms = _time_kernel(torch, lambda i: im[i % ring][0].convolve(k, out=im[i % ring][1]))
         return rate(ms, ROWS * COLS, 8 * ROWS * COLS)
 
+    def traffic_ratio(r, op, bytes_alg):
+        """counted HBM bytes of ONE call (every kernel of it) over its algorithmic bytes: how much of the traffic is waste"""
+        if isinstance(r, dict) and "error" not in r and not os.environ.get("ZG_BENCH_NO_LIVE_TRAFFIC"):
+            t = live_traffic(op, None)
+            if t is not None:
+                r["hbm_bytes_per_call"] = t
+                r["traffic_ratio"] = round(t / bytes_alg, 3)
+        return r
+
+    def host_layer(op):
+        """The layer a zignal caller gets by default (image.zig:954-994 takes host slices): zg_gaussian_blur_host / zg_resize_host on numpy arrays,
+        PCIe both ways inside the call. Pageable and pinned (zg_malloc_host) memory; banded (upload, kernel and download of neighbouring bands
+        overlap on three streams) and whole-frame (ZIGNAL_HIP_NO_BANDS). Best of five calls each; GB/s is per direction."""
+        import ctypes as C
+        L = zg.lib()
+        if op == "blur":
+            in_shape, out_shape, dt = (ROWS, COLS, 4), (ROWS, COLS, 4), np.float32
+        else:
+            in_shape, out_shape, dt = (ROWS, COLS, 4), (1024, 1024, 4), np.uint8
+        nin, nout = int(np.prod(in_shape)) * np.dtype(dt).itemsize, int(np.prod(out_shape)) * np.dtype(dt).itemsize
+        rng = np.random.default_rng(3)
+        pins = []
+
+        def alloc(shape, pinned):
+            nb = int(np.prod(shape)) * np.dtype(dt).itemsize
+            if not pinned:
+                return np.empty(shape, dt)
+            ptr = C.c_void_p()
+            if L.zg_malloc_host(C.byref(ptr), nb) != 0:
+                raise MemoryError(f"zg_malloc_host({nb})")
+            pins.append(ptr)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (nb,)).view(dt).reshape(shape)
+
+        out = {"bytes_up": nin, "bytes_down": nout}
+        try:
+            for mem in ("pageable", "pinned"):
+                src, dst = alloc(in_shape, mem == "pinned"), alloc(out_shape, mem == "pinned")
+                src[...] = rng.random(in_shape, dtype=np.float32) if dt == np.float32 else rng.integers(0, 256, in_shape, dtype=np.uint8)
+                a, b = zg.Image(src), zg.Image(dst)
+                call = (lambda: a.gaussian_blur(SIGMA, out=b)) if op == "blur" else (lambda: a.resize(b, I.bilinear))
+                for mode in ("banded", "whole_frame"):
+                    if mode == "whole_frame":
+                        os.environ["ZIGNAL_HIP_NO_BANDS"] = "1"
+                    try:
+                        call()
+                        best = float("inf")
+                        for _ in range(5):
+                            t0 = time.perf_counter()
+                            call()
+                            best = min(best, time.perf_counter() - t0)
+                    finally:
+                        os.environ.pop("ZIGNAL_HIP_NO_BANDS", None)
+                    out[f"{mem}_{mode}"] = {"ms": round(best * 1e3, 3), "Mpixels/s": round(ROWS * COLS / best / 1e6, 1), "GB/s_up": round(nin / best / 1e9, 2),
+                                            "GB/s_down": round(nout / best / 1e9, 2)}
+                del a, b, src, dst
+        finally:
+            for ptr in pins:
+                L.zg_free_host(ptr)
+        return out
+
+    def config1():
+        """BASELINE configs[0]: 3 x 3 box blur (radius 1) of a 256 x 256 Image(u8) — plumbing: rows * cols * 255 < 2^24, so k_box_direct sums the window
+        itself and the call is one launch. Device-resident (graph-replayed) and through the host layer (numpy in, numpy out)."""
+        src = zg.Image(torch.randint(0, 256, (256, 256), dtype=torch.uint8, device="cuda"))
+        dst = zg.Image(torch.empty((256, 256), dtype=torch.uint8, device="cuda"))
+        ms = _time_kernel(torch, lambda i: src.box_blur(1, out=dst), n=64, warm=8)
+        r = rate(ms, 256 * 256, 2 * 256 * 256)
+        h = np.random.default_rng(4).integers(0, 256, (256, 256), dtype=np.uint8)
+        ho = np.empty_like(h)
+        a, b = zg.Image(h), zg.Image(ho)
+        a.box_blur(1, out=b)
+        best = float("inf")
+        for _ in range(20):
+            t0 = time.perf_counter()
+            a.box_blur(1, out=b)
+            best = min(best, time.perf_counter() - t0)
+        r["host_layer_ms"] = round(best * 1e3, 4)
+        return r
+
+    leg("config1_box_blur_256_u8", config1)
+    leg("host_layer_gaussian_rgba_f32_4096", lambda: host_layer("blur"))
+    leg("host_layer_resize_rgba_u8_4096", lambda: host_layer("resize"))
     leg("pipeline_example_recipe_64x1080p_rgba_u8", recipe_example)
     leg("s4_convolve_5x5_rgba_u8_4096", conv5x5)
-    leg("s5_box_blur_r2_rgba_u8_4096", lambda: box("rgba"))
-    leg("s5_box_blur_r2_u8_4096", lambda: box("grey"))
+    leg("s5_box_blur_r2_rgba_u8_4096", lambda: traffic_ratio(box("rgba"), "box_rgba8", 8 * ROWS * COLS))
+    leg("s5_box_blur_r2_u8_4096", lambda: traffic_ratio(box("grey"), "box_u8", 2 * ROWS * COLS))
     leg("s5_box_blur_r1_u8_4096", lambda: box("grey", 1))
     leg("s5_sharpen_r2_rgba_u8_4096", lambda: box("rgba", 2, True))
     leg("s4_convolve_3x3_rgba_u8_4096", lambda: conv3x3("u8"))
     leg("s4_convolve_3x3_rgba_f32_4096", lambda: conv3x3("f32"))
     leg("config3_fused_resize_oklab_16_frames_per_launch", fused_batch16)
     leg("next_sobel_rgba_u8_4096", sobel)
-    leg("next_pyramid_build_default_u8_4096", pyramid_build)
+    leg("next_pyramid_build_default_u8_4096", lambda: traffic_ratio(pyramid_build(), "pyramid", 2 * ROWS * COLS))
     leg("next_canny_rgba_u8_4096", canny)
     leg("next_shen_castan_rgba_u8_4096", shen)
     leg("next_canny_and_shen_castan_photo_like_rgba_u8_4096", detectors_photo)
