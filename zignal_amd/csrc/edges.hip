@@ -1523,6 +1523,11 @@ int zg_pyramid_build(const zg_image *source, const zg_image *levels, const float
         bool all_ok = true;
         for (uint32_t i = 0; i < n_levels; ++i) all_ok = all_ok && check_image(&levels[i], "level") == ZG_OK && levels[i].pixel == source->pixel;
         if (all_ok) {
+            // round 6: every level whose taps fit (<= 35, each <= 255) as one tile kernel with no plane in between (pyramid_tile.hip); what it leaves goes on as before
+            const int rct = try_pyramid_tiles_u8(source, levels, sigmas, n_levels, handled.data(), lanes[n_lanes - 1]);
+            if (rct > 0) rc = rct;
+        }
+        if (all_ok && rc == ZG_OK) {
             if (n_lanes >= 3) { // two independent batches on two lanes: levels reduced by 2 and more (fused column pass), and the others (dense + resize)
                 const int rcf = try_pyramid_levels_u8(source, levels, sigmas, n_levels, handled.data(), 0, lanes[n_lanes - 1]);
                 const int rcd = try_pyramid_levels_u8(source, levels, sigmas, n_levels, handled.data(), 1, lanes[n_lanes - 2]);

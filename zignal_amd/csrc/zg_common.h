@@ -214,6 +214,7 @@ int resize_frames(const zg_image *src, const zg_image *dst, const zg_method *met
 int warp_frames(const zg_image *src, const zg_image *dst, int kind, const float *mat, const zg_method *method, uint32_t n, size_t src_frame, size_t dst_frame,
                 hipStream_t s);                                                                                                                        // geom.hip
 int try_pyramid_levels_u8(const zg_image *src, const zg_image *levels, const float *sigmas, uint32_t n, uint8_t *handled, int which, hipStream_t s); // conv_sep_bytes2.hip: several levels in three launches
+int try_pyramid_tiles_u8(const zg_image *src, const zg_image *levels, const float *sigmas, uint32_t n, uint8_t *handled, hipStream_t s); // pyramid_tile.hip: a level per kernel, nothing but the level written
 int try_pyramid_level_u8(const zg_image *src, const zg_image *level, const int32_t *taps, int nk, hipStream_t s); // conv_sep_bytes2.hip: blur + bilinear level, -1 = not this shape
 int box_blur_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, uint32_t radius, hipStream_t s);                   // box_blur.hip
 int motion_linear_frames(const zg_image *src, const zg_image *dst, uint32_t n, size_t src_frame, size_t dst_frame, float cos_a, float sin_a, uint32_t distance,
