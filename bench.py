@@ -630,6 +630,44 @@ def _time_kernel(torch, fn, n=50, warm=5, capture=True):
     return ms
 
 
+def _time_kernel_two_streams(torch, fn, n=50, warm=5):
+    """As _time_kernel, but the n calls of the captured graph alternate between TWO streams forked from the capture stream and joined back at the end
+    (VERDICT r05 next-6): independent frames, still one frame per launch, so that one launch's ramp overlaps its predecessor's tail instead of waiting
+    behind it on the same stream. Mean ms per call; None if the capture fails."""
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    try:
+        side, s1, s2 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            fn(0)
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                s1.wait_stream(side)
+                s2.wait_stream(side)
+                for i in range(n):
+                    with torch.cuda.stream(s1 if i % 2 == 0 else s2):
+                        fn(i)
+                side.wait_stream(s1)
+                side.wait_stream(s2)
+        graph.replay()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(3):
+            graph.replay()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / (n * 3)
+        del graph
+        import zignal_amd as _zg
+        _zg.lib().zg_release_graph_scratch()
+        return ms
+    except Exception:
+        return None
+
+
 def extras(zg, torch, np):
     """Secondary numbers (not the headline): the other configurations of BASELINE.json, each with its
     algorithmic bytes so the same roofline arithmetic applies. Ring-rotated buffers, HIP events."""
@@ -650,6 +688,13 @@ def extras(zg, torch, np):
         return {"ms": round(ms, 5), "Mpixels/s": round(px / ms / 1e3, 1), "GB/s_algorithmic": round(bytes_alg / ms / 1e6, 1),
                 "frac_of_8TB/s": round(bytes_alg / ms / 1e6 / HBM_PEAK_GBS, 4)}
 
+    def two_streams(r, fn):
+        """the same leg with the launches alternating between two forked streams (a separate key: the single-stream figure stays the leg's own)"""
+        ms2 = _time_kernel_two_streams(torch, fn)
+        if ms2 is not None:
+            r["two_streams_ms"] = round(ms2, 5)
+        return r
+
     def u8_frames(n, shape):
         return [torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda") for _ in range(n)]
 
@@ -657,7 +702,7 @@ def extras(zg, torch, np):
         ring = 8
         im = [(zg.Image(s), zg.Image(torch.empty_like(s))) for s in u8_frames(ring, (ROWS, COLS, 4))]
         ms = _time_kernel(torch, lambda i: im[i % ring][0].gaussian_blur(SIGMA, out=im[i % ring][1]))
-        return rate(ms, ROWS * COLS, 8 * ROWS * COLS)  # 4 B read + 4 B written per pixel
+        return two_streams(rate(ms, ROWS * COLS, 8 * ROWS * COLS), lambda i: im[i % ring][0].gaussian_blur(SIGMA, out=im[i % ring][1]))  # 4 B read + 4 B written per pixel
 
     def resize_u8():
         ring = 16  # 1 GiB of sources
@@ -665,7 +710,7 @@ def extras(zg, torch, np):
         ms = _time_kernel(torch, lambda i: im[i % ring][0].resize(im[i % ring][1], I.bilinear))
         r = rate(ms, ROWS * COLS, 20 * 1024 * 1024)  # 4 taps x 4 B + 4 B per OUTPUT pixel (strict)
         r["GB/s_sector_basis"] = round((ROWS * COLS * 4 // 2 + 4 * 1024 * 1024) / ms / 1e6, 1)  # rows 1,2 mod 4 are touched whole
-        return r
+        return two_streams(r, lambda i: im[i % ring][0].resize(im[i % ring][1], I.bilinear))
 
     def resize_dense(sr, dr):
         # a dense case for the same kernel: every source byte is a tap (2:1) or every destination byte is new (1:2),
@@ -689,7 +734,7 @@ def extras(zg, torch, np):
         ms = _time_kernel(torch, lambda i: im[i % ring][0].resize_convert(im[i % ring][1], zg.CS_OKLAB))
         r = rate(ms, ROWS * COLS, 28 * 1024 * 1024)  # 4 taps x 4 B read + 12 B written per OUTPUT pixel
         r["GB/s_sector_basis"] = round((ROWS * COLS * 4 // 2 + 12 * 1024 * 1024) / ms / 1e6, 1)
-        return r
+        return two_streams(r, lambda i: im[i % ring][0].resize_convert(im[i % ring][1], zg.CS_OKLAB))
 
     def warp(kind):
         tr = zg.ProjectiveTransform.from_points([(0, 0), (4095, 0), (0, 4095), (4095, 4095)], [(200, 120), (3900, 60), (90, 3980), (4000, 4050)])
@@ -724,7 +769,7 @@ def extras(zg, torch, np):
         im = [(zg.Image(torch.rand((ROWS, COLS), dtype=torch.float32, device="cuda")), zg.Image(torch.empty((ROWS, COLS), dtype=torch.float32, device="cuda")))
               for _ in range(ring)]
         ms = _time_kernel(torch, lambda i: im[i % ring][0].gaussian_blur(SIGMA, out=im[i % ring][1]))
-        return rate(ms, ROWS * COLS, 8 * ROWS * COLS)  # one f32 plane: 4 B read + 4 B written per pixel
+        return two_streams(rate(ms, ROWS * COLS, 8 * ROWS * COLS), lambda i: im[i % ring][0].gaussian_blur(SIGMA, out=im[i % ring][1]))  # one f32 plane: 4 B read + 4 B written per pixel
 
     def blur_planes4():
         # BASELINE configs[1] in the one form a zignal caller can express for f32 data: four Image(f32) planes (convolveSeparable rejects
