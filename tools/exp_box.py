@@ -73,7 +73,10 @@ if "check" in what:
 if "time" in what:
     R = 4096
     rr = tuple(int(x) for x in os.environ.get("BOX_RADII", "1,2,3").split(","))
+    kinds = os.environ.get("BOX_KINDS", "u8,rgba_u8").split(",")
     for kind, tail, radii in (("u8", (), rr), ("rgba_u8", (4,), rr)):
+        if kind not in kinds:
+            continue
         n_src = 16 if not tail else 8  # past the Infinity Cache
         srcs = [zg.Image(torch.randint(0, 256, (R, R) + tail, dtype=torch.uint8, device="cuda")) for _ in range(n_src)]
         dsts = [zg.Image(torch.empty((R, R) + tail, dtype=torch.uint8, device="cuda")) for _ in range(2)]

@@ -72,6 +72,15 @@ __host__ __device__ constexpr int box_strip_left(int C, int R) { return C == 4 ?
 // The first version had a slot of padding per quarter and the quarter in the low lane bits (a scan by quad DPP moves): 42 % of its LDS cycles were conflicts.
 __device__ __forceinline__ int bf_pos(int l) { return l; }
 
+struct BfRoleList { int r[16]; };
+struct BfRoles { unsigned long long lo, hi; }; // 8 bits per wave
+constexpr BfRoles bf_roles(BfRoleList l) {
+    BfRoles v{0, 0};
+    for (int w = 0; w < 8; ++w) v.lo |= (unsigned long long)l.r[w] << (8 * w);
+    for (int w = 8; w < 16; ++w) v.hi |= (unsigned long long)l.r[w] << (8 * (w - 8));
+    return v;
+}
+
 struct BoxFusedArgs {
     DImg src, dst;
     const float *carries; // [frame][row][strip 0 .. nwg][C]
@@ -291,12 +300,13 @@ __device__ __forceinline__ void bf_prefixes(const uint32_t (&raw)[4], const floa
 // compares it with the IEEE division sequence over EVERY integer-valued f32 sum below 2^34, every area h x w (h, w <= 7), blur and sharpen: no byte differs
 // (profiles/r06_box_quot_check.txt; Markstein's three-operation quotient, also checked there, is not needed).
 //
-// A loader. Four channels: wave li owns the four-row groups 8 hh .. 8 hh + 7 (hh = li >> 1) of blocks par, par + 2, ... (par = li & 1): in the strip's first
-// four quarters lane = (group, row pair h, quarter) — the first row of a pair is worked at step blk (kept in registers), the second at step blk + 1, then both
-// go to LDS as the low or the high half of 16 chain lanes' vectors — and in the last two quarters lane = (group, row of four, quarter), one row each, at step
-// blk + 1 (until step blk the chain still reads this slot), with the carry of the NEXT strip. One channel: wave li owns blocks li, li + 2, ..., whole:
-// lane = (group, row pair, quarter of two). Right behind each row the load of the same row of the wave's next block. No condition inside the loop: with one
-// the compiler waits for the loads at the loop's end.
+// A loader of the strip's first four quarters (four channels) or of the whole strip (one channel). Four channels: wave li owns the four-row groups
+// 8 hh .. 8 hh + 7 (hh = li >> 1) of blocks par, par + 2, ... (par = li & 1), lane = (group, row pair h, quarter); one channel: wave li owns blocks li,
+// li + 2, ..., whole: lane = (group, row pair, quarter of two). The first row of a pair is worked at step blk (kept in registers), the second at step
+// blk + 1, then both go to LDS as the low or the high half of 16 chain lanes' vectors (the slot is read by the chain until step blk). Right behind each row
+// the load of the same row of the wave's next block. No condition inside the loop: with one the compiler waits for the loads at the loop's end.
+// What bounds a step is its LONGEST wave — a wave of this kernel issues an instruction every ~10 cycles whatever its neighbours do — so the work is cut
+// into many waves of ~90 instructions per step rather than few long ones (the last two quarters have waves of their own: box_loader_b).
 template <int C, int EDGE>
 __device__ __forceinline__ void box_loader(const BoxFusedArgs &A, float4 (*Pr)[BF_G][16 * BoxGeo<C>::NQ + 1], int li, int lane, int k, const uint8_t *src, size_t spitch, const float *K,
                                            int a0, int nblocks, int nsteps) {
@@ -324,39 +334,16 @@ __device__ __forceinline__ void box_loader(const BoxFusedArgs &A, float4 (*Pr)[B
         for (int ch = 0; ch < C; ++ch) kk[u][ch] = kp[ch];
     };
     auto row_off_of = [&](int r) { return (uint32_t)r * (uint32_t)spitch; };
-    auto k_off_of = [&](int r, int kk_) { return ((uint32_t)r * (uint32_t)A.nk + (uint32_t)kk_) * (uint32_t)(C * sizeof(float)); };
+    auto k_off_of = [&](int r) { return ((uint32_t)r * (uint32_t)A.nk + (uint32_t)k) * (uint32_t)(C * sizeof(float)); };
     auto fetch = [&](int blk, int u) { // row 2h + u of my group in block blk, clamped into the image
 #if defined(BF_NO_LOADERS) || defined(BF_NO_FETCH)
         return;
 #endif
         const int r = min(blk * BF_B + rg * 4 + 2 * h + u, rows - 1);
-        fetch_at(row_off_of(r), k_off_of(r, k), u);
-    };
-    // four channels: my share of the last two quarters (pixels 16 .. 23 of the strip)
-    const int q2 = lane >> 5, rg2 = 8 * (li >> 1) + (lane & 7), row2 = 4 * rg2 + ((lane >> 3) & 3); // my row inside a block
-    const float fm2 = q2 ? 1.0f : 0.0f;
-    BfCols<C, EDGE> mine2;
-    uint32_t raw2[4];
-    float kk2[C];
-    if constexpr (C == 4) mine2.init(a0 + 16 + 4 * q2, cols);
-    auto fetch2_at = [&](uint32_t row_off, uint32_t k_off) {
-        if constexpr (C == 4) {
-            mine2.load(src + row_off, raw2);
-            const float *kp = (const float *)((const char *)K + k_off);
-#pragma unroll
-            for (int ch = 0; ch < C; ++ch) kk2[ch] = kp[ch];
-        }
-    };
-    auto fetch2 = [&](int blk) {
-#if defined(BF_NO_LOADERS) || defined(BF_NO_FETCH)
-        return;
-#endif
-        const int r = min(blk * BF_B + row2, rows - 1);
-        fetch2_at(row_off_of(r), k_off_of(r, k + 1));
+        fetch_at(row_off_of(r), k_off_of(r), u);
     };
     fetch(par, 0);
     fetch(par, 1);
-    fetch2(par);
     int done = 0;
     if (par == 1) { BF_SYNC(); done = 1; }
     auto step_a = [&](float (&va)[16]) {
@@ -366,31 +353,19 @@ __device__ __forceinline__ void box_loader(const BoxFusedArgs &A, float4 (*Pr)[B
     };
     auto step_b = [&](const float (&va)[16]) {
 #if !defined(BF_NO_LOADERS) && !defined(BF_NO_PUBLISH)
-        {
-            float vb[16];
-            bf_prefixes<C, SCAN>(raw[1], kk[1], fm0, fm1, vb);
-            float2 *o = (float2 *)&Pr[par][rg][16 * q] + h; // my blocks sit in slot blk & 1 = par
+        float vb[16];
+        bf_prefixes<C, SCAN>(raw[1], kk[1], fm0, fm1, vb);
+        float2 *o = (float2 *)&Pr[par][rg][16 * q] + h; // my blocks sit in slot blk & 1 = par
 #pragma unroll
-            for (int i = 0; i < 16; ++i) o[2 * i] = make_float2(va[i], vb[i]);
-        }
-        if constexpr (C == 4) { // the last two quarters, whole in this step: at step blk the chain still reads this slot
-            __builtin_amdgcn_sched_barrier(0);
-            float v2[16];
-            bf_prefixes<C, 3>(raw2, kk2, fm2, 0.0f, v2);
-            float *o2 = (float *)&Pr[par][rg2][16 * (4 + q2)] + (row2 & 3);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o2[4 * i] = v2[i];
-        }
+        for (int i = 0; i < 16; ++i) o[2 * i] = make_float2(va[i], vb[i]);
 #endif
     };
     int blk = par;
-    // while the block fetched next (blk + 2) is whole, its rows are reached by moving pointers on (the clamped form multiplies: quarter-rate instructions)
+    // while the block fetched next (blk + 2) is whole, its rows are reached by moving offsets on (the clamped form multiplies: quarter-rate instructions)
     const int nfull = rows / BF_B;
     const uint32_t row_step = 2u * BF_B * (uint32_t)spitch, k_step = 2u * BF_B * (uint32_t)krow * (uint32_t)sizeof(float);
     const int r_next = min((par + 2) * BF_B + rg * 4 + 2 * h, rows - 1); // my first row of block par + 2 (used only when that block is whole)
-    uint32_t ro = row_off_of(r_next), ko = k_off_of(r_next, k);
-    const int r2_next = min((par + 2) * BF_B + row2, rows - 1);
-    uint32_t ro2 = row_off_of(r2_next), ko2 = k_off_of(r2_next, k + 1);
+    uint32_t ro = row_off_of(r_next), ko = k_off_of(r_next);
     for (; blk + 2 < nfull; blk += 2) {
         float va[16];
         BF_SYNC(); // step blk
@@ -402,12 +377,9 @@ __device__ __forceinline__ void box_loader(const BoxFusedArgs &A, float4 (*Pr)[B
         step_b(va);
 #if !defined(BF_NO_LOADERS) && !defined(BF_NO_FETCH)
         fetch_at(ro + (uint32_t)spitch, ko + (uint32_t)(krow * sizeof(float)), 1);
-        fetch2_at(ro2, ko2);
 #endif
         ro += row_step;
         ko += k_step;
-        ro2 += row_step;
-        ko2 += k_step;
         done += 2;
     }
     for (; blk < nblocks; blk += 2) { // the last blocks: what they fetch is partial or past the end (clamped, never used)
@@ -418,12 +390,94 @@ __device__ __forceinline__ void box_loader(const BoxFusedArgs &A, float4 (*Pr)[B
         BF_SYNC(); // step blk + 1
         step_b(va);
         fetch(blk + 2, 1);
-        fetch2(blk + 2);
         done += 2;
     }
     for (; done < nsteps; ++done) BF_SYNC();
 #ifdef BF_TIMING
-    if (lane == 0) { const int w = C == 4 ? (li == 0 ? 1 : li == 1 ? 5 : li == 2 ? 2 : 6) : li + 1; A.timing[(k * 16 + w) * 2] = bf_timer.busy; A.timing[(k * 16 + w) * 2 + 1] = bf_timer.wait; }
+    if (lane == 0) { const int w = 3 + li; A.timing[(k * 16 + w) * 2] = bf_timer.busy; A.timing[(k * 16 + w) * 2 + 1] = bf_timer.wait; }
+#endif
+}
+
+// A loader of the strip's last two quarters (four channels: pixels 16 .. 23, carry of the NEXT strip, which starts where they start). Wave hh owns the groups
+// 8 hh .. 8 hh + 7 of EVERY block: lane = (group, row of four, quarter), one row each, worked and stored at step blk + 1 (until step blk the chain still reads
+// the slot); its loads run two blocks ahead, in two register sets.
+template <int EDGE>
+__device__ __forceinline__ void box_loader_b(const BoxFusedArgs &A, float4 (*Pr)[BF_G][16 * BoxGeo<4>::NQ + 1], int hh, int lane, int k, const uint8_t *src, size_t spitch, const float *K,
+                                             int a0, int nblocks, int nsteps) {
+#ifdef BF_TIMING
+    BfTimer bf_timer;
+#endif
+    constexpr int C = 4;
+    const int rows = A.src.rows, cols = A.src.cols;
+    const int q2 = lane >> 5, rg2 = 8 * hh + (lane & 7), rin = (lane >> 3) & 3, row2 = 4 * rg2 + rin; // my row inside a block
+    const float fm2 = q2 ? 1.0f : 0.0f;
+    BfCols<C, EDGE> mine;
+    mine.init(a0 + 16 + 4 * q2, cols);
+    uint32_t raw[2][4]; // [block parity][dword]
+    float kk[2][C];
+    auto fetch_at = [&](uint32_t row_off, uint32_t k_off, int u) {
+        mine.load(src + row_off, raw[u]);
+        const float *kp = (const float *)((const char *)K + k_off);
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) kk[u][ch] = kp[ch];
+    };
+    auto row_off_of = [&](int r) { return (uint32_t)r * (uint32_t)spitch; };
+    auto k_off_of = [&](int r) { return ((uint32_t)r * (uint32_t)A.nk + (uint32_t)(k + 1)) * (uint32_t)(C * sizeof(float)); };
+    auto fetch = [&](int blk, int u) {
+#if defined(BF_NO_LOADERS) || defined(BF_NO_FETCH)
+        return;
+#endif
+        const int r = min(blk * BF_B + row2, rows - 1);
+        fetch_at(row_off_of(r), k_off_of(r), u);
+    };
+    auto work = [&](int u) { // block parity = LDS slot = register set
+#if !defined(BF_NO_LOADERS) && !defined(BF_NO_PUBLISH)
+        float v[16];
+        bf_prefixes<C, 3>(raw[u], kk[u], fm2, 0.0f, v);
+        float *o = (float *)&Pr[u][rg2][16 * (4 + q2)] + rin;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[4 * i] = v[i];
+#endif
+    };
+    fetch(0, 0);
+    fetch(1, 1);
+    BF_SYNC(); // step 0
+    int done = 1, blk = 0;
+    const int nfull = rows / BF_B;
+    const uint32_t row_step = 2u * BF_B * (uint32_t)spitch, k_step = 2u * BF_B * (uint32_t)A.nk * (uint32_t)(C * sizeof(float));
+    const int r_next = min(2 * BF_B + row2, rows - 1); // my row of block 2 (used only when that block is whole)
+    uint32_t ro = row_off_of(r_next), ko = k_off_of(r_next);
+    const uint32_t row_blk = (uint32_t)BF_B * (uint32_t)spitch, k_blk = (uint32_t)BF_B * (uint32_t)A.nk * (uint32_t)(C * sizeof(float));
+    for (; blk + 3 < nfull; blk += 2) { // the blocks fetched, blk + 2 and blk + 3, are whole
+        BF_SYNC(); // step blk + 1
+        work(0);
+#if !defined(BF_NO_LOADERS) && !defined(BF_NO_FETCH)
+        fetch_at(ro, ko, 0);
+#endif
+        BF_SYNC(); // step blk + 2
+        work(1);
+#if !defined(BF_NO_LOADERS) && !defined(BF_NO_FETCH)
+        fetch_at(ro + row_blk, ko + k_blk, 1);
+#endif
+        ro += row_step;
+        ko += k_step;
+        done += 2;
+    }
+    for (; blk < nblocks; blk += 2) { // the last blocks: what they fetch is partial or past the end (clamped, never used)
+        BF_SYNC(); // step blk + 1
+        work(0);
+        fetch(blk + 2, 0);
+        ++done;
+        if (blk + 1 < nblocks) {
+            BF_SYNC(); // step blk + 2
+            work(1);
+            fetch(blk + 3, 1);
+            ++done;
+        }
+    }
+    for (; done < nsteps; ++done) BF_SYNC();
+#ifdef BF_TIMING
+    if (lane == 0) { const int w = 15; A.timing[(k * 16 + w) * 2] += bf_timer.busy; A.timing[(k * 16 + w) * 2 + 1] += bf_timer.wait; }
 #endif
 }
 
@@ -444,7 +498,14 @@ __global__ __launch_bounds__(BoxGeo<C>::THREADS) void k_box_fused(BoxFusedArgs A
     const int lane = threadIdx.x & 63;
     // role of a wave (SIMD = wave % 4). Four channels: 0, 4 the chain, 8, 12 leave at once (SIMD 0 is the chain's); 1, 5, 2, 6 loaders, the other eight are means.
     // One channel: 0 the chain, 4 leaves; 1, 2 loaders; 3, 5, 6, 7 means
-    if (wave == 8 || wave == 12 || (C == 1 && wave == 4)) return;
+    // role of wave w: 0 leaves at once, 1 / 2 the chain's waves, 3 .. 6 loaders 0 .. 3, 7 .. 14 mean waves 0 .. 7, 15 / 16 the loaders of the last two quarters.
+    // Waves w and w + 4 share a SIMD (which roles share one made no difference: +-1 % over three placements).
+#ifndef BF_ROLES4 //          SIMD: 0  1  2  3   0  1  2   3  0  1  2   3   0   1   2   3
+#define BF_ROLES4 bf_roles({1, 3, 2, 5, 15, 4, 16, 6, 7, 8, 9, 10, 11, 12, 13, 14}) // 0, 2: a chain wave, a loader of the last quarters, two mean waves; 1, 3: two loaders, two mean waves
+#endif
+    constexpr BfRoles ROLES = C == 4 ? BF_ROLES4 : bf_roles({1, 3, 4, 7, 0, 8, 9, 10, 0, 0, 0, 0, 0, 0, 0, 0}); // one channel: 8 waves
+    const int role = (int)(((wave < 8 ? ROLES.lo : ROLES.hi) >> (8 * (wave & 7))) & 255);
+    if (role == 0) return;
     // strips of one XCD are neighbours: they share source lines (the re-chained columns) and the halves of output lines in that XCD's L2
     const int b = (int)blockIdx.x;
     const int k = ZG_XCD_ORDER ? (b & 7) * A.nwg8 + (b >> 3) : b;
@@ -456,11 +517,12 @@ __global__ __launch_bounds__(BoxGeo<C>::THREADS) void k_box_fused(BoxFusedArgs A
     const size_t spitch = (size_t)A.src.stride * C, dpitch = (size_t)A.dst.stride * C;
     const float *K = A.carries + (size_t)frame * rows * A.nk * C;
     const int nblocks = (rows + BF_B - 1) / BF_B;
-    const int nsteps = nblocks + 3; // loaders at s = blk, blk + 1; chain at blk + 2; means at blk + 3
+    constexpr int LAG = 2;
+    const int nsteps = nblocks + LAG + 1; // loaders at s = blk, blk + 1; chain at blk + LAG; means at blk + LAG + 1
     const int x0 = k * W;          // first output column
     const int a0 = x0 - LEFT;      // first chained column (may be negative: those columns hold zeros, which is what the reference's c1 == 0 case reads)
 
-    if (wave == 0 || (C == 4 && wave == 3)) { // ---- a chain wave ------------------------------------------------------------------------------------------------------
+    if (role <= 2) { // ---- a chain wave ------------------------------------------------------------------------------------------------------
         // lane l of wave 0 chains byte column l of the strip; with four channels the 32 columns from 64 on are wave 4's (its upper half idles: an LDS
         // instruction costs what its live lanes move). One channel: 32 columns, wave 0's lower half. The two waves share SIMD 0 and nothing else does:
         // a chain's additions wait for each other, the other chain's fill the gaps.
@@ -468,68 +530,86 @@ __global__ __launch_bounds__(BoxGeo<C>::THREADS) void k_box_fused(BoxFusedArgs A
         BfTimer bf_timer;
 #endif
         static_assert(CL == 32 || CL == 96, "lane masks below");
-        const int first = wave == 0 ? 0 : 64, nl = min(CL - first, 64); // wave-uniform
+        const int first = role == 1 ? 0 : 64, nl = min(CL - first, 64); // wave-uniform
         const int pl = bf_pos(first + (lane & (nl - 1)));
         float run = 0.0f;
+        // every group's SAT values replace its row prefixes in the SAME registers and the stores trail the additions by half a block: a register
+        // that a store still reads is never the target of an addition
+        auto get = [&](float4 (&v)[BF_G], int pslot) {
+#pragma unroll
+            for (int g = 0; g < BF_G; ++g) v[g] = Pr[pslot][g][pl];
+        };
+        auto chain = [&](float4 (&v)[BF_G], int sslot) {
+            auto add = [&](int g) {
+#ifdef BF_NO_CHAIN_ADD
+                return;
+#endif
+                run = run + v[g].x; v[g].x = run;
+                run = run + v[g].y; v[g].y = run;
+                run = run + v[g].z; v[g].z = run;
+                run = run + v[g].w; v[g].w = run;
+            };
+            auto put = [&](int g) {
+#ifdef BF_NO_CHAIN_PUT
+                return;
+#endif
+                Sr[HG + sslot * BF_G + g][pl] = v[g];
+                if (g >= BF_G - HG && sslot == BF_NS - 1) Sr[g - (BF_G - HG)][pl] = v[g]; // the header (wave-uniform)
+            };
+#pragma unroll
+            for (int g = 0; g < BF_G / 2; ++g) add(g);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = BF_G / 2; g < BF_G; ++g) { add(g); put(g - BF_G / 2); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = BF_G / 2; g < BF_G; ++g) put(g);
+        };
         BF_SYNC();
         BF_SYNC();
         int pslot = 0, sslot = 0;
-        for (int blk = 0; blk < nblocks; ++blk) {
-            BF_SYNC(); // step blk + 2
+        {
+            for (int blk = 0; blk < nblocks; ++blk) {
+                BF_SYNC(); // step blk + 2
 #ifdef BF_NO_CHAIN // removal timings (tools/build_variant.sh): profiles/r06_box_blur.txt
-            continue;
+                continue;
 #endif
-            if (lane < nl) {
-                // every group's SAT values replace its row prefixes in the SAME registers and the stores trail the additions by half a block: a register
-                // that a store still reads is never the target of an addition
-                float4 v[BF_G];
-#pragma unroll
-                for (int g = 0; g < BF_G; ++g) v[g] = Pr[pslot][g][pl];
-                auto add = [&](int g) {
-                    run = run + v[g].x; v[g].x = run;
-                    run = run + v[g].y; v[g].y = run;
-                    run = run + v[g].z; v[g].z = run;
-                    run = run + v[g].w; v[g].w = run;
-                };
-                auto put = [&](int g) {
-                    Sr[HG + sslot * BF_G + g][pl] = v[g];
-                    if (g >= BF_G - HG && sslot == BF_NS - 1) Sr[g - (BF_G - HG)][pl] = v[g]; // the header (wave-uniform)
-                };
-#pragma unroll
-                for (int g = 0; g < BF_G / 2; ++g) add(g);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = BF_G / 2; g < BF_G; ++g) { add(g); put(g - BF_G / 2); }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = BF_G / 2; g < BF_G; ++g) put(g);
+                if (lane < nl) {
+                    float4 v[BF_G];
+                    get(v, pslot);
+                    chain(v, sslot);
+                }
+                pslot = pslot + 1 == BF_NP ? 0 : pslot + 1;
+                sslot = sslot + 1 == BF_NS ? 0 : sslot + 1;
             }
-            pslot = pslot + 1 == BF_NP ? 0 : pslot + 1;
-            sslot = sslot + 1 == BF_NS ? 0 : sslot + 1;
         }
-        BF_SYNC(); // step nblocks + 2
+        BF_SYNC(); // the last step: the means' last block
 #ifdef BF_TIMING
-        if (lane == 0) { A.timing[(k * 16 + wave) * 2] = bf_timer.busy; A.timing[(k * 16 + wave) * 2 + 1] = bf_timer.wait; }
+        if (lane == 0) { A.timing[(k * 16 + role) * 2] = bf_timer.busy; A.timing[(k * 16 + role) * 2 + 1] = bf_timer.wait; }
 #endif
         return;
     }
 
-    const bool is_loader = C == 4 ? (wave == 1 || wave == 5 || wave == 2 || wave == 6) : (wave == 1 || wave == 2);
-    if (is_loader) { // ---- a loader ------------------------------------------------------------------------------------------------------------------
-        // four channels: a SIMD's two loaders take blocks of either parity, so that it has one first and one (longer) second step in every step
-        const int li = C == 4 ? (wave == 1 ? 0 : wave == 5 ? 1 : wave == 2 ? 2 : 3) : wave - 1;
-        const bool edge = a0 < 0 || a0 + CL / C > cols; // workgroup-uniform: some chained columns lie outside the image
+    const bool edge = a0 < 0 || a0 + CL / C > cols; // workgroup-uniform: some chained columns lie outside the image
+    if (role <= 6) { // ---- a loader ----------------------------------------------------------------------------------------------------------------
+        const int li = role - 3;
         if (!edge) box_loader<C, 0>(A, Pr, li, lane, k, src, spitch, K, a0, nblocks, nsteps);
         else if (C == 4 || (cols & 3) == 0) box_loader<C, 1>(A, Pr, li, lane, k, src, spitch, K, a0, nblocks, nsteps);
         else if constexpr (C == 1) box_loader<C, 2>(A, Pr, li, lane, k, src, spitch, K, a0, nblocks, nsteps);
+        return;
+    }
+    if (role >= 15) { // ---- a loader of the last two quarters -----------------------------------------------------------------------------------------
+        if constexpr (C == 4) {
+            if (!edge) box_loader_b<0>(A, Pr, role - 15, lane, k, src, spitch, K, a0, nblocks, nsteps);
+            else box_loader_b<1>(A, Pr, role - 15, lane, k, src, spitch, K, a0, nblocks, nsteps);
+        }
         return;
     }
 
     // ---- a mean wave -------------------------------------------------------------------------------------------------------------------------------
     // GPW of a block's sixteen groups each. Four channels: a lane = an output byte column, two groups per step. One channel: a lane = (one of four groups,
     // output column).
-    const int mi = C == 4 ? (wave == 9 ? 0 : wave == 13 ? 1 : wave == 10 ? 2 : wave == 14 ? 3 : wave == 4 ? 4 : wave == 7 ? 5 : wave == 11 ? 6 : 7)
-                          : (wave == 3 ? 0 : wave == 5 ? 1 : wave == 6 ? 2 : 3);
+    const int mi = role - 7;
     const int gbase = mi * GPW;          // the wave's first group inside a block
     // my group among the 64 / LPG the wave works on at once. One channel: the 16 lanes one cycle of a ds_read_b128 serves — {0-3, 12-15, 20-27},
     // {4-11, 16-19, 28-31}, the same + 32 — work on one group (whole quads each, and lane & 15 takes every value once: the columns)
@@ -627,9 +707,9 @@ __global__ __launch_bounds__(BoxGeo<C>::THREADS) void k_box_fused(BoxFusedArgs A
                     pk = __builtin_amdgcn_cvt_pk_u8_f32(val, (uint32_t)j, pk);
                 }
                 // bytes = rows of my column -> bytes = the quad's columns of row tj
-                const uint32_t x1 = (uint32_t)__builtin_amdgcn_update_dpp((int)pk, (int)pk, 0xb1, 0xf, 0xf, false); // quad_perm [1,0,3,2]
+                const uint32_t x1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0xb1, 0xf, 0xf, false); // quad_perm [1,0,3,2]
                 const uint32_t t1 = __builtin_amdgcn_perm(pk, x1, sel1);
-                const uint32_t y1 = (uint32_t)__builtin_amdgcn_update_dpp((int)t1, (int)t1, 0x4e, 0xf, 0xf, false); // quad_perm [2,3,0,1]
+                const uint32_t y1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)t1, 0x4e, 0xf, 0xf, false); // quad_perm [2,3,0,1]
                 const uint32_t rowv = __builtin_amdgcn_perm(t1, y1, sel2);
                 uint8_t *o = dst + (size_t)(r0 + tj) * dpitch + (size_t)(x0 * C + tq);
                 if (gsel == 0) {
@@ -674,9 +754,9 @@ __global__ __launch_bounds__(BoxGeo<C>::THREADS) void k_box_fused(BoxFusedArgs A
                 else val = __builtin_fmaf(sum, yrcp, BF_BIAS);
                 pk = __builtin_amdgcn_cvt_pk_u8_f32(val, (uint32_t)j, pk);
             }
-            const uint32_t x1 = (uint32_t)__builtin_amdgcn_update_dpp((int)pk, (int)pk, 0xb1, 0xf, 0xf, false); // quad_perm [1,0,3,2]
+            const uint32_t x1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)pk, 0xb1, 0xf, 0xf, false); // quad_perm [1,0,3,2]
             const uint32_t t1 = __builtin_amdgcn_perm(pk, x1, sel1);
-            const uint32_t y1 = (uint32_t)__builtin_amdgcn_update_dpp((int)t1, (int)t1, 0x4e, 0xf, 0xf, false); // quad_perm [2,3,0,1]
+            const uint32_t y1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)t1, 0x4e, 0xf, 0xf, false); // quad_perm [2,3,0,1]
             *(uint32_t *)(orow + (out_off + (uint32_t)(4 * t) * (uint32_t)dpitch)) = __builtin_amdgcn_perm(t1, y1, sel2);
         }
     };
@@ -684,32 +764,44 @@ __global__ __launch_bounds__(BoxGeo<C>::THREADS) void k_box_fused(BoxFusedArgs A
 #ifdef BF_TIMING
     BfTimer bf_timer;
 #endif
-    BF_SYNC();
-    BF_SYNC();
-    BF_SYNC();
+    for (int i = 0; i <= LAG; ++i) BF_SYNC();
     int sslot = 0;
     uint32_t so = 0;
     uint8_t *orow = dst + ((ptrdiff_t)(4 * gbase) - R) * (ptrdiff_t)dpitch; // first output row of the wave's groups of block 0 (negative rows are never touched)
     const uint8_t *srow = src + ((ptrdiff_t)(4 * gbase) - R) * (ptrdiff_t)spitch;
-    for (int blk = 0; blk < nblocks; ++blk) {
-        BF_SYNC(); // step blk + 3
-#ifdef BF_NO_MEANS
-        continue;
-#endif
-        if (blk == 0 && mi == NM - 1) { // the clipped rows at the top: the SAT rows they read (< 4 HG + 4) are all in block 0
-            for (int r = 0; r < min(top_end, rows); ++r) generic_row(r);
-        }
-        const int G0 = blk * BF_G + gbase;
-        if (!tail_strip && G0 >= g_lo && G0 + GPW - 1 <= g_hi) fast(so, orow, srow);
-        else groups(blk, sslot);
+    auto advance = [&]() {
         sslot = sslot + 1 == BF_NS ? 0 : sslot + 1;
         so = so + SLOT_BYTES == BF_NS * SLOT_BYTES ? 0 : so + SLOT_BYTES;
         orow += (size_t)BF_B * dpitch;
         srow += (size_t)BF_B * spitch;
+    };
+    // block 0 (it holds the clipped rows at the top: the SAT rows they read, < 4 HG + 4, are all in it), then the blocks whose groups are all unclipped in a
+    // loop without a condition, then what is left (the last block or two; every block of a strip whose rows do not end on a dword)
+    const int fast_num = g_hi - gbase - GPW + 1; // block blk of mine is unclipped iff 1 <= blk <= fast_num / 16
+    const int last_fast = tail_strip || fast_num < 0 ? 0 : min(fast_num / BF_G, nblocks - 1);
+    int blk = 0;
+#ifndef BF_NO_MEANS
+    BF_SYNC(); // step LAG + 1
+    if (mi == NM - 1)
+        for (int r = 0; r < min(top_end, rows); ++r) generic_row(r);
+    groups(0, sslot);
+    advance();
+    for (blk = 1; blk <= last_fast; ++blk) {
+        BF_SYNC(); // step blk + LAG + 1
+        fast(so, orow, srow);
+        advance();
     }
+    for (; blk < nblocks; ++blk) {
+        BF_SYNC();
+        groups(blk, sslot);
+        advance();
+    }
+#else
+    for (; blk < nblocks; ++blk) BF_SYNC();
+#endif
     // the clipped rows at the bottom: the ring still holds the last two blocks (every row they read is >= bot_start - R - 1)
 #ifdef BF_TIMING
-    if (lane == 0) { A.timing[(k * 16 + wave) * 2] = bf_timer.busy; A.timing[(k * 16 + wave) * 2 + 1] = bf_timer.wait; }
+    if (lane == 0) { A.timing[(k * 16 + role) * 2] = bf_timer.busy; A.timing[(k * 16 + role) * 2 + 1] = bf_timer.wait; }
 #endif
     for (int r = max(bot_start, 0) + mi; r < rows; r += NM) generic_row(r);
 }
@@ -793,7 +885,7 @@ int try_box_fused(const zg_image *src, const zg_image *dst, uint32_t n, size_t s
             static unsigned long long host[1024 * 16 * 2];
             (void)hipMemcpy(host, timing, sizeof(host), hipMemcpyDeviceToHost);
             for (int kk : {0, 1, nwg / 2, nwg - 1}) {
-                printf("strip %d of %d (C=%d r=%u): busy / wait cycles per wave:", kk, nwg, C, radius);
+                printf("strip %d of %d (C=%d r=%u): busy / wait cycles per role (1, 2 chain; 3.. loaders; 7.. means):", kk, nwg, C, radius);
                 for (int w = 0; w < 16; ++w) printf(" %d:%llu/%llu", w, host[(kk * 16 + w) * 2], host[(kk * 16 + w) * 2 + 1]);
                 printf("\n");
             }
