@@ -44,12 +44,13 @@ namespace zg {
 
 int copy_impl(const zg_image *src, const zg_image *dst, hipStream_t s);
 
-constexpr int BF_B = 64;        // rows per block
-constexpr int BF_G = BF_B / 4;  // four-row groups per block
 constexpr int BF_W = 16;        // output pixel columns per strip: 4096 columns = 256 strips = one workgroup per CU
 constexpr int BF_NP = 2;        // row-prefix ring: block s - 1 is written (at the end of its loaders' second step) while block s - 2 is read
 constexpr int BF_NS = 3;        // SAT ring: block s - 2 is written while the means read s - 3 and its predecessor (history rows)
 constexpr int BF_MAX_R = 3;
+#ifndef BF_DEPTH
+#define BF_DEPTH 1
+#endif
 constexpr int BF_MAX_HG = 2;    // (2 R + 1 + 3) / 4 groups of history at most
 
 // A strip is NQ QUARTERS of 16 byte columns of the image's rows (a byte column = pixel column x channel): its 16 output pixels, LEFT columns left of them —
@@ -57,10 +58,13 @@ constexpr int BF_MAX_HG = 2;    // (2 R + 1 + 3) / 4 groups of history at most
 // the right. Rgba(u8): 6 quarters = 24 pixels (16 + 4 + 3 at most); Image(u8): 2 quarters = 32 columns.
 template <int C> struct BoxGeo;
 template <> struct BoxGeo<4> {
-    static constexpr int NQ = 6, THREADS = 1024, NM = 8 /* mean waves */, NG = 2 /* groups of four rows a mean lane takes per step */, LPG = 64 /* lanes per group: 16 pixels x 4 */;
+    static constexpr int B = 64 /* rows per block = per step */, NQ = 6, THREADS = 1024, NM = 8 /* mean waves */, NG = 2 /* groups of four rows a mean lane takes at once */,
+                         LPG = 64 /* lanes per group: 16 pixels x 4 */, NLOAD = 4;
 };
 template <> struct BoxGeo<1> {
-    static constexpr int NQ = 2, THREADS = 512, NM = 4, NG = 1, LPG = 16;
+    // a step costs ~600 cycles whatever is done in it (a barrier, an LDS round trip or two: removing any one role's work saved 4 .. 12 % of the kernel's time), and
+    // one channel has the LDS for twice the rows per step
+    static constexpr int B = 128, NQ = 2, THREADS = 576, NM = 4, NG = 1, LPG = 16, NLOAD = 4;
 };
 __host__ __device__ constexpr int box_strip_left(int C, int R) { return C == 4 ? R + 1 : 4; }
 
@@ -120,17 +124,23 @@ __global__ __launch_bounds__(256) void k_box_carries(DImg src, float *K, int nwg
     // the left end, at a multiple of four columns).
     const int npieces = C == 4 ? nwg : nwg - 1;
     const int row_dwords = src.cols * C / 4;
+    constexpr int LD = LEFT * C / 4;                              // dwords of piece 0 that lie left of the row
+    const bool overhang = npieces * BF_W - LEFT > src.cols;       // (never for one channel: its last piece ends inside the row)
     for (int p0 = 0; p0 < npieces; p0 += 64) {
         const int p = min(p0 + lane, npieces - 1);
         const int d0 = (p * BF_W - LEFT) * C / 4; // first dword of my piece
         const uint32_t *d = (const uint32_t *)row + d0;
         uint32_t v[ND];
-        if (p0 == 0 || p0 + 64 >= npieces) { // wave-uniform: the batch holds the row's first or last piece
+        if (overhang && p0 + 64 >= npieces) { // wave-uniform: the batch holds the row's last piece and that reaches past the row's end (cols % 16 != 0)
 #pragma unroll
             for (int i = 0; i < ND; ++i) {
                 const bool real = d0 + i >= 0 && d0 + i < row_dwords;
                 v[i] = ((const uint32_t *)row)[min(max(d0 + i, 0), row_dwords - 1)] & (real ? 0xffffffffu : 0u);
             }
+        } else if (p0 == 0) { // piece 0 starts LD dwords left of the row: its lane reads the row's first ND dwords instead and drops the last LD of them
+            d = (const uint32_t *)row + max(d0, 0);
+#pragma unroll
+            for (int i = 0; i < ND; ++i) v[i] = d[i] & ((i >= ND - LD && p == 0) ? 0u : 0xffffffffu);
         } else {
 #pragma unroll
             for (int i = 0; i < ND; ++i) v[i] = d[i];
@@ -308,89 +318,101 @@ __device__ __forceinline__ void bf_prefixes(const uint32_t (&raw)[4], const floa
 // What bounds a step is its LONGEST wave — a wave of this kernel issues an instruction every ~10 cycles whatever its neighbours do — so the work is cut
 // into many waves of ~90 instructions per step rather than few long ones (the last two quarters have waves of their own: box_loader_b).
 template <int C, int EDGE>
-__device__ __forceinline__ void box_loader(const BoxFusedArgs &A, float4 (*Pr)[BF_G][16 * BoxGeo<C>::NQ + 1], int li, int lane, int k, const uint8_t *src, size_t spitch, const float *K,
+__device__ __forceinline__ void box_loader(const BoxFusedArgs &A, float4 (*Pr)[BoxGeo<C>::B / 4][16 * BoxGeo<C>::NQ + 1], int li, int lane, int k, const uint8_t *src, size_t spitch, const float *K,
                                            int a0, int nblocks, int nsteps) {
 #ifdef BF_TIMING
     BfTimer bf_timer;
 #endif
-    constexpr int SCAN = C == 4 ? 2 : 1;
+    constexpr int SCAN = C == 4 ? 2 : 1, BF_B = BoxGeo<C>::B;
     const int rows = A.src.rows, cols = A.src.cols;
-    const int par = C == 4 ? (li & 1) : li;
+    const int par = li & 1;
     const int q = C == 4 ? lane >> 4 : (lane >> 4) & 1;
-    const int rg = C == 4 ? 8 * (li >> 1) + (lane & 7) : (lane & 7) + 8 * (lane >> 5);
+    const int rg = C == 4 ? 8 * (li >> 1) + (lane & 7) : 16 * (li >> 1) + (lane & 7) + 8 * (lane >> 5);
     const int h = (lane >> 3) & 1;
     const float fm0 = (q & 1) ? 1.0f : 0.0f, fm1 = (q & 2) ? 1.0f : 0.0f;
     BfCols<C, EDGE> mine;
     mine.init(C == 4 ? a0 + 4 * q : a0 + 16 * q, cols);
     const uint32_t krow = (uint32_t)A.nk * C; // floats of a row of carries
-    uint32_t raw[2][4]; // [row][dword]
-    float kk[2][C];
+    constexpr int DEPTH = BF_DEPTH; // blocks of mine whose rows are in flight or in registers
+    uint32_t raw[DEPTH][2][4]; // [block][row][dword]
+    float kk[DEPTH][2][C];
     // rows and carries are reached by 32-bit offsets from wave-uniform bases (the host keeps both below 2^32 bytes): half the registers and half the
     // additions of per-lane pointers
-    auto fetch_at = [&](uint32_t row_off, uint32_t k_off, int u) {
-        mine.load(src + row_off, raw[u]);
+    auto fetch_at = [&](uint32_t row_off, uint32_t k_off, int d, int u) {
+        mine.load(src + row_off, raw[d][u]);
         const float *kp = (const float *)((const char *)K + k_off);
 #pragma unroll
-        for (int ch = 0; ch < C; ++ch) kk[u][ch] = kp[ch];
+        for (int ch = 0; ch < C; ++ch) kk[d][u][ch] = kp[ch];
     };
     auto row_off_of = [&](int r) { return (uint32_t)r * (uint32_t)spitch; };
     auto k_off_of = [&](int r) { return ((uint32_t)r * (uint32_t)A.nk + (uint32_t)k) * (uint32_t)(C * sizeof(float)); };
-    auto fetch = [&](int blk, int u) { // row 2h + u of my group in block blk, clamped into the image
+    auto fetch = [&](int blk, int d, int u) { // row 2h + u of my group in block blk, clamped into the image
 #if defined(BF_NO_LOADERS) || defined(BF_NO_FETCH)
         return;
 #endif
         const int r = min(blk * BF_B + rg * 4 + 2 * h + u, rows - 1);
-        fetch_at(row_off_of(r), k_off_of(r), u);
+        fetch_at(row_off_of(r), k_off_of(r), d, u);
     };
-    fetch(par, 0);
-    fetch(par, 1);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        fetch(par + 2 * d, d, 0);
+        fetch(par + 2 * d, d, 1);
+    }
     int done = 0;
     if (par == 1) { BF_SYNC(); done = 1; }
-    auto step_a = [&](float (&va)[16]) {
+    auto step_a = [&](int d, float (&va)[16]) {
 #if !defined(BF_NO_LOADERS) && !defined(BF_NO_PUBLISH)
-        bf_prefixes<C, SCAN>(raw[0], kk[0], fm0, fm1, va);
+        bf_prefixes<C, SCAN>(raw[d][0], kk[d][0], fm0, fm1, va);
 #endif
     };
-    auto step_b = [&](const float (&va)[16]) {
+    auto step_b = [&](int d, const float (&va)[16]) {
 #if !defined(BF_NO_LOADERS) && !defined(BF_NO_PUBLISH)
         float vb[16];
-        bf_prefixes<C, SCAN>(raw[1], kk[1], fm0, fm1, vb);
+        bf_prefixes<C, SCAN>(raw[d][1], kk[d][1], fm0, fm1, vb);
         float2 *o = (float2 *)&Pr[par][rg][16 * q] + h; // my blocks sit in slot blk & 1 = par
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[2 * i] = make_float2(va[i], vb[i]);
 #endif
     };
     int blk = par;
-    // while the block fetched next (blk + 2) is whole, its rows are reached by moving offsets on (the clamped form multiplies: quarter-rate instructions)
+    // while the blocks fetched next are whole, their rows are reached by moving offsets on (the clamped form multiplies: quarter-rate instructions)
     const int nfull = rows / BF_B;
     const uint32_t row_step = 2u * BF_B * (uint32_t)spitch, k_step = 2u * BF_B * (uint32_t)krow * (uint32_t)sizeof(float);
-    const int r_next = min((par + 2) * BF_B + rg * 4 + 2 * h, rows - 1); // my first row of block par + 2 (used only when that block is whole)
+    const int r_next = min((par + 2 * DEPTH) * BF_B + rg * 4 + 2 * h, rows - 1); // my first row of the next block to fetch (used only when that block is whole)
     uint32_t ro = row_off_of(r_next), ko = k_off_of(r_next);
-    for (; blk + 2 < nfull; blk += 2) {
-        float va[16];
-        BF_SYNC(); // step blk
-        step_a(va);
+    for (; blk + 4 * DEPTH - 2 < nfull; blk += 2 * DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            float va[16];
+            BF_SYNC(); // step blk + 2 d
+            step_a(d, va);
 #if !defined(BF_NO_LOADERS) && !defined(BF_NO_FETCH)
-        fetch_at(ro, ko, 0);
+            fetch_at(ro, ko, d, 0);
 #endif
-        BF_SYNC(); // step blk + 1
-        step_b(va);
+            BF_SYNC(); // step blk + 2 d + 1
+            step_b(d, va);
 #if !defined(BF_NO_LOADERS) && !defined(BF_NO_FETCH)
-        fetch_at(ro + (uint32_t)spitch, ko + (uint32_t)(krow * sizeof(float)), 1);
+            fetch_at(ro + (uint32_t)spitch, ko + (uint32_t)(krow * sizeof(float)), d, 1);
 #endif
-        ro += row_step;
-        ko += k_step;
-        done += 2;
+            ro += row_step;
+            ko += k_step;
+            done += 2;
+        }
     }
-    for (; blk < nblocks; blk += 2) { // the last blocks: what they fetch is partial or past the end (clamped, never used)
-        float va[16];
-        BF_SYNC(); // step blk
-        step_a(va);
-        fetch(blk + 2, 0);
-        BF_SYNC(); // step blk + 1
-        step_b(va);
-        fetch(blk + 2, 1);
-        done += 2;
+    for (; blk < nblocks; blk += 2 * DEPTH) { // the last blocks: what they fetch is partial or past the end (clamped, never used)
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (blk + 2 * d < nblocks) {
+                float va[16];
+                BF_SYNC();
+                step_a(d, va);
+                fetch(blk + 2 * d + 2 * DEPTH, d, 0);
+                BF_SYNC();
+                step_b(d, va);
+                fetch(blk + 2 * d + 2 * DEPTH, d, 1);
+                done += 2;
+            }
+        }
     }
     for (; done < nsteps; ++done) BF_SYNC();
 #ifdef BF_TIMING
@@ -402,12 +424,12 @@ __device__ __forceinline__ void box_loader(const BoxFusedArgs &A, float4 (*Pr)[B
 // 8 hh .. 8 hh + 7 of EVERY block: lane = (group, row of four, quarter), one row each, worked and stored at step blk + 1 (until step blk the chain still reads
 // the slot); its loads run two blocks ahead, in two register sets.
 template <int EDGE>
-__device__ __forceinline__ void box_loader_b(const BoxFusedArgs &A, float4 (*Pr)[BF_G][16 * BoxGeo<4>::NQ + 1], int hh, int lane, int k, const uint8_t *src, size_t spitch, const float *K,
+__device__ __forceinline__ void box_loader_b(const BoxFusedArgs &A, float4 (*Pr)[BoxGeo<4>::B / 4][16 * BoxGeo<4>::NQ + 1], int hh, int lane, int k, const uint8_t *src, size_t spitch, const float *K,
                                              int a0, int nblocks, int nsteps) {
 #ifdef BF_TIMING
     BfTimer bf_timer;
 #endif
-    constexpr int C = 4;
+    constexpr int C = 4, BF_B = BoxGeo<4>::B;
     const int rows = A.src.rows, cols = A.src.cols;
     const int q2 = lane >> 5, rg2 = 8 * hh + (lane & 7), rin = (lane >> 3) & 3, row2 = 4 * rg2 + rin; // my row inside a block
     const float fm2 = q2 ? 1.0f : 0.0f;
@@ -487,8 +509,9 @@ __global__ __launch_bounds__(BoxGeo<C>::THREADS) void k_box_fused(BoxFusedArgs A
     constexpr int W = BF_W, LEFT = box_strip_left(C, R);
     constexpr int CL = 16 * Geo::NQ, RS = CL + 1; // chain lanes; 16-byte units from one group to the next in LDS (odd: see bf_pos)
     constexpr int HG = (2 * R + 1 + 3) / 4;             // groups of history a group's d / e rows reach back into
-    constexpr int NM = Geo::NM, NG = Geo::NG, LPG = Geo::LPG, GPW = NG * (64 / LPG); // groups a mean wave takes per step
-    static_assert(NM * GPW == BF_G && HG <= BF_MAX_HG && LEFT + W + R <= CL / C, "geometry");
+    constexpr int BF_B = Geo::B, BF_G = BF_B / 4; // rows and four-row groups per block
+    constexpr int NM = Geo::NM, NG = Geo::NG, LPG = Geo::LPG, GPW = NG * (64 / LPG), NPASS = BF_G / (NM * GPW); // groups a mean wave takes at once; times per step
+    static_assert(NM * GPW * NPASS == BF_G && HG <= BF_MAX_HG && LEFT + W + R <= CL / C, "geometry");
     __shared__ float4 Pr[BF_NP][BF_G][RS];
     // the SAT ring, with a header: the last HG groups of the last slot once more, so that the groups above slot 0 are found where those above any other slot
     // are — HG groups before it
@@ -503,7 +526,7 @@ __global__ __launch_bounds__(BoxGeo<C>::THREADS) void k_box_fused(BoxFusedArgs A
 #ifndef BF_ROLES4 //          SIMD: 0  1  2  3   0  1  2   3  0  1  2   3   0   1   2   3
 #define BF_ROLES4 bf_roles({1, 3, 2, 5, 15, 4, 16, 6, 7, 8, 9, 10, 11, 12, 13, 14}) // 0, 2: a chain wave, a loader of the last quarters, two mean waves; 1, 3: two loaders, two mean waves
 #endif
-    constexpr BfRoles ROLES = C == 4 ? BF_ROLES4 : bf_roles({1, 3, 4, 7, 0, 8, 9, 10, 0, 0, 0, 0, 0, 0, 0, 0}); // one channel: 8 waves
+    constexpr BfRoles ROLES = C == 4 ? BF_ROLES4 : bf_roles({1, 3, 4, 5, 7, 6, 8, 9, 10, 0, 0, 0, 0, 0, 0, 0}); // one channel: 9 waves
     const int role = (int)(((wave < 8 ? ROLES.lo : ROLES.hi) >> (8 * (wave & 7))) & 255);
     if (role == 0) return;
     // strips of one XCD are neighbours: they share source lines (the re-chained columns) and the halves of output lines in that XCD's L2
@@ -565,23 +588,31 @@ __global__ __launch_bounds__(BoxGeo<C>::THREADS) void k_box_fused(BoxFusedArgs A
 #pragma unroll
             for (int g = BF_G / 2; g < BF_G; ++g) put(g);
         };
-        BF_SYNC();
-        BF_SYNC();
-        int pslot = 0, sslot = 0;
-        {
-            for (int blk = 0; blk < nblocks; ++blk) {
-                BF_SYNC(); // step blk + 2
+        auto step = [&](int pslot, int sslot) {
 #ifdef BF_NO_CHAIN // removal timings (tools/build_variant.sh): profiles/r06_box_blur.txt
-                continue;
+            return;
 #endif
-                if (lane < nl) {
-                    float4 v[BF_G];
-                    get(v, pslot);
-                    chain(v, sslot);
-                }
-                pslot = pslot + 1 == BF_NP ? 0 : pslot + 1;
-                sslot = sslot + 1 == BF_NS ? 0 : sslot + 1;
+            if (lane < nl) {
+                float4 v[BF_G];
+                get(v, pslot);
+                chain(v, sslot);
             }
+        };
+        BF_SYNC();
+        BF_SYNC();
+        int sslot = 0, blk = 0;
+        static_assert(BF_NP == 2, "slots by parity below");
+        for (; blk + 1 < nblocks; blk += 2) {
+            BF_SYNC(); // step blk + 2
+            step(0, sslot);
+            sslot = sslot + 1 == BF_NS ? 0 : sslot + 1;
+            BF_SYNC(); // step blk + 3
+            step(1, sslot);
+            sslot = sslot + 1 == BF_NS ? 0 : sslot + 1;
+        }
+        if (blk < nblocks) {
+            BF_SYNC();
+            step(0, sslot);
         }
         BF_SYNC(); // the last step: the means' last block
 #ifdef BF_TIMING
@@ -610,7 +641,7 @@ __global__ __launch_bounds__(BoxGeo<C>::THREADS) void k_box_fused(BoxFusedArgs A
     // GPW of a block's sixteen groups each. Four channels: a lane = an output byte column, two groups per step. One channel: a lane = (one of four groups,
     // output column).
     const int mi = role - 7;
-    const int gbase = mi * GPW;          // the wave's first group inside a block
+    const int gbase = mi * GPW * NPASS;  // the wave's first group inside a block
     // my group among the 64 / LPG the wave works on at once. One channel: the 16 lanes one cycle of a ds_read_b128 serves — {0-3, 12-15, 20-27},
     // {4-11, 16-19, 28-31}, the same + 32 — work on one group (whole quads each, and lane & 15 takes every value once: the columns)
     const int l31 = lane & 31;
@@ -647,7 +678,7 @@ __global__ __launch_bounds__(BoxGeo<C>::THREADS) void k_box_fused(BoxFusedArgs A
     const uint32_t sel2 = (lane & 2) ? 0x07060302u : 0x01000504u; // lanes 2, 3: {Y2, Y3, T2, T3}; lanes 0, 1: {T0, T1, Y0, Y1}
 
     auto sat_at = [&](int row, int p) -> float { // any SAT row still in the ring
-        const int blk = row >> 6;
+        const int blk = row / BF_B;
         const float *v = (const float *)&Sr[HG + (blk % BF_NS) * BF_G + ((row >> 2) & (BF_G - 1))][p];
         return v[row & 3];
     };
@@ -672,12 +703,12 @@ __global__ __launch_bounds__(BoxGeo<C>::THREADS) void k_box_fused(BoxFusedArgs A
     const int top_end = any_fast ? 4 * g_lo - R : 0;          // generic rows [0, top_end)
     const int bot_start = any_fast ? 4 * (g_hi + 1) - R : 0;  // generic rows [bot_start, rows)
 
-    auto groups = [&](int blk, int sslot) { // the wave's GPW groups of block blk, one after the other, every lane on the same group (the first and the last
+    auto groups = [&](int blk, int sslot, int gb) { // GPW groups of block blk from group gb on, one after the other, every lane on the same group (the first and the last
                                             // blocks, strips whose rows do not end on a dword): the lanes of gsel 0 store
-        const int G0 = blk * BF_G + gbase;
+        const int G0 = blk * BF_G + gb;
         if (G0 + GPW - 1 < g_lo || G0 > g_hi) return;
         float a[(HG + GPW) * 4], bq[(HG + GPW) * 4];
-        const int first = HG + sslot * BF_G + gbase - HG; // ring row of the first history group (the header when sslot == 0 and gbase == 0)
+        const int first = HG + sslot * BF_G + gb - HG; // ring row of the first history group (the header when sslot == 0 and gb == 0)
 #pragma unroll
         for (int h = 0; h < HG + GPW; ++h) {
             const float4 va = Sr[first + h][pa], vb = Sr[first + h][pb];
@@ -777,23 +808,26 @@ __global__ __launch_bounds__(BoxGeo<C>::THREADS) void k_box_fused(BoxFusedArgs A
     };
     // block 0 (it holds the clipped rows at the top: the SAT rows they read, < 4 HG + 4, are all in it), then the blocks whose groups are all unclipped in a
     // loop without a condition, then what is left (the last block or two; every block of a strip whose rows do not end on a dword)
-    const int fast_num = g_hi - gbase - GPW + 1; // block blk of mine is unclipped iff 1 <= blk <= fast_num / 16
+    const int fast_num = g_hi - gbase - GPW * NPASS + 1; // block blk of mine is unclipped iff 1 <= blk <= fast_num / groups per block
     const int last_fast = tail_strip || fast_num < 0 ? 0 : min(fast_num / BF_G, nblocks - 1);
     int blk = 0;
 #ifndef BF_NO_MEANS
     BF_SYNC(); // step LAG + 1
     if (mi == NM - 1)
         for (int r = 0; r < min(top_end, rows); ++r) generic_row(r);
-    groups(0, sslot);
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) groups(0, sslot, gbase + ps * GPW);
     advance();
     for (blk = 1; blk <= last_fast; ++blk) {
         BF_SYNC(); // step blk + LAG + 1
-        fast(so, orow, srow);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) fast(so + (uint32_t)(ps * GPW) * GROUP_BYTES, orow + (size_t)(ps * 4 * GPW) * dpitch, srow + (size_t)(ps * 4 * GPW) * spitch);
         advance();
     }
     for (; blk < nblocks; ++blk) {
         BF_SYNC();
-        groups(blk, sslot);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) groups(blk, sslot, gbase + ps * GPW);
         advance();
     }
 #else
