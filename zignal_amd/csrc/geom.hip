@@ -344,49 +344,19 @@ __global__ __launch_bounds__(256) void k_resize_bilinear_u8_rows(DImg src, DImg 
         sel[p] = o * 0x00010001u + 0x0c010c00u;          // bytes (o, zero, o + 1, zero): the u16 pair (left tap, right tap)
         wpair[p] = (uint32_t)fx[p] * 65535u + 256u;       // (256 - fx) | fx << 16
     }
-    for (int rr = 0; rr < R; ++rr) {
-        const int r = rbase + rr; // wave-uniform
-        if (r >= dst.rows) break;
+    auto row_taps = [&](int r, int &r0, int &r1, int &fy) { // wave-uniform
         const float sy = ((float)r + 0.5f) * ry - 0.5f;
         const float ft = floorf(sy);
         const int top = (int)ft;
-        int r0 = top, r1 = top + 1;
+        r0 = top;
+        r1 = top + 1;
         if (top < 0 || top + 1 >= src.rows) {
             r0 = resolve_index(top, src.rows, ZG_BORDER_MIRROR);
             r1 = resolve_index(top + 1, src.rows, ZG_BORDER_MIRROR);
         }
-        const int fy = (int)roundf((sy - ft) * 256);
-        const uint8_t *row0 = (const uint8_t *)src.data + (size_t)r0 * src.stride, *row1 = (const uint8_t *)src.data + (size_t)r1 * src.stride;
-        uint32_t packed = 0;
-        if (fast) {
-            uint32_t a[2], b[2];
-            __builtin_memcpy(a, row0 + left[0], 8);
-            __builtin_memcpy(b, row1 + left[0], 8);
-            uint32_t v[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const uint32_t tp = __builtin_amdgcn_perm(a[1], a[0], sel[p]), bp = __builtin_amdgcn_perm(b[1], b[0], sel[p]);
-                uint32_t top_val, bottom_val;
-                asm("v_dot2_u32_u16 %0, %1, %2, 0" : "=v"(top_val) : "v"(tp), "v"(wpair[p]));
-                asm("v_dot2_u32_u16 %0, %1, %2, 0" : "=v"(bottom_val) : "v"(bp), "v"(wpair[p]));
-                v[p] = top_val * (uint32_t)(256 - fy) + bottom_val * (uint32_t)fy + 32768u; // < 2^24 + 2^15; the pixel is byte 2
-            }
-            packed = __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u) | __builtin_amdgcn_perm(v[3], v[2], 0x06020c0cu);
-        } else {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if (p >= n) break;
-                int cl = left[p], cr = left[p] + 1;
-                if (left[p] < 0 || left[p] + 1 >= src.cols) {
-                    cl = resolve_index(left[p], src.cols, ZG_BORDER_MIRROR);
-                    cr = resolve_index(left[p] + 1, src.cols, ZG_BORDER_MIRROR);
-                }
-                const int tl = row0[cl], tr = row0[cr], bl = row1[cl], br = row1[cr];
-                const int top_val = tl * (256 - fx[p]) + tr * fx[p];
-                const int bottom_val = bl * (256 - fx[p]) + br * fx[p];
-                packed |= (uint32_t)((top_val * (256 - fy) + bottom_val * fy + 32768) >> 16) << (8 * p);
-            }
-        }
+        fy = (int)roundf((sy - ft) * 256);
+    };
+    auto store = [&](int r, uint32_t packed) {
         uint8_t *o = (uint8_t *)dst.data + (size_t)r * dst.stride + (size_t)c0;
         if (n == 4 && dword_rows) *(uint32_t *)o = packed;
         else {
@@ -394,6 +364,58 @@ __global__ __launch_bounds__(256) void k_resize_bilinear_u8_rows(DImg src, DImg 
             for (int p = 0; p < 4; ++p)
                 if (p < n) o[p] = (uint8_t)(packed >> (8 * p));
         }
+    };
+    if (fast) {
+        // every load of the wave's R rows first, then the arithmetic: a loop of load - wait - use leaves the memory's latency in the open once per row
+        // (rows past the image's last are clamped, loaded and dropped)
+        uint32_t a[R][2], b[R][2];
+        int fys[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            int r0, r1;
+            row_taps(min(rbase + rr, dst.rows - 1), r0, r1, fys[rr]);
+            __builtin_memcpy(a[rr], (const uint8_t *)src.data + (size_t)r0 * src.stride + left[0], 8);
+            __builtin_memcpy(b[rr], (const uint8_t *)src.data + (size_t)r1 * src.stride + left[0], 8);
+        }
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int r = rbase + rr; // wave-uniform
+            if (r >= dst.rows) break;
+            const int fy = fys[rr];
+            uint32_t v[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t tp = __builtin_amdgcn_perm(a[rr][1], a[rr][0], sel[p]), bp = __builtin_amdgcn_perm(b[rr][1], b[rr][0], sel[p]);
+                uint32_t top_val, bottom_val;
+                asm("v_dot2_u32_u16 %0, %1, %2, 0" : "=v"(top_val) : "v"(tp), "v"(wpair[p]));
+                asm("v_dot2_u32_u16 %0, %1, %2, 0" : "=v"(bottom_val) : "v"(bp), "v"(wpair[p]));
+                v[p] = top_val * (uint32_t)(256 - fy) + bottom_val * (uint32_t)fy + 32768u; // < 2^24 + 2^15; the pixel is byte 2
+            }
+            store(r, __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u) | __builtin_amdgcn_perm(v[3], v[2], 0x06020c0cu));
+        }
+        return;
+    }
+    for (int rr = 0; rr < R; ++rr) {
+        const int r = rbase + rr; // wave-uniform
+        if (r >= dst.rows) break;
+        int r0, r1, fy;
+        row_taps(r, r0, r1, fy);
+        const uint8_t *row0 = (const uint8_t *)src.data + (size_t)r0 * src.stride, *row1 = (const uint8_t *)src.data + (size_t)r1 * src.stride;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            if (p >= n) break;
+            int cl = left[p], cr = left[p] + 1;
+            if (left[p] < 0 || left[p] + 1 >= src.cols) {
+                cl = resolve_index(left[p], src.cols, ZG_BORDER_MIRROR);
+                cr = resolve_index(left[p] + 1, src.cols, ZG_BORDER_MIRROR);
+            }
+            const int tl = row0[cl], tr = row0[cr], bl = row1[cl], br = row1[cr];
+            const int top_val = tl * (256 - fx[p]) + tr * fx[p];
+            const int bottom_val = bl * (256 - fx[p]) + br * fx[p];
+            packed |= (uint32_t)((top_val * (256 - fy) + bottom_val * fy + 32768) >> 16) << (8 * p);
+        }
+        store(r, packed);
     }
 }
 
@@ -408,9 +430,10 @@ static int launch_resize_bilinear_u8(const zg_image *src, const zg_image *dst, u
     const float rx = (float)src->cols / (float)dst->cols;
     static const int rows_form = getenv("ZIGNAL_HIP_RESIZE_U8_ROWS") ? atoi(getenv("ZIGNAL_HIP_RESIZE_U8_ROWS")) : 2; // A/B hook of round 5: 0 = the one-row kernel; 4096^2 -> 3413^2: 21.3 / 18.2 / 20.4 us for 0 / 2 / 4 rows
     if (rows_form > 0 && rx < 2.0f && src->cols >= 8) { // taps computed once for several rows, one 8-byte load per source row and lane
-        const int R = rows_form >= 4 ? 4 : 2;
+        const int R = rows_form >= 8 ? 8 : rows_form >= 4 ? 4 : 2;
         const uint64_t tiles_r = (uint64_t)tiles_x * ceil_div(dst->rows, (uint32_t)(4 * R));
-        if (R == 4) hipLaunchKernelGGL((k_resize_bilinear_u8_rows<4>), dim3((unsigned)tiles_r, n), dim3(256), 0, s, dimg(src), dimg(dst), rx, (float)src->rows / (float)dst->rows, tiles_x, fr, dword_rows);
+        if (R == 8) hipLaunchKernelGGL((k_resize_bilinear_u8_rows<8>), dim3((unsigned)tiles_r, n), dim3(256), 0, s, dimg(src), dimg(dst), rx, (float)src->rows / (float)dst->rows, tiles_x, fr, dword_rows);
+        else if (R == 4) hipLaunchKernelGGL((k_resize_bilinear_u8_rows<4>), dim3((unsigned)tiles_r, n), dim3(256), 0, s, dimg(src), dimg(dst), rx, (float)src->rows / (float)dst->rows, tiles_x, fr, dword_rows);
         else hipLaunchKernelGGL((k_resize_bilinear_u8_rows<2>), dim3((unsigned)tiles_r, n), dim3(256), 0, s, dimg(src), dimg(dst), rx, (float)src->rows / (float)dst->rows, tiles_x, fr, dword_rows);
         ZG_HIP(hipGetLastError());
         return ZG_OK;

@@ -33,7 +33,10 @@ namespace zg {
 constexpr int PT_TW = 64;        // output columns per tile: one output row per wave instruction
 constexpr int PT_SR = 128;       // staged source rows (halo included)
 constexpr int PT_SP = 304;       // bytes per staged row: 64 x 3.9 + 2 + 2 x 17 + 3 of alignment, rounded up to a multiple of 16
-constexpr int PT_THREADS = 512;
+#ifndef PT_THREADS_N
+#define PT_THREADS_N 512
+#endif
+constexpr int PT_THREADS = PT_THREADS_N;
 constexpr int PT_MAX_JOBS = 8;
 constexpr int PT_MAX_HM = 17;    // taps <= 35
 
@@ -66,7 +69,7 @@ __device__ __forceinline__ int pt_mirror(int i, int n) { // border.zig:46-63, .m
 }
 
 template <int HM>
-__device__ __forceinline__ void pyr_tile_body(const PyrTileJobs &jobs, const PyrTileJob &job, uint32_t (*srcT)[PT_SP / 4], uint2 (*Hp)[PT_TW], uint32_t *tapw) {
+__device__ __forceinline__ void pyr_tile_body(const PyrTileJobs &jobs, const PyrTileJob &job, uint32_t (*srcT)[PT_SP / 4], uint2 (*Hp)[PT_TW], uint32_t *tapw, uint2 *rowtab) {
     constexpr int ND = (2 * HM + 5 + 3) / 4; // dwords a lane's two windows (columns cb, cb + 1, any byte phase) span
     constexpr int NQ = HM + 1;               // row pairs a column window spans when it starts on an even row
     const int tile = (int)blockIdx.x - job.block0;
@@ -118,31 +121,41 @@ __device__ __forceinline__ void pyr_tile_body(const PyrTileJobs &jobs, const Pyr
     const int nsr = __builtin_amdgcn_readfirstlane((int)tapw[14]), nsd = __builtin_amdgcn_readfirstlane((int)tapw[15]);
     const bool plain = __builtin_amdgcn_readfirstlane((int)tapw[16]) != 0;
 
+    // the resize's taps of the tile's output rows, one lane per row, once: as scalar work per output row and wave (floor, round, the mirror rule, ~60
+    // instructions) they were a sixth of the kernel
+    for (int t = tid; t <= Rlast - R0; t += PT_THREADS) {
+        int rb, fy;
+        bool swy;
+        taps_of(R0 + t, job.ry, rows, rb, swy, fy);
+        rowtab[t] = make_uint2((uint32_t)(rb - HM - YA) | (swy ? 0x80000000u : 0u), (uint32_t)fy);
+    }
     // ---- 1. stage ------------------------------------------------------------------------------------------------------------------------------------
+#ifndef PT_NO_STAGE // removal timings (tools/build_variant.sh): profiles/r06_pyramid.txt
     {
         // a wave takes whole rows (the row's mirror rule and pointer are scalar work), a lane dwords lane and lane + 64 of them
         const bool inside_x = XA >= 0 && XA + 4 * nsd <= cols; // workgroup-uniform: whole dwords of the image
         const bool second = lane + 64 < nsd;
-        if (inside_x && YA >= 0 && YA + nsr <= rows) { // the whole tile inside the image: the row pointer just moves on
+        if (inside_x) {
+            // every load of the wave's rows first, then the stores: a loop of load - wait - store left the memory's latency in the open once per row (sixteen
+            // times per tile; the kernel spent most of its time there: profiles/r06_pyramid.txt). Rows past the tile's last are clamped, loaded and dropped.
+            constexpr int NR = PT_SR / (PT_THREADS / 64); // rows per wave at most
             const uint32_t o0 = (uint32_t)(XA + 4 * min(lane, nsd - 1)), o1 = (uint32_t)(XA + 4 * min(lane + 64, nsd - 1)); // clamped, unpredicated
-            const uint8_t *rowp = src + (size_t)(YA + wave) * spitch;
-            const size_t step = (size_t)(PT_THREADS / 64) * spitch;
-            uint32_t *d0p = &srcT[wave][min(lane, PT_SP / 4 - 1)], *d1p = &srcT[wave][min(lane + 64, PT_SP / 4 - 1)];
-            for (int r = wave; r < nsr; r += PT_THREADS / 64) {
-                const uint32_t v0 = *(const uint32_t *)(rowp + o0), v1 = *(const uint32_t *)(rowp + o1);
-                if (lane < nsd) *d0p = v0;
-                if (second) *d1p = v1;
-                rowp += step;
-                d0p += (PT_THREADS / 64) * (PT_SP / 4);
-                d1p += (PT_THREADS / 64) * (PT_SP / 4);
+            const bool inside_y = YA >= 0 && YA + nsr <= rows; // workgroup-uniform: no row of the tile is mirrored
+            uint32_t v0[NR], v1[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int r = min(wave + i * (PT_THREADS / 64), nsr - 1);
+                const uint8_t *rowp = src + (size_t)(inside_y ? YA + r : pt_mirror(YA + r, rows)) * spitch;
+                v0[i] = *(const uint32_t *)(rowp + o0);
+                v1[i] = *(const uint32_t *)(rowp + o1);
             }
-        } else if (inside_x) {
-            const uint32_t o0 = (uint32_t)(XA + 4 * min(lane, nsd - 1)), o1 = (uint32_t)(XA + 4 * min(lane + 64, nsd - 1)); // clamped, unpredicated
-            for (int r = wave; r < nsr; r += PT_THREADS / 64) {
-                const uint8_t *rowp = src + (size_t)pt_mirror(YA + r, rows) * spitch;
-                const uint32_t v0 = *(const uint32_t *)(rowp + o0), v1 = *(const uint32_t *)(rowp + o1);
-                if (lane < nsd) srcT[r][lane] = v0;
-                if (second) srcT[r][lane + 64] = v1;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int r = wave + i * (PT_THREADS / 64);
+                if (r < nsr) { // wave-uniform
+                    srcT[r][lane] = v0[i]; // (lanes past the staged dwords write the row's unused tail: a row has room for 76)
+                    if (second) srcT[r][lane + 64] = v1[i];
+                }
             }
         } else { // the image's left or right edge runs through the tile: byte by byte through the mirror rule
             uint32_t bo[2][4];
@@ -162,6 +175,7 @@ __device__ __forceinline__ void pyr_tile_body(const PyrTileJobs &jobs, const Pyr
             }
         }
     }
+#endif
     __syncthreads();
 
     // ---- 2. the row pass at the tapped columns ------------------------------------------------------------------------------------------------------------
@@ -180,7 +194,11 @@ __device__ __forceinline__ void pyr_tile_body(const PyrTileJobs &jobs, const Pyr
             ka[m] = p == 0 ? hi : __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(4 - p));
             kb[m] = p == 3 ? lo : __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(3 - p));
         }
+#ifdef PT_NO_ROWS
+        const int npairs = 0;
+#else
         const int npairs = (nsr + 1) >> 1;
+#endif
         for (int q = wave; q < npairs; q += PT_THREADS / 64) {
             const uint32_t *r0 = &srcT[2 * q][d0], *r1 = &srcT[2 * q + 1][d0];
             uint32_t a0 = 0, b0 = 0, a1 = 0, b1 = 0;
@@ -208,18 +226,14 @@ __device__ __forceinline__ void pyr_tile_body(const PyrTileJobs &jobs, const Pyr
     uint8_t *out_col = job.dst + (size_t)(C0 + lane);
     const uint32_t hp_lane = (uint32_t)lane * 8u;
     const char *hp0 = (const char *)&Hp[0][0];
+#ifdef PT_NO_COLS
+    if (false)
+#endif
     for (int R = R0 + wave; R <= Rlast; R += PT_THREADS / 64) { // wave-uniform
-        int rb, fy;
-        bool swy = false;
-        if (plain) {
-            const float sp = ((float)R + 0.5f) * job.ry - 0.5f;
-            const float fl = floorf(sp);
-            rb = (int)fl;
-            fy = (int)roundf((sp - fl) * 256);
-        } else {
-            taps_of(R, job.ry, rows, rb, swy, fy);
-        }
-        const int a = rb - HM - YA; // staged row of the first tap of blurred row rb (>= 0)
+        const uint2 rt = rowtab[R - R0];                                  // one address for the wave: a broadcast read
+        const int a = __builtin_amdgcn_readfirstlane((int)(rt.x & 0x7fffffffu)); // staged row of the first tap of blurred row rb (>= 0)
+        const bool swy = !plain && __builtin_amdgcn_readfirstlane((int)rt.x) < 0;
+        const int fy = (int)rt.y;
         const uint2 *hq = (const uint2 *)(hp0 + (uint32_t)(a >> 1) * (uint32_t)(PT_TW * 8) + hp_lane);
         uint32_t va = 32768u, vb = 32768u, wa = 32768u, wb = 32768u; // column cb: rows rb, rb + 1; column cb + 1: the same; divClampU8's rounding term rides along
         if ((a & 1) == 0) { // row rb's window starts a pair, row rb + 1's one row later: the same NQ pairs
@@ -268,15 +282,16 @@ __global__ __launch_bounds__(PT_THREADS) void k_pyr_tile(PyrTileJobs jobs) {
     __shared__ uint32_t srcT[PT_SR + 1][PT_SP / 4]; // + 1, + 2: slack rows that only ever meet zero taps (no clamp in the loops)
     __shared__ uint2 Hp[PT_SR / 2 + 2][PT_TW];
     __shared__ uint32_t tapw[20]; // the taps as bytes (12 dwords), then the tile's geometry
+    __shared__ uint2 rowtab[PT_SR];  // per output row of the tile: staged row of its window's first tap | swapped << 31, fy
     int ji = 0; // jobs are few: a scalar walk
     for (int i = 1; i < jobs.n; ++i)
         if ((int)blockIdx.x >= jobs.j[i].block0) ji = i;
     const PyrTileJob &job = jobs.j[ji];
     switch (job.hm) { // workgroup-uniform
-    case 5: pyr_tile_body<5>(jobs, job, srcT, Hp, tapw); break;
-    case 9: pyr_tile_body<9>(jobs, job, srcT, Hp, tapw); break;
-    case 13: pyr_tile_body<13>(jobs, job, srcT, Hp, tapw); break;
-    default: pyr_tile_body<17>(jobs, job, srcT, Hp, tapw); break;
+    case 5: pyr_tile_body<5>(jobs, job, srcT, Hp, tapw, rowtab); break;
+    case 9: pyr_tile_body<9>(jobs, job, srcT, Hp, tapw, rowtab); break;
+    case 13: pyr_tile_body<13>(jobs, job, srcT, Hp, tapw, rowtab); break;
+    default: pyr_tile_body<17>(jobs, job, srcT, Hp, tapw, rowtab); break;
     }
 }
 
