@@ -49,6 +49,7 @@ struct PyrTileJob {
     int32_t th;                   // output rows per tile
     int32_t wide;                 // the taps sum to 257: a blurred value can pass 255 and divClampU8 clamps it (sums <= 256 never do)
     int32_t tiles_x, block0;      // tiles across; this job's first workgroup in the launch
+    int32_t ntiles;               // this job's workgroups
     uint32_t tapb[12];            // the taps as bytes: tap j at byte 4 + j + (HM - half), zeros around (48 bytes)
     uint32_t pair_a[PT_MAX_HM + 1]; // (k[2q], k[2q + 1]): a window that starts on an even row of the pairs
     uint32_t pair_b[PT_MAX_HM + 1]; // (k[2q - 1], k[2q]): one that starts on an odd row
@@ -72,7 +73,13 @@ template <int HM>
 __device__ __forceinline__ void pyr_tile_body(const PyrTileJobs &jobs, const PyrTileJob &job, uint32_t (*srcT)[PT_SP / 4], uint2 (*Hp)[PT_TW], uint32_t *tapw, uint2 *rowtab) {
     constexpr int ND = (2 * HM + 5 + 3) / 4; // dwords a lane's two windows (columns cb, cb + 1, any byte phase) span
     constexpr int NQ = HM + 1;               // row pairs a column window spans when it starts on an even row
-    const int tile = (int)blockIdx.x - job.block0;
+    // workgroup b runs on XCD b % 8: the tiles of one XCD are a run of neighbours (they share source lines — a tile's rows are 90 .. 270 bytes of 128-byte
+    // lines — in that XCD's L2 instead of each L2 fetching them for itself)
+    int tile = (int)blockIdx.x - job.block0;
+    {
+        const int per_xcd = job.ntiles >> 3;
+        if (ZG_XCD_ORDER && tile < (per_xcd << 3)) tile = (tile & 7) * per_xcd + (tile >> 3);
+    }
     const int ty = tile / job.tiles_x, tx = tile - ty * job.tiles_x;
     const int rows = jobs.src.rows, cols = jobs.src.cols;
     const uint8_t *src = (const uint8_t *)jobs.src.data;
@@ -142,12 +149,20 @@ __device__ __forceinline__ void pyr_tile_body(const PyrTileJobs &jobs, const Pyr
             const uint32_t o0 = (uint32_t)(XA + 4 * min(lane, nsd - 1)), o1 = (uint32_t)(XA + 4 * min(lane + 64, nsd - 1)); // clamped, unpredicated
             const bool inside_y = YA >= 0 && YA + nsr <= rows; // workgroup-uniform: no row of the tile is mirrored
             uint32_t v0[NR], v1[NR];
+            if (inside_y) { // (two copies of the loop: the mirror rule's scalar arithmetic stays out of the interior tiles' code)
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const int r = min(wave + i * (PT_THREADS / 64), nsr - 1);
-                const uint8_t *rowp = src + (size_t)(inside_y ? YA + r : pt_mirror(YA + r, rows)) * spitch;
-                v0[i] = *(const uint32_t *)(rowp + o0);
-                v1[i] = *(const uint32_t *)(rowp + o1);
+                for (int i = 0; i < NR; ++i) {
+                    const uint8_t *rowp = src + (size_t)(YA + min(wave + i * (PT_THREADS / 64), nsr - 1)) * spitch;
+                    v0[i] = *(const uint32_t *)(rowp + o0);
+                    v1[i] = *(const uint32_t *)(rowp + o1);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    const uint8_t *rowp = src + (size_t)pt_mirror(YA + min(wave + i * (PT_THREADS / 64), nsr - 1), rows) * spitch;
+                    v0[i] = *(const uint32_t *)(rowp + o0);
+                    v1[i] = *(const uint32_t *)(rowp + o1);
+                }
             }
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
@@ -357,6 +372,7 @@ int try_pyramid_tiles_u8(const zg_image *src, const zg_image *levels, const floa
         const uint64_t tiles = (uint64_t)job.tiles_x * ceil_div(lv.rows, (unsigned)job.th);
         if (tiles + (uint64_t)grid > 0x3fffffffu) continue;
         job.block0 = grid;
+        job.ntiles = (int32_t)tiles;
         uint8_t tb[48];
         memset(tb, 0, sizeof(tb));
         int32_t k[2 * PT_MAX_HM + 3]; // k[j + 1] = padded tap j, zeros around
