@@ -335,10 +335,13 @@ int try_pyramid_tiles_u8(const zg_image *src, const zg_image *levels, const floa
         if (handled[i] || !(sigmas[i] > 0.5f) || lv.pixel != ZG_PIXEL_U8 || lv.rows == 0 || lv.cols == 0 || lv.rows > src->rows || lv.cols > src->cols) continue;
         const float rx = (float)src->cols / (float)lv.cols, ry = (float)src->rows / (float)lv.rows;
         if (!(rx < 3.9f) || !(ry < 3.9f) || (size_t)lv.stride > 0xffffffffu) continue;
-        // From a reduction by 2 the resize looks at fewer blurred pixels than there are (4 / s^2 of them) and evaluating the blur only there pays; below it the
-        // tile kernel computes pixels twice and round 5's dense passes stay cheaper (profiles/r06_pyramid.txt: thresholds 0 / 1.4 / 1.7 / 2.0 / 2.4 / 2.9 ->
-        // 239 / 231 / 223 / 212 / 215 / 231 us for ORB's default pyramid of a 4096^2 plane). ZIGNAL_HIP_PYRAMID_TILE_MIN_RATIO moves the threshold (read once).
-        static const float min_ratio = getenv("ZIGNAL_HIP_PYRAMID_TILE_MIN_RATIO") ? (float)atof(getenv("ZIGNAL_HIP_PYRAMID_TILE_MIN_RATIO")) : 2.0f;
+        // From a reduction by 2 the resize looks at fewer blurred pixels than there are (4 / s^2 of them) and evaluating the blur only there wins on arithmetic;
+        // below it the tile kernel computes pixels twice, but it also never writes a temp or a blurred plane. With the first staging loop the best threshold was
+        // 2.0 (thresholds 0 / 1.4 / 1.7 / 2.0 / 2.4 / 2.9 -> 239 / 231 / 223 / 212 / 215 / 231 us for ORB's default pyramid of a 4096^2 plane); with every load
+        // of a tile in flight at once it is a tie in the graph replay (0 / 1.3 / 1.6 / 2.0 -> 182 - 186 / 177 - 183 / 182 / 177 us) and the tile kernel's side
+        // wins the eager call (183 - 186 / 187 - 190 / 211 / 208 us) and the traffic (156 / 190 / - / 405 MB): 1.3, i.e. every level but a 1.2 x one
+        // (profiles/r06_pyramid.txt). ZIGNAL_HIP_PYRAMID_TILE_MIN_RATIO moves the threshold (read once).
+        static const float min_ratio = getenv("ZIGNAL_HIP_PYRAMID_TILE_MIN_RATIO") ? (float)atof(getenv("ZIGNAL_HIP_PYRAMID_TILE_MIN_RATIO")) : 1.3f;
         if (rx < min_ratio) continue;
         const int nfull = zg_gaussian_kernel(sigmas[i], nullptr, 0);
         if (nfull < 1 || nfull > 129) continue;
