@@ -31,7 +31,10 @@
 namespace zg {
 
 constexpr int PT_TW = 64;        // output columns per tile: one output row per wave instruction
-constexpr int PT_SR = 128;       // staged source rows (halo included)
+#ifndef PT_SR_N
+#define PT_SR_N 128
+#endif
+constexpr int PT_SR = PT_SR_N;   // staged source rows (halo included)
 constexpr int PT_SP = 304;       // bytes per staged row: 64 x 3.9 + 2 + 2 x 17 + 3 of alignment, rounded up to a multiple of 16
 #ifndef PT_THREADS_N
 #define PT_THREADS_N 512
@@ -145,7 +148,7 @@ __device__ __forceinline__ void pyr_tile_body(const PyrTileJobs &jobs, const Pyr
         if (inside_x) {
             // every load of the wave's rows first, then the stores: a loop of load - wait - store left the memory's latency in the open once per row (sixteen
             // times per tile; the kernel spent most of its time there: profiles/r06_pyramid.txt). Rows past the tile's last are clamped, loaded and dropped.
-            constexpr int NR = PT_SR / (PT_THREADS / 64); // rows per wave at most
+            constexpr int NR = (PT_SR + PT_THREADS / 64 - 1) / (PT_THREADS / 64); // rows per wave at most
             const uint32_t o0 = (uint32_t)(XA + 4 * min(lane, nsd - 1)), o1 = (uint32_t)(XA + 4 * min(lane + 64, nsd - 1)); // clamped, unpredicated
             const bool inside_y = YA >= 0 && YA + nsr <= rows; // workgroup-uniform: no row of the tile is mirrored
             uint32_t v0[NR], v1[NR];
