@@ -110,3 +110,13 @@ def test_agrees_with_the_integral_image_route(env):
     )
     out = subprocess.run([sys.executable, "-c", code], env={**os.environ, "ZIGNAL_HIP_BOX_UNFUSED": "1"}, capture_output=True, text=True, timeout=300)
     assert out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+
+
+def test_the_widest_and_the_tallest(env):
+    """65 536 columns (4096 strips; the widest row whose sums stay exact), one column more (the integral-image route), 16 385 Rgba pixels (a last strip of one
+    pixel, a carry piece that reaches past the row), a plane 70 000 rows tall (1094 / 547 steps)"""
+    torch, zg, oracle = env
+    for shape in ((64, 65536), (100, 65537), (66, 16385, 4), (70000, 64), (40000, 70, 4)):
+        src = oracle.synth_u8(11, shape)
+        got = _get(torch, _dev(torch, zg, src).box_blur(2))
+        assert np.array_equal(got, oracle.box_blur(src, 2)), f"boxBlur {shape}"
