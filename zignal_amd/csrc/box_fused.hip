@@ -93,7 +93,7 @@ struct BoxFusedArgs {
     int nwg8;             // ceil(nwg / 8): strips per XCD
     size_t src_frame, dst_frame;
 #ifdef BF_TIMING
-    unsigned long long *timing; // [strip][wave][2]: cycles a wave spent between barriers, cycles it waited in them (tools/build_variant.sh ... -DBF_TIMING)
+    unsigned long long *timing; // [strip < 1024][role < 16][2]: cycles a wave spent between barriers, cycles it waited in them (tools/build_variant.sh ... -DBF_TIMING)
 #endif
 };
 
@@ -416,7 +416,7 @@ __device__ __forceinline__ void box_loader(const BoxFusedArgs &A, float4 (*Pr)[B
     }
     for (; done < nsteps; ++done) BF_SYNC();
 #ifdef BF_TIMING
-    if (lane == 0) { const int w = 3 + li; A.timing[(k * 16 + w) * 2] = bf_timer.busy; A.timing[(k * 16 + w) * 2 + 1] = bf_timer.wait; }
+    if (lane == 0 && k < 1024) { const int w = 3 + li; A.timing[(k * 16 + w) * 2] = bf_timer.busy; A.timing[(k * 16 + w) * 2 + 1] = bf_timer.wait; }
 #endif
 }
 
@@ -499,7 +499,7 @@ __device__ __forceinline__ void box_loader_b(const BoxFusedArgs &A, float4 (*Pr)
     }
     for (; done < nsteps; ++done) BF_SYNC();
 #ifdef BF_TIMING
-    if (lane == 0) { const int w = 15; A.timing[(k * 16 + w) * 2] += bf_timer.busy; A.timing[(k * 16 + w) * 2 + 1] += bf_timer.wait; }
+    if (lane == 0 && k < 1024 && hh == 0) { const int w = 15; A.timing[(k * 16 + w) * 2] = bf_timer.busy; A.timing[(k * 16 + w) * 2 + 1] = bf_timer.wait; }
 #endif
 }
 
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(BoxGeo<C>::THREADS) void k_box_fused(BoxFusedArgs A
         }
         BF_SYNC(); // the last step: the means' last block
 #ifdef BF_TIMING
-        if (lane == 0) { A.timing[(k * 16 + role) * 2] = bf_timer.busy; A.timing[(k * 16 + role) * 2 + 1] = bf_timer.wait; }
+        if (lane == 0 && k < 1024) { A.timing[(k * 16 + role) * 2] = bf_timer.busy; A.timing[(k * 16 + role) * 2 + 1] = bf_timer.wait; }
 #endif
         return;
     }
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(BoxGeo<C>::THREADS) void k_box_fused(BoxFusedArgs A
 #endif
     // the clipped rows at the bottom: the ring still holds the last two blocks (every row they read is >= bot_start - R - 1)
 #ifdef BF_TIMING
-    if (lane == 0) { A.timing[(k * 16 + role) * 2] = bf_timer.busy; A.timing[(k * 16 + role) * 2 + 1] = bf_timer.wait; }
+    if (lane == 0 && k < 1024) { A.timing[(k * 16 + role) * 2] = bf_timer.busy; A.timing[(k * 16 + role) * 2 + 1] = bf_timer.wait; }
 #endif
     for (int r = max(bot_start, 0) + mi; r < rows; r += NM) generic_row(r);
 }
