@@ -64,7 +64,10 @@ template <> struct BoxGeo<4> {
 template <> struct BoxGeo<1> {
     // a step costs ~600 cycles whatever is done in it (a barrier, an LDS round trip or two: removing any one role's work saved 4 .. 12 % of the kernel's time), and
     // one channel has the LDS for twice the rows per step
-    static constexpr int B = 128, NQ = 2, THREADS = 576, NM = 4, NG = 1, LPG = 16, NLOAD = 4;
+#ifndef BF_THREADS1
+#define BF_THREADS1 576
+#endif
+    static constexpr int B = 128, NQ = 2, THREADS = BF_THREADS1, NM = 4, NG = 1, LPG = 16, NLOAD = 4;
 };
 __host__ __device__ constexpr int box_strip_left(int C, int R) { return C == 4 ? R + 1 : 4; }
 
@@ -526,7 +529,10 @@ __global__ __launch_bounds__(BoxGeo<C>::THREADS) void k_box_fused(BoxFusedArgs A
 #ifndef BF_ROLES4 //          SIMD: 0  1  2  3   0  1  2   3  0  1  2   3   0   1   2   3
 #define BF_ROLES4 bf_roles({1, 3, 2, 5, 15, 4, 16, 6, 7, 8, 9, 10, 11, 12, 13, 14}) // 0, 2: a chain wave, a loader of the last quarters, two mean waves; 1, 3: two loaders, two mean waves
 #endif
-    constexpr BfRoles ROLES = C == 4 ? BF_ROLES4 : bf_roles({1, 3, 4, 5, 7, 6, 8, 9, 10, 0, 0, 0, 0, 0, 0, 0}); // one channel: 9 waves
+#ifndef BF_ROLES1
+#define BF_ROLES1 bf_roles({1, 3, 4, 5, 7, 6, 8, 9, 10, 0, 0, 0, 0, 0, 0, 0})
+#endif
+    constexpr BfRoles ROLES = C == 4 ? BF_ROLES4 : BF_ROLES1; // one channel: 9 waves
     const int role = (int)(((wave < 8 ? ROLES.lo : ROLES.hi) >> (8 * (wave & 7))) & 255);
     if (role == 0) return;
     // strips of one XCD are neighbours: they share source lines (the re-chained columns) and the halves of output lines in that XCD's L2
